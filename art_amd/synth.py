@@ -1,0 +1,72 @@
+"""Deterministic synthetic CFA frames (integer-generated, identical on every host).
+
+The reference ships no sample raws, so every test and benchmark
+input comes from here.  Values are integers in [0, 65535] stored as float32, i.e. what
+``RawImageSource::rawData`` holds after ``scaleColors`` for a 16-bit sensor
+(reference: rtengine/rawimagesource.cc:2677-2859).
+
+Scene = smooth gradient (integer sine table) + 64-px checker + a patch of 1-px
+(Nyquist) stripes (exercises amaze_demosaic_RT.cc:846-954) + a clipped patch at 65535
+(exercises the clip_pt paths, L417-425,565) + hash noise, multiplied by per-colour
+gains R 0.6 / G 1.0 / B 0.7 through the CFA.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+FILTERS_RGGB = 0x94949494
+FILTERS_BGGR = 0x16161616
+FILTERS_GRBG = 0x61616161
+FILTERS_GBRG = 0x49494949
+
+_SINE = np.round(32767.0 * np.sin(2.0 * np.pi * np.arange(4096) / 4096.0)).astype(np.int64)
+
+
+def fc(filters: int, row, col):
+    """RawImage::FC (reference: rtengine/rawimage.h:186-189)."""
+    row = np.asarray(row, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    sh = ((((row << 1) & 14) + (col & 1)) << 1)
+    return (np.int64(filters) >> sh) & 3
+
+
+def _hash64(idx: np.ndarray, seed: int) -> np.ndarray:
+    """splitmix64 finaliser on (index + seed * golden); uint64 wrap-around arithmetic."""
+    with np.errstate(over="ignore"):
+        z = idx.astype(np.uint64) + np.uint64((seed * 0x9E3779B97F4A7C15 + 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def bayer_frame(width: int, height: int, filters: int = FILTERS_RGGB, seed: int = 0,
+                noise: int = 1024, clip_patch: bool = True, nyquist_patch: bool = True) -> np.ndarray:
+    """Return a (height, width) float32 CFA frame with integer values in [0, 65535]."""
+    out = np.empty((height, width), dtype=np.float32)
+    x = np.arange(width, dtype=np.int64)[None, :]
+    band = 512
+    for y0 in range(0, height, band):
+        y1 = min(height, y0 + band)
+        y = np.arange(y0, y1, dtype=np.int64)[:, None]
+        sx = _SINE[(x * 7) & 4095]
+        sy = _SINE[(y * 9 + 1024) & 4095]
+        v = 20000 + ((15000 * sx * sy) >> 30)
+        v = v + np.where((((x >> 6) ^ (y >> 6)) & 1) == 1, 6000, -6000)
+        if nyquist_patch:
+            nx0, ny0, ns = width // 8, height // 8, max(16, min(512, width // 4))
+            inside = (x >= nx0) & (x < nx0 + ns) & (y >= ny0) & (y < ny0 + ns)
+            v = v + np.where(inside, np.where((x & 1) == 1, 8000, -8000), 0)
+        idx = y * width + x
+        if noise > 0:
+            h = _hash64(idx, seed)
+            v = v + (h & np.uint64(2 * noise - 1)).astype(np.int64) - noise
+        c = fc(filters, y, x)
+        gain = np.where(c == 0, 614, np.where(c == 1, 1024, 717))
+        v = (v * gain) >> 10
+        if clip_patch:
+            cx0, cy0, cs = width // 2, height // 8, max(8, min(256, width // 8))
+            inside = (x >= cx0) & (x < cx0 + cs) & (y >= cy0) & (y < cy0 + cs)
+            v = np.where(inside, 65535, v)
+        out[y0:y1] = np.clip(v, 0, 65535).astype(np.float32)
+    return out

@@ -1,0 +1,35 @@
+/*
+ * oracle/oracle.h -- entry points of the CPU oracle (liboracle.so).
+ * TEST INFRASTRUCTURE ONLY: tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg are the only callers.  The product (libartgpu.so) never links or loads this.
+ */
+#ifndef ART_ORACLE_H
+#define ART_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* strides are in floats */
+int oracle_rcd_demosaic(const float *raw, size_t raw_stride, int W, int H, unsigned filters,
+                        float *red, float *green, float *blue, size_t out_stride);
+void oracle_rcd_tile(const float *raw, size_t rs, int W, int H, unsigned filters,
+                     int tr, int tc, int numTh, int numTw,
+                     float *red, float *green, float *blue, size_t os, float *work);
+void oracle_border_interpolate2(int W, int H, int bord, const float *raw, size_t rs, unsigned filters,
+                                float *red, float *green, float *blue, size_t os);
+
+size_t oracle_amaze_arena_floats(void);
+void oracle_amaze_tile(const float *raw, size_t rs, int width, int height, unsigned filters,
+                       float clip_pt, float clip_pt8, int top, int left,
+                       float *red, float *green, float *blue, size_t os,
+                       float *arena, int poison);
+int oracle_amaze_demosaic(const float *raw, size_t raw_stride, int W, int H, unsigned filters,
+                          double initialGain, int border,
+                          float *red, float *green, float *blue, size_t out_stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,75 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so).  Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ORACLE_DIR = os.path.join(_ROOT, "oracle")
+_LIB = None
+
+_fp = C.POINTER(C.c_float)
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(_fp)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_ORACLE_DIR, "liboracle.so")
+        srcs = [os.path.join(_ORACLE_DIR, f) for f in os.listdir(_ORACLE_DIR) if f.endswith((".c", ".h"))]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR, "liboracle.so"])
+        _LIB = C.CDLL(so)
+        _LIB.oracle_amaze_arena_floats.restype = C.c_size_t
+    return _LIB
+
+
+def _planes(h, w):
+    return [np.full((h, w), np.nan, dtype=np.float32) for _ in range(3)]
+
+
+def rcd(raw: np.ndarray, filters: int):
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    h, w = raw.shape
+    r, g, b = _planes(h, w)
+    rc = lib().oracle_rcd_demosaic(_ptr(raw), C.c_size_t(w), w, h, C.c_uint(filters), _ptr(r), _ptr(g), _ptr(b), C.c_size_t(w))
+    if rc != 0:
+        raise RuntimeError(f"oracle_rcd_demosaic failed: {rc}")
+    return r, g, b
+
+
+def amaze(raw: np.ndarray, filters: int, initial_gain: float = 1.0, border: int = 4):
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    h, w = raw.shape
+    r, g, b = _planes(h, w)
+    rc = lib().oracle_amaze_demosaic(_ptr(raw), C.c_size_t(w), w, h, C.c_uint(filters), C.c_double(initial_gain), border,
+                                     _ptr(r), _ptr(g), _ptr(b), C.c_size_t(w))
+    if rc != 0:
+        raise RuntimeError(f"oracle_amaze_demosaic failed: {rc}")
+    return r, g, b
+
+
+def amaze_tiles_stale(raw: np.ndarray, filters: int, initial_gain: float, order: str = "raster"):
+    """AMaZE tile by tile on ONE arena that is zeroed once and never cleared again (what a
+    reference thread does: calloc once, amaze_demosaic_RT.cc:124), visiting the tiles in
+    raster or reverse order."""
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    h, w = raw.shape
+    r, g, b = _planes(h, w)
+    L = lib()
+    arena = np.zeros(L.oracle_amaze_arena_floats(), dtype=np.float32)
+    clip_pt = np.float32(1.0 / initial_gain)
+    clip_pt8 = np.float32(0.8 / initial_gain)
+    tiles = [(top, left) for top in range(-16, h, 128) for left in range(-16, w, 128)]
+    if order == "reverse":
+        tiles = tiles[::-1]
+    for top, left in tiles:
+        L.oracle_amaze_tile(_ptr(raw), C.c_size_t(w), w, h, C.c_uint(filters), C.c_float(clip_pt), C.c_float(clip_pt8),
+                            top, left, _ptr(r), _ptr(g), _ptr(b), C.c_size_t(w), _ptr(arena), 1)
+    return r, g, b
