@@ -1,0 +1,133 @@
+"""ctypes binding of ``libartgpu.so`` (the C ABI in ``include/artgpu.h``).
+
+This is plumbing for the tests and ``bench.py``: device memory comes from torch (ROCm),
+pointers and sizes go straight through the C ABI, the same entry points a C++ adapter inside
+ART would call.  No CPU fallback: if the library is missing, import fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libartgpu.so")
+
+BAYER_AMAZE = 0
+BAYER_RCD = 1
+
+
+class Plane(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("w", C.c_int32), ("h", C.c_int32),
+                ("row_stride_bytes", C.c_int64), ("on_device", C.c_int32)]
+
+
+class RGB(C.Structure):
+    _fields_ = [("r", Plane), ("g", Plane), ("b", Plane)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("demosaic_ms", C.c_float), ("border_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+class ArtGpuError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback for the device path)")
+    lib = C.CDLL(LIB_PATH)
+    lib.artgpu_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.artgpu_destroy.argtypes = [C.c_void_p]
+    lib.artgpu_last_error.argtypes = [C.c_void_p]
+    lib.artgpu_last_error.restype = C.c_char_p
+    lib.artgpu_version.restype = C.c_char_p
+    lib.artgpu_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    lib.artgpu_synchronize.argtypes = [C.c_void_p]
+    lib.artgpu_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.artgpu_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
+    lib.artgpu_scratch_bytes.argtypes = [C.c_void_p]
+    lib.artgpu_scratch_bytes.restype = C.c_size_t
+    lib.artgpu_demosaic_bayer.argtypes = [C.c_void_p, C.c_int, C.POINTER(Plane), C.c_uint32, C.c_double, C.c_int, C.POINTER(RGB)]
+    lib.artgpu_border_interpolate2.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_uint32, C.c_int, C.POINTER(RGB)]
+    return lib
+
+
+LIB = _load()
+
+EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
+           "artgpu_synchronize", "artgpu_enable_timing", "artgpu_get_timings", "artgpu_scratch_bytes",
+           "artgpu_demosaic_bayer", "artgpu_border_interpolate2"]
+
+
+def host_plane(a: np.ndarray) -> Plane:
+    assert a.dtype == np.float32 and a.ndim == 2 and a.strides[1] == 4
+    return Plane(a.ctypes.data, a.shape[1], a.shape[0], a.strides[0], 0)
+
+
+def device_plane(t) -> Plane:
+    """`t`: a 2-D float32 torch tensor on the context's device with unit column stride."""
+    assert t.dim() == 2 and t.stride(1) == 1 and t.element_size() == 4
+    return Plane(t.data_ptr(), t.shape[1], t.shape[0], t.stride(0) * 4, 1)
+
+
+class Context:
+    """One device context (include/artgpu.h: artgpu_create / artgpu_destroy)."""
+
+    def __init__(self, device: int = 0, stream=None):
+        self._h = C.c_void_p()
+        rc = LIB.artgpu_create(device, C.byref(self._h))
+        if rc != 0:
+            raise ArtGpuError(f"artgpu_create(device={device}) failed: {rc}")
+        if stream is not None:
+            self.set_stream(stream)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise ArtGpuError(f"[{rc}] {LIB.artgpu_last_error(self._h).decode()}")
+
+    def set_stream(self, stream_handle: int):
+        self._chk(LIB.artgpu_set_stream(self._h, C.c_void_p(stream_handle)))
+
+    def synchronize(self):
+        self._chk(LIB.artgpu_synchronize(self._h))
+
+    def enable_timing(self, on: bool = True):
+        self._chk(LIB.artgpu_enable_timing(self._h, int(on)))
+
+    def timings(self) -> Timings:
+        t = Timings()
+        self._chk(LIB.artgpu_get_timings(self._h, C.byref(t)))
+        return t
+
+    def scratch_bytes(self) -> int:
+        return LIB.artgpu_scratch_bytes(self._h)
+
+    def demosaic_bayer(self, method: int, raw: Plane, filters: int, initial_gain: float, border: int, out: RGB):
+        self._chk(LIB.artgpu_demosaic_bayer(self._h, method, C.byref(raw), filters, initial_gain, border, C.byref(out)))
+
+    def border_interpolate2(self, raw: Plane, filters: int, lborders: int, out: RGB):
+        self._chk(LIB.artgpu_border_interpolate2(self._h, C.byref(raw), filters, lborders, C.byref(out)))
+
+    # convenience for tests: host numpy in, host numpy out (staged through the library)
+    def demosaic_bayer_host(self, method: int, raw: np.ndarray, filters: int, initial_gain: float = 1.0, border: int = 4):
+        raw = np.ascontiguousarray(raw, dtype=np.float32)
+        h, w = raw.shape
+        planes = [np.full((h, w), np.nan, dtype=np.float32) for _ in range(3)]
+        out = RGB(host_plane(planes[0]), host_plane(planes[1]), host_plane(planes[2]))
+        self.demosaic_bayer(method, host_plane(raw), filters, initial_gain, border, out)
+        return planes
+
+    def close(self):
+        if self._h:
+            LIB.artgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

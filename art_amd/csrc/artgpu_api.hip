@@ -1,0 +1,304 @@
+// art_amd/csrc/artgpu_api.hip -- the C ABI of libartgpu.so (include/artgpu.h): context,
+// device buffers, staging for host-pointer calls, kernel launches, error reporting.
+// There is no CPU fallback here: every entry point either runs the HIP kernels or fails.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/artgpu.h"
+#include "kernels.h"
+
+using namespace artgpu;
+
+struct artgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // per-workgroup work arenas (demosaic)
+    float *arena = nullptr;
+    size_t arena_bytes = 0;
+    // staging for host-pointer calls: one CFA plane + three output planes
+    float *stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t stage_bytes[4] = {0, 0, 0, 0};
+    // timing
+    bool timing = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    artgpu_timings last = {0.f, 0.f, 0.f};
+};
+
+namespace {
+
+int fail(artgpu_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(ctx, ARTGPU_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+int ensure(artgpu_ctx *ctx, float **buf, size_t *cur, size_t need)
+{
+    if (*cur >= need) return ARTGPU_OK;
+    if (*buf) { HIPCHK(ctx, hipFree(*buf)); *buf = nullptr; *cur = 0; }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(buf), need);
+    if (e != hipSuccess) {
+        *buf = nullptr;
+        return fail(ctx, ARTGPU_ENOMEM, "hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e));
+    }
+    *cur = need;
+    return ARTGPU_OK;
+}
+
+bool plane_ok(const artgpu_plane *p)
+{
+    return p && p->p && p->w > 0 && p->h > 0 && p->row_stride_bytes >= (int64_t)p->w * 4 && (p->row_stride_bytes % 4) == 0;
+}
+
+struct DevImage {
+    const float *raw; size_t raw_stride;
+    float *r, *g, *b; size_t out_stride;
+    bool staged;
+};
+
+// Resolve device pointers for (raw, out); host planes are staged through ctx buffers.
+int bind_images(artgpu_ctx *ctx, const artgpu_plane *raw, artgpu_rgb *out, DevImage *d)
+{
+    const int W = raw->w, H = raw->h;
+    const artgpu_plane *op[3] = {&out->r, &out->g, &out->b};
+    for (int k = 0; k < 3; ++k) {
+        if (!plane_ok(op[k]) || op[k]->w != W || op[k]->h != H) return fail(ctx, ARTGPU_EINVAL, "output plane %d: bad pointer/size/stride", k);
+        if ((op[k]->on_device != 0) != (out->r.on_device != 0) || op[k]->row_stride_bytes != out->r.row_stride_bytes)
+            return fail(ctx, ARTGPU_EINVAL, "output planes must share residency and row stride");
+    }
+    d->staged = false;
+    if (raw->on_device) {
+        d->raw = raw->p;
+        d->raw_stride = (size_t)(raw->row_stride_bytes / 4);
+    } else {
+        int rc = ensure(ctx, &ctx->stage[0], &ctx->stage_bytes[0], (size_t)W * H * 4);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage[0], (size_t)W * 4, raw->p, (size_t)raw->row_stride_bytes, (size_t)W * 4, H, hipMemcpyHostToDevice, ctx->stream));
+        d->raw = ctx->stage[0];
+        d->raw_stride = W;
+    }
+    if (out->r.on_device) {
+        d->r = out->r.p; d->g = out->g.p; d->b = out->b.p;
+        d->out_stride = (size_t)(out->r.row_stride_bytes / 4);
+    } else {
+        for (int k = 0; k < 3; ++k) {
+            int rc = ensure(ctx, &ctx->stage[1 + k], &ctx->stage_bytes[1 + k], (size_t)W * H * 4);
+            if (rc) return rc;
+        }
+        d->r = ctx->stage[1]; d->g = ctx->stage[2]; d->b = ctx->stage[3];
+        d->out_stride = W;
+        d->staged = true;
+    }
+    return ARTGPU_OK;
+}
+
+int unbind_images(artgpu_ctx *ctx, artgpu_rgb *out, const DevImage *d)
+{
+    if (!d->staged) return ARTGPU_OK;
+    const int W = out->r.w, H = out->r.h;
+    artgpu_plane *op[3] = {&out->r, &out->g, &out->b};
+    const float *src[3] = {d->r, d->g, d->b};
+    for (int k = 0; k < 3; ++k)
+        HIPCHK(ctx, hipMemcpy2DAsync(op[k]->p, (size_t)op[k]->row_stride_bytes, src[k], (size_t)W * 4, (size_t)W * 4, H, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
+int launch_border(artgpu_ctx *ctx, const DevImage &d, int W, int H, unsigned filters, int bord)
+{
+    if (bord <= 0) return ARTGPU_OK;
+    if (W <= 2 * bord || H <= 2 * bord) return fail(ctx, ARTGPU_EUNSUPPORTED, "border_interpolate2: image %dx%d too small for border %d", W, H, bord);
+    BorderArgs b;
+    b.raw = d.raw; b.raw_stride = d.raw_stride;
+    b.red = d.r; b.green = d.g; b.blue = d.b; b.out_stride = d.out_stride;
+    b.W = W; b.H = H; b.bord = bord; b.filters = filters;
+    const long long total = 2LL * bord * H + 2LL * bord * (W - 2 * bord);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    HIPCHK(ctx, launch_border_interpolate2(b, grid, ctx->stream));
+    return ARTGPU_OK;
+}
+
+constexpr int MAX_TILE_WORKGROUPS = 8192;
+
+} // namespace
+
+extern "C" {
+
+const char *artgpu_version(void) { return "artgpu 0.1 (gfx950)"; }
+
+int artgpu_create(int hip_device, artgpu_ctx **out)
+{
+    if (!out) return ARTGPU_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || hip_device < 0 || hip_device >= n) return ARTGPU_EHIP;
+    artgpu_ctx *ctx = new (std::nothrow) artgpu_ctx;
+    if (!ctx) return ARTGPU_ENOMEM;
+    ctx->device = hip_device;
+    if (hipSetDevice(hip_device) != hipSuccess) { delete ctx; return ARTGPU_EHIP; }
+    for (int k = 0; k < 3; ++k)
+        if (hipEventCreate(&ctx->ev[k]) != hipSuccess) { delete ctx; return ARTGPU_EHIP; }
+    *out = ctx;
+    return ARTGPU_OK;
+}
+
+int artgpu_destroy(artgpu_ctx *ctx)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    for (int k = 0; k < 4; ++k)
+        if (ctx->stage[k]) (void)hipFree(ctx->stage[k]);
+    for (int k = 0; k < 3; ++k)
+        if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+    delete ctx;
+    return ARTGPU_OK;
+}
+
+const char *artgpu_last_error(const artgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int artgpu_set_stream(artgpu_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return ARTGPU_OK;
+}
+
+int artgpu_synchronize(artgpu_ctx *ctx)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
+int artgpu_enable_timing(artgpu_ctx *ctx, int enable)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    ctx->timing = enable != 0;
+    return ARTGPU_OK;
+}
+
+int artgpu_get_timings(const artgpu_ctx *ctx, artgpu_timings *out)
+{
+    if (!ctx || !out) return ARTGPU_EINVAL;
+    *out = ctx->last;
+    return ARTGPU_OK;
+}
+
+size_t artgpu_scratch_bytes(const artgpu_ctx *ctx)
+{
+    if (!ctx) return 0;
+    size_t s = ctx->arena_bytes;
+    for (int k = 0; k < 4; ++k) s += ctx->stage_bytes[k];
+    return s;
+}
+
+int artgpu_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, uint32_t filters,
+                          double initial_gain, int border, artgpu_rgb *out)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!plane_ok(raw) || !out) return fail(ctx, ARTGPU_EINVAL, "demosaic_bayer: bad raw plane or null output");
+    if (method != ARTGPU_BAYER_AMAZE && method != ARTGPU_BAYER_RCD) return fail(ctx, ARTGPU_EUNSUPPORTED, "demosaic_bayer: method %d is not on the device path", method);
+    if (!(initial_gain > 0.0)) return fail(ctx, ARTGPU_EINVAL, "demosaic_bayer: initial_gain must be > 0");
+    // RGB Bayer only: the reference falls back to igv_interpolate for 4-colour CFAs (rcd_demosaic.cc:57-66)
+    for (unsigned r = 0; r < 2; ++r)
+        for (unsigned c = 0; c < 2; ++c)
+            if (((filters >> ((((r << 1) & 14) + (c & 1)) << 1)) & 3) == 3) return fail(ctx, ARTGPU_EUNSUPPORTED, "demosaic_bayer: 4-colour CFA");
+    const int W = raw->w, H = raw->h;
+    if (W < 64 || H < 64) return fail(ctx, ARTGPU_EUNSUPPORTED, "demosaic_bayer: image %dx%d smaller than 64x64", W, H);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+
+    DevImage d;
+    int rc = bind_images(ctx, raw, out, &d);
+    if (rc) return rc;
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+
+    int bord = 0;
+    if (method == ARTGPU_BAYER_AMAZE) {
+        const int nty = (H + 16 + AMAZE_STEP - 1) / AMAZE_STEP, ntx = (W + 16 + AMAZE_STEP - 1) / AMAZE_STEP;
+        const int ntiles = nty * ntx;
+        const int grid = ntiles < MAX_TILE_WORKGROUPS ? ntiles : MAX_TILE_WORKGROUPS;
+        rc = ensure(ctx, &ctx->arena, &ctx->arena_bytes, (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float));
+        if (rc) return rc;
+        AmazeArgs a;
+        a.raw = d.raw; a.raw_stride = d.raw_stride;
+        a.red = d.r; a.green = d.g; a.blue = d.b; a.out_stride = d.out_stride;
+        a.arena = ctx->arena;
+        a.W = W; a.H = H; a.ntx = ntx; a.ntiles = ntiles;
+        a.filters = filters;
+        a.clip_pt = (float)(1.0 / initial_gain);   // amaze_demosaic_RT.cc:53-54
+        a.clip_pt8 = (float)(0.8 / initial_gain);
+        HIPCHK(ctx, launch_amaze(a, grid, ctx->stream));
+        bord = border < 4 ? 3 : 0; // amaze_demosaic_RT.cc:1587-1589
+    } else {
+        const int tileSizeN = RCD_TS - 2 * RCD_BORDER;
+        const int numTh = H / tileSizeN + ((H % tileSizeN) ? 1 : 0), numTw = W / tileSizeN + ((W % tileSizeN) ? 1 : 0);
+        const int ntiles = numTh * numTw;
+        const int grid = ntiles < MAX_TILE_WORKGROUPS ? ntiles : MAX_TILE_WORKGROUPS;
+        rc = ensure(ctx, &ctx->arena, &ctx->arena_bytes, (size_t)grid * RCD_ARENA_FLOATS * sizeof(float));
+        if (rc) return rc;
+        RcdArgs a;
+        a.raw = d.raw; a.raw_stride = d.raw_stride;
+        a.red = d.r; a.green = d.g; a.blue = d.b; a.out_stride = d.out_stride;
+        a.arena = ctx->arena;
+        a.W = W; a.H = H; a.numTw = numTw; a.ntiles = ntiles;
+        a.filters = filters;
+        HIPCHK(ctx, launch_rcd(a, grid, ctx->stream));
+        bord = RCD_BORDER; // rcd_demosaic.cc:342
+    }
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    rc = launch_border(ctx, d, W, H, filters, bord);
+    if (rc) return rc;
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    rc = unbind_images(ctx, out, &d);
+    if (rc) return rc;
+    if (ctx->timing) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev[2]));
+        HIPCHK(ctx, hipEventElapsedTime(&ctx->last.demosaic_ms, ctx->ev[0], ctx->ev[1]));
+        HIPCHK(ctx, hipEventElapsedTime(&ctx->last.border_ms, ctx->ev[1], ctx->ev[2]));
+        HIPCHK(ctx, hipEventElapsedTime(&ctx->last.total_ms, ctx->ev[0], ctx->ev[2]));
+    }
+    return ARTGPU_OK;
+}
+
+int artgpu_border_interpolate2(artgpu_ctx *ctx, const artgpu_plane *raw, uint32_t filters, int lborders, artgpu_rgb *out)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!plane_ok(raw) || !out || lborders < 0) return fail(ctx, ARTGPU_EINVAL, "border_interpolate2: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevImage d;
+    int rc = bind_images(ctx, raw, out, &d);
+    if (rc) return rc;
+    if (d.staged) {
+        // host outputs: start from the caller's current contents so that only the frame changes
+        const int W = raw->w, H = raw->h;
+        artgpu_plane *op[3] = {&out->r, &out->g, &out->b};
+        float *dst[3] = {d.r, d.g, d.b};
+        for (int k = 0; k < 3; ++k)
+            HIPCHK(ctx, hipMemcpy2DAsync(dst[k], (size_t)W * 4, op[k]->p, (size_t)op[k]->row_stride_bytes, (size_t)W * 4, H, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = launch_border(ctx, d, raw->w, raw->h, filters, lborders);
+    if (rc) return rc;
+    return unbind_images(ctx, out, &d);
+}
+
+} // extern "C"

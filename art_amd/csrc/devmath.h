@@ -1,0 +1,50 @@
+// art_amd/csrc/devmath.h -- device-side fp32 primitives with the reference's x86-64 semantics.
+//
+// Everything here is compiled with -ffp-contract=off and hipcc's default correctly rounded
+// fp32 division, so an expression written in the reference's operation order gives the
+// reference's bits (rtengine is built with -ffp-contract=off, CMakeLists.txt:35-38).
+//
+//   sse_min/sse_max : _mm_min_ps/_mm_max_ps operand order (rtengine/helpersse2.h:168-179)
+//   intp            : a*b + (1-a)*c (rtengine/rt_math.h:109-118, sleefsseavx.h:1435-1442)
+//   median3         : rtengine/median.h:52-64
+//   xdiv2f/xdivf    : exponent-field arithmetic (rtengine/sleef.h:1267-1301)
+//   fc              : RawImage::FC (rtengine/rawimage.h:186-189)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace artgpu {
+
+__device__ __forceinline__ unsigned fc(unsigned filters, unsigned row, unsigned col)
+{
+    return (filters >> (((((row) << 1) & 14u) + ((col) & 1u)) << 1)) & 3u;
+}
+__device__ __forceinline__ float sse_min(float x, float y) { return x < y ? x : y; }
+__device__ __forceinline__ float sse_max(float x, float y) { return x > y ? x : y; }
+__device__ __forceinline__ float std_min(float a, float b) { return b < a ? b : a; }
+__device__ __forceinline__ float std_max(float a, float b) { return a < b ? b : a; }
+__device__ __forceinline__ float sqr(float x) { return x * x; }
+__device__ __forceinline__ float intp(float a, float b, float c) { return a * b + (1.f - a) * c; }
+__device__ __forceinline__ float median3(float a, float b, float c)
+{
+    return sse_max(sse_min(a, b), sse_min(c, sse_max(a, b)));
+}
+__device__ __forceinline__ float lim01(float a) { return std_max(0.f, std_min(a, 1.f)); }
+__device__ __forceinline__ float xdiv2f(float d)
+{
+    int i = __float_as_int(d);
+    if (i & 0x7FFFFFFF) i -= 1 << 23;
+    return __int_as_float(i);
+}
+__device__ __forceinline__ float xdivf(float d, int n)
+{
+    int i = __float_as_int(d);
+    if (i & 0x7FFFFFFF) i -= n << 23;
+    return __int_as_float(i);
+}
+__device__ __forceinline__ int ngroups(int start, int bound, int step)
+{
+    return bound > start ? (bound - start + step - 1) / step : 0;
+}
+
+} // namespace artgpu

@@ -1,0 +1,61 @@
+// art_amd/csrc/kernels.h -- kernel argument blocks and launch geometry shared by the
+// .hip kernels and the C-ABI host code (artgpu_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace artgpu {
+
+// ---- AMaZE (amaze.hip) ----
+constexpr int AMAZE_THREADS = 256;
+constexpr int AMAZE_ARENA_FLOATS = 362208; // 1 448 832 B per workgroup (reference: 1 448 767 B, amaze_demosaic_RT.cc:124)
+constexpr int AMAZE_TS = 160;
+constexpr int AMAZE_STEP = 128;
+
+struct AmazeArgs {
+    const float *raw;   // CFA plane
+    size_t raw_stride;  // floats
+    float *red, *green, *blue;
+    size_t out_stride;  // floats
+    float *arena;       // gridDim.x * AMAZE_ARENA_FLOATS
+    int W, H;
+    int ntx, ntiles;
+    unsigned filters;
+    float clip_pt, clip_pt8;
+};
+__global__ void amaze_tiles_kernel(AmazeArgs a);
+hipError_t launch_amaze(const AmazeArgs &a, int grid, hipStream_t stream);
+
+// ---- RCD (rcd.hip) ----
+constexpr int RCD_THREADS = 256;
+constexpr int RCD_TS = 194;
+constexpr int RCD_BORDER = 9;
+constexpr int RCD_ARENA_FLOATS = ((RCD_TS * RCD_TS * 13 / 2) + 3) & ~3; // cfa, rgb[3], VH_Dir + 3 half planes
+
+struct RcdArgs {
+    const float *raw;
+    size_t raw_stride;
+    float *red, *green, *blue;
+    size_t out_stride;
+    float *arena;
+    int W, H;
+    int numTw, ntiles;
+    unsigned filters;
+};
+__global__ void rcd_tiles_kernel(RcdArgs a);
+hipError_t launch_rcd(const RcdArgs &a, int grid, hipStream_t stream);
+
+// ---- border_interpolate2 (border.hip) ----
+struct BorderArgs {
+    const float *raw;
+    size_t raw_stride;
+    float *red, *green, *blue;
+    size_t out_stride;
+    int W, H, bord;
+    unsigned filters;
+};
+__global__ void border_interpolate2_kernel(BorderArgs a);
+hipError_t launch_border_interpolate2(const BorderArgs &a, int grid, hipStream_t stream);
+
+} // namespace artgpu

@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- megapixels/second of the raw-development hot path on MI355X.
+
+A "step" is one pass of the hot path over one synthetic 45 MP (8192x5464) Bayer frame per
+GPU, CFA already resident in HBM, result left resident in HBM.
+Frames are independent, so N GPUs process N frames per step with no data-path collective
+(weak scaling); the only collective is the completion barrier / max-over-ranks of the time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     : dominant kernel's algorithmic bytes / its average launch time vs 8 TB/s HBM
+  cpu_baseline : the CPU oracle (port of the reference's x86-64 path) timed on this host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W45, H45 = 8192, 5464
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+ALGO_BYTES_PER_PX = 16         # 4 B CFA in + 12 B RGB out
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=W45)
+    ap.add_argument("--height", type=int, default=H45)
+    ap.add_argument("--workload", default="amaze", choices=["amaze", "rcd"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-repeats", type=int, default=3)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from art_amd import capi, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    W, H = args.width, args.height
+    filt = synth.FILTERS_RGGB
+    raw = synth.bayer_frame(W, H, filt, seed=rank)            # frame `rank` of the batch
+    d_raw = torch.from_numpy(raw).to(dev)
+    d_out = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(3)]
+    stream = torch.cuda.current_stream(dev)
+    ctx = capi.Context(local_rank, stream.cuda_stream)
+    out = capi.RGB(*[capi.device_plane(t) for t in d_out])
+    p_raw = capi.device_plane(d_raw)
+    method = capi.BAYER_AMAZE if args.workload == "amaze" else capi.BAYER_RCD
+
+    def step():
+        ctx.demosaic_bayer(method, p_raw, filt, 1.0, 4, out)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # per-launch duration of the dominant kernel, HIP events on the launch stream
+    ctx.enable_timing(True)
+    kernel_ms = []
+    evs = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    barrier()
+    t0 = time.perf_counter()
+    evs[0].record(stream)
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(ctx.timings().demosaic_ms)
+    evs[1].record(stream)
+    barrier()
+    t1 = time.perf_counter()
+    ctx.enable_timing(False)
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    mp = W * H / 1e6
+    value = world * args.steps * mp / elapsed
+    kern_ms = statistics.mean(kernel_ms)
+    achieved = (W * H * ALGO_BYTES_PER_PX / 1e9) / (kern_ms / 1e3)
+
+    result = {
+        "metric": "megapixels/sec end-to-end (AMaZE+FTblockDN+tone), 45 MP Bayer",
+        "value": round(value, 2),
+        "unit": "MP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.workload.upper()} demosaic, {W}x{H} Bayer RGGB fp32, 1 frame per GPU per step "
+                        "(BASELINE configs[1]; FTblockDN+tone stages not built yet)",
+            "frame": f"{W}x{H}", "frames_per_step": world, "parallelism": f"frame-per-gpu x{world}",
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "amaze_tiles_kernel" if method == capi.BAYER_AMAZE else "rcd_tiles_kernel",
+            "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": W * H * ALGO_BYTES_PER_PX,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_lib
+        ncores = os.cpu_count() or 1
+        os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
+        fn = (lambda: oracle_lib.amaze(raw, filt, 1.0, 4)) if method == capi.BAYER_AMAZE else (lambda: oracle_lib.rcd(raw, filt))
+        fn()  # warm-up (page faults)
+        ts = []
+        for _ in range(args.cpu_repeats):
+            c0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - c0)
+        result["cpu_baseline"] = {
+            "value": round(mp / statistics.median(ts), 2), "unit": "MP/s", "cores": ncores, "kind": "port",
+            "sample": f"{args.cpu_repeats} x full {W}x{H} frame, oracle/{args.workload}.c with OpenMP over tiles, median",
+        }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

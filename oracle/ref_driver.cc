@@ -1,0 +1,57 @@
+// oracle/ref_driver.cc -- thin extern "C" shim over the parts of the REFERENCE that compile in
+// this image from the sources where they lie (no stand-in headers): the sleef scalar and SSE
+// math (rtengine/sleef.h, sleefsseavx.h, helpersse2.h), LUTf (rtengine/LUT.h, with -DNDEBUG),
+// median.h, rt_math.h.  Built by oracle/Makefile.ref into oracle/_ref/libartref.so (git-ignored)
+// and used ONLY by tests to pin the oracle's restatement of these primitives.
+// Everything that needs rtengine.h / rawimagesource.h / StopWatch.h (-> glibmm, lcms2) is
+// unbuildable here: amaze_demosaic_RT.cc, rcd_demosaic.cc, demosaic_algos.cc, boxblur.h,
+// gauss.cc, guidedfilter.cc, FTblockDN.cc, nlmeans.cc, ip*.cc.
+#include <cstddef>
+#include "sleef.h"
+#include "LUT.h"
+#include "median.h"
+#include "rt_math.h"
+
+extern "C" {
+
+void ref_xexpf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xexpf(x[i]); }
+void ref_xlogf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xlogf(x[i]); }
+void ref_xsinf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xsinf(x[i]); }
+void ref_xcosf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xcosf(x[i]); }
+void ref_xatan2f(const float *a, const float *b, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xatan2f(a[i], b[i]); }
+void ref_xdiv2f(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xdiv2f(x[i]); }
+void ref_xdivf2(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xdivf(x[i], 2); }
+void ref_xlin2log(const float *x, float base, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xlin2log(x[i], base); }
+void ref_xlog2lin(const float *x, float base, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xlog2lin(x[i], base); }
+void ref_pow_F(const float *a, const float *b, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = pow_F(a[i], b[i]); }
+
+#ifdef __SSE2__
+// 4-lane SSE variants (n must be a multiple of 4)
+void ref_vexpf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, xexpf(_mm_loadu_ps(x + i))); }
+void ref_vlogf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, xlogf(_mm_loadu_ps(x + i))); }
+void ref_vmedian3(const float *a, const float *b, const float *c, float *y, size_t n)
+{
+    for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, median(_mm_loadu_ps(a + i), _mm_loadu_ps(b + i), _mm_loadu_ps(c + i)));
+}
+void ref_vintpf(const float *a, const float *b, const float *c, float *y, size_t n)
+{
+    for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, vintpf(_mm_loadu_ps(a + i), _mm_loadu_ps(b + i), _mm_loadu_ps(c + i)));
+}
+void ref_vminmax(const float *a, const float *b, float *mn, float *mx, size_t n)
+{
+    for (size_t i = 0; i < n; i += 4) {
+        _mm_storeu_ps(mn + i, vminf(_mm_loadu_ps(a + i), _mm_loadu_ps(b + i)));
+        _mm_storeu_ps(mx + i, vmaxf(_mm_loadu_ps(a + i), _mm_loadu_ps(b + i)));
+    }
+}
+// LUTf lookups: scalar operator[](float) and the SSE operator[](vfloat) (LUT.h:349-459)
+void ref_lutf(const float *table, size_t tsize, const float *x, float *y_scalar, float *y_vec, size_t n)
+{
+    LUTf lut(tsize);
+    for (size_t i = 0; i < tsize; ++i) lut[(int)i] = table[i];
+    for (size_t i = 0; i < n; ++i) y_scalar[i] = lut[x[i]];
+    for (size_t i = 0; i + 3 < n; i += 4) _mm_storeu_ps(y_vec + i, lut[_mm_loadu_ps(x + i)]);
+}
+#endif
+
+} // extern "C"
