@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libartgpu.so")
+LIB_PATH = os.environ.get("ARTGPU_LIB", os.path.join(_HERE, "libartgpu.so"))  # ARTGPU_LIB: kernel-variant experiments
 
 BAYER_AMAZE = 0
 BAYER_RCD = 1

@@ -114,7 +114,10 @@ __device__ __forceinline__ float g_bound(float Gint, float rb, float nA, float n
 
 } // namespace
 
-__global__ void __launch_bounds__(AMAZE_THREADS)
+#ifndef AMAZE_MIN_WAVES
+#define AMAZE_MIN_WAVES 4
+#endif
+__global__ void __launch_bounds__(AMAZE_THREADS, AMAZE_MIN_WAVES)
 amaze_tiles_kernel(AmazeArgs a)
 {
     const int tid = threadIdx.x;
