@@ -53,6 +53,11 @@ def _load():
     lib.artgpu_scratch_bytes.restype = C.c_size_t
     lib.artgpu_demosaic_bayer.argtypes = [C.c_void_p, C.c_int, C.POINTER(Plane), C.c_uint32, C.c_double, C.c_int, C.POINTER(RGB)]
     lib.artgpu_border_interpolate2.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_uint32, C.c_int, C.POINTER(RGB)]
+    lib.artgpu_get_image.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int,
+                                     C.POINTER(C.c_double), C.POINTER(RGB)]
+    lib.artgpu_convert_color_space.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double)]
+    lib.artgpu_exposure.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_float, C.c_float]
+    lib.artgpu_tone_curve.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.POINTER(C.c_float), C.c_float, C.c_int]
     return lib
 
 
@@ -60,12 +65,17 @@ LIB = _load()
 
 EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
            "artgpu_synchronize", "artgpu_enable_timing", "artgpu_get_timings", "artgpu_scratch_bytes",
-           "artgpu_demosaic_bayer", "artgpu_border_interpolate2"]
+           "artgpu_demosaic_bayer", "artgpu_border_interpolate2", "artgpu_get_image",
+           "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
     assert a.dtype == np.float32 and a.ndim == 2 and a.strides[1] == 4
     return Plane(a.ctypes.data, a.shape[1], a.shape[0], a.strides[0], 0)
+
+
+def host_rgb(planes) -> RGB:
+    return RGB(*[host_plane(p) for p in planes])
 
 
 def device_plane(t) -> Plane:
@@ -111,6 +121,26 @@ class Context:
 
     def border_interpolate2(self, raw: Plane, filters: int, lborders: int, out: RGB):
         self._chk(LIB.artgpu_border_interpolate2(self._h, C.byref(raw), filters, lborders, C.byref(out)))
+
+    def get_image(self, planes: RGB, sx1: int, sy1: int, mul, do_clip: bool, mat, image: RGB):
+        m = (C.c_float * 3)(*[float(v) for v in mul])
+        mp = None if mat is None else (C.c_double * 9)(*[float(v) for v in np.asarray(mat, dtype=np.float64).reshape(9)])
+        self._chk(LIB.artgpu_get_image(self._h, C.byref(planes), sx1, sy1, m, int(do_clip), mp, C.byref(image)))
+
+    def convert_color_space(self, image: RGB, mat):
+        mp = (C.c_double * 9)(*[float(v) for v in np.asarray(mat, dtype=np.float64).reshape(9)])
+        self._chk(LIB.artgpu_convert_color_space(self._h, C.byref(image), mp))
+
+    def exposure(self, image: RGB, exp_scale: float, black: float):
+        self._chk(LIB.artgpu_exposure(self._h, C.byref(image), exp_scale, black))
+
+    def tone_curve(self, image: RGB, lut, whitept: float = 1.0, filmlike_clip: bool = True, mode: int = 0):
+        lp = None
+        if lut is not None:
+            lut = np.ascontiguousarray(lut, dtype=np.float32)
+            assert lut.shape == (65536,)
+            lp = lut.ctypes.data_as(C.POINTER(C.c_float))
+        self._chk(LIB.artgpu_tone_curve(self._h, C.byref(image), mode, lp, whitept, int(filmlike_clip)))
 
     # convenience for tests: host numpy in, host numpy out (staged through the library)
     def demosaic_bayer_host(self, method: int, raw: np.ndarray, filters: int, initial_gain: float = 1.0, border: int = 4):

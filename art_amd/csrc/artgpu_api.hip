@@ -21,8 +21,11 @@ struct artgpu_ctx {
     float *arena = nullptr;
     size_t arena_bytes = 0;
     // staging for host-pointer calls: one CFA plane + three output planes
-    float *stage[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t stage_bytes[4] = {0, 0, 0, 0};
+    static constexpr int NSTAGE = 8;
+    float *stage[NSTAGE] = {};
+    size_t stage_bytes[NSTAGE] = {};
+    float *lut = nullptr; // 65536-entry tone LUT on the device
+    size_t lut_bytes = 0;
     // timing
     bool timing = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -135,6 +138,56 @@ int launch_border(artgpu_ctx *ctx, const DevImage &d, int W, int H, unsigned fil
     return ARTGPU_OK;
 }
 
+
+// Generic RGB image binding: device planes are used in place, host planes are staged through
+// ctx->stage[slot..slot+2] (copy_in: H2D now; the D2H happens in unbind_rgb).
+struct DevRGB {
+    float *p[3];
+    size_t stride; // floats
+    int w, h;
+    bool staged;
+};
+
+int bind_rgb(artgpu_ctx *ctx, const artgpu_rgb *img, int slot, bool copy_in, DevRGB *d, const char *what)
+{
+    const artgpu_plane *pl[3] = {&img->r, &img->g, &img->b};
+    for (int k = 0; k < 3; ++k) {
+        if (!plane_ok(pl[k]) || pl[k]->w != img->r.w || pl[k]->h != img->r.h)
+            return fail(ctx, ARTGPU_EINVAL, "%s: plane %d has a bad pointer/size/stride", what, k);
+        if ((pl[k]->on_device != 0) != (img->r.on_device != 0) || pl[k]->row_stride_bytes != img->r.row_stride_bytes)
+            return fail(ctx, ARTGPU_EINVAL, "%s: planes must share residency and row stride", what);
+    }
+    d->w = img->r.w; d->h = img->r.h;
+    if (img->r.on_device) {
+        for (int k = 0; k < 3; ++k) d->p[k] = pl[k]->p;
+        d->stride = (size_t)(img->r.row_stride_bytes / 4);
+        d->staged = false;
+        return ARTGPU_OK;
+    }
+    const size_t rowb = (size_t)d->w * 4;
+    for (int k = 0; k < 3; ++k) {
+        int rc = ensure(ctx, &ctx->stage[slot + k], &ctx->stage_bytes[slot + k], rowb * d->h);
+        if (rc) return rc;
+        d->p[k] = ctx->stage[slot + k];
+        if (copy_in)
+            HIPCHK(ctx, hipMemcpy2DAsync(d->p[k], rowb, pl[k]->p, (size_t)pl[k]->row_stride_bytes, rowb, d->h, hipMemcpyHostToDevice, ctx->stream));
+    }
+    d->stride = d->w;
+    d->staged = true;
+    return ARTGPU_OK;
+}
+
+int unbind_rgb(artgpu_ctx *ctx, artgpu_rgb *img, const DevRGB *d)
+{
+    if (!d->staged) return ARTGPU_OK;
+    artgpu_plane *pl[3] = {&img->r, &img->g, &img->b};
+    const size_t rowb = (size_t)d->w * 4;
+    for (int k = 0; k < 3; ++k)
+        HIPCHK(ctx, hipMemcpy2DAsync(pl[k]->p, (size_t)pl[k]->row_stride_bytes, d->p[k], rowb, rowb, d->h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
 constexpr int MAX_TILE_WORKGROUPS = 8192;
 
 } // namespace
@@ -165,8 +218,9 @@ int artgpu_destroy(artgpu_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->arena) (void)hipFree(ctx->arena);
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < artgpu_ctx::NSTAGE; ++k)
         if (ctx->stage[k]) (void)hipFree(ctx->stage[k]);
+    if (ctx->lut) (void)hipFree(ctx->lut);
     for (int k = 0; k < 3; ++k)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     delete ctx;
@@ -208,7 +262,8 @@ size_t artgpu_scratch_bytes(const artgpu_ctx *ctx)
 {
     if (!ctx) return 0;
     size_t s = ctx->arena_bytes;
-    for (int k = 0; k < 4; ++k) s += ctx->stage_bytes[k];
+    for (int k = 0; k < artgpu_ctx::NSTAGE; ++k) s += ctx->stage_bytes[k];
+    s += ctx->lut_bytes;
     return s;
 }
 
@@ -299,6 +354,87 @@ int artgpu_border_interpolate2(artgpu_ctx *ctx, const artgpu_plane *raw, uint32_
     rc = launch_border(ctx, d, raw->w, raw->h, filters, lborders);
     if (rc) return rc;
     return unbind_images(ctx, out, &d);
+}
+
+int artgpu_get_image(artgpu_ctx *ctx, const artgpu_rgb *planes, int sx1, int sy1, const float mul[3],
+                     int do_clip, const double *mat, artgpu_rgb *image)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!planes || !image || !mul) return fail(ctx, ARTGPU_EINVAL, "get_image: null argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB src, dst;
+    int rc = bind_rgb(ctx, planes, 1, true, &src, "get_image(planes)");
+    if (rc) return rc;
+    rc = bind_rgb(ctx, image, 4, false, &dst, "get_image(image)");
+    if (rc) return rc;
+    if (sx1 < 0 || sy1 < 0 || sx1 + dst.w > src.w || sy1 + dst.h > src.h)
+        return fail(ctx, ARTGPU_EINVAL, "get_image: crop %dx%d+%d+%d outside the %dx%d planes", dst.w, dst.h, sx1, sy1, src.w, src.h);
+    PixArgs a = {};
+    for (int k = 0; k < 3; ++k) { a.src[k] = src.p[k]; a.dst[k] = dst.p[k]; a.mul[k] = mul[k]; }
+    a.src_stride = src.stride; a.dst_stride = dst.stride;
+    a.sx1 = sx1; a.sy1 = sy1; a.w = dst.w; a.h = dst.h;
+    a.has_mul = 1; a.do_clip = do_clip ? 1 : 0;
+    a.has_mat = mat ? 1 : 0;
+    if (mat) for (int k = 0; k < 9; ++k) a.mat[k] = mat[k];
+    HIPCHK(ctx, launch_get_image_convert(a, ctx->stream));
+    return unbind_rgb(ctx, image, &dst);
+}
+
+int artgpu_convert_color_space(artgpu_ctx *ctx, artgpu_rgb *image, const double mat[9])
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!image || !mat) return fail(ctx, ARTGPU_EINVAL, "convert_color_space: null argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB d;
+    int rc = bind_rgb(ctx, image, 4, true, &d, "convert_color_space");
+    if (rc) return rc;
+    PixArgs a = {};
+    for (int k = 0; k < 3; ++k) { a.src[k] = d.p[k]; a.dst[k] = d.p[k]; }
+    a.src_stride = d.stride; a.dst_stride = d.stride; a.w = d.w; a.h = d.h;
+    a.has_mul = 0; a.has_mat = 1;
+    for (int k = 0; k < 9; ++k) a.mat[k] = mat[k];
+    HIPCHK(ctx, launch_get_image_convert(a, ctx->stream));
+    return unbind_rgb(ctx, image, &d);
+}
+
+int artgpu_exposure(artgpu_ctx *ctx, artgpu_rgb *image, float exp_scale, float black)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!image) return fail(ctx, ARTGPU_EINVAL, "exposure: null image");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB d;
+    int rc = bind_rgb(ctx, image, 4, true, &d, "exposure");
+    if (rc) return rc;
+    PixArgs a = {};
+    for (int k = 0; k < 3; ++k) a.dst[k] = d.p[k];
+    a.dst_stride = d.stride; a.w = d.w; a.h = d.h;
+    a.exp_scale = exp_scale; a.black = black;
+    HIPCHK(ctx, launch_exposure(a, ctx->stream));
+    return unbind_rgb(ctx, image, &d);
+}
+
+int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float *lut65536, float whitept, int filmlike_clip)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!image) return fail(ctx, ARTGPU_EINVAL, "tone_curve: null image");
+    if (mode != ARTGPU_TONE_STD) return fail(ctx, ARTGPU_EUNSUPPORTED, "tone_curve: curve mode %d is not on the device path", mode);
+    if (!(whitept > 0.f) || whitept > 1.f) return fail(ctx, ARTGPU_EUNSUPPORTED, "tone_curve: whitept %g needs the analytic curve beyond the LUT", (double)whitept);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB d;
+    int rc = bind_rgb(ctx, image, 4, true, &d, "tone_curve");
+    if (rc) return rc;
+    PixArgs a = {};
+    for (int k = 0; k < 3; ++k) a.dst[k] = d.p[k];
+    a.dst_stride = d.stride; a.w = d.w; a.h = d.h;
+    a.do_clip = filmlike_clip ? 1 : 0; a.whitept = whitept;
+    if (lut65536) {
+        rc = ensure(ctx, &ctx->lut, &ctx->lut_bytes, 65536 * sizeof(float));
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->lut, lut65536, 65536 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        a.lut = ctx->lut;
+    }
+    HIPCHK(ctx, launch_tone_std(a, ctx->stream));
+    return unbind_rgb(ctx, image, &d);
 }
 
 } // extern "C"

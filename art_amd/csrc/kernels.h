@@ -58,4 +58,25 @@ struct BorderArgs {
 __global__ void border_interpolate2_kernel(BorderArgs a);
 hipError_t launch_border_interpolate2(const BorderArgs &a, int grid, hipStream_t stream);
 
+// ---- per-pixel stages (pixelops.hip) ----
+struct PixArgs {
+    const float *src[3];   // get_image: demosaiced planes
+    size_t src_stride;
+    int sx1, sy1;          // crop origin in src (RawImageSource::border)
+    float *dst[3];         // destination / in-place image
+    size_t dst_stride;
+    int w, h;
+    float mul[3];          // rm, gm, bm
+    int has_mul;           // get_image: apply the channel multipliers (0 = pure matrix conversion)
+    int do_clip;           // get_image: CLIP; tone: filmlike_clip
+    int has_mat;
+    double mat[9];         // raw->working matrix, row-major
+    float exp_scale, black;
+    const float *lut;      // tone: 65536-entry LUT on the device (nullable)
+    float whitept;
+};
+hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s);
+hipError_t launch_exposure(const PixArgs &a, hipStream_t s);
+hipError_t launch_tone_std(const PixArgs &a, hipStream_t s);
+
 } // namespace artgpu

@@ -1,0 +1,135 @@
+// art_amd/csrc/pixelops.hip -- per-pixel stages around the demosaic, one lane per pixel,
+// coalesced row accesses, HBM-bound (12 B in + 12 B out per pixel):
+//   get_image_convert : RawImageSource::getImage (skip=1, tran=0; rawimagesource.cc:940-1025)
+//                       fused with the matrix branch of colorSpaceConversion_ (L3184-3213;
+//                       double accumulation, float store) -- the intermediate the reference
+//                       stores between the two is the same float the fused kernel converts
+//   convert_color_space: the matrix branch alone, in place
+//   exposure           : ImProcFunctions::expcomp (ipexposure.cc:28-72), SSE lanes use
+//                        _mm_max_ps(x,0), the W%4 tail uses std::max(x,0.f)
+//   tone_std           : filmlike_clip (iptonecurve.cc:214-231 -> color.cc:6648-6690) followed by
+//                        StandardToneCurve::Apply (curves.h:224-231,360-368; LUT.h:436-459)
+#include <hip/hip_runtime.h>
+#include "devmath.h"
+#include "kernels.h"
+
+namespace artgpu {
+
+namespace {
+__device__ __forceinline__ float clipf(float a) { return std_max(0.f, std_min(a, 65535.f)); }
+
+__device__ __forceinline__ void clip_rgb_tone(float &r, float &g, float &b, float L)
+{
+    const float r_ = r > L ? L : r;
+    const float b_ = b > L ? L : b;
+    const float g_ = b_ + ((r_ - b_) * (g - b) / (r - b));
+    r = r_; g = g_; b = b_;
+}
+__device__ __forceinline__ void filmlike_clip_px(float &r, float &g, float &b, float L)
+{
+    if (r >= g) {
+        if (g > b) clip_rgb_tone(r, g, b, L);
+        else if (b > r) clip_rgb_tone(b, r, g, L);
+        else if (b > g) clip_rgb_tone(r, b, g, L);
+        else { r = r > L ? L : r; g = g > L ? L : g; b = g; }
+    } else {
+        if (r >= b) clip_rgb_tone(g, r, b, L);
+        else if (b > g) clip_rgb_tone(b, g, r, L);
+        else clip_rgb_tone(g, b, r, L);
+    }
+}
+__device__ __forceinline__ float lutf(const float *__restrict__ data, int size, float index)
+{
+    const int maxs = size - 2, upper = size - 1;
+    if (index < 0.f || !(index == index)) return data[0];
+    if (index > (float)maxs) return data[upper];
+    const int idx = (int)index;
+    const float diff = index - (float)idx;
+    const float p1 = data[idx];
+    const float p2 = data[idx + 1] - p1;
+    return p1 + p2 * diff;
+}
+} // namespace
+
+__global__ void __launch_bounds__(256) get_image_convert_kernel(PixArgs a)
+{
+    const long long n = (long long)a.w * a.h;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+        const size_t si = (size_t)(a.sy1 + y) * a.src_stride + a.sx1 + x;
+        float r, g, b;
+        if (a.has_mul) {
+            r = 0.f; g = 0.f; b = 0.f;
+            r += a.src[0][si]; g += a.src[1][si]; b += a.src[2][si];
+            r *= a.mul[0]; g *= a.mul[1]; b *= a.mul[2];
+            if (a.do_clip) { r = clipf(r); g = clipf(g); b = clipf(b); }
+        } else {
+            r = a.src[0][si]; g = a.src[1][si]; b = a.src[2][si];
+        }
+        if (a.has_mat) {
+            const double dr = r, dg = g, db = b;
+            r = (float)(a.mat[0] * dr + a.mat[1] * dg + a.mat[2] * db);
+            g = (float)(a.mat[3] * dr + a.mat[4] * dg + a.mat[5] * db);
+            b = (float)(a.mat[6] * dr + a.mat[7] * dg + a.mat[8] * db);
+        }
+        const size_t di = (size_t)y * a.dst_stride + x;
+        a.dst[0][di] = r; a.dst[1][di] = g; a.dst[2][di] = b;
+    }
+}
+
+__global__ void __launch_bounds__(256) exposure_kernel(PixArgs a)
+{
+    const long long n = (long long)a.w * a.h;
+    const int wv = (a.w / 4) * 4;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+        const size_t di = (size_t)y * a.dst_stride + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = a.dst[c][di] * a.exp_scale - a.black;
+            a.dst[c][di] = x < wv ? sse_max(v, 0.f) : std_max(v, 0.f);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) tone_std_kernel(PixArgs a)
+{
+    const long long n = (long long)a.w * a.h;
+    const float Lmax = 65535.f * a.whitept;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+        const size_t di = (size_t)y * a.dst_stride + x;
+        float r = a.dst[0][di], g = a.dst[1][di], b = a.dst[2][di];
+        if (a.do_clip) filmlike_clip_px(r, g, b, Lmax);
+        if (a.lut) {
+            r = lutf(a.lut, 65536, std_max(r, 0.f));
+            g = lutf(a.lut, 65536, std_max(g, 0.f));
+            b = lutf(a.lut, 65536, std_max(b, 0.f));
+        }
+        a.dst[0][di] = r; a.dst[1][di] = g; a.dst[2][di] = b;
+    }
+}
+
+static int pix_grid(const PixArgs &a)
+{
+    const long long n = (long long)a.w * a.h;
+    const long long g = (n + 255) / 256;
+    return (int)(g < 16384 ? g : 16384);
+}
+hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(get_image_convert_kernel, dim3(pix_grid(a)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_exposure(const PixArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(exposure_kernel, dim3(pix_grid(a)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_tone_std(const PixArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(tone_std_kernel, dim3(pix_grid(a)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace artgpu

@@ -92,6 +92,39 @@ int artgpu_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, 
 int artgpu_border_interpolate2(artgpu_ctx *ctx, const artgpu_plane *raw, uint32_t filters,
                                int lborders, artgpu_rgb *out);
 
+/* Replaces RawImageSource::getImage for tran=0, skip=1, no highlight recovery
+ * (rtengine/rawimagesource.cc:781-1104; pixel loop L940-1025), optionally fused with the matrix
+ * branch of colorSpaceConversion_ (L3184-3213) when `mat` is not NULL:
+ *   image(y,x) = CLIP?( planes(sy1+y, sx1+x) * mul[c] ),  then  image = (float)(mat * image)
+ * planes : red/green/blue produced by artgpu_demosaic_bayer (full sensor size)
+ * sx1,sy1: crop origin = RawImageSource::border (transformRect, L664-700)
+ * mul    : rm, gm, bm computed by the caller as in L790-928
+ * do_clip: the reference's doClip (L964-973)
+ * mat    : 9 doubles row-major = work^-1 * xyz_cam (L3187-3195), or NULL
+ * image  : destination Imagefloat planes (w,h = cropped size), may not alias `planes`. */
+int artgpu_get_image(artgpu_ctx *ctx, const artgpu_rgb *planes, int sx1, int sy1, const float mul[3],
+                     int do_clip, const double *mat, artgpu_rgb *image);
+
+/* RawImageSource::convertColorSpace, default-camera-profile (matrix) branch, in place
+ * (rtengine/rawimagesource.cc:1128-1143,3184-3213): double accumulation, float store. */
+int artgpu_convert_color_space(artgpu_ctx *ctx, artgpu_rgb *image, const double mat[9]);
+
+/* ImProcFunctions::exposure -> expcomp (rtengine/ipexposure.cc:28-79), in place:
+ *   v = max(v * exp_scale - black, 0), exp_scale = pow(2.f, expcomp), black = params.black*2000
+ * (both computed by the caller, L39-40). */
+int artgpu_exposure(artgpu_ctx *ctx, artgpu_rgb *image, float exp_scale, float black);
+
+/* Device part of ImProcFunctions::toneCurve (rtengine/iptonecurve.cc:553-716) for
+ * curveMode == STD with a single curve: optional filmlike_clip(img, whitept) (L214-231; taken
+ * when basecurve is LINEAR, L593) followed by StandardToneCurve::Apply with the 65536-entry
+ * LUT that ToneCurve::Set built on the host (rtengine/curves.cc:221-231; curves.h:224-231,
+ * 360-368).  `lut65536` is a HOST pointer (copied to the device), NULL = clip only.
+ * whitept > 1 needs the analytic curve beyond the LUT (setLutVal's else branch) and returns
+ * ARTGPU_EUNSUPPORTED; other curve modes (NEUTRAL, PERCEPTUAL, ...) likewise. */
+#define ARTGPU_TONE_STD 0
+int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float *lut65536,
+                      float whitept, int filmlike_clip);
+
 /* Bytes of device scratch the context currently holds (arena + staging). */
 size_t artgpu_scratch_bytes(const artgpu_ctx *ctx);
 

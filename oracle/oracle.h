@@ -29,6 +29,15 @@ int oracle_amaze_demosaic(const float *raw, size_t raw_stride, int W, int H, uns
                           double initialGain, int border,
                           float *red, float *green, float *blue, size_t out_stride);
 
+/* per-pixel stages (oracle/pixelops.c); strides in floats */
+void oracle_get_image(const float *const src[3], size_t ss, int sx1, int sy1,
+                      float *const dst[3], size_t ds, int w, int h, const float mul[3], int do_clip);
+void oracle_convert_color_space(float *const img[3], size_t s, int w, int h, const double mat[9]);
+void oracle_exposure(float *const img[3], size_t s, int w, int h, float exp_scale, float black);
+void oracle_filmlike_clip(float *const img[3], size_t s, int w, int h, float whitept);
+float oracle_lutf(const float *data, int size, float index);
+void oracle_tone_curve_std(float *const img[3], size_t s, int w, int h, const float *lut65536);
+
 #ifdef __cplusplus
 }
 #endif

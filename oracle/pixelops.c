@@ -1,0 +1,122 @@
+/*
+ * oracle/pixelops.c -- CPU restatement of the per-pixel stages around the demosaic:
+ *   oracle_get_image           RawImageSource::getImage, skip=1/tran=0/no highlight recovery
+ *                              (reference: rtengine/rawimagesource.cc:781-1104, loop L940-1025)
+ *   oracle_convert_color_space colorSpaceConversion_ matrix branch (rawimagesource.cc:3184-3213)
+ *   oracle_exposure            ImProcFunctions::expcomp (rtengine/ipexposure.cc:28-72)
+ *   oracle_filmlike_clip       filmlike_clip -> Color::filmlike_clip (iptonecurve.cc:214-231,
+ *                              color.cc:6648-6690)
+ *   oracle_tone_curve_std      StandardToneCurve::Apply via curves::setLutVal and the scalar
+ *                              LUTf::operator[](float) (curves.h:224-231,360-368; LUT.h:436-459)
+ *
+ * TEST INFRASTRUCTURE ONLY.  PARITY: the LUTf lookup is pinned against the reference's own
+ * LUT.h through oracle/_ref (tests/golden/lutf.npz); the other functions are unpinned
+ * (their translation units need glibmm/lcms2 headers).
+ */
+#include "oracle.h"
+#include "oracle_common.h"
+
+void oracle_get_image(const float *const src[3], size_t ss, int sx1, int sy1,
+                      float *const dst[3], size_t ds, int w, int h, const float mul[3], int do_clip)
+{
+#pragma omp parallel for
+    for (int y = 0; y < h; ++y)
+        for (int c = 0; c < 3; ++c) {
+            const float *s = src[c] + (size_t)(sy1 + y) * ss + sx1;
+            float *d = dst[c] + (size_t)y * ds;
+            for (int x = 0; x < w; ++x) {
+                float t = 0.f;
+                t += s[x];          /* skip == 1: one term of the rtot accumulation (L950-956) */
+                t *= mul[c];
+                if (do_clip) t = rt_maxf(0.f, rt_minf(t, 65535.f)); /* CLIP = LIM(a,0,MAXVAL) */
+                d[x] = t;
+            }
+        }
+}
+
+void oracle_convert_color_space(float *const img[3], size_t s, int w, int h, const double mat[9])
+{
+#pragma omp parallel for
+    for (int y = 0; y < h; ++y) {
+        float *r = img[0] + (size_t)y * s, *g = img[1] + (size_t)y * s, *b = img[2] + (size_t)y * s;
+        for (int x = 0; x < w; ++x) {
+            float nr = mat[0] * r[x] + mat[1] * g[x] + mat[2] * b[x];
+            float ng = mat[3] * r[x] + mat[4] * g[x] + mat[5] * b[x];
+            float nb = mat[6] * r[x] + mat[7] * g[x] + mat[8] * b[x];
+            r[x] = nr; g[x] = ng; b[x] = nb;
+        }
+    }
+}
+
+void oracle_exposure(float *const img[3], size_t s, int w, int h, float exp_scale, float black)
+{
+    const int wv = (w / 4) * 4; /* SSE loop `for (; x < W - 3; x += 4)` covers [0, 4*floor(W/4)) */
+#pragma omp parallel for
+    for (int y = 0; y < h; ++y)
+        for (int c = 0; c < 3; ++c) {
+            float *p = img[c] + (size_t)y * s;
+            for (int x = 0; x < w; ++x) {
+                float t = p[x] * exp_scale - black;
+                p[x] = x < wv ? sse_maxf(t, 0.f) : std_maxf(t, 0.f);
+            }
+        }
+}
+
+static inline void clip_rgb_tone(float *r, float *g, float *b, float L)
+{
+    float r_ = *r > L ? L : *r;
+    float b_ = *b > L ? L : *b;
+    float g_ = b_ + ((r_ - b_) * (*g - *b) / (*r - *b));
+    *r = r_; *g = g_; *b = b_;
+}
+
+static inline void filmlike_clip_px(float *r, float *g, float *b, float L)
+{
+    if (*r >= *g) {
+        if (*g > *b) clip_rgb_tone(r, g, b, L);
+        else if (*b > *r) clip_rgb_tone(b, r, g, L);
+        else if (*b > *g) clip_rgb_tone(r, b, g, L);
+        else { *r = *r > L ? L : *r; *g = *g > L ? L : *g; *b = *g; }
+    } else {
+        if (*r >= *b) clip_rgb_tone(g, r, b, L);
+        else if (*b > *g) clip_rgb_tone(b, g, r, L);
+        else clip_rgb_tone(g, b, r, L);
+    }
+}
+
+void oracle_filmlike_clip(float *const img[3], size_t s, int w, int h, float whitept)
+{
+    const float Lmax = 65535.f * whitept;
+#pragma omp parallel for
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            size_t o = (size_t)y * s + x;
+            filmlike_clip_px(&img[0][o], &img[1][o], &img[2][o], Lmax);
+        }
+}
+
+/* LUTf::operator[](float) with the default LUT_CLIP_BELOW|LUT_CLIP_ABOVE (LUT.h:436-459) */
+float oracle_lutf(const float *data, int size, float index)
+{
+    const int maxs = size - 2, upper = size - 1;
+    int idx = (int)index;
+    if (index < 0.f || !(index == index)) return data[0];
+    if (index > (float)maxs) return data[upper];
+    float diff = index - (float)idx;
+    float p1 = data[idx];
+    float p2 = data[idx + 1] - p1;
+    return p1 + p2 * diff;
+}
+
+void oracle_tone_curve_std(float *const img[3], size_t s, int w, int h, const float *lut65536)
+{
+#pragma omp parallel for
+    for (int y = 0; y < h; ++y)
+        for (int c = 0; c < 3; ++c) {
+            float *p = img[c] + (size_t)y * s;
+            for (int x = 0; x < w; ++x) {
+                /* setLutVal: val <= 65535 (always true after filmlike_clip with whitept <= 1) */
+                p[x] = oracle_lutf(lut65536, 65536, std_maxf(p[x], 0.f));
+            }
+        }
+}

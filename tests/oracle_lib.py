@@ -73,3 +73,49 @@ def amaze_tiles_stale(raw: np.ndarray, filters: int, initial_gain: float, order:
         L.oracle_amaze_tile(_ptr(raw), C.c_size_t(w), w, h, C.c_uint(filters), C.c_float(clip_pt), C.c_float(clip_pt8),
                             top, left, _ptr(r), _ptr(g), _ptr(b), C.c_size_t(w), _ptr(arena), 1)
     return r, g, b
+
+
+def _p3(planes):
+    arr = (_fp * 3)(*[_ptr(p) for p in planes])
+    return arr
+
+
+def get_image(planes, sx1, sy1, w, h, mul, do_clip):
+    planes = [np.ascontiguousarray(p, dtype=np.float32) for p in planes]
+    out = [np.full((h, w), np.nan, dtype=np.float32) for _ in range(3)]
+    m = (C.c_float * 3)(*[float(v) for v in mul])
+    lib().oracle_get_image(_p3(planes), C.c_size_t(planes[0].shape[1]), sx1, sy1, _p3(out), C.c_size_t(w), w, h, m, int(do_clip))
+    return out
+
+
+def convert_color_space(img, mat):
+    img = [np.array(p, dtype=np.float32, order="C") for p in img]
+    h, w = img[0].shape
+    m = (C.c_double * 9)(*[float(v) for v in np.asarray(mat, dtype=np.float64).reshape(9)])
+    lib().oracle_convert_color_space(_p3(img), C.c_size_t(w), w, h, m)
+    return img
+
+
+def exposure(img, exp_scale, black):
+    img = [np.array(p, dtype=np.float32, order="C") for p in img]
+    h, w = img[0].shape
+    lib().oracle_exposure(_p3(img), C.c_size_t(w), w, h, C.c_float(exp_scale), C.c_float(black))
+    return img
+
+
+def tone_std(img, lut, whitept=1.0, filmlike_clip=True):
+    img = [np.array(p, dtype=np.float32, order="C") for p in img]
+    h, w = img[0].shape
+    if filmlike_clip:
+        lib().oracle_filmlike_clip(_p3(img), C.c_size_t(w), w, h, C.c_float(whitept))
+    if lut is not None:
+        lut = np.ascontiguousarray(lut, dtype=np.float32)
+        lib().oracle_tone_curve_std(_p3(img), C.c_size_t(w), w, h, _ptr(lut))
+    return img
+
+
+def lutf(table, x):
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    L = lib()
+    L.oracle_lutf.restype = C.c_float
+    return np.array([L.oracle_lutf(_ptr(table), len(table), C.c_float(float(v))) for v in x], dtype=np.float32)

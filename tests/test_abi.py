@@ -1,0 +1,40 @@
+"""CPU: libartgpu.so loads and exports every function include/artgpu.h declares (no compute)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "artgpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(artgpu_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from art_amd import capi
+    names = declared_functions()
+    assert len(names) >= 15
+    missing = [n for n in names if not hasattr(capi.LIB, n)]
+    assert not missing, missing
+    assert sorted(capi.EXPORTS) == names, "capi.EXPORTS must list exactly the header's functions"
+
+
+def test_version_string():
+    from art_amd import capi
+    assert b"gfx950" in capi.LIB.artgpu_version()
+
+
+def test_null_context_is_an_error_not_a_crash():
+    from art_amd import capi
+    assert capi.LIB.artgpu_synchronize(None) != 0
+    assert capi.LIB.artgpu_destroy(None) != 0
+
+
+def test_no_oracle_in_product():
+    """The product library must not link or reference the CPU oracle."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", os.path.join(ROOT, "art_amd", "libartgpu.so")], capture_output=True, text=True).stdout
+    assert "oracle_" not in out
+    for f in os.listdir(os.path.join(ROOT, "art_amd", "csrc")):
+        assert "oracle" not in open(os.path.join(ROOT, "art_amd", "csrc", f), errors="ignore").read().lower() or f.endswith(".o")
