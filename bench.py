@@ -93,11 +93,11 @@ def main() -> None:
     barrier()
     t1 = time.perf_counter()
     ctx.enable_timing(False)
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # completion step: all-gather of the 64-byte per-rank records (the batch's only collective),
+    # elapsed = MAX over ranks
+    from art_amd import batch
+    records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, args.steps, 0,
+                                            batch.checksum64([int(d_out[1][H // 2, W // 2].item())]), t1 - t0)
 
     mp = W * H / 1e6
     value = world * args.steps * mp / elapsed
@@ -121,6 +121,7 @@ def main() -> None:
             "workload": f"{args.workload.upper()} demosaic, {W}x{H} Bayer RGGB fp32, 1 frame per GPU per step "
                         "(BASELINE configs[1]; FTblockDN+tone stages not built yet)",
             "frame": f"{W}x{H}", "frames_per_step": world, "parallelism": f"frame-per-gpu x{world}",
+            "completion_records": len(records),
         },
         "roofline": {
             "bound": "hbm", "kernel": "amaze_tiles_kernel" if method == capi.BAYER_AMAZE else "rcd_tiles_kernel",

@@ -1,0 +1,63 @@
+"""CPU, world_size 2, gloo: the N>1 path of bench.py (frame sharding + completion all-gather)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from art_amd import batch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nframes, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = batch.frames_for_rank(nframes, rank, world)
+    # "process" each frame: checksum of (frame id, a frame-dependent word)
+    cs = batch.checksum64([w for f in mine for w in (f, f * 2654435761 + 12345)])
+    recs, tmax = batch.complete_batch(dist, torch.device("cpu"), rank, len(mine), 0, cs, 0.001 * (rank + 1))
+    q.put((rank, mine, recs, tmax))
+    dist.destroy_process_group()
+
+
+def test_frames_partition_round_robin():
+    for world in (1, 2, 4, 8):
+        owned = [batch.frames_for_rank(8, r, world) for r in range(world)]
+        assert sorted(f for o in owned for f in o) == list(range(8))
+        assert all(len(o) == 8 // world for o in owned)
+    with pytest.raises(ValueError):
+        batch.frames_for_rank(8, 2, 2)
+
+
+def test_two_rank_completion_gather():
+    world, nframes = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nframes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3]
+    for rank, mine, recs, tmax in res:
+        assert [r["rank"] for r in recs] == [0, 1]
+        assert [r["frames"] for r in recs] == [3, 2]
+        assert all(r["status"] == 0 for r in recs)
+        assert abs(tmax - 0.002) < 1e-6          # MAX over ranks
+    # every rank sees the same records, and they match a local recomputation
+    assert res[0][2] == res[1][2]
+    exp0 = batch.checksum64([w for f in (0, 2, 4) for w in (f, f * 2654435761 + 12345)])
+    assert res[0][2][0]["checksum"] == exp0
