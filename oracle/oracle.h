@@ -38,6 +38,28 @@ void oracle_filmlike_clip(float *const img[3], size_t s, int w, int h, float whi
 float oracle_lutf(const float *data, int size, float index);
 void oracle_tone_curve_std(float *const img[3], size_t s, int w, int h, const float *lut65536);
 
+/* wavelet_decomposition, subsampling == 1 (oracle/wavelet.c) */
+typedef struct {
+    int w, h, w2, h2, nlevels;
+    float *band[10][4]; /* band[l][1..3]: detail subbands, w2*h2 floats each */
+    float *coeff0;      /* final low-pass, w2*h2 */
+} oracle_wavelet;
+int oracle_wavelet_skip(int level);
+oracle_wavelet *oracle_wavelet_decompose(const float *src, int w, int h, int maxlvl);
+void oracle_wavelet_reconstruct(oracle_wavelet *d, float *dst, float blend);
+void oracle_wavelet_free(oracle_wavelet *d);
+
+/* sleef-derived math (oracle/sleef.c); _s = scalar form, _v = per-lane SSE form */
+float oracle_xexpf_s(float d);
+float oracle_xexpf_v(float d);
+float oracle_xexpf_v_nocheck(float d);
+float oracle_xlogf_s(float d);
+float oracle_xlogf_v(float d);
+float oracle_xlogf_v_nocheck(float d);
+float oracle_pow_F(float a, float b);
+float oracle_xlin2log(float x, float base);
+float oracle_xlog2lin(float x, float base);
+
 #ifdef __cplusplus
 }
 #endif

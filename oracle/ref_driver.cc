@@ -11,8 +11,20 @@
 #include "LUT.h"
 #include "median.h"
 #include "rt_math.h"
+#include "cplx_wavelet_dec.h"
 
 extern "C" {
+
+// ---- rtengine::wavelet_decomposition (cplx_wavelet_dec.h, subsampling = 1, Daub4 6 taps) ----
+void *ref_wavelet_new(float *src, int w, int h, int maxlvl) { return new rtengine::wavelet_decomposition(src, w, h, maxlvl, 1, 1, 1); }
+int ref_wavelet_maxlevel(void *p) { return static_cast<rtengine::wavelet_decomposition *>(p)->maxlevel(); }
+int ref_wavelet_W(void *p, int l) { return static_cast<rtengine::wavelet_decomposition *>(p)->level_W(l); }
+int ref_wavelet_H(void *p, int l) { return static_cast<rtengine::wavelet_decomposition *>(p)->level_H(l); }
+int ref_wavelet_stride(void *p, int l) { return static_cast<rtengine::wavelet_decomposition *>(p)->level_stride(l); }
+float *ref_wavelet_band(void *p, int l, int dir) { return static_cast<rtengine::wavelet_decomposition *>(p)->level_coeffs(l)[dir]; }
+float *ref_wavelet_coeff0(void *p) { return static_cast<rtengine::wavelet_decomposition *>(p)->coeff0; }
+void ref_wavelet_reconstruct(void *p, float *dst, float blend) { static_cast<rtengine::wavelet_decomposition *>(p)->reconstruct(dst, blend); }
+void ref_wavelet_delete(void *p) { delete static_cast<rtengine::wavelet_decomposition *>(p); }
 
 void ref_xexpf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xexpf(x[i]); }
 void ref_xlogf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xlogf(x[i]); }
@@ -29,6 +41,8 @@ void ref_pow_F(const float *a, const float *b, float *y, size_t n) { for (size_t
 // 4-lane SSE variants (n must be a multiple of 4)
 void ref_vexpf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, xexpf(_mm_loadu_ps(x + i))); }
 void ref_vlogf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, xlogf(_mm_loadu_ps(x + i))); }
+void ref_vexpf_nocheck(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, xexpfNoCheck(_mm_loadu_ps(x + i))); }
+void ref_vlogf_nocheck(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, xlogfNoCheck(_mm_loadu_ps(x + i))); }
 void ref_vmedian3(const float *a, const float *b, const float *c, float *y, size_t n)
 {
     for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, median(_mm_loadu_ps(a + i), _mm_loadu_ps(b + i), _mm_loadu_ps(c + i)));

@@ -1,0 +1,138 @@
+/*
+ * oracle/sleef.c -- restatement of the sleef-derived fp32 math the hot path uses
+ * (reference: rtengine/sleef.h and rtengine/sleefsseavx.h).
+ *
+ * TEST INFRASTRUCTURE ONLY.  PARITY PINNED: every function here is checked bit-for-bit against
+ * the reference's own headers compiled in place (oracle/_ref, tests/golden/sleef.npz).
+ *
+ * The scalar and the 4-lane SSE forms are DIFFERENT functions in the last bits and both occur
+ * on the path (bulk lanes vs loop tails, e.g. FTblockDN.cc:673-683):
+ *   xexpf  scalar  sleef.h:1247-1265      u = s*(s*u+1)+1 ; ldexpkf: x*(u*u)*(u*u)*2^q'
+ *   xexpf  vector  sleefsseavx.h:1326-1345 u = 1+((s*s)*u+s) ; vldexpf: (((x*u)*u)*u)*u*2^q'
+ *   xlogf  scalar  sleef.h:1198-1221 ; vector sleefsseavx.h:1232-1255 (differ only in ldexp)
+ * mlaf/vmlaf are unfused x*y+z (sleef.h:938, helpersse2.h:157-159): build with -ffp-contract=off.
+ */
+#include "oracle.h"
+#include "oracle_common.h"
+#include <xmmintrin.h>
+
+#define R_LN2f 1.442695040888963407359924681001892137426645954152985934135449406931f
+#define L2Uf 0.693145751953125f
+#define L2Lf 1.428606765330187045e-06f
+
+static inline int32_t f2i(float f) { union { float f; int32_t i; } u; u.f = f; return u.i; }
+static inline float i2f(int32_t i) { union { float f; int32_t i; } u; u.i = i; return u.f; }
+static inline float mla(float x, float y, float z) { return x * y + z; }
+/* _mm_cvt_ss2si / _mm_cvtps_epi32: round to nearest even (sleef.h:903-905) */
+static inline int rint_i(float x) { return _mm_cvt_ss2si(_mm_set_ss(x)); }
+
+static inline int ilogbp1f(float d)
+{
+    int m = d < 5.421010862427522E-20f;
+    d = m ? 1.8446744073709552E19f * d : d;
+    int q = (f2i(d) >> 23) & 0xff;
+    return m ? q - (64 + 0x7e) : q - 0x7e;
+}
+static inline float ldexpk_scalar(float x, int q)
+{
+    int m = q >> 31;
+    m = (((m + q) >> 6) - m) << 4;
+    q = q - (m << 2);
+    float u = i2f((int32_t)(m + 0x7f) << 23);
+    u = u * u;
+    x = x * u * u;
+    u = i2f((int32_t)(q + 0x7f) << 23);
+    return x * u;
+}
+static inline float ldexpk_vector(float x, int q)
+{
+    int m = q >> 31;
+    m = (((m + q) >> 6) - m) << 4;
+    q = q - (m << 2);
+    float u = i2f((int32_t)(m + 0x7f) << 23);
+    x = (((x * u) * u) * u) * u;
+    u = i2f((int32_t)(q + 0x7f) << 23);
+    return x * u;
+}
+
+float oracle_xexpf_s(float d)
+{
+    if (d <= -104.0f) return 0.0f;
+    int q = rint_i(d * R_LN2f);
+    float s = mla((float)q, -L2Uf, d);
+    s = mla((float)q, -L2Lf, s);
+    float u = 0.00136324646882712841033936f;
+    u = mla(u, s, 0.00836596917361021041870117f);
+    u = mla(u, s, 0.0416710823774337768554688f);
+    u = mla(u, s, 0.166665524244308471679688f);
+    u = mla(u, s, 0.499999850988388061523438f);
+    u = mla(s, mla(s, u, 1.f), 1.f);
+    return ldexpk_scalar(u, q);
+}
+
+static inline float xexpf_v_core(float d)
+{
+    int q = rint_i(d * R_LN2f);
+    float s = mla((float)q, -L2Uf, d);
+    s = mla((float)q, -L2Lf, s);
+    float u = 0.00136324646882712841033936f;
+    u = mla(u, s, 0.00836596917361021041870117f);
+    u = mla(u, s, 0.0416710823774337768554688f);
+    u = mla(u, s, 0.166665524244308471679688f);
+    u = mla(u, s, 0.499999850988388061523438f);
+    u = 1.0f + mla(s * s, u, s);
+    return ldexpk_vector(u, q);
+}
+float oracle_xexpf_v(float d)
+{
+    float u = xexpf_v_core(d);
+    return (-104.f > d) ? 0.f : u; /* vselfnotzero(vmaskf_gt(-104, d), u) */
+}
+float oracle_xexpf_v_nocheck(float d) { return xexpf_v_core(d); }
+
+static inline float xlogf_core(float d, int vector)
+{
+    int e = ilogbp1f(d * 0.7071f);
+    float m = vector ? ldexpk_vector(d, -e) : ldexpk_scalar(d, -e);
+    float x = vector ? ((-1.0f + m) / (1.0f + m)) : ((m - 1.0f) / (m + 1.0f));
+    float x2 = x * x;
+    float t = 0.2371599674224853515625f;
+    t = mla(t, x2, 0.285279005765914916992188f);
+    t = mla(t, x2, 0.400005519390106201171875f);
+    t = mla(t, x2, 0.666666567325592041015625f);
+    t = mla(t, x2, 2.0f);
+    return x * t + 0.693147180559945286226764f * (float)e;
+}
+float oracle_xlogf_s(float d)
+{
+    float x = xlogf_core(d, 0);
+    if (d == INFINITY) x = INFINITY;
+    if (d < 0) x = NAN;
+    if (d == 0) x = -INFINITY;
+    return x;
+}
+float oracle_xlogf_v(float d)
+{
+    float x = xlogf_core(d, 1);
+    if (d == INFINITY) x = INFINITY;
+    if (0.f > d) x = NAN;
+    if (d == 0) x = -INFINITY;
+    return x;
+}
+float oracle_xlogf_v_nocheck(float d) { return xlogf_core(d, 1); }
+
+/* opthelper.h:24  pow_F(a,b) = xexpf(b*xlogf(a)) ; sleef.h:1303-1313 */
+float oracle_pow_F(float a, float b) { return oracle_xexpf_s(b * oracle_xlogf_s(a)); }
+float oracle_xlin2log(float x, float base) { return oracle_xlogf_s(x * (base - 1.f) + 1.f) / oracle_xlogf_s(base); }
+float oracle_xlog2lin(float x, float base) { return (oracle_pow_F(base, x) - 1.f) / (base - 1.f); }
+
+#define MAP1(name, fn) void name(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = fn(x[i]); }
+MAP1(oracle_t_xexpf_s, oracle_xexpf_s)
+MAP1(oracle_t_xexpf_v, oracle_xexpf_v)
+MAP1(oracle_t_xexpf_vn, oracle_xexpf_v_nocheck)
+MAP1(oracle_t_xlogf_s, oracle_xlogf_s)
+MAP1(oracle_t_xlogf_v, oracle_xlogf_v)
+MAP1(oracle_t_xlogf_vn, oracle_xlogf_v_nocheck)
+void oracle_t_pow_F(const float *a, const float *b, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = oracle_pow_F(a[i], b[i]); }
+void oracle_t_xlin2log(const float *x, float base, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = oracle_xlin2log(x[i], base); }
+void oracle_t_xlog2lin(const float *x, float base, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = oracle_xlog2lin(x[i], base); }

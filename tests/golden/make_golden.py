@@ -10,10 +10,13 @@ import ctypes as C
 import os
 import subprocess
 
+import sys
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
 subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref"])
 R = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libartref.so"))
 fp = C.POINTER(C.c_float)
@@ -58,7 +61,80 @@ def lutf():
     np.savez_compressed(os.path.join(HERE, "lutf.npz"), table_size=size, index=idx, scalar=ys, vector=yv)
 
 
+def sleef():
+    rng = np.random.default_rng(3)
+    n = 16384
+    # exp arguments: the ranges the path uses (shrinkage: [-40, 0]; gamma LUT: [-12, 0.1]) plus extremes
+    xe = np.concatenate([rng.uniform(-110, 5, n // 2), rng.uniform(-2, 2, n // 4), rng.uniform(-104.5, -103.5, n // 8),
+                         rng.uniform(80, 90, n // 8)]).astype(np.float32)
+    xe[:8] = [0.0, -0.0, -104.0, -103.99999, 88.0, -87.5, 1e-8, -1e-8]
+    xl = np.concatenate([rng.uniform(1e-6, 70000, n // 2), np.exp(rng.uniform(-80, 80, n // 2))]).astype(np.float32)
+    xl[:10] = [1.0, 0.5, 2.0, 65535.0, 0.7071, 1.4142135, 1e-38, 1e-42, 3e38, 10.0]
+    out = {"xe": xe, "xl": xl}
+    for name, fn, src in (("exp_s", R.ref_xexpf, xe), ("exp_v", R.ref_vexpf, xe), ("exp_vn", R.ref_vexpf_nocheck, xe),
+                          ("log_s", R.ref_xlogf, xl), ("log_v", R.ref_vlogf, xl), ("log_vn", R.ref_vlogf_nocheck, xl)):
+        y = np.empty(n, np.float32)
+        fn(P(src), P(y), C.c_size_t(n))
+        out[name] = y
+    a = rng.uniform(0.001, 100.0, n).astype(np.float32)
+    b = rng.uniform(-3.0, 3.0, n).astype(np.float32)
+    y = np.empty(n, np.float32)
+    R.ref_pow_F(P(a), P(b), P(y), C.c_size_t(n))
+    out.update(pow_a=a, pow_b=b, pow_F=y)
+    x01 = rng.uniform(0.0, 1.2, n).astype(np.float32)
+    for base in (10.0, 101.0):
+        y1, y2 = np.empty(n, np.float32), np.empty(n, np.float32)
+        R.ref_xlin2log(P(x01), C.c_float(base), P(y1), C.c_size_t(n))
+        R.ref_xlog2lin(P(x01), C.c_float(base), P(y2), C.c_size_t(n))
+        out[f"lin2log_{int(base)}"] = y1
+        out[f"log2lin_{int(base)}"] = y2
+    out["x01"] = x01
+    np.savez_compressed(os.path.join(HERE, "sleef.npz"), **out)
+
+
+from make_golden_inputs import wavelet_input  # noqa: E402
+
+
+def wavelet():
+    import hashlib
+    R.ref_wavelet_new.restype = C.c_void_p
+    R.ref_wavelet_band.restype = fp
+    R.ref_wavelet_coeff0.restype = fp
+    out = {}
+    for (w, h, lv, full) in ((129, 97, 5, True), (258, 196, 6, False), (321, 255, 5, False)):
+        src = wavelet_input(w, h, w + h)
+        d = C.c_void_p(R.ref_wavelet_new(P(src), w, h, lv))
+        assert R.ref_wavelet_maxlevel(d) == lv
+        w2, h2 = R.ref_wavelet_W(d, 0), R.ref_wavelet_H(d, 0)
+        bands = np.empty((lv, 3, h2, w2), np.float32)
+        for l in range(lv):
+            assert (R.ref_wavelet_W(d, l), R.ref_wavelet_H(d, l)) == (w2, h2)
+            for k in range(3):
+                bands[l, k] = np.ctypeslib.as_array(R.ref_wavelet_band(d, l, k + 1), shape=(h2, w2))
+        c0 = np.ctypeslib.as_array(R.ref_wavelet_coeff0(d), shape=(h2, w2)).copy()
+        strides = [R.ref_wavelet_stride(d, l) for l in range(lv)]
+        # perturb the coefficients like a shrinkage would, then reconstruct
+        for l in range(lv):
+            for k in range(3):
+                b = np.ctypeslib.as_array(R.ref_wavelet_band(d, l, k + 1), shape=(h2, w2))
+                b *= np.float32(0.5 + 0.1 * (l + k))
+        rec = np.full((h, w), 7.0, np.float32)
+        R.ref_wavelet_reconstruct(d, P(rec), C.c_float(1.0))
+        R.ref_wavelet_delete(d)
+        key = f"{w}x{h}x{lv}"
+        out[key + "_strides"] = np.array(strides)
+        if full:
+            out[key + "_bands"] = bands
+            out[key + "_coeff0"] = c0
+            out[key + "_recon"] = rec
+        else:
+            out[key + "_sha"] = np.frombuffer(hashlib.sha256(bands.tobytes() + c0.tobytes() + rec.tobytes()).digest(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "wavelet.npz"), **out)
+
+
 if __name__ == "__main__":
+    wavelet()
     helpers()
     lutf()
+    sleef()
     print("golden vectors written to", HERE)

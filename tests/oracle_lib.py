@@ -119,3 +119,38 @@ def lutf(table, x):
     L = lib()
     L.oracle_lutf.restype = C.c_float
     return np.array([L.oracle_lutf(_ptr(table), len(table), C.c_float(float(v))) for v in x], dtype=np.float32)
+
+
+class _OW(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("w2", C.c_int), ("h2", C.c_int), ("nlevels", C.c_int),
+                ("band", (_fp * 4) * 10), ("coeff0", _fp)]
+
+
+def wavelet_decompose(src, maxlvl):
+    """Returns (bands[l,3,h2,w2] view-copies, coeff0, handle). handle must be freed/reconstructed."""
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    h, w = src.shape
+    L = lib()
+    L.oracle_wavelet_decompose.restype = C.POINTER(_OW)
+    d = L.oracle_wavelet_decompose(_ptr(src), w, h, maxlvl)
+    return d
+
+
+def wavelet_bands(d):
+    o = d.contents
+    bands = np.empty((o.nlevels, 3, o.h2, o.w2), np.float32)
+    views = []
+    for l in range(o.nlevels):
+        for k in range(3):
+            v = np.ctypeslib.as_array(o.band[l][k + 1], shape=(o.h2, o.w2))
+            bands[l, k] = v
+            views.append(v)
+    c0 = np.ctypeslib.as_array(o.coeff0, shape=(o.h2, o.w2)).copy()
+    return bands, c0, views
+
+
+def wavelet_reconstruct(d, h, w, blend=1.0, fill=7.0):
+    rec = np.full((h, w), fill, np.float32)
+    lib().oracle_wavelet_reconstruct(d, _ptr(rec), C.c_float(blend))
+    lib().oracle_wavelet_free(d)
+    return rec

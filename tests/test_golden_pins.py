@@ -44,3 +44,55 @@ def test_lutf_scalar_matches_reference_lut_h():
     table = (np.sqrt(x) * 65535.0).astype(np.float32)
     got = O.lutf(table, g["index"])
     assert same_bits(got, g["scalar"])
+
+
+def test_sleef_scalar_and_vector_forms_match_reference():
+    g = np.load(os.path.join(G, "sleef.npz"))
+    L = O.lib()
+    n = len(g["xe"])
+    for name, fn, src in (("exp_s", L.oracle_t_xexpf_s, g["xe"]), ("exp_v", L.oracle_t_xexpf_v, g["xe"]),
+                          ("exp_vn", L.oracle_t_xexpf_vn, g["xe"]), ("log_s", L.oracle_t_xlogf_s, g["xl"]),
+                          ("log_v", L.oracle_t_xlogf_v, g["xl"]), ("log_vn", L.oracle_t_xlogf_vn, g["xl"])):
+        y = np.empty(n, np.float32)
+        src = np.ascontiguousarray(src)
+        fn(P(src), P(y), C.c_size_t(n))
+        assert same_bits(y, g[name]), name
+    # the scalar and vector exp really are different functions (guards against collapsing them)
+    assert not np.array_equal(g["exp_s"].view(np.uint32), g["exp_v"].view(np.uint32))
+    y = np.empty(n, np.float32)
+    a, b = np.ascontiguousarray(g["pow_a"]), np.ascontiguousarray(g["pow_b"])
+    L.oracle_t_pow_F(P(a), P(b), P(y), C.c_size_t(n))
+    assert same_bits(y, g["pow_F"])
+    x01 = np.ascontiguousarray(g["x01"])
+    for base in (10, 101):
+        L.oracle_t_xlin2log(P(x01), C.c_float(base), P(y), C.c_size_t(n))
+        assert same_bits(y, g[f"lin2log_{base}"])
+        L.oracle_t_xlog2lin(P(x01), C.c_float(base), P(y), C.c_size_t(n))
+        assert same_bits(y, g[f"log2lin_{base}"])
+
+
+def test_wavelet_matches_reference_decomposition():
+    import hashlib
+    import sys
+    sys.path.insert(0, G)
+    from make_golden_inputs import wavelet_input
+    g = np.load(os.path.join(G, "wavelet.npz"))
+    for (w, h, lv, full) in ((129, 97, 5, True), (258, 196, 6, False), (321, 255, 5, False)):
+        key = f"{w}x{h}x{lv}"
+        src = wavelet_input(w, h, w + h)
+        d = O.wavelet_decompose(src, lv)
+        bands, c0, views = O.wavelet_bands(d)
+        assert [O.lib().oracle_wavelet_skip(l) for l in range(lv)] == list(g[key + "_strides"])
+        i = 0
+        for l in range(lv):
+            for k in range(3):
+                views[i] *= np.float32(0.5 + 0.1 * (l + k))
+                i += 1
+        rec = O.wavelet_reconstruct(d, h, w)
+        if full:
+            assert same_bits(bands, g[key + "_bands"])
+            assert same_bits(c0, g[key + "_coeff0"])
+            assert same_bits(rec, g[key + "_recon"])
+        else:
+            sha = np.frombuffer(hashlib.sha256(bands.tobytes() + c0.tobytes() + rec.tobytes()).digest(), dtype=np.uint8)
+            assert np.array_equal(sha, g[key + "_sha"])
