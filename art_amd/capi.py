@@ -53,6 +53,12 @@ def _load():
     lib.artgpu_scratch_bytes.restype = C.c_size_t
     lib.artgpu_demosaic_bayer.argtypes = [C.c_void_p, C.c_int, C.POINTER(Plane), C.c_uint32, C.c_double, C.c_int, C.POINTER(RGB)]
     lib.artgpu_border_interpolate2.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_uint32, C.c_int, C.POINTER(RGB)]
+    lib.artgpu_wavelet_decompose.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_int, C.POINTER(C.c_void_p)]
+    lib.artgpu_wavelet_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.artgpu_wavelet_get_band.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    lib.artgpu_wavelet_set_band.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    lib.artgpu_wavelet_reconstruct.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Plane), C.c_float]
+    lib.artgpu_wavelet_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.artgpu_get_image.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int,
                                      C.POINTER(C.c_double), C.POINTER(RGB)]
     lib.artgpu_convert_color_space.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double)]
@@ -66,7 +72,9 @@ LIB = _load()
 EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
            "artgpu_synchronize", "artgpu_enable_timing", "artgpu_get_timings", "artgpu_scratch_bytes",
            "artgpu_demosaic_bayer", "artgpu_border_interpolate2", "artgpu_get_image",
-           "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve"]
+           "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
+           "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
+           "artgpu_wavelet_reconstruct", "artgpu_wavelet_free"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -141,6 +149,33 @@ class Context:
             assert lut.shape == (65536,)
             lp = lut.ctypes.data_as(C.POINTER(C.c_float))
         self._chk(LIB.artgpu_tone_curve(self._h, C.byref(image), mode, lp, whitept, int(filmlike_clip)))
+
+    # ---- wavelet_decomposition ----
+    def wavelet_decompose(self, src: Plane, maxlvl: int):
+        h = C.c_void_p()
+        self._chk(LIB.artgpu_wavelet_decompose(self._h, C.byref(src), maxlvl, C.byref(h)))
+        return h
+
+    def wavelet_info(self, wv):
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(LIB.artgpu_wavelet_info(wv, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def wavelet_get_band(self, wv, level: int, direction: int) -> np.ndarray:
+        w2, h2, _ = self.wavelet_info(wv)
+        out = np.empty((h2, w2), np.float32)
+        self._chk(LIB.artgpu_wavelet_get_band(self._h, wv, level, direction, out.ctypes.data, 0))
+        return out
+
+    def wavelet_set_band(self, wv, level: int, direction: int, data: np.ndarray):
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        self._chk(LIB.artgpu_wavelet_set_band(self._h, wv, level, direction, data.ctypes.data, 0))
+
+    def wavelet_reconstruct(self, wv, dst: Plane, blend: float = 1.0):
+        self._chk(LIB.artgpu_wavelet_reconstruct(self._h, wv, C.byref(dst), blend))
+
+    def wavelet_free(self, wv):
+        LIB.artgpu_wavelet_free(self._h, wv)
 
     # convenience for tests: host numpy in, host numpy out (staged through the library)
     def demosaic_bayer_host(self, method: int, raw: np.ndarray, filters: int, initial_gain: float = 1.0, border: int = 4):

@@ -437,4 +437,152 @@ int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float 
     return unbind_rgb(ctx, image, &d);
 }
 
+// ---------------------------------------------------------------------------------------------
+// wavelet_decomposition
+// ---------------------------------------------------------------------------------------------
+} // extern "C"
+
+struct artgpu_wavelet {
+    int w = 0, h = 0, w2 = 0, h2 = 0, nlevels = 0;
+    float *bands = nullptr;   // nlevels * 3 * n floats
+    float *lowpass[2] = {nullptr, nullptr};
+    int cur = 0;              // lowpass[cur] is coeff0
+    size_t n = 0;
+    float *band(int l, int dir) const { return bands + ((size_t)l * 3 + (dir - 1)) * n; }
+};
+
+namespace {
+int wavelet_skip(int level) { return level <= 1 ? 1 : 1 << (level - 1); }
+}
+
+extern "C" {
+
+int artgpu_wavelet_decompose(artgpu_ctx *ctx, const artgpu_plane *src, int maxlvl, artgpu_wavelet **out)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!plane_ok(src) || !out || maxlvl < 1 || maxlvl > 9) return fail(ctx, ARTGPU_EINVAL, "wavelet_decompose: bad arguments");
+    *out = nullptr;
+    const int w = src->w, h = src->h, w2 = (w + 1) / 2, h2 = (h + 1) / 2;
+    if ((w2 < h2 ? w2 : h2) < 2 * wavelet_skip(maxlvl - 1) || w < 8 || h < 8)
+        return fail(ctx, ARTGPU_EUNSUPPORTED, "wavelet_decompose: %dx%d too small for %d levels", w, h, maxlvl);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const float *dsrc = src->p;
+    size_t sstride = (size_t)(src->row_stride_bytes / 4);
+    if (!src->on_device) {
+        int rc = ensure(ctx, &ctx->stage[0], &ctx->stage_bytes[0], (size_t)w * h * 4);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage[0], (size_t)w * 4, src->p, (size_t)src->row_stride_bytes, (size_t)w * 4, h, hipMemcpyHostToDevice, ctx->stream));
+        dsrc = ctx->stage[0];
+        sstride = w;
+    }
+    artgpu_wavelet *wv = new (std::nothrow) artgpu_wavelet;
+    if (!wv) return fail(ctx, ARTGPU_ENOMEM, "wavelet_decompose: out of host memory");
+    wv->w = w; wv->h = h; wv->w2 = w2; wv->h2 = h2; wv->nlevels = maxlvl; wv->n = (size_t)w2 * h2;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&wv->bands), (size_t)maxlvl * 3 * wv->n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&wv->lowpass[0]), wv->n * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&wv->lowpass[1]), wv->n * sizeof(float));
+    if (e != hipSuccess) {
+        artgpu_wavelet_free(ctx, wv);
+        return fail(ctx, ARTGPU_ENOMEM, "wavelet_decompose: hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    WaveArgs a = {};
+    a.w = w; a.h = h; a.w2 = w2; a.h2 = h2;
+    for (int l = 0; l < maxlvl; ++l) {
+        a.b1 = wv->band(l, 1); a.b2 = wv->band(l, 2); a.b3 = wv->band(l, 3);
+        hipError_t le;
+        if (l == 0) {
+            a.src = dsrc; a.src_stride = sstride; a.lo = wv->lowpass[0];
+            wv->cur = 0;
+            le = launch_wavelet_analysis0(a, ctx->stream);
+        } else {
+            a.src = wv->lowpass[wv->cur]; a.lo = wv->lowpass[wv->cur ^ 1]; a.skip = wavelet_skip(l);
+            le = launch_wavelet_haar_analysis(a, ctx->stream);
+            wv->cur ^= 1;
+        }
+        if (le != hipSuccess) {
+            artgpu_wavelet_free(ctx, wv);
+            return fail(ctx, ARTGPU_EHIP, "wavelet_decompose: launch failed: %s", hipGetErrorString(le));
+        }
+    }
+    if (!src->on_device) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = wv;
+    return ARTGPU_OK;
+}
+
+int artgpu_wavelet_info(const artgpu_wavelet *wv, int32_t *w2, int32_t *h2, int32_t *nlevels)
+{
+    if (!wv) return ARTGPU_EINVAL;
+    if (w2) *w2 = wv->w2;
+    if (h2) *h2 = wv->h2;
+    if (nlevels) *nlevels = wv->nlevels;
+    return ARTGPU_OK;
+}
+
+int artgpu_wavelet_get_band(artgpu_ctx *ctx, const artgpu_wavelet *wv, int level, int dir, float *dst, int on_device)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!wv || !dst || dir < 0 || dir > 3 || (dir > 0 && (level < 0 || level >= wv->nlevels))) return fail(ctx, ARTGPU_EINVAL, "wavelet_get_band: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const float *p = dir == 0 ? wv->lowpass[wv->cur] : wv->band(level, dir);
+    HIPCHK(ctx, hipMemcpyAsync(dst, p, wv->n * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    if (!on_device) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
+int artgpu_wavelet_set_band(artgpu_ctx *ctx, artgpu_wavelet *wv, int level, int dir, const float *src, int on_device)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!wv || !src || dir < 0 || dir > 3 || (dir > 0 && (level < 0 || level >= wv->nlevels))) return fail(ctx, ARTGPU_EINVAL, "wavelet_set_band: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    float *p = dir == 0 ? wv->lowpass[wv->cur] : wv->band(level, dir);
+    HIPCHK(ctx, hipMemcpyAsync(p, src, wv->n * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    if (!on_device) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
+int artgpu_wavelet_reconstruct(artgpu_ctx *ctx, artgpu_wavelet *wv, artgpu_plane *dst, float blend)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!wv || !plane_ok(dst) || dst->w != wv->w || dst->h != wv->h) return fail(ctx, ARTGPU_EINVAL, "wavelet_reconstruct: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    float *ddst = dst->p;
+    size_t dstride = (size_t)(dst->row_stride_bytes / 4);
+    if (!dst->on_device) {
+        int rc = ensure(ctx, &ctx->stage[0], &ctx->stage_bytes[0], (size_t)wv->w * wv->h * 4);
+        if (rc) return rc;
+        // dst participates in the blend (dst*(1-blend) + blend*4*tot): bring the host contents over
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->stage[0], (size_t)wv->w * 4, dst->p, (size_t)dst->row_stride_bytes, (size_t)wv->w * 4, wv->h, hipMemcpyHostToDevice, ctx->stream));
+        ddst = ctx->stage[0];
+        dstride = wv->w;
+    }
+    WaveArgs a = {};
+    a.w = wv->w; a.h = wv->h; a.w2 = wv->w2; a.h2 = wv->h2; a.blend = blend;
+    for (int l = wv->nlevels - 1; l > 0; --l) {
+        a.src = wv->lowpass[wv->cur]; a.lo = wv->lowpass[wv->cur ^ 1];
+        a.b1 = wv->band(l, 1); a.b2 = wv->band(l, 2); a.b3 = wv->band(l, 3); a.skip = wavelet_skip(l);
+        HIPCHK(ctx, launch_wavelet_haar_synthesis(a, ctx->stream));
+        wv->cur ^= 1;
+    }
+    a.src = wv->lowpass[wv->cur];
+    a.b1 = wv->band(0, 1); a.b2 = wv->band(0, 2); a.b3 = wv->band(0, 3);
+    a.dst = ddst; a.dst_stride = dstride;
+    HIPCHK(ctx, launch_wavelet_synthesis0(a, ctx->stream));
+    if (!dst->on_device) {
+        HIPCHK(ctx, hipMemcpy2DAsync(dst->p, (size_t)dst->row_stride_bytes, ddst, (size_t)wv->w * 4, (size_t)wv->w * 4, wv->h, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ARTGPU_OK;
+}
+
+int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
+{
+    if (!wv) return ARTGPU_EINVAL;
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+    if (wv->bands) (void)hipFree(wv->bands);
+    if (wv->lowpass[0]) (void)hipFree(wv->lowpass[0]);
+    if (wv->lowpass[1]) (void)hipFree(wv->lowpass[1]);
+    delete wv;
+    return ARTGPU_OK;
+}
+
 } // extern "C"

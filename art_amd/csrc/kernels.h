@@ -79,4 +79,21 @@ hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s);
 hipError_t launch_exposure(const PixArgs &a, hipStream_t s);
 hipError_t launch_tone_std(const PixArgs &a, hipStream_t s);
 
+// ---- wavelet_decomposition (wavelet.hip) ----
+struct WaveArgs {
+    const float *src;      // analysis: input plane / previous low-pass; synthesis: low-pass in
+    size_t src_stride;     // floats (level-0 analysis input only)
+    float *lo;             // analysis: low-pass out; Haar synthesis: low-pass out (ping-pong)
+    float *b1, *b2, *b3;   // detail subbands (w2*h2, contiguous rows)
+    float *dst;            // level-0 synthesis destination plane
+    size_t dst_stride;
+    int w, h, w2, h2;
+    int skip;
+    float blend;
+};
+hipError_t launch_wavelet_analysis0(const WaveArgs &a, hipStream_t s);
+hipError_t launch_wavelet_haar_analysis(const WaveArgs &a, hipStream_t s);
+hipError_t launch_wavelet_haar_synthesis(const WaveArgs &a, hipStream_t s);
+hipError_t launch_wavelet_synthesis0(const WaveArgs &a, hipStream_t s);
+
 } // namespace artgpu

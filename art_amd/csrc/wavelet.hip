@@ -1,0 +1,187 @@
+// art_amd/csrc/wavelet.hip -- rtengine::wavelet_decomposition for subsampling == 1 on gfx950
+// (reference: rtengine/cplx_wavelet_dec.h:97-270, cplx_wavelet_level.h:206-744).
+//
+//   level 0      decimated Daub4 (6 taps incl. two zero taps, offset 2): vertical then horizontal,
+//                fused in one kernel: the vertically filtered rows (the reference's tmpLo/tmpHi)
+//                live in LDS, the input is read ~1.2x, the four half-size subbands written once.
+//   levels >= 1  undecimated Haar, skip = 2^(level-1): 4 taps per output, one lane per pixel.
+//   synthesis    mirrors: Haar levels fused (H then V) through a ping-pong low-pass buffer,
+//                level 0 fused with the horizontally synthesised rows in LDS, x4 and blend.
+// All tap sums keep the reference's accumulation order (zero taps included) -> bit-exact.
+// HBM-bound: analysis0 4 B/px in + 4 B/px out; Haar level 4 B/px(sub) in + 16 B out.
+#include <hip/hip_runtime.h>
+#include "devmath.h"
+#include "kernels.h"
+
+namespace artgpu {
+
+namespace {
+__constant__ float DAUB_LO[6] = {0.f, 0.f, 0.34150635f, 0.59150635f, 0.15849365f, -0.091506351f};
+__constant__ float DAUB_HI[6] = {-0.091506351f, -0.15849365f, 0.59150635f, -0.34150635f, 0.f, 0.f};
+// synthesis filters = reversed analysis filters (cplx_wavelet_dec.h:113-115)
+__constant__ float SYN_LO[6] = {-0.091506351f, 0.15849365f, 0.59150635f, 0.34150635f, 0.f, 0.f};
+__constant__ float SYN_HI[6] = {0.f, 0.f, -0.34150635f, 0.59150635f, -0.15849365f, -0.091506351f};
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+constexpr int A0_TW = 64, A0_TH = 16;          // output tile of the level-0 analysis
+constexpr int A0_LW = 2 * A0_TW + 6;           // tmp columns kept in LDS
+constexpr int S0_TW = 128, S0_TH = 32;         // output tile of the level-0 synthesis
+constexpr int S0_LH = S0_TH / 2 + 4;           // horizontally synthesised rows kept in LDS
+} // namespace
+
+// ---- level 0 analysis: src (w x h) -> lo, b1, b2, b3 (w2 x h2) ----
+__global__ void __launch_bounds__(256) wavelet_analysis0_kernel(WaveArgs a)
+{
+    __shared__ float tLo[A0_TH][A0_LW], tHi[A0_TH][A0_LW];
+    const int w = a.w, h = a.h, w2 = a.w2;
+    const int c0 = blockIdx.x * A0_TW, r0 = blockIdx.y * A0_TH; // output coords
+    const int icol0 = 2 * c0 - 3;                                // first tmp column held
+    for (int t = threadIdx.x; t < A0_TH * A0_LW; t += 256) {
+        const int rr = t / A0_LW, cc = t - rr * A0_LW;
+        const int orow = r0 + rr;
+        if (orow >= a.h2) continue;
+        const int row = 2 * orow;
+        const int k = clampi(icol0 + cc, 0, w - 1);
+        float l = 0.f, hh = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float s = a.src[(size_t)clampi(row + (2 - j), 0, h - 1) * a.src_stride + k];
+            l += DAUB_LO[j] * s;
+            hh += DAUB_HI[j] * s;
+        }
+        tLo[rr][cc] = l;
+        tHi[rr][cc] = hh;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < A0_TH * A0_TW; t += 256) {
+        const int rr = t / A0_TW, cc = t - rr * A0_TW;
+        const int orow = r0 + rr, ocol = c0 + cc;
+        if (orow >= a.h2 || ocol >= w2) continue;
+        const int i = 2 * ocol;
+        float l0 = 0.f, h0 = 0.f, l1 = 0.f, h1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            // clamped column i+2-j, expressed in LDS coordinates (LDS column x holds clamp(icol0+x))
+            const int x = clampi(i + (2 - j), 0, w - 1) - icol0;
+            const float sl = tLo[rr][x], sh = tHi[rr][x];
+            l0 += DAUB_LO[j] * sl; h0 += DAUB_HI[j] * sl;
+            l1 += DAUB_LO[j] * sh; h1 += DAUB_HI[j] * sh;
+        }
+        const size_t o = (size_t)orow * w2 + ocol;
+        a.lo[o] = l0; a.b1[o] = h0; a.b2[o] = l1; a.b3[o] = h1;
+    }
+}
+
+// ---- levels >= 1 analysis: undecimated Haar (cplx_wavelet_level.h:206-238) ----
+__global__ void __launch_bounds__(256) wavelet_haar_analysis_kernel(WaveArgs a)
+{
+    const int w = a.w2, h = a.h2, skip = a.skip;
+    const long long n = (long long)w * h;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(t / w), i = (int)(t - (long long)row * w);
+        const int rp = row < h - skip ? row + skip : row - skip;
+        const int ip = i < w - skip ? i + skip : i - skip;
+        const float s00 = a.src[(size_t)row * w + i], s01 = a.src[(size_t)row * w + ip];
+        const float s10 = a.src[(size_t)rp * w + i], s11 = a.src[(size_t)rp * w + ip];
+        const float tl0 = 0.25f * (s00 + s10), tl1 = 0.25f * (s01 + s11);
+        const float th0 = 0.25f * (s00 - s10), th1 = 0.25f * (s01 - s11);
+        a.lo[t] = tl0 + tl1; a.b1[t] = tl0 - tl1;
+        a.b2[t] = th0 + th1; a.b3[t] = th0 - th1;
+    }
+}
+
+// ---- levels >= 1 synthesis, fused H then V (cplx_wavelet_level.h:243-298) ----
+__device__ __forceinline__ float haar_syn(float lo, float hi, float lop, float hip, bool first)
+{
+    return first ? (lo + hi) : 0.5f * (lo + hi + lop - hip);
+}
+__global__ void __launch_bounds__(256) wavelet_haar_synthesis_kernel(WaveArgs a)
+{
+    const int w = a.w2, h = a.h2, skip = a.skip;
+    const long long n = (long long)w * h;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(t / w), j = (int)(t - (long long)row * w);
+        const bool fj = j < skip, fr = row < skip;
+        const int jp = fj ? j : j - skip, rp = fr ? row : row - skip;
+        const size_t o00 = (size_t)row * w + j, o01 = (size_t)row * w + jp, o10 = (size_t)rp * w + j, o11 = (size_t)rp * w + jp;
+        // tmpLo = synthH(src, b1), tmpHi = synthH(b2, b3) at (row, j) and (row-skip, j)
+        const float tLo0 = haar_syn(a.src[o00], a.b1[o00], a.src[o01], a.b1[o01], fj);
+        const float tHi0 = haar_syn(a.b2[o00], a.b3[o00], a.b2[o01], a.b3[o01], fj);
+        float r;
+        if (fr) {
+            r = tLo0 + tHi0;
+        } else {
+            const float tLo1 = haar_syn(a.src[o10], a.b1[o10], a.src[o11], a.b1[o11], fj);
+            const float tHi1 = haar_syn(a.b2[o10], a.b3[o10], a.b2[o11], a.b3[o11], fj);
+            r = 0.5f * (tLo0 + tHi0 + tLo1 - tHi1);
+        }
+        a.lo[t] = r;
+    }
+}
+
+// ---- level 0 synthesis (cplx_wavelet_level.h:449-584): H (w2 -> w) into LDS, V (h2 -> h), x4, blend ----
+__global__ void __launch_bounds__(256) wavelet_synthesis0_kernel(WaveArgs a)
+{
+    __shared__ float tLo[S0_LH][S0_TW], tHi[S0_LH][S0_TW];
+    const int w = a.w, h = a.h, w2 = a.w2, h2 = a.h2;
+    const int c0 = blockIdx.x * S0_TW, r0 = blockIdx.y * S0_TH;
+    constexpr int shift = 3; // taps - offset - 1
+    const int srow0 = (r0 + shift) / 2 - 2; // first (unclamped) source row held in LDS
+    for (int t = threadIdx.x; t < S0_LH * S0_TW; t += 256) {
+        const int rr = t / S0_TW, cc = t - rr * S0_TW;
+        const int i = c0 + cc;
+        if (i >= w) continue;
+        const int k = clampi(srow0 + rr, 0, h2 - 1);
+        const int i_src = (i + shift) / 2, begin = (i + shift) % 2;
+        float totLo = 0.f, totHi = 0.f;
+        for (int j = begin, l = 0; j < 6; j += 2, l += 1) {
+            const size_t arg = (size_t)k * w2 + clampi(i_src - l, 0, w2 - 1);
+            totLo += (SYN_LO[j] * a.src[arg] + SYN_HI[j] * a.b1[arg]);
+            totHi += (SYN_LO[j] * a.b2[arg] + SYN_HI[j] * a.b3[arg]);
+        }
+        tLo[rr][cc] = totLo;
+        tHi[rr][cc] = totHi;
+    }
+    __syncthreads();
+    const float srcFactor = 1.f - a.blend;
+    for (int t = threadIdx.x; t < S0_TH * S0_TW; t += 256) {
+        const int rr = t / S0_TW, cc = t - rr * S0_TW;
+        const int i = r0 + rr, k = c0 + cc;
+        if (i >= h || k >= w) continue;
+        const int i_src = (i + shift) / 2, begin = (i + shift) % 2;
+        float tot = 0.f;
+        for (int j = begin, l = 0; j < 6; j += 2, l += 1) {
+            // LDS row rr holds source row clamp(srow0 + rr); the clamped row R sits at R - srow0 (0..18)
+            const int lr = clampi(i_src - l, 0, h2 - 1) - srow0;
+            tot += (SYN_LO[j] * tLo[lr][cc] + SYN_HI[j] * tHi[lr][cc]);
+        }
+        const size_t o = (size_t)i * a.dst_stride + k;
+        a.dst[o] = a.dst[o] * srcFactor + a.blend * 4.f * tot;
+    }
+}
+
+hipError_t launch_wavelet_analysis0(const WaveArgs &a, hipStream_t s)
+{
+    dim3 grid((a.w2 + A0_TW - 1) / A0_TW, (a.h2 + A0_TH - 1) / A0_TH);
+    hipLaunchKernelGGL(wavelet_analysis0_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+static int flat_grid(long long n) { long long g = (n + 255) / 256; return (int)(g < 16384 ? g : 16384); }
+hipError_t launch_wavelet_haar_analysis(const WaveArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(wavelet_haar_analysis_kernel, dim3(flat_grid((long long)a.w2 * a.h2)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_wavelet_haar_synthesis(const WaveArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(wavelet_haar_synthesis_kernel, dim3(flat_grid((long long)a.w2 * a.h2)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_wavelet_synthesis0(const WaveArgs &a, hipStream_t s)
+{
+    dim3 grid((a.w + S0_TW - 1) / S0_TW, (a.h + S0_TH - 1) / S0_TH);
+    hipLaunchKernelGGL(wavelet_synthesis0_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace artgpu

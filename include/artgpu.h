@@ -125,6 +125,23 @@ int artgpu_exposure(artgpu_ctx *ctx, artgpu_rgb *image, float exp_scale, float b
 int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float *lut65536,
                       float whitept, int filmlike_clip);
 
+/* rtengine::wavelet_decomposition with subsampling == 1 and the 6-tap Daub4 filters, the only
+ * configuration the denoise path uses (rtengine/cplx_wavelet_dec.h:97-270; constructed at
+ * rtengine/FTblockDN.cc:2296,2328,2365).  The object owns its coefficients in HBM.
+ *   decompose   == the constructor (level 0 decimated Daub4, levels >= 1 undecimated Haar)
+ *   band access == level_coeffs(level)[dir], dir 1..3; dir 0 = coeff0 (final low-pass)
+ *   reconstruct == reconstruct(dst, blend); like the reference it consumes the object's
+ *                  coefficients (the low-pass is overwritten level by level).
+ * Requires min(w2,h2) >= 2^maxlvl (no Haar level wider than half the plane). */
+typedef struct artgpu_wavelet artgpu_wavelet;
+int artgpu_wavelet_decompose(artgpu_ctx *ctx, const artgpu_plane *src, int maxlvl, artgpu_wavelet **out);
+int artgpu_wavelet_info(const artgpu_wavelet *wv, int32_t *w2, int32_t *h2, int32_t *nlevels);
+/* copy one subband out of / into the object; `host_or_device` follows `on_device` */
+int artgpu_wavelet_get_band(artgpu_ctx *ctx, const artgpu_wavelet *wv, int level, int dir, float *dst, int on_device);
+int artgpu_wavelet_set_band(artgpu_ctx *ctx, artgpu_wavelet *wv, int level, int dir, const float *src, int on_device);
+int artgpu_wavelet_reconstruct(artgpu_ctx *ctx, artgpu_wavelet *wv, artgpu_plane *dst, float blend);
+int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv);
+
 /* Bytes of device scratch the context currently holds (arena + staging). */
 size_t artgpu_scratch_bytes(const artgpu_ctx *ctx);
 
