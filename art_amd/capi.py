@@ -31,6 +31,15 @@ class Timings(C.Structure):
     _fields_ = [("demosaic_ms", C.c_float), ("border_ms", C.c_float), ("total_ms", C.c_float)]
 
 
+class DenoiseParams(C.Structure):
+    _fields_ = [("luminance", C.c_double), ("luminance_detail", C.c_double), ("luminance_detail_threshold", C.c_int32),
+                ("chrominance", C.c_double), ("chrominance_red_green", C.c_double), ("chrominance_blue_yellow", C.c_double),
+                ("gamma", C.c_double), ("aggressive", C.c_int32), ("color_space", C.c_int32), ("chrominance_method", C.c_int32)]
+
+
+DN_SKIP_DETAIL_RECOVERY = 1
+
+
 class ArtGpuError(RuntimeError):
     pass
 
@@ -59,6 +68,8 @@ def _load():
     lib.artgpu_wavelet_set_band.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     lib.artgpu_wavelet_reconstruct.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Plane), C.c_float]
     lib.artgpu_wavelet_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.artgpu_rgb_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseParams), C.POINTER(C.c_float), C.c_double,
+                                       C.c_double, C.POINTER(Plane), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_get_image.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int,
                                      C.POINTER(C.c_double), C.POINTER(RGB)]
     lib.artgpu_convert_color_space.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double)]
@@ -74,7 +85,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_demosaic_bayer", "artgpu_border_interpolate2", "artgpu_get_image",
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
-           "artgpu_wavelet_reconstruct", "artgpu_wavelet_free"]
+           "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -149,6 +160,12 @@ class Context:
             assert lut.shape == (65536,)
             lp = lut.ctypes.data_as(C.POINTER(C.c_float))
         self._chk(LIB.artgpu_tone_curve(self._h, C.byref(image), mode, lp, whitept, int(filmlike_clip)))
+
+    def rgb_denoise(self, image: RGB, params: DenoiseParams, ws, expcomp: float = 0.0, scale: float = 1.0,
+                    ccalc: Plane = None, flags: int = DN_SKIP_DETAIL_RECOVERY):
+        wsf = (C.c_float * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float32).reshape(9)])
+        self._chk(LIB.artgpu_rgb_denoise(self._h, C.byref(image), C.byref(params), wsf, expcomp, scale,
+                                         None if ccalc is None else C.byref(ccalc), flags, None, None))
 
     # ---- wavelet_decomposition ----
     def wavelet_decompose(self, src: Plane, maxlvl: int):

@@ -2,6 +2,7 @@
 // device buffers, staging for host-pointer calls, kernel launches, error reporting.
 // There is no CPU fallback here: every entry point either runs the HIP kernels or fails.
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstdio>
 #include <cstdarg>
 #include <cstring>
@@ -24,6 +25,10 @@ struct artgpu_ctx {
     static constexpr int NSTAGE = 8;
     float *stage[NSTAGE] = {};
     size_t stage_bytes[NSTAGE] = {};
+    // grow-only scratch pool for the denoise path (planes, decompositions, shrink buffers)
+    static constexpr int NPOOL = 16;
+    float *pool[NPOOL] = {};
+    size_t pool_bytes[NPOOL] = {};
     float *lut = nullptr; // 65536-entry tone LUT on the device
     size_t lut_bytes = 0;
     // timing
@@ -221,6 +226,8 @@ int artgpu_destroy(artgpu_ctx *ctx)
     for (int k = 0; k < artgpu_ctx::NSTAGE; ++k)
         if (ctx->stage[k]) (void)hipFree(ctx->stage[k]);
     if (ctx->lut) (void)hipFree(ctx->lut);
+    for (int k = 0; k < artgpu_ctx::NPOOL; ++k)
+        if (ctx->pool[k]) (void)hipFree(ctx->pool[k]);
     for (int k = 0; k < 3; ++k)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     delete ctx;
@@ -264,6 +271,7 @@ size_t artgpu_scratch_bytes(const artgpu_ctx *ctx)
     size_t s = ctx->arena_bytes;
     for (int k = 0; k < artgpu_ctx::NSTAGE; ++k) s += ctx->stage_bytes[k];
     s += ctx->lut_bytes;
+    for (int k = 0; k < artgpu_ctx::NPOOL; ++k) s += ctx->pool_bytes[k];
     return s;
 }
 
@@ -583,6 +591,205 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
     if (wv->lowpass[1]) (void)hipFree(wv->lowpass[1]);
     delete wv;
     return ARTGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RGB_denoise (wavelet part)
+// ---------------------------------------------------------------------------------------------
+} // extern "C"
+
+namespace {
+
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC };
+
+struct DevDecomp {
+    float *bands, *low[2];
+    int cur, nlevels, w, h, w2, h2;
+    size_t n;
+    float *band(int l, int dir) const { return bands + ((size_t)l * 3 + (dir - 1)) * n; }
+};
+
+int decompose_dev(artgpu_ctx *ctx, DevDecomp &d, const float *src)
+{
+    WaveArgs a = {};
+    a.w = d.w; a.h = d.h; a.w2 = d.w2; a.h2 = d.h2;
+    for (int l = 0; l < d.nlevels; ++l) {
+        a.b1 = d.band(l, 1); a.b2 = d.band(l, 2); a.b3 = d.band(l, 3);
+        if (l == 0) {
+            a.src = src; a.src_stride = d.w; a.lo = d.low[0]; d.cur = 0;
+            HIPCHK(ctx, launch_wavelet_analysis0(a, ctx->stream));
+        } else {
+            a.src = d.low[d.cur]; a.lo = d.low[d.cur ^ 1]; a.skip = wavelet_skip(l);
+            HIPCHK(ctx, launch_wavelet_haar_analysis(a, ctx->stream));
+            d.cur ^= 1;
+        }
+    }
+    return ARTGPU_OK;
+}
+
+int reconstruct_dev(artgpu_ctx *ctx, DevDecomp &d, float *dst)
+{
+    WaveArgs a = {};
+    a.w = d.w; a.h = d.h; a.w2 = d.w2; a.h2 = d.h2; a.blend = 1.f;
+    for (int l = d.nlevels - 1; l > 0; --l) {
+        a.src = d.low[d.cur]; a.lo = d.low[d.cur ^ 1];
+        a.b1 = d.band(l, 1); a.b2 = d.band(l, 2); a.b3 = d.band(l, 3); a.skip = wavelet_skip(l);
+        HIPCHK(ctx, launch_wavelet_haar_synthesis(a, ctx->stream));
+        d.cur ^= 1;
+    }
+    a.src = d.low[d.cur];
+    a.b1 = d.band(0, 1); a.b2 = d.band(0, 2); a.b3 = d.band(0, 3);
+    a.dst = dst; a.dst_stride = d.w;
+    HIPCHK(ctx, launch_wavelet_synthesis0(a, ctx->stream));
+    return ARTGPU_OK;
+}
+
+int pool_get(artgpu_ctx *ctx, int slot, size_t bytes, float **out)
+{
+    int rc = ensure(ctx, &ctx->pool[slot], &ctx->pool_bytes[slot], bytes);
+    *out = ctx->pool[slot];
+    return rc;
+}
+
+} // namespace
+
+extern "C" {
+
+int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_params *p, const float ws[9],
+                       double expcomp, double scale, const artgpu_plane *ccalc, uint32_t flags,
+                       float *nresi, float *highresi)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!img || !p || !ws) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: null argument");
+    if (p->aggressive) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: aggressive (QUALITY_HIGH) mode is not on the device path");
+    if (p->color_space != 0) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: LAB colour space is not on the device path");
+    if (!(flags & ARTGPU_DN_SKIP_DETAIL_RECOVERY)) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: detail recovery (DCT) is not on the device path yet; pass ARTGPU_DN_SKIP_DETAIL_RECOVERY");
+    if (nresi || highresi) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: nresi/highresi (Noise_residualAB) not on the device path yet");
+    if (!(scale >= 1.0)) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: scale must be >= 1");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB d;
+    int rc = bind_rgb(ctx, img, 4, true, &d, "rgb_denoise");
+    if (rc) return rc;
+    const int w = d.w, h = d.h, w2 = (w + 1) / 2, h2 = (h + 1) / 2;
+    if (w > 32767 || h > 32767) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: the reference holds the size in short (FTblockDN.cc:1779)");
+    const size_t n = (size_t)w * h, n2 = (size_t)w2 * h2;
+    const bool useNoiseCCurve = ccalc != nullptr;
+    if (p->luminance == 0 && p->chrominance == 0 && !useNoiseCCurve) return unbind_rgb(ctx, img, &d); // L1655-1668: nothing to do
+
+    // ---- scalar set-up, as the reference computes it on the host (L1687-1688,1795-1825,2032-2082,2246-2293)
+    const float noiseluma = (float)p->luminance;
+    const double nl_t = (noiseluma / 125.0) * (1.0 + noiseluma / 25.0);
+    const float noisevarL = (float)(nl_t * nl_t);
+    const bool denoiseLuminance = noisevarL > 0.00001f;
+    const float gam = (float)p->gamma;
+    const float gamthresh = 0.001f;
+    const float gamslope = (float)(std::exp(std::log((double)gamthresh) / gam) / gamthresh);
+    const float igam = 1.f / gam, igamthresh = gamthresh * gamslope, igamslope = 1.f / gamslope;
+    const float gain = std::pow(2.0f, float(expcomp));
+    const float interm_med = (float)p->chrominance / 10.0;
+    float intermred = p->chrominance_red_green > 0. ? (p->chrominance_red_green / 10.) : (float)p->chrominance_red_green / 7.0;
+    float intermblue = p->chrominance_blue_yellow > 0. ? (p->chrominance_blue_yellow / 10.) : (float)p->chrominance_blue_yellow / 7.0;
+    float realred = interm_med + intermred;
+    if (realred <= 0.f) realred = 0.001f;
+    float realblue = interm_med + intermblue;
+    if (realblue <= 0.f) realblue = 0.001f;
+    const float noisevarab_r = realred * realred, noisevarab_b = realblue * realblue;
+    const float maxNoiseVarab = noisevarab_b > noisevarab_r ? noisevarab_b : noisevarab_r;
+    int levwav = 5;
+    const float maxreal = realred > realblue ? realred : realblue;
+    if (maxreal < 8.f) levwav = 5; else if (maxreal < 10.f) levwav = 6; else if (maxreal < 15.f) levwav = 7; else levwav = 8;
+    if (levwav > 8) levwav = 8;
+    { const int t = int(levwav - std::ceil(std::log(scale))); levwav = t > 5 ? t : 5; }
+    const int minsizetile = w < h ? w : h;
+    int maxlev2 = 8;
+    if (minsizetile < 256) maxlev2 = 7;
+    if (minsizetile < 128) maxlev2 = 6;
+    if (minsizetile < 64) maxlev2 = 5;
+    if (minsizetile < 32) maxlev2 = 4;
+    if (minsizetile < 16) maxlev2 = 3;
+    levwav = levwav < maxlev2 ? levwav : maxlev2;
+    if ((w2 < h2 ? w2 : h2) < 2 * wavelet_skip(levwav - 1) || w < 8 || h < 8)
+        return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: %dx%d too small for %d wavelet levels on the device path", w, h, levwav);
+    const int nsub = 3 * levwav;
+    bool autoch = p->chrominance_method == 1;
+
+    // ---- device buffers
+    float *L, *A, *B, *sf, *tmp, *gamlut, *mad, *histo_f, *ccalc_dev = nullptr;
+    DevDecomp Ld = {}, Cd = {};
+    Ld.w = Cd.w = w; Ld.h = Cd.h = h; Ld.w2 = Cd.w2 = w2; Ld.h2 = Cd.h2 = h2; Ld.n = Cd.n = n2; Ld.nlevels = Cd.nlevels = levwav;
+    if ((rc = pool_get(ctx, P_L, n * 4, &L)) || (rc = pool_get(ctx, P_A, n * 4, &A)) || (rc = pool_get(ctx, P_B, n * 4, &B)) ||
+        (rc = pool_get(ctx, P_LBANDS, (size_t)nsub * n2 * 4, &Ld.bands)) || (rc = pool_get(ctx, P_LLOW0, n2 * 4, &Ld.low[0])) || (rc = pool_get(ctx, P_LLOW1, n2 * 4, &Ld.low[1])) ||
+        (rc = pool_get(ctx, P_CBANDS, (size_t)nsub * n2 * 4, &Cd.bands)) || (rc = pool_get(ctx, P_CLOW0, n2 * 4, &Cd.low[0])) || (rc = pool_get(ctx, P_CLOW1, n2 * 4, &Cd.low[1])) ||
+        (rc = pool_get(ctx, P_SF, (size_t)nsub * n2 * 4, &sf)) || (rc = pool_get(ctx, P_TMP, (size_t)nsub * n2 * 4, &tmp)) ||
+        (rc = pool_get(ctx, P_HISTO, (size_t)nsub * 65536 * 4, &histo_f)) || (rc = pool_get(ctx, P_MAD, 3 * 32 * 4, &mad)) ||
+        (rc = pool_get(ctx, P_GAM, 2 * 65536 * 4, &gamlut)))
+        return rc;
+    int *histo = reinterpret_cast<int *>(histo_f);
+    float *madL = mad, *madab = mad + 32;
+    if (useNoiseCCurve) {
+        if (!plane_ok(ccalc) || ccalc->w != w2 || ccalc->h != h2) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: ccalc must be %dx%d", w2, h2);
+        if ((rc = pool_get(ctx, P_CCALC, n2 * 4, &ccalc_dev))) return rc;
+        HIPCHK(ctx, hipMemcpy2DAsync(ccalc_dev, (size_t)w2 * 4, ccalc->p, (size_t)ccalc->row_stride_bytes, (size_t)w2 * 4, h2,
+                                     ccalc->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    }
+
+    // ---- gamma LUTs (built on the device with the SSE-form sleef, color.cc:1128-1161)
+    HIPCHK(ctx, launch_gamma_lut(gamlut, gam, gamthresh, gamslope, 65535.f, 65535.f, ctx->stream));
+    HIPCHK(ctx, launch_gamma_lut(gamlut + 65536, igam, igamthresh, igamslope, 65535.f, 65535.f, ctx->stream));
+
+    DnPixArgs px = {};
+    for (int k = 0; k < 3; ++k) { px.rgb[k] = d.p[k]; px.ws1[k] = ws[3 + k]; }
+    px.stride = d.stride; px.L = L; px.A = A; px.B = B; px.w = w; px.h = h;
+    px.gain = gain; px.newGain = 1.f / gain;
+    px.gam = gam; px.gamthresh = gamthresh; px.gamslope = gamslope; px.igam = igam; px.igamthresh = igamthresh; px.igamslope = igamslope;
+    px.gamcurve = gamlut; px.igamcurve = gamlut + 65536;
+    px.realred = realred; px.realblue = realblue; px.qhighFactor = 1.0f;
+    HIPCHK(ctx, launch_rgb2yuv(px, ctx->stream));
+
+    // ---- L decomposition and its MADs (L2296-2320)
+    if ((rc = decompose_dev(ctx, Ld, L))) return rc;
+    HIPCHK(ctx, launch_mad(Ld.bands, n2, nsub, histo, madL, ctx->stream));
+
+    BlurArgs bl = {};
+    bl.n = n2; bl.w = w2; bl.h = h2;
+    for (int l = 0; l < levwav; ++l) { const int r = int((l + 2) / scale); bl.rad[l] = r > 1 ? r : 1; }
+
+    // ---- a then b: decompose, shrink against L, reconstruct (L2328-2402)
+    for (int ch = 0; ch < 2; ++ch) {
+        float *plane = ch == 0 ? A : B;
+        float noisevar_ab = ch == 0 ? noisevarab_r : noisevarab_b;
+        if (autoch && noisevar_ab <= 0.001f) noisevar_ab = 0.02f;
+        if ((rc = decompose_dev(ctx, Cd, plane))) return rc;
+        if (noisevar_ab > 0.001f) {
+            HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, madab, ctx->stream));
+            ShrinkArgs sa = {};
+            sa.coef = Cd.bands; sa.coefL = Ld.bands; sa.sfave = sf; sa.n = n2; sa.madL = madL; sa.madab = madab;
+            sa.noisevar = ccalc_dev; sa.noisevar_scale = maxNoiseVarab; sa.noisevar_ab = noisevar_ab; sa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
+            HIPCHK(ctx, launch_shrink_sf(sa, nsub, true, ctx->stream));
+            bl.src = sf; bl.dst = tmp;
+            HIPCHK(ctx, launch_hblur(bl, nsub, ctx->stream));
+            bl.src = tmp; bl.sfave = sf; bl.coef = Cd.bands;
+            HIPCHK(ctx, launch_vblur_combine(bl, nsub, ctx->stream));
+        }
+        if ((rc = reconstruct_dev(ctx, Cd, plane))) return rc;
+    }
+
+    // ---- L: shrink the first min(levels,5) levels, reconstruct (L2405-2438)
+    if (denoiseLuminance) {
+        const int nsubL = 3 * (levwav < 5 ? levwav : 5);
+        ShrinkArgs sa = {};
+        sa.coef = Ld.bands; sa.sfave = sf; sa.n = n2; sa.madL = madL; sa.noisevar = nullptr; sa.noisevar_const = noisevarL;
+        HIPCHK(ctx, launch_shrink_sf(sa, nsubL, false, ctx->stream));
+        bl.src = sf; bl.dst = tmp;
+        HIPCHK(ctx, launch_hblur(bl, nsubL, ctx->stream));
+        bl.src = tmp; bl.sfave = sf; bl.coef = Ld.bands;
+        HIPCHK(ctx, launch_vblur_combine(bl, nsubL, ctx->stream));
+        if ((rc = reconstruct_dev(ctx, Ld, L))) return rc;
+    }
+
+    // ---- back to RGB (L2502-2550)
+    HIPCHK(ctx, launch_yuv2rgb(px, ctx->stream));
+    return unbind_rgb(ctx, img, &d);
 }
 
 } // extern "C"

@@ -1,0 +1,372 @@
+// art_amd/csrc/denoise.hip -- wavelet part of denoise::RGB_denoise on gfx950
+// (reference: rtengine/FTblockDN.cc:569-603 MadRgb, 638-839 ShrinkAllL/AB, 1781-1823 gamma LUTs,
+//  2084-2128 RGB->YUV, 2502-2550 YUV->RGB; rtengine/boxblur.h:558-743; rtengine/color.cc:1128-1161).
+//
+// All 3 x levels subbands of one decomposition are processed by ONE launch per step (blockIdx.y =
+// subband), and every data-dependent scalar (MAD) stays on the device, so the host never syncs:
+//   mad_hist / mad_finish : int32 histogram of min(65535,|int(x)|) with LDS-privatised low bins,
+//                           exact median walk -> SQR(MadRgb) per subband                 (integer, exact)
+//   shrink_sf_L / _AB     : shrink factor per coefficient; bulk lanes use the vector sleef exp,
+//                           the N%4 tail the scalar one (FTblockDN.cc:673-683,770-785)
+//   hblur                 : sliding-sum box blur along rows.  The fp32 recurrence is sequential
+//                           along the row (association order is part of the result), so
+//                           parallelism comes from the rows: one lane per row, 64-row x 64-column
+//                           tiles transposed through LDS so that HBM sees coalesced rows.
+//   vblur_combine         : the vertical recurrence, one lane per column (naturally coalesced),
+//                           fused with the coefficient update c *= (sfd^2+sf^2)/(sfd+sf+eps).
+// Everything is HBM-bound streaming; bytes per coefficient: sf 8-16 in + 4 out, hblur 4+4,
+// vblur 4+4+4 in + 4 out.
+#include <hip/hip_runtime.h>
+#include "devmath.h"
+#include "devsleef.h"
+#include "kernels.h"
+
+namespace artgpu {
+
+// ---------------------------------------------------------------- gamma LUT (color.cc:1128-1161, SSE form)
+__global__ void __launch_bounds__(256) gamma_lut_kernel(float *lut, float gamma, float start, float slope, float divisor, float factor)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 65536) return;
+    const float gammav = 1.f / gamma;
+    const float slopev = (slope / divisor) * factor;
+    const float divisorv = xlogf_s(divisor);
+    const float comparev = start * divisor;
+    const int border = (int)(start * divisor);
+    const int border1 = border - (border & 3), border2 = border1 + 4;
+    const float iv = (float)i;
+    float r;
+    if (i < border1) {
+        r = iv * slopev;
+    } else if (i < border2) {
+        const float r0 = iv * slopev;
+        const float r1 = xexpf_v((xlogf_v(iv) - divisorv) * gammav) * factor;
+        r = iv <= comparev ? r0 : r1;
+    } else {
+        r = xexpf_v_nocheck((xlogf_v_nocheck(iv) - divisorv) * gammav) * factor;
+    }
+    lut[i] = r;
+}
+
+__device__ __forceinline__ float gammaf_s(float x, float gamma, float start, float slope)
+{
+    return x <= start ? x * slope : xexpf_s(xlogf_s(x) / gamma);
+}
+
+// ---------------------------------------------------------------- RGB -> gamma -> YUV (FTblockDN.cc:2084-2128)
+__global__ void __launch_bounds__(256) rgb2yuv_kernel(DnPixArgs a)
+{
+    const long long n = (long long)a.w * a.h;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+        const size_t si = (size_t)y * a.stride + x;
+        float X = a.gain * a.rgb[0][si], Y = a.gain * a.rgb[1][si], Z = a.gain * a.rgb[2][si];
+        if (a.gam > 1.f) {
+            if (X > 0.f) X = X < 65535.f ? lutf_lookup<false>(a.gamcurve, 65536, X) : (gammaf_s(X / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
+            if (Y > 0.f) Y = Y < 65535.f ? lutf_lookup<false>(a.gamcurve, 65536, Y) : (gammaf_s(Y / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
+            if (Z > 0.f) Z = Z < 65535.f ? lutf_lookup<false>(a.gamcurve, 65536, Z) : (gammaf_s(Z / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
+        }
+        const float l = X * a.ws1[0] + Y * a.ws1[1] + Z * a.ws1[2];
+        a.L[t] = l;
+        a.A[t] = X - l; // v
+        a.B[t] = l - Z; // u
+    }
+}
+
+// ---------------------------------------------------------------- YUV -> inverse gamma -> RGB (FTblockDN.cc:2502-2550)
+__global__ void __launch_bounds__(256) yuv2rgb_kernel(DnPixArgs a)
+{
+    const long long n = (long long)a.w * a.h;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+        float av = a.A[t], bv = a.B[t];
+        const float Lv = a.L[t];
+        const float c_h = sqrtf(sqr(av) + sqr(bv));
+        if (c_h > 3000.f) {
+            av *= 1.f + a.qhighFactor * a.realred / 100.f;
+            bv *= 1.f + a.qhighFactor * a.realblue / 100.f;
+        }
+        float Z = Lv - bv;
+        float X = av + Lv;
+        float Y = (Lv - X * a.ws1[0] - Z * a.ws1[2]) / a.ws1[1];
+        if (a.gam > 1.f) {
+            if (X > 0.f) X = X < 65536.f ? lutf_lookup<false>(a.igamcurve, 65536, X) : (gammaf_s(X / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
+            if (Y > 0.f) Y = Y < 65536.f ? lutf_lookup<false>(a.igamcurve, 65536, Y) : (gammaf_s(Y / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
+            if (Z > 0.f) Z = Z < 65536.f ? lutf_lookup<false>(a.igamcurve, 65536, Z) : (gammaf_s(Z / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
+        }
+        const size_t di = (size_t)y * a.stride + x;
+        a.rgb[0][di] = a.newGain * X;
+        a.rgb[1][di] = a.newGain * Y;
+        a.rgb[2][di] = a.newGain * Z;
+    }
+}
+
+// ---------------------------------------------------------------- MadRgb (FTblockDN.cc:569-603)
+constexpr int MAD_LDS_BINS = 4096;
+__global__ void __launch_bounds__(256) mad_hist_kernel(const float *bands, size_t n, int *histo /*[nsub][65536]*/)
+{
+    __shared__ int h[MAD_LDS_BINS];
+    const int sub = blockIdx.y;
+    const float *data = bands + (size_t)sub * n;
+    int *gh = histo + (size_t)sub * 65536;
+    for (int i = threadIdx.x; i < MAD_LDS_BINS; i += 256) h[i] = 0;
+    __syncthreads();
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        int v = abs((int)data[i]);
+        v = v < 65535 ? v : 65535;
+        if (v < MAD_LDS_BINS) atomicAdd(&h[v], 1);
+        else atomicAdd(&gh[v], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MAD_LDS_BINS; i += 256)
+        if (h[i]) atomicAdd(&gh[i], h[i]);
+}
+
+// one workgroup per subband: exact median walk; out[sub] = SQR(MadRgb)
+__global__ void __launch_bounds__(256) mad_finish_kernel(const int *histo, int datalen, float *out)
+{
+    __shared__ int part[256];
+    const int sub = blockIdx.x;
+    const int *h = histo + (size_t)sub * 65536;
+    int s = 0;
+    for (int i = 0; i < 256; ++i) s += h[threadIdx.x * 256 + i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = 0.f;
+        if (datalen > 1) {
+            const int half = datalen / 2;
+            int count = 0, chunk = 0;
+            // `while (count < half) { count += histo[median]; ++median; }` -- skip whole 256-bin chunks first
+            while (chunk < 256 && count + part[chunk] < half) { count += part[chunk]; ++chunk; }
+            int median = chunk * 256;
+            while (count < half) { count += h[median]; ++median; }
+            const int count_ = count - h[median - 1];
+            const float q = ((median - 1) + (half - count_) / ((float)(count - count_)));
+            r = (float)((double)q / 0.6745);
+        }
+        out[sub] = r * r;
+    }
+}
+
+// ---------------------------------------------------------------- shrink factors
+__global__ void __launch_bounds__(256) shrink_sf_L_kernel(ShrinkArgs a)
+{
+    const int sub = blockIdx.y, level = sub / 3;
+    const float *c = a.coef + (size_t)sub * a.n;
+    float *sf = a.sfave + (size_t)sub * a.n;
+    const float mad_L = a.madL[sub];
+    const float levelFactor = mad_L * 5.f / (float)(level + 1);
+    const float eps = 0.01f;
+    const size_t nv4 = (a.n / 4) * 4;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        const float nv = a.noisevar ? a.noisevar[i] : a.noisevar_const;
+        const float mag = sqr(c[i]);
+        float r;
+        if (i < nv4) {
+            const float madv = nv * levelFactor;
+            r = mag / (mag + madv * xexpf_v(-mag / (9.0f * madv)) + eps);
+        } else {
+            r = mag / (mag + levelFactor * nv * xexpf_s(-mag / (9 * levelFactor * nv)) + eps);
+        }
+        sf[i] = r;
+    }
+}
+
+__global__ void __launch_bounds__(256) shrink_sf_AB_kernel(ShrinkArgs a)
+{
+    const int sub = blockIdx.y;
+    const float *c = a.coef + (size_t)sub * a.n;
+    const float *cL = a.coefL + (size_t)sub * a.n;
+    float *sf = a.sfave + (size_t)sub * a.n;
+    const float mad_L = a.madL[sub];
+    float madab = a.madab[sub];
+    madab = a.useNoiseCCurve ? madab : madab * a.noisevar_ab;
+    const float rmadLm9 = 1.f / (mad_L * 9.f);
+    const size_t nv4 = (a.n / 4) * 4;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        // noisevarchrom[i] = useNoiseCCurve ? maxNoiseVarab * ccalc[i] : 1 (FTblockDN.cc:2124)
+        const float nvc = a.noisevar ? a.noisevar_scale * a.noisevar[i] : 1.f;
+        const float mag_ab = sqr(c[i]);
+        float r;
+        if (i < nv4) {
+            const float mad_abv = nvc * madab;
+            const float mag_L = sqr(cL[i]) * rmadLm9;
+            r = 1.f - xexpf_v(-(mag_ab / mad_abv) - mag_L);
+        } else {
+            const float mag_L = sqr(cL[i]);
+            r = 1.f - xexpf_s(-(mag_ab / (nvc * madab)) - (mag_L / (9.f * mad_L)));
+        }
+        sf[i] = r;
+    }
+}
+
+// ---------------------------------------------------------------- horizontal box blur (boxblur.h:565-600)
+constexpr int HB_ROWS = 64, HB_COLS = 64, HB_MAXR = 15;
+constexpr int HB_TW = HB_COLS + 2 * HB_MAXR + 2; // source window held in LDS
+__global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
+{
+    __shared__ float sT[HB_ROWS][HB_TW + 1];
+    __shared__ float oT[HB_ROWS][HB_COLS + 1];
+    const int sub = blockIdx.y, level = sub / 3;
+    const int rad = a.rad[level];
+    const int W = a.w, H = a.h;
+    const float *src = a.src + (size_t)sub * a.n;
+    float *dst = a.dst + (size_t)sub * a.n;
+    const int r0 = blockIdx.x * HB_ROWS;
+    const int lane = threadIdx.x;
+    const int myrow = r0 + lane;
+    float tempval = 0.f;
+    int len = rad + 1;
+    float reclen = 0.f;
+    for (int c0 = 0; c0 < W; c0 += HB_COLS) {
+        // window columns [c0 - rad - 1, c0 + HB_COLS + rad): coalesced row segments -> LDS
+        const int wc0 = c0 - rad - 1, wn = HB_COLS + 2 * rad + 1;
+        for (int k = 0; k < HB_ROWS; ++k) {
+            const int row = r0 + k;
+            if (row >= H) break;
+            for (int x = lane; x < wn; x += 64) {
+                const int col = wc0 + x;
+                sT[k][x] = (col >= 0 && col < W) ? src[(size_t)row * W + col] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (myrow < H) {
+            const float *s = &sT[lane][rad + 1]; // s[j] = src[row][c0 + j]
+            const int cend = min(HB_COLS, W - c0);
+            for (int j = 0; j < cend; ++j) {
+                const int col = c0 + j;
+                if (col == 0) {
+                    tempval = s[0];
+                    for (int q = 1; q <= rad; q++) tempval += s[q];
+                    tempval = tempval / len;
+                } else if (col <= rad) {
+                    tempval = (tempval * len + s[j + rad]) / (len + 1);
+                    len++;
+                    if (col == rad) reclen = 1.f / len;
+                } else if (col < W - rad) {
+                    tempval = tempval + (s[j + rad] - s[j - rad - 1]) * reclen;
+                } else {
+                    tempval = (tempval * len - s[j - rad - 1]) / (len - 1);
+                    len--;
+                }
+                oT[lane][j] = tempval;
+            }
+        }
+        __syncthreads();
+        {
+            const int cend = min(HB_COLS, W - c0);
+            for (int k = 0; k < HB_ROWS; ++k) {
+                const int row = r0 + k;
+                if (row >= H) break;
+                if (lane < cend) dst[(size_t)row * W + c0 + lane] = oT[k][lane];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- vertical box blur + coefficient update (boxblur.h:602-742)
+__global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
+{
+    const int sub = blockIdx.y, level = sub / 3;
+    const int rad = a.rad[level];
+    const int W = a.w, H = a.h;
+    const float *t = a.src + (size_t)sub * a.n;   // horizontally blurred
+    const float *sfave = a.sfave + (size_t)sub * a.n;
+    float *coef = a.coef + (size_t)sub * a.n;
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (col >= W) return;
+    const size_t nv4 = (a.n / 4) * 4;
+    const float eps = 0.01f;
+    const bool vec = col < (W / 4) * 4;
+    float tv;
+    float lenf = (float)(rad + 1);
+    int leni = rad + 1;
+    float rlen = 0.f;
+    for (int row = 0; row < H; ++row) {
+        if (row == 0) {
+            if (vec) {
+                tv = t[col];
+                for (int i = 1; i <= rad; i++) tv = tv + t[(size_t)i * W + col];
+                tv = tv / lenf;
+            } else {
+                tv = t[col] / leni;
+                for (int i = 1; i <= rad; i++) tv += t[(size_t)i * W + col] / leni;
+            }
+        } else if (row <= rad) {
+            if (vec) {
+                const float lenp1 = lenf + 1.f;
+                tv = (tv * lenf + t[(size_t)(row + rad) * W + col]) / lenp1;
+                lenf = lenp1;
+                if (row == rad) rlen = 1.f / lenf;
+            } else {
+                tv = (tv * leni + t[(size_t)(row + rad) * W + col]) / (leni + 1);
+                leni++;
+            }
+        } else if (row < H - rad) {
+            const float d = t[(size_t)(row + rad) * W + col] - t[(size_t)(row - rad - 1) * W + col];
+            tv = vec ? tv + d * rlen : tv + d / leni;
+        } else {
+            if (vec) {
+                const float lenm1 = lenf - 1.f;
+                tv = (tv * lenf - t[(size_t)(row - rad - 1) * W + col]) / lenm1;
+                lenf = lenm1;
+            } else {
+                tv = (tv * leni - t[(size_t)(row - rad - 1) * W + col]) / (leni - 1);
+                leni--;
+            }
+        }
+        // coefficient update (FTblockDN.cc:698-714,803-836): vector lanes (c*num)/den, tail c*(num/den)
+        const size_t i = (size_t)row * W + col;
+        const float sf = sfave[i], sfd = tv, c = coef[i];
+        const float num = sqr(sfd) + sqr(sf), den = sfd + sf + eps;
+        coef[i] = i < nv4 ? c * num / den : c * (num / den);
+    }
+}
+
+// ---------------------------------------------------------------- launchers
+static int flat_grid(long long n, int cap) { long long g = (n + 255) / 256; return (int)(g < cap ? g : cap); }
+
+hipError_t launch_gamma_lut(float *lut, float gamma, float start, float slope, float divisor, float factor, hipStream_t s)
+{
+    hipLaunchKernelGGL(gamma_lut_kernel, dim3(256), dim3(256), 0, s, lut, gamma, start, slope, divisor, factor);
+    return hipGetLastError();
+}
+hipError_t launch_rgb2yuv(const DnPixArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(rgb2yuv_kernel, dim3(flat_grid((long long)a.w * a.h, 16384)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_yuv2rgb(const DnPixArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(yuv2rgb_kernel, dim3(flat_grid((long long)a.w * a.h, 16384)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_mad(const float *bands, size_t n, int nsub, int *histo, float *out, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(histo, 0, (size_t)nsub * 65536 * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mad_hist_kernel, dim3(flat_grid((long long)n, 512), nsub), dim3(256), 0, s, bands, n, histo);
+    hipLaunchKernelGGL(mad_finish_kernel, dim3(nsub), dim3(256), 0, s, (const int *)histo, (int)n, out);
+    return hipGetLastError();
+}
+hipError_t launch_shrink_sf(const ShrinkArgs &a, int nsub, bool ab, hipStream_t s)
+{
+    dim3 grid(flat_grid((long long)a.n, 1024), nsub);
+    if (ab) hipLaunchKernelGGL(shrink_sf_AB_kernel, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(shrink_sf_L_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_hblur(const BlurArgs &a, int nsub, hipStream_t s)
+{
+    hipLaunchKernelGGL(hblur_kernel, dim3((a.h + HB_ROWS - 1) / HB_ROWS, nsub), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_vblur_combine(const BlurArgs &a, int nsub, hipStream_t s)
+{
+    hipLaunchKernelGGL(vblur_combine_kernel, dim3((a.w + 63) / 64, nsub), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace artgpu

@@ -1,0 +1,104 @@
+// art_amd/csrc/devsleef.h -- device-side sleef-derived fp32 math, scalar (_s) and per-lane SSE (_v)
+// forms (reference: rtengine/sleef.h:938-966,1198-1265 and rtengine/sleefsseavx.h:978-1000,1232-1372).
+// Both forms occur on the path (bulk lanes vs loop tails) and differ in the last bits:
+//   exp: scalar  u = s*(s*u+1)+1, ldexp x*(u*u)*(u*u)*2^q' ; vector u = 1+((s*s)*u+s), ldexp (((x*u)*u)*u)*u*2^q'
+// mlaf/vmlaf are unfused x*y+z: this file must be compiled with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace artgpu {
+
+#define ART_R_LN2f 1.442695040888963407359924681001892137426645954152985934135449406931f
+#define ART_L2Uf 0.693145751953125f
+#define ART_L2Lf 1.428606765330187045e-06f
+
+__device__ __forceinline__ float sl_mla(float x, float y, float z) { return x * y + z; }
+
+__device__ __forceinline__ int sl_ilogbp1f(float d)
+{
+    const bool m = d < 5.421010862427522E-20f;
+    d = m ? 1.8446744073709552E19f * d : d;
+    const int q = (__float_as_int(d) >> 23) & 0xff;
+    return m ? q - (64 + 0x7e) : q - 0x7e;
+}
+template <bool VEC>
+__device__ __forceinline__ float sl_ldexpk(float x, int q)
+{
+    int m = q >> 31;
+    m = (((m + q) >> 6) - m) << 4;
+    q = q - (m << 2);
+    float u = __int_as_float((m + 0x7f) << 23);
+    if (VEC) {
+        x = (((x * u) * u) * u) * u;
+    } else {
+        u = u * u;
+        x = x * u * u;
+    }
+    u = __int_as_float((q + 0x7f) << 23);
+    return x * u;
+}
+template <bool VEC>
+__device__ __forceinline__ float sl_exp_core(float d)
+{
+    const int q = __float2int_rn(d * ART_R_LN2f); // cvtss2si / cvtps2dq: round to nearest even
+    float s = sl_mla((float)q, -ART_L2Uf, d);
+    s = sl_mla((float)q, -ART_L2Lf, s);
+    float u = 0.00136324646882712841033936f;
+    u = sl_mla(u, s, 0.00836596917361021041870117f);
+    u = sl_mla(u, s, 0.0416710823774337768554688f);
+    u = sl_mla(u, s, 0.166665524244308471679688f);
+    u = sl_mla(u, s, 0.499999850988388061523438f);
+    if (VEC) u = 1.0f + sl_mla(s * s, u, s);
+    else u = sl_mla(s, sl_mla(s, u, 1.f), 1.f);
+    return sl_ldexpk<VEC>(u, q);
+}
+__device__ __forceinline__ float xexpf_s(float d) { return d <= -104.0f ? 0.0f : sl_exp_core<false>(d); }
+__device__ __forceinline__ float xexpf_v(float d) { const float u = sl_exp_core<true>(d); return (-104.f > d) ? 0.f : u; }
+__device__ __forceinline__ float xexpf_v_nocheck(float d) { return sl_exp_core<true>(d); }
+
+template <bool VEC>
+__device__ __forceinline__ float sl_log_core(float d)
+{
+    const int e = sl_ilogbp1f(d * 0.7071f);
+    const float m = sl_ldexpk<VEC>(d, -e);
+    const float x = VEC ? ((-1.0f + m) / (1.0f + m)) : ((m - 1.0f) / (m + 1.0f));
+    const float x2 = x * x;
+    float t = 0.2371599674224853515625f;
+    t = sl_mla(t, x2, 0.285279005765914916992188f);
+    t = sl_mla(t, x2, 0.400005519390106201171875f);
+    t = sl_mla(t, x2, 0.666666567325592041015625f);
+    t = sl_mla(t, x2, 2.0f);
+    return x * t + 0.693147180559945286226764f * (float)e;
+}
+template <bool VEC>
+__device__ __forceinline__ float sl_logf(float d)
+{
+    float x = sl_log_core<VEC>(d);
+    if (d == INFINITY) x = INFINITY;
+    if (d < 0.f) x = NAN;
+    if (d == 0.f) x = -INFINITY;
+    return x;
+}
+__device__ __forceinline__ float xlogf_s(float d) { return sl_logf<false>(d); }
+__device__ __forceinline__ float xlogf_v(float d) { return sl_logf<true>(d); }
+__device__ __forceinline__ float xlogf_v_nocheck(float d) { return sl_log_core<true>(d); }
+
+// LUTf::operator[](float) (rtengine/LUT.h:436-459): clip_above selects LUT_CLIP_ABOVE behaviour
+template <bool CLIP_ABOVE>
+__device__ __forceinline__ float lutf_lookup(const float *__restrict__ data, int size, float index)
+{
+    const int maxs = size - 2;
+    if (index < 0.f || !(index == index)) return data[0];
+    int idx = (int)index;
+    if (index > (float)maxs) {
+        if (CLIP_ABOVE) return data[size - 1];
+        idx = maxs;
+    }
+    const float diff = index - (float)idx;
+    const float p1 = data[idx];
+    const float p2 = data[idx + 1] - p1;
+    return p1 + p2 * diff;
+}
+
+} // namespace artgpu

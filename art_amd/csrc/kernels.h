@@ -96,4 +96,46 @@ hipError_t launch_wavelet_haar_analysis(const WaveArgs &a, hipStream_t s);
 hipError_t launch_wavelet_haar_synthesis(const WaveArgs &a, hipStream_t s);
 hipError_t launch_wavelet_synthesis0(const WaveArgs &a, hipStream_t s);
 
+// ---- wavelet denoise (denoise.hip) ----
+struct DnPixArgs {
+    float *rgb[3];          // Imagefloat planes (in for rgb2yuv, out for yuv2rgb)
+    size_t stride;
+    float *L, *A, *B;       // LabImage planes, contiguous w*h
+    int w, h;
+    float gain, newGain;
+    float gam, gamthresh, gamslope, igam, igamthresh, igamslope;
+    const float *gamcurve, *igamcurve;
+    float ws1[3];           // working-space matrix row 1 (luminance)
+    float realred, realblue, qhighFactor;
+};
+struct ShrinkArgs {
+    float *coef;            // bands of the decomposition being shrunk: [nsub][n]
+    const float *coefL;     // bands of the L decomposition (AB only)
+    float *sfave;           // [nsub][n]
+    size_t n;
+    const float *madL;      // [nsub] SQR(MadRgb) of the L bands
+    const float *madab;     // [nsub] SQR(MadRgb) of the ab bands (AB only)
+    const float *noisevar;  // per-coefficient noise variance map (n floats) or nullptr
+    float noisevar_const;   // L: noisevarL when no map
+    float noisevar_scale;   // AB: maxNoiseVarab
+    float noisevar_ab;
+    int useNoiseCCurve;
+};
+struct BlurArgs {
+    const float *src;       // hblur: sfave ; vblur: hblur output
+    float *dst;             // hblur output
+    const float *sfave;     // vblur: unblurred shrink factors
+    float *coef;            // vblur: coefficients updated in place
+    size_t n;
+    int w, h;
+    int rad[10];            // blur radius per level
+};
+hipError_t launch_gamma_lut(float *lut, float gamma, float start, float slope, float divisor, float factor, hipStream_t s);
+hipError_t launch_rgb2yuv(const DnPixArgs &a, hipStream_t s);
+hipError_t launch_yuv2rgb(const DnPixArgs &a, hipStream_t s);
+hipError_t launch_mad(const float *bands, size_t n, int nsub, int *histo, float *out, hipStream_t s);
+hipError_t launch_shrink_sf(const ShrinkArgs &a, int nsub, bool ab, hipStream_t s);
+hipError_t launch_hblur(const BlurArgs &a, int nsub, hipStream_t s);
+hipError_t launch_vblur_combine(const BlurArgs &a, int nsub, hipStream_t s);
+
 } // namespace artgpu

@@ -142,6 +142,36 @@ int artgpu_wavelet_set_band(artgpu_ctx *ctx, artgpu_wavelet *wv, int level, int 
 int artgpu_wavelet_reconstruct(artgpu_ctx *ctx, artgpu_wavelet *wv, artgpu_plane *dst, float blend);
 int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv);
 
+/* The fields of procparams::DenoiseParams the path reads (rtengine/procparams.cc:1901-1918). */
+typedef struct {
+    double  luminance;                 /* 0..100 */
+    double  luminance_detail;          /* 0..100 */
+    int32_t luminance_detail_threshold;
+    double  chrominance;
+    double  chrominance_red_green;
+    double  chrominance_blue_yellow;
+    double  gamma;
+    int32_t aggressive;                /* QUALITY_HIGH: not on the device path yet */
+    int32_t color_space;               /* 0 = RGB (device path), 1 = LAB (unsupported) */
+    int32_t chrominance_method;        /* 0 = MANUAL, 1 = AUTOMATIC (only sets `autoch`) */
+} artgpu_denoise_params;
+
+#define ARTGPU_DN_SKIP_DETAIL_RECOVERY 1u  /* leave out detail_recovery (FTblockDN.cc:1479-1635) */
+
+/* Replaces denoise::RGB_denoise(im, kall=0, src=img, dst=img, calclum, ..., isRAW=true, dnparams,
+ * expcomp, noiseLCurve(empty), noiseCCurve, nresi, highresi) (rtengine/FTblockDN.cc:1638-2689) for
+ * colorSpace RGB, QUALITY_STANDARD, one tile (Tile_calc always yields one, L442-480).
+ * img      : Imagefloat planes, denoised in place
+ * ws       : ICCStore::workingSpaceMatrix(params->icm.workingProfile) as 9 floats, row-major (wpi)
+ * expcomp  : RGB_denoise's `expcomp` argument (gain = 2^expcomp; 0 from ImProcFunctions::denoise)
+ * scale    : ImProcData::scale (1 for full-resolution export)
+ * ccalc    : the quarter-resolution chroma noise-curve map `ccalc` (L1707-1777), ((w+1)/2 x (h+1)/2),
+ *            or NULL when the chroma curve is off (noisevarchrom = 1)
+ * flags    : ARTGPU_DN_* ; nresi/highresi: nullable, only computed when not NULL. */
+int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_params *params, const float ws[9],
+                       double expcomp, double scale, const artgpu_plane *ccalc, uint32_t flags,
+                       float *nresi, float *highresi);
+
 /* Bytes of device scratch the context currently holds (arena + staging). */
 size_t artgpu_scratch_bytes(const artgpu_ctx *ctx);
 

@@ -49,6 +49,22 @@ oracle_wavelet *oracle_wavelet_decompose(const float *src, int w, int h, int max
 void oracle_wavelet_reconstruct(oracle_wavelet *d, float *dst, float blend);
 void oracle_wavelet_free(oracle_wavelet *d);
 
+/* wavelet part of RGB_denoise (oracle/denoise.c) */
+typedef struct {
+    double luminance, luminanceDetail, chrominance, chrominanceRedGreen, chrominanceBlueYellow, gamma;
+    double expcomp;   /* RGB_denoise's expcomp argument (0 when called from ImProcFunctions::denoise) */
+    double scale;     /* ImProcData::scale (1 for full-size export) */
+    int autoch;       /* chrominanceMethod == AUTOMATIC */
+} oracle_denoise_params;
+float oracle_madrgb(const float *data, int datalen);
+void oracle_boxblur_flat(const float *src, float *dst, float *temp, int radx, int rady, int W, int H);
+void oracle_shrink_all_L(oracle_wavelet *L, int level, int dir, const float *noisevarlum, const float *madL3, double scale);
+void oracle_shrink_all_AB(const oracle_wavelet *L, oracle_wavelet *ab, int level, int dir, const float *noisevarchrom,
+                          float noisevar_ab, int useNoiseCCurve, int autoch, const float *madL3, double scale);
+void oracle_gamma_lut(float *lut, float gamma, float start, float slope, float divisor, float factor);
+int oracle_rgb_denoise(float *const img[3], size_t stride, int w, int h, const oracle_denoise_params *p,
+                       const float wpi[9], const float *noisevarchrom_in, float *Lin_out, float *Lden_out);
+
 /* sleef-derived math (oracle/sleef.c); _s = scalar form, _v = per-lane SSE form */
 float oracle_xexpf_s(float d);
 float oracle_xexpf_v(float d);

@@ -154,3 +154,51 @@ def wavelet_reconstruct(d, h, w, blend=1.0, fill=7.0):
     lib().oracle_wavelet_reconstruct(d, _ptr(rec), C.c_float(blend))
     lib().oracle_wavelet_free(d)
     return rec
+
+
+class DenoiseParams(C.Structure):
+    _fields_ = [("luminance", C.c_double), ("luminanceDetail", C.c_double), ("chrominance", C.c_double),
+                ("chrominanceRedGreen", C.c_double), ("chrominanceBlueYellow", C.c_double), ("gamma", C.c_double),
+                ("expcomp", C.c_double), ("scale", C.c_double), ("autoch", C.c_int)]
+
+
+def default_denoise_params(**kw):
+    p = DenoiseParams(40.0, 50.0, 15.0, 0.0, 0.0, 1.7, 0.0, 1.0, 0)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+REC2020_WS = np.array([[0.6734241, 0.1656411, 0.1251286],
+                       [0.2790177, 0.6753402, 0.0456377],
+                       [-0.0019300, 0.0299784, 0.7973330]], dtype=np.float32)
+
+
+def rgb_denoise(img, params=None, wpi=REC2020_WS, noisevarchrom=None, want_L=False):
+    img = [np.array(p, dtype=np.float32, order="C") for p in img]
+    h, w = img[0].shape
+    params = params or default_denoise_params()
+    wp = np.ascontiguousarray(wpi, dtype=np.float32).reshape(9)
+    nvc = None if noisevarchrom is None else _ptr(np.ascontiguousarray(noisevarchrom, dtype=np.float32))
+    Lin = np.zeros((h, w), np.float32) if want_L else None
+    Lden = np.zeros((h, w), np.float32) if want_L else None
+    rc = lib().oracle_rgb_denoise(_p3(img), C.c_size_t(w), w, h, C.byref(params), _ptr(wp), nvc,
+                                  _ptr(Lin) if want_L else None, _ptr(Lden) if want_L else None)
+    assert rc == 0
+    return (img, Lin, Lden) if want_L else img
+
+
+def madrgb(a):
+    a = np.ascontiguousarray(a, dtype=np.float32).ravel()
+    L = lib()
+    L.oracle_madrgb.restype = C.c_float
+    return float(L.oracle_madrgb(_ptr(a), len(a)))
+
+
+def boxblur_flat(src, radx, rady):
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    h, w = src.shape
+    dst = np.empty_like(src)
+    tmp = np.empty_like(src)
+    lib().oracle_boxblur_flat(_ptr(src), _ptr(dst), _ptr(tmp), radx, rady, w, h)
+    return dst
