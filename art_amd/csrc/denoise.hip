@@ -216,50 +216,77 @@ __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
     const int r0 = blockIdx.x * HB_ROWS;
     const int lane = threadIdx.x;
     const int myrow = r0 + lane;
+    const int nrows = min(HB_ROWS, H - r0);
     float tempval = 0.f;
     int len = rad + 1;
     float reclen = 0.f;
     for (int c0 = 0; c0 < W; c0 += HB_COLS) {
-        // window columns [c0 - rad - 1, c0 + HB_COLS + rad): coalesced row segments -> LDS
+        // window columns [c0 - rad - 1, c0 + HB_COLS + rad): coalesced row segments -> LDS,
+        // 8 rows (16 independent loads) in flight per lane before the LDS stores
         const int wc0 = c0 - rad - 1, wn = HB_COLS + 2 * rad + 1;
-        for (int k = 0; k < HB_ROWS; ++k) {
-            const int row = r0 + k;
-            if (row >= H) break;
-            for (int x = lane; x < wn; x += 64) {
-                const int col = wc0 + x;
-                sT[k][x] = (col >= 0 && col < W) ? src[(size_t)row * W + col] : 0.f;
+        const int colA = wc0 + lane, colB = wc0 + lane + 64;
+        const bool okA = colA >= 0 && colA < W, okB = (lane + 64 < wn) && colB >= 0 && colB < W;
+        for (int k0 = 0; k0 < HB_ROWS; k0 += 8) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = k0 + i;
+                const size_t ro = (size_t)(r0 + k) * W;
+                va[i] = (okA && k < nrows) ? src[ro + colA] : 0.f;
+                vb[i] = (okB && k < nrows) ? src[ro + colB] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                sT[k0 + i][lane] = va[i];
+                if (lane + 64 < wn) sT[k0 + i][lane + 64] = vb[i];
             }
         }
         __syncthreads();
+        const int cend = min(HB_COLS, W - c0);
         if (myrow < H) {
             const float *s = &sT[lane][rad + 1]; // s[j] = src[row][c0 + j]
-            const int cend = min(HB_COLS, W - c0);
-            for (int j = 0; j < cend; ++j) {
-                const int col = c0 + j;
-                if (col == 0) {
-                    tempval = s[0];
-                    for (int q = 1; q <= rad; q++) tempval += s[q];
-                    tempval = tempval / len;
-                } else if (col <= rad) {
-                    tempval = (tempval * len + s[j + rad]) / (len + 1);
-                    len++;
-                    if (col == rad) reclen = 1.f / len;
-                } else if (col < W - rad) {
-                    tempval = tempval + (s[j + rad] - s[j - rad - 1]) * reclen;
-                } else {
-                    tempval = (tempval * len - s[j - rad - 1]) / (len - 1);
-                    len--;
+            if (c0 > rad && c0 + HB_COLS <= W - rad) {
+                // steady state for the whole chunk: tempval += (s[j+rad] - s[j-rad-1]) * reclen
+                for (int j0 = 0; j0 < HB_COLS; j0 += 8) {
+                    float hi[8], lo[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { hi[i] = s[j0 + i + rad]; lo[i] = s[j0 + i - rad - 1]; }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        tempval = tempval + (hi[i] - lo[i]) * reclen;
+                        oT[lane][j0 + i] = tempval;
+                    }
                 }
-                oT[lane][j] = tempval;
+            } else {
+                for (int j = 0; j < cend; ++j) {
+                    const int col = c0 + j;
+                    if (col == 0) {
+                        tempval = s[0];
+                        for (int q = 1; q <= rad; q++) tempval += s[q];
+                        tempval = tempval / len;
+                    } else if (col <= rad) {
+                        tempval = (tempval * len + s[j + rad]) / (len + 1);
+                        len++;
+                        if (col == rad) reclen = 1.f / len;
+                    } else if (col < W - rad) {
+                        tempval = tempval + (s[j + rad] - s[j - rad - 1]) * reclen;
+                    } else {
+                        tempval = (tempval * len - s[j - rad - 1]) / (len - 1);
+                        len--;
+                    }
+                    oT[lane][j] = tempval;
+                }
             }
         }
         __syncthreads();
-        {
-            const int cend = min(HB_COLS, W - c0);
-            for (int k = 0; k < HB_ROWS; ++k) {
-                const int row = r0 + k;
-                if (row >= H) break;
-                if (lane < cend) dst[(size_t)row * W + c0 + lane] = oT[k][lane];
+        if (lane < cend) {
+            for (int k0 = 0; k0 < nrows; k0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = oT[(k0 + i) & (HB_ROWS - 1)][lane];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (k0 + i < nrows) dst[(size_t)(r0 + k0 + i) * W + c0 + lane] = v[i];
             }
         }
         __syncthreads();
@@ -280,11 +307,18 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
     const size_t nv4 = (a.n / 4) * 4;
     const float eps = 0.01f;
     const bool vec = col < (W / 4) * 4;
-    float tv;
+    float tv = 0.f;
     float lenf = (float)(rad + 1);
     int leni = rad + 1;
     float rlen = 0.f;
-    for (int row = 0; row < H; ++row) {
+    // coefficient update (FTblockDN.cc:698-714,803-836): vector lanes (c*num)/den, tail c*(num/den)
+    auto commit = [&](int row, float sfd, float sf, float c) {
+        const size_t i = (size_t)row * W + col;
+        const float num = sqr(sfd) + sqr(sf), den = sfd + sf + eps;
+        coef[i] = i < nv4 ? c * num / den : c * (num / den);
+    };
+    int row = 0;
+    for (; row <= rad && row < H; ++row) {
         if (row == 0) {
             if (vec) {
                 tv = t[col];
@@ -294,34 +328,53 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
                 tv = t[col] / leni;
                 for (int i = 1; i <= rad; i++) tv += t[(size_t)i * W + col] / leni;
             }
-        } else if (row <= rad) {
-            if (vec) {
-                const float lenp1 = lenf + 1.f;
-                tv = (tv * lenf + t[(size_t)(row + rad) * W + col]) / lenp1;
-                lenf = lenp1;
-                if (row == rad) rlen = 1.f / lenf;
-            } else {
-                tv = (tv * leni + t[(size_t)(row + rad) * W + col]) / (leni + 1);
-                leni++;
-            }
-        } else if (row < H - rad) {
-            const float d = t[(size_t)(row + rad) * W + col] - t[(size_t)(row - rad - 1) * W + col];
-            tv = vec ? tv + d * rlen : tv + d / leni;
+        } else if (vec) {
+            const float lenp1 = lenf + 1.f;
+            tv = (tv * lenf + t[(size_t)(row + rad) * W + col]) / lenp1;
+            lenf = lenp1;
         } else {
-            if (vec) {
-                const float lenm1 = lenf - 1.f;
-                tv = (tv * lenf - t[(size_t)(row - rad - 1) * W + col]) / lenm1;
-                lenf = lenm1;
-            } else {
-                tv = (tv * leni - t[(size_t)(row - rad - 1) * W + col]) / (leni - 1);
-                leni--;
-            }
+            tv = (tv * leni + t[(size_t)(row + rad) * W + col]) / (leni + 1);
+            leni++;
         }
-        // coefficient update (FTblockDN.cc:698-714,803-836): vector lanes (c*num)/den, tail c*(num/den)
         const size_t i = (size_t)row * W + col;
-        const float sf = sfave[i], sfd = tv, c = coef[i];
-        const float num = sqr(sfd) + sqr(sf), den = sfd + sf + eps;
-        coef[i] = i < nv4 ? c * num / den : c * (num / den);
+        commit(row, tv, sfave[i], coef[i]);
+    }
+    rlen = 1.f / lenf;
+    // steady state, 8 rows of independent loads in flight
+    const int steady_end = H - rad;
+    for (; row + 8 <= steady_end; row += 8) {
+        float hi[8], lo[8], sf[8], c[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            hi[k] = t[(size_t)(row + k + rad) * W + col];
+            lo[k] = t[(size_t)(row + k - rad - 1) * W + col];
+            sf[k] = sfave[(size_t)(row + k) * W + col];
+            c[k] = coef[(size_t)(row + k) * W + col];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float d = hi[k] - lo[k];
+            tv = vec ? tv + d * rlen : tv + d / leni;
+            commit(row + k, tv, sf[k], c[k]);
+        }
+    }
+    for (; row < steady_end; ++row) {
+        const float d = t[(size_t)(row + rad) * W + col] - t[(size_t)(row - rad - 1) * W + col];
+        tv = vec ? tv + d * rlen : tv + d / leni;
+        const size_t i = (size_t)row * W + col;
+        commit(row, tv, sfave[i], coef[i]);
+    }
+    for (; row < H; ++row) {
+        if (vec) {
+            const float lenm1 = lenf - 1.f;
+            tv = (tv * lenf - t[(size_t)(row - rad - 1) * W + col]) / lenm1;
+            lenf = lenm1;
+        } else {
+            tv = (tv * leni - t[(size_t)(row - rad - 1) * W + col]) / (leni - 1);
+            leni--;
+        }
+        const size_t i = (size_t)row * W + col;
+        commit(row, tv, sfave[i], coef[i]);
     }
 }
 
