@@ -8,6 +8,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
+#include <algorithm>
 
 #include "../../include/artgpu.h"
 #include "kernels.h"
@@ -26,7 +28,7 @@ struct artgpu_ctx {
     float *stage[NSTAGE] = {};
     size_t stage_bytes[NSTAGE] = {};
     // grow-only scratch pool for the denoise path (planes, decompositions, shrink buffers)
-    static constexpr int NPOOL = 16;
+    static constexpr int NPOOL = 20;
     float *pool[NPOOL] = {};
     size_t pool_bytes[NPOOL] = {};
     float *lut = nullptr; // 65536-entry tone LUT on the device
@@ -600,7 +602,7 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB };
 
 struct DevDecomp {
     float *bands, *low[2];
@@ -663,7 +665,8 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     if (!img || !p || !ws) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: null argument");
     if (p->aggressive) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: aggressive (QUALITY_HIGH) mode is not on the device path");
     if (p->color_space != 0) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: LAB colour space is not on the device path");
-    if (!(flags & ARTGPU_DN_SKIP_DETAIL_RECOVERY)) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: detail recovery (DCT) is not on the device path yet; pass ARTGPU_DN_SKIP_DETAIL_RECOVERY");
+    const bool do_detail = !(flags & ARTGPU_DN_SKIP_DETAIL_RECOVERY);
+    if (do_detail && p->luminance_detail_threshold > 0) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: luminanceDetailThreshold > 0 (detail_mask) is not on the device path yet");
     if (nresi || highresi) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: nresi/highresi (Noise_residualAB) not on the device path yet");
     if (!(scale >= 1.0)) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: scale must be >= 1");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -784,7 +787,53 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         HIPCHK(ctx, launch_hblur(bl, nsubL, ctx->stream));
         bl.src = tmp; bl.sfave = sf; bl.coef = Ld.bands;
         HIPCHK(ctx, launch_vblur_combine(bl, nsubL, ctx->stream));
+        float *Lin = nullptr;
+        if (do_detail) {
+            // copy labdn->L to Lin before it gets modified by reconstruction (L2423-2432)
+            if ((rc = pool_get(ctx, P_LIN, n * 4, &Lin))) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(Lin, L, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        }
         if ((rc = reconstruct_dev(ctx, Ld, L))) return rc;
+        if (do_detail) {
+            // ---- detail_recovery (L1479-1635): host-side tables exactly as the reference builds them
+            DetailArgs da = {};
+            da.w = w; da.h = h;
+            da.numblox_W = (int)std::ceil(((float)w) / 25) + 2;
+            da.numblox_H = (int)std::ceil(((float)h) / 25) + 2;
+            const float params_Ldetail = std::min(float(p->luminance_detail), 99.9f);
+            auto compute_detail = [](float dd) -> float { const float t = static_cast<float>((100. - dd) * (100. - dd) + 50. * (100. - dd)) * 64 * 0.5f; return t * t; };
+            da.detail_hi = compute_detail(params_Ldetail);
+            da.detail_lo = compute_detail(0.f);
+            { const int br = int(3 / scale); da.blur_rad = br > 1 ? br : 1; }
+            float *dtab;
+            if ((rc = pool_get(ctx, P_DTAB, 4 * 4096 * 4, &dtab))) return rc;
+            if ((rc = pool_get(ctx, P_BLOCKS, (size_t)da.numblox_W * da.numblox_H * 4096 * 4, &da.blocks))) return rc;
+            {
+                std::vector<float> host(4 * 4096);
+                float *tm_in = host.data(), *tm_out = tm_in + 4096, *ct = tm_out + 4096, *ctt = ct + 4096;
+                const float epsilon = 0.001f / (64 * 64);
+                const int border = 4; // MAX(2, TS/16)
+                for (int i = 0; i < 64; ++i) {
+                    const float i1 = std::abs((i > 32 ? i - 64 + 1 : i));
+                    const float vmask = (i1 < border ? (float)0 + (std::sin((M_PI * i1) / (2 * border)) * std::sin((M_PI * i1) / (2 * border))) : 1.0f);
+                    const float vmask2 = (i1 < 2 * border ? (std::sin((M_PI * i1) / (2 * border)) * std::sin((M_PI * i1) / (2 * border))) : 1.0f);
+                    for (int j = 0; j < 64; ++j) {
+                        const float j1 = std::abs((j > 32 ? j - 64 + 1 : j));
+                        const double sj = std::sin((M_PI * j1) / (2 * border));
+                        tm_in[i * 64 + j] = (vmask * (j1 < border ? sj * sj : 1.0f)) + epsilon;
+                        tm_out[i * 64 + j] = (vmask2 * (j1 < 2 * border ? sj * sj : 1.0f)) + epsilon;
+                        ct[i * 64 + j] = (float)std::cos(M_PI * (j + 0.5) * i / 64.0);
+                        ctt[j * 64 + i] = ct[i * 64 + j];
+                    }
+                }
+                HIPCHK(ctx, hipMemcpyAsync(dtab, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // host vector goes out of scope
+            }
+            da.tm_in = dtab; da.tm_out = dtab + 4096; da.costab = dtab + 2 * 4096; da.costab_t = dtab + 3 * 4096;
+            da.L = L; da.Lin = Lin;
+            HIPCHK(ctx, launch_detail_blocks(da, ctx->stream));
+            HIPCHK(ctx, launch_detail_gather(da, ctx->stream));
+        }
     }
 
     // ---- back to RGB (L2502-2550)

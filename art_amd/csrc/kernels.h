@@ -138,4 +138,18 @@ hipError_t launch_shrink_sf(const ShrinkArgs &a, int nsub, bool ab, hipStream_t 
 hipError_t launch_hblur(const BlurArgs &a, int nsub, hipStream_t s);
 hipError_t launch_vblur_combine(const BlurArgs &a, int nsub, hipStream_t s);
 
+// ---- DCT detail recovery (detail.hip) ----
+struct DetailArgs {
+    float *L;               // denoised luminance, updated in place by the gather kernel
+    const float *Lin;       // luminance before reconstruction
+    const float *tm_in, *tm_out;    // 64x64 tile masks
+    const float *costab, *costab_t; // C[k][j] = cos(pi (j+1/2) k / 64) and its transpose
+    float *blocks;          // numblox_H * numblox_W * 64 * 64
+    int w, h, numblox_W, numblox_H;
+    float detail_hi, detail_lo;
+    int blur_rad;
+};
+hipError_t launch_detail_blocks(const DetailArgs &a, hipStream_t s);
+hipError_t launch_detail_gather(const DetailArgs &a, hipStream_t s);
+
 } // namespace artgpu

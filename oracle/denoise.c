@@ -230,7 +230,7 @@ static inline float gammaf_s(float x, float gamma, float start, float slope)
 }
 
 int oracle_rgb_denoise(float *const img[3], size_t stride, int w, int h, const oracle_denoise_params *p,
-                       const float wpi[9], const float *noisevarchrom_in, float *Lin_out, float *Lden_out)
+                       const float wpi[9], const float *noisevarchrom_in, float *Lin_out, float *Lden_out, int detail_recovery)
 {
     const double scale = p->scale > 0 ? p->scale : 1.0;
     const float noiseluma = (float)p->luminance;
@@ -320,13 +320,18 @@ int oracle_rgb_denoise(float *const img[3], size_t stride, int w, int h, const o
         const int maxlvl = levwav < 5 ? levwav : 5;
         for (int lvl = 0; lvl < maxlvl; ++lvl)
             for (int dir = 1; dir < 4; ++dir) oracle_shrink_all_L(Ldecomp, lvl, dir, noisevarlum, madL[lvl], scale);
+        float *Lin = (float *)malloc(sizeof(float) * n);
+        memcpy(Lin, labL, sizeof(float) * n);
         if (Lin_out) memcpy(Lin_out, labL, sizeof(float) * n);
         oracle_wavelet_reconstruct(Ldecomp, labL, 1.f);
+        if (Lden_out) memcpy(Lden_out, labL, sizeof(float) * n);
+        if (detail_recovery) {
+            float params_Ldetail = rt_minf((float)p->luminanceDetail, 99.9f);
+            oracle_detail_recovery(w, h, labL, Lin, params_Ldetail, scale);
+        }
+        free(Lin);
     }
     oracle_wavelet_free(Ldecomp);
-    if (Lden_out) memcpy(Lden_out, labL, sizeof(float) * n);
-
-    /* (detail recovery goes here: FTblockDN.cc:2453) */
 
     /* chroma boost, YUV -> RGB, inverse gamma (L2502-2550); numtiles == 1 */
     const float qhighFactor = 1.0f;

@@ -1,0 +1,184 @@
+/*
+ * oracle/detail.c -- CPU restatement of detail_recovery (reference: rtengine/FTblockDN.cc:1479-1635)
+ * with RGBtile_denoise (L494-525), RGBoutput_tile_row (L531-558), the tile masks (L1828-1846) and
+ * boxabsblur (rtengine/boxblur.h:745-886), for luminanceDetailThreshold == 0 (no detail_mask).
+ *
+ * TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED, and not pinnable at the bit level: the reference
+ * calls FFTW3 (fftwf_plan_many_r2r, FFTW_REDFT10 / FFTW_REDFT01, FFTW_MEASURE; L1604,1614,1924-1931),
+ * a system library that is not part of /root/reference and not installed here; its round-off
+ * depends on the planner's codelet choice, so the reference itself is not reproducible at the ULP
+ * level across machines.  This restatement evaluates FFTW's documented definitions
+ *     REDFT10: Y_k = 2 sum_j X_j cos(pi (j+1/2) k / n)
+ *     REDFT01: Y_k = X_0 + 2 sum_{j>=1} X_j cos(pi j (k+1/2) / n)
+ * directly with double accumulation (rounded to float per 1-D pass, like FFTW's float plans), and
+ * tests compare the device result with a tolerance.  Block accumulation order: vblk ascending,
+ * hblk ascending (the reference's serial order; its OpenMP loop over vblk also races on totwt).
+ */
+#include "oracle.h"
+#include "oracle_common.h"
+#include <stdlib.h>
+
+#define DTS 64
+#define DOFF 25
+#define DBLKRAD 1
+
+void oracle_detail_tilemasks(float *tilemask_in, float *tilemask_out)
+{
+    const float epsilon = 0.001f / (DTS * DTS);
+    const int border = 4; /* MAX(2, TS/16) */
+    for (int i = 0; i < DTS; ++i) {
+        float i1 = abs((i > DTS / 2 ? i - DTS + 1 : i));
+        float vmask = (i1 < border ? sqr_d(sin((M_PI * i1) / (2 * border))) : 1.0f);
+        float vmask2 = (i1 < 2 * border ? sqr_d(sin((M_PI * i1) / (2 * border))) : 1.0f);
+        for (int j = 0; j < DTS; ++j) {
+            float j1 = abs((j > DTS / 2 ? j - DTS + 1 : j));
+            tilemask_in[i * DTS + j] = (vmask * (j1 < border ? sqr_d(sin((M_PI * j1) / (2 * border))) : 1.0f)) + epsilon;
+            tilemask_out[i * DTS + j] = (vmask2 * (j1 < 2 * border ? sqr_d(sin((M_PI * j1) / (2 * border))) : 1.0f)) + epsilon;
+        }
+    }
+}
+
+float oracle_detail_factor(float d)
+{
+    /* compute_detail (L1482-1486) */
+    float t = (float)(((100. - d) * (100. - d)) + 50. * (100. - d)) * DTS * 0.5f;
+    return t * t;
+}
+
+static void dct2d(float *blk, const double *costab, int inverse)
+{
+    /* costab[k*64+j] = cos(pi*(j+0.5)*k/64).  Rows then columns; float storage between passes. */
+    float tmp[DTS * DTS];
+    for (int pass = 0; pass < 2; ++pass) {
+        const float *src = pass == 0 ? blk : tmp;
+        float *dst = pass == 0 ? tmp : blk;
+        for (int r = 0; r < DTS; ++r)      /* line index in the non-transformed dimension */
+            for (int k = 0; k < DTS; ++k) { /* output index */
+                double acc;
+                if (!inverse) {
+                    acc = 0.0;
+                    for (int j = 0; j < DTS; ++j) acc += (double)(pass == 0 ? src[r * DTS + j] : src[j * DTS + r]) * costab[k * DTS + j];
+                    acc *= 2.0;
+                } else {
+                    acc = (double)(pass == 0 ? src[r * DTS] : src[r]);
+                    for (int j = 1; j < DTS; ++j) acc += 2.0 * (double)(pass == 0 ? src[r * DTS + j] : src[j * DTS + r]) * costab[j * DTS + k];
+                }
+                if (pass == 0) dst[r * DTS + k] = (float)acc; else dst[k * DTS + r] = (float)acc;
+            }
+    }
+}
+
+static void boxabsblur64(const float *src, float *dst, int rad)
+{
+    float temp[DTS * DTS];
+    for (int row = 0; row < DTS; row++) {
+        const float *s = src + row * DTS;
+        int len = rad + 1;
+        float tempval = fabsf(s[0]);
+        for (int j = 1; j <= rad; j++) tempval += fabsf(s[j]);
+        tempval /= len;
+        temp[row * DTS] = tempval;
+        for (int col = 1; col <= rad; col++) {
+            tempval = (tempval * len + fabsf(s[col + rad])) / (len + 1);
+            temp[row * DTS + col] = tempval;
+            len++;
+        }
+        float rlen = 1.f / (float)len;
+        for (int col = rad + 1; col < DTS - rad; col++) {
+            tempval = tempval + ((float)(fabsf(s[col + rad]) - fabsf(s[col - rad - 1]))) * rlen;
+            temp[row * DTS + col] = tempval;
+        }
+        for (int col = DTS - rad; col < DTS; col++) {
+            tempval = (tempval * len - fabsf(s[col - rad - 1])) / (len - 1);
+            temp[row * DTS + col] = tempval;
+            len--;
+        }
+    }
+    for (int col = 0; col < DTS; ++col) { /* W % 4 == 0: every column takes the SSE form */
+        float len = (float)(rad + 1);
+        float tv = temp[col];
+        for (int i = 1; i <= rad; i++) tv = tv + temp[i * DTS + col];
+        tv = tv / len;
+        dst[col] = tv;
+        for (int row = 1; row <= rad; row++) {
+            float lenp1 = len + 1.f;
+            tv = (tv * len + temp[(row + rad) * DTS + col]) / lenp1;
+            dst[row * DTS + col] = tv;
+            len = lenp1;
+        }
+        float rlen = 1.f / len;
+        for (int row = rad + 1; row < DTS - rad; row++) {
+            tv = tv + (temp[(row + rad) * DTS + col] - temp[(row - rad - 1) * DTS + col]) * rlen;
+            dst[row * DTS + col] = tv;
+        }
+        for (int row = DTS - rad; row < DTS; row++) {
+            float lenm1 = len - 1.f;
+            tv = (tv * len - temp[(row - rad - 1) * DTS + col]) / lenm1;
+            dst[row * DTS + col] = tv;
+            len = lenm1;
+        }
+    }
+}
+
+void oracle_detail_recovery(int width, int height, float *L, const float *Lin, float params_Ldetail, double scale)
+{
+    const float detail_hi = oracle_detail_factor(params_Ldetail), detail_lo = oracle_detail_factor(0.f);
+    const int numblox_W = (int)ceil(((float)width) / DOFF) + 2 * DBLKRAD;
+    const int numblox_H = (int)ceil(((float)height) / DOFF) + 2 * DBLKRAD;
+    float tm_in[DTS * DTS], tm_out[DTS * DTS];
+    oracle_detail_tilemasks(tm_in, tm_out);
+    double *costab = (double *)malloc(sizeof(double) * DTS * DTS);
+    for (int k = 0; k < DTS; ++k)
+        for (int j = 0; j < DTS; ++j) costab[k * DTS + j] = cos(M_PI * (j + 0.5) * k / DTS);
+    const float DCTnorm = 1.0f / (4 * DTS * DTS);
+    const int blur_rad = (int)(3 / scale) > 1 ? (int)(3 / scale) : 1;
+    const size_t n = (size_t)width * height;
+    float *Ldetail = (float *)calloc(n, sizeof(float)), *totwt = (float *)calloc(n, sizeof(float));
+    /* block results first (parallel), accumulation afterwards in the reference's serial order */
+    float *blocks = (float *)malloc(sizeof(float) * (size_t)numblox_W * numblox_H * DTS * DTS);
+#pragma omp parallel for collapse(2) schedule(dynamic)
+    for (int vblk = 0; vblk < numblox_H; ++vblk)
+        for (int hblk = 0; hblk < numblox_W; ++hblk) {
+            float *blk = blocks + ((size_t)vblk * numblox_W + hblk) * DTS * DTS;
+            float factor[DTS * DTS], nbrwt[DTS * DTS];
+            const int top = (vblk - DBLKRAD) * DOFF, left = (hblk - DBLKRAD) * DOFF;
+            for (int i = 0; i < DTS; ++i) {
+                int row = top + i, rr = row;
+                if (row < 0) rr = -row < height - 1 ? -row : height - 1;
+                else if (row >= height) rr = 2 * height - 2 - row > 0 ? 2 * height - 2 - row : 0;
+                for (int j = 0; j < DTS; ++j) {
+                    int col = left + j, cc = col;
+                    /* datarow padding (L1556-1562) */
+                    if (col < 0) cc = -col < width - 1 ? -col : width - 1;
+                    else if (col >= width) cc = 2 * width - 2 - col > 0 ? 2 * width - 2 - col : 0;
+                    const float v = Lin[(size_t)rr * width + cc] - L[(size_t)rr * width + cc];
+                    blk[i * DTS + j] = tm_in[i * DTS + j] * v;
+                    factor[i * DTS + j] = (row >= 0 && row < height && col >= 0 && col < width) ? detail_hi : detail_lo;
+                }
+            }
+            dct2d(blk, costab, 0);
+            boxabsblur64(blk, nbrwt, blur_rad);
+            for (int k = 0; k < DTS * DTS; ++k) blk[k] = blk[k] * (1.0f - oracle_xexpf_v(-sqrf(nbrwt[k]) / factor[k]));
+            dct2d(blk, costab, 1);
+        }
+    for (int vblk = 0; vblk < numblox_H; ++vblk) {
+        const int top = (vblk - DBLKRAD) * DOFF;
+        for (int i = 0; i < DTS; ++i) {
+            const int y = top + i;
+            if (y < 0 || y >= height) continue;
+            for (int hblk = 0; hblk < numblox_W; ++hblk) {
+                const int left = (hblk - DBLKRAD) * DOFF;
+                const float *blk = blocks + ((size_t)vblk * numblox_W + hblk) * DTS * DTS;
+                for (int j = 0; j < DTS; ++j) {
+                    const int x = left + j;
+                    if (x < 0 || x >= width) continue;
+                    Ldetail[(size_t)y * width + x] += tm_out[i * DTS + j] * blk[i * DTS + j] * DCTnorm;
+                    totwt[(size_t)y * width + x] += tm_in[i * DTS + j] * tm_out[i * DTS + j];
+                }
+            }
+        }
+    }
+#pragma omp parallel for
+    for (long long k = 0; k < (long long)n; ++k) L[k] += Ldetail[k] / totwt[k];
+    free(blocks); free(Ldetail); free(totwt); free(costab);
+}

@@ -63,7 +63,12 @@ void oracle_shrink_all_AB(const oracle_wavelet *L, oracle_wavelet *ab, int level
                           float noisevar_ab, int useNoiseCCurve, int autoch, const float *madL3, double scale);
 void oracle_gamma_lut(float *lut, float gamma, float start, float slope, float divisor, float factor);
 int oracle_rgb_denoise(float *const img[3], size_t stride, int w, int h, const oracle_denoise_params *p,
-                       const float wpi[9], const float *noisevarchrom_in, float *Lin_out, float *Lden_out);
+                       const float wpi[9], const float *noisevarchrom_in, float *Lin_out, float *Lden_out, int detail_recovery);
+
+/* DCT detail recovery (oracle/detail.c) */
+void oracle_detail_tilemasks(float *tilemask_in, float *tilemask_out);
+float oracle_detail_factor(float d);
+void oracle_detail_recovery(int width, int height, float *L, const float *Lin, float params_Ldetail, double scale);
 
 /* sleef-derived math (oracle/sleef.c); _s = scalar form, _v = per-lane SSE form */
 float oracle_xexpf_s(float d);

@@ -39,6 +39,7 @@ static inline float sse_maxf(float x, float y) { return x > y ? x : y; }
 static inline float rt_minf(float a, float b) { return b < a ? b : a; }
 static inline float rt_maxf(float a, float b) { return a < b ? b : a; }
 static inline float sqrf(float x) { return x * x; }
+static inline double sqr_d(double x) { return x * x; }
 static inline float intpf(float a, float b, float c) { return a * b + (1.f - a) * c; }
 static inline float median3_sse(float a, float b, float c)
 {

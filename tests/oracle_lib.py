@@ -174,7 +174,7 @@ REC2020_WS = np.array([[0.6734241, 0.1656411, 0.1251286],
                        [-0.0019300, 0.0299784, 0.7973330]], dtype=np.float32)
 
 
-def rgb_denoise(img, params=None, wpi=REC2020_WS, noisevarchrom=None, want_L=False):
+def rgb_denoise(img, params=None, wpi=REC2020_WS, noisevarchrom=None, want_L=False, detail_recovery=False):
     img = [np.array(p, dtype=np.float32, order="C") for p in img]
     h, w = img[0].shape
     params = params or default_denoise_params()
@@ -183,7 +183,7 @@ def rgb_denoise(img, params=None, wpi=REC2020_WS, noisevarchrom=None, want_L=Fal
     Lin = np.zeros((h, w), np.float32) if want_L else None
     Lden = np.zeros((h, w), np.float32) if want_L else None
     rc = lib().oracle_rgb_denoise(_p3(img), C.c_size_t(w), w, h, C.byref(params), _ptr(wp), nvc,
-                                  _ptr(Lin) if want_L else None, _ptr(Lden) if want_L else None)
+                                  _ptr(Lin) if want_L else None, _ptr(Lden) if want_L else None, int(detail_recovery))
     assert rc == 0
     return (img, Lin, Lden) if want_L else img
 

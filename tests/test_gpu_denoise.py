@@ -63,4 +63,23 @@ def test_unsupported_modes_fail_loudly(gpu_ctx):
     with pytest.raises(capi.ArtGpuError):
         gpu_ctx.rgb_denoise(capi.host_rgb(img), _params(aggressive=1), O.REC2020_WS)
     with pytest.raises(capi.ArtGpuError):
-        gpu_ctx.rgb_denoise(capi.host_rgb(img), _params(), O.REC2020_WS, flags=0)   # DCT detail recovery not built yet
+        gpu_ctx.rgb_denoise(capi.host_rgb(img), _params(luminance_detail_threshold=30), O.REC2020_WS, flags=0)   # detail_mask not built yet
+
+
+@pytest.mark.parametrize("w,h,detail", [(640, 480, 50.0), (517, 389, 80.0), (330, 260, 0.0)])
+def test_rgb_denoise_with_detail_recovery_tolerance(gpu_ctx, w, h, detail):
+    """detail_recovery goes through a third-party DCT in the reference (FFTW, not reproducible);
+    the device evaluates the same DCT-II/III definitions in fp32, the oracle with double
+    accumulation: agreement to <= 2e-5 of full scale and identical everywhere the stage is exact."""
+    from art_amd import capi
+    img = _rgb(w, h, w + 1)
+    got = [p.copy() for p in img]
+    gpu_ctx.rgb_denoise(capi.host_rgb(got), _params(luminance_detail=detail), O.REC2020_WS, flags=0)
+    ref = O.rgb_denoise(img, O.default_denoise_params(luminanceDetail=detail), detail_recovery=True)
+    nodetail = O.rgb_denoise(img, O.default_denoise_params(luminanceDetail=detail), detail_recovery=False)
+    for g, r, nd in zip(got, ref, nodetail):
+        err = np.abs(g.astype(np.float64) - r.astype(np.float64))
+        assert err.max() <= 65535.0 * 2e-5, err.max()
+        assert np.median(err) <= 0.02
+        # the stage really ran: result is far from the no-detail-recovery image
+        assert np.abs(r - nd).max() > 50.0
