@@ -6,14 +6,15 @@
 // FFTW_MEASURE, L1604,1614,1924-1931): a third-party library whose round-off is not reproducible,
 // so this stage is compared with a tolerance, everything else on the path is
 // bit-exact.  Here one WAVE owns one block: each lane keeps a 64-sample line in registers and
-// evaluates FFTW's documented DCT-II / DCT-III definitions against a cosine table read through
-// the scalar cache (wave-uniform addresses), two LDS transposes per transform.  64 lanes x
-// 4 passes x 4096 FMA = 1.05 M FMA per block, ~73 k blocks per 45 MP frame: VALU-bound (~1 ms).
+// runs a straight-line fast DCT-II / DCT-III on it (dct64.h, Lee's recursion: ~770 VALU ops per
+// line instead of 4096), with one LDS transpose between the two dimensions of each transform.
+// ~73 k blocks per 45 MP frame; VALU-bound.
 // Block results go to a block buffer; a second kernel sums the up-to-9 overlapping blocks per
 // pixel in the reference's serial order (vblk, then hblk) -- deterministic, no float atomics.
 #include <hip/hip_runtime.h>
 #include "devmath.h"
 #include "devsleef.h"
+#include "dct64.h"
 #include "kernels.h"
 
 namespace artgpu {
@@ -34,11 +35,10 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
     __shared__ float T[TS][TS + 1];
     __shared__ float N[TS][TS + 1];
     const int lane = threadIdx.x;
+    constexpr int wv = 0;
     const int blk = blockIdx.x;
     const int vblk = blk / a.numblox_W, hblk = blk - vblk * a.numblox_W;
     const int top = (vblk - BLKRAD) * OFF, left = (hblk - BLKRAD) * OFF;
-    const float *__restrict__ C = a.costab;   // C[k][j]  = cos(pi (j+1/2) k / 64)
-    const float *__restrict__ Ct = a.costab_t; // Ct[j][k] = C[k][j]
     float x[TS];
 
     // 1. load: lane = column j; x[i] = tilemask_in[i][j] * (Lin - L)(top+i, left+j), reflected
@@ -51,35 +51,21 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
             x[i] = a.tm_in[i * TS + lane] * (a.Lin[o] - a.L[o]);
         }
     }
-    // 2. DCT-II along i (REDFT10: 2 sum x_i cos(pi (i+1/2) k / n)) -> T[k][j]
-    for (int k = 0; k < TS; k += 2) {
-        float acc0 = 0.f, acc1 = 0.f;
+    // 2. REDFT10 along i (= 2 * DCT-II) -> T[k][j]
+    lee_fwd<TS>(x);
 #pragma unroll
-        for (int i = 0; i < TS; ++i) {
-            acc0 = fmaf(x[i], C[k * TS + i], acc0);
-            acc1 = fmaf(x[i], C[(k + 1) * TS + i], acc1);
-        }
-        T[k][lane] = 2.f * acc0;
-        T[k + 1][lane] = 2.f * acc1;
-    }
+    for (int k = 0; k < TS; ++k) T[k][lane] = 2.f * x[k];
     __syncthreads();
-    // 3. DCT-II along j: lane = row k
+    // 3. REDFT10 along j: lane = row k
 #pragma unroll
     for (int j = 0; j < TS; ++j) x[j] = T[lane][j];
-    for (int m = 0; m < TS; m += 2) {
-        float acc0 = 0.f, acc1 = 0.f;
+    lee_fwd<TS>(x);
 #pragma unroll
-        for (int j = 0; j < TS; ++j) {
-            acc0 = fmaf(x[j], C[m * TS + j], acc0);
-            acc1 = fmaf(x[j], C[(m + 1) * TS + j], acc1);
-        }
-        T[lane][m] = 2.f * acc0;
-        T[lane][m + 1] = 2.f * acc1;
-    }
+    for (int m = 0; m < TS; ++m) T[lane][m] = 2.f * x[m];
     __syncthreads();
-    // 4. boxabsblur of the coefficients, radius `rad` (boxblur.h:745-886): rows (lane = row) ...
+    // 4. boxabsblur of the coefficients, radius `rad` (boxblur.h:745-886): rows (lane = row), wave 0 only
     const int rad = a.blur_rad;
-    {
+    if (wv == 0) {
         const float *s = &T[lane][0];
         int len = rad + 1;
         float tempval = fabsf(s[0]);
@@ -103,8 +89,8 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
         }
     }
     __syncthreads();
-    // ... then columns (lane = column m), shrink, and keep the column of Y' in registers
-    {
+    // ... then columns (lane = column m) and the shrink
+    if (wv == 0) {
         float lenf = (float)(rad + 1);
         float tv = N[0][lane];
         for (int i = 1; i <= rad; i++) tv = tv + N[i][lane];
@@ -133,34 +119,21 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
         }
     }
     __syncthreads();
-    // 5. DCT-III along k (REDFT01: y_0 + 2 sum_{k>=1} y_k cos(pi k (i+1/2) / n)): lane = column m
+    // 5. REDFT01 along k (= DCT-III of (X0, 2 X1, 2 X2, ...)): lane = column m
+    x[0] = T[0][lane];
 #pragma unroll
-    for (int k = 0; k < TS; ++k) x[k] = T[k][lane];
+    for (int k = 1; k < TS; ++k) x[k] = 2.f * T[k][lane];
+    lee_inv<TS>(x);
+#pragma unroll
+    for (int i = 0; i < TS; ++i) T[i][lane] = x[i];
     __syncthreads();
-    for (int i = 0; i < TS; i += 2) {
-        float acc0 = 0.f, acc1 = 0.f;
+    // 6. REDFT01 along m: lane = row i
+    x[0] = T[lane][0];
 #pragma unroll
-        for (int k = 1; k < TS; ++k) {
-            acc0 = fmaf(x[k], Ct[i * TS + k], acc0);
-            acc1 = fmaf(x[k], Ct[(i + 1) * TS + k], acc1);
-        }
-        T[i][lane] = x[0] + 2.f * acc0;
-        T[i + 1][lane] = x[0] + 2.f * acc1;
-    }
-    __syncthreads();
-    // 6. DCT-III along m: lane = row i
+    for (int m = 1; m < TS; ++m) x[m] = 2.f * T[lane][m];
+    lee_inv<TS>(x);
 #pragma unroll
-    for (int m = 0; m < TS; ++m) x[m] = T[lane][m];
-    for (int j = 0; j < TS; j += 2) {
-        float acc0 = 0.f, acc1 = 0.f;
-#pragma unroll
-        for (int m = 1; m < TS; ++m) {
-            acc0 = fmaf(x[m], Ct[j * TS + m], acc0);
-            acc1 = fmaf(x[m], Ct[(j + 1) * TS + m], acc1);
-        }
-        T[lane][j] = x[0] + 2.f * acc0;
-        T[lane][j + 1] = x[0] + 2.f * acc1;
-    }
+    for (int j = 0; j < TS; ++j) T[lane][j] = x[j];
     __syncthreads();
     // 7. store the block, coalesced rows
     float *out = a.blocks + (size_t)blk * TS * TS;

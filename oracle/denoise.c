@@ -304,12 +304,14 @@ int oracle_rgb_denoise(float *const img[3], size_t stride, int w, int h, const o
 
     oracle_wavelet *Ldecomp = oracle_wavelet_decompose(labL, w, h, levwav);
     float madL[8][3];
+#pragma omp parallel for collapse(2) schedule(dynamic)
     for (int lvl = 0; lvl < levwav; ++lvl)
         for (int dir = 1; dir < 4; ++dir) madL[lvl][dir - 1] = sqrf(oracle_madrgb(Ldecomp->band[lvl][dir], (int)n2));
 
     for (int ch = 0; ch < 2; ++ch) {
         float *plane = ch == 0 ? laba : labb;
         oracle_wavelet *d = oracle_wavelet_decompose(plane, w, h, levwav);
+#pragma omp parallel for collapse(2) schedule(dynamic)
         for (int lvl = 0; lvl < levwav; ++lvl)
             for (int dir = 1; dir < 4; ++dir)
                 oracle_shrink_all_AB(Ldecomp, d, lvl, dir, noisevarchrom, ch == 0 ? noisevarab_r : noisevarab_b, useNoiseCCurve, p->autoch, madL[lvl], scale);
@@ -318,6 +320,7 @@ int oracle_rgb_denoise(float *const img[3], size_t stride, int w, int h, const o
     }
     if (denoiseLuminance) {
         const int maxlvl = levwav < 5 ? levwav : 5;
+#pragma omp parallel for collapse(2) schedule(dynamic)
         for (int lvl = 0; lvl < maxlvl; ++lvl)
             for (int dir = 1; dir < 4; ++dir) oracle_shrink_all_L(Ldecomp, lvl, dir, noisevarlum, madL[lvl], scale);
         float *Lin = (float *)malloc(sizeof(float) * n);
