@@ -1,0 +1,127 @@
+// art_amd/host/artgpu_cli.cc -- command-line counterpart of ART-cli for the hot path
+// (reference: rtgui/main-cli.cc:786-903 -> rtengine/simpleprocess.cc:75-420): load a CFA frame,
+// run stage_init (demosaic, getImage), stage_denoise (convertColorSpace, denoise), stage_finish
+// (process STAGE_1..3) on the GPU through the rtengine-shaped classes of rtengine_gpu.h, write a
+// 16-bit PPM.  Input: raw little-endian float32 (values 0..65535) or uint16, W*H samples.
+//
+//   artgpu-cli --in frame.f32 --width 4000 --height 3000 [--u16] [--filters 0x94949494]
+//              [--method amaze|rcd] [--border 4] [--denoise L,C] [--expcomp 0.3] [--out out.ppm]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+#include "rtengine_gpu.h"
+
+using namespace artgpu_host;
+
+static std::vector<float> default_tone_lut()
+{
+    // a fixed S-curve (an input of the tone stage; ART builds it from the user's DiagonalCurve, curves.cc:221-231)
+    std::vector<float> lut(65536);
+    for (int i = 0; i < 65536; ++i) {
+        const double x = i / 65535.0;
+        lut[i] = (float)((1.0 - std::cos(M_PI * std::pow(x, 0.7))) / 2.0 * 65535.0);
+    }
+    return lut;
+}
+
+int main(int argc, char **argv)
+{
+    std::string in, out;
+    int W = 0, H = 0, border = 4, method = ARTGPU_BAYER_AMAZE;
+    bool u16 = false;
+    uint32_t filters = 0x94949494u;
+    double lum = 0, chroma = 0, expcomp = 0;
+    bool dn = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
+        if (a == "--in") in = next();
+        else if (a == "--out") out = next();
+        else if (a == "--width") W = std::atoi(next());
+        else if (a == "--height") H = std::atoi(next());
+        else if (a == "--u16") u16 = true;
+        else if (a == "--filters") filters = (uint32_t)std::strtoul(next(), nullptr, 0);
+        else if (a == "--border") border = std::atoi(next());
+        else if (a == "--expcomp") expcomp = std::atof(next());
+        else if (a == "--method") { std::string m = next(); method = (m == "rcd") ? ARTGPU_BAYER_RCD : ARTGPU_BAYER_AMAZE; }
+        else if (a == "--denoise") { dn = true; if (std::sscanf(next(), "%lf,%lf", &lum, &chroma) != 2) { std::fprintf(stderr, "--denoise L,C\n"); return 2; } }
+        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    if (in.empty() || W <= 0 || H <= 0) { std::fprintf(stderr, "usage: artgpu-cli --in frame.f32 --width W --height H [options]\n"); return 2; }
+    try {
+        std::vector<float> cfa((size_t)W * H);
+        std::ifstream f(in, std::ios::binary);
+        if (!f) throw std::runtime_error("cannot open " + in);
+        if (u16) {
+            std::vector<uint16_t> t((size_t)W * H);
+            f.read(reinterpret_cast<char *>(t.data()), (std::streamsize)t.size() * 2);
+            for (size_t k = 0; k < t.size(); ++k) cfa[k] = (float)t[k];
+        } else {
+            f.read(reinterpret_cast<char *>(cfa.data()), (std::streamsize)cfa.size() * 4);
+        }
+        if (!f) throw std::runtime_error("short read on " + in);
+
+        Context ctx(0);
+        ProcParams params;
+        params.bayersensor.method = method;
+        params.bayersensor.border = border;
+        params.denoise.enabled = dn; params.denoise.luminance = lum; params.denoise.chrominance = chroma; params.denoise.luminanceDetail = 50;
+        params.exposure.expcomp = expcomp;
+        params.toneCurve.lut = default_tone_lut();
+
+        auto t0 = std::chrono::steady_clock::now();
+        // stage_init (simpleprocess.cc:215-259)
+        RawImageSource imgsrc(ctx, W, H, filters, 1.0);
+        imgsrc.setBorder(border);
+        imgsrc.load(cfa.data());
+        imgsrc.demosaic(params);
+        int fw, fh;
+        imgsrc.getFullSize(fw, fh);
+        Imagefloat img(fw, fh);
+        const float mul[3] = {2.1374f, 1.0f, 1.5918f};
+        imgsrc.getImage(mul, true, &img);
+        // stage_denoise (simpleprocess.cc:311-315)
+        const double mat[9] = {0.6325, 0.2312, 0.0921, 0.2198, 0.7712, 0.0090, 0.0166, 0.0713, 0.7514};
+        imgsrc.convertColorSpace(&img, mat);
+        ImProcFunctions ipf(ctx, &params, 1.0);
+        ipf.denoise(&img);
+        // stage_finish (simpleprocess.cc:389-396)
+        ipf.process(ImProcFunctions::Pipeline::OUTPUT, ImProcFunctions::Stage::STAGE_1, &img);
+        ipf.process(ImProcFunctions::Pipeline::OUTPUT, ImProcFunctions::Stage::STAGE_2, &img);
+        ipf.process(ImProcFunctions::Pipeline::OUTPUT, ImProcFunctions::Stage::STAGE_3, &img);
+        ctx.synchronize();
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+        std::vector<float> r((size_t)fw * fh), g(r.size()), b(r.size());
+        img.r.download(r.data()); img.g.download(g.data()); img.b.download(b.data());
+        double sum = 0;
+        for (size_t k = 0; k < r.size(); ++k) sum += r[k] + g[k] + b[k];
+        if (!out.empty()) {
+            std::ofstream o(out, std::ios::binary);
+            o << "P6\n" << fw << " " << fh << "\n65535\n";
+            std::vector<unsigned char> row((size_t)fw * 6);
+            for (int y = 0; y < fh; ++y) {
+                for (int x = 0; x < fw; ++x) {
+                    const float v[3] = {r[(size_t)y * fw + x], g[(size_t)y * fw + x], b[(size_t)y * fw + x]};
+                    for (int c = 0; c < 3; ++c) {
+                        const int q = (int)std::lrint(std::fmin(std::fmax(v[c], 0.f), 65535.f));
+                        row[(size_t)x * 6 + 2 * c] = (unsigned char)(q >> 8);
+                        row[(size_t)x * 6 + 2 * c + 1] = (unsigned char)(q & 255);
+                    }
+                }
+                o.write(reinterpret_cast<char *>(row.data()), (std::streamsize)row.size());
+            }
+        }
+        std::printf("{\"width\": %d, \"height\": %d, \"out_width\": %d, \"out_height\": %d, \"total_ms_incl_io\": %.3f, \"mean\": %.4f}\n",
+                    W, H, fw, fh, ms, sum / (3.0 * r.size()));
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "artgpu-cli: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,178 @@
+// art_amd/host/rtengine_gpu.h -- C++ host-side mirror of the rtengine classes on the hot path, over the
+// C ABI of include/artgpu.h.  Same method names, argument meaning and call order as the reference, so
+// that a caller written against rtengine (rtgui/main-cli.cc:786-903, rtengine/simpleprocess.cc:75-420)
+// reads the same:
+//   RawImageSource::{demosaic, getImage, convertColorSpace, setBorder}   rawimagesource.h:119-136,266-290
+//   ImProcFunctions::{process, exposure, toneCurve, denoise}             improcfun.h:95,132-133,147,150
+//   Imagefloat (planar fp32 R|G|B, row stride ceil16(W*4))               iimage.h:653-720
+// Frames stay resident in HBM between stages (on_device planes).  Error behaviour: the reference
+// methods return void; here a failing artgpu_* call throws std::runtime_error with the library's
+// message -- an adapter inside ART would instead fall through to the CPU code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/artgpu.h"
+
+namespace artgpu_host {
+
+inline void hipcheck(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+class Context {
+public:
+    explicit Context(int device = 0) { if (artgpu_create(device, &ctx_) != 0) throw std::runtime_error("artgpu_create failed"); }
+    ~Context() { if (ctx_) artgpu_destroy(ctx_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    artgpu_ctx *get() const { return ctx_; }
+    void check(int rc) const { if (rc != 0) throw std::runtime_error(std::string("artgpu: ") + artgpu_last_error(ctx_)); }
+    void synchronize() const { check(artgpu_synchronize(ctx_)); }
+private:
+    artgpu_ctx *ctx_ = nullptr;
+};
+
+// One fp32 plane in HBM (array2D<float> counterpart; rows contiguous, stride W*4)
+class DevicePlane {
+public:
+    DevicePlane() = default;
+    DevicePlane(int w, int h, int64_t stride_bytes = 0) { alloc(w, h, stride_bytes); }
+    ~DevicePlane() { release(); }
+    DevicePlane(const DevicePlane &) = delete;
+    DevicePlane &operator=(const DevicePlane &) = delete;
+    void alloc(int w, int h, int64_t stride_bytes = 0)
+    {
+        release();
+        w_ = w; h_ = h; stride_ = stride_bytes ? stride_bytes : (int64_t)w * 4;
+        hipcheck(hipMalloc(reinterpret_cast<void **>(&p_), (size_t)stride_ * h), "hipMalloc(plane)");
+    }
+    void release() { if (p_) { (void)hipFree(p_); p_ = nullptr; } }
+    void upload(const float *host) { hipcheck(hipMemcpy2D(p_, (size_t)stride_, host, (size_t)w_ * 4, (size_t)w_ * 4, h_, hipMemcpyHostToDevice), "upload"); }
+    void download(float *host) const { hipcheck(hipMemcpy2D(host, (size_t)w_ * 4, p_, (size_t)stride_, (size_t)w_ * 4, h_, hipMemcpyDeviceToHost), "download"); }
+    artgpu_plane view() const { return artgpu_plane{p_, w_, h_, stride_, 1}; }
+    int width() const { return w_; }
+    int height() const { return h_; }
+private:
+    float *p_ = nullptr;
+    int w_ = 0, h_ = 0;
+    int64_t stride_ = 0;
+};
+
+// rtengine::Imagefloat counterpart: three planes, row stride ceil16(W*4) bytes (iimage.h:653-720)
+class Imagefloat {
+public:
+    Imagefloat(int w, int h) : r(w, h, ((int64_t)w * 4 + 15) / 16 * 16), g(w, h, ((int64_t)w * 4 + 15) / 16 * 16), b(w, h, ((int64_t)w * 4 + 15) / 16 * 16) {}
+    int getWidth() const { return r.width(); }
+    int getHeight() const { return r.height(); }
+    artgpu_rgb view() const { return artgpu_rgb{r.view(), g.view(), b.view()}; }
+    DevicePlane r, g, b;
+};
+
+// The fields of ProcParams the path reads (procparams.cc:1528-3335 for the defaults)
+struct ProcParams {
+    struct { int method = ARTGPU_BAYER_AMAZE; int border = 4; } bayersensor;  // raw.bayersensor.{method,border}
+    struct { bool enabled = false; double luminance = 0, luminanceDetail = 0; int luminanceDetailThreshold = 0; double chrominance = 15,
+             chrominanceRedGreen = 0, chrominanceBlueYellow = 0, gamma = 1.7; bool aggressive = false; int colorSpace = 0, chrominanceMethod = 0; } denoise;
+    struct { bool enabled = true; double expcomp = 0, black = 0; } exposure;
+    struct { bool enabled = true; int curveMode = ARTGPU_TONE_STD; std::vector<float> lut; float whitePoint = 1.f; bool basecurveLinear = true; } toneCurve;
+    float workingSpace[9] = {0.6734241f, 0.1656411f, 0.1251286f, 0.2790177f, 0.6753402f, 0.0456377f, -0.0019300f, 0.0299784f, 0.7973330f}; // Rec2020 (iccmatrices.h:151-161)
+};
+
+// rtengine::RawImageSource counterpart for a Bayer sensor
+class RawImageSource {
+public:
+    RawImageSource(Context &c, int W, int H, uint32_t filters, double initialGain = 1.0)
+        : ctx(c), W(W), H(H), filters(filters), initialGain(initialGain), rawData(W, H), red(W, H), green(W, H), blue(W, H) {}
+    void setBorder(int b) { border = b; }                                   // rawimagesource.h (simpleprocess.cc:138-146)
+    void load(const float *cfa_host) { rawData.upload(cfa_host); }          // stands in for load()/preprocess(): CFA 0..65535
+    // RawImageSource::demosaic (rawimagesource.cc:1854-1962)
+    void demosaic(const ProcParams &p)
+    {
+        artgpu_plane raw = rawData.view();
+        artgpu_rgb out{red.view(), green.view(), blue.view()};
+        ctx.check(artgpu_demosaic_bayer(ctx.get(), p.bayersensor.method, &raw, filters, initialGain, border, &out));
+    }
+    void getFullSize(int &w, int &h) const { w = W - 2 * border; h = H - 2 * border; }   // computeFullSize (L1163-1193), tran = 0
+    // RawImageSource::getImage (rawimagesource.cc:781-1104): tran = 0, skip = 1; rm/gm/bm as the caller computed them
+    void getImage(const float mul[3], bool doClip, Imagefloat *image)
+    {
+        artgpu_rgb planes{red.view(), green.view(), blue.view()};
+        artgpu_rgb img = image->view();
+        ctx.check(artgpu_get_image(ctx.get(), &planes, border, border, mul, doClip ? 1 : 0, nullptr, &img));
+    }
+    // RawImageSource::convertColorSpace, matrix branch (rawimagesource.cc:1128-1143,3184-3213)
+    void convertColorSpace(Imagefloat *image, const double mat[9])
+    {
+        artgpu_rgb img = image->view();
+        ctx.check(artgpu_convert_color_space(ctx.get(), &img, mat));
+    }
+    Context &ctx;
+    int W, H, border = 4;
+    uint32_t filters;
+    double initialGain;
+    DevicePlane rawData, red, green, blue;
+};
+
+// rtengine::ImProcFunctions counterpart
+class ImProcFunctions {
+public:
+    enum class Stage { STAGE_0, STAGE_1, STAGE_2, STAGE_3 };
+    enum class Pipeline { THUMBNAIL, NAVIGATOR, PREVIEW, OUTPUT };
+    ImProcFunctions(Context &c, const ProcParams *p, double scale = 1.0) : ctx(c), params(p), scale(scale) {}
+
+    // ImProcFunctions::process (improcfun.cc:567-641): same step order; steps that are disabled / identity in the
+    // default ProcParams (dehaze, DRC, channelMixer, hslEqualizer, toneEqualizer, sharpening, ... blackAndWhite) are
+    // not on the device path and are skipped here exactly as their `enabled == false` early-outs skip them.
+    bool process(Pipeline, Stage stage, Imagefloat *img)
+    {
+        switch (stage) {
+        case Stage::STAGE_0: break;
+        case Stage::STAGE_1: exposure(img); break;
+        case Stage::STAGE_2: break;
+        case Stage::STAGE_3: toneCurve(img); break;
+        }
+        return false;
+    }
+    // ImProcFunctions::exposure -> expcomp (ipexposure.cc:28-79)
+    void exposure(Imagefloat *img) { expcomp(img, params->exposure.expcomp, params->exposure.black, params->exposure.enabled); }
+    void expcomp(Imagefloat *img, double ec, double black, bool enabled)
+    {
+        if (!enabled) return;
+        const float exp_scale = std::pow(2.f, (float)ec);
+        const float blk = (float)black * 2000.f;
+        artgpu_rgb i = img->view();
+        ctx.check(artgpu_exposure(ctx.get(), &i, exp_scale, blk));
+    }
+    // ImProcFunctions::toneCurve (iptonecurve.cc:553-716): single STD curve, LINEAR base curve
+    void toneCurve(Imagefloat *img)
+    {
+        if (!params->toneCurve.enabled) return;
+        artgpu_rgb i = img->view();
+        const float *lut = params->toneCurve.lut.size() == 65536 ? params->toneCurve.lut.data() : nullptr;
+        ctx.check(artgpu_tone_curve(ctx.get(), &i, params->toneCurve.curveMode, lut, params->toneCurve.whitePoint, params->toneCurve.basecurveLinear ? 1 : 0));
+    }
+    // ImProcFunctions::denoise (ipdenoise.cc:1096-1189): exposure pre-compensation, RGB_denoise, post-compensation.
+    // `ccalc` = the chroma noise-curve map of the quarter-size calclum image (FTblockDN.cc:1707-1777), or nullptr.
+    void denoise(Imagefloat *img, const artgpu_plane *ccalc = nullptr)
+    {
+        const auto &d = params->denoise;
+        if (!d.enabled) return;
+        const double ecomp = params->exposure.enabled ? params->exposure.expcomp : 0.0;
+        if (ecomp > 0) expcomp(img, ecomp, 0.0, true);
+        artgpu_denoise_params dp{d.luminance, d.luminanceDetail, d.luminanceDetailThreshold, d.chrominance, d.chrominanceRedGreen,
+                                 d.chrominanceBlueYellow, d.gamma, d.aggressive ? 1 : 0, d.colorSpace, d.chrominanceMethod};
+        artgpu_rgb i = img->view();
+        ctx.check(artgpu_rgb_denoise(ctx.get(), &i, &dp, params->workingSpace, 0.0, scale, ccalc, 0u, nullptr, nullptr));
+        if (ecomp > 0) expcomp(img, -ecomp, 0.0, true);
+    }
+    Context &ctx;
+    const ProcParams *params;
+    double scale;
+};
+
+} // namespace artgpu_host

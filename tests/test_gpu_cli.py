@@ -1,0 +1,74 @@
+"""GPU: the C++ front end (art_amd/artgpu-cli over rtengine_gpu.h) end to end against the oracle,
+on BASELINE config 1 (RCD, 4000x3000 RGGB) and a small AMaZE + denoise run."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from art_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "art_amd", "artgpu-cli")
+MUL = (2.1374, 1.0, 1.5918)
+MAT = np.array([[0.6325, 0.2312, 0.0921], [0.2198, 0.7712, 0.0090], [0.0166, 0.0713, 0.7514]])
+
+
+def tone_lut():
+    x = np.arange(65536, dtype=np.float64) / 65535.0
+    return ((1.0 - np.cos(np.pi * x ** 0.7)) / 2.0 * 65535.0).astype(np.float32)
+
+
+def read_ppm16(path):
+    with open(path, "rb") as f:
+        assert f.readline().strip() == b"P6"
+        w, h = map(int, f.readline().split())
+        assert f.readline().strip() == b"65535"
+        data = np.frombuffer(f.read(), dtype=">u2").reshape(h, w, 3)
+    return data
+
+
+def oracle_pipeline(raw, filt, method, border, denoise=None):
+    planes = O.rcd(raw, filt) if method == "rcd" else O.amaze(raw, filt, 1.0, border)
+    h, w = raw.shape
+    img = O.get_image(planes, border, border, w - 2 * border, h - 2 * border, MUL, True)
+    img = O.convert_color_space(img, MAT)
+    if denoise:
+        img = O.rgb_denoise(img, O.default_denoise_params(luminance=denoise[0], chrominance=denoise[1]), detail_recovery=True)
+    img = O.exposure(img, 1.0, 0.0)
+    img = O.tone_std(img, tone_lut(), 1.0, True)
+    return img
+
+
+def run_cli(tmp_path, raw, method, extra=()):
+    inp = tmp_path / "frame.f32"
+    out = tmp_path / "out.ppm"
+    raw.astype("<f4").tofile(inp)
+    h, w = raw.shape
+    res = subprocess.run([CLI, "--in", str(inp), "--width", str(w), "--height", str(h), "--method", method, "--out", str(out), *extra],
+                         capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    return json.loads(res.stdout.strip().splitlines()[-1]), read_ppm16(out)
+
+
+def test_config1_rcd_12mp_through_cli(tmp_path):
+    w, h, filt = 4000, 3000, synth.FILTERS_RGGB
+    raw = synth.bayer_frame(w, h, filt, seed=1)
+    info, ppm = run_cli(tmp_path, raw, "rcd")
+    assert (info["out_width"], info["out_height"]) == (w - 8, h - 8)
+    ref = oracle_pipeline(raw, filt, "rcd", 4)
+    q = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.uint16) for p in ref], axis=-1)
+    assert np.array_equal(ppm, q)          # bit-exact fp32 pipeline -> identical 16-bit output
+
+
+def test_amaze_denoise_through_cli(tmp_path):
+    w, h, filt = 648, 488, synth.FILTERS_RGGB
+    raw = synth.bayer_frame(w, h, filt, seed=2, noise=2048)
+    info, ppm = run_cli(tmp_path, raw, "amaze", ("--denoise", "40,15"))
+    ref = oracle_pipeline(raw, filt, "amaze", 4, denoise=(40.0, 15.0))
+    q = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.int32) for p in ref], axis=-1)
+    # the DCT detail-recovery stage is tolerance-checked (third-party FFTW in the reference): allow +-3 counts
+    assert np.abs(ppm.astype(np.int32) - q).max() <= 3
