@@ -70,6 +70,7 @@ def _load():
     lib.artgpu_wavelet_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.artgpu_rgb_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseParams), C.POINTER(C.c_float), C.c_double,
                                        C.c_double, C.POINTER(Plane), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.artgpu_denoise_guided_smoothing.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double), C.c_int, C.c_double]
     lib.artgpu_get_image.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int,
                                      C.POINTER(C.c_double), C.POINTER(RGB)]
     lib.artgpu_convert_color_space.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double)]
@@ -85,7 +86,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_demosaic_bayer", "artgpu_border_interpolate2", "artgpu_get_image",
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
-           "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise"]
+           "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -166,6 +167,10 @@ class Context:
         wsf = (C.c_float * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float32).reshape(9)])
         self._chk(LIB.artgpu_rgb_denoise(self._h, C.byref(image), C.byref(params), wsf, expcomp, scale,
                                          None if ccalc is None else C.byref(ccalc), flags, None, None))
+
+    def denoise_guided_smoothing(self, image: RGB, ws, radius: int = 3, scale: float = 1.0):
+        m = (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)])
+        self._chk(LIB.artgpu_denoise_guided_smoothing(self._h, C.byref(image), m, radius, scale))
 
     # ---- wavelet_decomposition ----
     def wavelet_decompose(self, src: Plane, maxlvl: int):

@@ -841,4 +841,67 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     return unbind_rgb(ctx, img, &d);
 }
 
+// ---------------------------------------------------------------------------------------------
+// guided chroma smoothing
+// ---------------------------------------------------------------------------------------------
+namespace {
+int gf_subsampling(int w, int h, int r)   // calculate_subsampling (guidedfilter.cc:58-75)
+{
+    if (r == 1) return 1;
+    if ((w > h ? w : h) <= 600) return 1;
+    for (int s = 5; s > 0; --s)
+        if (r % s == 0) return s;
+    const int t = r / 2;
+    return t < 2 ? 2 : (t > 4 ? 4 : t);
+}
+}
+
+int artgpu_denoise_guided_smoothing(artgpu_ctx *ctx, artgpu_rgb *img, const double ws[9], int guided_chroma_radius, double scale)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!img || !ws || !(scale >= 1.0)) return fail(ctx, ARTGPU_EINVAL, "denoise_guided_smoothing: bad arguments");
+    if (guided_chroma_radius == 0) return ARTGPU_OK;   // ipsmoothing.cc:877-879
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB d;
+    int rc = bind_rgb(ctx, img, 4, true, &d, "denoise_guided_smoothing");
+    if (rc) return rc;
+    const int W = d.w, H = d.h;
+    int r = (int)std::round(guided_chroma_radius / scale);
+    r = r > 0 ? r : 0;
+    GuidedArgs g = {};
+    for (int k = 0; k < 3; ++k) { g.rgb[k] = d.p[k]; g.ws1[k] = ws[3 + k]; }
+    g.stride = d.stride; g.W = W; g.H = H; g.epsilon = 0.001f;
+    const int sub = gf_subsampling(W, H, r);
+    g.w = W / sub; g.h = H / sub;
+    if (r == 0 || g.w < 8 || g.h < 8) return fail(ctx, ARTGPU_EUNSUPPORTED, "denoise_guided_smoothing: radius/scale combination not on the device path");
+    const size_t n = (size_t)W * H, nl = (size_t)g.w * g.h;
+    float *big, *low, *tmp;
+    if ((rc = pool_get(ctx, P_SF, 7 * n * 4, &big)) || (rc = pool_get(ctx, P_TMP, 8 * nl * 4, &low)) || (rc = pool_get(ctx, P_LIN, 8 * nl * 4, &tmp))) return rc;
+    for (int k = 0; k < 3; ++k) { g.in[k] = big + k * n; g.chan[k] = big + (3 + k) * n; }
+    g.guide = big + 6 * n;
+    for (int k = 0; k < 8; ++k) g.low[k] = low + k * nl;
+    HIPCHK(ctx, launch_gf_prepare(g, ctx->stream));
+    HIPCHK(ctx, launch_gf_subsample(g, ctx->stream));
+    // f_mean (guidedfilter.cc:160-167): rad = LIM(int(r1), 0, (min(w,h)-1)/2 - 1); boxblur.h:318 variant
+    const float r1 = float(r) / sub;
+    int rad = (int)r1;
+    { const int hi = ((g.w < g.h ? g.w : g.h) - 1) / 2 - 1; rad = rad < hi ? rad : hi; rad = rad > 0 ? rad : 0; }
+    BlurArgs bl = {};
+    bl.n = nl; bl.w = g.w; bl.h = g.h; bl.steady_div = 1; bl.plain = 1;
+    for (int l = 0; l < 10; ++l) bl.rad[l] = rad;
+    auto blur_planes = [&](float *planes, int count) -> int {
+        if (rad == 0) return ARTGPU_OK;
+        bl.src = planes; bl.dst = tmp;
+        HIPCHK(ctx, launch_hblur(bl, count, ctx->stream));
+        bl.src = tmp; bl.dst = planes; bl.sfave = nullptr; bl.coef = nullptr;
+        HIPCHK(ctx, launch_vblur_combine(bl, count, ctx->stream));
+        return ARTGPU_OK;
+    };
+    if ((rc = blur_planes(low, 8))) return rc;                 // meanI, corrI, meanp[3], corrIp[3]
+    HIPCHK(ctx, launch_gf_ab(g, ctx->stream));
+    if ((rc = blur_planes(low + 2 * nl, 6))) return rc;        // mean a[3], mean b[3]
+    HIPCHK(ctx, launch_gf_finish(g, ctx->stream));
+    return unbind_rgb(ctx, img, &d);
+}
+
 } // extern "C"

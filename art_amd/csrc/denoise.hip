@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
                     for (int i = 0; i < 8; ++i) { hi[i] = s[j0 + i + rad]; lo[i] = s[j0 + i - rad - 1]; }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        tempval = tempval + (hi[i] - lo[i]) * reclen;
+                        tempval = a.steady_div ? tempval + (hi[i] - lo[i]) / (float)len : tempval + (hi[i] - lo[i]) * reclen;
                         oT[lane][j0 + i] = tempval;
                     }
                 }
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
                         len++;
                         if (col == rad) reclen = 1.f / len;
                     } else if (col < W - rad) {
-                        tempval = tempval + (s[j + rad] - s[j - rad - 1]) * reclen;
+                        tempval = a.steady_div ? tempval + (s[j + rad] - s[j - rad - 1]) / (float)len : tempval + (s[j + rad] - s[j - rad - 1]) * reclen;
                     } else {
                         tempval = (tempval * len - s[j - rad - 1]) / (len - 1);
                         len--;
@@ -306,7 +306,8 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
     if (col >= W) return;
     const size_t nv4 = (a.n / 4) * 4;
     const float eps = 0.01f;
-    const bool vec = col < (W / 4) * 4;
+    const bool vec = a.plain ? true : col < (W / 4) * 4;
+    float *plain_dst = a.plain ? a.dst + (size_t)sub * a.n : nullptr;
     float tv = 0.f;
     float lenf = (float)(rad + 1);
     int leni = rad + 1;
@@ -314,6 +315,7 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
     // coefficient update (FTblockDN.cc:698-714,803-836): vector lanes (c*num)/den, tail c*(num/den)
     auto commit = [&](int row, float sfd, float sf, float c) {
         const size_t i = (size_t)row * W + col;
+        if (plain_dst) { plain_dst[i] = sfd; return; }
         const float num = sqr(sfd) + sqr(sf), den = sfd + sf + eps;
         coef[i] = i < nv4 ? c * num / den : c * (num / den);
     };
@@ -337,7 +339,7 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
             leni++;
         }
         const size_t i = (size_t)row * W + col;
-        commit(row, tv, sfave[i], coef[i]);
+        commit(row, tv, a.plain ? 0.f : sfave[i], a.plain ? 0.f : coef[i]);
     }
     rlen = 1.f / lenf;
     // steady state, 8 rows of independent loads in flight
@@ -348,8 +350,8 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
         for (int k = 0; k < 8; ++k) {
             hi[k] = t[(size_t)(row + k + rad) * W + col];
             lo[k] = t[(size_t)(row + k - rad - 1) * W + col];
-            sf[k] = sfave[(size_t)(row + k) * W + col];
-            c[k] = coef[(size_t)(row + k) * W + col];
+            sf[k] = a.plain ? 0.f : sfave[(size_t)(row + k) * W + col];
+            c[k] = a.plain ? 0.f : coef[(size_t)(row + k) * W + col];
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -362,7 +364,7 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
         const float d = t[(size_t)(row + rad) * W + col] - t[(size_t)(row - rad - 1) * W + col];
         tv = vec ? tv + d * rlen : tv + d / leni;
         const size_t i = (size_t)row * W + col;
-        commit(row, tv, sfave[i], coef[i]);
+        commit(row, tv, a.plain ? 0.f : sfave[i], a.plain ? 0.f : coef[i]);
     }
     for (; row < H; ++row) {
         if (vec) {
@@ -374,7 +376,7 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
             leni--;
         }
         const size_t i = (size_t)row * W + col;
-        commit(row, tv, sfave[i], coef[i]);
+        commit(row, tv, a.plain ? 0.f : sfave[i], a.plain ? 0.f : coef[i]);
     }
 }
 

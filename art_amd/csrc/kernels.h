@@ -129,6 +129,8 @@ struct BlurArgs {
     size_t n;
     int w, h;
     int rad[10];            // blur radius per level
+    int steady_div;         // hblur: steady state divides by len (boxblur.h:318 variant) instead of multiplying by 1/len
+    int plain;              // vblur: store the blurred value to dst (all columns take the vector form); no coefficient update
 };
 hipError_t launch_gamma_lut(float *lut, float gamma, float start, float slope, float divisor, float factor, hipStream_t s);
 hipError_t launch_rgb2yuv(const DnPixArgs &a, hipStream_t s);
@@ -151,5 +153,23 @@ struct DetailArgs {
 };
 hipError_t launch_detail_blocks(const DetailArgs &a, hipStream_t s);
 hipError_t launch_detail_gather(const DetailArgs &a, hipStream_t s);
+
+// ---- guided chroma smoothing (guided.hip) ----
+struct GuidedArgs {
+    float *rgb[3];         // Imagefloat planes (0..65535), updated in place
+    size_t stride;
+    int W, H;              // full resolution
+    int w, h;              // statistics grid (W/s, H/s)
+    float *in[3];          // normalised input copy (iR,iG,iB), W*H each
+    float *guide;          // W*H
+    float *chan[3];        // log-encoded channels, W*H each
+    float *low[8];         // w*h planes: I1/meanI, corrI, p1/meanp/a[3], corrIp/b[3]
+    double ws1[3];         // working-space matrix row 1 (double, TMatrix)
+    float epsilon;
+};
+hipError_t launch_gf_prepare(const GuidedArgs &a, hipStream_t s);
+hipError_t launch_gf_subsample(const GuidedArgs &a, hipStream_t s);
+hipError_t launch_gf_ab(const GuidedArgs &a, hipStream_t s);
+hipError_t launch_gf_finish(const GuidedArgs &a, hipStream_t s);
 
 } // namespace artgpu

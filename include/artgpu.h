@@ -172,6 +172,12 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
                        double expcomp, double scale, const artgpu_plane *ccalc, uint32_t flags,
                        float *nresi, float *highresi);
 
+/* Replaces denoise::denoiseGuidedSmoothing (rtengine/ipsmoothing.cc:875-897): normalise to [0,1],
+ * guided_smoothing(R,G,B, ws, iws, Channel::C, guidedChromaRadius, 0.001, scale) (L334-409) built on
+ * guidedFilterLog / guidedFilter (rtengine/guidedfilter.cc:58-265), back to [0,65535].  In place.
+ * ws: ICCStore::workingSpaceMatrix as 9 DOUBLES (TMatrix), row-major. */
+int artgpu_denoise_guided_smoothing(artgpu_ctx *ctx, artgpu_rgb *img, const double ws[9], int guided_chroma_radius, double scale);
+
 /* Bytes of device scratch the context currently holds (arena + staging). */
 size_t artgpu_scratch_bytes(const artgpu_ctx *ctx);
 

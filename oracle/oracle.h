@@ -70,6 +70,14 @@ void oracle_detail_tilemasks(float *tilemask_in, float *tilemask_out);
 float oracle_detail_factor(float d);
 void oracle_detail_recovery(int width, int height, float *L, const float *Lin, float params_Ldetail, double scale);
 
+/* guided chroma smoothing (oracle/guided.c) */
+void oracle_boxblur_ring(float *img, int radius, int W, int H);
+float oracle_bilinear(const float *src, int W, int H, float x, float y);
+void oracle_rescale_bilinear(const float *src, int Ws, int Hs, float *dst, int Wd, int Hd);
+void oracle_guided_filter(const float *guide, const float *src, float *dst, int W, int H, int r, float epsilon, int subsampling);
+void oracle_guided_filter_log(const float *guide, float base, float *chan, int W, int H, int r, float eps, int subsampling);
+void oracle_denoise_guided_smoothing(float *const img[3], int W, int H, const double ws[9], int guidedChromaRadius, double scale);
+
 /* sleef-derived math (oracle/sleef.c); _s = scalar form, _v = per-lane SSE form */
 float oracle_xexpf_s(float d);
 float oracle_xexpf_v(float d);

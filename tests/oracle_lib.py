@@ -202,3 +202,28 @@ def boxblur_flat(src, radx, rady):
     tmp = np.empty_like(src)
     lib().oracle_boxblur_flat(_ptr(src), _ptr(dst), _ptr(tmp), radx, rady, w, h)
     return dst
+
+
+REC2020_WS_D = np.array([[0.6734241, 0.1656411, 0.1251286], [0.2790177, 0.6753402, 0.0456377], [-0.0019300, 0.0299784, 0.7973330]], dtype=np.float64)
+
+
+def guided_smoothing(img, ws=REC2020_WS_D, radius=3, scale=1.0):
+    img = [np.array(p, dtype=np.float32, order="C") for p in img]
+    h, w = img[0].shape
+    m = (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)])
+    lib().oracle_denoise_guided_smoothing(_p3(img), w, h, m, radius, C.c_double(scale))
+    return img
+
+
+def boxblur_ring(a, radius):
+    a = np.array(a, dtype=np.float32, order="C")
+    lib().oracle_boxblur_ring(_ptr(a), radius, a.shape[1], a.shape[0])
+    return a
+
+
+def guided_filter(guide, src, r, eps, subsampling=0):
+    guide = np.ascontiguousarray(guide, dtype=np.float32)
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    dst = np.empty_like(src)
+    lib().oracle_guided_filter(_ptr(guide), _ptr(src), _ptr(dst), src.shape[1], src.shape[0], r, C.c_float(eps), subsampling)
+    return dst

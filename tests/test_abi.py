@@ -36,5 +36,11 @@ def test_no_oracle_in_product():
     import subprocess
     out = subprocess.run(["nm", "-D", os.path.join(ROOT, "art_amd", "libartgpu.so")], capture_output=True, text=True).stdout
     assert "oracle_" not in out
-    for f in os.listdir(os.path.join(ROOT, "art_amd", "csrc")):
-        assert "oracle" not in open(os.path.join(ROOT, "art_amd", "csrc", f), errors="ignore").read().lower() or f.endswith(".o")
+    import re
+    for sub in ("csrc", "host"):
+        for f in os.listdir(os.path.join(ROOT, "art_amd", sub)):
+            if f.endswith(".o"):
+                continue
+            src = open(os.path.join(ROOT, "art_amd", sub, f), errors="ignore").read()
+            code = re.sub(r"//[^\n]*|/\*.*?\*/", "", src, flags=re.S)   # comments may cite the checker, code may not use it
+            assert "oracle" not in code.lower(), f
