@@ -195,7 +195,10 @@ int unbind_rgb(artgpu_ctx *ctx, artgpu_rgb *img, const DevRGB *d)
     return ARTGPU_OK;
 }
 
-constexpr int MAX_TILE_WORKGROUPS = 8192;
+#ifndef ARTGPU_MAX_TILE_WG
+#define ARTGPU_MAX_TILE_WG 8192
+#endif
+constexpr int MAX_TILE_WORKGROUPS = ARTGPU_MAX_TILE_WG;
 
 } // namespace
 

@@ -8,7 +8,10 @@
 namespace artgpu {
 
 // ---- AMaZE (amaze.hip) ----
-constexpr int AMAZE_THREADS = 256;
+#ifndef ARTGPU_AMAZE_THREADS
+#define ARTGPU_AMAZE_THREADS 256
+#endif
+constexpr int AMAZE_THREADS = ARTGPU_AMAZE_THREADS;
 constexpr int AMAZE_ARENA_FLOATS = 362208; // 1 448 832 B per workgroup (reference: 1 448 767 B, amaze_demosaic_RT.cc:124)
 constexpr int AMAZE_TS = 160;
 constexpr int AMAZE_STEP = 128;
