@@ -71,6 +71,9 @@ def _load():
     lib.artgpu_rgb_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseParams), C.POINTER(C.c_float), C.c_double,
                                        C.c_double, C.POINTER(Plane), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_denoise_guided_smoothing.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double), C.c_int, C.c_double]
+    lib.artgpu_gaussian_blur.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_double]
+    lib.artgpu_detail_mask.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(Plane), C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
+    lib.artgpu_nlmeans.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_float, C.c_int, C.c_int, C.c_float]
     lib.artgpu_get_image.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int,
                                      C.POINTER(C.c_double), C.POINTER(RGB)]
     lib.artgpu_convert_color_space.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double)]
@@ -86,7 +89,8 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_demosaic_bayer", "artgpu_border_interpolate2", "artgpu_get_image",
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
-           "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing"]
+           "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -171,6 +175,15 @@ class Context:
     def denoise_guided_smoothing(self, image: RGB, ws, radius: int = 3, scale: float = 1.0):
         m = (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)])
         self._chk(LIB.artgpu_denoise_guided_smoothing(self._h, C.byref(image), m, radius, scale))
+
+    def gaussian_blur(self, img: Plane, sigma: float):
+        self._chk(LIB.artgpu_gaussian_blur(self._h, C.byref(img), sigma))
+
+    def detail_mask(self, src: Plane, mask: Plane, scaling, threshold, ceiling, factor, blur):
+        self._chk(LIB.artgpu_detail_mask(self._h, C.byref(src), C.byref(mask), scaling, threshold, ceiling, factor, blur))
+
+    def nlmeans(self, img: Plane, strength: int = 50, detail: int = 80, scale: float = 1.0, normcoeff: float = 65535.0):
+        self._chk(LIB.artgpu_nlmeans(self._h, C.byref(img), normcoeff, strength, detail, scale))
 
     # ---- wavelet_decomposition ----
     def wavelet_decompose(self, src: Plane, maxlvl: int):

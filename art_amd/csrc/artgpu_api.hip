@@ -907,4 +907,144 @@ int artgpu_denoise_guided_smoothing(artgpu_ctx *ctx, artgpu_rgb *img, const doub
     return unbind_rgb(ctx, img, &d);
 }
 
+// ---------------------------------------------------------------------------------------------
+// gaussian blur, detail mask, NL-means
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// calculateYvVFactors<double> + M rescaling (gauss.cc:94-126,556-562)
+void yvv_factors(double sigma, GaussArgs &g)
+{
+    double q;
+    if (sigma < 2.5) q = 3.97156 - 4.14554 * std::sqrt(1.0 - 0.26891 * sigma);
+    else q = 0.98711 * sigma - 0.96330;
+    const double b0 = 1.57825 + 2.44413 * q + 1.4281 * q * q + 0.422205 * q * q * q;
+    double b1 = 2.44413 * q + 2.85619 * q * q + 1.26661 * q * q * q;
+    double b2 = -1.4281 * q * q - 1.26661 * q * q * q;
+    double b3 = 0.422205 * q * q * q;
+    g.B = 1.0 - (b1 + b2 + b3) / b0;
+    b1 /= b0; b2 /= b0; b3 /= b0;
+    double *M = g.M;
+    M[0] = -b3 * b1 + 1.0 - b3 * b3 - b2;
+    M[1] = (b3 + b1) * (b2 + b3 * b1);
+    M[2] = b3 * (b1 + b3 * b2);
+    M[3] = b1 + b3 * b2;
+    M[4] = -(b2 - 1.0) * (b2 + b3 * b1);
+    M[5] = -(b3 * b1 + b3 * b3 + b2 - 1.0) * b3;
+    M[6] = b3 * b1 + b2 + b1 * b1 - b2 * b2;
+    M[7] = b1 * b2 + b3 * b2 * b2 - b1 * b3 * b3 - b3 * b3 * b3 - b3 * b2 + b3;
+    M[8] = b3 * (b1 + b3 * b2);
+    for (int i = 0; i < 9; ++i) {
+        M[i] *= (1.0 + b2 + (b1 - b3) * b3);
+        M[i] /= (1.0 + b1 - b2 + b3) * (1.0 - b1 - b2 - b3);
+        g.Mf[i] = (float)M[i];
+    }
+    g.b[0] = b1; g.b[1] = b2; g.b[2] = b3;
+    g.Bf = (float)g.B; g.bf[0] = (float)b1; g.bf[1] = (float)b2; g.bf[2] = (float)b3;
+}
+
+// contiguous device working copy of one plane (host planes are staged, strided device planes copied)
+int plane_to_pool(artgpu_ctx *ctx, const artgpu_plane *pl, int slot, float **out)
+{
+    const size_t rowb = (size_t)pl->w * 4;
+    int rc = pool_get(ctx, slot, rowb * pl->h, out);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(*out, rowb, pl->p, (size_t)pl->row_stride_bytes, rowb, pl->h,
+                                 pl->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    return ARTGPU_OK;
+}
+int pool_to_plane(artgpu_ctx *ctx, const float *src, artgpu_plane *pl)
+{
+    const size_t rowb = (size_t)pl->w * 4;
+    HIPCHK(ctx, hipMemcpy2DAsync(pl->p, (size_t)pl->row_stride_bytes, src, rowb, rowb, pl->h,
+                                 pl->on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    if (!pl->on_device) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
+int gaussian_dev(artgpu_ctx *ctx, float *img, float *tmp, int W, int H, double sigma)
+{
+    if (!(sigma >= 0.6 && sigma < 25.0) || W < 8 || H < 8) return fail(ctx, ARTGPU_EUNSUPPORTED, "gaussian_blur: sigma %g / size %dx%d not on the device path", sigma, W, H);
+    GaussArgs g = {};
+    g.img = img; g.tmp = tmp; g.W = W; g.H = H;
+    yvv_factors((double)(float)sigma, g);   // the Sse functions take `const float sigma`
+    HIPCHK(ctx, launch_gaussian(g, ctx->stream));
+    return ARTGPU_OK;
+}
+
+int detail_mask_dev(artgpu_ctx *ctx, const float *src, size_t src_stride, float *mask, int W, int H,
+                    float scaling, float threshold, float ceiling, float factor, float blur, float *scratch /* >= W*H + 2*(W/4)*(H/4) */)
+{
+    MaskArgs m = {};
+    m.src = src; m.src_stride = src_stride; m.mask = mask; m.W = W; m.H = H; m.w4 = W / 4; m.h4 = H / 4;
+    m.L2 = scratch + (size_t)W * H; m.m2 = m.L2 + (size_t)m.w4 * m.h4;
+    m.scaling = scaling; m.threshold = threshold; m.ceiling = ceiling; m.factor = factor;
+    HIPCHK(ctx, launch_detail_mask(m, ctx->stream));
+    return gaussian_dev(ctx, mask, scratch, W, H, blur);
+}
+
+} // namespace
+
+int artgpu_gaussian_blur(artgpu_ctx *ctx, artgpu_plane *img, double sigma)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!plane_ok(img)) return fail(ctx, ARTGPU_EINVAL, "gaussian_blur: bad plane");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    float *work, *tmp;
+    int rc = plane_to_pool(ctx, img, P_SF, &work);
+    if (rc) return rc;
+    if ((rc = pool_get(ctx, P_TMP, (size_t)img->w * img->h * 4, &tmp))) return rc;
+    if ((rc = gaussian_dev(ctx, work, tmp, img->w, img->h, sigma))) return rc;
+    return pool_to_plane(ctx, work, img);
+}
+
+int artgpu_detail_mask(artgpu_ctx *ctx, const artgpu_plane *src, artgpu_plane *mask, float scaling, float threshold,
+                       float ceiling, float factor, float blur)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!plane_ok(src) || !plane_ok(mask) || mask->w != src->w || mask->h != src->h) return fail(ctx, ARTGPU_EINVAL, "detail_mask: bad planes");
+    if (src->w < 32 || src->h < 32) return fail(ctx, ARTGPU_EUNSUPPORTED, "detail_mask: image smaller than 32x32");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int W = src->w, H = src->h;
+    float *in, *m, *scratch;
+    int rc = plane_to_pool(ctx, src, P_SF, &in);
+    if (rc) return rc;
+    if ((rc = pool_get(ctx, P_TMP, (size_t)W * H * 4, &m))) return rc;
+    if ((rc = pool_get(ctx, P_LIN, ((size_t)W * H + 2 * (size_t)(W / 4) * (H / 4)) * 4, &scratch))) return rc;
+    if ((rc = detail_mask_dev(ctx, in, W, m, W, H, scaling, threshold, ceiling, factor, blur, scratch))) return rc;
+    return pool_to_plane(ctx, m, mask);
+}
+
+int artgpu_nlmeans(artgpu_ctx *ctx, artgpu_plane *img, float normcoeff, int strength, int detail_thresh, float scale)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!plane_ok(img) || !(scale >= 1.f)) return fail(ctx, ARTGPU_EINVAL, "nlmeans: bad arguments");
+    if (!strength) return ARTGPU_OK;                       // nlmeans.cc:52-54
+    if (img->w < 32 || img->h < 32) return fail(ctx, ARTGPU_EUNSUPPORTED, "nlmeans: image smaller than 32x32");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int W = img->w, H = img->h;
+    NlmArgs a = {};
+    a.search_radius = int(std::ceil(5.f / scale));
+    a.patch_radius = int(std::ceil(2.f / scale));
+    const float t = std::pow(float(strength) / 100.f, 0.9f) / 10.f / scale;
+    a.h2 = t * t;
+    float amount = float(detail_thresh) / 100.f;
+    amount = amount < 0.f ? 0.f : (amount > 0.99f ? 0.99f : amount);   // LIM(x, 0, 0.99)
+    a.border = a.search_radius + a.patch_radius;
+    a.W = W; a.H = H; a.WW = W + 2 * a.border; a.HH = H + 2 * a.border; a.factor = normcoeff;
+    a.ntiles_x = int(std::ceil(float(a.WW) / (150 - 2 * a.border)));
+    a.ntiles_y = int(std::ceil(float(a.HH) / (150 - 2 * a.border)));
+    float *work, *scratch, *pad;
+    int rc = plane_to_pool(ctx, img, P_SF, &work);
+    if (rc) return rc;
+    if ((rc = pool_get(ctx, P_TMP, (size_t)W * H * 4 * 2 + 8192 * 4, &a.mask))) return rc;
+    a.SW = a.mask + (size_t)W * H; a.explut = a.SW + (size_t)W * H;
+    if ((rc = pool_get(ctx, P_LIN, ((size_t)W * H + 2 * (size_t)(W / 4) * (H / 4)) * 4, &scratch))) return rc;
+    if ((rc = pool_get(ctx, P_BLOCKS, (size_t)a.WW * a.HH * 4, &pad))) return rc;
+    if ((rc = detail_mask_dev(ctx, work, W, a.mask, W, H, normcoeff, 1e-3f * normcoeff, normcoeff, amount, 2.f / scale, scratch))) return rc;
+    a.img = work; a.img_stride = W; a.src = pad;
+    HIPCHK(ctx, launch_nlm(a, ctx->stream));
+    return pool_to_plane(ctx, work, img);
+}
+
 } // extern "C"

@@ -175,4 +175,31 @@ hipError_t launch_gf_subsample(const GuidedArgs &a, hipStream_t s);
 hipError_t launch_gf_ab(const GuidedArgs &a, hipStream_t s);
 hipError_t launch_gf_finish(const GuidedArgs &a, hipStream_t s);
 
+// ---- NL-means stage (nlmeans.hip) ----
+struct MaskArgs {
+    const float *src; size_t src_stride;   // W x H input (values ~ 0..scaling)
+    float *L2, *m2;                        // W/4 x H/4 scratch
+    float *mask;                           // W x H output (contiguous)
+    int W, H, w4, h4;
+    float scaling, threshold, ceiling, factor;
+};
+struct GaussArgs {
+    float *img, *tmp;                      // W x H contiguous, blurred in place; tmp = forward-pass storage
+    int W, H;
+    double B, b[3], M[9];
+    float Bf, bf[3], Mf[9];
+};
+struct NlmArgs {
+    float *img; size_t img_stride;         // Y plane, replaced by the filtered result
+    float *src;                            // padded source WW x HH (already divided by factor)
+    float *mask;                           // W x H: detail mask -> weight scale
+    float *SW;                             // W x H weight sums
+    float *explut;                         // 8192 entries
+    int W, H, WW, HH, border, search_radius, patch_radius, ntiles_x, ntiles_y;
+    float factor, h2;
+};
+hipError_t launch_detail_mask(const MaskArgs &a, hipStream_t s);
+hipError_t launch_gaussian(const GaussArgs &a, hipStream_t s);
+hipError_t launch_nlm(const NlmArgs &a, hipStream_t s);
+
 } // namespace artgpu

@@ -1,0 +1,283 @@
+// art_amd/csrc/nlmeans.hip -- NL-means stage of the denoise tool on gfx950
+// (reference: rtengine/nlmeans.cc:50-280 denoise::NLMeans; rtengine/FTblockDN.cc:1366-1476 detail_mask +
+//  laplacian; rtengine/gauss.cc:94-126,554-665,716-856 Young-van Vliet recursive gaussian, x86-64 path).
+//
+// v1, correctness first.  Everything keeps the reference's fp32 association order:
+//   gauss_h / gauss_v : 3rd-order IIR forward+backward per line; one lane per line (the recurrence is
+//                       sequential along the line).  Lines in the reference's SSE groups (rows < H-H%4,
+//                       columns < W-W%8) use float coefficients, the tail lines double ones.
+//   nlm_tile          : one workgroup per REFERENCE tile (150x150, stride 150-2*border: the per-tile
+//                       fp32 integral image is part of the result).  For each of the (2r+1)^2 offsets the
+//                       integral image St is swept along anti-diagonals (one lane per row, a barrier per
+//                       diagonal, 16 diagonals kept in LDS); patch distances come from the four corners,
+//                       weights from the 8192-entry exp LUT (LDS), accumulation in offset order.
+//                       MXCSR flush-to-zero (nlmeans.cc:157-160) is reproduced with explicit ftz().
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "devmath.h"
+#include "devsleef.h"
+#include "kernels.h"
+
+namespace artgpu {
+
+namespace {
+__device__ __forceinline__ float ftz(float x) { return fabsf(x) < FLT_MIN ? copysignf(0.f, x) : x; }
+__device__ __forceinline__ float pow_F(float a, float b) { return xexpf_s(b * xlogf_s(a)); }
+__device__ __forceinline__ float xlin2log(float x, float base) { return xlogf_s(x * (base - 1.f) + 1.f) / xlogf_s(base); }
+__device__ __forceinline__ float bilinear(const float *__restrict__ src, int W, int H, float x, float y)
+{
+    const int xi = min((int)x, W - 1), yi = min((int)y, H - 1);
+    const float xf = x - xi, yf = y - yi;
+    const int xi1 = min(xi + 1, W - 1), yi1 = min(yi + 1, H - 1);
+    const float bl = src[(size_t)yi * W + xi], br = src[(size_t)yi * W + xi1];
+    const float tl = src[(size_t)yi1 * W + xi], tr = src[(size_t)yi1 * W + xi1];
+    const float b = xf * br + (1.f - xf) * bl;
+    const float t = xf * tr + (1.f - xf) * tl;
+    return yf * t + (1.f - yf) * b;
+}
+} // namespace
+
+// ---------------------------------------------------------------- detail_mask (FTblockDN.cc:1408-1476)
+// L2 = xlin2log(rescaleBilinear(src -> W/4 x H/4) / scaling, 50)
+__global__ void __launch_bounds__(256) dm_down_log_kernel(MaskArgs a)
+{
+    const long long n = (long long)a.w4 * a.h4;
+    const float col_scale = (float)a.W / (float)a.w4, row_scale = (float)a.H / (float)a.h4;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.w4), x = (int)(t - (long long)y * a.w4);
+        // src may have a row stride: bilinear on a strided plane
+        const float fx = x * col_scale, fy = y * row_scale;
+        const int xi = min((int)fx, a.W - 1), yi = min((int)fy, a.H - 1);
+        const float xf = fx - xi, yf = fy - yi;
+        const int xi1 = min(xi + 1, a.W - 1), yi1 = min(yi + 1, a.H - 1);
+        const float bl = a.src[(size_t)yi * a.src_stride + xi], br = a.src[(size_t)yi * a.src_stride + xi1];
+        const float tl = a.src[(size_t)yi1 * a.src_stride + xi], tr = a.src[(size_t)yi1 * a.src_stride + xi1];
+        const float b = xf * br + (1.f - xf) * bl;
+        const float tt = xf * tr + (1.f - xf) * tl;
+        const float v = yf * tt + (1.f - yf) * b;
+        a.L2[t] = xlin2log(v / a.scaling, 50.f);
+    }
+}
+// laplacian (FTblockDN.cc:1366-1403)
+__global__ void __launch_bounds__(256) dm_laplacian_kernel(MaskArgs a)
+{
+    const int w = a.w4, h = a.h4;
+    const long long n = (long long)w * h;
+    const float thr = a.threshold / a.scaling, ceil_ = a.ceiling / a.scaling;
+    const float f = a.factor / ceil_;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / w), x = (int)(t - (long long)y * w);
+        const int nn = (y - 1 < 0) ? y + 1 : y - 1, s = (y + 1 >= h) ? y - 1 : y + 1;
+        const int ww = (x - 1 < 0) ? x + 1 : x - 1, e = (x + 1 >= w) ? x - 1 : x + 1;
+#define GETL(yy, xx) std_max(a.L2[(size_t)(yy) * w + (xx)], 0.f)
+        const float v = -8.f * GETL(y, x) + GETL(nn, x) + GETL(s, x) + GETL(y, ww) + GETL(y, e) + GETL(nn, ww) + GETL(nn, e) + GETL(s, ww) + GETL(s, e);
+#undef GETL
+        float tt = fabsf(v) - thr;
+        tt = std_max(0.f, std_min(tt, ceil_));
+        a.m2[t] = tt * f;
+    }
+}
+// mask = scurve(LIM01(rescaleBilinear(m2 -> W x H) + 1 - factor))
+__global__ void __launch_bounds__(256) dm_up_scurve_kernel(MaskArgs a)
+{
+    const long long n = (long long)a.W * a.H;
+    const float col_scale = (float)a.w4 / (float)a.W, row_scale = (float)a.h4 / (float)a.H;
+    const float thr1 = 1.f - a.factor;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.W), x = (int)(t - (long long)y * a.W);
+        const float v = lim01(bilinear(a.m2, a.w4, a.h4, x * col_scale, y * row_scale) + thr1);
+        a.mask[t] = xlin2log(pow_F(v, 2.23f), 101.f);
+    }
+}
+
+// ---------------------------------------------------------------- Young-van Vliet gaussian (gauss.cc:554-665,716-856)
+template <typename C>
+__device__ __forceinline__ void yvv_line(float *p, size_t st, float *tmp, size_t tst, int n, C B, C b1, C b2, C b3, const C *M)
+{
+    // forward (tmp may alias nothing; float storage as in the reference's AlignedMatrix<float>)
+    const float s0 = p[0], sl = p[(size_t)(n - 1) * st];
+    float t0 = s0 * (B + b1 + b2 + b3);
+    float t1 = sizeof(C) == 4 ? (float)(p[st] * B + t0 * b1 + s0 * (b2 + b3)) : (float)(B * p[st] + b1 * t0 + s0 * (b2 + b3));
+    float t2 = sizeof(C) == 4 ? (float)(p[2 * st] * B + t1 * b1 + t0 * b2 + s0 * b3) : (float)(B * p[2 * st] + b1 * t1 + b2 * t0 + b3 * s0);
+    tmp[0] = t0; tmp[tst] = t1; tmp[2 * tst] = t2;
+    float m3 = t0, m2 = t1, m1 = t2;
+    for (int j = 3; j < n; j++) {
+        const float v = sizeof(C) == 4 ? (float)(p[(size_t)j * st] * B + m1 * b1 + m2 * b2 + m3 * b3) : (float)(B * p[(size_t)j * st] + b1 * m1 + b2 * m2 + b3 * m3);
+        tmp[(size_t)j * tst] = v;
+        m3 = m2; m2 = m1; m1 = v;
+    }
+    // Triggs-Sdika boundary (m1 = tmp[n-1], m2 = tmp[n-2], m3 = tmp[n-3])
+    const float t2Wp1 = (float)(sl + M[6] * (m1 - sl) + M[7] * (m2 - sl) + M[8] * (m3 - sl));
+    const float t2W = (float)(sl + M[3] * (m1 - sl) + M[4] * (m2 - sl) + M[5] * (m3 - sl));
+    const float r1 = (float)(sl + M[0] * (m1 - sl) + M[1] * (m2 - sl) + M[2] * (m3 - sl));
+    const float r2 = (float)(B * m2 + b1 * r1 + b2 * t2W + b3 * t2Wp1);
+    const float r3 = (float)(B * m3 + b1 * r2 + b2 * r1 + b3 * t2W);
+    p[(size_t)(n - 1) * st] = r1; p[(size_t)(n - 2) * st] = r2; p[(size_t)(n - 3) * st] = r3;
+    float a1 = r3, a2 = r2, a3 = r1; // outputs at j+1, j+2, j+3
+    for (int j = n - 4; j >= 0; j--) {
+        const float tj = tmp[(size_t)j * tst];
+        const float v = sizeof(C) == 4 ? (float)(tj * B + a1 * b1 + a2 * b2 + a3 * b3) : (float)(B * tj + b1 * a1 + b2 * a2 + b3 * a3);
+        p[(size_t)j * st] = v;
+        a3 = a2; a2 = a1; a1 = v;
+    }
+}
+
+__global__ void __launch_bounds__(64) gauss_h_kernel(GaussArgs a)
+{
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= a.H) return;
+    float *p = a.img + (size_t)row * a.W, *tmp = a.tmp + (size_t)row * a.W;
+    if (row < a.H - (a.H % 4)) yvv_line<float>(p, 1, tmp, 1, a.W, a.Bf, a.bf[0], a.bf[1], a.bf[2], a.Mf);
+    else yvv_line<double>(p, 1, tmp, 1, a.W, a.B, a.b[0], a.b[1], a.b[2], a.M);
+}
+__global__ void __launch_bounds__(64) gauss_v_kernel(GaussArgs a)
+{
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (col >= a.W) return;
+    float *p = a.img + col, *tmp = a.tmp + col;
+    if (col < a.W - (a.W % 8)) yvv_line<float>(p, (size_t)a.W, tmp, (size_t)a.W, a.H, a.Bf, a.bf[0], a.bf[1], a.bf[2], a.Mf);
+    else yvv_line<double>(p, (size_t)a.W, tmp, (size_t)a.W, a.H, a.B, a.b[0], a.b[1], a.b[2], a.M);
+}
+
+// ---------------------------------------------------------------- NL-means
+// padded source (nlmeans.cc:98-109), dst = 0 (L111-119), mask -> (1/(mask*h2))/lutfactor (L129-136)
+__global__ void __launch_bounds__(256) nlm_prepare_kernel(NlmArgs a)
+{
+    const long long npad = (long long)a.WW * a.HH, n = (long long)a.W * a.H;
+    const float lutfactor = 100.f / 8191.f;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < npad; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.WW), x = (int)(t - (long long)y * a.WW);
+        const int yy = y <= a.border ? 0 : y >= a.H ? a.H - 1 : y - a.border;
+        const int xx = x <= a.border ? 0 : x >= a.W ? a.W - 1 : x - a.border;
+        a.src[t] = a.img[(size_t)yy * a.img_stride + xx] / a.factor;
+        if (t < n) a.mask[t] = (1.f / (a.mask[t] * a.h2)) / lutfactor;
+        if (t < 8192) a.explut[t] = xexpf_s(-((float)t * lutfactor));
+    }
+}
+__global__ void __launch_bounds__(256) nlm_zero_kernel(NlmArgs a)
+{
+    const long long n = (long long)a.W * a.H;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.W), x = (int)(t - (long long)y * a.W);
+        a.img[(size_t)y * a.img_stride + x] = 0.f;
+        a.SW[t] = 0.f;
+    }
+}
+
+constexpr int NLM_TS = 150, NLM_RING = 16, NLM_THREADS = 192;
+__global__ void __launch_bounds__(NLM_THREADS) nlm_tile_kernel(NlmArgs a)
+{
+    __shared__ float ring[NLM_RING][NLM_TS + 2];
+    __shared__ float explut[8192];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 8192; i += NLM_THREADS) explut[i] = a.explut[i];
+    const int tile_y = blockIdx.x / a.ntiles_x, tile_x = blockIdx.x - tile_y * a.ntiles_x;
+    const int border = a.border, WW = a.WW, HH = a.HH, W = a.W;
+    const int step = NLM_TS - 2 * border;
+    const int start_y = tile_y * step, end_y = min(start_y + NLM_TS, HH), TH = end_y - start_y;
+    const int start_x = tile_x * step, end_x = min(start_x + NLM_TS, WW), TW = end_x - start_x;
+    const int pr = a.patch_radius, sr = a.search_radius;
+    const int yy = tid;                         // this lane's row of the tile
+    const bool rowok = yy < TH;
+    const int gy = min(max(yy + start_y, 0), HH - 1);
+    // vector / scalar lane split of the weight loop (nlmeans.cc:213,230)
+    const int xx0 = start_x + border, xvec_end = end_x - border - 3;
+    const int nvec = xvec_end > xx0 ? (xvec_end - xx0 + 3) / 4 * 4 : 0;
+    __syncthreads();
+    for (int ty = -sr; ty <= sr; ++ty) {
+        const int gy2 = min(max(yy + ty + start_y, 0), HH - 1);
+        for (int tx = -sr; tx <= sr; ++tx) {
+            for (int d = 0; d < TW + TH - 1; ++d) {
+                const int xx = d - yy;
+                float st = 0.f;
+                if (rowok && xx >= 0 && xx < TW) {
+                    if (!(xx == 0 && yy == 0)) {
+                        const int gx = min(max(xx + start_x, 0), WW - 1), gx2 = min(max(xx + tx + start_x, 0), WW - 1);
+                        const float sc = ftz(sqr(ftz(a.src[(size_t)gy * WW + gx] - a.src[(size_t)gy2 * WW + gx2])));
+                        const float left = xx > 0 ? ring[(d - 1) & (NLM_RING - 1)][yy] : 0.f;
+                        const float up = yy > 0 ? ring[(d - 1) & (NLM_RING - 1)][yy - 1] : 0.f;
+                        const float upleft = (yy > 0 && xx > 0) ? ring[(d - 2) & (NLM_RING - 1)][yy - 1] : 0.f;
+                        // first row / column: running sums; interior: (left + up) - (upleft - score)
+                        if (yy == 0) st = ftz(left + sc);
+                        else if (xx == 0) st = ftz(up + sc);
+                        else st = ftz(ftz(left + up) - ftz(upleft - sc));
+                    }
+                    ring[d & (NLM_RING - 1)][yy] = st;
+                }
+                __syncthreads();
+                // box sums whose (+pr,+pr) corner is (yy, xx): pixel (sty, stx) = (yy - pr, xx - pr)
+                if (rowok && xx >= 0 && xx < TW) {
+                    const int sty = yy - pr, stx = xx - pr;
+                    const int py = sty + start_y, px = stx + start_x; // padded coordinates (yy_ref, xx_ref)
+                    if (py >= start_y + border && py < end_y - border && px >= start_x + border && px < end_x - border) {
+                        const float cA = st;                                                          // St[sty+pr][stx+pr]
+                        const float cB = ring[(d - 4 * pr) & (NLM_RING - 1)][yy - 2 * pr];            // St[sty-pr][stx-pr]
+                        const float cC = ring[(d - 2 * pr) & (NLM_RING - 1)][yy];                     // St[sty+pr][stx-pr]
+                        const float cD = ring[(d - 2 * pr) & (NLM_RING - 1)][yy - 2 * pr];            // St[sty-pr][stx+pr]
+                        float dist2 = ftz(ftz(ftz(cA + cB) - cC) - cD);
+                        const bool vec = (px - xx0) < nvec;
+                        dist2 = vec ? sse_max(dist2, 0.f) : std_max(dist2, 0.f);
+                        const int y = py - border, x = px - border;
+                        const float dd = ftz(dist2 * a.mask[(size_t)y * W + x]);
+                        float weight;
+                        if (vec) {
+                            const float clamped = sse_max(sse_min(8190.f, dd), 0.f);
+                            const int idx = (int)clamped;
+                            const float diff = ftz(sse_max(sse_min(8191.f, dd), 0.f) - (float)idx);
+                            weight = ftz(ftz(diff * explut[idx + 1]) + ftz(ftz(1.f - diff) * explut[idx]));
+                        } else {
+                            if (dd < 0.f || !(dd == dd)) weight = explut[0];
+                            else if (dd > 8190.f) weight = explut[8191];
+                            else {
+                                const int idx = (int)dd;
+                                const float diff = ftz(dd - (float)idx);
+                                const float p1 = explut[idx], p2 = ftz(explut[idx + 1] - p1);
+                                weight = ftz(p1 + ftz(p2 * diff));
+                            }
+                        }
+                        const size_t o = (size_t)y * W + x;
+                        a.SW[o] = ftz(a.SW[o] + weight);
+                        const float Yv = ftz(weight * a.src[(size_t)(py + ty) * WW + (px + tx)]);
+                        const size_t io = (size_t)y * a.img_stride + x;
+                        a.img[io] = ftz(a.img[io] + Yv);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // final estimate (nlmeans.cc:252-273)
+    for (int t = tid; t < (TH - 2 * border) * (TW - 2 * border); t += NLM_THREADS) {
+        const int ry = t / (TW - 2 * border), rx = t - ry * (TW - 2 * border);
+        const int y = start_y + ry, x = start_x + rx; // = (yy_ref - border), (xx_ref - border)
+        if (TH - 2 * border <= 0 || TW - 2 * border <= 0) break;
+        const size_t io = (size_t)y * a.img_stride + x;
+        const float f = ftz(1e-5f + a.SW[(size_t)y * W + x]);
+        a.img[io] = ftz(ftz(a.img[io] / f) * a.factor);
+    }
+}
+
+static int fgrid(long long n) { long long g = (n + 255) / 256; return (int)(g < 16384 ? g : 16384); }
+hipError_t launch_detail_mask(const MaskArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(dm_down_log_kernel, dim3(fgrid((long long)a.w4 * a.h4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dm_laplacian_kernel, dim3(fgrid((long long)a.w4 * a.h4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dm_up_scurve_kernel, dim3(fgrid((long long)a.W * a.H)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_gaussian(const GaussArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(gauss_h_kernel, dim3((a.H + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(gauss_v_kernel, dim3((a.W + 63) / 64), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_nlm(const NlmArgs &a, hipStream_t s)
+{
+    const long long npad = (long long)a.WW * a.HH;
+    hipLaunchKernelGGL(nlm_prepare_kernel, dim3(fgrid(npad > 8192 ? npad : 8192)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nlm_zero_kernel, dim3(fgrid((long long)a.W * a.H)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nlm_tile_kernel, dim3(a.ntiles_x * a.ntiles_y), dim3(NLM_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace artgpu

@@ -178,6 +178,19 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
  * ws: ICCStore::workingSpaceMatrix as 9 DOUBLES (TMatrix), row-major. */
 int artgpu_denoise_guided_smoothing(artgpu_ctx *ctx, artgpu_rgb *img, const double ws[9], int guided_chroma_radius, double scale);
 
+/* gaussianBlur(src, src, W, H, sigma) in place for 0.6 <= sigma < 25, GAUSS_STANDARD (rtengine/gauss.cc:1387-1574:
+ * gaussHorizontalSse + gaussVerticalSse, L554-665,716-856).  Other sigma ranges: ARTGPU_EUNSUPPORTED. */
+int artgpu_gaussian_blur(artgpu_ctx *ctx, artgpu_plane *img, double sigma);
+
+/* denoise::detail_mask(src, mask, scaling, threshold, ceiling, factor, BlurType::GAUSS, blur)
+ * (rtengine/FTblockDN.cc:1408-1476).  mask: same size as src, written. */
+int artgpu_detail_mask(artgpu_ctx *ctx, const artgpu_plane *src, artgpu_plane *mask, float scaling, float threshold,
+                       float ceiling, float factor, float blur);
+
+/* denoise::NLMeans(img, normcoeff, strength, detail_thresh, scale) (rtengine/nlmeans.cc:50-280) on one plane
+ * (the Y plane after Imagefloat::setMode(YUV), ipdenoise.cc:1174-1177), in place. */
+int artgpu_nlmeans(artgpu_ctx *ctx, artgpu_plane *img, float normcoeff, int strength, int detail_thresh, float scale);
+
 /* Bytes of device scratch the context currently holds (arena + staging). */
 size_t artgpu_scratch_bytes(const artgpu_ctx *ctx);
 

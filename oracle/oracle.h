@@ -78,6 +78,13 @@ void oracle_guided_filter(const float *guide, const float *src, float *dst, int 
 void oracle_guided_filter_log(const float *guide, float base, float *chan, int W, int H, int r, float eps, int subsampling);
 void oracle_denoise_guided_smoothing(float *const img[3], int W, int H, const double ws[9], int guidedChromaRadius, double scale);
 
+/* NL-means stage and helpers (oracle/nlmeans.c) */
+void oracle_yvv_factors(double sigma, double *b1, double *b2, double *b3, double *B, double M[9]);
+void oracle_gaussian_blur(float *img, int W, int H, double sigma);
+void oracle_detail_mask(const float *src, float *mask, int W, int H, float scaling, float threshold, float ceiling, float factor, float blur);
+float oracle_lutf_vec(const float *data, int size, float index);
+void oracle_nlmeans(float *img, int W, int H, float normcoeff, int strength, int detail_thresh, float scale);
+
 /* sleef-derived math (oracle/sleef.c); _s = scalar form, _v = per-lane SSE form */
 float oracle_xexpf_s(float d);
 float oracle_xexpf_v(float d);

@@ -227,3 +227,30 @@ def guided_filter(guide, src, r, eps, subsampling=0):
     dst = np.empty_like(src)
     lib().oracle_guided_filter(_ptr(guide), _ptr(src), _ptr(dst), src.shape[1], src.shape[0], r, C.c_float(eps), subsampling)
     return dst
+
+
+def gaussian_blur(a, sigma):
+    a = np.array(a, dtype=np.float32, order="C")
+    lib().oracle_gaussian_blur(_ptr(a), a.shape[1], a.shape[0], C.c_double(sigma))
+    return a
+
+
+def detail_mask(src, scaling, threshold, ceiling, factor, blur):
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    m = np.empty_like(src)
+    lib().oracle_detail_mask(_ptr(src), _ptr(m), src.shape[1], src.shape[0], C.c_float(scaling), C.c_float(threshold),
+                             C.c_float(ceiling), C.c_float(factor), C.c_float(blur))
+    return m
+
+
+def nlmeans(img, strength=50, detail=80, scale=1.0, normcoeff=65535.0):
+    img = np.array(img, dtype=np.float32, order="C")
+    lib().oracle_nlmeans(_ptr(img), img.shape[1], img.shape[0], C.c_float(normcoeff), strength, detail, C.c_float(scale))
+    return img
+
+
+def lutf_vec(table, x):
+    table = np.ascontiguousarray(table, dtype=np.float32)
+    L = lib()
+    L.oracle_lutf_vec.restype = C.c_float
+    return np.array([L.oracle_lutf_vec(_ptr(table), len(table), C.c_float(float(v))) for v in x], dtype=np.float32)

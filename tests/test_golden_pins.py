@@ -44,6 +44,9 @@ def test_lutf_scalar_matches_reference_lut_h():
     table = (np.sqrt(x) * 65535.0).astype(np.float32)
     got = O.lutf(table, g["index"])
     assert same_bits(got, g["scalar"])
+    n4 = len(g["index"]) // 4 * 4
+    gotv = O.lutf_vec(table, g["index"][:n4])
+    assert same_bits(gotv, g["vector"][:n4])     # LUTf::operator[](vfloat)
 
 
 def test_sleef_scalar_and_vector_forms_match_reference():
