@@ -37,6 +37,11 @@ class DenoiseParams(C.Structure):
                 ("gamma", C.c_double), ("aggressive", C.c_int32), ("color_space", C.c_int32), ("chrominance_method", C.c_int32)]
 
 
+class DenoiseToolParams(C.Structure):
+    _fields_ = [("dn", DenoiseParams), ("smoothing_enabled", C.c_int32), ("guided_chroma_radius", C.c_int32),
+                ("nl_strength", C.c_int32), ("nl_detail", C.c_int32)]
+
+
 DN_SKIP_DETAIL_RECOVERY = 1
 
 
@@ -74,6 +79,8 @@ def _load():
     lib.artgpu_gaussian_blur.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_double]
     lib.artgpu_detail_mask.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(Plane), C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
     lib.artgpu_nlmeans.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_float, C.c_int, C.c_int, C.c_float]
+    lib.artgpu_improc_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseToolParams), C.POINTER(C.c_double), C.c_double,
+                                          C.c_double, C.POINTER(Plane), C.c_uint32]
     lib.artgpu_get_image.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int,
                                      C.POINTER(C.c_double), C.POINTER(RGB)]
     lib.artgpu_convert_color_space.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double)]
@@ -90,7 +97,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -184,6 +191,11 @@ class Context:
 
     def nlmeans(self, img: Plane, strength: int = 50, detail: int = 80, scale: float = 1.0, normcoeff: float = 65535.0):
         self._chk(LIB.artgpu_nlmeans(self._h, C.byref(img), normcoeff, strength, detail, scale))
+
+    def improc_denoise(self, image: RGB, params: DenoiseToolParams, ws, ecomp: float = 0.0, scale: float = 1.0, ccalc: Plane = None, flags: int = 0):
+        m = (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)])
+        self._chk(LIB.artgpu_improc_denoise(self._h, C.byref(image), C.byref(params), m, ecomp, scale,
+                                            None if ccalc is None else C.byref(ccalc), flags))
 
     # ---- wavelet_decomposition ----
     def wavelet_decompose(self, src: Plane, maxlvl: int):

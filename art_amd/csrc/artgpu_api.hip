@@ -1047,4 +1047,36 @@ int artgpu_nlmeans(artgpu_ctx *ctx, artgpu_plane *img, float normcoeff, int stre
     return pool_to_plane(ctx, work, img);
 }
 
+// ---------------------------------------------------------------------------------------------
+// ImProcFunctions::denoise
+// ---------------------------------------------------------------------------------------------
+int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_tool_params *p, const double ws[9],
+                          double ecomp, double scale, const artgpu_plane *ccalc, uint32_t flags)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!img || !p || !ws) return fail(ctx, ARTGPU_EINVAL, "improc_denoise: null argument");
+    if (!img->r.on_device) return fail(ctx, ARTGPU_EUNSUPPORTED, "improc_denoise: device-resident image required (the stages chain on the device)");
+    float wsf[9];
+    for (int k = 0; k < 9; ++k) wsf[k] = (float)ws[k];
+    int rc;
+    if (ecomp > 0) { if ((rc = artgpu_exposure(ctx, img, std::pow(2.f, (float)ecomp), 0.f * 2000.f))) return rc; }   // ipdenoise.cc:1161-1163
+    if ((rc = artgpu_rgb_denoise(ctx, img, &p->dn, wsf, 0.0, scale, ccalc, flags, nullptr, nullptr))) return rc;
+    if (p->smoothing_enabled) {
+        if ((rc = artgpu_denoise_guided_smoothing(ctx, img, ws, p->guided_chroma_radius, scale))) return rc;
+        if (p->nl_strength) {
+            PixArgs a = {};
+            float *pl[3] = {img->r.p, img->g.p, img->b.p};
+            for (int k = 0; k < 3; ++k) { a.dst[k] = pl[k]; a.mul[k] = wsf[3 + k]; }
+            a.dst_stride = (size_t)(img->r.row_stride_bytes / 4); a.w = img->r.w; a.h = img->r.h;
+            a.do_clip = 0;
+            HIPCHK(ctx, launch_yuv_mode(a, ctx->stream));
+            if ((rc = artgpu_nlmeans(ctx, &img->g, 65535.f, p->nl_strength, p->nl_detail, (float)scale))) return rc;
+            a.do_clip = 1;
+            HIPCHK(ctx, launch_yuv_mode(a, ctx->stream));
+        }
+    }
+    if (ecomp > 0) { if ((rc = artgpu_exposure(ctx, img, std::pow(2.f, (float)(-ecomp)), 0.f))) return rc; }         // L1181-1184
+    return ARTGPU_OK;
+}
+
 } // extern "C"

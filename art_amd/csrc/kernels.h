@@ -81,6 +81,7 @@ struct PixArgs {
 hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s);
 hipError_t launch_exposure(const PixArgs &a, hipStream_t s);
 hipError_t launch_tone_std(const PixArgs &a, hipStream_t s);
+hipError_t launch_yuv_mode(const PixArgs &a, hipStream_t s);
 
 // ---- wavelet_decomposition (wavelet.hip) ----
 struct WaveArgs {

@@ -110,6 +110,27 @@ __global__ void __launch_bounds__(256) tone_std_kernel(PixArgs a)
     }
 }
 
+// Imagefloat::setMode RGB -> YUV (imagefloat.cc:700-725: Y -> g plane, u = Y-b -> b plane, v = r-Y -> r plane) and
+// YUV -> RGB (L779-804), float working-space row ws_[1][*]; in place.  a.do_clip: 0 = to YUV, 1 = to RGB.
+__global__ void __launch_bounds__(256) yuv_mode_kernel(PixArgs a)
+{
+    const long long n = (long long)a.w * a.h;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+        const size_t di = (size_t)y * a.dst_stride + x;
+        if (!a.do_clip) {
+            const float r = a.dst[0][di], g = a.dst[1][di], b = a.dst[2][di];
+            const float Y = r * a.mul[0] + g * a.mul[1] + b * a.mul[2];
+            a.dst[1][di] = Y; a.dst[2][di] = Y - b; a.dst[0][di] = r - Y;
+        } else {
+            const float Y = a.dst[1][di], u = a.dst[2][di], v = a.dst[0][di];
+            const float b = Y - u, r = v + Y;
+            const float g = (Y - r * a.mul[0] - b * a.mul[2]) / a.mul[1];
+            a.dst[0][di] = r; a.dst[1][di] = g; a.dst[2][di] = b;
+        }
+    }
+}
+
 static int pix_grid(const PixArgs &a)
 {
     const long long n = (long long)a.w * a.h;
@@ -124,6 +145,11 @@ hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s)
 hipError_t launch_exposure(const PixArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(exposure_kernel, dim3(pix_grid(a)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_yuv_mode(const PixArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(yuv_mode_kernel, dim3(pix_grid(a)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_tone_std(const PixArgs &a, hipStream_t s)

@@ -191,6 +191,23 @@ int artgpu_detail_mask(artgpu_ctx *ctx, const artgpu_plane *src, artgpu_plane *m
  * (the Y plane after Imagefloat::setMode(YUV), ipdenoise.cc:1174-1177), in place. */
 int artgpu_nlmeans(artgpu_ctx *ctx, artgpu_plane *img, float normcoeff, int strength, int detail_thresh, float scale);
 
+/* Replaces ImProcFunctions::denoise (rtengine/ipdenoise.cc:1096-1189) after its noise-curve set-up:
+ *   if (ecomp > 0) expcomp(+ecomp); RGB_denoise(kall 0, isRAW, expcomp 0); if (smoothing_enabled) {
+ *   denoiseGuidedSmoothing; if (nl_strength) { setMode(YUV); NLMeans(Y, 65535, nl_strength, nl_detail, scale);
+ *   setMode(RGB); } } if (ecomp > 0) expcomp(-ecomp).
+ * ecomp = params->exposure.enabled ? params->exposure.expcomp : 0 (L1155).  ws: working-space matrix as doubles
+ * (TMatrix); the float casts the reference makes (wpi, Imagefloat::ws_) are made inside.  ccalc as in
+ * artgpu_rgb_denoise; flags: ARTGPU_DN_* (0 = the reference's behaviour). */
+typedef struct {
+    artgpu_denoise_params dn;
+    int32_t smoothing_enabled;
+    int32_t guided_chroma_radius;
+    int32_t nl_strength;
+    int32_t nl_detail;
+} artgpu_denoise_tool_params;
+int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_tool_params *params, const double ws[9],
+                          double ecomp, double scale, const artgpu_plane *ccalc, uint32_t flags /* as artgpu_rgb_denoise */);
+
 /* Bytes of device scratch the context currently holds (arena + staging). */
 size_t artgpu_scratch_bytes(const artgpu_ctx *ctx);
 

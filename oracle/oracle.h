@@ -37,6 +37,8 @@ void oracle_exposure(float *const img[3], size_t s, int w, int h, float exp_scal
 void oracle_filmlike_clip(float *const img[3], size_t s, int w, int h, float whitept);
 float oracle_lutf(const float *data, int size, float index);
 void oracle_tone_curve_std(float *const img[3], size_t s, int w, int h, const float *lut65536);
+void oracle_rgb_to_yuv(float *const img[3], size_t s, int w, int h, const float ws[9]);
+void oracle_yuv_to_rgb(float *const img[3], size_t s, int w, int h, const float ws[9]);
 
 /* wavelet_decomposition, subsampling == 1 (oracle/wavelet.c) */
 typedef struct {

@@ -120,3 +120,28 @@ void oracle_tone_curve_std(float *const img[3], size_t s, int w, int h, const fl
             }
         }
 }
+
+/* Imagefloat::setMode(YUV) / setMode(RGB) (imagefloat.cc:700-725,779-804), float working-space matrix */
+void oracle_rgb_to_yuv(float *const img[3], size_t s, int w, int h, const float ws[9])
+{
+#pragma omp parallel for
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            size_t o = (size_t)y * s + x;
+            float r = img[0][o], g = img[1][o], b = img[2][o];
+            float Y = r * ws[3] + g * ws[4] + b * ws[5];
+            img[1][o] = Y; img[2][o] = Y - b; img[0][o] = r - Y;
+        }
+}
+void oracle_yuv_to_rgb(float *const img[3], size_t s, int w, int h, const float ws[9])
+{
+#pragma omp parallel for
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            size_t o = (size_t)y * s + x;
+            float Y = img[1][o], u = img[2][o], v = img[0][o];
+            float b = Y - u, r = v + Y;
+            float g = (Y - r * ws[3] - b * ws[5]) / ws[4];
+            img[0][o] = r; img[1][o] = g; img[2][o] = b;
+        }
+}

@@ -254,3 +254,24 @@ def lutf_vec(table, x):
     L = lib()
     L.oracle_lutf_vec.restype = C.c_float
     return np.array([L.oracle_lutf_vec(_ptr(table), len(table), C.c_float(float(v))) for v in x], dtype=np.float32)
+
+
+def improc_denoise(img, dn_kw=None, smoothing=True, radius=3, nl_strength=50, nl_detail=80, ecomp=0.0, scale=1.0,
+                   ws=REC2020_WS_D, detail_recovery=True):
+    """ImProcFunctions::denoise (ipdenoise.cc:1096-1189) composed from the oracle stages."""
+    wsf = np.asarray(ws, dtype=np.float64).astype(np.float32)
+    if ecomp > 0:
+        img = exposure(img, float(np.float32(2.0) ** np.float32(ecomp)), 0.0)
+    img = rgb_denoise(img, default_denoise_params(scale=scale, **(dn_kw or {})), wsf, detail_recovery=detail_recovery)
+    if smoothing:
+        img = guided_smoothing(img, ws, radius, scale)
+        if nl_strength:
+            img = [np.array(p, dtype=np.float32, order="C") for p in img]
+            h, w = img[0].shape
+            wp = np.ascontiguousarray(wsf).reshape(9)
+            lib().oracle_rgb_to_yuv(_p3(img), C.c_size_t(w), w, h, _ptr(wp))
+            img[1] = nlmeans(img[1], nl_strength, nl_detail, scale)
+            lib().oracle_yuv_to_rgb(_p3(img), C.c_size_t(w), w, h, _ptr(wp))
+    if ecomp > 0:
+        img = exposure(img, float(np.float32(2.0) ** np.float32(-ecomp)), 0.0)
+    return img

@@ -53,3 +53,29 @@ def test_nlmeans_strength_zero_is_identity(gpu_ctx):
     got = img.copy()
     gpu_ctx.nlmeans(capi.host_plane(got), 0, 80, 1.0)
     assert same(got, img) == 0
+
+
+@pytest.mark.parametrize("detail", [False, True])
+def test_full_denoise_tool_config4_stages(gpu_ctx, detail):
+    """ImProcFunctions::denoise with smoothing on: RGB_denoise + guided chroma smoothing + setMode(YUV) + NL-means on Y +
+    setMode(RGB), bracketed by expcomp (BASELINE config 4's per-frame stages).  Without the FFTW-defined DCT detail recovery
+    the whole tool is bit-exact; with it the DCT tolerance propagates through the NL-means weights."""
+    import torch
+    from art_amd import capi
+    w, h = 640, 480
+    raw = synth.bayer_frame(w, h, synth.FILTERS_RGGB, seed=9, noise=2048)
+    img = O.amaze(raw, synth.FILTERS_RGGB, 1.0, 4)
+    d = [torch.from_numpy(p.copy()).cuda() for p in img]
+    rgb = capi.RGB(*[capi.device_plane(t) for t in d])
+    tp = capi.DenoiseToolParams(capi.DenoiseParams(40.0, 50.0, 0, 15.0, 0.0, 0.0, 1.7, 0, 0, 0), 1, 3, 50, 80)
+    gpu_ctx.improc_denoise(rgb, tp, O.REC2020_WS_D, ecomp=0.3, flags=0 if detail else capi.DN_SKIP_DETAIL_RECOVERY)
+    gpu_ctx.synchronize()
+    got = [t.cpu().numpy() for t in d]
+    ref = O.improc_denoise(img, smoothing=True, radius=3, nl_strength=50, nl_detail=80, ecomp=0.3, detail_recovery=detail)
+    for g, r in zip(got, ref):
+        if not detail:
+            assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+        else:
+            err = np.abs(g.astype(np.float64) - r.astype(np.float64))
+            # on a 0..65535 scale: the NL-means weights amplify the DCT round-off at isolated pixels
+            assert err.max() <= 512.0 and np.percentile(err, 99.9) <= 8.0 and np.median(err) <= 0.05, (err.max(), np.percentile(err, 99.9), np.median(err))
