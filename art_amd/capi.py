@@ -43,6 +43,20 @@ class DenoiseToolParams(C.Structure):
 
 
 DN_SKIP_DETAIL_RECOVERY = 1
+# the chroma noise curve ImProcFunctions::denoise always installs (ipdenoise.cc:1139-1149)
+DEFAULT_NOISE_C_CURVE_POINTS = (1.0, 0.05, 0.50, 0.35, 0.35, 0.35, 0.05, 0.35, 0.35)
+
+
+def noise_curve_lut(points=DEFAULT_NOISE_C_CURVE_POINTS):
+    """NoiseCurve::Set -> (501-entry float32 LUT, sum)."""
+    pts = (C.c_double * len(points))(*[float(p) for p in points])
+    lut = np.zeros(501, np.float32)
+    s = C.c_float(0)
+    rc = LIB.artgpu_noise_curve_lut(pts, len(points), lut.ctypes.data_as(C.POINTER(C.c_float)), C.byref(s))
+    if rc:
+        raise ArtGpuError(f"artgpu_noise_curve_lut: error {rc}")
+    return lut, float(s.value)
+
 
 
 class ArtGpuError(RuntimeError):
@@ -53,6 +67,13 @@ def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for the device path)")
+    # When this process also uses torch (device buffers, torch.distributed), torch must load its bundled HIP/HSA runtime
+    # FIRST: loading libartgpu.so (linked against /opt/rocm's libamdhip64) before torch leaves two runtimes in the process
+    # and hipGetDeviceCount fails.  Stand-alone users of the library (artgpu-cli, a C++ host) are unaffected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.artgpu_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     lib.artgpu_destroy.argtypes = [C.c_void_p]
@@ -80,7 +101,10 @@ def _load():
     lib.artgpu_detail_mask.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(Plane), C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
     lib.artgpu_nlmeans.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_float, C.c_int, C.c_int, C.c_float]
     lib.artgpu_improc_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseToolParams), C.POINTER(C.c_double), C.c_double,
-                                          C.c_double, C.POINTER(Plane), C.c_uint32]
+                                          C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_uint32]
+    lib.artgpu_noise_curve_lut.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.artgpu_denoise_chroma_map.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float),
+                                              C.POINTER(Plane)]
     lib.artgpu_get_image.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int,
                                      C.POINTER(C.c_double), C.POINTER(RGB)]
     lib.artgpu_convert_color_space.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double)]
@@ -97,7 +121,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -192,10 +216,23 @@ class Context:
     def nlmeans(self, img: Plane, strength: int = 50, detail: int = 80, scale: float = 1.0, normcoeff: float = 65535.0):
         self._chk(LIB.artgpu_nlmeans(self._h, C.byref(img), normcoeff, strength, detail, scale))
 
-    def improc_denoise(self, image: RGB, params: DenoiseToolParams, ws, ecomp: float = 0.0, scale: float = 1.0, ccalc: Plane = None, flags: int = 0):
-        m = (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)])
-        self._chk(LIB.artgpu_improc_denoise(self._h, C.byref(image), C.byref(params), m, ecomp, scale,
-                                            None if ccalc is None else C.byref(ccalc), flags))
+    def denoise_chroma_map(self, image: RGB, calclum_mat, ws, curve, ccalc: Plane):
+        m = None if calclum_mat is None else (C.c_double * 9)(*[float(v) for v in np.asarray(calclum_mat, dtype=np.float64).reshape(9)])
+        wsd = (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)])
+        cv = np.ascontiguousarray(curve, dtype=np.float32)
+        assert cv.shape == (501,)
+        self._chk(LIB.artgpu_denoise_chroma_map(self._h, C.byref(image), m, wsd, cv.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ccalc)))
+
+    def improc_denoise(self, image: RGB, params: DenoiseToolParams, ws, ecomp: float = 0.0, scale: float = 1.0, calclum_mat=None,
+                       noise_c_curve=None, flags: int = 0):
+        wsd = (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)])
+        m = None if calclum_mat is None else (C.c_double * 9)(*[float(v) for v in np.asarray(calclum_mat, dtype=np.float64).reshape(9)])
+        cv = None
+        if noise_c_curve is not None:
+            cva = np.ascontiguousarray(noise_c_curve, dtype=np.float32)
+            assert cva.shape == (501,)
+            cv = cva.ctypes.data_as(C.POINTER(C.c_float))
+        self._chk(LIB.artgpu_improc_denoise(self._h, C.byref(image), C.byref(params), wsd, ecomp, scale, m, cv, flags))
 
     # ---- wavelet_decomposition ----
     def wavelet_decompose(self, src: Plane, maxlvl: int):

@@ -605,7 +605,7 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF };
 
 struct DevDecomp {
     float *bands, *low[2];
@@ -1048,10 +1048,64 @@ int artgpu_nlmeans(artgpu_ctx *ctx, artgpu_plane *img, float normcoeff, int stre
 }
 
 // ---------------------------------------------------------------------------------------------
-// ImProcFunctions::denoise
+// chroma noise-curve map + ImProcFunctions::denoise
 // ---------------------------------------------------------------------------------------------
+int artgpu_noise_curve_lut(const double *points, int npoints, float lut[501], float *sum)
+{
+    if (!points || npoints < 0 || !lut) return ARTGPU_EINVAL;
+    const float s = noise_curve_lut(points, npoints, lut);
+    if (sum) *sum = s;
+    return ARTGPU_OK;
+}
+
+// fills P_CCMAP ((w+1)/2 x (h+1)/2, contiguous) from device planes
+static int chroma_map_dev(artgpu_ctx *ctx, float *const planes[3], size_t stride, int w, int h, const double *mat, const double ws[9],
+                          const float *curve, float **out)
+{
+    const int wid = (w + 1) / 2, hei = (h + 1) / 2;
+    float *map, *tab;
+    int rc;
+    const bool fresh = ctx->pool[P_CACHEF] == nullptr;
+    if ((rc = pool_get(ctx, P_CCMAP, (size_t)wid * hei * 4, &map)) || (rc = pool_get(ctx, P_CACHEF, (65536 + 512) * 4, &tab))) return rc;
+    if (fresh) {
+        std::vector<float> host(65536);
+        build_cachef(host.data());
+        HIPCHK(ctx, hipMemcpyAsync(tab, host.data(), 65536 * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host vector goes out of scope
+    }
+    HIPCHK(ctx, hipMemcpyAsync(tab + 65536, curve, 501 * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));       // caller's curve may be a temporary
+    ChromaMapArgs a = {};
+    for (int k = 0; k < 3; ++k) a.src[k] = planes[k];
+    a.stride = stride; a.wid = wid; a.hei = hei;
+    a.has_mat = mat ? 1 : 0;
+    for (int k = 0; k < 9; ++k) { a.mat[k] = mat ? mat[k] : 0.0; a.wpi[k] = (float)ws[k]; }
+    a.cachef = tab; a.curve = tab + 65536; a.out = map;
+    HIPCHK(ctx, launch_chroma_map(a, ctx->stream));
+    *out = map;
+    return ARTGPU_OK;
+}
+
+int artgpu_denoise_chroma_map(artgpu_ctx *ctx, const artgpu_rgb *img, const double *calclum_mat, const double ws[9],
+                              const float noise_c_curve[501], artgpu_plane *ccalc)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!img || !ws || !noise_c_curve || !ccalc) return fail(ctx, ARTGPU_EINVAL, "denoise_chroma_map: null argument");
+    DevRGB d;
+    int rc = bind_rgb(ctx, img, 4, true, &d, "denoise_chroma_map");
+    if (rc) return rc;
+    const int wid = (d.w + 1) / 2, hei = (d.h + 1) / 2;
+    if (!plane_ok(ccalc) || ccalc->w != wid || ccalc->h != hei) return fail(ctx, ARTGPU_EINVAL, "denoise_chroma_map: ccalc must be %dx%d", wid, hei);
+    float *map;
+    if ((rc = chroma_map_dev(ctx, d.p, d.stride, d.w, d.h, calclum_mat, ws, noise_c_curve, &map))) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(ccalc->p, (size_t)ccalc->row_stride_bytes, map, (size_t)wid * 4, (size_t)wid * 4, hei,
+                                 ccalc->on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    if (!ccalc->on_device) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
 int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_tool_params *p, const double ws[9],
-                          double ecomp, double scale, const artgpu_plane *ccalc, uint32_t flags)
+                          double ecomp, double scale, const double *calclum_mat, const float *noise_c_curve, uint32_t flags)
 {
     if (!ctx) return ARTGPU_EINVAL;
     if (!img || !p || !ws) return fail(ctx, ARTGPU_EINVAL, "improc_denoise: null argument");
@@ -1059,8 +1113,21 @@ int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise
     float wsf[9];
     for (int k = 0; k < 9; ++k) wsf[k] = (float)ws[k];
     int rc;
-    if (ecomp > 0) { if ((rc = artgpu_exposure(ctx, img, std::pow(2.f, (float)ecomp), 0.f * 2000.f))) return rc; }   // ipdenoise.cc:1161-1163
-    if ((rc = artgpu_rgb_denoise(ctx, img, &p->dn, wsf, 0.0, scale, ccalc, flags, nullptr, nullptr))) return rc;
+    artgpu_plane ccalc = {}, *ccalc_p = nullptr;
+    if (noise_c_curve) {
+        float sum = 0.f;
+        for (int i = 0; i < 501; ++i) sum += noise_c_curve[i];      // NoiseCurve::getSum (ipdenoise.cc:698)
+        if (sum > 5.f) {                                            // useNoiseCCurve, FTblockDN.cc:1672
+            float *pl[3] = {img->r.p, img->g.p, img->b.p}, *map;
+            if (img->g.row_stride_bytes != img->r.row_stride_bytes || img->b.row_stride_bytes != img->r.row_stride_bytes)
+                return fail(ctx, ARTGPU_EINVAL, "improc_denoise: planes must share one row stride");
+            if ((rc = chroma_map_dev(ctx, pl, (size_t)(img->r.row_stride_bytes / 4), img->r.w, img->r.h, calclum_mat, ws, noise_c_curve, &map))) return rc;
+            ccalc.p = map; ccalc.w = (img->r.w + 1) / 2; ccalc.h = (img->r.h + 1) / 2; ccalc.row_stride_bytes = (int64_t)ccalc.w * 4; ccalc.on_device = 1;
+            ccalc_p = &ccalc;
+        }
+    }
+    if (ecomp > 0) { if ((rc = artgpu_exposure(ctx, img, (float)std::pow(2.0, ecomp), 0.f))) return rc; }   // ipdenoise.cc:1161-1163
+    if ((rc = artgpu_rgb_denoise(ctx, img, &p->dn, wsf, 0.0, scale, ccalc_p, flags, nullptr, nullptr))) return rc;
     if (p->smoothing_enabled) {
         if ((rc = artgpu_denoise_guided_smoothing(ctx, img, ws, p->guided_chroma_radius, scale))) return rc;
         if (p->nl_strength) {
@@ -1075,7 +1142,7 @@ int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise
             HIPCHK(ctx, launch_yuv_mode(a, ctx->stream));
         }
     }
-    if (ecomp > 0) { if ((rc = artgpu_exposure(ctx, img, std::pow(2.f, (float)(-ecomp)), 0.f))) return rc; }         // L1181-1184
+    if (ecomp > 0) { if ((rc = artgpu_exposure(ctx, img, (float)std::pow(2.0, -ecomp), 0.f))) return rc; }         // L1181-1184
     return ARTGPU_OK;
 }
 

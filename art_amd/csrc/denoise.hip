@@ -424,4 +424,54 @@ hipError_t launch_vblur_combine(const BlurArgs &a, int nsub, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Chroma noise-curve map.  calclum = every second pixel of the image (ipdenoise.cc:1113-1129), pushed through
+// convertColorSpace's matrix branch again (L1131 -> rawimagesource.cc:3184-3213, double accumulation), then
+// Color::rgbxyz(float wpi) + Color::XYZ2Lab (color.cc:833-838,1247-1259,1382-1397) and
+// ccalc = SQR(1 + 4*noiseCCurve[cN/60]) for cN > 100, else the cN = 100 constant (FTblockDN.cc:1733-1771).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float xyz2lab_f(const float *__restrict__ cachef, float f)
+{
+    if (f != f) return f;
+    if (f < 0.f) return (float)(327.68 * (((24389.0 / 27.0) * (double)f / (double)65535.f + 16.0) / 116.0));
+    if (f > 65535.f) return 327.68f * xcbrtf_s(f / 65535.f);
+    return lutf_lookup<false>(cachef, 65536, f);
+}
+__global__ void __launch_bounds__(256) chroma_map_kernel(ChromaMapArgs a)
+{
+    const long long n = (long long)a.wid * a.hei;
+    const float t0 = 1.f + 1.f * (4.f * lutf_lookup<true>(a.curve, 501, 100.f / 60.f));
+    const float cn100 = t0 * t0;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int ii = (int)(t / a.wid), jj = (int)(t - (long long)ii * a.wid);
+        const size_t o = (size_t)(2 * ii) * a.stride + 2 * jj;
+        float RL = a.src[0][o], GL = a.src[1][o], BL = a.src[2][o];
+        if (a.has_mat) {
+            const double dr = RL, dg = GL, db = BL;
+            RL = (float)(a.mat[0] * dr + a.mat[1] * dg + a.mat[2] * db);
+            GL = (float)(a.mat[3] * dr + a.mat[4] * dg + a.mat[5] * db);
+            BL = (float)(a.mat[6] * dr + a.mat[7] * dg + a.mat[8] * db);
+        }
+        const float XL = a.wpi[0] * RL + a.wpi[1] * GL + a.wpi[2] * BL;
+        const float YL = a.wpi[3] * RL + a.wpi[4] * GL + a.wpi[5] * BL;
+        const float ZL = a.wpi[6] * RL + a.wpi[7] * GL + a.wpi[8] * BL;
+        const float fx = xyz2lab_f(a.cachef, XL / 0.9642f), fy = xyz2lab_f(a.cachef, YL), fz = xyz2lab_f(a.cachef, ZL / 0.8249f);
+        const float A = 500.0f * (fx - fy), B = 200.0f * (fy - fz);
+        const float cN = sqrtf(A * A + B * B);   // sqrtf is the correctly rounded one (__fsqrt_rn maps to the native approximation)
+        float r = cn100;
+        if (cN > 100) {
+            const float u = 1.f + 1.f * (4.f * lutf_lookup<true>(a.curve, 501, cN / 60.f));
+            r = u * u;
+        }
+        a.out[t] = r;
+    }
+}
+hipError_t launch_chroma_map(const ChromaMapArgs &a, hipStream_t s)
+{
+    const long long n = (long long)a.wid * a.hei;
+    long long g = (n + 255) / 256;
+    hipLaunchKernelGGL(chroma_map_kernel, dim3((unsigned)(g < 8192 ? (g ? g : 1) : 8192)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 } // namespace artgpu

@@ -84,6 +84,29 @@ __device__ __forceinline__ float xlogf_s(float d) { return sl_logf<false>(d); }
 __device__ __forceinline__ float xlogf_v(float d) { return sl_logf<true>(d); }
 __device__ __forceinline__ float xlogf_v_nocheck(float d) { return sl_log_core<true>(d); }
 
+// xcbrtf (rtengine/sleef.h:966-991), scalar form
+__device__ __forceinline__ float xcbrtf_s(float d)
+{
+    float q = 1.0f;
+    const int e = sl_ilogbp1f(d);
+    d = sl_ldexpk<false>(d, -e);
+    const int r = (e + 6144) % 3;
+    q = (r == 1) ? 1.2599210498948731647672106f : q;
+    q = (r == 2) ? 1.5874010519681994747517056f : q;
+    q = sl_ldexpk<false>(q, (e + 6144) / 3 - 2048);
+    q = __int_as_float(__float_as_int(q) ^ (__float_as_int(d) & (int)0x80000000));
+    d = __int_as_float(__float_as_int(d) & 0x7fffffff);
+    float x = -0.601564466953277587890625f;
+    x = sl_mla(x, d, 2.8208892345428466796875f);
+    x = sl_mla(x, d, -5.532182216644287109375f);
+    x = sl_mla(x, d, 5.898262500762939453125f);
+    x = sl_mla(x, d, -3.8095417022705078125f);
+    x = sl_mla(x, d, 2.2241256237030029296875f);
+    float y = d * x * x;
+    y = (y - (2.0f / 3.0f) * y * (y * x - 1.0f)) * q;
+    return y;
+}
+
 // LUTf::operator[](float) (rtengine/LUT.h:436-459): clip_above selects LUT_CLIP_ABOVE behaviour
 template <bool CLIP_ABOVE>
 __device__ __forceinline__ float lutf_lookup(const float *__restrict__ data, int size, float index)

@@ -1,0 +1,161 @@
+// hostluts.hip -- host-side construction of the small look-up tables the device stages take as inputs.  These are
+// the counterparts of tables the reference also builds once on the host (no per-pixel work here):
+//   FlatCurve (FCT_MinMaxCPoints) polyline     rtengine/flatcurves.cc:27-77,124-360, rtengine/curves.cc:98-132
+//   NoiseCurve::Set -> 501-entry LUT + sum     rtengine/ipdenoise.cc:684-716
+//   Color::cachef                              rtengine/color.cc:178,202-217
+#include "kernels.h"
+#include <cmath>
+#include <vector>
+
+namespace artgpu {
+
+namespace {
+
+struct Polyline {
+    std::vector<double> x, y, slope;
+    void add(double px, double py) { x.push_back(px); y.push_back(py); }
+    // Curve::fillDyByDx
+    void finish()
+    {
+        slope.resize(x.size() - 1);
+        for (size_t i = 0; i + 1 < x.size(); ++i) slope[i] = (y[i + 1] - y[i]) / (x[i + 1] - x[i]);
+    }
+    // FlatCurve::getVal, FCT_MinMaxCPoints branch
+    double eval(double t) const
+    {
+        if (t < x[0]) t += 1.0;
+        unsigned lo = 0, hi = (unsigned)x.size() - 1;
+        while (hi > 1 + lo) {
+            const unsigned mid = (hi + lo) / 2;
+            if (x[mid] > t) hi = mid; else lo = mid;
+        }
+        return y[lo] + (t - x[lo]) * slope[lo];
+    }
+};
+
+struct Knot { double x, y, left, right; };
+
+// One sub-curve of FlatCurve::CtrlPoints_set: either a straight segment (2 points) or a quadratic Bezier (3 points).
+struct SubCurve { double px[3], py[3]; bool linear; double length; };
+
+double seg(double x0, double y0, double x1, double y1) { const double dx = x1 - x0, dy = y1 - y0; return std::sqrt(dx * dx + dy * dy); }
+
+SubCurve line(double x0, double y0, double x1, double y1)
+{
+    SubCurve s = {{x0, x1, 0.}, {y0, y1, 0.}, true, 0.};
+    s.length = seg(x0, y0, x1, y1);
+    return s;
+}
+SubCurve bezier(double x0, double y0, double x1, double y1, double x2, double y2)
+{
+    SubCurve s = {{x0, x1, x2}, {y0, y1, y2}, false, 0.};
+    s.length = seg(x0, y0, x1, y1);
+    s.length += seg(x1, y1, x2, y2);
+    return s;
+}
+
+// FlatCurve::CtrlPoints_set (flatcurves.cc:124-327)
+bool build_polyline(const std::vector<Knot> &k, bool periodic, int ppn, Polyline &poly)
+{
+    const int nseg = (int)k.size() - 1;   // the caller appended the wrap-around knot for periodic curves
+    std::vector<SubCurve> sc;
+    double total = 0.;
+    for (int i = 0; i < nseg; ++i) {
+        const Knot &a = k[i], &b = k[i + 1];
+        const bool start_linear = a.right == 0. || a.y == b.y;
+        const bool end_linear = b.left == 0. || a.y == b.y;
+        if (start_linear && end_linear) {
+            sc.push_back(line(a.x, a.y, b.x, b.y));
+            total += sc.back().length;
+            continue;
+        }
+        double xp1 = start_linear ? a.x : (b.x - a.x) * a.right + a.x;
+        double xp3 = end_linear ? b.x : (a.x - b.x) * b.left + b.x;
+        const double xp2 = (xp1 + xp3) / 2.0, yp2 = (a.y + b.y) / 2.0;
+        if (a.right + b.left > 1.0) xp1 = xp3 = xp2;
+        sc.push_back(start_linear ? line(a.x, a.y, xp2, yp2) : bezier(a.x, a.y, xp1, a.y, xp2, yp2));
+        total += sc.back().length;
+        sc.push_back(end_linear ? line(xp2, yp2, b.x, b.y) : bezier(xp2, yp2, xp3, b.y, b.x, b.y));
+        total += sc.back().length;
+    }
+    if (sc.empty()) return false;
+    if (!periodic && sc[0].px[0] != 0.) poly.add(0., sc[0].py[0]);
+    poly.add(sc[0].px[0], sc[0].py[0]);
+    double last_y = sc[0].py[0];
+    for (const SubCurve &s : sc) {
+        if (s.linear) {
+            poly.add(s.px[1], s.py[1]);
+            last_y = s.py[1];
+        } else {
+            const int npoints = (int)(((double)ppn * s.length) / total);
+            if (npoints < 0) return false;
+            const double increment = 1.0 / (double)(npoints - 1);
+            for (int q = 1; q < npoints - 1; ++q) {          // Curve::AddPolygons, firstPointIncluded == false
+                const double t = q * increment;
+                const double t2 = t * t;
+                const double tr = 1. - t;
+                const double tr2 = tr * tr;
+                const double tr2t = tr * 2 * t;
+                poly.add(tr2 * s.px[0] + tr2t * s.px[1] + t2 * s.px[2], tr2 * s.py[0] + tr2t * s.py[1] + t2 * s.py[2]);
+            }
+            poly.add(s.px[2], s.py[2]);
+            last_y = s.py[2];
+        }
+    }
+    poly.add(3.0, last_y);
+    poly.finish();
+    return true;
+}
+
+} // namespace
+
+// FlatCurve(points, periodic, ppn) + setIdentityValue(identity), sampled at i/(nout-1).  Returns true if identity.
+bool flat_curve_sample(const double *pts, int npts, bool periodic, int ppn, double identity, int nout, double *out)
+{
+    bool identity_curve = true;
+    Polyline poly;
+    if (npts > 4 && (int)pts[0] == 1 /* FCT_MinMaxCPoints */) {
+        const int n = (npts - 1) / 4;
+        std::vector<Knot> k;
+        for (int i = 0; i < n; ++i) k.push_back({pts[1 + 4 * i], pts[2 + 4 * i], pts[3 + 4 * i], pts[4 + 4 * i]});
+        if (periodic) k.push_back({pts[1] + 1.0, pts[2], pts[3], pts[4]});
+        for (const Knot &q : k)
+            if (q.y >= identity + 1.e-7 || q.y <= identity - 1.e-7) { identity_curve = false; break; }
+        if (!identity_curve && n > (periodic ? 1 : 0)) {
+            if (!build_polyline(k, periodic, ppn > 65500 ? 65500 : ppn, poly)) identity_curve = true;
+        } else {
+            identity_curve = true;
+        }
+    }
+    for (int s = 0; s < nout; ++s) out[s] = identity_curve ? identity : poly.eval((double)s / (double)(nout - 1));
+    return identity_curve;
+}
+
+// NoiseCurve::Set(const std::vector<double>&): returns the running float sum (0 when the curve is reset)
+float noise_curve_lut(const double *pts, int npts, float lut[501])
+{
+    for (int i = 0; i < 501; ++i) lut[i] = 0.f;
+    if (!(npts > 0 && pts[0] > 0. && pts[0] < 2.)) return 0.f;      // FCT_Linear < kind < FCT_Unchanged
+    double v[501];
+    if (flat_curve_sample(pts, npts, false, 1000 / 2, 0., 501, v)) return 0.f;
+    float sum = 0.f;
+    for (int i = 0; i < 501; ++i) {
+        lut[i] = (float)v[i];
+        if (lut[i] < 0.01f) lut[i] = 0.01f;
+        sum += lut[i];
+    }
+    return sum;
+}
+
+// Color::cachef
+void build_cachef(float *lut)
+{
+    const double kappa = 24389.0 / 27.0, eps = 216.0 / 24389.0;
+    const float maxvalf = 65535.f;
+    const int epsmaxint = (int)((double)maxvalf * eps);
+    int i = 0;
+    for (; i <= epsmaxint; i++) lut[i] = (float)(327.68 * ((kappa * i / maxvalf + 16.0) / 116.0));
+    for (; i < 65536; i++) lut[i] = (float)(327.68 * std::cbrt((double)i / maxvalf));
+}
+
+} // namespace artgpu

@@ -112,6 +112,21 @@ struct DnPixArgs {
     float ws1[3];           // working-space matrix row 1 (luminance)
     float realred, realblue, qhighFactor;
 };
+// chroma noise-curve map (ipdenoise.cc:1113-1131 + FTblockDN.cc:1716-1777)
+struct ChromaMapArgs {
+    const float *src[3]; size_t stride;   // full-resolution image
+    int wid, hei;                         // (w+1)/2 x (h+1)/2
+    int has_mat; double mat[9];           // convertColorSpace matrix applied to the subsampled copy
+    float wpi[9];                         // working space -> XYZ, float casts
+    const float *cachef;                  // 65536-entry Lab f() LUT (device)
+    const float *curve;                   // 501-entry NoiseCurve LUT (device)
+    float *out;                           // wid x hei
+};
+hipError_t launch_chroma_map(const ChromaMapArgs &a, hipStream_t s);
+bool flat_curve_sample(const double *pts, int npts, bool periodic, int ppn, double identity, int nout, double *out);
+float noise_curve_lut(const double *pts, int npts, float lut[501]);
+void build_cachef(float *lut65536);
+
 struct ShrinkArgs {
     float *coef;            // bands of the decomposition being shrunk: [nsub][n]
     const float *coefL;     // bands of the L decomposition (AB only)

@@ -36,7 +36,8 @@ int main(int argc, char **argv)
     bool u16 = false;
     uint32_t filters = 0x94949494u;
     double lum = 0, chroma = 0, expcomp = 0;
-    bool dn = false;
+    bool dn = false, smoothing = false;
+    int gradius = 3, nlstrength = 0, nldetail = 80;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -50,6 +51,7 @@ int main(int argc, char **argv)
         else if (a == "--expcomp") expcomp = std::atof(next());
         else if (a == "--method") { std::string m = next(); method = (m == "rcd") ? ARTGPU_BAYER_RCD : ARTGPU_BAYER_AMAZE; }
         else if (a == "--denoise") { dn = true; if (std::sscanf(next(), "%lf,%lf", &lum, &chroma) != 2) { std::fprintf(stderr, "--denoise L,C\n"); return 2; } }
+        else if (a == "--smoothing") { smoothing = true; if (std::sscanf(next(), "%d,%d,%d", &gradius, &nlstrength, &nldetail) != 3) { std::fprintf(stderr, "--smoothing radius,nlStrength,nlDetail\n"); return 2; } }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (in.empty() || W <= 0 || H <= 0) { std::fprintf(stderr, "usage: artgpu-cli --in frame.f32 --width W --height H [options]\n"); return 2; }
@@ -71,6 +73,7 @@ int main(int argc, char **argv)
         params.bayersensor.method = method;
         params.bayersensor.border = border;
         params.denoise.enabled = dn; params.denoise.luminance = lum; params.denoise.chrominance = chroma; params.denoise.luminanceDetail = 50;
+        params.denoise.smoothingEnabled = smoothing; params.denoise.guidedChromaRadius = gradius; params.denoise.nlStrength = nlstrength; params.denoise.nlDetail = nldetail;
         params.exposure.expcomp = expcomp;
         params.toneCurve.lut = default_tone_lut();
 
@@ -89,7 +92,7 @@ int main(int argc, char **argv)
         const double mat[9] = {0.6325, 0.2312, 0.0921, 0.2198, 0.7712, 0.0090, 0.0166, 0.0713, 0.7514};
         imgsrc.convertColorSpace(&img, mat);
         ImProcFunctions ipf(ctx, &params, 1.0);
-        ipf.denoise(&img);
+        ipf.denoise(&imgsrc, &img);
         // stage_finish (simpleprocess.cc:389-396)
         ipf.process(ImProcFunctions::Pipeline::OUTPUT, ImProcFunctions::Stage::STAGE_1, &img);
         ipf.process(ImProcFunctions::Pipeline::OUTPUT, ImProcFunctions::Stage::STAGE_2, &img);

@@ -77,10 +77,11 @@ public:
 struct ProcParams {
     struct { int method = ARTGPU_BAYER_AMAZE; int border = 4; } bayersensor;  // raw.bayersensor.{method,border}
     struct { bool enabled = false; double luminance = 0, luminanceDetail = 0; int luminanceDetailThreshold = 0; double chrominance = 15,
-             chrominanceRedGreen = 0, chrominanceBlueYellow = 0, gamma = 1.7; bool aggressive = false; int colorSpace = 0, chrominanceMethod = 0; } denoise;
+             chrominanceRedGreen = 0, chrominanceBlueYellow = 0, gamma = 1.7; bool aggressive = false; int colorSpace = 0, chrominanceMethod = 0;
+             bool smoothingEnabled = false; int guidedChromaRadius = 3, nlDetail = 80, nlStrength = 0; } denoise;   // procparams.cc:1900-1918 (chrominanceMethod 0 = MANUAL here)
     struct { bool enabled = true; double expcomp = 0, black = 0; } exposure;
     struct { bool enabled = true; int curveMode = ARTGPU_TONE_STD; std::vector<float> lut; float whitePoint = 1.f; bool basecurveLinear = true; } toneCurve;
-    float workingSpace[9] = {0.6734241f, 0.1656411f, 0.1251286f, 0.2790177f, 0.6753402f, 0.0456377f, -0.0019300f, 0.0299784f, 0.7973330f}; // Rec2020 (iccmatrices.h:151-161)
+    double workingSpace[9] = {0.6734241, 0.1656411, 0.1251286, 0.2790177, 0.6753402, 0.0456377, -0.0019300, 0.0299784, 0.7973330}; // Rec2020 TMatrix (iccmatrices.h:151-161)
 };
 
 // rtengine::RawImageSource counterpart for a Bayer sensor
@@ -108,9 +109,15 @@ public:
     // RawImageSource::convertColorSpace, matrix branch (rawimagesource.cc:1128-1143,3184-3213)
     void convertColorSpace(Imagefloat *image, const double mat[9])
     {
+        setColorMatrix(mat);
         artgpu_rgb img = image->view();
         ctx.check(artgpu_convert_color_space(ctx.get(), &img, mat));
     }
+    // the camera -> working-space matrix convertColorSpace derives from params->icm (rawimagesource.cc:1128-1143); remembered
+    // because ImProcFunctions::denoise applies it again to its quarter-size calclum copy (ipdenoise.cc:1131)
+    void setColorMatrix(const double mat[9]) { for (int k = 0; k < 9; ++k) colorMatrix[k] = mat[k]; hasColorMatrix = true; }
+    double colorMatrix[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    bool hasColorMatrix = false;
     Context &ctx;
     int W, H, border = 4;
     uint32_t filters;
@@ -143,8 +150,8 @@ public:
     void expcomp(Imagefloat *img, double ec, double black, bool enabled)
     {
         if (!enabled) return;
-        const float exp_scale = std::pow(2.f, (float)ec);
-        const float blk = (float)black * 2000.f;
+        const float exp_scale = (float)std::pow(2.0, ec);          // pow(2.f, double) promotes (ipexposure.cc:40)
+        const float blk = (float)(black * 2000.0);
         artgpu_rgb i = img->view();
         ctx.check(artgpu_exposure(ctx.get(), &i, exp_scale, blk));
     }
@@ -156,19 +163,22 @@ public:
         const float *lut = params->toneCurve.lut.size() == 65536 ? params->toneCurve.lut.data() : nullptr;
         ctx.check(artgpu_tone_curve(ctx.get(), &i, params->toneCurve.curveMode, lut, params->toneCurve.whitePoint, params->toneCurve.basecurveLinear ? 1 : 0));
     }
-    // ImProcFunctions::denoise (ipdenoise.cc:1096-1189): exposure pre-compensation, RGB_denoise, post-compensation.
-    // `ccalc` = the chroma noise-curve map of the quarter-size calclum image (FTblockDN.cc:1707-1777), or nullptr.
-    void denoise(Imagefloat *img, const artgpu_plane *ccalc = nullptr)
+    // ImProcFunctions::denoise (ipdenoise.cc:1096-1189): calclum/ccalc chroma noise map with the fixed noise curve
+    // (L1139-1149), exposure pre-compensation, RGB_denoise, guided smoothing + NL-means, post-compensation.
+    void denoise(RawImageSource *imgsrc, Imagefloat *img)
     {
         const auto &d = params->denoise;
         if (!d.enabled) return;
         const double ecomp = params->exposure.enabled ? params->exposure.expcomp : 0.0;
-        if (ecomp > 0) expcomp(img, ecomp, 0.0, true);
-        artgpu_denoise_params dp{d.luminance, d.luminanceDetail, d.luminanceDetailThreshold, d.chrominance, d.chrominanceRedGreen,
-                                 d.chrominanceBlueYellow, d.gamma, d.aggressive ? 1 : 0, d.colorSpace, d.chrominanceMethod};
+        artgpu_denoise_tool_params tp{{d.luminance, d.luminanceDetail, d.luminanceDetailThreshold, d.chrominance, d.chrominanceRedGreen,
+                                       d.chrominanceBlueYellow, d.gamma, d.aggressive ? 1 : 0, d.colorSpace, d.chrominanceMethod},
+                                      d.smoothingEnabled ? 1 : 0, d.guidedChromaRadius, d.nlStrength, d.nlDetail};
+        static const double curve_points[9] = {1 /*FCT_MinMaxCPoints*/, 0.05, 0.50, 0.35, 0.35, 0.35, 0.05, 0.35, 0.35};
+        float curve[501], sum = 0.f;
+        ctx.check(artgpu_noise_curve_lut(curve_points, 9, curve, &sum));
         artgpu_rgb i = img->view();
-        ctx.check(artgpu_rgb_denoise(ctx.get(), &i, &dp, params->workingSpace, 0.0, scale, ccalc, 0u, nullptr, nullptr));
-        if (ecomp > 0) expcomp(img, -ecomp, 0.0, true);
+        ctx.check(artgpu_improc_denoise(ctx.get(), &i, &tp, params->workingSpace, ecomp, scale, imgsrc && imgsrc->hasColorMatrix ? imgsrc->colorMatrix : nullptr,
+                                        curve, 0u));
     }
     Context &ctx;
     const ProcParams *params;

@@ -191,13 +191,28 @@ int artgpu_detail_mask(artgpu_ctx *ctx, const artgpu_plane *src, artgpu_plane *m
  * (the Y plane after Imagefloat::setMode(YUV), ipdenoise.cc:1174-1177), in place. */
 int artgpu_nlmeans(artgpu_ctx *ctx, artgpu_plane *img, float normcoeff, int strength, int detail_thresh, float scale);
 
-/* Replaces ImProcFunctions::denoise (rtengine/ipdenoise.cc:1096-1189) after its noise-curve set-up:
+/* NoiseCurve::Set(const std::vector<double>&) (rtengine/ipdenoise.cc:684-716): builds the 501-entry noise-curve LUT
+ * from FlatCurve control points {kind, x, y, leftTangent, rightTangent, ...} on the host (pure table construction,
+ * no context needed).  *sum receives NoiseCurve::getSum(); RGB_denoise uses the chroma curve only when sum > 5
+ * (FTblockDN.cc:1672).  The curve ImProcFunctions::denoise always sets is
+ * {1, 0.05,0.50,0.35,0.35, 0.35,0.05,0.35,0.35} (ipdenoise.cc:1139-1149). */
+int artgpu_noise_curve_lut(const double *points, int npoints, float lut[501], float *sum);
+
+/* The quarter-resolution chroma noise map `ccalc` of RGB_denoise: calclum = every second pixel of img
+ * (ipdenoise.cc:1113-1129), converted by calclum_mat like RawImageSource::convertColorSpace does to it (L1131;
+ * NULL = no conversion), then Color::rgbxyz(ws)/XYZ2Lab and the curve (FTblockDN.cc:1716-1777).
+ * ccalc: (w+1)/2 x (h+1)/2, host or device. */
+int artgpu_denoise_chroma_map(artgpu_ctx *ctx, const artgpu_rgb *img, const double *calclum_mat, const double ws[9],
+                              const float noise_c_curve[501], artgpu_plane *ccalc);
+
+/* Replaces ImProcFunctions::denoise (rtengine/ipdenoise.cc:1096-1189):
+ *   calclum/ccalc map from the un-compensated image (only if noise_c_curve != NULL and its sum > 5);
  *   if (ecomp > 0) expcomp(+ecomp); RGB_denoise(kall 0, isRAW, expcomp 0); if (smoothing_enabled) {
  *   denoiseGuidedSmoothing; if (nl_strength) { setMode(YUV); NLMeans(Y, 65535, nl_strength, nl_detail, scale);
  *   setMode(RGB); } } if (ecomp > 0) expcomp(-ecomp).
  * ecomp = params->exposure.enabled ? params->exposure.expcomp : 0 (L1155).  ws: working-space matrix as doubles
- * (TMatrix); the float casts the reference makes (wpi, Imagefloat::ws_) are made inside.  ccalc as in
- * artgpu_rgb_denoise; flags: ARTGPU_DN_* (0 = the reference's behaviour). */
+ * (TMatrix); the float casts the reference makes (wpi, Imagefloat::ws_) are made inside.
+ * calclum_mat / noise_c_curve as in artgpu_denoise_chroma_map; flags: ARTGPU_DN_* (0 = the reference's behaviour). */
 typedef struct {
     artgpu_denoise_params dn;
     int32_t smoothing_enabled;
@@ -206,7 +221,7 @@ typedef struct {
     int32_t nl_detail;
 } artgpu_denoise_tool_params;
 int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_tool_params *params, const double ws[9],
-                          double ecomp, double scale, const artgpu_plane *ccalc, uint32_t flags /* as artgpu_rgb_denoise */);
+                          double ecomp, double scale, const double *calclum_mat, const float *noise_c_curve, uint32_t flags);
 
 /* Bytes of device scratch the context currently holds (arena + staging). */
 size_t artgpu_scratch_bytes(const artgpu_ctx *ctx);

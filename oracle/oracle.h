@@ -36,6 +36,13 @@ void oracle_convert_color_space(float *const img[3], size_t s, int w, int h, con
 void oracle_exposure(float *const img[3], size_t s, int w, int h, float exp_scale, float black);
 void oracle_filmlike_clip(float *const img[3], size_t s, int w, int h, float whitept);
 float oracle_lutf(const float *data, int size, float index);
+float oracle_xcbrtf(float d);
+void oracle_t_xcbrtf(const float *x, float *y, size_t n);
+int oracle_flat_curve_sample(const double *pts, int npts, int periodic, int ppn, double identity, int nout, double *out);
+float oracle_noise_curve(const double *pts, int npts, float lut[501]);
+void oracle_cachef(float lut[65536]);
+void oracle_chroma_noise_map(const float *const img[3], size_t s, int w, int h, const double *mat, const float wpi[9],
+                             const float curve[501], float *out);
 void oracle_tone_curve_std(float *const img[3], size_t s, int w, int h, const float *lut65536);
 void oracle_rgb_to_yuv(float *const img[3], size_t s, int w, int h, const float ws[9]);
 void oracle_yuv_to_rgb(float *const img[3], size_t s, int w, int h, const float ws[9]);

@@ -27,6 +27,7 @@ void ref_wavelet_reconstruct(void *p, float *dst, float blend) { static_cast<rte
 void ref_wavelet_delete(void *p) { delete static_cast<rtengine::wavelet_decomposition *>(p); }
 
 void ref_xexpf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xexpf(x[i]); }
+void ref_xcbrtf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xcbrtf(x[i]); }
 void ref_xlogf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xlogf(x[i]); }
 void ref_xsinf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xsinf(x[i]); }
 void ref_xcosf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xcosf(x[i]); }

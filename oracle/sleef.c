@@ -122,6 +122,31 @@ float oracle_xlogf_v(float d)
 float oracle_xlogf_v_nocheck(float d) { return xlogf_core(d, 1); }
 
 /* opthelper.h:24  pow_F(a,b) = xexpf(b*xlogf(a)) ; sleef.h:1303-1313 */
+/* xcbrtf, sleef.h:966-991 (scalar only on the path) */
+float oracle_xcbrtf(float d)
+{
+    float x, y, q = 1.0f;
+    int e, r;
+    e = ilogbp1f(d);
+    d = ldexpk_scalar(d, -e);
+    r = (e + 6144) % 3;
+    q = (r == 1) ? 1.2599210498948731647672106f : q;
+    q = (r == 2) ? 1.5874010519681994747517056f : q;
+    q = ldexpk_scalar(q, (e + 6144) / 3 - 2048);
+    q = i2f(f2i(q) ^ (f2i(d) & (int32_t)0x80000000));
+    d = i2f(f2i(d) & 0x7fffffff);
+    x = -0.601564466953277587890625f;
+    x = mla(x, d, 2.8208892345428466796875f);
+    x = mla(x, d, -5.532182216644287109375f);
+    x = mla(x, d, 5.898262500762939453125f);
+    x = mla(x, d, -3.8095417022705078125f);
+    x = mla(x, d, 2.2241256237030029296875f);
+    y = d * x * x;
+    y = (y - (2.0f / 3.0f) * y * (y * x - 1.0f)) * q;
+    return y;
+}
+void oracle_t_xcbrtf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = oracle_xcbrtf(x[i]); }
+
 float oracle_pow_F(float a, float b) { return oracle_xexpf_s(b * oracle_xlogf_s(a)); }
 float oracle_xlin2log(float x, float base) { return oracle_xlogf_s(x * (base - 1.f) + 1.f) / oracle_xlogf_s(base); }
 float oracle_xlog2lin(float x, float base) { return (oracle_pow_F(base, x) - 1.f) / (base - 1.f); }

@@ -92,6 +92,17 @@ def sleef():
     np.savez_compressed(os.path.join(HERE, "sleef.npz"), **out)
 
 
+def sleef2():
+    """functions added after sleef.npz was frozen (kept in a second file so the first stays byte-stable)"""
+    rng = np.random.default_rng(11)
+    n = 8192
+    xc = np.concatenate([rng.uniform(1.0, 40.0, n // 2), np.exp(rng.uniform(-60, 60, n // 4)), -np.exp(rng.uniform(-20, 20, n // 4))]).astype(np.float32)
+    xc[:6] = [1.0, 8.0, 27.0, 1.0000153, 0.0, 1e-40]
+    y = np.empty(n, np.float32)
+    R.ref_xcbrtf(P(xc), P(y), C.c_size_t(n))
+    np.savez_compressed(os.path.join(HERE, "sleef2.npz"), xc=xc, cbrt=y)
+
+
 from make_golden_inputs import wavelet_input  # noqa: E402
 
 
@@ -137,4 +148,5 @@ if __name__ == "__main__":
     helpers()
     lutf()
     sleef()
+    sleef2()
     print("golden vectors written to", HERE)

@@ -256,13 +256,47 @@ def lutf_vec(table, x):
     return np.array([L.oracle_lutf_vec(_ptr(table), len(table), C.c_float(float(v))) for v in x], dtype=np.float32)
 
 
-def improc_denoise(img, dn_kw=None, smoothing=True, radius=3, nl_strength=50, nl_detail=80, ecomp=0.0, scale=1.0,
+NOISE_C_CURVE_POINTS = (1.0, 0.05, 0.50, 0.35, 0.35, 0.35, 0.05, 0.35, 0.35)   # ipdenoise.cc:1139-1149
+
+
+def flat_curve_sample(points, periodic, ppn, identity, nout):
+    pts = (C.c_double * len(points))(*[float(p) for p in points])
+    out = np.zeros(nout, np.float64)
+    ident = lib().oracle_flat_curve_sample(pts, len(points), int(periodic), int(ppn), C.c_double(identity), nout,
+                                           out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out, bool(ident)
+
+
+def noise_curve(points=NOISE_C_CURVE_POINTS):
+    pts = (C.c_double * len(points))(*[float(p) for p in points])
+    lut = np.zeros(501, np.float32)
+    lib().oracle_noise_curve.restype = C.c_float
+    s = lib().oracle_noise_curve(pts, len(points), _ptr(lut))
+    return lut, float(s)
+
+
+def chroma_noise_map(img, mat, ws, curve):
+    """calclum + ccalc (ipdenoise.cc:1113-1131, FTblockDN.cc:1716-1777); ws = working-space matrix (doubles)."""
+    img = [np.ascontiguousarray(p, dtype=np.float32) for p in img]
+    h, w = img[0].shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.float32)
+    m = None if mat is None else (C.c_double * 9)(*[float(v) for v in np.asarray(mat, dtype=np.float64).reshape(9)])
+    wpi = np.ascontiguousarray(np.asarray(ws, dtype=np.float64).astype(np.float32)).reshape(9)
+    cv = np.ascontiguousarray(curve, dtype=np.float32)
+    lib().oracle_chroma_noise_map(_p3(img), C.c_size_t(w), w, h, m, _ptr(wpi), _ptr(cv), _ptr(out))
+    return out
+
+
+def improc_denoise(img, dn_kw=None, calclum_mat=None, noise_c_curve=None, smoothing=True, radius=3, nl_strength=50, nl_detail=80, ecomp=0.0, scale=1.0,
                    ws=REC2020_WS_D, detail_recovery=True):
     """ImProcFunctions::denoise (ipdenoise.cc:1096-1189) composed from the oracle stages."""
     wsf = np.asarray(ws, dtype=np.float64).astype(np.float32)
+    ccalc = None
+    if noise_c_curve is not None and float(np.cumsum(np.asarray(noise_c_curve, np.float32), dtype=np.float32)[-1]) > 5.0:
+        ccalc = chroma_noise_map(img, calclum_mat, ws, noise_c_curve)
     if ecomp > 0:
-        img = exposure(img, float(np.float32(2.0) ** np.float32(ecomp)), 0.0)
-    img = rgb_denoise(img, default_denoise_params(scale=scale, **(dn_kw or {})), wsf, detail_recovery=detail_recovery)
+        img = exposure(img, float(np.float32(2.0 ** ecomp)), 0.0)
+    img = rgb_denoise(img, default_denoise_params(scale=scale, **(dn_kw or {})), wsf, detail_recovery=detail_recovery, noisevarchrom=ccalc)
     if smoothing:
         img = guided_smoothing(img, ws, radius, scale)
         if nl_strength:
@@ -273,5 +307,5 @@ def improc_denoise(img, dn_kw=None, smoothing=True, radius=3, nl_strength=50, nl
             img[1] = nlmeans(img[1], nl_strength, nl_detail, scale)
             lib().oracle_yuv_to_rgb(_p3(img), C.c_size_t(w), w, h, _ptr(wp))
     if ecomp > 0:
-        img = exposure(img, float(np.float32(2.0) ** np.float32(-ecomp)), 0.0)
+        img = exposure(img, float(np.float32(2.0 ** -ecomp)), 0.0)
     return img

@@ -31,14 +31,17 @@ def read_ppm16(path):
     return data
 
 
-def oracle_pipeline(raw, filt, method, border, denoise=None):
+def oracle_pipeline(raw, filt, method, border, denoise=None, smoothing=None, expcomp=0.0):
     planes = O.rcd(raw, filt) if method == "rcd" else O.amaze(raw, filt, 1.0, border)
     h, w = raw.shape
     img = O.get_image(planes, border, border, w - 2 * border, h - 2 * border, MUL, True)
     img = O.convert_color_space(img, MAT)
     if denoise:
-        img = O.rgb_denoise(img, O.default_denoise_params(luminance=denoise[0], chrominance=denoise[1]), detail_recovery=True)
-    img = O.exposure(img, 1.0, 0.0)
+        curve, _ = O.noise_curve()
+        img = O.improc_denoise(img, dict(luminance=denoise[0], chrominance=denoise[1]), calclum_mat=MAT, noise_c_curve=curve,
+                               smoothing=smoothing is not None, radius=(smoothing or (3, 0, 0))[0], nl_strength=(smoothing or (3, 0, 0))[1],
+                               nl_detail=(smoothing or (3, 0, 80))[2], ecomp=expcomp, detail_recovery=True)
+    img = O.exposure(img, float(np.float32(2.0 ** expcomp)), 0.0)
     img = O.tone_std(img, tone_lut(), 1.0, True)
     return img
 
@@ -72,3 +75,15 @@ def test_amaze_denoise_through_cli(tmp_path):
     q = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.int32) for p in ref], axis=-1)
     # the DCT detail-recovery stage is tolerance-checked (third-party FFTW in the reference): allow +-3 counts
     assert np.abs(ppm.astype(np.int32) - q).max() <= 3
+
+
+def test_config4_stages_through_cli(tmp_path):
+    """BASELINE config 4's per-frame pipe: AMaZE + FTblockDN + guided smoothing + NL-means + exposure + tone."""
+    w, h, filt = 648, 488, synth.FILTERS_RGGB
+    raw = synth.bayer_frame(w, h, filt, seed=3, noise=2048)
+    info, ppm = run_cli(tmp_path, raw, "amaze", ("--denoise", "40,15", "--smoothing", "3,50,80", "--expcomp", "0.3"))
+    ref = oracle_pipeline(raw, filt, "amaze", 4, denoise=(40.0, 15.0), smoothing=(3, 50, 80), expcomp=0.3)
+    q = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.int32) for p in ref], axis=-1)
+    err = np.abs(ppm.astype(np.int32) - q)
+    # DCT round-off (tolerance-checked stage) -> NL-means weights -> S-curve slope; on the 16-bit output scale
+    assert err.max() <= 512 and np.percentile(err, 99.9) <= 64 and np.median(err) <= 1, (err.max(), np.percentile(err, 99.9))

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from art_amd import synth
+from art_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -83,3 +83,40 @@ def test_rgb_denoise_with_detail_recovery_tolerance(gpu_ctx, w, h, detail):
         assert np.median(err) <= 0.02
         # the stage really ran: result is far from the no-detail-recovery image
         assert np.abs(r - nd).max() > 50.0
+
+
+def test_chroma_noise_map_bit_exact(gpu_ctx):
+    """calclum + ccalc (ipdenoise.cc:1113-1131, FTblockDN.cc:1716-1777) incl. the f<0 and f>65535 branches of XYZ2Lab."""
+    w, h = 333, 251
+    rng = np.random.default_rng(5)
+    img = [rng.uniform(-200.0, 70000.0, (h, w)).astype(np.float32) for _ in range(3)]
+    img[0][:40] *= 3.0                      # strongly coloured band: cN > 100 and X/D50x > 65535
+    img[2][60:90] = 0.0
+    mat = np.array([[0.6325, 0.2312, 0.0921], [0.2198, 0.7712, 0.0090], [0.0166, 0.0713, 0.7514]])
+    curve, s = capi.noise_curve_lut()
+    assert s > 5.0
+    for m in (mat, None):
+        got = np.zeros(((h + 1) // 2, (w + 1) // 2), np.float32)
+        gpu_ctx.denoise_chroma_map(capi.host_rgb(img), m, O.REC2020_WS_D, curve, capi.host_plane(got))
+        ref = O.chroma_noise_map(img, m, O.REC2020_WS_D, curve)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        assert len(np.unique(ref)) > 100     # the map is not the cN<=100 constant everywhere
+
+
+def test_improc_denoise_with_noise_curve_bit_exact(gpu_ctx):
+    """ImProcFunctions::denoise as ART runs it: fixed chroma noise curve, exposure bracketing; DCT stage skipped so every
+    remaining stage must agree bit for bit."""
+    import torch
+    w, h = 400, 296
+    raw = synth.bayer_frame(w, h, synth.FILTERS_RGGB, seed=4, noise=2048)
+    img = O.amaze(raw, synth.FILTERS_RGGB, 1.0, 4)
+    mat = np.array([[0.6325, 0.2312, 0.0921], [0.2198, 0.7712, 0.0090], [0.0166, 0.0713, 0.7514]])
+    curve, _ = capi.noise_curve_lut()
+    d = [torch.from_numpy(p.copy()).cuda() for p in img]
+    rgb = capi.RGB(*[capi.device_plane(t) for t in d])
+    tp = capi.DenoiseToolParams(capi.DenoiseParams(40.0, 50.0, 0, 15.0, 0.0, 0.0, 1.7, 0, 0, 0), 0, 3, 0, 80)
+    gpu_ctx.improc_denoise(rgb, tp, O.REC2020_WS_D, ecomp=0.3, calclum_mat=mat, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    gpu_ctx.synchronize()
+    ref = O.improc_denoise(img, calclum_mat=mat, noise_c_curve=curve, smoothing=False, ecomp=0.3, detail_recovery=False)
+    for t, r in zip(d, ref):
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))
