@@ -37,6 +37,10 @@ class DenoiseParams(C.Structure):
                 ("gamma", C.c_double), ("aggressive", C.c_int32), ("color_space", C.c_int32), ("chrominance_method", C.c_int32)]
 
 
+class NeutralState(C.Structure):
+    _fields_ = [("ws", C.c_double * 9), ("iws", C.c_double * 9), ("to_out", C.c_float * 9), ("to_work", C.c_float * 9)]
+
+
 class DenoiseToolParams(C.Structure):
     _fields_ = [("dn", DenoiseParams), ("smoothing_enabled", C.c_int32), ("guided_chroma_radius", C.c_int32),
                 ("nl_strength", C.c_int32), ("nl_detail", C.c_int32)]
@@ -102,6 +106,7 @@ def _load():
     lib.artgpu_nlmeans.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_float, C.c_int, C.c_int, C.c_float]
     lib.artgpu_improc_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseToolParams), C.POINTER(C.c_double), C.c_double,
                                           C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_uint32]
+    lib.artgpu_tone_curve_neutral.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.c_float, C.POINTER(NeutralState)]
     lib.artgpu_noise_curve_lut.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_denoise_chroma_map.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float),
                                               C.POINTER(Plane)]
@@ -121,7 +126,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -215,6 +220,17 @@ class Context:
 
     def nlmeans(self, img: Plane, strength: int = 50, detail: int = 80, scale: float = 1.0, normcoeff: float = 65535.0):
         self._chk(LIB.artgpu_nlmeans(self._h, C.byref(img), normcoeff, strength, detail, scale))
+
+    def tone_curve_neutral(self, image: RGB, lut65536, whitecoeff, ws, iws, to_out=None, to_work=None):
+        lut = np.ascontiguousarray(lut65536, dtype=np.float32)
+        assert lut.shape == (65536,)
+        ident = np.eye(3, dtype=np.float32)
+        st = NeutralState()
+        st.ws[:] = [float(v) for v in np.asarray(ws, np.float64).reshape(9)]
+        st.iws[:] = [float(v) for v in np.asarray(iws, np.float64).reshape(9)]
+        st.to_out[:] = [float(v) for v in np.asarray(ident if to_out is None else to_out, np.float32).reshape(9)]
+        st.to_work[:] = [float(v) for v in np.asarray(ident if to_work is None else to_work, np.float32).reshape(9)]
+        self._chk(LIB.artgpu_tone_curve_neutral(self._h, C.byref(image), lut.ctypes.data_as(C.POINTER(C.c_float)), whitecoeff, C.byref(st)))
 
     def denoise_chroma_map(self, image: RGB, calclum_mat, ws, curve, ccalc: Plane):
         m = None if calclum_mat is None else (C.c_double * 9)(*[float(v) for v in np.asarray(calclum_mat, dtype=np.float64).reshape(9)])

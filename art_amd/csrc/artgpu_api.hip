@@ -28,7 +28,7 @@ struct artgpu_ctx {
     float *stage[NSTAGE] = {};
     size_t stage_bytes[NSTAGE] = {};
     // grow-only scratch pool for the denoise path (planes, decompositions, shrink buffers)
-    static constexpr int NPOOL = 20;
+    static constexpr int NPOOL = 24;
     float *pool[NPOOL] = {};
     size_t pool_bytes[NPOOL] = {};
     float *lut = nullptr; // 65536-entry tone LUT on the device
@@ -605,7 +605,7 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ };
 
 struct DevDecomp {
     float *bands, *low[2];
@@ -1045,6 +1045,39 @@ int artgpu_nlmeans(artgpu_ctx *ctx, artgpu_plane *img, float normcoeff, int stre
     a.img = work; a.img_stride = W; a.src = pad;
     HIPCHK(ctx, launch_nlm(a, ctx->stream));
     return pool_to_plane(ctx, work, img);
+}
+
+// ---------------------------------------------------------------------------------------------
+// NEUTRAL tone curve
+// ---------------------------------------------------------------------------------------------
+int artgpu_tone_curve_neutral(artgpu_ctx *ctx, artgpu_rgb *image, const float *lut65536, float whitecoeff, const artgpu_neutral_state *st)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!image || !lut65536 || !st || !(whitecoeff > 0.f)) return fail(ctx, ARTGPU_EINVAL, "tone_curve_neutral: null/invalid argument");
+    DevRGB d;
+    int rc = bind_rgb(ctx, image, 4, true, &d, "tone_curve_neutral");
+    if (rc) return rc;
+    float *pq;
+    const bool fresh = ctx->pool[P_PQ] == nullptr;
+    if ((rc = pool_get(ctx, P_PQ, (2 * 65536 + 64) * 4, &pq))) return rc;
+    if (fresh) {
+        std::vector<float> host(2 * 65536);
+        build_pq_luts(host.data(), host.data() + 65536);
+        HIPCHK(ctx, hipMemcpyAsync(pq, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    rc = ensure(ctx, &ctx->lut, &ctx->lut_bytes, 65536 * sizeof(float));
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->lut, lut65536, 65536 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    NeutralArgs a = {};
+    for (int k = 0; k < 3; ++k) a.img[k] = d.p[k];
+    a.stride = d.stride; a.w = d.w; a.h = d.h;
+    a.lut = ctx->lut; a.pq = pq; a.pq_inv = pq + 65536; a.hues = pq + 2 * 65536;
+    for (int k = 0; k < 9; ++k) { a.ws[k] = (float)st->ws[k]; a.iws[k] = (float)st->iws[k]; a.to_out[k] = st->to_out[k]; a.to_work[k] = st->to_work[k]; }
+    a.whitecoeff = whitecoeff;
+    if (fresh) HIPCHK(ctx, launch_neutral_hues(a, ctx->stream));
+    HIPCHK(ctx, launch_tone_neutral(a, ctx->stream));
+    return unbind_rgb(ctx, image, &d);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -107,6 +107,68 @@ __device__ __forceinline__ float xcbrtf_s(float d)
     return y;
 }
 
+// xatan2f (rtengine/sleef.h:1155-1188), scalar form
+__device__ __forceinline__ float sl_atan2kf(float y, float x)
+{
+    float q = 0.f;
+    if (x < 0) { x = -x; q = -2.f; }
+    if (y > x) { const float t = x; x = y; y = -t; q += 1.f; }
+    const float s = y / x;
+    float t = s * s;
+    float u = 0.00282363896258175373077393f;
+    u = sl_mla(u, t, -0.0159569028764963150024414f);
+    u = sl_mla(u, t, 0.0425049886107444763183594f);
+    u = sl_mla(u, t, -0.0748900920152664184570312f);
+    u = sl_mla(u, t, 0.106347933411598205566406f);
+    u = sl_mla(u, t, -0.142027363181114196777344f);
+    u = sl_mla(u, t, 0.199926957488059997558594f);
+    u = sl_mla(u, t, -0.333331018686294555664062f);
+    t = u * t;
+    t = sl_mla(t, s, s);
+    return sl_mla(q, (float)1.57079632679489661923, t);
+}
+__device__ __forceinline__ float sl_mulsign(float x, float y) { return __int_as_float(__float_as_int(x) ^ (__float_as_int(y) & (int)0x80000000)); }
+__device__ __forceinline__ bool sl_isinf(float x) { return x == __builtin_huge_valf() || x == -__builtin_huge_valf(); }
+__device__ __forceinline__ float xatan2f_s(float y, float x)
+{
+    const float PI_F = (float)3.14159265358979323846;
+    float r = sl_atan2kf(__int_as_float(__float_as_int(y) & 0x7fffffff), x);
+    r = sl_mulsign(r, x);
+    const float sgx = copysignf(1.f, x);
+    if (sl_isinf(x) || x == 0) r = PI_F / 2 - (sl_isinf(x) ? (sgx * (float)(PI_F * .5f)) : 0);
+    if (sl_isinf(y)) r = PI_F / 2 - (sl_isinf(x) ? (sgx * (float)(PI_F * .25f)) : 0);
+    if (y == 0) r = (sgx == -1 ? PI_F : 0);
+    return (x != x) || (y != y) ? __builtin_nanf("") : sl_mulsign(r, y);
+}
+// xsincosf(float) under SSE2 = lane 0 of the vector form (sleef.h:1048-1052 -> sleefsseavx.h:1051-1100)
+__device__ __forceinline__ void xsincosf_v(float d, float &sn, float &cs)
+{
+    const int q = __float2int_rn(d * (float)0.63661977236758134308);
+    float u = (float)q, s = d;
+    s = sl_mla(u, -0.78515625f * 2, s);
+    s = sl_mla(u, -0.00024127960205078125f * 2, s);
+    s = sl_mla(u, -6.3329935073852539062e-07f * 2, s);
+    s = sl_mla(u, -4.9604681473525147339e-10f * 2, s);
+    const float t = s;
+    s = s * s;
+    u = -0.000195169282960705459117889f;
+    u = sl_mla(u, s, 0.00833215750753879547119141f);
+    u = sl_mla(u, s, -0.166666537523269653320312f);
+    u = (u * s) * t;
+    const float rx = t + u;
+    u = -2.71811842367242206819355e-07f;
+    u = sl_mla(u, s, 2.47990446951007470488548e-05f);
+    u = sl_mla(u, s, -0.00138888787478208541870117f);
+    u = sl_mla(u, s, 0.0416666641831398010253906f);
+    u = sl_mla(u, s, -0.5f);
+    const float ry = 1.f + s * u;
+    float x = (q & 1) == 0 ? rx : ry, y = (q & 1) == 0 ? ry : rx;
+    if ((q & 2) == 2) x = -x;
+    if (((q + 1) & 2) == 2) y = -y;
+    if (sl_isinf(d)) x = y = __builtin_nanf("");
+    sn = x; cs = y;
+}
+
 // LUTf::operator[](float) (rtengine/LUT.h:436-459): clip_above selects LUT_CLIP_ABOVE behaviour
 template <bool CLIP_ABOVE>
 __device__ __forceinline__ float lutf_lookup(const float *__restrict__ data, int size, float index)

@@ -4,6 +4,7 @@
 //   NoiseCurve::Set -> 501-entry LUT + sum     rtengine/ipdenoise.cc:684-716
 //   Color::cachef                              rtengine/color.cc:178,202-217
 #include "kernels.h"
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -156,6 +157,21 @@ void build_cachef(float *lut)
     int i = 0;
     for (; i <= epsmaxint; i++) lut[i] = (float)(327.68 * ((kappa * i / maxvalf + 16.0) / 116.0));
     for (; i < 65536; i++) lut[i] = (float)(327.68 * std::cbrt((double)i / maxvalf));
+}
+
+
+// Color::init jzazbz_pq_ / jzazbz_pq_inv_ (color.cc:323-326) with PQ / PQ_inv (color.cc:67-86): std::pow(float, float) is the
+// host libm's powf, as in the reference
+void build_pq_luts(float *pq, float *pq_inv)
+{
+    for (int i = 0; i < 65536; ++i) {
+        const float v = (float)i / 65535.f;
+        float X = std::max(v, 1e-10f);
+        const float XX = std::pow(X * 1e-4f, 0.1593017578125f);
+        pq[i] = std::pow((0.8359375f + 18.8515625f * XX) / (1 + 18.6875f * XX), 134.034375f);
+        const float YY = std::pow(X, 7.460772656268214e-03f);
+        pq_inv[i] = 1e4f * std::pow((0.8359375f - YY) / (18.6875f * YY - 18.8515625f), 6.277394636015326f);
+    }
 }
 
 } // namespace artgpu

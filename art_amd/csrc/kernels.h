@@ -82,6 +82,18 @@ hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s);
 hipError_t launch_exposure(const PixArgs &a, hipStream_t s);
 hipError_t launch_tone_std(const PixArgs &a, hipStream_t s);
 hipError_t launch_yuv_mode(const PixArgs &a, hipStream_t s);
+// NEUTRAL tone curve (curves.cc:854-1038)
+struct NeutralArgs {
+    float *img[3]; size_t stride; int w, h;
+    const float *lut;            // 65536-entry tone LUT
+    const float *pq, *pq_inv;    // 65536-entry PQ LUTs (host-built)
+    float *hues;                 // [4] rhue, bhue, yhue, ohue (device; written by launch_neutral_hues)
+    float ws[9], iws[9], to_out[9], to_work[9];
+    float whitecoeff;
+};
+hipError_t launch_neutral_hues(const NeutralArgs &a, hipStream_t s);
+hipError_t launch_tone_neutral(const NeutralArgs &a, hipStream_t s);
+void build_pq_luts(float *pq65536, float *pq_inv65536);
 
 // ---- wavelet_decomposition (wavelet.hip) ----
 struct WaveArgs {

@@ -37,6 +37,7 @@ int main(int argc, char **argv)
     uint32_t filters = 0x94949494u;
     double lum = 0, chroma = 0, expcomp = 0;
     bool dn = false, smoothing = false;
+    int tone_mode = ARTGPU_TONE_STD;
     int gradius = 3, nlstrength = 0, nldetail = 80;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -51,6 +52,7 @@ int main(int argc, char **argv)
         else if (a == "--expcomp") expcomp = std::atof(next());
         else if (a == "--method") { std::string m = next(); method = (m == "rcd") ? ARTGPU_BAYER_RCD : ARTGPU_BAYER_AMAZE; }
         else if (a == "--denoise") { dn = true; if (std::sscanf(next(), "%lf,%lf", &lum, &chroma) != 2) { std::fprintf(stderr, "--denoise L,C\n"); return 2; } }
+        else if (a == "--tone") { std::string m = next(); tone_mode = (m == "neutral") ? ARTGPU_TONE_NEUTRAL : ARTGPU_TONE_STD; }
         else if (a == "--smoothing") { smoothing = true; if (std::sscanf(next(), "%d,%d,%d", &gradius, &nlstrength, &nldetail) != 3) { std::fprintf(stderr, "--smoothing radius,nlStrength,nlDetail\n"); return 2; } }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -76,6 +78,7 @@ int main(int argc, char **argv)
         params.denoise.smoothingEnabled = smoothing; params.denoise.guidedChromaRadius = gradius; params.denoise.nlStrength = nlstrength; params.denoise.nlDetail = nldetail;
         params.exposure.expcomp = expcomp;
         params.toneCurve.lut = default_tone_lut();
+        params.toneCurve.curveMode = tone_mode;
 
         auto t0 = std::chrono::steady_clock::now();
         // stage_init (simpleprocess.cc:215-259)

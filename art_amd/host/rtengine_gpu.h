@@ -81,7 +81,11 @@ struct ProcParams {
              bool smoothingEnabled = false; int guidedChromaRadius = 3, nlDetail = 80, nlStrength = 0; } denoise;   // procparams.cc:1900-1918 (chrominanceMethod 0 = MANUAL here)
     struct { bool enabled = true; double expcomp = 0, black = 0; } exposure;
     struct { bool enabled = true; int curveMode = ARTGPU_TONE_STD; std::vector<float> lut; float whitePoint = 1.f; bool basecurveLinear = true; } toneCurve;
-    double workingSpace[9] = {0.6734241, 0.1656411, 0.1251286, 0.2790177, 0.6753402, 0.0456377, -0.0019300, 0.0299784, 0.7973330}; // Rec2020 TMatrix (iccmatrices.h:151-161)
+    // toneCurve.curveMode: ARTGPU_TONE_STD or ARTGPU_TONE_NEUTRAL (ART's default, procparams.cc:1585)
+    double workingSpace[9] = {0.6734241, 0.1656411, 0.1251286, 0.2790177, 0.6753402, 0.0456377, -0.0019300, 0.0299784, 0.7973330}; // Rec2020 TMatrix (iccmatrices.h:151-155)
+    double workingSpaceInverse[9] = {1.6473376, -0.3935675, -0.2359961, -0.6826036, 1.6475887, 0.0128190, 0.0296524, -0.0628993, 1.2531279};   // iccmatrices.h:157-161
+    // NeutralToneCurve::ApplyState::to_out / to_work (curves.cc:870-878): identity unless the output profile has a matrix
+    float toOut[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, toWork[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 };
 
 // rtengine::RawImageSource counterpart for a Bayer sensor
@@ -161,6 +165,13 @@ public:
         if (!params->toneCurve.enabled) return;
         artgpu_rgb i = img->view();
         const float *lut = params->toneCurve.lut.size() == 65536 ? params->toneCurve.lut.data() : nullptr;
+        if (params->toneCurve.curveMode == ARTGPU_TONE_NEUTRAL) {
+            // single NEUTRAL curve: no filmlike_clip pre-pass (iptonecurve.cc:586-595), apply_tc(NEUTRAL) with basecurve == nullptr
+            artgpu_neutral_state st;
+            for (int k = 0; k < 9; ++k) { st.ws[k] = params->workingSpace[k]; st.iws[k] = params->workingSpaceInverse[k]; st.to_out[k] = params->toOut[k]; st.to_work[k] = params->toWork[k]; }
+            ctx.check(artgpu_tone_curve_neutral(ctx.get(), &i, lut, params->toneCurve.whitePoint, &st));
+            return;
+        }
         ctx.check(artgpu_tone_curve(ctx.get(), &i, params->toneCurve.curveMode, lut, params->toneCurve.whitePoint, params->toneCurve.basecurveLinear ? 1 : 0));
     }
     // ImProcFunctions::denoise (ipdenoise.cc:1096-1189): calclum/ccalc chroma noise map with the fixed noise curve

@@ -122,6 +122,7 @@ int artgpu_exposure(artgpu_ctx *ctx, artgpu_rgb *image, float exp_scale, float b
  * whitept > 1 needs the analytic curve beyond the LUT (setLutVal's else branch) and returns
  * ARTGPU_EUNSUPPORTED; other curve modes (NEUTRAL, PERCEPTUAL, ...) likewise. */
 #define ARTGPU_TONE_STD 0
+#define ARTGPU_TONE_NEUTRAL 1   /* through artgpu_tone_curve_neutral */
 int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float *lut65536,
                       float whitept, int filmlike_clip);
 
@@ -190,6 +191,19 @@ int artgpu_detail_mask(artgpu_ctx *ctx, const artgpu_plane *src, artgpu_plane *m
 /* denoise::NLMeans(img, normcoeff, strength, detail_thresh, scale) (rtengine/nlmeans.cc:50-280) on one plane
  * (the Y plane after Imagefloat::setMode(YUV), ipdenoise.cc:1174-1177), in place. */
 int artgpu_nlmeans(artgpu_ctx *ctx, artgpu_plane *img, float normcoeff, int strength, int detail_thresh, float scale);
+
+/* NEUTRAL tone-curve mode (ToneCurveParams::TcMode::NEUTRAL, ART's default): replaces apply_tc(..., NEUTRAL, ...)
+ * = NeutralToneCurve::ApplyState + BatchApply (rtengine/iptonecurve.cc:88-99, rtengine/curves.cc:854-1038) for
+ * BcMode::LINEAR (basecurve == nullptr).  lut65536 = ToneCurve::lutToneCurve (host), whitecoeff = ToneCurve::whitecoeff.
+ * ws / iws: ICCStore workingSpaceMatrix / workingSpaceInverseMatrix (doubles; cast to float inside, curves.cc:861-868);
+ * to_out / to_work: the output-profile gamut matrices inverse(om)*work and iwork*om (curves.cc:870-878; identity when
+ * the output profile has no matrix).  Pixels whose Jzazbz LMS response exceeds 1 evaluate powf per pixel (device powf:
+ * <= 2 ulp of the host libm's), every other pixel is bit-exact. */
+typedef struct {
+    double ws[9], iws[9];
+    float to_out[9], to_work[9];
+} artgpu_neutral_state;
+int artgpu_tone_curve_neutral(artgpu_ctx *ctx, artgpu_rgb *img, const float *lut65536, float whitecoeff, const artgpu_neutral_state *state);
 
 /* NoiseCurve::Set(const std::vector<double>&) (rtengine/ipdenoise.cc:684-716): builds the 501-entry noise-curve LUT
  * from FlatCurve control points {kind, x, y, leftTangent, rightTangent, ...} on the host (pure table construction,

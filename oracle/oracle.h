@@ -37,6 +37,20 @@ void oracle_exposure(float *const img[3], size_t s, int w, int h, float exp_scal
 void oracle_filmlike_clip(float *const img[3], size_t s, int w, int h, float whitept);
 float oracle_lutf(const float *data, int size, float index);
 float oracle_xcbrtf(float d);
+float oracle_xatan2f(float y, float x);
+void oracle_xsincosf(float d, float *sn, float *cs);
+void oracle_t_xatan2f(const float *y, const float *x, float *r, size_t n);
+void oracle_t_xsincosf(const float *d, float *sn, float *cs, size_t n);
+/* NEUTRAL tone curve (tonecurve.c) */
+typedef struct {
+    float ws[9], iws[9];            /* working space <-> XYZ, float casts (curves.cc:861-868) */
+    float to_out[9], to_work[9];    /* output-profile gamut matrices (curves.cc:870-878) */
+    float rhue, bhue, yhue, rrange, brange, yrange;   /* curves.cc:880-890 */
+} oracle_neutral_state;
+void oracle_pq_luts(float *pq65536, float *pq_inv65536);
+void oracle_neutral_state_init(oracle_neutral_state *st, const double ws[9], const double iws[9], const float *to_out, const float *to_work);
+void oracle_tone_curve_neutral(float *const img[3], size_t s, int w, int h, const float *lut65536, float whitecoeff,
+                               const oracle_neutral_state *st, unsigned char *out_of_lut_range);
 void oracle_t_xcbrtf(const float *x, float *y, size_t n);
 int oracle_flat_curve_sample(const double *pts, int npts, int periodic, int ppn, double identity, int nout, double *out);
 float oracle_noise_curve(const double *pts, int npts, float lut[501]);

@@ -28,6 +28,7 @@ void ref_wavelet_delete(void *p) { delete static_cast<rtengine::wavelet_decompos
 
 void ref_xexpf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xexpf(x[i]); }
 void ref_xcbrtf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xcbrtf(x[i]); }
+void ref_xsincosf(const float *d, float *sn, float *cs, size_t n) { for (size_t i = 0; i < n; ++i) { float2 v = xsincosf(d[i]); sn[i] = v.x; cs[i] = v.y; } }
 void ref_xlogf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xlogf(x[i]); }
 void ref_xsinf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xsinf(x[i]); }
 void ref_xcosf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xcosf(x[i]); }

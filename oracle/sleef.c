@@ -147,6 +147,69 @@ float oracle_xcbrtf(float d)
 }
 void oracle_t_xcbrtf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = oracle_xcbrtf(x[i]); }
 
+/* atan2kf / xatan2f, sleef.h:1155-1188 (scalar) */
+static float atan2kf_(float y, float x)
+{
+    float s, t, u, q = 0.f;
+    if (x < 0) { x = -x; q = -2.f; }
+    if (y > x) { t = x; x = y; y = -t; q += 1.f; }
+    s = y / x;
+    t = s * s;
+    u = 0.00282363896258175373077393f;
+    u = mla(u, t, -0.0159569028764963150024414f);
+    u = mla(u, t, 0.0425049886107444763183594f);
+    u = mla(u, t, -0.0748900920152664184570312f);
+    u = mla(u, t, 0.106347933411598205566406f);
+    u = mla(u, t, -0.142027363181114196777344f);
+    u = mla(u, t, 0.199926957488059997558594f);
+    u = mla(u, t, -0.333331018686294555664062f);
+    t = u * t;
+    t = mla(t, s, s);
+    return mla(q, (float)1.57079632679489661923, t);
+}
+static inline float mulsign_(float x, float y) { return i2f(f2i(x) ^ (f2i(y) & (int32_t)0x80000000)); }
+static inline int isinf_(float x) { return x == INFINITY || x == -INFINITY; }
+float oracle_xatan2f(float y, float x)
+{
+    const float PI_F = (float)3.14159265358979323846;
+    float r = atan2kf_(i2f(f2i(y) & 0x7fffffff), x);
+    r = mulsign_(r, x);
+    if (isinf_(x) || x == 0) r = PI_F / 2 - (isinf_(x) ? (copysignf(1.f, x) * (float)(PI_F * .5f)) : 0);
+    if (isinf_(y)) r = PI_F / 2 - (isinf_(x) ? (copysignf(1.f, x) * (float)(PI_F * .25f)) : 0);
+    if (y == 0) r = (copysignf(1.f, x) == -1 ? PI_F : 0);
+    return (x != x) || (y != y) ? NAN : mulsign_(r, y);
+}
+/* xsincosf(float) on SSE2 = lane 0 of the vector form, sleef.h:1048-1052 -> sleefsseavx.h:1051-1100 */
+void oracle_xsincosf(float d, float *sn, float *cs)
+{
+    const int q = rint_i(d * (float)0.63661977236758134308);
+    float u = (float)q, s = d, t, rx, ry;
+    s = mla(u, -0.78515625f * 2, s);
+    s = mla(u, -0.00024127960205078125f * 2, s);
+    s = mla(u, -6.3329935073852539062e-07f * 2, s);
+    s = mla(u, -4.9604681473525147339e-10f * 2, s);
+    t = s;
+    s = s * s;
+    u = -0.000195169282960705459117889f;
+    u = mla(u, s, 0.00833215750753879547119141f);
+    u = mla(u, s, -0.166666537523269653320312f);
+    u = (u * s) * t;
+    rx = t + u;
+    u = -2.71811842367242206819355e-07f;
+    u = mla(u, s, 2.47990446951007470488548e-05f);
+    u = mla(u, s, -0.00138888787478208541870117f);
+    u = mla(u, s, 0.0416666641831398010253906f);
+    u = mla(u, s, -0.5f);
+    ry = 1.f + s * u;
+    float x = (q & 1) == 0 ? rx : ry, y = (q & 1) == 0 ? ry : rx;
+    if ((q & 2) == 2) x = i2f(f2i(x) ^ (int32_t)0x80000000);
+    if (((q + 1) & 2) == 2) y = i2f(f2i(y) ^ (int32_t)0x80000000);
+    if (isinf_(d)) x = y = NAN;
+    *sn = x; *cs = y;
+}
+void oracle_t_xatan2f(const float *y, const float *x, float *r, size_t n) { for (size_t i = 0; i < n; ++i) r[i] = oracle_xatan2f(y[i], x[i]); }
+void oracle_t_xsincosf(const float *d, float *sn, float *cs, size_t n) { for (size_t i = 0; i < n; ++i) oracle_xsincosf(d[i], sn + i, cs + i); }
+
 float oracle_pow_F(float a, float b) { return oracle_xexpf_s(b * oracle_xlogf_s(a)); }
 float oracle_xlin2log(float x, float base) { return oracle_xlogf_s(x * (base - 1.f) + 1.f) / oracle_xlogf_s(base); }
 float oracle_xlog2lin(float x, float base) { return (oracle_pow_F(base, x) - 1.f) / (base - 1.f); }

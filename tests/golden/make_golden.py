@@ -100,7 +100,18 @@ def sleef2():
     xc[:6] = [1.0, 8.0, 27.0, 1.0000153, 0.0, 1e-40]
     y = np.empty(n, np.float32)
     R.ref_xcbrtf(P(xc), P(y), C.c_size_t(n))
-    np.savez_compressed(os.path.join(HERE, "sleef2.npz"), xc=xc, cbrt=y)
+    # xatan2f / xsincosf(float) as the Jzazbz hue code uses them (color.cc:6690-6703): small-magnitude az/bz, hue in [-pi, pi]
+    ay = np.concatenate([rng.uniform(-0.2, 0.2, n // 2), rng.uniform(-1e-4, 1e-4, n // 4), rng.uniform(-50, 50, n // 4)]).astype(np.float32)
+    ax = np.concatenate([rng.uniform(-0.2, 0.2, n // 2), rng.uniform(-1e-4, 1e-4, n // 4), rng.uniform(-50, 50, n // 4)]).astype(np.float32)
+    ay[:8] = [0.0, -0.0, 1.0, -1.0, 0.0, 1e-30, np.inf, 0.3]
+    ax[:8] = [1.0, -1.0, 0.0, 0.0, 0.0, -1e-30, 1.0, np.nan]
+    at = np.empty(n, np.float32)
+    R.ref_xatan2f(P(ay), P(ax), P(at), C.c_size_t(n))
+    sd = np.concatenate([rng.uniform(-3.5, 3.5, n // 2), rng.uniform(-40, 40, n // 4), rng.uniform(-1e-3, 1e-3, n // 4)]).astype(np.float32)
+    sd[:6] = [0.0, -0.0, np.pi / 2, np.pi, -np.pi, 0.7853982]
+    sn, cs = np.empty(n, np.float32), np.empty(n, np.float32)
+    R.ref_xsincosf(P(sd), P(sn), P(cs), C.c_size_t(n))
+    np.savez_compressed(os.path.join(HERE, "sleef2.npz"), xc=xc, cbrt=y, ay=ay, ax=ax, atan2=at, sd=sd, sin=sn, cos=cs)
 
 
 from make_golden_inputs import wavelet_input  # noqa: E402

@@ -309,3 +309,34 @@ def improc_denoise(img, dn_kw=None, calclum_mat=None, noise_c_curve=None, smooth
     if ecomp > 0:
         img = exposure(img, float(np.float32(2.0 ** -ecomp)), 0.0)
     return img
+
+
+class NeutralState(C.Structure):
+    _fields_ = [("ws", C.c_float * 9), ("iws", C.c_float * 9), ("to_out", C.c_float * 9), ("to_work", C.c_float * 9),
+                ("rhue", C.c_float), ("bhue", C.c_float), ("yhue", C.c_float), ("rrange", C.c_float), ("brange", C.c_float),
+                ("yrange", C.c_float)]
+
+
+# rec2020_xyz (iccmatrices.h:156-160), the inverse working-space matrix
+REC2020_IWS_D = np.array([[1.6473376, -0.3935675, -0.2359961], [-0.6826036, 1.6475887, 0.0128190], [0.0296524, -0.0628993, 1.2531279]], dtype=np.float64)
+
+
+def neutral_state(ws=REC2020_WS_D, iws=REC2020_IWS_D, to_out=None, to_work=None):
+    st = NeutralState()
+    a = (C.c_double * 9)(*[float(v) for v in np.asarray(ws, np.float64).reshape(9)])
+    b = (C.c_double * 9)(*[float(v) for v in np.asarray(iws, np.float64).reshape(9)])
+    o = None if to_out is None else (C.c_float * 9)(*[float(v) for v in np.asarray(to_out, np.float32).reshape(9)])
+    k = None if to_work is None else (C.c_float * 9)(*[float(v) for v in np.asarray(to_work, np.float32).reshape(9)])
+    lib().oracle_neutral_state_init(C.byref(st), a, b, o, k)
+    return st
+
+
+def tone_neutral(img, lut, whitecoeff=1.0, state=None, want_oor=False):
+    img = [np.array(p, dtype=np.float32, order="C") for p in img]
+    h, w = img[0].shape
+    st = state or neutral_state()
+    lut = np.ascontiguousarray(lut, dtype=np.float32)
+    oor = np.zeros((h, w), np.uint8)
+    lib().oracle_tone_curve_neutral(_p3(img), C.c_size_t(w), w, h, _ptr(lut), C.c_float(whitecoeff), C.byref(st),
+                                    oor.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return (img, oor.astype(bool)) if want_oor else img

@@ -87,3 +87,19 @@ def test_config4_stages_through_cli(tmp_path):
     err = np.abs(ppm.astype(np.int32) - q)
     # DCT round-off (tolerance-checked stage) -> NL-means weights -> S-curve slope; on the 16-bit output scale
     assert err.max() <= 512 and np.percentile(err, 99.9) <= 64 and np.median(err) <= 1, (err.max(), np.percentile(err, 99.9))
+
+
+def test_neutral_tone_mode_through_cli(tmp_path):
+    """ART's default curve mode end to end: RCD + NEUTRAL tone curve (in-range pixels are bit-exact, so the 16-bit output
+    may differ only where the input exceeded the PQ LUT range -- none here after the getImage clip at 65535)."""
+    w, h, filt = 1000, 600, synth.FILTERS_RGGB
+    raw = synth.bayer_frame(w, h, filt, seed=5)
+    info, ppm = run_cli(tmp_path, raw, "rcd", ("--tone", "neutral"))
+    planes = O.rcd(raw, filt)
+    img = O.get_image(planes, 4, 4, w - 8, h - 8, MUL, True)
+    img = O.convert_color_space(img, MAT)
+    img = O.exposure(img, 1.0, 0.0)
+    ref, oor = O.tone_neutral(img, tone_lut(), 1.0, want_oor=True)
+    q = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.int32) for p in ref], axis=-1)
+    err = np.abs(ppm.astype(np.int32) - q)
+    assert err[~oor].max() == 0 and err.max() <= 8

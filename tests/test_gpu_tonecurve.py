@@ -1,0 +1,55 @@
+"""GPU: NEUTRAL tone-curve mode (NeutralToneCurve::BatchApply, curves.cc:893-1038) vs the oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from art_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def s_curve():
+    x = np.arange(65536, dtype=np.float64) / 65535.0
+    return ((1.0 - np.cos(np.pi * x ** 0.7)) / 2.0 * 65535.0).astype(np.float32)
+
+
+def frame(w, h, seed, top):
+    rng = np.random.default_rng(seed)
+    base = rng.uniform(0.0, top, (h, w)).astype(np.float32)
+    img = [(base * rng.uniform(0.2, 1.0, (h, w))).astype(np.float32) for _ in range(3)]
+    img[0][:8] = img[1][:8] = img[2][:8]          # neutral rows
+    img[1][8:12] = 0.0
+    img[0][12:14] = -50.0                          # negative input is clamped first
+    img[2][14:16, ::2] = 0.0; img[0][14:16, ::2] = 0.0; img[1][14:16, ::2] = 0.0   # black
+    return img
+
+
+@pytest.mark.parametrize("whitecoeff", [1.0, 1.5])
+def test_neutral_tone_curve_in_range_pixels_bit_exact(gpu_ctx, whitecoeff):
+    w, h = 517, 203
+    img = frame(w, h, 21, 65535.0)
+    lut = s_curve()
+    ref, oor = O.tone_neutral(img, lut, whitecoeff, want_oor=True)
+    got = [p.copy() for p in img]
+    gpu_ctx.tone_curve_neutral(capi.host_rgb(got), lut, whitecoeff, O.REC2020_WS_D, O.REC2020_IWS_D)
+    assert oor.mean() < 0.02
+    for g, r in zip(got, ref):
+        assert np.array_equal(g[~oor].view(np.uint32), r[~oor].view(np.uint32))
+        assert np.allclose(g[oor], r[oor], rtol=2e-4, atol=0.5)
+
+
+def test_neutral_tone_curve_super_white_within_tolerance(gpu_ctx):
+    """input above 65535 (after +EV exposure): LMS > 1 -> powf per pixel (host libm in the reference, ocml here)."""
+    w, h = 320, 120
+    img = frame(w, h, 22, 90000.0)
+    lut = s_curve()
+    out_m = np.array([[1.2, -0.15, -0.05], [-0.08, 1.1, -0.02], [0.0, -0.1, 1.1]], np.float32)   # a wider-than-output gamut pair
+    in_m = np.linalg.inv(out_m.astype(np.float64)).astype(np.float32)
+    st = O.neutral_state(to_out=out_m, to_work=in_m)
+    ref, oor = O.tone_neutral(img, lut, 1.0, state=st, want_oor=True)
+    got = [p.copy() for p in img]
+    gpu_ctx.tone_curve_neutral(capi.host_rgb(got), lut, 1.0, O.REC2020_WS_D, O.REC2020_IWS_D, out_m, in_m)
+    assert 0.01 < oor.mean() < 0.9
+    for g, r in zip(got, ref):
+        assert np.array_equal(g[~oor].view(np.uint32), r[~oor].view(np.uint32))
+        assert np.allclose(g[oor], r[oor], rtol=2e-4, atol=0.5)

@@ -45,3 +45,31 @@ def test_xcbrtf_matches_reference():
     y = np.empty_like(x)
     O.lib().oracle_t_xcbrtf(x.ctypes.data_as(C.POINTER(C.c_float)), y.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(len(x)))
     assert np.array_equal(y.view(np.uint32), g["cbrt"].view(np.uint32))
+
+
+def test_xatan2f_xsincosf_match_reference():
+    g = np.load(os.path.join(G, "sleef2.npz"))
+    P = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    ay, ax, sd = (np.ascontiguousarray(g[k]) for k in ("ay", "ax", "sd"))
+    r = np.empty_like(ay)
+    O.lib().oracle_t_xatan2f(P(ay), P(ax), P(r), C.c_size_t(len(ay)))
+    same = (r.view(np.uint32) == g["atan2"].view(np.uint32)) | (np.isnan(r) & np.isnan(g["atan2"]))
+    assert same.all()
+    sn, cs = np.empty_like(sd), np.empty_like(sd)
+    O.lib().oracle_t_xsincosf(P(sd), P(sn), P(cs), C.c_size_t(len(sd)))
+    assert np.array_equal(sn.view(np.uint32), g["sin"].view(np.uint32)) and np.array_equal(cs.view(np.uint32), g["cos"].view(np.uint32))
+
+
+def test_oracle_neutral_curve_keeps_greys_and_range():
+    """identity LUT: greys come back (sat ~ 0, no luminance change); output stays inside [0, whitept]."""
+    lut = np.arange(65536, dtype=np.float32)
+    g = np.linspace(100.0, 60000.0, 256, dtype=np.float32)[None, :].repeat(4, 0)
+    out = O.tone_neutral([g, g, g], lut, 1.0)
+    for p in out:
+        assert np.allclose(p, g, rtol=2e-3, atol=2.0)
+    rng = np.random.default_rng(0)
+    img = [rng.uniform(0, 70000, (32, 64)).astype(np.float32) for _ in range(3)]
+    out = O.tone_neutral(img, lut, 1.0)
+    assert all(np.isfinite(p).all() and p.min() >= 0 and p.max() <= 65535.0 for p in out)
+    st = O.neutral_state()
+    assert -np.pi < st.bhue < st.rhue < st.yhue < np.pi and st.rrange > 0 and st.yrange > 0
