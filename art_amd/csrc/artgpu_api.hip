@@ -1142,7 +1142,17 @@ int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise
 {
     if (!ctx) return ARTGPU_EINVAL;
     if (!img || !p || !ws) return fail(ctx, ARTGPU_EINVAL, "improc_denoise: null argument");
-    if (!img->r.on_device) return fail(ctx, ARTGPU_EUNSUPPORTED, "improc_denoise: device-resident image required (the stages chain on the device)");
+    if (!img->r.on_device) {
+        // host planes: stage once, run the whole tool on the staged copy, copy back
+        DevRGB d;
+        int rc0 = bind_rgb(ctx, img, 4, true, &d, "improc_denoise");
+        if (rc0) return rc0;
+        artgpu_rgb dv;
+        artgpu_plane *pl[3] = {&dv.r, &dv.g, &dv.b};
+        for (int k = 0; k < 3; ++k) { pl[k]->p = d.p[k]; pl[k]->w = d.w; pl[k]->h = d.h; pl[k]->row_stride_bytes = (int64_t)d.stride * 4; pl[k]->on_device = 1; }
+        if ((rc0 = artgpu_improc_denoise(ctx, &dv, p, ws, ecomp, scale, calclum_mat, noise_c_curve, flags))) return rc0;
+        return unbind_rgb(ctx, img, &d);
+    }
     float wsf[9];
     for (int k = 0; k < 9; ++k) wsf[k] = (float)ws[k];
     int rc;

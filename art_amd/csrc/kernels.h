@@ -229,5 +229,7 @@ struct NlmArgs {
 hipError_t launch_detail_mask(const MaskArgs &a, hipStream_t s);
 hipError_t launch_gaussian(const GaussArgs &a, hipStream_t s);
 hipError_t launch_nlm(const NlmArgs &a, hipStream_t s);
+bool nlm_sweep_supported(const NlmArgs &a);
+hipError_t launch_nlm_sweep(const NlmArgs &a, hipStream_t s);   // nlm_sweep.hip (flush-to-zero TU)
 
 } // namespace artgpu

@@ -14,6 +14,7 @@
 //                       MXCSR flush-to-zero (nlmeans.cc:157-160) is reproduced with explicit ftz().
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <stdlib.h>
 #include "devmath.h"
 #include "devsleef.h"
 #include "kernels.h"
@@ -276,6 +277,10 @@ hipError_t launch_nlm(const NlmArgs &a, hipStream_t s)
     const long long npad = (long long)a.WW * a.HH;
     hipLaunchKernelGGL(nlm_prepare_kernel, dim3(fgrid(npad > 8192 ? npad : 8192)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(nlm_zero_kernel, dim3(fgrid((long long)a.W * a.H)), dim3(256), 0, s, a);
+    // v2 (one wave per tile, nlm_sweep.hip) handles patch radii up to 2 (scale >= 1); the v1 workgroup-per-tile kernel is
+    // the exact general path (and ARTGPU_NLM_V1=1 forces it for A/B runs)
+    static const bool force_v1 = getenv("ARTGPU_NLM_V1") != nullptr;
+    if (!force_v1 && nlm_sweep_supported(a)) return launch_nlm_sweep(a, s);
     hipLaunchKernelGGL(nlm_tile_kernel, dim3(a.ntiles_x * a.ntiles_y), dim3(NLM_THREADS), 0, s, a);
     return hipGetLastError();
 }

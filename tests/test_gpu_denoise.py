@@ -120,3 +120,8 @@ def test_improc_denoise_with_noise_curve_bit_exact(gpu_ctx):
     ref = O.improc_denoise(img, calclum_mat=mat, noise_c_curve=curve, smoothing=False, ecomp=0.3, detail_recovery=False)
     for t, r in zip(d, ref):
         assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))
+    # host-pointer (drop-in) form of the same call
+    got = [p.copy() for p in img]
+    gpu_ctx.improc_denoise(capi.host_rgb(got), tp, O.REC2020_WS_D, ecomp=0.3, calclum_mat=mat, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
