@@ -106,6 +106,7 @@ def _load():
     lib.artgpu_nlmeans.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_float, C.c_int, C.c_int, C.c_float]
     lib.artgpu_improc_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseToolParams), C.POINTER(C.c_double), C.c_double,
                                           C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_uint32]
+    lib.artgpu_demosaic_xtrans.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Plane), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(RGB)]
     lib.artgpu_tone_curve_neutral.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.c_float, C.POINTER(NeutralState)]
     lib.artgpu_noise_curve_lut.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_denoise_chroma_map.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float),
@@ -126,7 +127,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -220,6 +221,12 @@ class Context:
 
     def nlmeans(self, img: Plane, strength: int = 50, detail: int = 80, scale: float = 1.0, normcoeff: float = 65535.0):
         self._chk(LIB.artgpu_nlmeans(self._h, C.byref(img), normcoeff, strength, detail, scale))
+
+    def demosaic_xtrans(self, passes: int, use_cielab: bool, raw: Plane, xtrans, rgb_cam, out: RGB):
+        xt = np.ascontiguousarray(xtrans, dtype=np.int32).reshape(36)
+        cam = np.ascontiguousarray(rgb_cam, dtype=np.float32).reshape(12)
+        self._chk(LIB.artgpu_demosaic_xtrans(self._h, passes, 1 if use_cielab else 0, C.byref(raw), xt.ctypes.data_as(C.POINTER(C.c_int32)),
+                                             cam.ctypes.data_as(C.POINTER(C.c_float)), C.byref(out)))
 
     def tone_curve_neutral(self, image: RGB, lut65536, whitecoeff, ws, iws, to_out=None, to_work=None):
         lut = np.ascontiguousarray(lut65536, dtype=np.float32)

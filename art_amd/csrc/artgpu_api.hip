@@ -605,7 +605,7 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT };
 
 struct DevDecomp {
     float *bands, *low[2];
@@ -1045,6 +1045,105 @@ int artgpu_nlmeans(artgpu_ctx *ctx, artgpu_plane *img, float normcoeff, int stre
     a.img = work; a.img_stride = W; a.src = pad;
     HIPCHK(ctx, launch_nlm(a, ctx->stream));
     return pool_to_plane(ctx, work, img);
+}
+
+// ---------------------------------------------------------------------------------------------
+// X-Trans demosaic
+// ---------------------------------------------------------------------------------------------
+int artgpu_demosaic_xtrans(artgpu_ctx *ctx, int passes, int use_cielab, const artgpu_plane *raw, const int32_t xtrans[36],
+                           const float rgb_cam[12], artgpu_rgb *out)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!plane_ok(raw) || !out || !xtrans || !rgb_cam) return fail(ctx, ARTGPU_EINVAL, "demosaic_xtrans: bad raw plane or null argument");
+    if (passes < 1 || passes > 4) return fail(ctx, ARTGPU_EINVAL, "demosaic_xtrans: passes must be 1..4");
+    const int W = raw->w, H = raw->h;
+    if (W < 64 || H < 64) return fail(ctx, ARTGPU_EUNSUPPORTED, "demosaic_xtrans: image %dx%d smaller than 64x64", W, H);
+    int ngreen = 0;
+    for (int i = 0; i < 36; ++i) {
+        if (xtrans[i] < 0 || xtrans[i] > 2) return fail(ctx, ARTGPU_EINVAL, "demosaic_xtrans: colour map entries must be 0..2");
+        ngreen += xtrans[i] == 1;
+    }
+    if (ngreen != 20) return fail(ctx, ARTGPU_EUNSUPPORTED, "demosaic_xtrans: not an X-Trans colour map (%d green of 36)", ngreen);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevImage d;
+    int rc = bind_images(ctx, raw, out, &d);
+    if (rc) return rc;
+    // the reference keeps the hexagon offsets in `short` (xtrans_demosaic.cc:233): same range limit here
+    if (2 * (long long)d.raw_stride + 2 > 32767) return fail(ctx, ARTGPU_EUNSUPPORTED, "demosaic_xtrans: row stride %zu exceeds the reference's short offsets", d.raw_stride);
+
+    XtransArgs a = {};
+    a.raw = d.raw; a.raw_stride = d.raw_stride;
+    a.red = d.r; a.green = d.g; a.blue = d.b; a.out_stride = d.out_stride;
+    a.W = W; a.H = H; a.passes = passes; a.ndir = 4 << (passes > 1); a.use_cielab = use_cielab ? 1 : 0;
+    for (int i = 0; i < 36; ++i) a.xtrans[i] = xtrans[i];
+    auto isgreen = [&](int row, int col) { return a.xtrans[(row % 3) * 6 + col % 3] & 1; };
+    {   // xyz_cam (L219-230)
+        static const float xyz_rgb[3][3] = {{0.412453, 0.357580, 0.180423}, {0.212671, 0.715160, 0.072169}, {0.019334, 0.119193, 0.950227}};
+        static const float d65_white[3] = {0.950456, 1, 1.088754};
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                float acc = 0;
+                for (int k = 0; k < 3; k++) acc += xyz_rgb[i][k] * rgb_cam[k * 4 + j] / d65_white[i];
+                a.xyz_cam[i * 3 + j] = acc;
+            }
+    }
+    {   // green hexagons around each site class and the solitary-green phase (L232-267)
+        static const int orth[12] = {1, 0, 0, 1, -1, 0, 0, -1, 1, 0, 0, 1};
+        static const int patt[2][16] = {{0, 1, 0, -1, 2, 0, -1, 0, 1, 1, 1, -1, 0, 0, 0, 0}, {0, 1, 0, -2, 1, 0, -2, 0, 1, 1, -2, -2, 1, -1, -1, 1}};
+        for (int row = 0; row < 3; row++)
+            for (int col = 0; col < 3; col++) {
+                const int gint = isgreen(row, col);
+                for (int ng = 0, dd = 0; dd < 10; dd += 2) {
+                    if (isgreen(row + orth[dd] + 6, col + orth[dd + 2] + 6)) ng = 0; else ng++;
+                    if (ng == 4) { a.sgrow = row; a.sgcol = col; }
+                    if (ng == gint + 1)
+                        for (int c = 0; c < 8; c++) {
+                            const int v = orth[dd] * patt[gint][c * 2] + orth[dd + 1] * patt[gint][c * 2 + 1];
+                            const int h = orth[dd + 2] * patt[gint][c * 2] + orth[dd + 3] * patt[gint][c * 2 + 1];
+                            a.allhex0[row][col][c ^ (gint * 2 & dd)] = h + v * (int)d.raw_stride;
+                            a.allhex1[row][col][c ^ (gint * 2 & dd)] = h + v * XTRANS_TS;
+                        }
+                }
+            }
+        for (int row = 0; row < 3; row++) {
+            int greencount = 0;
+            for (int col = 0; col < 3; col++) greencount += isgreen(row, col);
+            a.right_shift[row] = greencount == 2;
+        }
+    }
+    float *lut;
+    const bool fresh = ctx->pool[P_XCBRT] == nullptr;
+    if ((rc = pool_get(ctx, P_XCBRT, 0x14000 * 4, &lut))) return rc;
+    if (fresh) {   // cielab's LUT (L43-57), built on the host like the reference's
+        std::vector<float> host(0x14000);
+        const double eps = 216.0 / 24389.0, kappa = 24389.0 / 27.0;
+        for (int i = 0; i < 0x14000; i++) {
+            const double r = i / 65535.0;
+            host[i] = (float)(r > eps ? std::cbrt(r) : (kappa * r + 16.0) / 116.0);
+        }
+        HIPCHK(ctx, hipMemcpyAsync(lut, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    a.cbrt_lut = lut;
+    a.ntx = (W - 22 + (XTRANS_TS - 16) - 1) / (XTRANS_TS - 16);
+    const int nty = (H - 22 + (XTRANS_TS - 16) - 1) / (XTRANS_TS - 16);
+    a.ntiles = a.ntx * nty;
+    const int grid = a.ntiles < MAX_TILE_WORKGROUPS ? a.ntiles : MAX_TILE_WORKGROUPS;
+    a.arena_floats = (size_t)XTRANS_TS * XTRANS_TS * (a.ndir * 4 + 3) + 128;
+    rc = ensure(ctx, &ctx->arena, &ctx->arena_bytes, (size_t)grid * a.arena_floats * sizeof(float));
+    if (rc) return rc;
+    a.arena = ctx->arena;
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    HIPCHK(ctx, launch_xtrans(a, grid, ctx->stream));
+    if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream)); HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream)); }
+    rc = unbind_images(ctx, out, &d);
+    if (rc) return rc;
+    if (ctx->timing) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev[2]));
+        HIPCHK(ctx, hipEventElapsedTime(&ctx->last.demosaic_ms, ctx->ev[0], ctx->ev[1]));
+        ctx->last.border_ms = 0.f; ctx->last.total_ms = ctx->last.demosaic_ms;
+    }
+    return ARTGPU_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -49,6 +49,24 @@ struct RcdArgs {
 __global__ void rcd_tiles_kernel(RcdArgs a);
 hipError_t launch_rcd(const RcdArgs &a, int grid, hipStream_t stream);
 
+// ---- X-Trans Markesteijn demosaic (xtrans.hip) ----
+#define XTRANS_TS 114
+#define XTRANS_THREADS 256
+struct XtransArgs {
+    const float *raw; size_t raw_stride;
+    float *red, *green, *blue; size_t out_stride;
+    float *arena; size_t arena_floats;       // per workgroup: TS*TS*(ndir*4+3)+128 floats, reference layout
+    const float *cbrt_lut;                   // cielab's 0x14000-entry LUT (device)
+    int W, H, ntx, ntiles, passes, ndir, use_cielab;
+    int sgrow, sgcol, right_shift[3];
+    int xtrans[36];
+    int allhex0[3][3][8];                    // offsets in the raw plane (h + v*raw_stride)
+    int allhex1[3][3][8];                    // offsets in a tile plane (h + v*TS)
+    float xyz_cam[9];
+    int border;                              // xtrans_border_kernel only
+};
+hipError_t launch_xtrans(const XtransArgs &a, int grid, hipStream_t s);
+
 // ---- border_interpolate2 (border.hip) ----
 struct BorderArgs {
     const float *raw;

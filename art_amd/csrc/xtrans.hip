@@ -1,0 +1,431 @@
+// art_amd/csrc/xtrans.hip -- X-Trans (Markesteijn) demosaic for gfx950, v1 "arena" kernel.
+//
+// Replaces RawImageSource::xtrans_interpolate(passes, useCieLab) (reference: rtengine/xtrans_demosaic.cc:181-969),
+// cielab (L41-116, x86-64 path) and xtransborder_interpolate (L122-173).  One workgroup per REFERENCE tile (114x114,
+// origin (3,3), stride 98 -- the tile grid decides where each direction buffer is defined, so it is part of the
+// result).  The per-workgroup HBM arena keeps the reference's layout and aliasing (L301-308):
+//     rgb[ndir][114][114][3] | lab[3][106][106] | drv[ndir][104][104]
+//     greenminmax + uint8 homogeneity maps alias lab, 5x5 sums alias drv, the per-pixel maximum aliases homo[ndir-1].
+// rgb[0] and the lab planes are cleared per tile (a reference thread's first tile); everything else is written before
+// it is read.  Every step of the algorithm reads only values produced by EARLIER steps (the in-place green
+// recalculation of pass >= 1 reads green and interpolated R/B at green sites only), so each step is a parallel loop
+// over the tile and steps are separated by workgroup barriers.
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "devmath.h"
+#include "kernels.h"
+
+namespace artgpu {
+
+namespace {
+constexpr int TS = XTRANS_TS, TSH = TS / 2, NT = XTRANS_THREADS;
+constexpr int LW = TS - 8;     // lab plane pitch
+constexpr int DW = TS - 10;    // drv plane pitch
+
+struct Geo {
+    const XtransArgs &a;
+    __device__ int fcol(int row, int col) const { return a.xtrans[(row % 6) * 6 + col % 6]; }
+    __device__ int isgreen(int row, int col) const { return a.xtrans[(row % 3) * 6 + col % 3] & 1; }
+};
+
+__device__ __forceinline__ float limf(float v, float lo, float hi) { return std_max(lo, std_min(v, hi)); }
+
+__device__ __forceinline__ void hex_minmax(const float *pix, const int *hex, float &mn, float &mx)
+{
+    float minval = FLT_MAX, maxval = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const float val = pix[hex[c]];
+        minval = minval < val ? minval : val;
+        maxval = maxval > val ? maxval : val;
+    }
+    mn = minval; mx = maxval;
+}
+__device__ __forceinline__ float cbrt_lut(const float *__restrict__ lut, int i) { return lut[i < 0 ? 0 : (i > 0x14000 - 1 ? 0x14000 - 1 : i)]; }
+} // namespace
+
+#define FOR_T(N) for (int t = tid, _n = (N); t < _n; t += NT)
+
+__global__ void __launch_bounds__(XTRANS_THREADS) xtrans_tiles_kernel(XtransArgs a)
+{
+    const int tid = threadIdx.x;
+    const Geo G{a};
+    const int ndir = a.ndir, passes = a.passes;
+    float *const buffer = a.arena + (size_t)blockIdx.x * a.arena_floats;
+    float *const labbase = buffer + (size_t)TS * TS * (ndir * 3);
+    float *const drvbase = buffer + (size_t)TS * TS * (ndir * 3 + 3);
+    unsigned char *const homo = reinterpret_cast<unsigned char *>(labbase);       // [ndir][TS][TS]
+    float *const gmm = labbase;                                                   // [TS][TSH][2]
+    unsigned char *const homosum = reinterpret_cast<unsigned char *>(drvbase);    // [ndir][TS][TS]
+    unsigned char *const homosummax = homo + (size_t)(ndir - 1) * TS * TS;        // [TS][TS]
+    const int width = a.W, height = a.H;
+    const size_t rs = a.raw_stride;
+    const int sgrow = a.sgrow, sgcol = a.sgcol;
+#define RGB(d, r, c) (buffer + ((size_t)((d) * TS + (r)) * TS + (c)) * 3)
+#define LAB(k, i, j) labbase[((k) * LW + (i)) * LW + (j)]
+#define DRV(d, i, j) drvbase[((d) * DW + (i)) * DW + (j)]
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
+        const int top = 3 + tyi * (TS - 16), left = 3 + txi * (TS - 16);
+        int mrow = min(top + TS, height - 3), mcol = min(left + TS, width - 3);
+
+        // ---- clear the lab planes (greenminmax / homo live there)
+        FOR_T(3 * LW * LW) labbase[t] = 0.f;
+        __syncthreads();
+
+        // ---- green min/max (L320-408): one item per (row, group of the row's non-green run)
+        FOR_T(TS * 40) {
+            const int r = t / 40, g = t - r * 40, row = top + r;
+            if (row >= mrow) continue;
+            int leftstart = left;
+            for (; leftstart < mcol; leftstart++)
+                if (!G.isgreen(row, leftstart)) break;
+            const float *rawrow = a.raw + (size_t)row * rs;
+            float mn, mx;
+            if (a.right_shift[row % 3]) {
+                const int col = leftstart + 3 * g;
+                if (col < mcol) {
+                    hex_minmax(rawrow + col, a.allhex0[row % 3][col % 3], mn, mx);
+                    float *s = gmm + ((size_t)r * TSH + ((col - left) >> 1)) * 2;
+                    s[0] = mn; s[1] = mx;
+                }
+            } else {
+                const int single = (G.fcol(row, leftstart + 1) & 1);    // coloffset == 2: the run starts with a lone pixel
+                if (single && g == 0) {
+                    hex_minmax(rawrow + leftstart, a.allhex0[row % 3][leftstart % 3], mn, mx);
+                    float *s = gmm + ((size_t)r * TSH + ((leftstart - left) >> 1)) * 2;
+                    s[0] = mn; s[1] = mx;
+                } else {
+                    const int col = leftstart + (single ? 2 : 0) + 3 * (g - single);
+                    if (col < mcol) {
+                        hex_minmax(rawrow + col, a.allhex0[row % 3][col % 3], mn, mx);   // the pair shares the first pixel's hexagon
+                        float *s = gmm + ((size_t)r * TSH + ((col - left) >> 1)) * 2;
+                        s[0] = mn; s[1] = mx;
+                        if (col < mcol - 1) {
+                            float *s2 = gmm + ((size_t)r * TSH + ((col + 1 - left) >> 1)) * 2;
+                            s2[0] = mn; s2[1] = mx;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- rgb[0..3] = CFA samples, green interpolated along the 4 directions at the non-green sites (L410-475)
+        FOR_T(TS * TS) {
+            const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
+            float base[3] = {0.f, 0.f, 0.f};
+            float gdir[4];
+            bool interp = false;
+            if (row < mrow && col < mcol) {
+                const int f = G.fcol(row, col);
+                const float *pix = a.raw + (size_t)row * rs + col;
+                base[f] = pix[0];
+                if (!(f & 1)) {
+                    interp = true;
+                    const int *hex = a.allhex0[row % 3][col % 3];
+                    float color[4];
+                    color[0] = 0.6796875f * (pix[hex[1]] + pix[hex[0]]) - 0.1796875f * (pix[2 * hex[1]] + pix[2 * hex[0]]);
+                    color[1] = 0.87109375f * pix[hex[3]] + pix[hex[2]] * 0.12890625f + 0.359375f * (pix[0] - pix[-hex[2]]);
+#pragma unroll
+                    for (int k = 0; k < 2; k++)
+                        color[2 + k] = 0.640625f * pix[hex[4 + k]] + 0.359375f * pix[-2 * hex[4 + k]] + 0.12890625f * (2.f * pix[0] - pix[3 * hex[4 + k]] - pix[-3 * hex[4 + k]]);
+                    const float *s = gmm + ((size_t)r * TSH + (c >> 1)) * 2;
+                    const int flip = a.right_shift[row % 3] ? 0 : 1;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) gdir[k ^ flip] = limf(color[k], s[0], s[1]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                float *p = RGB(d, r, c);
+                p[0] = base[0]; p[1] = interp ? gdir[d] : base[1]; p[2] = base[2];
+            }
+        }
+        __syncthreads();
+
+        for (int pass = 0; pass < passes; pass++) {
+            const int B = pass ? 4 : 0;
+            if (pass == 1) {
+                FOR_T(4 * TS * TS * 3) buffer[(size_t)4 * TS * TS * 3 + t] = buffer[t];
+                __syncthreads();
+            }
+            // recalculate green from interpolated values of closer pixels (L483-524)
+            if (pass) {
+                FOR_T(TS * TS) {
+                    const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
+                    if (r < 2 || c < 2 || row >= mrow - 2 || col >= mcol - 2 || G.isgreen(row, col)) continue;
+                    const int f = G.fcol(row, col);
+                    const int *hex = a.allhex1[row % 3][col % 3];
+                    const int flip = a.right_shift[row % 3] ? 0 : 1;
+                    const float *s = gmm + ((size_t)r * TSH + (c >> 1)) * 2;
+#pragma unroll
+                    for (int d = 3; d < 6; d++) {
+                        float *rix = RGB(B + ((d - 2) ^ flip), r, c);
+                        const float val = 0.33333333f * (rix[-2 * hex[d] * 3 + 1] + 2 * (rix[hex[d] * 3 + 1] - rix[hex[d] * 3 + f]) - rix[-2 * hex[d] * 3 + f]) + rix[f];
+                        rix[1] = limf(val, s[0], s[1]);
+                    }
+                }
+                __syncthreads();
+            }
+            // red and blue for solitary green pixels (L527-561)
+            {
+                const int row0 = (top - sgrow + 4) / 3 * 3 + sgrow, col0 = (left - sgcol + 4) / 3 * 3 + sgcol;
+                FOR_T(40 * 40) {
+                    const int i3 = t / 40, j3 = t - i3 * 40;
+                    const int row = row0 + 3 * i3, col = col0 + 3 * j3;
+                    if (row >= mrow - 2 || col >= mcol - 2) continue;
+                    int h = G.fcol(row, col0 + 1) ^ ((j3 & 1) ? 2 : 0);
+                    float *rix = RGB(B, row - top, col - left);
+                    float color[3][6];
+                    float diff[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    int i = 1;
+#pragma unroll
+                    for (int d = 0; d < 6; d++) {
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const int o = (i << k) * 3;
+                            const float g = rix[1] + rix[1] - rix[o + 1] - rix[-o + 1];
+                            color[h][d] = g + rix[o + h] + rix[-o + h];
+                            if (d > 1) diff[d] += sqr(rix[o + 1] - rix[-o + 1] - rix[o + h] + rix[-o + h]) + sqr(g);
+                            h ^= 2;
+                        }
+                        if (d > 2 && (d & 1))
+                            if (diff[d - 1] < diff[d]) { color[0][d] = color[0][d - 1]; color[2][d] = color[2][d - 1]; }
+                        if ((d & 1) || d < 2) {
+                            rix[0] = 0.5f * color[0][d];
+                            rix[2] = 0.5f * color[2][d];
+                            rix += TS * TS * 3;
+                        }
+                        i ^= TS ^ 1;
+                        h ^= 2;
+                    }
+                }
+            }
+            __syncthreads();
+            // red for blue pixels and vice versa (L564-606)
+            FOR_T(TS * TS) {
+                const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
+                if (r < 3 || c < 3 || row >= mrow - 3 || col >= mcol - 3 || G.isgreen(row, col)) continue;
+                const int cd = ((row - sgrow) % 3) ? TS : 1;
+                const int hd = 3 * (cd ^ TS ^ 1);
+                const int f = 2 - G.fcol(row, col);
+                float *rix = RGB(B, r, c);
+#pragma unroll
+                for (int d = 0; d < 4; d++, rix += TS * TS * 3) {
+                    const int i = d > 1 || ((d ^ cd) & 1) ||
+                                  ((fabsf(rix[1] - rix[cd * 3 + 1]) + fabsf(rix[1] - rix[-cd * 3 + 1])) < 2.f * (fabsf(rix[1] - rix[hd * 3 + 1]) + fabsf(rix[1] - rix[-hd * 3 + 1]))) ? cd : hd;
+                    rix[f] = rix[1] + 0.5f * (rix[i * 3 + f] + rix[-i * 3 + f] - rix[i * 3 + 1] - rix[-i * 3 + 1]);
+                }
+            }
+            __syncthreads();
+            // red and blue for 2x2 blocks of green (L609-650)
+            FOR_T(TS * TS) {
+                const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
+                if (r < 2 || c < 2 || row >= mrow - 2 || col >= mcol - 2) continue;
+                if ((row - sgrow) % 3 == 0 || (col - sgcol) % 3 == 0) continue;
+                const int *hex = a.allhex1[row % 3][col % 3];
+                float *rix = RGB(B, r, c);
+                for (int d = 0; d < ndir; d += 2, rix += TS * TS * 3) {
+                    if (hex[d] + hex[d + 1]) {
+                        const float g = 3 * rix[1] - 2 * rix[hex[d] * 3 + 1] - rix[hex[d + 1] * 3 + 1];
+                        rix[0] = (g + 2 * rix[hex[d] * 3 + 0] + rix[hex[d + 1] * 3 + 0]) * 0.33333333f;
+                        rix[2] = (g + 2 * rix[hex[d] * 3 + 2] + rix[hex[d + 1] * 3 + 2]) * 0.33333333f;
+                    } else {
+                        const float g = 2 * rix[1] - rix[hex[d] * 3 + 1] - rix[hex[d + 1] * 3 + 1];
+                        rix[0] = (g + rix[hex[d] * 3 + 0] + rix[hex[d + 1] * 3 + 0]) * 0.5f;
+                        rix[2] = (g + rix[hex[d] * 3 + 2] + rix[hex[d + 1] * 3 + 2]) * 0.5f;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        const int mrl = mrow - top, mcl = mcol - left;   // tile-local bounds (L654-655)
+        // ---- perceptual space + directional derivatives (L657-741), one direction at a time (lab is reused)
+        for (int d = 0; d < ndir; d++) {
+            if (a.use_cielab) {
+                FOR_T((mrl - 8) * LW) {
+                    const int i = t / LW, j = t - i * LW;
+                    const float *p = RGB(d, 4 + i, 4 + j);
+                    float c0, c1, c2;
+                    if (j < ((LW - 3 + 3) / 4) * 4) {       // 4-lane groups while j < labWidth - 3
+                        const float x0 = p[0] * a.xyz_cam[0] + p[1] * a.xyz_cam[1] + p[2] * a.xyz_cam[2];
+                        const float x1 = p[0] * a.xyz_cam[3] + p[1] * a.xyz_cam[4] + p[2] * a.xyz_cam[5];
+                        const float x2 = p[0] * a.xyz_cam[6] + p[1] * a.xyz_cam[7] + p[2] * a.xyz_cam[8];
+                        c0 = cbrt_lut(a.cbrt_lut, __float2int_rn(x0)); c1 = cbrt_lut(a.cbrt_lut, __float2int_rn(x1)); c2 = cbrt_lut(a.cbrt_lut, __float2int_rn(x2));
+                        LAB(0, i, j) = 116.f * c1 - 16.f;
+                    } else {
+                        float x0 = 0.5f, x1 = 0.5f, x2 = 0.5f;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) { x0 += a.xyz_cam[k] * p[k]; x1 += a.xyz_cam[3 + k] * p[k]; x2 += a.xyz_cam[6 + k] * p[k]; }
+                        c0 = cbrt_lut(a.cbrt_lut, (int)x0); c1 = cbrt_lut(a.cbrt_lut, (int)x1); c2 = cbrt_lut(a.cbrt_lut, (int)x2);
+                        LAB(0, i, j) = 116 * c1 - 16;
+                    }
+                    LAB(1, i, j) = 500.f * (c0 - c1);
+                    LAB(2, i, j) = 200.f * (c1 - c2);
+                }
+            } else {
+                FOR_T(TS * TS) {
+                    const int r = t / TS, c = t - r * TS;
+                    if (r < 4 || c < 4 || r >= mrl - 4 || c >= mcl - 4) continue;
+                    const float *p = RGB(d, r, c);
+                    const float y = 0.2627f * p[0] + 0.6780f * p[1] + 0.0593f * p[2];
+                    LAB(0, r - 4, c - 4) = y;
+                    LAB(1, r - 4, c - 4) = (p[2] - y) * 0.56433f;
+                    LAB(2, r - 4, c - 4) = (p[0] - y) * 0.67815f;
+                }
+            }
+            __syncthreads();
+            {
+                const int dd = d & 3;
+                const int f = dd == 0 ? 1 : (dd == 1 ? LW : (dd == 2 ? LW + 1 : LW - 1));
+                FOR_T(TS * TS) {
+                    const int r = t / TS, c = t - r * TS;
+                    if (r < 5 || c < 5 || r >= mrl - 5 || c >= mcl - 5) continue;
+                    const float *l = &LAB(0, r - 4, c - 4), *aa = &LAB(1, r - 4, c - 4), *b = &LAB(2, r - 4, c - 4);
+                    float v;
+                    if (a.use_cielab) {
+                        const float g = 2 * l[0] - l[f] - l[-f];
+                        v = sqr(g) + sqr((2 * aa[0] - aa[f] - aa[-f] + g * 2.1551724f)) + sqr((2 * b[0] - b[f] - b[-f] - g * 0.86206896f));
+                    } else {
+                        v = sqr(2 * l[0] - l[f] - l[-f]) + sqr(2 * aa[0] - aa[f] - aa[-f]) + sqr(2 * b[0] - b[f] - b[-f]);
+                    }
+                    DRV(d, r - 5, c - 5) = v;
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---- homogeneity maps (L744-811)
+        FOR_T(TS * TS) {
+            const int r = t / TS, c = t - r * TS;
+            if (r < 6 || c < 6 || r >= mrl - 6 || c >= mcl - 6) continue;
+            float tr = DRV(0, r - 5, c - 5) < DRV(1, r - 5, c - 5) ? DRV(0, r - 5, c - 5) : DRV(1, r - 5, c - 5);
+            for (int d = 2; d < ndir; d++) tr = (DRV(d, r - 5, c - 5) < tr ? DRV(d, r - 5, c - 5) : tr);
+            tr *= 8;
+            for (int d = 0; d < ndir; d++) {
+                int cnt = 0;
+#pragma unroll
+                for (int v = -1; v <= 1; v++)
+#pragma unroll
+                    for (int h = -1; h <= 1; h++) cnt += (DRV(d, r + v - 5, c + h - 5) <= tr ? 1 : 0);
+                homo[((size_t)d * TS + r) * TS + c] = (unsigned char)cnt;
+            }
+        }
+        __syncthreads();
+
+        int mr2 = mrl, mc2 = mcl;
+        if (height - top < TS + 4) mr2 = height - top + 2;
+        if (width - left < TS + 4) mc2 = width - left + 2;
+        const int startrow = min(top, 8), startcol = min(left, 8);
+        // ---- 5x5 sums of the homogeneity maps (L823-866)
+        FOR_T(ndir * TS * TS) {
+            const int d = t / (TS * TS), q = t - d * TS * TS, r = q / TS, c = q - r * TS;
+            if (r < startrow || c < startcol || r >= mr2 - 8 || c >= mc2 - 8) continue;
+            int sum = 0;
+#pragma unroll
+            for (int v = -2; v <= 2; v++)
+#pragma unroll
+                for (int h = -2; h <= 2; h++) sum += homo[((size_t)d * TS + r + v) * TS + c + h];
+            // the reference's 16-wide loop adds with unsigned saturation (_mm_adds_epu8, L835-843); its running-sum tail,
+            // which only the last row reaches, truncates to uint8 (L846-864).  Sums above 255 arise where never-written
+            // homogeneity bytes (= lab bytes) are read at the right / bottom edge.
+            const int endcol = r < mr2 - 9 ? mc2 - 8 : mc2 - 23;
+            const int ncov = endcol > startcol ? ((endcol - startcol + 15) / 16) * 16 : 0;
+            homosum[((size_t)d * TS + r) * TS + c] = (c < startcol + ncov) ? (unsigned char)(sum > 255 ? 255 : sum) : (unsigned char)sum;
+        }
+        __syncthreads();
+        // ---- per-pixel maximum (L870-906)
+        FOR_T(TS * TS) {
+            const int r = t / TS, c = t - r * TS;
+            if (r < startrow || c < startcol || r >= mr2 - 8 || c >= mc2 - 8) continue;
+            unsigned char maxval = homosum[(size_t)r * TS + c];
+            for (int d = 1; d < ndir; d++) {
+                const unsigned char v = homosum[((size_t)d * TS + r) * TS + c];
+                maxval = maxval < v ? v : maxval;
+            }
+            maxval -= maxval >> 3;
+            homosummax[(size_t)r * TS + c] = maxval;
+        }
+        __syncthreads();
+        // ---- average the most homogeneous directions (L910-949)
+        FOR_T(TS * TS) {
+            const int r = t / TS, c = t - r * TS;
+            if (r < startrow || c < startcol || r >= mr2 - 8 || c >= mc2 - 8) continue;
+            unsigned char hm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int d = 0; d < 4; d++) hm[d] = homosum[((size_t)d * TS + r) * TS + c];
+            if (ndir > 4) {
+#pragma unroll
+                for (int d = 4; d < 8; d++) {
+                    hm[d] = homosum[((size_t)d * TS + r) * TS + c];
+                    if (hm[d - 4] < hm[d]) hm[d - 4] = 0;
+                    else if (hm[d - 4] > hm[d]) hm[d] = 0;
+                }
+            }
+            float avg[4] = {0.f, 0.f, 0.f, 0.f};
+            const unsigned char maxval = homosummax[(size_t)r * TS + c];
+#pragma unroll
+            for (int d = 0; d < 8; d++)
+                if (d < ndir && hm[d] >= maxval) {
+                    const float *p = RGB(d, r, c);
+                    avg[0] += p[0]; avg[1] += p[1]; avg[2] += p[2];
+                    avg[3]++;
+                }
+            const size_t o = (size_t)(r + top) * a.out_stride + c + left;
+            a.red[o] = std_max(0.f, avg[0] / avg[3]);
+            a.green[o] = std_max(0.f, avg[1] / avg[3]);
+            a.blue[o] = std_max(0.f, avg[2] / avg[3]);
+        }
+        __syncthreads();
+    }
+}
+
+// xtransborder_interpolate (L122-173): one lane per frame pixel inside the border strips
+__global__ void __launch_bounds__(256) xtrans_border_kernel(XtransArgs a)
+{
+    const int width = a.W, height = a.H, border = a.border;
+    const long long n = (long long)width * height;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(t / width), col = (int)(t - (long long)row * width);
+        if (row >= border && row < height - border && col >= border && col < width - border) continue;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;   // sum[0..2], sum[3..5]
+        for (int y = max(0, row - 1); y <= min(row + 1, height - 1); y++)
+            for (int x = max(0, col - 1); x <= min(col + 1, width - 1); x++) {
+                const int f = a.xtrans[(y % 6) * 6 + x % 6];
+                const float wgt = (y == row && x == col) ? 0.f : ((y == row || x == col) ? 0.5f : 0.25f);
+                const float v = a.raw[(size_t)y * a.raw_stride + x] * wgt;
+                if (f == 0) { s0 += v; w0 += wgt; }
+                else if (f == 1) { s1 += v; w1 += wgt; }
+                else { s2 += v; w2 += wgt; }
+            }
+        const float here = a.raw[(size_t)row * a.raw_stride + col];
+        const size_t o = (size_t)row * a.out_stride + col;
+        const int fc_ = a.xtrans[(row % 6) * 6 + col % 6];
+        if (fc_ == 0) {
+            a.red[o] = here; a.green[o] = s1 / w1; a.blue[o] = s2 / w2;
+        } else if (fc_ == 1) {
+            if (w0 == 0.f) { a.red[o] = here; a.green[o] = here; a.blue[o] = here; }
+            else { a.red[o] = s0 / w0; a.green[o] = here; a.blue[o] = s2 / w2; }
+        } else {
+            a.red[o] = s0 / w0; a.green[o] = s1 / w1; a.blue[o] = here;
+        }
+    }
+}
+
+hipError_t launch_xtrans(const XtransArgs &a, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(xtrans_tiles_kernel, dim3(grid), dim3(XTRANS_THREADS), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long long n = (long long)a.W * a.H;
+    long long g = (n + 255) / 256;
+    XtransArgs b = a;
+    b.border = a.passes > 1 ? 8 : 11;   // xtrans_demosaic.cc:968
+    hipLaunchKernelGGL(xtrans_border_kernel, dim3((unsigned)(g < 16384 ? g : 16384)), dim3(256), 0, s, b);
+    return hipGetLastError();
+}
+
+} // namespace artgpu

@@ -38,6 +38,7 @@ int main(int argc, char **argv)
     double lum = 0, chroma = 0, expcomp = 0;
     bool dn = false, smoothing = false;
     int tone_mode = ARTGPU_TONE_STD;
+    int xtrans_passes = 0;   // 0 = Bayer; 1 / 3 = X-Trans ONE_PASS / THREE_PASS with the Fuji colour map
     int gradius = 3, nlstrength = 0, nldetail = 80;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -52,6 +53,7 @@ int main(int argc, char **argv)
         else if (a == "--expcomp") expcomp = std::atof(next());
         else if (a == "--method") { std::string m = next(); method = (m == "rcd") ? ARTGPU_BAYER_RCD : ARTGPU_BAYER_AMAZE; }
         else if (a == "--denoise") { dn = true; if (std::sscanf(next(), "%lf,%lf", &lum, &chroma) != 2) { std::fprintf(stderr, "--denoise L,C\n"); return 2; } }
+        else if (a == "--xtrans") { xtrans_passes = std::atoi(next()); border = 7; }
         else if (a == "--tone") { std::string m = next(); tone_mode = (m == "neutral") ? ARTGPU_TONE_NEUTRAL : ARTGPU_TONE_STD; }
         else if (a == "--smoothing") { smoothing = true; if (std::sscanf(next(), "%d,%d,%d", &gradius, &nlstrength, &nldetail) != 3) { std::fprintf(stderr, "--smoothing radius,nlStrength,nlDetail\n"); return 2; } }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
@@ -82,7 +84,10 @@ int main(int argc, char **argv)
 
         auto t0 = std::chrono::steady_clock::now();
         // stage_init (simpleprocess.cc:215-259)
-        RawImageSource imgsrc(ctx, W, H, filters, 1.0);
+        static const int32_t fuji[36] = {1, 1, 0, 1, 1, 2, 1, 1, 2, 1, 1, 0, 2, 0, 1, 0, 2, 1, 1, 1, 2, 1, 1, 0, 1, 1, 0, 1, 1, 2, 0, 2, 1, 2, 0, 1};
+        static const float cam[12] = {1.60f, -0.45f, -0.15f, 0.f, -0.20f, 1.45f, -0.25f, 0.f, 0.02f, -0.50f, 1.48f, 0.f};
+        RawImageSource imgsrc = xtrans_passes ? RawImageSource(ctx, W, H, fuji, cam) : RawImageSource(ctx, W, H, filters, 1.0);
+        params.xtranssensor.method = xtrans_passes == 1 ? ProcParams::ONE_PASS : ProcParams::THREE_PASS;
         imgsrc.setBorder(border);
         imgsrc.load(cfa.data());
         imgsrc.demosaic(params);

@@ -76,6 +76,8 @@ public:
 // The fields of ProcParams the path reads (procparams.cc:1528-3335 for the defaults)
 struct ProcParams {
     struct { int method = ARTGPU_BAYER_AMAZE; int border = 4; } bayersensor;  // raw.bayersensor.{method,border}
+    enum XTransMethod { ONE_PASS = 1, THREE_PASS = 3 };
+    struct { int method = THREE_PASS; int border = 7; } xtranssensor;          // raw.xtranssensor.{method,border} (procparams.cc:3064)
     struct { bool enabled = false; double luminance = 0, luminanceDetail = 0; int luminanceDetailThreshold = 0; double chrominance = 15,
              chrominanceRedGreen = 0, chrominanceBlueYellow = 0, gamma = 1.7; bool aggressive = false; int colorSpace = 0, chrominanceMethod = 0;
              bool smoothingEnabled = false; int guidedChromaRadius = 3, nlDetail = 80, nlStrength = 0; } denoise;   // procparams.cc:1900-1918 (chrominanceMethod 0 = MANUAL here)
@@ -93,6 +95,14 @@ class RawImageSource {
 public:
     RawImageSource(Context &c, int W, int H, uint32_t filters, double initialGain = 1.0)
         : ctx(c), W(W), H(H), filters(filters), initialGain(initialGain), rawData(W, H), red(W, H), green(W, H), blue(W, H) {}
+    // X-Trans sensor: 6x6 colour map (RawImage::getXtransMatrix) and camera matrix (getRgbCam)
+    RawImageSource(Context &c, int W, int H, const int32_t xtrans_[36], const float rgb_cam_[12])
+        : ctx(c), W(W), H(H), filters(9), initialGain(1.0), rawData(W, H), red(W, H), green(W, H), blue(W, H), isXtrans(true)
+    {
+        for (int i = 0; i < 36; ++i) xtrans[i] = xtrans_[i];
+        for (int i = 0; i < 12; ++i) rgb_cam[i] = rgb_cam_[i];
+        border = 7;
+    }
     void setBorder(int b) { border = b; }                                   // rawimagesource.h (simpleprocess.cc:138-146)
     void load(const float *cfa_host) { rawData.upload(cfa_host); }          // stands in for load()/preprocess(): CFA 0..65535
     // RawImageSource::demosaic (rawimagesource.cc:1854-1962)
@@ -100,6 +110,11 @@ public:
     {
         artgpu_plane raw = rawData.view();
         artgpu_rgb out{red.view(), green.view(), blue.view()};
+        if (isXtrans) {   // rawimagesource.cc:1915-1925: ONE_PASS -> (1, false), THREE_PASS -> (3, true)
+            const int passes = p.xtranssensor.method == ProcParams::ONE_PASS ? 1 : 3;
+            ctx.check(artgpu_demosaic_xtrans(ctx.get(), passes, passes > 1 ? 1 : 0, &raw, xtrans, rgb_cam, &out));
+            return;
+        }
         ctx.check(artgpu_demosaic_bayer(ctx.get(), p.bayersensor.method, &raw, filters, initialGain, border, &out));
     }
     void getFullSize(int &w, int &h) const { w = W - 2 * border; h = H - 2 * border; }   // computeFullSize (L1163-1193), tran = 0
@@ -127,6 +142,9 @@ public:
     uint32_t filters;
     double initialGain;
     DevicePlane rawData, red, green, blue;
+    bool isXtrans = false;
+    int32_t xtrans[36] = {};
+    float rgb_cam[12] = {};
 };
 
 // rtengine::ImProcFunctions counterpart

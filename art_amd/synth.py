@@ -41,8 +41,9 @@ def _hash64(idx: np.ndarray, seed: int) -> np.ndarray:
 
 
 def bayer_frame(width: int, height: int, filters: int = FILTERS_RGGB, seed: int = 0,
-                noise: int = 1024, clip_patch: bool = True, nyquist_patch: bool = True) -> np.ndarray:
-    """Return a (height, width) float32 CFA frame with integer values in [0, 65535]."""
+                noise: int = 1024, clip_patch: bool = True, nyquist_patch: bool = True, xtrans=None) -> np.ndarray:
+    """Return a (height, width) float32 CFA frame with integer values in [0, 65535] (xtrans: 6x6 colour map instead of
+    the Bayer `filters` word)."""
     out = np.empty((height, width), dtype=np.float32)
     x = np.arange(width, dtype=np.int64)[None, :]
     band = 512
@@ -61,7 +62,7 @@ def bayer_frame(width: int, height: int, filters: int = FILTERS_RGGB, seed: int 
         if noise > 0:
             h = _hash64(idx, seed)
             v = v + (h & np.uint64(2 * noise - 1)).astype(np.int64) - noise
-        c = fc(filters, y, x)
+        c = fc(filters, y, x) if xtrans is None else xtrans[y % 6, x % 6]
         gain = np.where(c == 0, 614, np.where(c == 1, 1024, 717))
         v = (v * gain) >> 10
         if clip_patch:
@@ -70,3 +71,20 @@ def bayer_frame(width: int, height: int, filters: int = FILTERS_RGGB, seed: int 
             v = np.where(inside, 65535, v)
         out[y0:y1] = np.clip(v, 0, 65535).astype(np.float32)
     return out
+
+
+# Fuji X-Trans 6x6 colour map (0 = R, 1 = G, 2 = B), SURVEY.md section 8d
+XTRANS_FUJI = np.array([[1, 1, 0, 1, 1, 2],
+                        [1, 1, 2, 1, 1, 0],
+                        [2, 0, 1, 0, 2, 1],
+                        [1, 1, 2, 1, 1, 0],
+                        [1, 1, 0, 1, 1, 2],
+                        [0, 2, 1, 2, 0, 1]], dtype=np.int32)
+# camera -> sRGB matrix rows (RawImage::getRgbCam is 3x4; 4th column unused for 3-colour sensors)
+XTRANS_RGB_CAM = np.array([[1.60, -0.45, -0.15, 0.0],
+                           [-0.20, 1.45, -0.25, 0.0],
+                           [0.02, -0.50, 1.48, 0.0]], dtype=np.float32)
+
+
+def xtrans_frame(width: int, height: int, seed: int = 0, noise: int = 1024, clip_patch: bool = True) -> np.ndarray:
+    return bayer_frame(width, height, 0, seed, noise, clip_patch, True, xtrans=XTRANS_FUJI)

@@ -35,10 +35,11 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=W45)
     ap.add_argument("--height", type=int, default=H45)
-    ap.add_argument("--workload", default="c3", choices=["amaze", "rcd", "c3", "c4"],
+    ap.add_argument("--workload", default="c3", choices=["amaze", "rcd", "c3", "c4", "c5"],
                     help="amaze/rcd: demosaic only (BASELINE configs[1]); c3: AMaZE + getImage/matrix + FTblockDN wavelet "
                          "denoise + exposure + tone curve (BASELINE configs[2], the configuration the metric is quoted on); "
-                         "c4: c3 + guided chroma smoothing + NL-means (the per-frame pipe of BASELINE configs[3])")
+                         "c4: c3 + guided chroma smoothing + NL-means (the per-frame pipe of BASELINE configs[3]); "
+                         "c5: X-Trans 3-pass (Markesteijn, CIELab) + the c3 stages on a 100 MP 11648x8736 frame (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     args = ap.parse_args()
@@ -61,8 +62,11 @@ def main() -> None:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     W, H = args.width, args.height
+    xtrans = args.workload == "c5"
+    if xtrans and (W, H) == (W45, H45):
+        W, H = 11648, 8736                                    # 100 MP X-Trans sensor
     filt = synth.FILTERS_RGGB
-    raw = synth.bayer_frame(W, H, filt, seed=rank)            # frame `rank` of the batch
+    raw = synth.xtrans_frame(W, H, seed=rank) if xtrans else synth.bayer_frame(W, H, filt, seed=rank)   # frame `rank` of the batch
     d_raw = torch.from_numpy(raw).to(dev)
     d_out = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(3)]
     stream = torch.cuda.current_stream(dev)
@@ -70,9 +74,9 @@ def main() -> None:
     out = capi.RGB(*[capi.device_plane(t) for t in d_out])
     p_raw = capi.device_plane(d_raw)
     method = capi.BAYER_RCD if args.workload == "rcd" else capi.BAYER_AMAZE
-    border = 4
+    border = 7 if xtrans else 4
     iw, ih = W - 2 * border, H - 2 * border
-    pipeline = args.workload in ("c3", "c4")
+    pipeline = args.workload in ("c3", "c4", "c5")
     smoothing = args.workload == "c4"
     if pipeline:
         d_img = [torch.empty((ih, iw), dtype=torch.float32, device=dev) for _ in range(3)]
@@ -99,7 +103,10 @@ def main() -> None:
 
     def step():
         mark(0)
-        ctx.demosaic_bayer(method, p_raw, filt, 1.0, border, out)
+        if xtrans:
+            ctx.demosaic_xtrans(3, True, p_raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, out)
+        else:
+            ctx.demosaic_bayer(method, p_raw, filt, 1.0, border, out)
         mark(1)
         if pipeline:
             ctx.get_image(out, border, border, mul, True, mat, img)
@@ -150,7 +157,8 @@ def main() -> None:
     achieved = (W * H * ALGO_BYTES_PER_PX / 1e9) / (kern_ms / 1e3)
 
     result = {
-        "metric": "megapixels/sec end-to-end (AMaZE+FTblockDN+tone), 45 MP Bayer",
+        "metric": ("megapixels/sec end-to-end (X-Trans+FTblockDN+tone), 100 MP X-Trans" if xtrans else
+                   "megapixels/sec end-to-end (AMaZE+FTblockDN+tone), 45 MP Bayer"),
         "value": round(value, 2),
         "unit": "MP/s",
         "n_gpus": world,
@@ -163,18 +171,18 @@ def main() -> None:
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": (f"AMaZE + getImage/matrix + ImProcFunctions::denoise (chroma noise-curve map, FTblockDN wavelet shrinkage luma 40 / "
+            "workload": (("X-Trans 3-pass Markesteijn (CIELab)" if xtrans else "AMaZE") + f" + getImage/matrix + ImProcFunctions::denoise (chroma noise-curve map, FTblockDN wavelet shrinkage luma 40 / "
                          f"chroma 15 / gamma 1.7 + DCT detail recovery 50"
                          + (", guided chroma smoothing r=3, NL-means 50/80" if smoothing else "")
-                         + f") + exposure 0.3 EV + tone curve STD, {W}x{H} Bayer RGGB fp32, 1 frame per GPU per step "
-                         + ("(per-frame pipe of BASELINE configs[3])" if smoothing else "(BASELINE configs[2])"))
+                         + f") + exposure 0.3 EV + tone curve STD, {W}x{H} " + ("X-Trans" if xtrans else "Bayer RGGB") + " fp32, 1 frame per GPU per step "
+                         + ("(BASELINE configs[4])" if xtrans else "(per-frame pipe of BASELINE configs[3])" if smoothing else "(BASELINE configs[2])"))
                         if pipeline else f"{args.workload.upper()} demosaic only, {W}x{H} Bayer RGGB fp32 (BASELINE configs[1])",
             "stage_ms": stage_ms,
             "frame": f"{W}x{H}", "frames_per_step": world, "parallelism": f"frame-per-gpu x{world}",
             "completion_records": len(records),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "amaze_tiles_kernel" if method == capi.BAYER_AMAZE else "rcd_tiles_kernel",
+            "bound": "hbm", "kernel": "xtrans_tiles_kernel" if xtrans else "amaze_tiles_kernel" if method == capi.BAYER_AMAZE else "rcd_tiles_kernel",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
             "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": W * H * ALGO_BYTES_PER_PX,
@@ -188,12 +196,15 @@ def main() -> None:
         cw, ch = W, H
         if pipeline:
             # bounded sample (~10-30 s of CPU work): the top-left quarter of the frame (same scene statistics)
-            cw, ch = (W // 2) & ~1, (H // 2) & ~1
+            cw, ch = ((W // 2) // 6 * 6, (H // 2) // 6 * 6) if xtrans else ((W // 2) & ~1, (H // 2) & ~1)
+            if xtrans:
+                cw, ch = cw // 2 // 6 * 6, ch // 2 // 6 * 6          # 1/16 of the 100 MP frame keeps the CPU leg bounded
             craw = np.ascontiguousarray(raw[:ch, :cw])
             ciw, cih = cw - 2 * border, ch - 2 * border
 
             def fn():
-                pl = oracle_lib.amaze(craw, filt, 1.0, border)
+                pl = (oracle_lib.xtrans_demosaic(craw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, 3, True) if xtrans
+                      else oracle_lib.amaze(craw, filt, 1.0, border))
                 im = oracle_lib.get_image(pl, border, border, ciw, cih, mul, True)
                 im = oracle_lib.convert_color_space(im, mat)
                 im = oracle_lib.improc_denoise(im, calclum_mat=mat, noise_c_curve=ccurve, smoothing=smoothing, radius=3,

@@ -92,6 +92,14 @@ int artgpu_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, 
 int artgpu_border_interpolate2(artgpu_ctx *ctx, const artgpu_plane *raw, uint32_t filters,
                                int lborders, artgpu_rgb *out);
 
+/* Replaces RawImageSource::xtrans_interpolate(passes, useCieLab) (rtengine/xtrans_demosaic.cc:181-969) including the
+ * final xtransborder_interpolate(passes > 1 ? 8 : 11) (L968).  ART calls it as (1, false) for ONE_PASS and (3, true)
+ * for THREE_PASS (rawimagesource.cc:1920-1925).
+ * xtrans : RawImage::getXtransMatrix, 6x6 row-major, 0 = R, 1 = G, 2 = B.
+ * rgb_cam: RawImage::getRgbCam, 3x4 row-major (only used to build xyz_cam for the CIELab path, L219-230). */
+int artgpu_demosaic_xtrans(artgpu_ctx *ctx, int passes, int use_cielab, const artgpu_plane *raw, const int32_t xtrans[36],
+                           const float rgb_cam[12], artgpu_rgb *out);
+
 /* Replaces RawImageSource::getImage for tran=0, skip=1, no highlight recovery
  * (rtengine/rawimagesource.cc:781-1104; pixel loop L940-1025), optionally fused with the matrix
  * branch of colorSpaceConversion_ (L3184-3213) when `mat` is not NULL:

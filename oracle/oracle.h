@@ -41,6 +41,10 @@ float oracle_xatan2f(float y, float x);
 void oracle_xsincosf(float d, float *sn, float *cs);
 void oracle_t_xatan2f(const float *y, const float *x, float *r, size_t n);
 void oracle_t_xsincosf(const float *d, float *sn, float *cs, size_t n);
+/* X-Trans (xtrans.c) */
+void oracle_xtrans_demosaic(const float *raw, int width, int height, const int xtrans[36], const float rgb_cam[12], int passes, int use_cielab,
+                            float *red, float *green, float *blue);
+void oracle_xtrans_border(const float *raw, int width, int height, const int xtrans[36], int border, float *red, float *green, float *blue);
 /* NEUTRAL tone curve (tonecurve.c) */
 typedef struct {
     float ws[9], iws[9];            /* working space <-> XYZ, float casts (curves.cc:861-868) */

@@ -340,3 +340,14 @@ def tone_neutral(img, lut, whitecoeff=1.0, state=None, want_oor=False):
     lib().oracle_tone_curve_neutral(_p3(img), C.c_size_t(w), w, h, _ptr(lut), C.c_float(whitecoeff), C.byref(st),
                                     oor.ctypes.data_as(C.POINTER(C.c_ubyte)))
     return (img, oor.astype(bool)) if want_oor else img
+
+
+def xtrans_demosaic(raw, xtrans, rgb_cam, passes=1, use_cielab=False):
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    h, w = raw.shape
+    xt = np.ascontiguousarray(xtrans, dtype=np.int32).reshape(36)
+    cam = np.ascontiguousarray(rgb_cam, dtype=np.float32).reshape(12)
+    out = [np.zeros((h, w), np.float32) for _ in range(3)]
+    lib().oracle_xtrans_demosaic(_ptr(raw), w, h, xt.ctypes.data_as(C.POINTER(C.c_int)), _ptr(cam), int(passes), int(use_cielab),
+                                 _ptr(out[0]), _ptr(out[1]), _ptr(out[2]))
+    return out

@@ -103,3 +103,20 @@ def test_neutral_tone_mode_through_cli(tmp_path):
     q = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.int32) for p in ref], axis=-1)
     err = np.abs(ppm.astype(np.int32) - q)
     assert err[~oor].max() == 0 and err.max() <= 8
+
+
+def test_xtrans_three_pass_through_cli(tmp_path):
+    """BASELINE config 5's stages at a small size: X-Trans 3-pass + denoise + exposure + tone through the C++ front end."""
+    w, h = 600, 450
+    raw = synth.xtrans_frame(w, h, seed=6, noise=2048)
+    info, ppm = run_cli(tmp_path, raw, "amaze", ("--xtrans", "3", "--denoise", "40,15"))
+    assert (info["out_width"], info["out_height"]) == (w - 14, h - 14)
+    planes = O.xtrans_demosaic(raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, 3, True)
+    img = O.get_image(planes, 7, 7, w - 14, h - 14, MUL, True)
+    img = O.convert_color_space(img, MAT)
+    curve, _ = O.noise_curve()
+    img = O.improc_denoise(img, dict(luminance=40.0, chrominance=15.0), calclum_mat=MAT, noise_c_curve=curve, smoothing=False, detail_recovery=True)
+    img = O.exposure(img, 1.0, 0.0)
+    img = O.tone_std(img, tone_lut(), 1.0, True)
+    q = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.int32) for p in img], axis=-1)
+    assert np.abs(ppm.astype(np.int32) - q).max() <= 3      # DCT detail recovery tolerance only
