@@ -202,7 +202,9 @@ __global__ void __launch_bounds__(256) shrink_sf_AB_kernel(ShrinkArgs a)
 }
 
 // ---------------------------------------------------------------- horizontal box blur (boxblur.h:565-600)
-constexpr int HB_ROWS = 64, HB_COLS = 64, HB_MAXR = 15;
+// 16 rows per wave (not 64): the running sum is serial along the row, so rows are the only parallelism; 16-row groups give
+// 10 waves per CU at 45 MP instead of 2.5 and keep ~24 loads per lane in flight (the stage is HBM-latency bound otherwise)
+constexpr int HB_ROWS = 16, HB_COLS = 64, HB_MAXR = 15;
 constexpr int HB_TW = HB_COLS + 2 * HB_MAXR + 2; // source window held in LDS
 __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
 {
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
         }
         __syncthreads();
         const int cend = min(HB_COLS, W - c0);
-        if (myrow < H) {
+        if (lane < HB_ROWS && myrow < H) {
             const float *s = &sT[lane][rad + 1]; // s[j] = src[row][c0 + j]
             if (c0 > rad && c0 + HB_COLS <= W - rad) {
                 // steady state for the whole chunk: tempval += (s[j+rad] - s[j-rad-1]) * reclen
