@@ -115,7 +115,7 @@ __device__ __forceinline__ float g_bound(float Gint, float rb, float nA, float n
 } // namespace
 
 #ifndef AMAZE_MIN_WAVES
-#define AMAZE_MIN_WAVES 4
+#define AMAZE_MIN_WAVES 3   // LDS (51 KB weight plane) allows 3 workgroups of 4 waves per CU
 #endif
 __global__ void __launch_bounds__(AMAZE_THREADS, AMAZE_MIN_WAVES)
 amaze_tiles_kernel(AmazeArgs a)
@@ -143,6 +143,8 @@ amaze_tiles_kernel(AmazeArgs a)
     const size_t rs = a.raw_stride;
 
     __shared__ int s_red[4]; // min row, max row, min col, max col of nyquist flags
+    __shared__ float s_plane[ts * tsh];   // P9 / P13: half-resolution weight plane; P8: list of flagged sites
+    __shared__ int s_count;
 
     int ex, ey;
     if (fc(filters, 0, 0) == 1) {
@@ -151,6 +153,14 @@ amaze_tiles_kernel(AmazeArgs a)
         if (fc(filters, 0, 0) == 0) { ey = 0; ex = 0; } else { ey = 1; ex = 1; }
     }
 
+    // per-barrier timestamps of workgroup 0 (build with -DARTGPU_AMAZE_PROFILE, run with ARTGPU_AMAZE_PROF=<file>): how the
+    // phase costs of profiles/r1/amaze_phase_profile.txt were measured
+#ifdef ARTGPU_AMAZE_PROFILE
+    int _pk = 0;
+#define PROF() do { if (a.prof && tid == 0 && blockIdx.x == 0 && _pk < 1000) a.prof[_pk] = wall_clock64(); ++_pk; } while (0)
+#else
+#define PROF() do { } while (0)
+#endif
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
         const int top = -16 + ty * (ts - 32), left = -16 + tx * (ts - 32);
@@ -162,12 +172,20 @@ amaze_tiles_kernel(AmazeArgs a)
 
         // ---- zero the arena (fresh-calloc semantics) ----
         {
-            float4 *A4 = reinterpret_cast<float4 *>(A);
+            constexpr int NREG = 17;
+            const int reg_off[NREG + 1] = {O_rgbgreen, O_delhvsqsum, O_dirwts0, O_dirwts1, O_vcd, O_hcd, O_vcdalt, O_hcdalt, O_cddiffsq, O_hvwt, O_dgintv,
+                                           O_dginth, O_Dgrbsq1m, O_Dgrbsq1p, O_cfa, O_nyquist, O_nyqutest, ARENA_FLOATS};
+            const unsigned zmask = (rr1 == ts && cc1 == ts) ? a.zero_mask : 0xffffffffu;   // partial tiles: everything
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int i = tid; i < AMAZE_ARENA_FLOATS / 4; i += NT) A4[i] = z;
+#pragma unroll
+            for (int r = 0; r < NREG; ++r)
+                if ((zmask >> r) & 1u) {
+                    float4 *A4 = reinterpret_cast<float4 *>(A + reg_off[r]);
+                    for (int i = tid; i < (reg_off[r + 1] - reg_off[r]) / 4; i += NT) A4[i] = z;
+                }
             if (tid == 0) { s_red[0] = 1 << 30; s_red[1] = 0; s_red[2] = ts + 1; s_red[3] = 0; }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
 
         // ---- tile initialisation (L205-334), in the reference's write order ----
 #define SETCFA(i, v) do { float t_ = (v) / 65535.f; cfa[i] = t_; rgbgreen[i] = t_; } while (0)
@@ -180,44 +198,44 @@ amaze_tiles_kernel(AmazeArgs a)
             const int n = ccmax - ccmin, nr = rrmax - rrmin;
             for (int t = tid; t < nr * n; t += NT) { int rr = rrmin + t / n, cc = ccmin + t % n; SETCFA(rr * ts + cc, RAW(rr + top, cc + left)); }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
         if (rrmax < rr1) {
             const int n = ccmax - ccmin;
             for (int t = tid; t < 16 * n; t += NT) { int rr = t / n, cc = ccmin + t - rr * n; SETCFA((rrmax + rr) * ts + cc, RAW(height - rr - 2, left + cc)); }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
         if (ccmin > 0) {
             const int nr = rrmax - rrmin;
             for (int t = tid; t < nr * 16; t += NT) { int rr = rrmin + (t >> 4), cc = t & 15; SETCFA(rr * ts + cc, RAW(rr + top, 32 - cc + left)); }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
         if (ccmax < cc1) {
             const int nr = rrmax - rrmin;
             for (int t = tid; t < nr * 16; t += NT) { int rr = rrmin + (t >> 4), cc = t & 15; SETCFA(rr * ts + ccmax + cc, RAW(top + rr, width - cc - 2)); }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
         if (tid < 256) {
             const int rr = tid >> 4, cc = tid & 15;
             if (rrmin > 0 && ccmin > 0) SETCFA(rr * ts + cc, RAW(32 - rr, 32 - cc));
         }
-        __syncthreads();
+        __syncthreads(); PROF();
         if (tid < 256) {
             const int rr = tid >> 4, cc = tid & 15;
             if (rrmax < rr1 && ccmax < cc1) SETCFA((rrmax + rr) * ts + ccmax + cc, RAW(height - rr - 2, width - cc - 2));
         }
-        __syncthreads();
+        __syncthreads(); PROF();
         if (tid < 256) {
             const int rr = tid >> 4, cc = tid & 15;
             if (rrmin > 0 && ccmax < cc1) SETCFA(rr * ts + ccmax + cc, RAW(32 - rr, width - cc - 2));
         }
-        __syncthreads();
+        __syncthreads(); PROF();
         if (tid < 256) {
             const int rr = tid >> 4, cc = tid & 15;
             if (rrmax < rr1 && ccmin > 0) SETCFA((rrmax + rr) * ts + cc, RAW(height - rr - 2, 32 - cc));
         }
 #undef SETCFA
 #undef RAW
-        __syncthreads();
+        __syncthreads(); PROF();
 
         // ---- P1: gradients (L342-351); 4-lane groups over [0, cc1) ----
         FOR_ITEMS(2, rr1 - 2, 4 * ngroups(0, cc1, 4)) {
@@ -229,7 +247,7 @@ amaze_tiles_kernel(AmazeArgs a)
             dirwts0[i] = eps + fabsf(cfa[i + v2] - c0) + fabsf(c0 - cfa[i - v2]) + delv;
             delhvsqsum[i] = sqr(delh) + sqr(delv);
         }
-        __syncthreads();
+        __syncthreads(); PROF();
 
         // ---- P2: vertical/horizontal colour differences (L380-434) ----
         FOR_ITEMS(4, rr1 - 4, 4 * ngroups(4, cc1 - 7, 4)) {
@@ -268,7 +286,7 @@ amaze_tiles_kernel(AmazeArgs a)
             dgintv[i] = sse_min(sqr(guha - gdha), sqr(guar - gdar));
             dginth[i] = sse_min(sqr(glha - grha), sqr(glar - grar));
         }
-        __syncthreads();
+        __syncthreads(); PROF();
 
         // ---- P3: variance choice + highlight bounding, in place in the reference (L540-583) ----
         const int ng3 = ngroups(4, cc1 - 4, 4);
@@ -285,7 +303,7 @@ amaze_tiles_kernel(AmazeArgs a)
             hcdv = hav < hv ? ha : hcdv;
             Thi[rr * tsh + it] = bound_cd(hcdv, sgn, cfa[i], cfa[i - 1], cfa[i + 1], clip_pt);
         }
-        __syncthreads();
+        __syncthreads(); PROF();
         // 3b: lanes 0,1 read the previous group's updated lanes 2,3 at i-2
         FOR_ITEMS(4, rr1 - 4, 2 * ng3) {
             const int g = it >> 1, k = it & 1, cc = 4 + 4 * g + k, i = rr * ts + cc;
@@ -320,7 +338,7 @@ amaze_tiles_kernel(AmazeArgs a)
                 cm1 = c0; c0 = cp1;
             }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
         // 3d: commit hcd, cddiffsq
         FOR_ITEMS(4, rr1 - 4, 4 * ng3) {
             const int g = it >> 2, k = it & 3, cc = 4 + it, i = rr * ts + cc;
@@ -328,7 +346,7 @@ amaze_tiles_kernel(AmazeArgs a)
             hcd[i] = h;
             cddiffsq[i] = sqr(vcd[i] - h);
         }
-        __syncthreads();
+        __syncthreads(); PROF();
 
         // ---- P4: h/v weight at R/B sites (L680-728) ----
         FOR_ITEMS(6, rr1 - 6, 4 * ngroups(6, cc1 - 6, 8)) {
@@ -397,7 +415,7 @@ amaze_tiles_kernel(AmazeArgs a)
                 }
             }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
 
         // ---- P6: nyquist flags + bounding box (L806-825) ----
         FOR_ITEMS(6, rr1 - 6, ngroups(6, cc1 - 6, 2)) {
@@ -413,7 +431,7 @@ amaze_tiles_kernel(AmazeArgs a)
                 }
             }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
         int nystartrow = s_red[0] == (1 << 30) ? 0 : s_red[0];
         int nyendrow = s_red[1], nystartcol = s_red[2], nyendcol = s_red[3];
         const bool doNyquist = nystartrow != nyendrow && nystartcol != nyendcol;
@@ -430,57 +448,96 @@ amaze_tiles_kernel(AmazeArgs a)
                 unsigned *w = reinterpret_cast<unsigned *>(nyquist2 + 4 * tsh);
                 for (int t = tid; t < (ts - 8) * tsh / 4; t += NT) w[t] = 0u;
             }
-            __syncthreads();
+            __syncthreads(); PROF();
             // ---- P7: majority vote with byte offsets independent of the row parity (L888-901) ----
-            FOR_ITEMS(nystartrow, nyendrow, 16 * ngroups(0, cc1, 32)) {
-                const int b = (rr * ts >> 1) + it;
-                const unsigned char *n = nyquist;
-                const int tsum = n[b - ts] + n[b - 81] + n[b - 80] + n[b - 1] + n[b + 1] + n[b + 79] + n[b + 80] + n[b + ts];
-                unsigned char val = n[b];
-                if (tsum > 4) val = 1;
-                if (tsum < 4) val = 0;
-                nyquist2[b] = val;
+            // four flags per item through aligned 32-bit accesses (byte-wise global loads/stores made this the slowest
+            // phase of the tile); per-byte logic unchanged
+            FOR_ITEMS(nystartrow, nyendrow, 4 * ngroups(0, cc1, 32)) {
+                const int b = (rr * ts >> 1) + 4 * it;
+                const unsigned *n4 = reinterpret_cast<const unsigned *>(nyquist + b);   // b and ts/2 are multiples of 4
+                const unsigned up = n4[-(ts / 4)], dn = n4[ts / 4];
+                const unsigned long long U = (unsigned long long)(n4[-21] >> 24) | ((unsigned long long)n4[-20] << 8);      // bytes b-81 .. b-77
+                const unsigned long long M = (unsigned long long)(n4[-1] >> 24) | ((unsigned long long)n4[0] << 8) | ((unsigned long long)(n4[1] & 0xffu) << 40);   // b-1 .. b+4
+                const unsigned long long D = (unsigned long long)(n4[19] >> 24) | ((unsigned long long)n4[20] << 8);        // bytes b+79 .. b+83
+                unsigned outw = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int tsum = (int)((up >> (8 * k)) & 0xff) + (int)((U >> (8 * k)) & 0xff) + (int)((U >> (8 * k + 8)) & 0xff) + (int)((M >> (8 * k)) & 0xff) +
+                                     (int)((M >> (8 * k + 16)) & 0xff) + (int)((D >> (8 * k)) & 0xff) + (int)((D >> (8 * k + 8)) & 0xff) + (int)((dn >> (8 * k)) & 0xff);
+                    unsigned val = (unsigned)((M >> (8 * k + 8)) & 0xff);
+                    if (tsum > 4) val = 1;
+                    if (tsum < 4) val = 0;
+                    outw |= val << (8 * k);
+                }
+                *reinterpret_cast<unsigned *>(nyquist2 + b) = outw;
             }
-            __syncthreads();
-            // ---- P8: area interpolation (L914-951) ----
+            __syncthreads(); PROF();
+            // ---- P8: area interpolation (L914-951).  Flagged sites are sparse: compact them into an LDS list first so
+            // that the 7x7 gather loop runs with full waves instead of once per wave that contains a flag ----
+            int *const s_list = reinterpret_cast<int *>(s_plane);
+            if (tid == 0) s_count = 0;
+            __syncthreads(); PROF();
             FOR_ITEMS(nystartrow, nyendrow, ngroups(nystartcol, nyendcol, 2)) {
                 const int cc = nystartcol + (fc(filters, rr, 2) & 1) + 2 * it;
                 const int i = rr * ts + cc;
-                if (cc < nyendcol && nyquist2[i >> 1]) {
-                    float sumcfa = 0.f, sumh = 0.f, sumv = 0.f, sumsqh = 0.f, sumsqv = 0.f, areawt = 0.f;
-                    for (int ai = -6; ai < 7; ai += 2) {
-                        int i1 = i + ai * ts - 6;
-                        for (int bj = -6; bj < 7; bj += 2, i1 += 2) {
-                            if (nyquist2[i1 >> 1]) {
-                                const float ct = cfa[i1];
-                                sumcfa += ct;
-                                sumh += (cfa[i1 - 1] + cfa[i1 + 1]);
-                                sumv += (cfa[i1 - v1] + cfa[i1 + v1]);
-                                sumsqh += sqr(ct - cfa[i1 - 1]) + sqr(ct - cfa[i1 + 1]);
-                                sumsqv += sqr(ct - cfa[i1 - v1]) + sqr(ct - cfa[i1 + v1]);
-                                areawt += 1.f;
-                            }
+                if (cc < nyendcol && nyquist2[i >> 1]) s_list[atomicAdd(&s_count, 1)] = i;   // at most (ts-16)*(ts-16)/2 entries
+            }
+            __syncthreads(); PROF();
+            for (int q = tid, nq = s_count; q < nq; q += NT) {
+                const int i = s_list[q];
+                float sumcfa = 0.f, sumh = 0.f, sumv = 0.f, sumsqh = 0.f, sumsqv = 0.f, areawt = 0.f;
+                for (int ai = -6; ai < 7; ai += 2) {
+                    int i1 = i + ai * ts - 6;
+                    for (int bj = -6; bj < 7; bj += 2, i1 += 2) {
+                        if (nyquist2[i1 >> 1]) {
+                            const float ct = cfa[i1];
+                            sumcfa += ct;
+                            sumh += (cfa[i1 - 1] + cfa[i1 + 1]);
+                            sumv += (cfa[i1 - v1] + cfa[i1 + v1]);
+                            sumsqh += sqr(ct - cfa[i1 - 1]) + sqr(ct - cfa[i1 + 1]);
+                            sumsqv += sqr(ct - cfa[i1 - v1]) + sqr(ct - cfa[i1 + v1]);
+                            areawt += 1.f;
                         }
                     }
-                    sumh = sumcfa - xdiv2f(sumh);
-                    sumv = sumcfa - xdiv2f(sumv);
-                    areawt = xdiv2f(areawt);
-                    const float hcdvar = epssq + fabsf(areawt * sumsqh - sumh * sumh);
-                    const float vcdvar = epssq + fabsf(areawt * sumsqv - sumv * sumv);
-                    hvwt[i >> 1] = hcdvar / (vcdvar + hcdvar);
                 }
+                sumh = sumcfa - xdiv2f(sumh);
+                sumv = sumcfa - xdiv2f(sumv);
+                areawt = xdiv2f(areawt);
+                const float hcdvar = epssq + fabsf(areawt * sumsqh - sumh * sumh);
+                const float vcdvar = epssq + fabsf(areawt * sumsqv - sumv * sumv);
+                hvwt[i >> 1] = hcdvar / (vcdvar + hcdvar);
             }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
 
         // ---- P9: hvwt refined in place, row by row; G at R/B sites (L957-974) ----
-        for (int rr = 8; rr < rr1 - 8; ++rr) {
-            const int cc = 8 + (fc(filters, rr, 2) & 1) + 2 * tid;
+        // The row recurrence only involves hvwt (row rr reads the updated row rr-1 and the old row rr+1): the half-resolution
+        // plane is staged in LDS, ONE wave walks the rows with wave-level ordering only (no workgroup barrier per row), and
+        // everything that merely consumes the refined weight runs afterwards as a parallel pass.
+        for (int t = tid; t < ts * tsh; t += NT) s_plane[t] = hvwt[t];
+        __syncthreads(); PROF();
+        if (tid < 64) {
+            for (int rr = 8; rr < rr1 - 8; ++rr) {
+                const int par = fc(filters, rr, 2) & 1;
+                for (int j = tid; j < 72; j += 64) {
+                    const int cc = 8 + par + 2 * j;
+                    if (cc < cc1 - 8) {
+                        const int i = rr * ts + cc;
+                        const float hvwtalt = xdivf(s_plane[(i - m1) >> 1] + s_plane[(i + p1) >> 1] + s_plane[(i - p1) >> 1] + s_plane[(i + m1) >> 1], 2);
+                        const float h0 = s_plane[i >> 1];
+                        s_plane[i >> 1] = fabsf(0.5f - h0) < fabsf(0.5f - hvwtalt) ? hvwtalt : h0;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads(); PROF();
+        FOR_ITEMS(8, rr1 - 8, 72) {
+            const int cc = 8 + (fc(filters, rr, 2) & 1) + 2 * it;
             if (cc < cc1 - 8) {
                 const int i = rr * ts + cc;
-                const float hvwtalt = xdivf(hvwt[(i - m1) >> 1] + hvwt[(i + p1) >> 1] + hvwt[(i - p1) >> 1] + hvwt[(i + m1) >> 1], 2);
-                const float h0 = hvwt[i >> 1];
-                const float h = fabsf(0.5f - h0) < fabsf(0.5f - hvwtalt) ? hvwtalt : h0;
+                const float h = s_plane[i >> 1];
                 hvwt[i >> 1] = h;
                 const float dg = intp(h, vcd[i], hcd[i]);
                 Dgrb0[i >> 1] = dg;
@@ -490,8 +547,8 @@ amaze_tiles_kernel(AmazeArgs a)
                 Dgrb2[2 * (i >> 1)] = ny ? sqr(gval - xdiv2f(rgbgreen[i - 1] + rgbgreen[i + 1])) : 0.f;
                 Dgrb2[2 * (i >> 1) + 1] = ny ? sqr(gval - xdiv2f(rgbgreen[i - v1] + rgbgreen[i + v1])) : 0.f;
             }
-            __syncthreads();
         }
+        __syncthreads(); PROF();
 
         // ---- P10: refine nyquist areas with the G curvature (L979-999) ----
         if (doNyquist) {
@@ -520,7 +577,7 @@ amaze_tiles_kernel(AmazeArgs a)
                 }
             }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
 
         // ---- P11: diagonal gradients (L1004-1027); delp/delm overwrite cddiffsq/nyquist2 ----
         FOR_ITEMS(6, rr1 - 6, 4 * ngroups(6, cc1 - 6, 8)) {
@@ -536,7 +593,7 @@ amaze_tiles_kernel(AmazeArgs a)
             Dgrbsq1m[i >> 1] = sm;
             Dgrbsq1p[i >> 1] = sp;
         }
-        __syncthreads();
+        __syncthreads(); PROF();
 
         // ---- P12: diagonal interpolation of R+B and plus/minus weight (L1061-1121) ----
         FOR_ITEMS(8, rr1 - 8, 4 * ngroups(8, cc1 - 8, 8)) {
@@ -572,21 +629,36 @@ amaze_tiles_kernel(AmazeArgs a)
                 pmwt[i1] = rbvarm / (rbvarp + rbvarm);
             }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
 
-        // ---- P13: pmwt refined in place row by row, rbint (L1213-1223) ----
-        for (int rr = 10; rr < rr1 - 10; ++rr) {
+        // ---- P13: pmwt refined in place row by row, rbint (L1213-1223); same scheme as P9 ----
+        for (int t = tid; t < ts * tsh; t += NT) s_plane[t] = pmwt[t];
+        __syncthreads(); PROF();
+        if (tid < 64) {
+            for (int rr = 10; rr < rr1 - 10; ++rr) {
+                const int par = fc(filters, rr, 2) & 1;
+                const int nit = 4 * ngroups(10 + par, cc1 - 10, 8);
+                for (int j = tid; j < nit; j += 64) {
+                    const int i = rr * ts + 10 + par + 2 * j, i1 = i >> 1;
+                    const float alt = 0.25f * (s_plane[(i - m1) >> 1] + s_plane[(i + p1) >> 1] + s_plane[(i - p1) >> 1] + s_plane[(i + m1) >> 1]);
+                    const float t = s_plane[i1];
+                    s_plane[i1] = fabsf(0.5f - t) < fabsf(0.5f - alt) ? alt : t;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads(); PROF();
+        FOR_ITEMS(10, rr1 - 10, 72) {
             const int par = fc(filters, rr, 2) & 1;
-            if (tid < 4 * ngroups(10 + par, cc1 - 10, 8)) {
-                const int i = rr * ts + 10 + par + 2 * tid, i1 = i >> 1;
-                const float alt = 0.25f * (pmwt[(i - m1) >> 1] + pmwt[(i + p1) >> 1] + pmwt[(i - p1) >> 1] + pmwt[(i + m1) >> 1]);
-                float t = pmwt[i1];
-                t = fabsf(0.5f - t) < fabsf(0.5f - alt) ? alt : t;
+            if (it < 4 * ngroups(10 + par, cc1 - 10, 8)) {
+                const int i = rr * ts + 10 + par + 2 * it, i1 = i >> 1;
+                const float t = s_plane[i1];
                 pmwt[i1] = t;
                 rbint[i1] = 0.5f * (cfa[i] + intp(t, rbp[i1], rbm[i1]));
             }
-            __syncthreads();
         }
+        __syncthreads(); PROF();
 
         // ---- P14: G re-interpolated from R+B where the diagonal weight is more decisive (L1241-1297) ----
         FOR_ITEMS(12, rr1 - 12, 4 * ngroups(12, cc1 - 12, 8)) {
@@ -613,7 +685,7 @@ amaze_tiles_kernel(AmazeArgs a)
                 }
             }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
 
         // ---- P15: split G-B out of G-R on the B rows (L1381-1386) ----
         {
@@ -628,7 +700,7 @@ amaze_tiles_kernel(AmazeArgs a)
                 }
             }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
 
         // ---- P16: chrominance at the opposite-colour sites (L1394-1408) ----
         FOR_ITEMS(14, rr1 - 14, 4 * ngroups(14, cc1 - 14, 8)) {
@@ -656,7 +728,7 @@ amaze_tiles_kernel(AmazeArgs a)
                 D[i >> 1] = val;
             }
         }
-        __syncthreads();
+        __syncthreads(); PROF();
 
         // ---- P17/P18: write R, G, B for [16,rr1-16) x [16,cc1-16) (L1441-1565) ----
         FOR_ITEMS(16, rr1 - 16, cc1 - 32 > 0 ? cc1 - 32 : 0) {
@@ -677,7 +749,7 @@ amaze_tiles_kernel(AmazeArgs a)
             a.blue[o] = sse_max(65535.f * b, 0.f);
             a.green[o] = sse_max(gval * 65535.f, 0.f);
         }
-        __syncthreads();
+        __syncthreads(); PROF();
     }
 }
 

@@ -26,6 +26,8 @@ struct AmazeArgs {
     int ntx, ntiles;
     unsigned filters;
     float clip_pt, clip_pt8;
+    long long *prof;
+    unsigned zero_mask;
 };
 __global__ void amaze_tiles_kernel(AmazeArgs a);
 hipError_t launch_amaze(const AmazeArgs &a, int grid, hipStream_t stream);

@@ -77,3 +77,18 @@ def test_errors(gpu_ctx):
         gpu_ctx.demosaic_bayer_host(7, raw, synth.FILTERS_RGGB)          # unknown method
     with pytest.raises(capi.ArtGpuError):
         gpu_ctx.demosaic_bayer_host(capi.BAYER_RCD, raw, 0xFFFFFFFF)     # 4-colour CFA
+
+
+def test_amaze_selective_arena_clear_is_exact(gpu_ctx, monkeypatch):
+    """Only six of the 17 arena regions are cleared per full tile (artgpu_api.hip: zero_mask).  With the arenas pre-filled
+    with different byte patterns the result must not move: no other region is read before it is written."""
+    from art_amd import capi
+    w, h, filt = 1152, 896, synth.FILTERS_RGGB
+    raw = synth.bayer_frame(w, h, filt, seed=21, noise=3000)
+    ref = oracle_lib.amaze(raw, filt, 1.0, 4)
+    for pattern in ("0xFF", "0x7F", "0xC0"):
+        monkeypatch.setenv("ARTGPU_AMAZE_POISON", pattern)
+        out = [np.zeros((h, w), np.float32) for _ in range(3)]
+        gpu_ctx.demosaic_bayer(capi.BAYER_AMAZE, capi.host_plane(raw), filt, 1.0, 4, capi.host_rgb(out))
+        for o, r in zip(out, ref):
+            assert np.array_equal(o.view(np.uint32), r.view(np.uint32))
