@@ -115,7 +115,7 @@ __device__ __forceinline__ float g_bound(float Gint, float rb, float nA, float n
 } // namespace
 
 #ifndef AMAZE_MIN_WAVES
-#define AMAZE_MIN_WAVES 3   // LDS (51 KB weight plane) allows 3 workgroups of 4 waves per CU
+#define AMAZE_MIN_WAVES 6   // 512 threads x 3 workgroups per CU (51 KB LDS plane each) = 6 waves per SIMD: <= 80 VGPRs (some spill); measured best of {256,384,512,640,768,1024} x {3..8}
 #endif
 __global__ void __launch_bounds__(AMAZE_THREADS, AMAZE_MIN_WAVES)
 amaze_tiles_kernel(AmazeArgs a)

@@ -9,7 +9,7 @@ namespace artgpu {
 
 // ---- AMaZE (amaze.hip) ----
 #ifndef ARTGPU_AMAZE_THREADS
-#define ARTGPU_AMAZE_THREADS 256
+#define ARTGPU_AMAZE_THREADS 512
 #endif
 constexpr int AMAZE_THREADS = ARTGPU_AMAZE_THREADS;
 constexpr int AMAZE_ARENA_FLOATS = 362208; // 1 448 832 B per workgroup (reference: 1 448 767 B, amaze_demosaic_RT.cc:124)
