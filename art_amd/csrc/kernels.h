@@ -53,7 +53,9 @@ hipError_t launch_rcd(const RcdArgs &a, int grid, hipStream_t stream);
 
 // ---- X-Trans Markesteijn demosaic (xtrans.hip) ----
 #define XTRANS_TS 114
-#define XTRANS_THREADS 256
+#ifndef XTRANS_THREADS
+#define XTRANS_THREADS 1024   // measured: {256,512,1024} x min-waves {4,6,8}: 1024 x 8 is the fastest (65.8 vs 69.0 ms at 100 MP)
+#endif
 struct XtransArgs {
     const float *raw; size_t raw_stride;
     float *red, *green, *blue; size_t out_stride;

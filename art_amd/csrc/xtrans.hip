@@ -46,7 +46,10 @@ __device__ __forceinline__ float cbrt_lut(const float *__restrict__ lut, int i) 
 
 #define FOR_T(N) for (int t = tid, _n = (N); t < _n; t += NT)
 
-__global__ void __launch_bounds__(XTRANS_THREADS) xtrans_tiles_kernel(XtransArgs a)
+#ifndef XTRANS_MIN_WAVES
+#define XTRANS_MIN_WAVES 8
+#endif
+__global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles_kernel(XtransArgs a)
 {
     const int tid = threadIdx.x;
     const Geo G{a};
