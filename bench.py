@@ -156,6 +156,16 @@ def main() -> None:
     kern_ms = statistics.mean(kernel_ms)
     achieved = (W * H * ALGO_BYTES_PER_PX / 1e9) / (kern_ms / 1e3)
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the figure is the mean per
+    # launch of the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command, committed under
+    # profiles/ (KB units; uncorrected -- the kernel's accesses are 4 B per lane, see profiles/r1/README.md)
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r1", "amaze_v15_pmc_summary.json")
+    if method == capi.BAYER_AMAZE and not xtrans and (W, H) == (W45, H45) and os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        traffic = int((pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+        traffic_src = "profiles/r1/amaze_v15_pmc_summary.json"
+
     result = {
         "metric": ("megapixels/sec end-to-end (X-Trans+FTblockDN+tone), 100 MP X-Trans" if xtrans else
                    "megapixels/sec end-to-end (AMaZE+FTblockDN+tone), 45 MP Bayer"),
@@ -184,7 +194,7 @@ def main() -> None:
         "roofline": {
             "bound": "hbm", "kernel": "xtrans_tiles_kernel" if xtrans else "amaze_tiles_kernel" if method == capi.BAYER_AMAZE else "rcd_tiles_kernel",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": W * H * ALGO_BYTES_PER_PX,
         },
     }
