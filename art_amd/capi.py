@@ -204,10 +204,14 @@ class Context:
         self._chk(LIB.artgpu_tone_curve(self._h, C.byref(image), mode, lp, whitept, int(filmlike_clip)))
 
     def rgb_denoise(self, image: RGB, params: DenoiseParams, ws, expcomp: float = 0.0, scale: float = 1.0,
-                    ccalc: Plane = None, flags: int = DN_SKIP_DETAIL_RECOVERY):
+                    ccalc: Plane = None, flags: int = DN_SKIP_DETAIL_RECOVERY, want_resid: bool = False):
         wsf = (C.c_float * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float32).reshape(9)])
+        nresi, highresi = C.c_float(0), C.c_float(0)
         self._chk(LIB.artgpu_rgb_denoise(self._h, C.byref(image), C.byref(params), wsf, expcomp, scale,
-                                         None if ccalc is None else C.byref(ccalc), flags, None, None))
+                                         None if ccalc is None else C.byref(ccalc), flags,
+                                         C.byref(nresi) if want_resid else None, C.byref(highresi) if want_resid else None))
+        if want_resid:
+            return float(nresi.value), float(highresi.value)
 
     def denoise_guided_smoothing(self, image: RGB, ws, radius: int = 3, scale: float = 1.0):
         m = (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)])

@@ -696,7 +696,6 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     if (p->color_space != 0) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: LAB colour space is not on the device path");
     const bool do_detail = !(flags & ARTGPU_DN_SKIP_DETAIL_RECOVERY);
     if (do_detail && p->luminance_detail_threshold > 0) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: luminanceDetailThreshold > 0 (detail_mask) is not on the device path yet");
-    if (nresi || highresi) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: nresi/highresi (Noise_residualAB) not on the device path yet");
     if (!(scale >= 1.0)) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: scale must be >= 1");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     DevRGB d;
@@ -787,6 +786,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     for (int l = 0; l < levwav; ++l) { const int r = int((l + 2) / scale); bl.rad[l] = r > 1 ? r : 1; }
 
     // ---- a then b: decompose, shrink against L, reconstruct (L2328-2402)
+    float chresidtemp = 0.f, chmaxresidtemp = 0.f;
     for (int ch = 0; ch < 2; ++ch) {
         float *plane = ch == 0 ? A : B;
         float noisevar_ab = ch == 0 ? noisevarab_r : noisevarab_b;
@@ -802,6 +802,25 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
             HIPCHK(ctx, launch_hblur(bl, nsub, ctx->stream));
             bl.src = tmp; bl.sfave = sf; bl.coef = Cd.bands;
             HIPCHK(ctx, launch_vblur_combine(bl, nsub, ctx->stream));
+        }
+        if (nresi || highresi) {
+            // Noise_residualAB (FTblockDN.cc:605-635, kall == 0): SQR(MadRgb) of the shrunk chroma bands, summed in level/dir order
+            float host[32];
+            HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, madab, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(host, madab, (size_t)nsub * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            float resid = 0.f, maxresid = 0.f;
+            for (int k = 0; k < nsub; ++k) {
+                resid += host[k];
+                if (host[k] > maxresid) maxresid = host[k];
+            }
+            if (ch == 0) { chresidtemp = resid; chmaxresidtemp = maxresid; }
+            else {
+                float chresid = resid + chresidtemp, chmaxresid = maxresid + chmaxresidtemp;      // L2389-2396
+                chresid = std::sqrt(chresid / (6 * (levwav)));
+                if (highresi) *highresi = chresid + 0.66f * (std::sqrt(chmaxresid) - chresid);
+                if (nresi) *nresi = chresid;
+            }
         }
         if ((rc = reconstruct_dev(ctx, Cd, plane))) return rc;
     }

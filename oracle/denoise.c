@@ -229,8 +229,17 @@ static inline float gammaf_s(float x, float gamma, float start, float slope)
     return x <= start ? x * slope : oracle_xexpf_s(oracle_xlogf_s(x) / gamma);
 }
 
+int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, const oracle_denoise_params *p,
+                          const float wpi[9], const float *noisevarchrom_in, float *Lin_out, float *Lden_out, int detail_recovery, float *resid_out);
 int oracle_rgb_denoise(float *const img[3], size_t stride, int w, int h, const oracle_denoise_params *p,
                        const float wpi[9], const float *noisevarchrom_in, float *Lin_out, float *Lden_out, int detail_recovery)
+{
+    return oracle_rgb_denoise_ex(img, stride, w, h, p, wpi, noisevarchrom_in, Lin_out, Lden_out, detail_recovery, NULL);
+}
+
+/* resid_out (nullable): {nresi, highresi} of Noise_residualAB (FTblockDN.cc:605-635, 2389-2396) */
+int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, const oracle_denoise_params *p,
+                          const float wpi[9], const float *noisevarchrom_in, float *Lin_out, float *Lden_out, int detail_recovery, float *resid_out)
 {
     const double scale = p->scale > 0 ? p->scale : 1.0;
     const float noiseluma = (float)p->luminance;
@@ -308,6 +317,7 @@ int oracle_rgb_denoise(float *const img[3], size_t stride, int w, int h, const o
     for (int lvl = 0; lvl < levwav; ++lvl)
         for (int dir = 1; dir < 4; ++dir) madL[lvl][dir - 1] = sqrf(oracle_madrgb(Ldecomp->band[lvl][dir], (int)n2));
 
+    float chresidtemp = 0.f, chmaxresidtemp = 0.f;
     for (int ch = 0; ch < 2; ++ch) {
         float *plane = ch == 0 ? laba : labb;
         oracle_wavelet *d = oracle_wavelet_decompose(plane, w, h, levwav);
@@ -315,6 +325,22 @@ int oracle_rgb_denoise(float *const img[3], size_t stride, int w, int h, const o
         for (int lvl = 0; lvl < levwav; ++lvl)
             for (int dir = 1; dir < 4; ++dir)
                 oracle_shrink_all_AB(Ldecomp, d, lvl, dir, noisevarchrom, ch == 0 ? noisevarab_r : noisevarab_b, useNoiseCCurve, p->autoch, madL[lvl], scale);
+        if (resid_out) {
+            float resid = 0.f, maxresid = 0.f;
+            for (int lvl = 0; lvl < levwav; ++lvl)
+                for (int dir = 1; dir < 4; ++dir) {
+                    const float madC = sqrf(oracle_madrgb(d->band[lvl][dir], (int)n2));
+                    resid += madC;
+                    if (madC > maxresid) maxresid = madC;
+                }
+            if (ch == 0) { chresidtemp = resid; chmaxresidtemp = maxresid; }
+            else {
+                float chresid = resid + chresidtemp, chmaxresid = maxresid + chmaxresidtemp;
+                chresid = sqrtf(chresid / (6 * (levwav)));
+                resid_out[1] = chresid + 0.66f * (sqrtf(chmaxresid) - chresid);
+                resid_out[0] = chresid;
+            }
+        }
         oracle_wavelet_reconstruct(d, plane, 1.f);
         oracle_wavelet_free(d);
     }

@@ -174,7 +174,7 @@ REC2020_WS = np.array([[0.6734241, 0.1656411, 0.1251286],
                        [-0.0019300, 0.0299784, 0.7973330]], dtype=np.float32)
 
 
-def rgb_denoise(img, params=None, wpi=REC2020_WS, noisevarchrom=None, want_L=False, detail_recovery=False):
+def rgb_denoise(img, params=None, wpi=REC2020_WS, noisevarchrom=None, want_L=False, detail_recovery=False, want_resid=False):
     img = [np.array(p, dtype=np.float32, order="C") for p in img]
     h, w = img[0].shape
     params = params or default_denoise_params()
@@ -182,9 +182,13 @@ def rgb_denoise(img, params=None, wpi=REC2020_WS, noisevarchrom=None, want_L=Fal
     nvc = None if noisevarchrom is None else _ptr(np.ascontiguousarray(noisevarchrom, dtype=np.float32))
     Lin = np.zeros((h, w), np.float32) if want_L else None
     Lden = np.zeros((h, w), np.float32) if want_L else None
-    rc = lib().oracle_rgb_denoise(_p3(img), C.c_size_t(w), w, h, C.byref(params), _ptr(wp), nvc,
-                                  _ptr(Lin) if want_L else None, _ptr(Lden) if want_L else None, int(detail_recovery))
+    resid = np.zeros(2, np.float32)
+    rc = lib().oracle_rgb_denoise_ex(_p3(img), C.c_size_t(w), w, h, C.byref(params), _ptr(wp), nvc,
+                                     _ptr(Lin) if want_L else None, _ptr(Lden) if want_L else None, int(detail_recovery),
+                                     _ptr(resid) if want_resid else None)
     assert rc == 0
+    if want_resid:
+        return img, float(resid[0]), float(resid[1])
     return (img, Lin, Lden) if want_L else img
 
 

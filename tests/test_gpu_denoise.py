@@ -125,3 +125,17 @@ def test_improc_denoise_with_noise_curve_bit_exact(gpu_ctx):
     gpu_ctx.improc_denoise(capi.host_rgb(got), tp, O.REC2020_WS_D, ecomp=0.3, calclum_mat=mat, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
     for g, r in zip(got, ref):
         assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+
+
+def test_noise_residuals_match_oracle(gpu_ctx):
+    """nresi / highresi of RGB_denoise (Noise_residualAB, FTblockDN.cc:605-635,2389-2396): exact integer-histogram medians"""
+    w, h = 360, 264
+    raw = synth.bayer_frame(w, h, synth.FILTERS_RGGB, seed=8, noise=2500)
+    img = O.amaze(raw, synth.FILTERS_RGGB, 1.0, 4)
+    got = [p.copy() for p in img]
+    nresi, highresi = gpu_ctx.rgb_denoise(capi.host_rgb(got), capi.DenoiseParams(40.0, 50.0, 0, 15.0, 0.0, 0.0, 1.7, 0, 0, 0), O.REC2020_WS,
+                                          want_resid=True)
+    ref, rn, rh = O.rgb_denoise(img, O.default_denoise_params(), want_resid=True)
+    assert np.float32(nresi) == np.float32(rn) and np.float32(highresi) == np.float32(rh) and rn > 0
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
