@@ -692,7 +692,6 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
 {
     if (!ctx) return ARTGPU_EINVAL;
     if (!img || !p || !ws) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: null argument");
-    if (p->aggressive) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: aggressive (QUALITY_HIGH) mode is not on the device path");
     if (p->color_space != 0) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: LAB colour space is not on the device path");
     const bool do_detail = !(flags & ARTGPU_DN_SKIP_DETAIL_RECOVERY);
     if (do_detail && p->luminance_detail_threshold > 0) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: luminanceDetailThreshold > 0 (detail_mask) is not on the device path yet");
@@ -729,6 +728,8 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     int levwav = 5;
     const float maxreal = realred > realblue ? realred : realblue;
     if (maxreal < 8.f) levwav = 5; else if (maxreal < 10.f) levwav = 6; else if (maxreal < 15.f) levwav = 7; else levwav = 8;
+    const bool aggressive = p->aggressive != 0;          // QUALITY_HIGH (L1671)
+    if (aggressive) levwav += 2;                         // L2260-2262
     if (levwav > 8) levwav = 8;
     { const int t = int(levwav - std::ceil(std::log(scale))); levwav = t > 5 ? t : 5; }
     const int minsizetile = w < h ? w : h;
@@ -774,7 +775,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     px.gain = gain; px.newGain = 1.f / gain;
     px.gam = gam; px.gamthresh = gamthresh; px.gamslope = gamslope; px.igam = igam; px.igamthresh = igamthresh; px.igamslope = igamslope;
     px.gamcurve = gamlut; px.igamcurve = gamlut + 65536;
-    px.realred = realred; px.realblue = realblue; px.qhighFactor = 1.0f;
+    px.realred = realred; px.realblue = realblue; px.qhighFactor = aggressive ? 1.f / static_cast<float>(0.9) : 1.0f;   // L1672
     HIPCHK(ctx, launch_rgb2yuv(px, ctx->stream));
 
     // ---- L decomposition and its MADs (L2296-2320)
@@ -792,6 +793,26 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         float noisevar_ab = ch == 0 ? noisevarab_r : noisevarab_b;
         if (autoch && noisevar_ab <= 0.001f) noisevar_ab = 0.02f;
         if ((rc = decompose_dev(ctx, Cd, plane))) return rc;
+        if (aggressive && noisevar_ab > 0.001f) {
+            // WaveletDenoiseAll_BiShrinkAB (L976-1108): MAD of all untouched bands, ShrinkAllAB on the top level (same MAD),
+            // point-wise shrink of the levels below
+            HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, madab, ctx->stream));
+            ShrinkArgs sa = {};
+            sa.n = n2; sa.noisevar = ccalc_dev; sa.noisevar_scale = maxNoiseVarab; sa.noisevar_ab = noisevar_ab; sa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
+            const size_t top = (size_t)(nsub - 3) * n2;
+            sa.coef = Cd.bands + top; sa.coefL = Ld.bands + top; sa.sfave = sf; sa.madL = madL + (nsub - 3); sa.madab = madab + (nsub - 3);
+            HIPCHK(ctx, launch_shrink_sf(sa, 3, true, ctx->stream));
+            BlurArgs bt = bl;
+            bt.level0 = levwav - 1;
+            bt.src = sf; bt.dst = tmp;
+            HIPCHK(ctx, launch_hblur(bt, 3, ctx->stream));
+            bt.src = tmp; bt.sfave = sf; bt.coef = Cd.bands + top;
+            HIPCHK(ctx, launch_vblur_combine(bt, 3, ctx->stream));
+            if (nsub > 3) {
+                sa.coef = Cd.bands; sa.coefL = Ld.bands; sa.madL = madL; sa.madab = madab;
+                HIPCHK(ctx, launch_bishrink_AB(sa, nsub - 3, ctx->stream));
+            }
+        }
         if (noisevar_ab > 0.001f) {
             HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, madab, ctx->stream));
             ShrinkArgs sa = {};
@@ -830,11 +851,15 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         const int nsubL = 3 * (levwav < 5 ? levwav : 5);
         ShrinkArgs sa = {};
         sa.coef = Ld.bands; sa.sfave = sf; sa.n = n2; sa.madL = madL; sa.noisevar = nullptr; sa.noisevar_const = noisevarL;
-        HIPCHK(ctx, launch_shrink_sf(sa, nsubL, false, ctx->stream));
-        bl.src = sf; bl.dst = tmp;
-        HIPCHK(ctx, launch_hblur(bl, nsubL, ctx->stream));
-        bl.src = tmp; bl.sfave = sf; bl.coef = Ld.bands;
-        HIPCHK(ctx, launch_vblur_combine(bl, nsubL, ctx->stream));
+        // QUALITY_HIGH runs WaveletDenoiseAll_BiShrinkL first (L842-973); its per-band body is ShrinkAllL's (top level included),
+        // and madL is not recomputed in between (L2408-2421): the standard pass simply runs twice
+        for (int rep = aggressive ? 0 : 1; rep < 2; ++rep) {
+            HIPCHK(ctx, launch_shrink_sf(sa, nsubL, false, ctx->stream));
+            bl.src = sf; bl.dst = tmp;
+            HIPCHK(ctx, launch_hblur(bl, nsubL, ctx->stream));
+            bl.src = tmp; bl.sfave = sf; bl.coef = Ld.bands;
+            HIPCHK(ctx, launch_vblur_combine(bl, nsubL, ctx->stream));
+        }
         float *Lin = nullptr;
         if (do_detail) {
             // copy labdn->L to Lin before it gets modified by reconstruction (L2423-2432)

@@ -201,6 +201,33 @@ __global__ void __launch_bounds__(256) shrink_sf_AB_kernel(ShrinkArgs a)
     }
 }
 
+// WaveletDenoiseAll_BiShrinkAB, levels below the top one (FTblockDN.cc:1049-1090): point-wise shrink in place, no box blur.
+// blockIdx.y = band; a.madab already holds SQR(MadRgb) of the untouched bands.
+__global__ void __launch_bounds__(256) bishrink_AB_kernel(ShrinkArgs a)
+{
+    const int sub = blockIdx.y;
+    float *c = a.coef + (size_t)sub * a.n;
+    const float *cL = a.coefL + (size_t)sub * a.n;
+    const float mad_Lr = a.madL[sub];
+    const float mab = a.madab[sub];
+    const float mad_abr = a.useNoiseCCurve ? a.noisevar_ab * mab : sqr(a.noisevar_ab) * mab;
+    const float rmad_Lm9 = 1.f / (mad_Lr * 9.f);
+    const size_t nv4 = (a.n / 4) * 4;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        const float nvc = a.noisevar ? a.noisevar_scale * a.noisevar[i] : 1.f;
+        const float tempab = c[i];
+        const float mag_ab = sqr(tempab);
+        if (i < nv4) {
+            const float mad_abv = nvc * mad_abr;
+            const float mag_L = sqr(cL[i]) * rmad_Lm9;
+            c[i] = tempab * sqr(1.f - xexpf_v(-(mag_ab / mad_abv) - (mag_L)));
+        } else {
+            const float mag_L = sqr(cL[i]);
+            c[i] = tempab * sqr(1.f - xexpf_s(-(mag_ab / (nvc * mad_abr)) - (mag_L / (9.f * mad_Lr))));
+        }
+    }
+}
+
 // ---------------------------------------------------------------- horizontal box blur (boxblur.h:565-600)
 // 16 rows per wave (not 64): the running sum is serial along the row, so rows are the only parallelism; 16-row groups give
 // 10 waves per CU at 45 MP instead of 2.5 and keep ~24 loads per lane in flight (the stage is HBM-latency bound otherwise)
@@ -210,7 +237,7 @@ __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
 {
     __shared__ float sT[HB_ROWS][HB_TW + 1];
     __shared__ float oT[HB_ROWS][HB_COLS + 1];
-    const int sub = blockIdx.y, level = sub / 3;
+    const int sub = blockIdx.y, level = a.level0 + sub / 3;
     const int rad = a.rad[level];
     const int W = a.w, H = a.h;
     const float *src = a.src + (size_t)sub * a.n;
@@ -298,7 +325,7 @@ __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
 // ---------------------------------------------------------------- vertical box blur + coefficient update (boxblur.h:602-742)
 __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
 {
-    const int sub = blockIdx.y, level = sub / 3;
+    const int sub = blockIdx.y, level = a.level0 + sub / 3;
     const int rad = a.rad[level];
     const int W = a.w, H = a.h;
     const float *t = a.src + (size_t)sub * a.n;   // horizontally blurred
@@ -413,6 +440,11 @@ hipError_t launch_shrink_sf(const ShrinkArgs &a, int nsub, bool ab, hipStream_t 
     dim3 grid(flat_grid((long long)a.n, 1024), nsub);
     if (ab) hipLaunchKernelGGL(shrink_sf_AB_kernel, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(shrink_sf_L_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_bishrink_AB(const ShrinkArgs &a, int nsub, hipStream_t s)
+{
+    hipLaunchKernelGGL(bishrink_AB_kernel, dim3(flat_grid((long long)a.n, 1024), nsub), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_hblur(const BlurArgs &a, int nsub, hipStream_t s)

@@ -184,10 +184,12 @@ struct BlurArgs {
     int rad[10];            // blur radius per level
     int steady_div;         // hblur: steady state divides by len (boxblur.h:318 variant) instead of multiplying by 1/len
     int plain;              // vblur: store the blurred value to dst (all columns take the vector form); no coefficient update
+    int level0;             // level of the first band passed (blockIdx.y = 0)
 };
 hipError_t launch_gamma_lut(float *lut, float gamma, float start, float slope, float divisor, float factor, hipStream_t s);
 hipError_t launch_rgb2yuv(const DnPixArgs &a, hipStream_t s);
 hipError_t launch_yuv2rgb(const DnPixArgs &a, hipStream_t s);
+hipError_t launch_bishrink_AB(const ShrinkArgs &a, int nsub, hipStream_t s);
 hipError_t launch_mad(const float *bands, size_t n, int nsub, int *histo, float *out, hipStream_t s);
 hipError_t launch_shrink_sf(const ShrinkArgs &a, int nsub, bool ab, hipStream_t s);
 hipError_t launch_hblur(const BlurArgs &a, int nsub, hipStream_t s);

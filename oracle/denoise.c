@@ -192,6 +192,47 @@ void oracle_shrink_all_AB(const oracle_wavelet *L, oracle_wavelet *ab, int level
     free(sfave);
 }
 
+/* WaveletDenoiseAll_BiShrinkAB (FTblockDN.cc:976-1108): MAD of every band first; the top level goes through ShrinkAllAB with
+ * that (identical) MAD, the lower levels get a point-wise shrink without the box blur */
+void oracle_bishrink_AB(const oracle_wavelet *L, oracle_wavelet *ab, const float *noisevarchrom, float noisevar_ab, int useNoiseCCurve,
+                        int autoch, float madL[8][3], double scale)
+{
+    const int maxlvl = L->nlevels;
+    if (autoch && noisevar_ab <= 0.001f) noisevar_ab = 0.02f;
+    float madab[8][3];
+    const int N = ab->w2 * ab->h2, nv4 = (N / 4) * 4;
+    for (int lvl = 0; lvl < maxlvl; ++lvl)
+        for (int dir = 1; dir < 4; ++dir) madab[lvl][dir - 1] = sqrf(oracle_madrgb(ab->band[lvl][dir], N));
+    for (int lvl = maxlvl - 1; lvl >= 0; lvl--)
+        for (int dir = 1; dir < 4; ++dir) {
+            if (lvl == maxlvl - 1) {
+                oracle_shrink_all_AB(L, ab, lvl, dir, noisevarchrom, noisevar_ab, useNoiseCCurve, autoch, madL[lvl], scale);
+            } else {
+                const float mad_Lr = madL[lvl][dir - 1];
+                const float mad_abr = useNoiseCCurve ? noisevar_ab * madab[lvl][dir - 1] : sqrf(noisevar_ab) * madab[lvl][dir - 1];
+                if (noisevar_ab > 0.001f) {
+                    const float *cL = L->band[lvl][dir];
+                    float *c = ab->band[lvl][dir];
+                    const float rmad_Lm9 = 1.f / (mad_Lr * 9.f);
+#pragma omp parallel for
+                    for (int i = 0; i < N; ++i) {
+                        if (i < nv4) {
+                            const float mad_abv = noisevarchrom[i] * mad_abr;
+                            const float tempab = c[i];
+                            float mag_L = cL[i];
+                            const float mag_ab = sqrf(tempab);
+                            mag_L = sqrf(mag_L) * rmad_Lm9;
+                            c[i] = tempab * sqrf(1.f - oracle_xexpf_v(-(mag_ab / mad_abv) - (mag_L)));
+                        } else {
+                            const float mag_L = sqrf(cL[i]), mag_ab = sqrf(c[i]);
+                            c[i] *= sqrf(1.f - oracle_xexpf_s(-(mag_ab / (noisevarchrom[i] * mad_abr)) - (mag_L / (9.f * mad_Lr))));
+                        }
+                    }
+                }
+            }
+        }
+}
+
 /* Color::gammaf2lut, SSE form: lut[65536] */
 void oracle_gamma_lut(float *lut, float gamma, float start, float slope, float divisor, float factor)
 {
@@ -301,6 +342,7 @@ int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, cons
     int levwav = 5;
     float maxreal = rt_maxf(realred, realblue);
     if (maxreal < 8.f) levwav = 5; else if (maxreal < 10.f) levwav = 6; else if (maxreal < 15.f) levwav = 7; else levwav = 8;
+    if (p->aggressive) levwav += 2;      /* QUALITY_HIGH (L2260-2262) */
     if (levwav > 8) levwav = 8;
     { int t = (int)(levwav - ceil(log(scale))); levwav = t > 5 ? t : 5; }
     int minsizetile = w < h ? w : h, maxlev2 = 8;
@@ -321,6 +363,7 @@ int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, cons
     for (int ch = 0; ch < 2; ++ch) {
         float *plane = ch == 0 ? laba : labb;
         oracle_wavelet *d = oracle_wavelet_decompose(plane, w, h, levwav);
+        if (p->aggressive) oracle_bishrink_AB(Ldecomp, d, noisevarchrom, ch == 0 ? noisevarab_r : noisevarab_b, useNoiseCCurve, p->autoch, madL, scale);
 #pragma omp parallel for collapse(2) schedule(dynamic)
         for (int lvl = 0; lvl < levwav; ++lvl)
             for (int dir = 1; dir < 4; ++dir)
@@ -346,9 +389,13 @@ int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, cons
     }
     if (denoiseLuminance) {
         const int maxlvl = levwav < 5 ? levwav : 5;
+        /* QUALITY_HIGH: WaveletDenoiseAll_BiShrinkL first (L842-973) -- its per-band body is ShrinkAllL's, top level included --
+         * then the standard pass; madL is not recomputed in between (L2408-2421) */
+        for (int rep = p->aggressive ? 0 : 1; rep < 2; ++rep) {
 #pragma omp parallel for collapse(2) schedule(dynamic)
-        for (int lvl = 0; lvl < maxlvl; ++lvl)
-            for (int dir = 1; dir < 4; ++dir) oracle_shrink_all_L(Ldecomp, lvl, dir, noisevarlum, madL[lvl], scale);
+            for (int lvl = 0; lvl < maxlvl; ++lvl)
+                for (int dir = 1; dir < 4; ++dir) oracle_shrink_all_L(Ldecomp, lvl, dir, noisevarlum, madL[lvl], scale);
+        }
         float *Lin = (float *)malloc(sizeof(float) * n);
         memcpy(Lin, labL, sizeof(float) * n);
         if (Lin_out) memcpy(Lin_out, labL, sizeof(float) * n);
@@ -363,7 +410,7 @@ int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, cons
     oracle_wavelet_free(Ldecomp);
 
     /* chroma boost, YUV -> RGB, inverse gamma (L2502-2550); numtiles == 1 */
-    const float qhighFactor = 1.0f;
+    const float qhighFactor = p->aggressive ? 1.f / (float)0.9 : 1.0f;   /* L1672 */
     const float newGain = 1.f / gain;
 #pragma omp parallel for
     for (int i = 0; i < h; ++i)

@@ -82,12 +82,15 @@ typedef struct {
     double expcomp;   /* RGB_denoise's expcomp argument (0 when called from ImProcFunctions::denoise) */
     double scale;     /* ImProcData::scale (1 for full-size export) */
     int autoch;       /* chrominanceMethod == AUTOMATIC */
+    int aggressive;   /* DenoiseParams::aggressive -> QUALITY_HIGH */
 } oracle_denoise_params;
 float oracle_madrgb(const float *data, int datalen);
 void oracle_boxblur_flat(const float *src, float *dst, float *temp, int radx, int rady, int W, int H);
 void oracle_shrink_all_L(oracle_wavelet *L, int level, int dir, const float *noisevarlum, const float *madL3, double scale);
 void oracle_shrink_all_AB(const oracle_wavelet *L, oracle_wavelet *ab, int level, int dir, const float *noisevarchrom,
                           float noisevar_ab, int useNoiseCCurve, int autoch, const float *madL3, double scale);
+void oracle_bishrink_AB(const oracle_wavelet *L, oracle_wavelet *ab, const float *noisevarchrom, float noisevar_ab, int useNoiseCCurve,
+                        int autoch, float madL[8][3], double scale);
 void oracle_gamma_lut(float *lut, float gamma, float start, float slope, float divisor, float factor);
 int oracle_rgb_denoise(float *const img[3], size_t stride, int w, int h, const oracle_denoise_params *p,
                        const float wpi[9], const float *noisevarchrom_in, float *Lin_out, float *Lden_out, int detail_recovery);

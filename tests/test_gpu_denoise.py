@@ -61,7 +61,7 @@ def test_unsupported_modes_fail_loudly(gpu_ctx):
     from art_amd import capi
     img = _rgb(256, 256, 1)
     with pytest.raises(capi.ArtGpuError):
-        gpu_ctx.rgb_denoise(capi.host_rgb(img), _params(aggressive=1), O.REC2020_WS)
+        gpu_ctx.rgb_denoise(capi.host_rgb(img), _params(color_space=1), O.REC2020_WS)   # LAB colour space
     with pytest.raises(capi.ArtGpuError):
         gpu_ctx.rgb_denoise(capi.host_rgb(img), _params(luminance_detail_threshold=30), O.REC2020_WS, flags=0)   # detail_mask not built yet
 
@@ -139,3 +139,23 @@ def test_noise_residuals_match_oracle(gpu_ctx):
     assert np.float32(nresi) == np.float32(rn) and np.float32(highresi) == np.float32(rh) and rn > 0
     for g, r in zip(got, ref):
         assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+
+
+@pytest.mark.parametrize("chroma", [15.0, 95.0])
+def test_aggressive_mode_bit_exact(gpu_ctx, chroma):
+    """DenoiseParams::aggressive (QUALITY_HIGH): two more wavelet levels, WaveletDenoiseAll_BiShrinkAB/L before the standard
+    passes, stronger chroma boost (FTblockDN.cc:842-1108,1671-1672,2260,2335-2421)."""
+    w, h = 520, 392
+    raw = synth.bayer_frame(w, h, synth.FILTERS_RGGB, seed=10, noise=2500)
+    img = O.amaze(raw, synth.FILTERS_RGGB, 1.0, 4)
+    rng = np.random.default_rng(2)
+    ccalc = (1.0 + 4.0 * rng.uniform(0.01, 0.5, ((h + 1) // 2, (w + 1) // 2))).astype(np.float32) ** 2
+    for cc in (None, ccalc):
+        got = [p.copy() for p in img]
+        gpu_ctx.rgb_denoise(capi.host_rgb(got), capi.DenoiseParams(40.0, 50.0, 0, chroma, 0.0, 0.0, 1.7, 1, 0, 0), O.REC2020_WS,
+                            ccalc=None if cc is None else capi.host_plane(cc))
+        ref = O.rgb_denoise(img, O.default_denoise_params(aggressive=1, chrominance=chroma), noisevarchrom=cc)
+        plain = O.rgb_denoise(img, O.default_denoise_params(chrominance=chroma), noisevarchrom=cc)
+        assert not np.array_equal(ref[1], plain[1])
+        for g, r in zip(got, ref):
+            assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
