@@ -631,7 +631,7 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK };
 
 struct DevDecomp {
     float *bands, *low[2];
@@ -686,6 +686,11 @@ int pool_get(artgpu_ctx *ctx, int slot, size_t bytes, float **out)
 
 extern "C" {
 
+namespace {
+int detail_mask_dev(artgpu_ctx *ctx, const float *src, size_t src_stride, float *mask, int W, int H,
+                    float scaling, float threshold, float ceiling, float factor, float blur, float *scratch);
+}
+
 int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_params *p, const float ws[9],
                        double expcomp, double scale, const artgpu_plane *ccalc, uint32_t flags,
                        float *nresi, float *highresi)
@@ -693,8 +698,8 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     if (!ctx) return ARTGPU_EINVAL;
     if (!img || !p || !ws) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: null argument");
     if (p->color_space != 0) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: LAB colour space is not on the device path");
+    if (p->chrominance_method != 0 && p->chrominance_method != 1) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: chrominance_method must be 0 (MANUAL) or 1 (AUTOMATIC)");
     const bool do_detail = !(flags & ARTGPU_DN_SKIP_DETAIL_RECOVERY);
-    if (do_detail && p->luminance_detail_threshold > 0) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: luminanceDetailThreshold > 0 (detail_mask) is not on the device path yet");
     if (!(scale >= 1.0)) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: scale must be >= 1");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     DevRGB d;
@@ -904,6 +909,14 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
             }
             da.tm_in = dtab; da.tm_out = dtab + 4096; da.costab = dtab + 2 * 4096; da.costab_t = dtab + 3 * 4096;
             da.L = L; da.Lin = Lin;
+            if (p->luminance_detail_threshold > 0) {
+                // detail_mask(LL, mask, 65535, 25, 10000, amount, GAUSS, 25 / scale) on the denoised L (FTblockDN.cc:1502-1507)
+                float *dmask;
+                if ((rc = pool_get(ctx, P_DMASK, n * 4, &dmask))) return rc;
+                const float amount = std::max(0.f, std::min(float(p->luminance_detail_threshold) / 100.f, 1.f));
+                if ((rc = detail_mask_dev(ctx, L, (size_t)w, dmask, w, h, 65535.f, 25.f, 10000.f, amount, (float)(25.f / scale), tmp))) return rc;
+                da.mask = dmask; da.params_Ldetail = params_Ldetail;
+            }
             HIPCHK(ctx, launch_detail_blocks(da, ctx->stream));
             HIPCHK(ctx, launch_detail_gather(da, ctx->stream));
         }
@@ -983,7 +996,7 @@ int artgpu_denoise_guided_smoothing(artgpu_ctx *ctx, artgpu_rgb *img, const doub
 namespace {
 
 // calculateYvVFactors<double> + M rescaling (gauss.cc:94-126,556-562)
-void yvv_factors(double sigma, GaussArgs &g)
+void yvv_factors(double sigma, GaussArgs &g, bool double_path = false)
 {
     double q;
     if (sigma < 2.5) q = 3.97156 - 4.14554 * std::sqrt(1.0 - 0.26891 * sigma);
@@ -1005,8 +1018,12 @@ void yvv_factors(double sigma, GaussArgs &g)
     M[7] = b1 * b2 + b3 * b2 * b2 - b1 * b3 * b3 - b3 * b3 * b3 - b3 * b2 + b3;
     M[8] = b3 * (b1 + b3 * b2);
     for (int i = 0; i < 9; ++i) {
-        M[i] *= (1.0 + b2 + (b1 - b3) * b3);
-        M[i] /= (1.0 + b1 - b2 + b3) * (1.0 - b1 - b2 - b3);
+        if (double_path) {           // gaussHorizontal<T> / gaussVertical<T> normalise differently (gauss.cc:674-677 vs 559-563)
+            M[i] /= (1.0 + b1 - b2 + b3) * (1.0 + b2 + (b1 - b3) * b3);
+        } else {
+            M[i] *= (1.0 + b2 + (b1 - b3) * b3);
+            M[i] /= (1.0 + b1 - b2 + b3) * (1.0 - b1 - b2 - b3);
+        }
         g.Mf[i] = (float)M[i];
     }
     g.b[0] = b1; g.b[1] = b2; g.b[2] = b3;
@@ -1034,10 +1051,18 @@ int pool_to_plane(artgpu_ctx *ctx, const float *src, artgpu_plane *pl)
 
 int gaussian_dev(artgpu_ctx *ctx, float *img, float *tmp, int W, int H, double sigma)
 {
-    if (!(sigma >= 0.6 && sigma < 25.0) || W < 8 || H < 8) return fail(ctx, ARTGPU_EUNSUPPORTED, "gaussian_blur: sigma %g / size %dx%d not on the device path", sigma, W, H);
+    if (!(sigma >= 0.6) || W < 8 || H < 8) return fail(ctx, ARTGPU_EUNSUPPORTED, "gaussian_blur: sigma %g / size %dx%d not on the device path", sigma, W, H);
     GaussArgs g = {};
     g.img = img; g.tmp = tmp; g.W = W; g.H = H;
-    yvv_factors((double)(float)sigma, g);   // the Sse functions take `const float sigma`
+    if (sigma >= 25.0) {                    // GAUSS_DOUBLE (gauss.cc:1393,1520-1523): all-double recursion
+        float *t64;
+        int rc = pool_get(ctx, P_GAUSS64, (size_t)W * H * sizeof(double), &t64);
+        if (rc) return rc;
+        g.tmp64 = reinterpret_cast<double *>(t64);
+        yvv_factors(sigma, g, true);
+    } else {
+        yvv_factors((double)(float)sigma, g);   // the Sse functions take `const float sigma`
+    }
     HIPCHK(ctx, launch_gaussian(g, ctx->stream));
     return ARTGPU_OK;
 }

@@ -113,7 +113,12 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
             if (row == rad) rlen = 1.f / lenf;
             // detail_factor is indexed by block position (FTblockDN.cc:1571-1596): hi inside the image
             const bool rowin = (top + row) >= 0 && (top + row) < a.h;
-            const float factor = (rowin && colin) ? a.detail_hi : a.detail_lo;
+            float factor = (rowin && colin) ? a.detail_hi : a.detail_lo;
+            if (a.mask && rowin && colin) {     // compute_detail(params_Ldetail * mask) (FTblockDN.cc:1481-1486,1583)
+                const float d = a.params_Ldetail * a.mask[(size_t)(top + row) * a.w + left + lane];
+                const float t = static_cast<float>((100. - d) * (100. - d) + 50. * (100. - d)) * TS * 0.5f;
+                factor = t * t;
+            }
             const float y = T[row][lane];
             T[row][lane] = y * (1.0f - xexpf_v(-sqr(tv) / factor));
         }

@@ -205,6 +205,8 @@ struct DetailArgs {
     int w, h, numblox_W, numblox_H;
     float detail_hi, detail_lo;
     int blur_rad;
+    const float *mask;      // luminanceDetailThreshold > 0: detail mask (w x h), else nullptr
+    float params_Ldetail;
 };
 hipError_t launch_detail_blocks(const DetailArgs &a, hipStream_t s);
 hipError_t launch_detail_gather(const DetailArgs &a, hipStream_t s);
@@ -237,6 +239,7 @@ struct MaskArgs {
 };
 struct GaussArgs {
     float *img, *tmp;                      // W x H contiguous, blurred in place; tmp = forward-pass storage
+    double *tmp64;                         // sigma >= 25: double forward buffer (selects the double kernels)
     int W, H;
     double B, b[3], M[9];
     float Bf, bf[3], Mf[9];

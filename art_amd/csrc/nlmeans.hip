@@ -140,6 +140,48 @@ __global__ void __launch_bounds__(64) gauss_v_kernel(GaussArgs a)
     else yvv_line<double>(p, (size_t)a.W, tmp, (size_t)a.W, a.H, a.B, a.b[0], a.b[1], a.b[2], a.M);
 }
 
+// sigma >= 25 (GAUSS_DOUBLE): gaussHorizontal<T> / gaussVertical<T> (gauss.cc:669-713,1148-1225): every line in double, with
+// a double forward buffer; one lane per line.
+__device__ __forceinline__ void yvv_line64(float *p, size_t st, double *tmp, size_t tst, int n, double B, double b1, double b2, double b3, const double *M)
+{
+    const double s0 = p[0];
+    tmp[0] = B * s0 + b1 * s0 + b2 * s0 + b3 * s0;
+    tmp[tst] = B * (double)p[st] + b1 * tmp[0] + b2 * s0 + b3 * s0;
+    tmp[2 * tst] = B * (double)p[2 * st] + b1 * tmp[tst] + b2 * tmp[0] + b3 * s0;
+    double m3 = tmp[0], m2 = tmp[tst], m1 = tmp[2 * tst];
+    for (int j = 3; j < n; j++) {
+        const double v = B * (double)p[(size_t)j * st] + b1 * m1 + b2 * m2 + b3 * m3;
+        tmp[(size_t)j * tst] = v;
+        m3 = m2; m2 = m1; m1 = v;
+    }
+    const double sl = p[(size_t)(n - 1) * st];
+    const double t2Wm1 = sl + M[0] * (m1 - sl) + M[1] * (m2 - sl) + M[2] * (m3 - sl);
+    const double t2W = sl + M[3] * (m1 - sl) + M[4] * (m2 - sl) + M[5] * (m3 - sl);
+    const double t2Wp1 = sl + M[6] * (m1 - sl) + M[7] * (m2 - sl) + M[8] * (m3 - sl);
+    const double r1 = t2Wm1;
+    const double r2 = B * m2 + b1 * r1 + b2 * t2W + b3 * t2Wp1;
+    const double r3 = B * m3 + b1 * r2 + b2 * r1 + b3 * t2W;
+    p[(size_t)(n - 1) * st] = (float)r1; p[(size_t)(n - 2) * st] = (float)r2; p[(size_t)(n - 3) * st] = (float)r3;
+    double a1 = r3, a2 = r2, a3 = r1;
+    for (int j = n - 4; j >= 0; j--) {
+        const double v = B * tmp[(size_t)j * tst] + b1 * a1 + b2 * a2 + b3 * a3;
+        p[(size_t)j * st] = (float)v;
+        a3 = a2; a2 = a1; a1 = v;
+    }
+}
+__global__ void __launch_bounds__(64) gauss_h64_kernel(GaussArgs a)
+{
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= a.H) return;
+    yvv_line64(a.img + (size_t)row * a.W, 1, a.tmp64 + (size_t)row * a.W, 1, a.W, a.B, a.b[0], a.b[1], a.b[2], a.M);
+}
+__global__ void __launch_bounds__(64) gauss_v64_kernel(GaussArgs a)
+{
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (col >= a.W) return;
+    yvv_line64(a.img + col, (size_t)a.W, a.tmp64 + col, (size_t)a.W, a.H, a.B, a.b[0], a.b[1], a.b[2], a.M);
+}
+
 // ---------------------------------------------------------------- NL-means
 // padded source (nlmeans.cc:98-109), dst = 0 (L111-119), mask -> (1/(mask*h2))/lutfactor (L129-136)
 __global__ void __launch_bounds__(256) nlm_prepare_kernel(NlmArgs a)
@@ -268,6 +310,11 @@ hipError_t launch_detail_mask(const MaskArgs &a, hipStream_t s)
 }
 hipError_t launch_gaussian(const GaussArgs &a, hipStream_t s)
 {
+    if (a.tmp64) {
+        hipLaunchKernelGGL(gauss_h64_kernel, dim3((a.H + 63) / 64), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(gauss_v64_kernel, dim3((a.W + 63) / 64), dim3(64), 0, s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(gauss_h_kernel, dim3((a.H + 63) / 64), dim3(64), 0, s, a);
     hipLaunchKernelGGL(gauss_v_kernel, dim3((a.W + 63) / 64), dim3(64), 0, s, a);
     return hipGetLastError();

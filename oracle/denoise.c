@@ -403,7 +403,7 @@ int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, cons
         if (Lden_out) memcpy(Lden_out, labL, sizeof(float) * n);
         if (detail_recovery) {
             float params_Ldetail = rt_minf((float)p->luminanceDetail, 99.9f);
-            oracle_detail_recovery(w, h, labL, Lin, params_Ldetail, scale);
+            oracle_detail_recovery_ex(w, h, labL, Lin, params_Ldetail, scale, p->detail_thresh);
         }
         free(Lin);
     }

@@ -120,8 +120,22 @@ static void boxabsblur64(const float *src, float *dst, int rad)
     }
 }
 
+void oracle_detail_recovery_ex(int width, int height, float *L, const float *Lin, float params_Ldetail, double scale, int detail_thresh);
 void oracle_detail_recovery(int width, int height, float *L, const float *Lin, float params_Ldetail, double scale)
 {
+    oracle_detail_recovery_ex(width, height, L, Lin, params_Ldetail, scale, 0);
+}
+
+/* detail_thresh = DenoiseParams::luminanceDetailThreshold (FTblockDN.cc:1502-1507,1583) */
+void oracle_detail_recovery_ex(int width, int height, float *L, const float *Lin, float params_Ldetail, double scale, int detail_thresh)
+{
+    float *mask = NULL;
+    if (detail_thresh > 0) {
+        float amount = (float)detail_thresh / 100.f;
+        amount = amount < 0.f ? 0.f : (amount > 1.f ? 1.f : amount);
+        mask = (float *)malloc(sizeof(float) * (size_t)width * height);
+        oracle_detail_mask(L, mask, width, height, 65535.f, 25.f, 10000.f, amount, (float)(25.f / scale));
+    }
     const float detail_hi = oracle_detail_factor(params_Ldetail), detail_lo = oracle_detail_factor(0.f);
     const int numblox_W = (int)ceil(((float)width) / DOFF) + 2 * DBLKRAD;
     const int numblox_H = (int)ceil(((float)height) / DOFF) + 2 * DBLKRAD;
@@ -153,7 +167,8 @@ void oracle_detail_recovery(int width, int height, float *L, const float *Lin, f
                     else if (col >= width) cc = 2 * width - 2 - col > 0 ? 2 * width - 2 - col : 0;
                     const float v = Lin[(size_t)rr * width + cc] - L[(size_t)rr * width + cc];
                     blk[i * DTS + j] = tm_in[i * DTS + j] * v;
-                    factor[i * DTS + j] = (row >= 0 && row < height && col >= 0 && col < width) ? detail_hi : detail_lo;
+                    factor[i * DTS + j] = (row >= 0 && row < height && col >= 0 && col < width)
+                                              ? (mask ? oracle_detail_factor(params_Ldetail * mask[(size_t)row * width + col]) : detail_hi) : detail_lo;
                 }
             }
             dct2d(blk, costab, 0);
@@ -180,5 +195,5 @@ void oracle_detail_recovery(int width, int height, float *L, const float *Lin, f
     }
 #pragma omp parallel for
     for (long long k = 0; k < (long long)n; ++k) L[k] += Ldetail[k] / totwt[k];
-    free(blocks); free(Ldetail); free(totwt); free(costab);
+    free(blocks); free(Ldetail); free(totwt); free(costab); free(mask);
 }

@@ -23,7 +23,7 @@
 #include <stdlib.h>
 #include <float.h>
 
-void oracle_yvv_factors(double sigma, double *b1, double *b2, double *b3, double *B, double M[9])
+static void oracle_yvv_factors_raw(double sigma, double *b1, double *b2, double *b3, double *B, double M[9])
 {
     double q;
     if (sigma < 2.5) q = 3.97156 - 4.14554 * sqrt(1.0 - 0.26891 * sigma);
@@ -44,6 +44,13 @@ void oracle_yvv_factors(double sigma, double *b1, double *b2, double *b3, double
     M[6] = c3 * c1 + c2 + c1 * c1 - c2 * c2;
     M[7] = c1 * c2 + c3 * c2 * c2 - c1 * c3 * c3 - c3 * c3 * c3 - c3 * c2 + c3;
     M[8] = c3 * (c1 + c3 * c2);
+}
+
+/* calculateYvVFactors + the normalisation of the Sse functions (gauss.cc:559-563) */
+void oracle_yvv_factors(double sigma, double *b1, double *b2, double *b3, double *B, double M[9])
+{
+    oracle_yvv_factors_raw(sigma, b1, b2, b3, B, M);
+    const double c1 = *b1, c2 = *b2, c3 = *b3;
     for (int i = 0; i < 9; ++i) {
         M[i] *= (1.0 + c2 + (c1 - c3) * c3);
         M[i] /= (1.0 + c1 - c2 + c3) * (1.0 - c1 - c2 - c3);
@@ -99,8 +106,42 @@ static void yvv_line_d(float *p, size_t st, int n, float *tmp, double B, double 
     for (int j = 0; j < n; ++j) p[(size_t)j * st] = tmp[j];
 }
 
+/* sigma >= 25: gaussHorizontal<T> / gaussVertical<T> (gauss.cc:669-713,1148-1225), all double, M normalised differently */
+static void yvv_line_64(float *p, size_t st, int n, double *tmp, double B, double b1, double b2, double b3, const double M[9])
+{
+    const double s0 = p[0];
+    tmp[0] = B * s0 + b1 * s0 + b2 * s0 + b3 * s0;
+    tmp[1] = B * p[st] + b1 * tmp[0] + b2 * s0 + b3 * s0;
+    tmp[2] = B * p[2 * st] + b1 * tmp[1] + b2 * tmp[0] + b3 * s0;
+    for (int j = 3; j < n; j++) tmp[j] = B * p[(size_t)j * st] + b1 * tmp[j - 1] + b2 * tmp[j - 2] + b3 * tmp[j - 3];
+    const double sl = p[(size_t)(n - 1) * st];
+    const double t2Wm1 = sl + M[0] * (tmp[n - 1] - sl) + M[1] * (tmp[n - 2] - sl) + M[2] * (tmp[n - 3] - sl);
+    const double t2W = sl + M[3] * (tmp[n - 1] - sl) + M[4] * (tmp[n - 2] - sl) + M[5] * (tmp[n - 3] - sl);
+    const double t2Wp1 = sl + M[6] * (tmp[n - 1] - sl) + M[7] * (tmp[n - 2] - sl) + M[8] * (tmp[n - 3] - sl);
+    tmp[n - 1] = t2Wm1;
+    tmp[n - 2] = B * tmp[n - 2] + b1 * tmp[n - 1] + b2 * t2W + b3 * t2Wp1;
+    tmp[n - 3] = B * tmp[n - 3] + b1 * tmp[n - 2] + b2 * tmp[n - 1] + b3 * t2W;
+    for (int j = n - 4; j >= 0; j--) tmp[j] = B * tmp[j] + b1 * tmp[j + 1] + b2 * tmp[j + 2] + b3 * tmp[j + 3];
+    for (int j = 0; j < n; ++j) p[(size_t)j * st] = (float)tmp[j];
+}
+
 void oracle_gaussian_blur(float *img, int W, int H, double sigma_d)
 {
+    if (sigma_d >= 25.0) {
+        double b1, b2, b3, B, M[9];
+        oracle_yvv_factors_raw(sigma_d, &b1, &b2, &b3, &B, M);
+        for (int i = 0; i < 9; ++i) M[i] /= (1.0 + b1 - b2 + b3) * (1.0 + b2 + (b1 - b3) * b3);
+#pragma omp parallel
+        {
+            double *tmp = (double *)malloc(sizeof(double) * (size_t)(W > H ? W : H));
+#pragma omp for
+            for (int i = 0; i < H; ++i) yvv_line_64(img + (size_t)i * W, 1, W, tmp, B, b1, b2, b3, M);
+#pragma omp for
+            for (int i = 0; i < W; ++i) yvv_line_64(img + i, (size_t)W, H, tmp, B, b1, b2, b3, M);
+            free(tmp);
+        }
+        return;
+    }
     const float sigma = (float)sigma_d; /* the Sse functions take `const float sigma` */
     double b1, b2, b3, B, M[9];
     oracle_yvv_factors(sigma, &b1, &b2, &b3, &B, M);

@@ -83,6 +83,7 @@ typedef struct {
     double scale;     /* ImProcData::scale (1 for full-size export) */
     int autoch;       /* chrominanceMethod == AUTOMATIC */
     int aggressive;   /* DenoiseParams::aggressive -> QUALITY_HIGH */
+    int detail_thresh; /* DenoiseParams::luminanceDetailThreshold */
 } oracle_denoise_params;
 float oracle_madrgb(const float *data, int datalen);
 void oracle_boxblur_flat(const float *src, float *dst, float *temp, int radx, int rady, int W, int H);
@@ -99,6 +100,7 @@ int oracle_rgb_denoise(float *const img[3], size_t stride, int w, int h, const o
 void oracle_detail_tilemasks(float *tilemask_in, float *tilemask_out);
 float oracle_detail_factor(float d);
 void oracle_detail_recovery(int width, int height, float *L, const float *Lin, float params_Ldetail, double scale);
+void oracle_detail_recovery_ex(int width, int height, float *L, const float *Lin, float params_Ldetail, double scale, int detail_thresh);
 
 /* guided chroma smoothing (oracle/guided.c) */
 void oracle_boxblur_ring(float *img, int radius, int W, int H);

@@ -63,7 +63,7 @@ def test_unsupported_modes_fail_loudly(gpu_ctx):
     with pytest.raises(capi.ArtGpuError):
         gpu_ctx.rgb_denoise(capi.host_rgb(img), _params(color_space=1), O.REC2020_WS)   # LAB colour space
     with pytest.raises(capi.ArtGpuError):
-        gpu_ctx.rgb_denoise(capi.host_rgb(img), _params(luminance_detail_threshold=30), O.REC2020_WS, flags=0)   # detail_mask not built yet
+        gpu_ctx.rgb_denoise(capi.host_rgb(img), _params(chrominance_method=2), O.REC2020_WS)   # not MANUAL / AUTOMATIC
 
 
 @pytest.mark.parametrize("w,h,detail", [(640, 480, 50.0), (517, 389, 80.0), (330, 260, 0.0)])
@@ -159,3 +159,18 @@ def test_aggressive_mode_bit_exact(gpu_ctx, chroma):
         assert not np.array_equal(ref[1], plain[1])
         for g, r in zip(got, ref):
             assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+
+
+def test_detail_recovery_with_detail_mask_threshold(gpu_ctx):
+    """luminanceDetailThreshold > 0: detail_mask (double-precision YvV gaussian, sigma 25) scales the per-position DCT shrink
+    strength (FTblockDN.cc:1502-1507,1583).  Same tolerance as the plain detail-recovery test (FFTW boundary)."""
+    w, h = 600, 440
+    img = _rgb(w, h, 33)
+    got = [p.copy() for p in img]
+    gpu_ctx.rgb_denoise(capi.host_rgb(got), _params(luminance_detail=60.0, luminance_detail_threshold=40), O.REC2020_WS, flags=0)
+    ref = O.rgb_denoise(img, O.default_denoise_params(luminanceDetail=60.0, detail_thresh=40), detail_recovery=True)
+    plain = O.rgb_denoise(img, O.default_denoise_params(luminanceDetail=60.0), detail_recovery=True)
+    for g, r, pl in zip(got, ref, plain):
+        err = np.abs(g.astype(np.float64) - r.astype(np.float64))
+        assert err.max() <= 65535.0 * 2e-5 and np.median(err) <= 0.02
+        assert np.abs(r - pl).max() > 5.0          # the mask changes the result

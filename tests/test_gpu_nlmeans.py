@@ -17,7 +17,7 @@ def _Y(w, h, seed):
     return O.amaze(raw, synth.FILTERS_RGGB, 1.0, 4)[1]
 
 
-@pytest.mark.parametrize("w,h,sigma", [(320, 240, 2.0), (323, 241, 2.0), (326, 243, 1.0), (200, 150, 0.8), (257, 129, 7.5)])
+@pytest.mark.parametrize("w,h,sigma", [(320, 240, 2.0), (323, 241, 2.0), (326, 243, 1.0), (200, 150, 0.8), (257, 129, 7.5), (323, 241, 25.0), (200, 151, 40.0)])
 def test_gaussian_blur(gpu_ctx, w, h, sigma):
     from art_amd import capi
     img = _Y(w, h, w)
