@@ -4,7 +4,7 @@
 // cielab (L41-116, x86-64 path) and xtransborder_interpolate (L122-173).  One workgroup per REFERENCE tile (114x114,
 // origin (3,3), stride 98 -- the tile grid decides where each direction buffer is defined, so it is part of the
 // result).  The per-workgroup HBM arena keeps the reference's layout and aliasing (L301-308):
-//     rgb[ndir][114][114][3] | lab[3][106][106] | drv[ndir][104][104]
+//     rgb[ndir] (planar here: [dir][channel][114][114], coalesced; interleaved [..][3] in the reference) | lab[3][106][106] | drv[ndir][104][104]
 //     greenminmax + uint8 homogeneity maps alias lab, 5x5 sums alias drv, the per-pixel maximum aliases homo[ndir-1].
 // rgb[0] and the lab planes are cleared per tile (a reference thread's first tile); everything else is written before
 // it is read.  Every step of the algorithm reads only values produced by EARLIER steps (the in-place green
@@ -21,6 +21,9 @@ namespace {
 constexpr int TS = XTRANS_TS, TSH = TS / 2, NT = XTRANS_THREADS;
 constexpr int LW = TS - 8;     // lab plane pitch
 constexpr int DW = TS - 10;    // drv plane pitch
+constexpr int PL = TS * TS;    // one colour plane of a direction buffer (the rgb buffers are kept PLANAR here:
+                               // [dir][channel][row][col] -- every value is written before it is read, so only the
+                               // lab/drv/homo regions need the reference's exact byte layout)
 
 struct Geo {
     const XtransArgs &a;
@@ -64,7 +67,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
     const int width = a.W, height = a.H;
     const size_t rs = a.raw_stride;
     const int sgrow = a.sgrow, sgcol = a.sgcol;
-#define RGB(d, r, c) (buffer + ((size_t)((d) * TS + (r)) * TS + (c)) * 3)
+#define RGB(d, r, c) (buffer + (size_t)(d) * 3 * PL + (r) * TS + (c))
 #define LAB(k, i, j) labbase[((k) * LW + (i)) * LW + (j)]
 #define DRV(d, i, j) drvbase[((d) * DW + (i)) * DW + (j)]
 
@@ -143,7 +146,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
 #pragma unroll
             for (int d = 0; d < 4; d++) {
                 float *p = RGB(d, r, c);
-                p[0] = base[0]; p[1] = interp ? gdir[d] : base[1]; p[2] = base[2];
+                p[0] = base[0]; p[PL] = interp ? gdir[d] : base[1]; p[2 * PL] = base[2];
             }
         }
         __syncthreads();
@@ -166,8 +169,8 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
 #pragma unroll
                     for (int d = 3; d < 6; d++) {
                         float *rix = RGB(B + ((d - 2) ^ flip), r, c);
-                        const float val = 0.33333333f * (rix[-2 * hex[d] * 3 + 1] + 2 * (rix[hex[d] * 3 + 1] - rix[hex[d] * 3 + f]) - rix[-2 * hex[d] * 3 + f]) + rix[f];
-                        rix[1] = limf(val, s[0], s[1]);
+                        const float val = 0.33333333f * (rix[-2 * hex[d] + PL] + 2 * (rix[hex[d] + PL] - rix[hex[d] + f * PL]) - rix[-2 * hex[d] + f * PL]) + rix[f * PL];
+                        rix[PL] = limf(val, s[0], s[1]);
                     }
                 }
                 __syncthreads();
@@ -188,18 +191,18 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                     for (int d = 0; d < 6; d++) {
 #pragma unroll
                         for (int k = 0; k < 2; k++) {
-                            const int o = (i << k) * 3;
-                            const float g = rix[1] + rix[1] - rix[o + 1] - rix[-o + 1];
-                            color[h][d] = g + rix[o + h] + rix[-o + h];
-                            if (d > 1) diff[d] += sqr(rix[o + 1] - rix[-o + 1] - rix[o + h] + rix[-o + h]) + sqr(g);
+                            const int o = (i << k);
+                            const float g = rix[PL] + rix[PL] - rix[o + PL] - rix[-o + PL];
+                            color[h][d] = g + rix[o + h * PL] + rix[-o + h * PL];
+                            if (d > 1) diff[d] += sqr(rix[o + PL] - rix[-o + PL] - rix[o + h * PL] + rix[-o + h * PL]) + sqr(g);
                             h ^= 2;
                         }
                         if (d > 2 && (d & 1))
                             if (diff[d - 1] < diff[d]) { color[0][d] = color[0][d - 1]; color[2][d] = color[2][d - 1]; }
                         if ((d & 1) || d < 2) {
                             rix[0] = 0.5f * color[0][d];
-                            rix[2] = 0.5f * color[2][d];
-                            rix += TS * TS * 3;
+                            rix[2 * PL] = 0.5f * color[2][d];
+                            rix += 3 * PL;
                         }
                         i ^= TS ^ 1;
                         h ^= 2;
@@ -216,10 +219,10 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                 const int f = 2 - G.fcol(row, col);
                 float *rix = RGB(B, r, c);
 #pragma unroll
-                for (int d = 0; d < 4; d++, rix += TS * TS * 3) {
+                for (int d = 0; d < 4; d++, rix += 3 * PL) {
                     const int i = d > 1 || ((d ^ cd) & 1) ||
-                                  ((fabsf(rix[1] - rix[cd * 3 + 1]) + fabsf(rix[1] - rix[-cd * 3 + 1])) < 2.f * (fabsf(rix[1] - rix[hd * 3 + 1]) + fabsf(rix[1] - rix[-hd * 3 + 1]))) ? cd : hd;
-                    rix[f] = rix[1] + 0.5f * (rix[i * 3 + f] + rix[-i * 3 + f] - rix[i * 3 + 1] - rix[-i * 3 + 1]);
+                                  ((fabsf(rix[PL] - rix[cd + PL]) + fabsf(rix[PL] - rix[-cd + PL])) < 2.f * (fabsf(rix[PL] - rix[hd + PL]) + fabsf(rix[PL] - rix[-hd + PL]))) ? cd : hd;
+                    rix[f * PL] = rix[PL] + 0.5f * (rix[i + f * PL] + rix[-i + f * PL] - rix[i + PL] - rix[-i + PL]);
                 }
             }
             __syncthreads();
@@ -230,15 +233,15 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                 if ((row - sgrow) % 3 == 0 || (col - sgcol) % 3 == 0) continue;
                 const int *hex = a.allhex1[row % 3][col % 3];
                 float *rix = RGB(B, r, c);
-                for (int d = 0; d < ndir; d += 2, rix += TS * TS * 3) {
+                for (int d = 0; d < ndir; d += 2, rix += 3 * PL) {
                     if (hex[d] + hex[d + 1]) {
-                        const float g = 3 * rix[1] - 2 * rix[hex[d] * 3 + 1] - rix[hex[d + 1] * 3 + 1];
-                        rix[0] = (g + 2 * rix[hex[d] * 3 + 0] + rix[hex[d + 1] * 3 + 0]) * 0.33333333f;
-                        rix[2] = (g + 2 * rix[hex[d] * 3 + 2] + rix[hex[d + 1] * 3 + 2]) * 0.33333333f;
+                        const float g = 3 * rix[PL] - 2 * rix[hex[d] + PL] - rix[hex[d + 1] + PL];
+                        rix[0] = (g + 2 * rix[hex[d]] + rix[hex[d + 1]]) * 0.33333333f;
+                        rix[2 * PL] = (g + 2 * rix[hex[d] + 2 * PL] + rix[hex[d + 1] + 2 * PL]) * 0.33333333f;
                     } else {
-                        const float g = 2 * rix[1] - rix[hex[d] * 3 + 1] - rix[hex[d + 1] * 3 + 1];
-                        rix[0] = (g + rix[hex[d] * 3 + 0] + rix[hex[d + 1] * 3 + 0]) * 0.5f;
-                        rix[2] = (g + rix[hex[d] * 3 + 2] + rix[hex[d + 1] * 3 + 2]) * 0.5f;
+                        const float g = 2 * rix[PL] - rix[hex[d] + PL] - rix[hex[d + 1] + PL];
+                        rix[0] = (g + rix[hex[d]] + rix[hex[d + 1]]) * 0.5f;
+                        rix[2 * PL] = (g + rix[hex[d] + 2 * PL] + rix[hex[d + 1] + 2 * PL]) * 0.5f;
                     }
                 }
             }
@@ -254,15 +257,15 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                     const float *p = RGB(d, 4 + i, 4 + j);
                     float c0, c1, c2;
                     if (j < ((LW - 3 + 3) / 4) * 4) {       // 4-lane groups while j < labWidth - 3
-                        const float x0 = p[0] * a.xyz_cam[0] + p[1] * a.xyz_cam[1] + p[2] * a.xyz_cam[2];
-                        const float x1 = p[0] * a.xyz_cam[3] + p[1] * a.xyz_cam[4] + p[2] * a.xyz_cam[5];
-                        const float x2 = p[0] * a.xyz_cam[6] + p[1] * a.xyz_cam[7] + p[2] * a.xyz_cam[8];
+                        const float x0 = p[0] * a.xyz_cam[0] + p[PL] * a.xyz_cam[1] + p[2 * PL] * a.xyz_cam[2];
+                        const float x1 = p[0] * a.xyz_cam[3] + p[PL] * a.xyz_cam[4] + p[2 * PL] * a.xyz_cam[5];
+                        const float x2 = p[0] * a.xyz_cam[6] + p[PL] * a.xyz_cam[7] + p[2 * PL] * a.xyz_cam[8];
                         c0 = cbrt_lut(a.cbrt_lut, __float2int_rn(x0)); c1 = cbrt_lut(a.cbrt_lut, __float2int_rn(x1)); c2 = cbrt_lut(a.cbrt_lut, __float2int_rn(x2));
                         LAB(0, i, j) = 116.f * c1 - 16.f;
                     } else {
                         float x0 = 0.5f, x1 = 0.5f, x2 = 0.5f;
 #pragma unroll
-                        for (int k = 0; k < 3; k++) { x0 += a.xyz_cam[k] * p[k]; x1 += a.xyz_cam[3 + k] * p[k]; x2 += a.xyz_cam[6 + k] * p[k]; }
+                        for (int k = 0; k < 3; k++) { x0 += a.xyz_cam[k] * p[k * PL]; x1 += a.xyz_cam[3 + k] * p[k * PL]; x2 += a.xyz_cam[6 + k] * p[k * PL]; }
                         c0 = cbrt_lut(a.cbrt_lut, (int)x0); c1 = cbrt_lut(a.cbrt_lut, (int)x1); c2 = cbrt_lut(a.cbrt_lut, (int)x2);
                         LAB(0, i, j) = 116 * c1 - 16;
                     }
@@ -274,9 +277,9 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                     const int r = t / TS, c = t - r * TS;
                     if (r < 4 || c < 4 || r >= mrl - 4 || c >= mcl - 4) continue;
                     const float *p = RGB(d, r, c);
-                    const float y = 0.2627f * p[0] + 0.6780f * p[1] + 0.0593f * p[2];
+                    const float y = 0.2627f * p[0] + 0.6780f * p[PL] + 0.0593f * p[2 * PL];
                     LAB(0, r - 4, c - 4) = y;
-                    LAB(1, r - 4, c - 4) = (p[2] - y) * 0.56433f;
+                    LAB(1, r - 4, c - 4) = (p[2 * PL] - y) * 0.56433f;
                     LAB(2, r - 4, c - 4) = (p[0] - y) * 0.67815f;
                 }
             }
@@ -374,7 +377,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             for (int d = 0; d < 8; d++)
                 if (d < ndir && hm[d] >= maxval) {
                     const float *p = RGB(d, r, c);
-                    avg[0] += p[0]; avg[1] += p[1]; avg[2] += p[2];
+                    avg[0] += p[0]; avg[1] += p[PL]; avg[2] += p[2 * PL];
                     avg[3]++;
                 }
             const size_t o = (size_t)(r + top) * a.out_stride + c + left;
