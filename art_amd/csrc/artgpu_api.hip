@@ -31,6 +31,7 @@ struct artgpu_ctx {
     static constexpr int NPOOL = 24;
     float *pool[NPOOL] = {};
     size_t pool_bytes[NPOOL] = {};
+    float fuse_pre = 0.f, fuse_post = 0.f;   // improc_denoise -> rgb_denoise: exposure compensation fused into rgb2yuv / yuv2rgb
     float *lut = nullptr; // 65536-entry tone LUT on the device
     size_t lut_bytes = 0;
     // timing
@@ -780,6 +781,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     px.gain = gain; px.newGain = 1.f / gain;
     px.gam = gam; px.gamthresh = gamthresh; px.gamslope = gamslope; px.igam = igam; px.igamthresh = igamthresh; px.igamslope = igamslope;
     px.gamcurve = gamlut; px.igamcurve = gamlut + 65536;
+    px.pre_scale = ctx->fuse_pre; px.post_scale = ctx->fuse_post;
     px.realred = realred; px.realblue = realblue; px.qhighFactor = aggressive ? 1.f / static_cast<float>(0.9) : 1.0f;   // L1672
     HIPCHK(ctx, launch_rgb2yuv(px, ctx->stream));
 
@@ -1363,8 +1365,16 @@ int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise
             ccalc_p = &ccalc;
         }
     }
-    if (ecomp > 0) { if ((rc = artgpu_exposure(ctx, img, (float)std::pow(2.0, ecomp), 0.f))) return rc; }   // ipdenoise.cc:1161-1163
-    if ((rc = artgpu_rgb_denoise(ctx, img, &p->dn, wsf, 0.0, scale, ccalc_p, flags, nullptr, nullptr))) return rc;
+    // expcomp(+ecomp) / expcomp(-ecomp) (ipdenoise.cc:1161-1163,1181-1184) are fused into RGB_denoise's first and last pixel
+    // passes when RGB_denoise will actually run them (same operations on the same values, two fewer passes over the image)
+    const bool dn_runs = !(p->dn.luminance == 0 && p->dn.chrominance == 0 && !ccalc_p);
+    const bool fuse_pre = ecomp > 0 && dn_runs, fuse_post = fuse_pre && !p->smoothing_enabled;
+    if (ecomp > 0 && !fuse_pre) { if ((rc = artgpu_exposure(ctx, img, (float)std::pow(2.0, ecomp), 0.f))) return rc; }
+    ctx->fuse_pre = fuse_pre ? (float)std::pow(2.0, ecomp) : 0.f;
+    ctx->fuse_post = fuse_post ? (float)std::pow(2.0, -ecomp) : 0.f;
+    rc = artgpu_rgb_denoise(ctx, img, &p->dn, wsf, 0.0, scale, ccalc_p, flags, nullptr, nullptr);
+    ctx->fuse_pre = ctx->fuse_post = 0.f;
+    if (rc) return rc;
     if (p->smoothing_enabled) {
         if ((rc = artgpu_denoise_guided_smoothing(ctx, img, ws, p->guided_chroma_radius, scale))) return rc;
         if (p->nl_strength) {
@@ -1379,7 +1389,7 @@ int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise
             HIPCHK(ctx, launch_yuv_mode(a, ctx->stream));
         }
     }
-    if (ecomp > 0) { if ((rc = artgpu_exposure(ctx, img, (float)std::pow(2.0, -ecomp), 0.f))) return rc; }         // L1181-1184
+    if (ecomp > 0 && !fuse_post) { if ((rc = artgpu_exposure(ctx, img, (float)std::pow(2.0, -ecomp), 0.f))) return rc; }         // L1181-1184
     return ARTGPU_OK;
 }
 

@@ -60,7 +60,12 @@ __global__ void __launch_bounds__(256) rgb2yuv_kernel(DnPixArgs a)
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
         const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
         const size_t si = (size_t)y * a.stride + x;
-        float X = a.gain * a.rgb[0][si], Y = a.gain * a.rgb[1][si], Z = a.gain * a.rgb[2][si];
+        float r0 = a.rgb[0][si], g0 = a.rgb[1][si], b0 = a.rgb[2][si];
+        if (a.pre_scale != 0.f) {   // fused ImProcFunctions::expcomp(+ecomp) (ipexposure.cc:56-70): 4-lane groups then scalar tail
+            if (x < (a.w / 4) * 4) { r0 = sse_max(r0 * a.pre_scale - 0.f, 0.f); g0 = sse_max(g0 * a.pre_scale - 0.f, 0.f); b0 = sse_max(b0 * a.pre_scale - 0.f, 0.f); }
+            else { r0 = std_max(r0 * a.pre_scale - 0.f, 0.f); g0 = std_max(g0 * a.pre_scale - 0.f, 0.f); b0 = std_max(b0 * a.pre_scale - 0.f, 0.f); }
+        }
+        float X = a.gain * r0, Y = a.gain * g0, Z = a.gain * b0;
         if (a.gam > 1.f) {
             if (X > 0.f) X = X < 65535.f ? lutf_lookup<false>(a.gamcurve, 65536, X) : (gammaf_s(X / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
             if (Y > 0.f) Y = Y < 65535.f ? lutf_lookup<false>(a.gamcurve, 65536, Y) : (gammaf_s(Y / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
@@ -95,9 +100,14 @@ __global__ void __launch_bounds__(256) yuv2rgb_kernel(DnPixArgs a)
             if (Z > 0.f) Z = Z < 65536.f ? lutf_lookup<false>(a.igamcurve, 65536, Z) : (gammaf_s(Z / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
         }
         const size_t di = (size_t)y * a.stride + x;
-        a.rgb[0][di] = a.newGain * X;
-        a.rgb[1][di] = a.newGain * Y;
-        a.rgb[2][di] = a.newGain * Z;
+        float ro = a.newGain * X, go = a.newGain * Y, bo = a.newGain * Z;
+        if (a.post_scale != 0.f) {  // fused ImProcFunctions::expcomp(-ecomp)
+            if (x < (a.w / 4) * 4) { ro = sse_max(ro * a.post_scale - 0.f, 0.f); go = sse_max(go * a.post_scale - 0.f, 0.f); bo = sse_max(bo * a.post_scale - 0.f, 0.f); }
+            else { ro = std_max(ro * a.post_scale - 0.f, 0.f); go = std_max(go * a.post_scale - 0.f, 0.f); bo = std_max(bo * a.post_scale - 0.f, 0.f); }
+        }
+        a.rgb[0][di] = ro;
+        a.rgb[1][di] = go;
+        a.rgb[2][di] = bo;
     }
 }
 

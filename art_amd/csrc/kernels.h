@@ -145,6 +145,7 @@ struct DnPixArgs {
     const float *gamcurve, *igamcurve;
     float ws1[3];           // working-space matrix row 1 (luminance)
     float realred, realblue, qhighFactor;
+    float pre_scale, post_scale;   // != 0: exposure compensation fused in front of rgb2yuv / behind yuv2rgb
 };
 // chroma noise-curve map (ipdenoise.cc:1113-1131 + FTblockDN.cc:1716-1777)
 struct ChromaMapArgs {
