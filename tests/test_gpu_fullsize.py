@@ -1,0 +1,59 @@
+"""GPU parity at BASELINE.json's full sizes (45 MP Bayer, 100 MP X-Trans): the whole frame against the oracle, bit for
+bit (the oracle runs with OpenMP on the GPU box's host cores; a few tens of seconds per test)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from art_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+MUL = (2.1374, 1.0, 1.5918)
+MAT = np.array([[0.6325, 0.2312, 0.0921], [0.2198, 0.7712, 0.0090], [0.0166, 0.0713, 0.7514]])
+
+
+def _dev_planes(h, w):
+    t = [torch.empty((h, w), dtype=torch.float32, device="cuda") for _ in range(3)]
+    return t, capi.RGB(*[capi.device_plane(x) for x in t])
+
+
+def test_config2_and_3_stages_45mp_bit_exact(gpu_ctx):
+    W, H = 8192, 5464
+    raw = synth.bayer_frame(W, H, synth.FILTERS_RGGB, seed=0)
+    d_raw = torch.from_numpy(raw).cuda()
+    d_out, out = _dev_planes(H, W)
+    gpu_ctx.demosaic_bayer(capi.BAYER_AMAZE, capi.device_plane(d_raw), synth.FILTERS_RGGB, 1.0, 4, out)
+    gpu_ctx.synchronize()
+    ref = O.amaze(raw, synth.FILTERS_RGGB, 1.0, 4)
+    for t, r in zip(d_out, ref):
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))          # BASELINE configs[1]
+    # configs[2] stages on top (DCT detail recovery skipped: it is the one tolerance-checked stage)
+    d_img, img = _dev_planes(H - 8, W - 8)
+    gpu_ctx.get_image(out, 4, 4, MUL, True, MAT, img)
+    curve, _ = capi.noise_curve_lut()
+    tp = capi.DenoiseToolParams(capi.DenoiseParams(40.0, 50.0, 0, 15.0, 0.0, 0.0, 1.7, 0, 0, 0), 0, 3, 0, 80)
+    gpu_ctx.improc_denoise(img, tp, O.REC2020_WS_D, ecomp=0.3, calclum_mat=MAT, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    gpu_ctx.exposure(img, float(np.float32(2.0 ** 0.3)), 0.0)
+    x = np.arange(65536, dtype=np.float64) / 65535.0
+    lut = ((1.0 - np.cos(np.pi * x ** 0.7)) / 2.0 * 65535.0).astype(np.float32)
+    gpu_ctx.tone_curve(img, lut, 1.0, True)
+    gpu_ctx.synchronize()
+    o = O.get_image(ref, 4, 4, W - 8, H - 8, MUL, True)
+    o = O.convert_color_space(o, MAT)
+    o = O.improc_denoise(o, calclum_mat=MAT, noise_c_curve=curve, smoothing=False, ecomp=0.3, detail_recovery=False)
+    o = O.exposure(o, float(np.float32(2.0 ** 0.3)), 0.0)
+    o = O.tone_std(o, lut, 1.0, True)
+    for t, r in zip(d_img, o):
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))
+
+
+def test_config5_xtrans_100mp_bit_exact(gpu_ctx):
+    W, H = 11648, 8736
+    raw = synth.xtrans_frame(W, H, seed=0)
+    d_raw = torch.from_numpy(raw).cuda()
+    d_out, out = _dev_planes(H, W)
+    gpu_ctx.demosaic_xtrans(3, True, capi.device_plane(d_raw), synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, out)
+    gpu_ctx.synchronize()
+    ref = O.xtrans_demosaic(raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, 3, True)
+    for t, r in zip(d_out, ref):
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))
