@@ -98,13 +98,13 @@ def _load():
     lib.artgpu_wavelet_set_band.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     lib.artgpu_wavelet_reconstruct.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Plane), C.c_float]
     lib.artgpu_wavelet_free.argtypes = [C.c_void_p, C.c_void_p]
-    lib.artgpu_rgb_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseParams), C.POINTER(C.c_float), C.c_double,
+    lib.artgpu_rgb_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseParams), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_double,
                                        C.c_double, C.POINTER(Plane), C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_denoise_guided_smoothing.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double), C.c_int, C.c_double]
     lib.artgpu_gaussian_blur.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_double]
     lib.artgpu_detail_mask.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(Plane), C.c_float, C.c_float, C.c_float, C.c_float, C.c_float]
     lib.artgpu_nlmeans.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_float, C.c_int, C.c_int, C.c_float]
-    lib.artgpu_improc_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseToolParams), C.POINTER(C.c_double), C.c_double,
+    lib.artgpu_improc_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseToolParams), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
                                           C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_uint32]
     lib.artgpu_demosaic_xtrans.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Plane), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(RGB)]
     lib.artgpu_tone_curve_neutral.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.c_float, C.POINTER(NeutralState)]
@@ -204,10 +204,11 @@ class Context:
         self._chk(LIB.artgpu_tone_curve(self._h, C.byref(image), mode, lp, whitept, int(filmlike_clip)))
 
     def rgb_denoise(self, image: RGB, params: DenoiseParams, ws, expcomp: float = 0.0, scale: float = 1.0,
-                    ccalc: Plane = None, flags: int = DN_SKIP_DETAIL_RECOVERY, want_resid: bool = False):
+                    ccalc: Plane = None, flags: int = DN_SKIP_DETAIL_RECOVERY, want_resid: bool = False, iws=None):
         wsf = (C.c_float * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float32).reshape(9)])
+        iwsf = None if iws is None else (C.c_float * 9)(*[float(v) for v in np.asarray(iws, dtype=np.float32).reshape(9)])
         nresi, highresi = C.c_float(0), C.c_float(0)
-        self._chk(LIB.artgpu_rgb_denoise(self._h, C.byref(image), C.byref(params), wsf, expcomp, scale,
+        self._chk(LIB.artgpu_rgb_denoise(self._h, C.byref(image), C.byref(params), wsf, iwsf, expcomp, scale,
                                          None if ccalc is None else C.byref(ccalc), flags,
                                          C.byref(nresi) if want_resid else None, C.byref(highresi) if want_resid else None))
         if want_resid:
@@ -251,7 +252,7 @@ class Context:
         self._chk(LIB.artgpu_denoise_chroma_map(self._h, C.byref(image), m, wsd, cv.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ccalc)))
 
     def improc_denoise(self, image: RGB, params: DenoiseToolParams, ws, ecomp: float = 0.0, scale: float = 1.0, calclum_mat=None,
-                       noise_c_curve=None, flags: int = 0):
+                       noise_c_curve=None, flags: int = 0, iws=None):
         wsd = (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)])
         m = None if calclum_mat is None else (C.c_double * 9)(*[float(v) for v in np.asarray(calclum_mat, dtype=np.float64).reshape(9)])
         cv = None
@@ -259,7 +260,8 @@ class Context:
             cva = np.ascontiguousarray(noise_c_curve, dtype=np.float32)
             assert cva.shape == (501,)
             cv = cva.ctypes.data_as(C.POINTER(C.c_float))
-        self._chk(LIB.artgpu_improc_denoise(self._h, C.byref(image), C.byref(params), wsd, ecomp, scale, m, cv, flags))
+        iwsd = None if iws is None else (C.c_double * 9)(*[float(v) for v in np.asarray(iws, dtype=np.float64).reshape(9)])
+        self._chk(LIB.artgpu_improc_denoise(self._h, C.byref(image), C.byref(params), wsd, iwsd, ecomp, scale, m, cv, flags))
 
     # ---- wavelet_decomposition ----
     def wavelet_decompose(self, src: Plane, maxlvl: int):

@@ -28,7 +28,7 @@ struct artgpu_ctx {
     float *stage[NSTAGE] = {};
     size_t stage_bytes[NSTAGE] = {};
     // grow-only scratch pool for the denoise path (planes, decompositions, shrink buffers)
-    static constexpr int NPOOL = 24;
+    static constexpr int NPOOL = 32;
     float *pool[NPOOL] = {};
     size_t pool_bytes[NPOOL] = {};
     float fuse_pre = 0.f, fuse_post = 0.f;   // improc_denoise -> rgb_denoise: exposure compensation fused into rgb2yuv / yuv2rgb
@@ -632,7 +632,8 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_NSLOTS };
+static_assert(P_NSLOTS <= artgpu_ctx::NPOOL, "grow artgpu_ctx::pool");
 
 struct DevDecomp {
     float *bands, *low[2];
@@ -692,13 +693,15 @@ int detail_mask_dev(artgpu_ctx *ctx, const float *src, size_t src_stride, float 
                     float scaling, float threshold, float ceiling, float factor, float blur, float *scratch);
 }
 
-int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_params *p, const float ws[9],
+int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_params *p, const float ws[9], const float *iws,
                        double expcomp, double scale, const artgpu_plane *ccalc, uint32_t flags,
                        float *nresi, float *highresi)
 {
     if (!ctx) return ARTGPU_EINVAL;
     if (!img || !p || !ws) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: null argument");
-    if (p->color_space != 0) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb_denoise: LAB colour space is not on the device path");
+    if (p->color_space != 0 && p->color_space != 1) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: color_space must be 0 (RGB) or 1 (LAB)");
+    const bool lab_mode = p->color_space == 1;
+    if (lab_mode && !iws) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: LAB mode needs the inverse working-space matrix");
     if (p->chrominance_method != 0 && p->chrominance_method != 1) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: chrominance_method must be 0 (MANUAL) or 1 (AUTOMATIC)");
     const bool do_detail = !(flags & ARTGPU_DN_SKIP_DETAIL_RECOVERY);
     if (!(scale >= 1.0)) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: scale must be >= 1");
@@ -782,6 +785,22 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     px.gam = gam; px.gamthresh = gamthresh; px.gamslope = gamslope; px.igam = igam; px.igamthresh = igamthresh; px.igamslope = igamslope;
     px.gamcurve = gamlut; px.igamcurve = gamlut + 65536;
     px.pre_scale = ctx->fuse_pre; px.post_scale = ctx->fuse_post;
+    if (lab_mode) {
+        // Color::cachef / cachefy / denoiseGammaTab / denoiseIGammaTab, built on the host like the reference's (color.cc:202-292)
+        float *tabs;
+        const bool fresh = ctx->pool[P_LABTABS] == nullptr;
+        if ((rc = pool_get(ctx, P_LABTABS, 4 * 65536 * 4, &tabs))) return rc;
+        if (fresh) {
+            std::vector<float> host(4 * 65536);
+            build_cachef(host.data()); build_cachefy(host.data() + 65536);
+            build_denoise_gamma_tabs(host.data() + 2 * 65536, host.data() + 3 * 65536);
+            HIPCHK(ctx, hipMemcpyAsync(tabs, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        px.lab_mode = 1;
+        px.cachef = tabs; px.cachefy = tabs + 65536; px.dn_gamma = tabs + 2 * 65536; px.dn_igamma = tabs + 3 * 65536;
+        for (int k = 0; k < 9; ++k) { px.wpi[k] = ws[k]; px.iws[k] = iws[k]; }
+    }
     px.realred = realred; px.realblue = realblue; px.qhighFactor = aggressive ? 1.f / static_cast<float>(0.9) : 1.0f;   // L1672
     HIPCHK(ctx, launch_rgb2yuv(px, ctx->stream));
 
@@ -1333,7 +1352,7 @@ int artgpu_denoise_chroma_map(artgpu_ctx *ctx, const artgpu_rgb *img, const doub
     return ARTGPU_OK;
 }
 
-int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_tool_params *p, const double ws[9],
+int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_tool_params *p, const double ws[9], const double *iws,
                           double ecomp, double scale, const double *calclum_mat, const float *noise_c_curve, uint32_t flags)
 {
     if (!ctx) return ARTGPU_EINVAL;
@@ -1346,7 +1365,7 @@ int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise
         artgpu_rgb dv;
         artgpu_plane *pl[3] = {&dv.r, &dv.g, &dv.b};
         for (int k = 0; k < 3; ++k) { pl[k]->p = d.p[k]; pl[k]->w = d.w; pl[k]->h = d.h; pl[k]->row_stride_bytes = (int64_t)d.stride * 4; pl[k]->on_device = 1; }
-        if ((rc0 = artgpu_improc_denoise(ctx, &dv, p, ws, ecomp, scale, calclum_mat, noise_c_curve, flags))) return rc0;
+        if ((rc0 = artgpu_improc_denoise(ctx, &dv, p, ws, iws, ecomp, scale, calclum_mat, noise_c_curve, flags))) return rc0;
         return unbind_rgb(ctx, img, &d);
     }
     float wsf[9];
@@ -1372,7 +1391,9 @@ int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise
     if (ecomp > 0 && !fuse_pre) { if ((rc = artgpu_exposure(ctx, img, (float)std::pow(2.0, ecomp), 0.f))) return rc; }
     ctx->fuse_pre = fuse_pre ? (float)std::pow(2.0, ecomp) : 0.f;
     ctx->fuse_post = fuse_post ? (float)std::pow(2.0, -ecomp) : 0.f;
-    rc = artgpu_rgb_denoise(ctx, img, &p->dn, wsf, 0.0, scale, ccalc_p, flags, nullptr, nullptr);
+    float iwsf[9];
+    if (iws) for (int k = 0; k < 9; ++k) iwsf[k] = (float)iws[k];
+    rc = artgpu_rgb_denoise(ctx, img, &p->dn, wsf, iws ? iwsf : nullptr, 0.0, scale, ccalc_p, flags, nullptr, nullptr);
     ctx->fuse_pre = ctx->fuse_post = 0.f;
     if (rc) return rc;
     if (p->smoothing_enabled) {

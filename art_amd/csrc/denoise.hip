@@ -53,6 +53,59 @@ __device__ __forceinline__ float gammaf_s(float x, float gamma, float start, flo
     return x <= start ? x * slope : xexpf_s(xlogf_s(x) / gamma);
 }
 
+// ---------------------------------------------------------------- Lab helpers (LAB colour-space mode of RGB_denoise)
+// LUTf::operator[](float) of a LUT constructed with flags 0: extrapolates on both sides (LUT.h:436-459)
+__device__ __forceinline__ float lutf_noclip(const float *__restrict__ data, float index)
+{
+    int idx = (int)index;
+    if (index < 0.f || !(index == index)) idx = 0;
+    else if (index > 65534.f) idx = 65534;
+    const float diff = index - (float)idx;
+    const float p1 = data[idx], p2 = data[idx + 1] - p1;
+    return p1 + p2 * diff;
+}
+// Color::computeXYZ2Lab (color.cc:1247-1259)
+__device__ __forceinline__ float xyz2lab_f(const float *__restrict__ cachef, float f)
+{
+    if (f != f) return f;
+    if (f < 0.f) return (float)(327.68 * (((24389.0 / 27.0) * (double)f / (double)65535.f + 16.0) / 116.0));
+    if (f > 65535.f) return 327.68f * xcbrtf_s(f / 65535.f);
+    return lutf_lookup<false>(cachef, 65536, f);
+}
+// Color::rgb2lab with a float matrix = rgbxyz + XYZ2Lab (color.h:630-636, color.cc:1262-1275,1382-1397)
+__device__ __forceinline__ void rgb2lab_dev(const DnPixArgs &a, float R, float G, float B, float &l, float &la, float &lb)
+{
+    const float X = a.wpi[0] * R + a.wpi[1] * G + a.wpi[2] * B, Y = a.wpi[3] * R + a.wpi[4] * G + a.wpi[5] * B, Z = a.wpi[6] * R + a.wpi[7] * G + a.wpi[8] * B;
+    const float x = X / 0.9642f, z = Z / 0.8249f, y = Y;
+    const float fx = xyz2lab_f(a.cachef, x), fy = xyz2lab_f(a.cachef, y), fz = xyz2lab_f(a.cachef, z);
+    if (y != y) l = y;
+    else if (y < 0.f) l = (float)(327.68 * ((24389.0 / 27.0) * (double)y / (double)65535.f));
+    else if (y > 65535.f) l = 327.68f * (116.f * xcbrtf_s(y / 65535.f) - 16.f);
+    else l = lutf_lookup<false>(a.cachefy, 65536, y);
+    la = 500.0f * (fx - fy);
+    lb = 200.0f * (fy - fz);
+}
+// Color::lab2rgb = Lab2XYZ + xyz2rgb (color.h:638-644,767-770, color.cc:1203-1214)
+__device__ __forceinline__ float f2xyz_f(float f)
+{
+    const float epsilonExpInv3f = (float)(6.0 / 29.0), kappaInvf = (float)(27.0 / 24389.0);
+    return (f > epsilonExpInv3f) ? f * f * f : (116.f * f - 16.f) * kappaInvf;
+}
+__device__ __forceinline__ void lab2rgb_dev(const DnPixArgs &a, float l, float la, float lb, float &R, float &G, float &B)
+{
+    const float c1By116 = (float)(1.0 / 116.0), c16By116 = (float)(16.0 / 116.0);
+    const float LL = l / 327.68f, aa = la / 327.68f, bb = lb / 327.68f;
+    const float fy = (c1By116 * LL) + c16By116;
+    const float fx = (0.002f * aa) + fy;
+    const float fz = fy - (0.005f * bb);
+    const float x = 65535.0f * f2xyz_f(fx) * 0.9642f;
+    const float z = 65535.0f * f2xyz_f(fz) * 0.8249f;
+    const float y = ((double)LL > 8.0) ? 65535.0f * fy * fy * fy : (float)((double)(65535.0f * LL) / (24389.0 / 27.0));
+    R = a.iws[0] * x + a.iws[1] * y + a.iws[2] * z;
+    G = a.iws[3] * x + a.iws[4] * y + a.iws[5] * z;
+    B = a.iws[6] * x + a.iws[7] * y + a.iws[8] * z;
+}
+
 // ---------------------------------------------------------------- RGB -> gamma -> YUV (FTblockDN.cc:2084-2128)
 __global__ void __launch_bounds__(256) rgb2yuv_kernel(DnPixArgs a)
 {
@@ -66,15 +119,18 @@ __global__ void __launch_bounds__(256) rgb2yuv_kernel(DnPixArgs a)
             else { r0 = std_max(r0 * a.pre_scale - 0.f, 0.f); g0 = std_max(g0 * a.pre_scale - 0.f, 0.f); b0 = std_max(b0 * a.pre_scale - 0.f, 0.f); }
         }
         float X = a.gain * r0, Y = a.gain * g0, Z = a.gain * b0;
+        if (a.lab_mode) { X = lutf_noclip(a.dn_igamma, X); Y = lutf_noclip(a.dn_igamma, Y); Z = lutf_noclip(a.dn_igamma, Z); }   // L2094-2098
         if (a.gam > 1.f) {
             if (X > 0.f) X = X < 65535.f ? lutf_lookup<false>(a.gamcurve, 65536, X) : (gammaf_s(X / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
             if (Y > 0.f) Y = Y < 65535.f ? lutf_lookup<false>(a.gamcurve, 65536, Y) : (gammaf_s(Y / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
             if (Z > 0.f) Z = Z < 65535.f ? lutf_lookup<false>(a.gamcurve, 65536, Z) : (gammaf_s(Z / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
         }
-        const float l = X * a.ws1[0] + Y * a.ws1[1] + Z * a.ws1[2];
+        float l = X * a.ws1[0] + Y * a.ws1[1] + Z * a.ws1[2];
+        float va = X - l, ub = l - Z;   // v -> labdn->a, u -> labdn->b
+        if (a.lab_mode) rgb2lab_dev(a, X, Y, Z, l, va, ub);    // rgb2lab(X, Y, Z, l, v, u, wpi), L2114-2116
         a.L[t] = l;
-        a.A[t] = X - l; // v
-        a.B[t] = l - Z; // u
+        a.A[t] = va;
+        a.B[t] = ub;
     }
 }
 
@@ -94,12 +150,14 @@ __global__ void __launch_bounds__(256) yuv2rgb_kernel(DnPixArgs a)
         float Z = Lv - bv;
         float X = av + Lv;
         float Y = (Lv - X * a.ws1[0] - Z * a.ws1[2]) / a.ws1[1];
+        if (a.lab_mode) lab2rgb_dev(a, Lv, av, bv, X, Y, Z);    // L2522-2524
         if (a.gam > 1.f) {
             if (X > 0.f) X = X < 65536.f ? lutf_lookup<false>(a.igamcurve, 65536, X) : (gammaf_s(X / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
             if (Y > 0.f) Y = Y < 65536.f ? lutf_lookup<false>(a.igamcurve, 65536, Y) : (gammaf_s(Y / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
             if (Z > 0.f) Z = Z < 65536.f ? lutf_lookup<false>(a.igamcurve, 65536, Z) : (gammaf_s(Z / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
         }
         const size_t di = (size_t)y * a.stride + x;
+        if (a.lab_mode) { X = lutf_noclip(a.dn_gamma, X); Y = lutf_noclip(a.dn_gamma, Y); Z = lutf_noclip(a.dn_gamma, Z); }   // L2533-2537
         float ro = a.newGain * X, go = a.newGain * Y, bo = a.newGain * Z;
         if (a.post_scale != 0.f) {  // fused ImProcFunctions::expcomp(-ecomp)
             if (x < (a.w / 4) * 4) { ro = sse_max(ro * a.post_scale - 0.f, 0.f); go = sse_max(go * a.post_scale - 0.f, 0.f); bo = sse_max(bo * a.post_scale - 0.f, 0.f); }
@@ -474,13 +532,6 @@ hipError_t launch_vblur_combine(const BlurArgs &a, int nsub, hipStream_t s)
 // Color::rgbxyz(float wpi) + Color::XYZ2Lab (color.cc:833-838,1247-1259,1382-1397) and
 // ccalc = SQR(1 + 4*noiseCCurve[cN/60]) for cN > 100, else the cN = 100 constant (FTblockDN.cc:1733-1771).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float xyz2lab_f(const float *__restrict__ cachef, float f)
-{
-    if (f != f) return f;
-    if (f < 0.f) return (float)(327.68 * (((24389.0 / 27.0) * (double)f / (double)65535.f + 16.0) / 116.0));
-    if (f > 65535.f) return 327.68f * xcbrtf_s(f / 65535.f);
-    return lutf_lookup<false>(cachef, 65536, f);
-}
 __global__ void __launch_bounds__(256) chroma_map_kernel(ChromaMapArgs a)
 {
     const long long n = (long long)a.wid * a.hei;

@@ -160,6 +160,27 @@ void build_cachef(float *lut)
 }
 
 
+// Color::cachefy (color.cc:219-234)
+void build_cachefy(float *lut)
+{
+    const double kappa = 24389.0 / 27.0, eps = 216.0 / 24389.0;
+    const float maxvalf = 65535.f;
+    const int epsmaxint = (int)((double)maxvalf * eps);
+    int i = 0;
+    for (; i <= epsmaxint; i++) lut[i] = (float)(327.68 * (kappa * i / maxvalf));
+    for (; i < 65536; i++) lut[i] = (float)(327.68 * (116.0 * std::cbrt((double)i / maxvalf) - 16.0));
+}
+
+// Color::denoiseGammaTab / denoiseIGammaTab (color.cc:278-292; gamma55 / igamma55, color.h:1155-1169)
+void build_denoise_gamma_tabs(float *gtab, float *igtab)
+{
+    for (int i = 0; i < 65536; i++) {
+        const double x = i / 65535.0;
+        gtab[i] = (float)(65535.0 * (x <= 0.013189 ? x * 10.0 : 1.593503 * std::exp(std::log(x) / 5.5) - 0.593503));
+        igtab[i] = (float)(65535.0 * (x <= 0.131889 ? x / 10.0 : std::exp(std::log((x + 0.593503) / 1.593503) * 5.5)));
+    }
+}
+
 // Color::init jzazbz_pq_ / jzazbz_pq_inv_ (color.cc:323-326) with PQ / PQ_inv (color.cc:67-86): std::pow(float, float) is the
 // host libm's powf, as in the reference
 void build_pq_luts(float *pq, float *pq_inv)

@@ -146,6 +146,9 @@ struct DnPixArgs {
     float ws1[3];           // working-space matrix row 1 (luminance)
     float realred, realblue, qhighFactor;
     float pre_scale, post_scale;   // != 0: exposure compensation fused in front of rgb2yuv / behind yuv2rgb
+    int lab_mode;                  // DenoiseParams::colorSpace == LAB (FTblockDN.cc:1996)
+    float wpi[9], iws[9];          // LAB: working space <-> XYZ, float casts
+    const float *cachef, *cachefy, *dn_gamma, *dn_igamma;   // LAB: 65536-entry LUTs
 };
 // chroma noise-curve map (ipdenoise.cc:1113-1131 + FTblockDN.cc:1716-1777)
 struct ChromaMapArgs {
@@ -161,6 +164,8 @@ hipError_t launch_chroma_map(const ChromaMapArgs &a, hipStream_t s);
 bool flat_curve_sample(const double *pts, int npts, bool periodic, int ppn, double identity, int nout, double *out);
 float noise_curve_lut(const double *pts, int npts, float lut[501]);
 void build_cachef(float *lut65536);
+void build_cachefy(float *lut65536);
+void build_denoise_gamma_tabs(float *gtab65536, float *igtab65536);
 
 struct ShrinkArgs {
     float *coef;            // bands of the decomposition being shrunk: [nsub][n]

@@ -206,7 +206,7 @@ public:
         float curve[501], sum = 0.f;
         ctx.check(artgpu_noise_curve_lut(curve_points, 9, curve, &sum));
         artgpu_rgb i = img->view();
-        ctx.check(artgpu_improc_denoise(ctx.get(), &i, &tp, params->workingSpace, ecomp, scale, imgsrc && imgsrc->hasColorMatrix ? imgsrc->colorMatrix : nullptr,
+        ctx.check(artgpu_improc_denoise(ctx.get(), &i, &tp, params->workingSpace, params->workingSpaceInverse, ecomp, scale, imgsrc && imgsrc->hasColorMatrix ? imgsrc->colorMatrix : nullptr,
                                         curve, 0u));
     }
     Context &ctx;

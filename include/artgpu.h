@@ -169,15 +169,16 @@ typedef struct {
 
 /* Replaces denoise::RGB_denoise(im, kall=0, src=img, dst=img, calclum, ..., isRAW=true, dnparams,
  * expcomp, noiseLCurve(empty), noiseCCurve, nresi, highresi) (rtengine/FTblockDN.cc:1638-2689) for
- * colorSpace RGB, QUALITY_STANDARD, one tile (Tile_calc always yields one, L442-480).
+ * colorSpace RGB or LAB, QUALITY_STANDARD or HIGH (aggressive), one tile (Tile_calc always yields one, L442-480).
  * img      : Imagefloat planes, denoised in place
  * ws       : ICCStore::workingSpaceMatrix(params->icm.workingProfile) as 9 floats, row-major (wpi)
+ * iws      : workingSpaceInverseMatrix as 9 floats (wpi_inverse, L1702-1706); only read in LAB mode, may be NULL otherwise
  * expcomp  : RGB_denoise's `expcomp` argument (gain = 2^expcomp; 0 from ImProcFunctions::denoise)
  * scale    : ImProcData::scale (1 for full-resolution export)
  * ccalc    : the quarter-resolution chroma noise-curve map `ccalc` (L1707-1777), ((w+1)/2 x (h+1)/2),
  *            or NULL when the chroma curve is off (noisevarchrom = 1)
  * flags    : ARTGPU_DN_* ; nresi/highresi: nullable, only computed when not NULL. */
-int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_params *params, const float ws[9],
+int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_params *params, const float ws[9], const float *iws,
                        double expcomp, double scale, const artgpu_plane *ccalc, uint32_t flags,
                        float *nresi, float *highresi);
 
@@ -242,7 +243,7 @@ typedef struct {
     int32_t nl_strength;
     int32_t nl_detail;
 } artgpu_denoise_tool_params;
-int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_tool_params *params, const double ws[9],
+int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_tool_params *params, const double ws[9], const double *iws /* LAB mode only */,
                           double ecomp, double scale, const double *calclum_mat, const float *noise_c_curve, uint32_t flags);
 
 /* Bytes of device scratch the context currently holds (arena + staging). */

@@ -300,6 +300,8 @@ int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, cons
     const float igam = 1.f / gam, igamthresh = gamthresh * gamslope, igamslope = 1.f / gamslope;
     oracle_gamma_lut(igamcurve, igam, igamthresh, igamslope, 65535.f, 65535.f);
     const float gain = powf(2.0f, (float)p->expcomp);
+    float *dn_gtab = NULL, *dn_igtab = NULL;
+    if (p->lab_mode) { dn_gtab = (float *)malloc(sizeof(float) * 65536 * 2); dn_igtab = dn_gtab + 65536; oracle_denoise_gamma_tabs(dn_gtab, dn_igtab); }
 
     const int w2 = (w + 1) / 2, h2 = (h + 1) / 2;
     const size_t n = (size_t)w * h, n2 = (size_t)w2 * h2;
@@ -323,12 +325,18 @@ int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, cons
             float X = gain * img[0][(size_t)i * stride + j];
             float Y = gain * img[1][(size_t)i * stride + j];
             float Z = gain * img[2][(size_t)i * stride + j];
+            if (p->lab_mode) {      /* L2094-2098 */
+                X = oracle_lutf_noclip(dn_igtab, 65536, X);
+                Y = oracle_lutf_noclip(dn_igtab, 65536, Y);
+                Z = oracle_lutf_noclip(dn_igtab, 65536, Z);
+            }
 #define APPLY_GAMMA(v) if (gam > 1.f && v > 0.f) v = v < 65535.f ? lutf_clip_below(gamcurve, 65536, v) : (gammaf_s(v / 65535.f, gam, gamthresh, gamslope) * 65535.f)
             APPLY_GAMMA(X); APPLY_GAMMA(Y); APPLY_GAMMA(Z);
 #undef APPLY_GAMMA
             /* Color::rgb2yuv with the float working-space matrix (color.h:783-788,204-207) */
             float l = X * wpi[3] + Y * wpi[4] + Z * wpi[5];
             float u = l - Z, v = X - l;
+            if (p->lab_mode) oracle_rgb2lab(X, Y, Z, &l, &v, &u, wpi);     /* L2114-2116: a -> labdn->a, b -> labdn->b */
             labL[(size_t)i * w + j] = l;
             laba[(size_t)i * w + j] = v;
             labb[(size_t)i * w + j] = u;
@@ -425,9 +433,15 @@ int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, cons
             float Z = Lv - b;
             float X = a + Lv;
             float Y = (Lv - X * wpi[3] - Z * wpi[5]) / wpi[4];
+            if (p->lab_mode) oracle_lab2rgb(Lv, a, b, &X, &Y, &Z, p->iws);       /* L2522-2524 */
 #define APPLY_IGAMMA(v) if (gam > 1.f && v > 0.f) v = v < 65536.f ? lutf_clip_below(igamcurve, 65536, v) : (gammaf_s(v / 65535.f, igam, igamthresh, igamslope) * 65535.f)
             APPLY_IGAMMA(X); APPLY_IGAMMA(Y); APPLY_IGAMMA(Z);
 #undef APPLY_IGAMMA
+            if (p->lab_mode) {      /* L2533-2537 */
+                X = oracle_lutf_noclip(dn_gtab, 65536, X);
+                Y = oracle_lutf_noclip(dn_gtab, 65536, Y);
+                Z = oracle_lutf_noclip(dn_gtab, 65536, Z);
+            }
             img[0][(size_t)i * stride + j] = newGain * X;
             img[1][(size_t)i * stride + j] = newGain * Y;
             img[2][(size_t)i * stride + j] = newGain * Z;
@@ -435,5 +449,6 @@ int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, cons
     free(lab);
     free(noisevarlum);
     free(gamcurve);
+    free(dn_gtab);
     return 0;
 }

@@ -201,7 +201,9 @@ void oracle_cachef(float lut[65536])
     for (; i < 65536; i++) lut[i] = (float)(327.68 * cbrt((double)i / MAXVALF));
 }
 
-static float xyz2lab_f(const float *cachef, float f)
+float oracle_xyz2lab_f(const float *cachef, float f);
+static float xyz2lab_f(const float *cachef, float f) { return oracle_xyz2lab_f(cachef, f); }
+float oracle_xyz2lab_f(const float *cachef, float f)
 {
     if (f != f) return f;
     if (f < 0.f) return (float)(327.68 * ((KAPPA * f / MAXVALF + 16.0) / 116.0));
@@ -253,4 +255,81 @@ void oracle_chroma_noise_map(const float *const img[3], size_t s, int w, int h, 
             }
             out[(size_t)ii * wid + jj] = r;
         }
+}
+
+/* ---------------------------------------------------------------- Lab helpers of RGB_denoise's LAB colour-space mode */
+/* Color::cachefy (color.cc:219-234), LUT_CLIP_BELOW */
+void oracle_cachefy(float lut[65536])
+{
+    const double eps_max = (double)MAXVALF * EPS_LAB;
+    int i = 0;
+    const int epsmaxint = (int)eps_max;
+    for (; i <= epsmaxint; i++) lut[i] = (float)(327.68 * (KAPPA * i / MAXVALF));
+    for (; i < 65536; i++) lut[i] = (float)(327.68 * (116.0 * cbrt((double)i / MAXVALF) - 16.0));
+}
+/* Color::denoiseGammaTab / denoiseIGammaTab (color.cc:278-292) with gamma55 / igamma55 (color.h:1155-1169) */
+void oracle_denoise_gamma_tabs(float *gtab, float *igtab)
+{
+    for (int i = 0; i < 65536; i++) {
+        const double x = i / 65535.0;
+        gtab[i] = (float)(65535.0 * (x <= 0.013189 ? x * 10.0 : 1.593503 * exp(log(x) / 5.5) - 0.593503));
+        igtab[i] = (float)(65535.0 * (x <= 0.131889 ? x / 10.0 : exp(log((x + 0.593503) / 1.593503) * 5.5)));
+    }
+}
+/* LUTf::operator[](float) of a LUT constructed with flags 0: extrapolates on both sides (LUT.h:436-459) */
+float oracle_lutf_noclip(const float *data, int size, float index)
+{
+    const int maxs = size - 2;
+    int idx = (int)index;
+    if (index < 0.f || !(index == index)) idx = 0;
+    else if (index > (float)maxs) idx = maxs;
+    const float diff = index - (float)idx;
+    const float p1 = data[idx], p2 = data[idx + 1] - p1;
+    return p1 + p2 * diff;
+}
+static float *g_cf, *g_cfy;
+static void lab_luts(void)
+{
+    if (!g_cf) {
+        float *a = (float *)malloc(sizeof(float) * 65536), *b = (float *)malloc(sizeof(float) * 65536);
+        oracle_cachef(a); oracle_cachefy(b);
+        g_cfy = b; g_cf = a;
+    }
+}
+/* Color::rgb2lab(R,G,B, float ws) = rgbxyz + XYZ2Lab (color.h:630-636, color.cc:1247-1275,1382-1397) */
+void oracle_rgb2lab(float R, float G, float B, float *l, float *a, float *b, const float ws[9])
+{
+    lab_luts();
+    const float X = ws[0] * R + ws[1] * G + ws[2] * B, Y = ws[3] * R + ws[4] * G + ws[5] * B, Z = ws[6] * R + ws[7] * G + ws[8] * B;
+    const float x = X / 0.9642f, z = Z / 0.8249f, y = Y;
+    const float fx = oracle_xyz2lab_f(g_cf, x), fy = oracle_xyz2lab_f(g_cf, y), fz = oracle_xyz2lab_f(g_cf, z);
+    float L;
+    if (y != y) L = y;
+    else if (y < 0.f) L = (float)(327.68 * (KAPPA * y / MAXVALF));
+    else if (y > 65535.f) L = 327.68f * (116.f * oracle_xcbrtf(y / MAXVALF) - 16.f);
+    else {
+        int idx = (int)y;
+        if (y > 65534.f) idx = 65534;
+        const float diff = y - (float)idx, p1 = g_cfy[idx], p2 = g_cfy[idx + 1] - p1;
+        L = p1 + p2 * diff;
+    }
+    *l = L; *a = 500.0f * (fx - fy); *b = 200.0f * (fy - fz);
+}
+/* Color::lab2rgb = Lab2XYZ + xyz2rgb (color.h:638-644, color.cc:1203-1214, color.h:767-770) */
+void oracle_lab2rgb(float l, float a, float b, float *R, float *G, float *B, const float iws[9])
+{
+    const float c1By116 = (float)(1.0 / 116.0), c16By116 = (float)(16.0 / 116.0);
+    const float epsilonExpInv3f = (float)(6.0 / 29.0), kappaInvf = (float)(27.0 / 24389.0);
+    const float LL = l / 327.68f, aa = a / 327.68f, bb = b / 327.68f;
+    const float fy = (c1By116 * LL) + c16By116;
+    const float fx = (0.002f * aa) + fy;
+    const float fz = fy - (0.005f * bb);
+#define F2XYZ(f) (((f) > epsilonExpInv3f) ? (f) * (f) * (f) : (116.f * (f) - 16.f) * kappaInvf)
+    const float x = 65535.0f * F2XYZ(fx) * 0.9642f;
+    const float z = 65535.0f * F2XYZ(fz) * 0.8249f;
+#undef F2XYZ
+    const float y = (LL > 8.0) ? 65535.0f * fy * fy * fy : (float)(65535.0f * LL / KAPPA);
+    *R = iws[0] * x + iws[1] * y + iws[2] * z;
+    *G = iws[3] * x + iws[4] * y + iws[5] * z;
+    *B = iws[6] * x + iws[7] * y + iws[8] * z;
 }

@@ -59,6 +59,11 @@ void oracle_t_xcbrtf(const float *x, float *y, size_t n);
 int oracle_flat_curve_sample(const double *pts, int npts, int periodic, int ppn, double identity, int nout, double *out);
 float oracle_noise_curve(const double *pts, int npts, float lut[501]);
 void oracle_cachef(float lut[65536]);
+void oracle_cachefy(float lut[65536]);
+void oracle_denoise_gamma_tabs(float *gtab, float *igtab);
+float oracle_lutf_noclip(const float *data, int size, float index);
+void oracle_rgb2lab(float R, float G, float B, float *l, float *a, float *b, const float ws[9]);
+void oracle_lab2rgb(float l, float a, float b, float *R, float *G, float *B, const float iws[9]);
 void oracle_chroma_noise_map(const float *const img[3], size_t s, int w, int h, const double *mat, const float wpi[9],
                              const float curve[501], float *out);
 void oracle_tone_curve_std(float *const img[3], size_t s, int w, int h, const float *lut65536);
@@ -84,6 +89,8 @@ typedef struct {
     int autoch;       /* chrominanceMethod == AUTOMATIC */
     int aggressive;   /* DenoiseParams::aggressive -> QUALITY_HIGH */
     int detail_thresh; /* DenoiseParams::luminanceDetailThreshold */
+    int lab_mode;      /* DenoiseParams::colorSpace == LAB */
+    float iws[9];      /* working-space inverse matrix (LAB mode only) */
 } oracle_denoise_params;
 float oracle_madrgb(const float *data, int datalen);
 void oracle_boxblur_flat(const float *src, float *dst, float *temp, int radx, int rady, int W, int H);

@@ -159,11 +159,12 @@ def wavelet_reconstruct(d, h, w, blend=1.0, fill=7.0):
 class DenoiseParams(C.Structure):
     _fields_ = [("luminance", C.c_double), ("luminanceDetail", C.c_double), ("chrominance", C.c_double),
                 ("chrominanceRedGreen", C.c_double), ("chrominanceBlueYellow", C.c_double), ("gamma", C.c_double),
-                ("expcomp", C.c_double), ("scale", C.c_double), ("autoch", C.c_int), ("aggressive", C.c_int), ("detail_thresh", C.c_int)]
+                ("expcomp", C.c_double), ("scale", C.c_double), ("autoch", C.c_int), ("aggressive", C.c_int), ("detail_thresh", C.c_int), ("lab_mode", C.c_int), ("iws", C.c_float * 9)]
 
 
 def default_denoise_params(**kw):
-    p = DenoiseParams(40.0, 50.0, 15.0, 0.0, 0.0, 1.7, 0.0, 1.0, 0, 0, 0)
+    p = DenoiseParams(40.0, 50.0, 15.0, 0.0, 0.0, 1.7, 0.0, 1.0, 0, 0, 0, 0)
+    p.iws[:] = [float(v) for v in REC2020_IWS_D.astype(np.float32).reshape(9)]
     for k, v in kw.items():
         setattr(p, k, v)
     return p

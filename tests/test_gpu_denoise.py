@@ -61,7 +61,7 @@ def test_unsupported_modes_fail_loudly(gpu_ctx):
     from art_amd import capi
     img = _rgb(256, 256, 1)
     with pytest.raises(capi.ArtGpuError):
-        gpu_ctx.rgb_denoise(capi.host_rgb(img), _params(color_space=1), O.REC2020_WS)   # LAB colour space
+        gpu_ctx.rgb_denoise(capi.host_rgb(img), _params(color_space=1), O.REC2020_WS)   # LAB without the inverse matrix
     with pytest.raises(capi.ArtGpuError):
         gpu_ctx.rgb_denoise(capi.host_rgb(img), _params(chrominance_method=2), O.REC2020_WS)   # not MANUAL / AUTOMATIC
 
@@ -174,3 +174,17 @@ def test_detail_recovery_with_detail_mask_threshold(gpu_ctx):
         err = np.abs(g.astype(np.float64) - r.astype(np.float64))
         assert err.max() <= 65535.0 * 2e-5 and np.median(err) <= 0.02
         assert np.abs(r - pl).max() > 5.0          # the mask changes the result
+
+
+@pytest.mark.parametrize("w,h", [(512, 384), (517, 389)])
+def test_lab_colour_space_mode_bit_exact(gpu_ctx, w, h):
+    """DenoiseParams::colorSpace == LAB: denoiseIGammaTab -> gamma -> rgb2lab ... lab2rgb -> inverse gamma -> denoiseGammaTab
+    (FTblockDN.cc:2094-2116,2522-2537)."""
+    img = _rgb(w, h, w + 5)
+    img[0][:6] *= 2.5                      # values above 65535 exercise the LUT extrapolation and the xcbrtf branch
+    got = [p.copy() for p in img]
+    gpu_ctx.rgb_denoise(capi.host_rgb(got), _params(color_space=1), O.REC2020_WS, iws=O.REC2020_IWS_D)
+    ref = O.rgb_denoise(img, O.default_denoise_params(lab_mode=1))
+    plain = O.rgb_denoise(img, O.default_denoise_params())
+    assert not np.array_equal(ref[0], plain[0])
+    assert _same(got, ref) == [0, 0, 0]
