@@ -41,10 +41,23 @@ class NeutralState(C.Structure):
     _fields_ = [("ws", C.c_double * 9), ("iws", C.c_double * 9), ("to_out", C.c_float * 9), ("to_work", C.c_float * 9)]
 
 
+class PipelineParams(C.Structure):
+    pass
+
+
 class DenoiseToolParams(C.Structure):
     _fields_ = [("dn", DenoiseParams), ("smoothing_enabled", C.c_int32), ("guided_chroma_radius", C.c_int32),
                 ("nl_strength", C.c_int32), ("nl_detail", C.c_int32)]
 
+
+PipelineParams._fields_ = [
+    ("sensor", C.c_int32), ("bayer_method", C.c_int32), ("filters", C.c_uint32), ("initial_gain", C.c_double),
+    ("xtrans_passes", C.c_int32), ("xtrans", C.c_int32 * 36), ("rgb_cam", C.c_float * 12), ("border", C.c_int32),
+    ("mul", C.c_float * 3), ("do_clip", C.c_int32), ("has_cam_to_work", C.c_int32), ("cam_to_work", C.c_double * 9),
+    ("ws", C.c_double * 9), ("iws", C.c_double * 9), ("denoise_enabled", C.c_int32), ("denoise", DenoiseToolParams),
+    ("exposure_enabled", C.c_int32), ("expcomp", C.c_double), ("black", C.c_double), ("tone_enabled", C.c_int32),
+    ("tone_mode", C.c_int32), ("tone_lut", C.POINTER(C.c_float)), ("white_point", C.c_float), ("to_out", C.c_float * 9),
+    ("to_work", C.c_float * 9), ("scale", C.c_double)]
 
 DN_SKIP_DETAIL_RECOVERY = 1
 # the chroma noise curve ImProcFunctions::denoise always installs (ipdenoise.cc:1139-1149)
@@ -106,6 +119,8 @@ def _load():
     lib.artgpu_nlmeans.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_float, C.c_int, C.c_int, C.c_float]
     lib.artgpu_improc_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseToolParams), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
                                           C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_uint32]
+    lib.artgpu_pipeline_run.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
+    lib.artgpu_batch_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
     lib.artgpu_demosaic_xtrans.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Plane), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(RGB)]
     lib.artgpu_tone_curve_neutral.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.c_float, C.POINTER(NeutralState)]
     lib.artgpu_noise_curve_lut.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -127,7 +142,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -226,6 +241,13 @@ class Context:
 
     def nlmeans(self, img: Plane, strength: int = 50, detail: int = 80, scale: float = 1.0, normcoeff: float = 65535.0):
         self._chk(LIB.artgpu_nlmeans(self._h, C.byref(img), normcoeff, strength, detail, scale))
+
+    def pipeline_run(self, raw: Plane, params: PipelineParams, out: RGB):
+        self._chk(LIB.artgpu_pipeline_run(self._h, C.byref(raw), C.byref(params), C.byref(out)))
+
+    def batch_run(self, raws, params: PipelineParams, outs):
+        n = len(raws)
+        self._chk(LIB.artgpu_batch_run(self._h, n, (Plane * n)(*raws), C.byref(params), (RGB * n)(*outs)))
 
     def demosaic_xtrans(self, passes: int, use_cielab: bool, raw: Plane, xtrans, rgb_cam, out: RGB):
         xt = np.ascontiguousarray(xtrans, dtype=np.int32).reshape(36)

@@ -632,7 +632,7 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_NSLOTS };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_NSLOTS };
 static_assert(P_NSLOTS <= artgpu_ctx::NPOOL, "grow artgpu_ctx::pool");
 
 struct DevDecomp {
@@ -1411,6 +1411,70 @@ int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise
         }
     }
     if (ecomp > 0 && !fuse_post) { if ((rc = artgpu_exposure(ctx, img, (float)std::pow(2.0, -ecomp), 0.f))) return rc; }         // L1181-1184
+    return ARTGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one frame / one batch share through the whole path
+// ---------------------------------------------------------------------------------------------
+int artgpu_pipeline_run(artgpu_ctx *ctx, const artgpu_plane *raw, const artgpu_pipeline_params *p, artgpu_rgb *out)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!plane_ok(raw) || !p || !out) return fail(ctx, ARTGPU_EINVAL, "pipeline_run: null/bad argument");
+    const int W = raw->w, H = raw->h, b = p->border;
+    if (b < 0 || W - 2 * b < 8 || H - 2 * b < 8) return fail(ctx, ARTGPU_EINVAL, "pipeline_run: border %d leaves no image", b);
+    if (out->r.w != W - 2 * b || out->r.h != H - 2 * b) return fail(ctx, ARTGPU_EINVAL, "pipeline_run: output must be %dx%d", W - 2 * b, H - 2 * b);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    // demosaiced planes live in the context pool (never leave the device)
+    float *pl[3];
+    for (int k = 0; k < 3; ++k)
+        if ((rc = pool_get(ctx, P_PIPE_R + k, (size_t)W * H * 4, &pl[k]))) return rc;
+    artgpu_rgb dem;
+    artgpu_plane *dp[3] = {&dem.r, &dem.g, &dem.b};
+    for (int k = 0; k < 3; ++k) { dp[k]->p = pl[k]; dp[k]->w = W; dp[k]->h = H; dp[k]->row_stride_bytes = (int64_t)W * 4; dp[k]->on_device = 1; }
+    if (p->sensor == 0) rc = artgpu_demosaic_bayer(ctx, p->bayer_method, raw, p->filters, p->initial_gain, b, &dem);
+    else rc = artgpu_demosaic_xtrans(ctx, p->xtrans_passes, p->xtrans_passes > 1 ? 1 : 0, raw, p->xtrans, p->rgb_cam, &dem);
+    if (rc) return rc;
+    // the image the remaining stages work on: the caller's planes if they are on the device, else a staged copy
+    DevRGB d;
+    if ((rc = bind_rgb(ctx, out, 4, false, &d, "pipeline_run(out)"))) return rc;
+    artgpu_rgb img;
+    artgpu_plane *ip[3] = {&img.r, &img.g, &img.b};
+    for (int k = 0; k < 3; ++k) { ip[k]->p = d.p[k]; ip[k]->w = d.w; ip[k]->h = d.h; ip[k]->row_stride_bytes = (int64_t)d.stride * 4; ip[k]->on_device = 1; }
+    if ((rc = artgpu_get_image(ctx, &dem, b, b, p->mul, p->do_clip, p->has_cam_to_work ? p->cam_to_work : nullptr, &img))) return rc;
+    if (p->denoise_enabled) {
+        static const double curve_points[9] = {1 /*FCT_MinMaxCPoints*/, 0.05, 0.50, 0.35, 0.35, 0.35, 0.05, 0.35, 0.35};   // ipdenoise.cc:1139-1149
+        float curve[501];
+        (void)noise_curve_lut(curve_points, 9, curve);
+        const double ecomp = p->exposure_enabled ? p->expcomp : 0.0;       // ipdenoise.cc:1155
+        if ((rc = artgpu_improc_denoise(ctx, &img, &p->denoise, p->ws, p->iws, ecomp, p->scale > 0 ? p->scale : 1.0,
+                                        p->has_cam_to_work ? p->cam_to_work : nullptr, curve, 0u)))
+            return rc;
+    }
+    if (p->exposure_enabled)
+        if ((rc = artgpu_exposure(ctx, &img, (float)std::pow(2.0, p->expcomp), (float)(p->black * 2000.0)))) return rc;
+    if (p->tone_enabled) {
+        if (p->tone_mode == ARTGPU_TONE_NEUTRAL) {
+            artgpu_neutral_state st;
+            for (int k = 0; k < 9; ++k) { st.ws[k] = p->ws[k]; st.iws[k] = p->iws[k]; st.to_out[k] = p->to_out[k]; st.to_work[k] = p->to_work[k]; }
+            rc = artgpu_tone_curve_neutral(ctx, &img, p->tone_lut, p->white_point, &st);
+        } else {
+            rc = artgpu_tone_curve(ctx, &img, p->tone_mode, p->tone_lut, p->white_point, 1);
+        }
+        if (rc) return rc;
+    }
+    return unbind_rgb(ctx, out, &d);
+}
+
+int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, const artgpu_pipeline_params *params, artgpu_rgb *outs)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (nframes < 0 || (nframes && (!raws || !params || !outs))) return fail(ctx, ARTGPU_EINVAL, "batch_run: null argument");
+    for (int f = 0; f < nframes; ++f) {
+        const int rc = artgpu_pipeline_run(ctx, &raws[f], params, &outs[f]);
+        if (rc) return rc;
+    }
     return ARTGPU_OK;
 }
 

@@ -246,6 +246,44 @@ typedef struct {
 int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_tool_params *params, const double ws[9], const double *iws /* LAB mode only */,
                           double ecomp, double scale, const double *calclum_mat, const float *noise_c_curve, uint32_t flags);
 
+/* The whole hot path for one frame in one call -- what ART's batch loop does per image between load and rgb2out
+ * (simpleprocess.cc stage_init L215-259, stage_denoise L311-315, stage_finish L389-396):
+ *   demosaic -> getImage (crop `border`, x mul, clip) + convertColorSpace matrix -> ImProcFunctions::denoise ->
+ *   ImProcFunctions::exposure -> ImProcFunctions::toneCurve.
+ * raw: CFA plane (host or device).  out: (W - 2*border) x (H - 2*border) planes (host or device; the frame stays on the device
+ * between the stages either way).  Disabled stages are skipped exactly like their `enabled == false` early-outs. */
+typedef struct {
+    int32_t sensor;                 /* 0 = Bayer, 1 = X-Trans */
+    int32_t bayer_method;           /* ARTGPU_BAYER_* */
+    uint32_t filters;
+    double initial_gain;
+    int32_t xtrans_passes;          /* 1 (ONE_PASS) or 3 (THREE_PASS, CIELab) */
+    int32_t xtrans[36];
+    float rgb_cam[12];
+    int32_t border;                 /* raw.bayersensor.border / raw.xtranssensor.border */
+    float mul[3];                   /* rm, gm, bm of getImage */
+    int32_t do_clip;
+    int32_t has_cam_to_work;
+    double cam_to_work[9];          /* matrix branch of convertColorSpace */
+    double ws[9], iws[9];           /* working space <-> XYZ (TMatrix) */
+    int32_t denoise_enabled;
+    artgpu_denoise_tool_params denoise;
+    int32_t exposure_enabled;
+    double expcomp, black;
+    int32_t tone_enabled;
+    int32_t tone_mode;              /* ARTGPU_TONE_STD / ARTGPU_TONE_NEUTRAL */
+    const float *tone_lut;          /* 65536 entries (host) */
+    float white_point;
+    float to_out[9], to_work[9];    /* NEUTRAL only */
+    double scale;
+} artgpu_pipeline_params;
+int artgpu_pipeline_run(artgpu_ctx *ctx, const artgpu_plane *raw, const artgpu_pipeline_params *params, artgpu_rgb *out);
+
+/* This rank's share of a batch: frames are independent (batchProcessingThread handles them one after another,
+ * simpleprocess.cc:586-612), so a multi-GPU batch is one context per GPU each running its own frames; the completion
+ * barrier / gather lives in the host driver (bench.py, art_amd/batch.py), not in the data path. */
+int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, const artgpu_pipeline_params *params, artgpu_rgb *outs);
+
 /* Bytes of device scratch the context currently holds (arena + staging). */
 size_t artgpu_scratch_bytes(const artgpu_ctx *ctx);
 
