@@ -17,6 +17,7 @@
 //       vcd: row rr reads the UPDATED row rr-2 -> one lane per column, sequential in rows;
 //   P9  hvwt / P13 pmwt: row rr reads the updated row rr-1 -> row loop with a barrier per row.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "devmath.h"
 #include "kernels.h"
 
@@ -29,7 +30,6 @@ constexpr int v1 = ts, v2 = 2 * ts, v3 = 3 * ts;
 constexpr int p1 = -ts + 1, p2 = -2 * ts + 2, p3 = -3 * ts + 3;
 constexpr int m1 = ts + 1, m2 = 2 * ts + 2, m3 = 3 * ts + 3;
 constexpr int F = ts * ts, Hh = ts * tsh, GAP = 32;
-constexpr int NT = AMAZE_THREADS;
 
 // arena offsets in floats (amaze_demosaic_RT.cc:124-174)
 constexpr int O_rgbgreen = 0;
@@ -55,7 +55,7 @@ static_assert(ARENA_FLOATS == AMAZE_ARENA_FLOATS, "arena size mismatch with kern
 constexpr float eps = 1e-5f, epssq = 1e-10f, arthresh = 0.75f;
 
 #define FOR_ITEMS(R0, R1, N)                                                         \
-    for (int _n = (N), _tot = ((R1) > (R0) ? ((R1) - (R0)) : 0) * _n, _t = tid; _t < _tot; _t += NT) \
+    for (int _n = (N), _tot = ((R1) > (R0) ? ((R1) - (R0)) : 0) * _n, _t = tid; _t < _tot; _t += NTT) \
         for (int rr = (R0) + _t / _n, it = _t - (rr - (R0)) * _n, _once = 1; _once; _once = 0)
 
 // highlight bounding of a colour difference (amaze_demosaic_RT.cc:555-581)
@@ -115,13 +115,36 @@ __device__ __forceinline__ float g_bound(float Gint, float rb, float nA, float n
 } // namespace
 
 #ifndef AMAZE_MIN_WAVES
-#define AMAZE_MIN_WAVES 6   // 512 threads x 3 workgroups per CU (51 KB LDS plane each) = 6 waves per SIMD: <= 80 VGPRs (some spill); measured best of {256,384,512,640,768,1024} x {3..8}
+#define AMAZE_MIN_WAVES 6   // fused kernel: 512 threads x 3 workgroups per CU (51 KB LDS plane each) = 6 waves per SIMD: <= 80 VGPRs (some spill); measured best of {256,384,512,640,768,1024} x {3..8}
 #endif
-__global__ void __launch_bounds__(AMAZE_THREADS, AMAZE_MIN_WAVES)
-amaze_tiles_kernel(AmazeArgs a)
+// LDS plane of the row-recurrence / site-list phases: allocated only in the kernels that contain one of them
+template <bool NEED>
+__device__ __forceinline__ float *lds_plane()
 {
-    const int tid = threadIdx.x;
-    float *const A = a.arena + (size_t)blockIdx.x * AMAZE_ARENA_FLOATS;
+    if constexpr (NEED) {
+        __shared__ float buf[ts * tsh];
+        return buf;
+    } else {
+        return nullptr;
+    }
+}
+constexpr int AMAZE_NPHASES = 20;
+
+// The tile algorithm as 20 phases.  amaze_kernel<FIRST, LAST, G, MINW> runs phases FIRST..LAST of one tile with G workgroups
+// per tile (G > 1 only for phases that are plain parallel loops).  <0, 19, 1, 6> is the fused one-workgroup-per-tile kernel
+// (barriers between phases, the default); <k, k, G, 1> is phase k alone over all tiles (ARTGPU_AMAZE_SPLIT=1: one launch per
+// phase, every tile keeps its arena in HBM between launches) -- same results, used to profile the phases individually.
+template <int FIRST, int LAST, int G, int MINW>
+__global__ void __launch_bounds__(AMAZE_THREADS, MINW)
+amaze_kernel(AmazeArgs a)
+{
+#define RUN(k) ((k) >= FIRST && (k) <= LAST)
+#define SYNC_AFTER(k) do { if constexpr (RUN(k) && RUN((k) + 1)) __syncthreads(); } while (0)
+    constexpr int NTT = AMAZE_THREADS * G;
+    const int tid = threadIdx.x + (G > 1 ? (int)(blockIdx.x % G) * AMAZE_THREADS : 0);
+    float *const A = a.arena + (size_t)(blockIdx.x / G) * AMAZE_ARENA_FLOATS;
+    int *const bbox = a.bbox + (size_t)(blockIdx.x / G) * 4;   // nyquist bounding box of the tile (min row, max row, min col, max col)
+    float *const s_plane = lds_plane<RUN(10) || RUN(11) || RUN(15)>();
     float *const rgbgreen = A + O_rgbgreen, *const delhvsqsum = A + O_delhvsqsum;
     float *const dirwts0 = A + O_dirwts0, *const dirwts1 = A + O_dirwts1;
     float *const vcd = A + O_vcd, *const hcd = A + O_hcd, *const vcdalt = A + O_vcdalt, *const hcdalt = A + O_hcdalt;
@@ -142,9 +165,8 @@ amaze_tiles_kernel(AmazeArgs a)
     const float *const raw = a.raw;
     const size_t rs = a.raw_stride;
 
-    __shared__ int s_red[4]; // min row, max row, min col, max col of nyquist flags
-    __shared__ float s_plane[ts * tsh];   // P9 / P13: half-resolution weight plane; P8: list of flagged sites
-    __shared__ int s_count;
+    __shared__ int s_red[5]; // min row, max row, min col, max col of nyquist flags; [4] = P8 site count
+    int &s_count = s_red[4];
 
     int ex, ey;
     if (fc(filters, 0, 0) == 1) {
@@ -153,15 +175,7 @@ amaze_tiles_kernel(AmazeArgs a)
         if (fc(filters, 0, 0) == 0) { ey = 0; ex = 0; } else { ey = 1; ex = 1; }
     }
 
-    // per-barrier timestamps of workgroup 0 (build with -DARTGPU_AMAZE_PROFILE, run with ARTGPU_AMAZE_PROF=<file>): how the
-    // phase costs of profiles/r1/amaze_phase_profile.txt were measured
-#ifdef ARTGPU_AMAZE_PROFILE
-    int _pk = 0;
-#define PROF() do { if (a.prof && tid == 0 && blockIdx.x == 0 && _pk < 1000) a.prof[_pk] = wall_clock64(); ++_pk; } while (0)
-#else
-#define PROF() do { } while (0)
-#endif
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x / G; tile < a.ntiles; tile += gridDim.x / G) {
         const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
         const int top = -16 + ty * (ts - 32), left = -16 + tx * (ts - 32);
         const int bottom = min(top + ts, height + 16), right = min(left + ts, width + 16);
@@ -170,6 +184,8 @@ amaze_tiles_kernel(AmazeArgs a)
         const int rrmax = bottom > height ? height - top : rr1;
         const int ccmax = right > width ? width - left : cc1;
 
+        // ======== phase 0: clear what has to be cleared, tile initialisation ========
+        if constexpr (RUN(0)) {
         // ---- zero the arena (fresh-calloc semantics) ----
         {
             constexpr int NREG = 17;
@@ -181,63 +197,65 @@ amaze_tiles_kernel(AmazeArgs a)
             for (int r = 0; r < NREG; ++r)
                 if ((zmask >> r) & 1u) {
                     float4 *A4 = reinterpret_cast<float4 *>(A + reg_off[r]);
-                    for (int i = tid; i < (reg_off[r + 1] - reg_off[r]) / 4; i += NT) A4[i] = z;
+                    for (int i = tid; i < (reg_off[r + 1] - reg_off[r]) / 4; i += NTT) A4[i] = z;
                 }
-            if (tid == 0) { s_red[0] = 1 << 30; s_red[1] = 0; s_red[2] = ts + 1; s_red[3] = 0; }
+            if (tid == 0) { bbox[0] = 1 << 30; bbox[1] = 0; bbox[2] = ts + 1; bbox[3] = 0; }
         }
-        __syncthreads(); PROF();
+        __syncthreads();
 
         // ---- tile initialisation (L205-334), in the reference's write order ----
 #define SETCFA(i, v) do { float t_ = (v) / 65535.f; cfa[i] = t_; rgbgreen[i] = t_; } while (0)
 #define RAW(r, c) raw[(size_t)(r) * rs + (c)]
         if (rrmin > 0) {
             const int n = ccmax - ccmin;
-            for (int t = tid; t < 16 * n; t += NT) { int rr = t / n, cc = ccmin + t - rr * n; SETCFA(rr * ts + cc, RAW(32 - rr + top, cc + left)); }
+            for (int t = tid; t < 16 * n; t += NTT) { int rr = t / n, cc = ccmin + t - rr * n; SETCFA(rr * ts + cc, RAW(32 - rr + top, cc + left)); }
         }
         {
             const int n = ccmax - ccmin, nr = rrmax - rrmin;
-            for (int t = tid; t < nr * n; t += NT) { int rr = rrmin + t / n, cc = ccmin + t % n; SETCFA(rr * ts + cc, RAW(rr + top, cc + left)); }
+            for (int t = tid; t < nr * n; t += NTT) { int rr = rrmin + t / n, cc = ccmin + t % n; SETCFA(rr * ts + cc, RAW(rr + top, cc + left)); }
         }
-        __syncthreads(); PROF();
+        __syncthreads();
         if (rrmax < rr1) {
             const int n = ccmax - ccmin;
-            for (int t = tid; t < 16 * n; t += NT) { int rr = t / n, cc = ccmin + t - rr * n; SETCFA((rrmax + rr) * ts + cc, RAW(height - rr - 2, left + cc)); }
+            for (int t = tid; t < 16 * n; t += NTT) { int rr = t / n, cc = ccmin + t - rr * n; SETCFA((rrmax + rr) * ts + cc, RAW(height - rr - 2, left + cc)); }
         }
-        __syncthreads(); PROF();
+        __syncthreads();
         if (ccmin > 0) {
             const int nr = rrmax - rrmin;
-            for (int t = tid; t < nr * 16; t += NT) { int rr = rrmin + (t >> 4), cc = t & 15; SETCFA(rr * ts + cc, RAW(rr + top, 32 - cc + left)); }
+            for (int t = tid; t < nr * 16; t += NTT) { int rr = rrmin + (t >> 4), cc = t & 15; SETCFA(rr * ts + cc, RAW(rr + top, 32 - cc + left)); }
         }
-        __syncthreads(); PROF();
+        __syncthreads();
         if (ccmax < cc1) {
             const int nr = rrmax - rrmin;
-            for (int t = tid; t < nr * 16; t += NT) { int rr = rrmin + (t >> 4), cc = t & 15; SETCFA(rr * ts + ccmax + cc, RAW(top + rr, width - cc - 2)); }
+            for (int t = tid; t < nr * 16; t += NTT) { int rr = rrmin + (t >> 4), cc = t & 15; SETCFA(rr * ts + ccmax + cc, RAW(top + rr, width - cc - 2)); }
         }
-        __syncthreads(); PROF();
+        __syncthreads();
         if (tid < 256) {
             const int rr = tid >> 4, cc = tid & 15;
             if (rrmin > 0 && ccmin > 0) SETCFA(rr * ts + cc, RAW(32 - rr, 32 - cc));
         }
-        __syncthreads(); PROF();
+        __syncthreads();
         if (tid < 256) {
             const int rr = tid >> 4, cc = tid & 15;
             if (rrmax < rr1 && ccmax < cc1) SETCFA((rrmax + rr) * ts + ccmax + cc, RAW(height - rr - 2, width - cc - 2));
         }
-        __syncthreads(); PROF();
+        __syncthreads();
         if (tid < 256) {
             const int rr = tid >> 4, cc = tid & 15;
             if (rrmin > 0 && ccmax < cc1) SETCFA(rr * ts + ccmax + cc, RAW(32 - rr, width - cc - 2));
         }
-        __syncthreads(); PROF();
+        __syncthreads();
         if (tid < 256) {
             const int rr = tid >> 4, cc = tid & 15;
             if (rrmax < rr1 && ccmin > 0) SETCFA((rrmax + rr) * ts + cc, RAW(height - rr - 2, 32 - cc));
         }
 #undef SETCFA
 #undef RAW
-        __syncthreads(); PROF();
+        }
+        SYNC_AFTER(0);
 
         // ---- P1: gradients (L342-351); 4-lane groups over [0, cc1) ----
+        if constexpr (RUN(1))
         FOR_ITEMS(2, rr1 - 2, 4 * ngroups(0, cc1, 4)) {
             const int i = rr * ts + it;
             const float c0 = cfa[i];
@@ -247,9 +265,10 @@ amaze_tiles_kernel(AmazeArgs a)
             dirwts0[i] = eps + fabsf(cfa[i + v2] - c0) + fabsf(c0 - cfa[i - v2]) + delv;
             delhvsqsum[i] = sqr(delh) + sqr(delv);
         }
-        __syncthreads(); PROF();
+        SYNC_AFTER(1);
 
         // ---- P2: vertical/horizontal colour differences (L380-434) ----
+        if constexpr (RUN(2))
         FOR_ITEMS(4, rr1 - 4, 4 * ngroups(4, cc1 - 7, 4)) {
             const int cc = 4 + it, i = rr * ts + cc;
             const float sgn = (fc(filters, rr, cc) & 1) ? -1.f : 1.f;
@@ -286,13 +305,14 @@ amaze_tiles_kernel(AmazeArgs a)
             dgintv[i] = sse_min(sqr(guha - gdha), sqr(guar - gdar));
             dginth[i] = sse_min(sqr(glha - grha), sqr(glar - grar));
         }
-        __syncthreads(); PROF();
+        SYNC_AFTER(2);
 
         // ---- P3: variance choice + highlight bounding, in place in the reference (L540-583) ----
         const int ng3 = ngroups(4, cc1 - 4, 4);
         float *const Thi = Dgrbsq1m; // new hcd of lanes 2,3 (plane is free until P11)
         float *const Tlo = Dgrbsq1p; // new hcd of lanes 0,1
         // 3a: lanes 2,3 read only original hcd
+        if constexpr (RUN(3))
         FOR_ITEMS(4, rr1 - 4, 2 * ng3) {
             const int g = it >> 1, k = 2 + (it & 1), cc = 4 + 4 * g + k, i = rr * ts + cc;
             const float sgn = (fc(filters, rr, cc) & 1) ? -1.f : 1.f;
@@ -303,8 +323,9 @@ amaze_tiles_kernel(AmazeArgs a)
             hcdv = hav < hv ? ha : hcdv;
             Thi[rr * tsh + it] = bound_cd(hcdv, sgn, cfa[i], cfa[i - 1], cfa[i + 1], clip_pt);
         }
-        __syncthreads(); PROF();
+        SYNC_AFTER(3);
         // 3b: lanes 0,1 read the previous group's updated lanes 2,3 at i-2
+        if constexpr (RUN(4)) {
         FOR_ITEMS(4, rr1 - 4, 2 * ng3) {
             const int g = it >> 1, k = it & 1, cc = 4 + 4 * g + k, i = rr * ts + cc;
             const float sgn = (fc(filters, rr, cc) & 1) ? -1.f : 1.f;
@@ -317,7 +338,7 @@ amaze_tiles_kernel(AmazeArgs a)
             Tlo[rr * tsh + it] = bound_cd(hcdv, sgn, cfa[i], cfa[i - 1], cfa[i + 1], clip_pt);
         }
         // 3c: vcd, one lane per column, rows in order (row rr reads the updated row rr-2)
-        for (int t = tid; t < 4 * ng3; t += NT) {
+        for (int t = tid; t < 4 * ng3; t += NTT) {
             const int cc = 4 + t;
             float n2 = vcd[2 * ts + cc], n1 = vcd[3 * ts + cc];
             float o0 = vcd[4 * ts + cc], o1 = vcd[5 * ts + cc];
@@ -338,17 +359,20 @@ amaze_tiles_kernel(AmazeArgs a)
                 cm1 = c0; c0 = cp1;
             }
         }
-        __syncthreads(); PROF();
+        }
+        SYNC_AFTER(4);
         // 3d: commit hcd, cddiffsq
+        if constexpr (RUN(5))
         FOR_ITEMS(4, rr1 - 4, 4 * ng3) {
             const int g = it >> 2, k = it & 3, cc = 4 + it, i = rr * ts + cc;
             const float h = (k < 2) ? Tlo[rr * tsh + 2 * g + k] : Thi[rr * tsh + 2 * g + (k - 2)];
             hcd[i] = h;
             cddiffsq[i] = sqr(vcd[i] - h);
         }
-        __syncthreads(); PROF();
+        SYNC_AFTER(5);
 
         // ---- P4: h/v weight at R/B sites (L680-728) ----
+        if constexpr (RUN(6)) {
         FOR_ITEMS(6, rr1 - 6, 4 * ngroups(6, cc1 - 6, 8)) {
             const int par = fc(filters, rr, 2) & 1;
             if (it < 4 * ngroups(6 + par, cc1 - 6, 8)) {
@@ -415,9 +439,13 @@ amaze_tiles_kernel(AmazeArgs a)
                 }
             }
         }
-        __syncthreads(); PROF();
+        }
+        SYNC_AFTER(6);
 
-        // ---- P6: nyquist flags + bounding box (L806-825) ----
+        // ---- P6: nyquist flags + bounding box (L806-825): per-workgroup box in LDS, merged into the tile's box in HBM ----
+        if constexpr (RUN(7)) {
+        if (threadIdx.x == 0) { s_red[0] = 1 << 30; s_red[1] = 0; s_red[2] = ts + 1; s_red[3] = 0; }
+        __syncthreads();
         FOR_ITEMS(6, rr1 - 6, ngroups(6, cc1 - 6, 2)) {
             const int cc = 6 + (fc(filters, rr, 2) & 1) + 2 * it;
             if (cc < cc1 - 6) {
@@ -431,24 +459,45 @@ amaze_tiles_kernel(AmazeArgs a)
                 }
             }
         }
-        __syncthreads(); PROF();
-        int nystartrow = s_red[0] == (1 << 30) ? 0 : s_red[0];
-        int nyendrow = s_red[1], nystartcol = s_red[2], nyendcol = s_red[3];
-        const bool doNyquist = nystartrow != nyendrow && nystartcol != nyendcol;
-        if (doNyquist) {
-            nyendrow++;
-            nyendcol++;
-            nystartcol -= (nystartcol & 1);
-            nystartrow = max(8, nystartrow);
-            nyendrow = min(rr1 - 8, nyendrow);
-            nystartcol = max(8, nystartcol);
-            nyendcol = min(cc1 - 8, nyendcol);
-            // memset(&nyquist2[4*tsh], 0, (ts-8)*tsh) (L879)
-            {
-                unsigned *w = reinterpret_cast<unsigned *>(nyquist2 + 4 * tsh);
-                for (int t = tid; t < (ts - 8) * tsh / 4; t += NT) w[t] = 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicMin(&bbox[0], s_red[0]); atomicMax(&bbox[1], s_red[1]);
+            atomicMin(&bbox[2], s_red[2]); atomicMax(&bbox[3], s_red[3]);
+        }
+        }
+        SYNC_AFTER(7);
+        // the tile's box: in a kernel that starts after phase 7 it comes from HBM (all workgroups of phase 7 have finished);
+        // in the fused kernel the single workgroup's LDS copy already is the tile's box
+        int nystartrow = 0, nyendrow = 0, nystartcol = 0, nyendcol = 0;
+        bool doNyquist = false;
+        if constexpr (LAST >= 8) {
+            if constexpr (FIRST >= 8) {
+                if (threadIdx.x < 4) s_red[threadIdx.x] = bbox[threadIdx.x];
+                __syncthreads();
             }
-            __syncthreads(); PROF();
+            nystartrow = s_red[0] == (1 << 30) ? 0 : s_red[0];
+            nyendrow = s_red[1]; nystartcol = s_red[2]; nyendcol = s_red[3];
+            doNyquist = nystartrow != nyendrow && nystartcol != nyendcol;
+            if (doNyquist) {
+                nyendrow++;
+                nyendcol++;
+                nystartcol -= (nystartcol & 1);
+                nystartrow = max(8, nystartrow);
+                nyendrow = min(rr1 - 8, nyendrow);
+                nystartcol = max(8, nystartcol);
+                nyendcol = min(cc1 - 8, nyendcol);
+            }
+        }
+        // ---- phase 8: memset(&nyquist2[4*tsh], 0, (ts-8)*tsh) (L879)
+        if constexpr (RUN(8)) {
+            if (doNyquist) {
+                unsigned *w = reinterpret_cast<unsigned *>(nyquist2 + 4 * tsh);
+                for (int t = tid; t < (ts - 8) * tsh / 4; t += NTT) w[t] = 0u;
+            }
+        }
+        SYNC_AFTER(8);
+        if constexpr (RUN(9)) {
+            if (doNyquist)
             // ---- P7: majority vote with byte offsets independent of the row parity (L888-901) ----
             // four flags per item through aligned 32-bit accesses (byte-wise global loads/stores made this the slowest
             // phase of the tile); per-byte logic unchanged
@@ -471,19 +520,22 @@ amaze_tiles_kernel(AmazeArgs a)
                 }
                 *reinterpret_cast<unsigned *>(nyquist2 + b) = outw;
             }
-            __syncthreads(); PROF();
+        }
+        SYNC_AFTER(9);
+        if constexpr (RUN(10)) {
+          if (doNyquist) {      // uniform over the workgroup
             // ---- P8: area interpolation (L914-951).  Flagged sites are sparse: compact them into an LDS list first so
             // that the 7x7 gather loop runs with full waves instead of once per wave that contains a flag ----
             int *const s_list = reinterpret_cast<int *>(s_plane);
             if (tid == 0) s_count = 0;
-            __syncthreads(); PROF();
+            __syncthreads();
             FOR_ITEMS(nystartrow, nyendrow, ngroups(nystartcol, nyendcol, 2)) {
                 const int cc = nystartcol + (fc(filters, rr, 2) & 1) + 2 * it;
                 const int i = rr * ts + cc;
                 if (cc < nyendcol && nyquist2[i >> 1]) s_list[atomicAdd(&s_count, 1)] = i;   // at most (ts-16)*(ts-16)/2 entries
             }
-            __syncthreads(); PROF();
-            for (int q = tid, nq = s_count; q < nq; q += NT) {
+            __syncthreads();
+            for (int q = tid, nq = s_count; q < nq; q += NTT) {
                 const int i = s_list[q];
                 float sumcfa = 0.f, sumh = 0.f, sumv = 0.f, sumsqh = 0.f, sumsqv = 0.f, areawt = 0.f;
                 for (int ai = -6; ai < 7; ai += 2) {
@@ -507,15 +559,17 @@ amaze_tiles_kernel(AmazeArgs a)
                 const float vcdvar = epssq + fabsf(areawt * sumsqv - sumv * sumv);
                 hvwt[i >> 1] = hcdvar / (vcdvar + hcdvar);
             }
+          }
         }
-        __syncthreads(); PROF();
+        SYNC_AFTER(10);
 
         // ---- P9: hvwt refined in place, row by row; G at R/B sites (L957-974) ----
         // The row recurrence only involves hvwt (row rr reads the updated row rr-1 and the old row rr+1): the half-resolution
         // plane is staged in LDS, ONE wave walks the rows with wave-level ordering only (no workgroup barrier per row), and
         // everything that merely consumes the refined weight runs afterwards as a parallel pass.
-        for (int t = tid; t < ts * tsh; t += NT) s_plane[t] = hvwt[t];
-        __syncthreads(); PROF();
+        if constexpr (RUN(11)) {
+        for (int t = tid; t < ts * tsh; t += NTT) s_plane[t] = hvwt[t];
+        __syncthreads();
         if (tid < 64) {
             for (int rr = 8; rr < rr1 - 8; ++rr) {
                 const int par = fc(filters, rr, 2) & 1;
@@ -532,7 +586,7 @@ amaze_tiles_kernel(AmazeArgs a)
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        __syncthreads(); PROF();
+        __syncthreads();
         FOR_ITEMS(8, rr1 - 8, 72) {
             const int cc = 8 + (fc(filters, rr, 2) & 1) + 2 * it;
             if (cc < cc1 - 8) {
@@ -548,9 +602,11 @@ amaze_tiles_kernel(AmazeArgs a)
                 Dgrb2[2 * (i >> 1) + 1] = ny ? sqr(gval - xdiv2f(rgbgreen[i - v1] + rgbgreen[i + v1])) : 0.f;
             }
         }
-        __syncthreads(); PROF();
+        }
+        SYNC_AFTER(11);
 
         // ---- P10: refine nyquist areas with the G curvature (L979-999) ----
+        if constexpr (RUN(12))
         if (doNyquist) {
             const float gq0 = 0.169917f, gq1 = 0.108947f, gq2 = 0.069855f, gq3 = 0.0287182f;
             // two sub-steps: the reference updates Dgrb0/rgbgreen of the site itself only and
@@ -577,9 +633,10 @@ amaze_tiles_kernel(AmazeArgs a)
                 }
             }
         }
-        __syncthreads(); PROF();
+        SYNC_AFTER(12);
 
         // ---- P11: diagonal gradients (L1004-1027); delp/delm overwrite cddiffsq/nyquist2 ----
+        if constexpr (RUN(13))
         FOR_ITEMS(6, rr1 - 6, 4 * ngroups(6, cc1 - 6, 8)) {
             const int i = rr * ts + 6 + 2 * it;
             const bool rbEven = (fc(filters, rr, 2) & 1) == 0;
@@ -593,9 +650,10 @@ amaze_tiles_kernel(AmazeArgs a)
             Dgrbsq1m[i >> 1] = sm;
             Dgrbsq1p[i >> 1] = sp;
         }
-        __syncthreads(); PROF();
+        SYNC_AFTER(13);
 
         // ---- P12: diagonal interpolation of R+B and plus/minus weight (L1061-1121) ----
+        if constexpr (RUN(14))
         FOR_ITEMS(8, rr1 - 8, 4 * ngroups(8, cc1 - 8, 8)) {
             const int par = fc(filters, rr, 2) & 1;
             if (it < 4 * ngroups(8 + par, cc1 - 8, 8)) {
@@ -629,11 +687,12 @@ amaze_tiles_kernel(AmazeArgs a)
                 pmwt[i1] = rbvarm / (rbvarp + rbvarm);
             }
         }
-        __syncthreads(); PROF();
+        SYNC_AFTER(14);
 
         // ---- P13: pmwt refined in place row by row, rbint (L1213-1223); same scheme as P9 ----
-        for (int t = tid; t < ts * tsh; t += NT) s_plane[t] = pmwt[t];
-        __syncthreads(); PROF();
+        if constexpr (RUN(15)) {
+        for (int t = tid; t < ts * tsh; t += NTT) s_plane[t] = pmwt[t];
+        __syncthreads();
         if (tid < 64) {
             for (int rr = 10; rr < rr1 - 10; ++rr) {
                 const int par = fc(filters, rr, 2) & 1;
@@ -648,7 +707,7 @@ amaze_tiles_kernel(AmazeArgs a)
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        __syncthreads(); PROF();
+        __syncthreads();
         FOR_ITEMS(10, rr1 - 10, 72) {
             const int par = fc(filters, rr, 2) & 1;
             if (it < 4 * ngroups(10 + par, cc1 - 10, 8)) {
@@ -658,9 +717,11 @@ amaze_tiles_kernel(AmazeArgs a)
                 rbint[i1] = 0.5f * (cfa[i] + intp(t, rbp[i1], rbm[i1]));
             }
         }
-        __syncthreads(); PROF();
+        }
+        SYNC_AFTER(15);
 
         // ---- P14: G re-interpolated from R+B where the diagonal weight is more decisive (L1241-1297) ----
+        if constexpr (RUN(16))
         FOR_ITEMS(12, rr1 - 12, 4 * ngroups(12, cc1 - 12, 8)) {
             const int par = fc(filters, rr, 2) & 1;
             if (it < 4 * ngroups(12 + par, cc1 - 12, 8)) {
@@ -685,13 +746,13 @@ amaze_tiles_kernel(AmazeArgs a)
                 }
             }
         }
-        __syncthreads(); PROF();
+        SYNC_AFTER(16);
 
         // ---- P15: split G-B out of G-R on the B rows (L1381-1386) ----
-        {
+        if constexpr (RUN(17)) {
             const int r0 = 13 - ey;
             const int nrow = rr1 - 12 > r0 ? (rr1 - 12 - r0 + 1) / 2 : 0;
-            for (int t = tid; t < nrow * tsh; t += NT) {
+            for (int t = tid; t < nrow * tsh; t += NTT) {
                 const int rr = r0 + 2 * (t / tsh), k = t % tsh;
                 const int i1 = ((rr * ts + 13 - ex) >> 1) + k;
                 if (i1 < ((rr * ts + cc1 - 12) >> 1)) {
@@ -700,9 +761,10 @@ amaze_tiles_kernel(AmazeArgs a)
                 }
             }
         }
-        __syncthreads(); PROF();
+        SYNC_AFTER(17);
 
         // ---- P16: chrominance at the opposite-colour sites (L1394-1408) ----
+        if constexpr (RUN(18))
         FOR_ITEMS(14, rr1 - 14, 4 * ngroups(14, cc1 - 14, 8)) {
             const int par = fc(filters, rr, 2) & 1;
             if (it < 4 * ngroups(14 + par, cc1 - 14, 8)) {
@@ -728,9 +790,10 @@ amaze_tiles_kernel(AmazeArgs a)
                 D[i >> 1] = val;
             }
         }
-        __syncthreads(); PROF();
+        SYNC_AFTER(18);
 
         // ---- P17/P18: write R, G, B for [16,rr1-16) x [16,cc1-16) (L1441-1565) ----
+        if constexpr (RUN(19))
         FOR_ITEMS(16, rr1 - 16, cc1 - 32 > 0 ? cc1 - 32 : 0) {
             const int cc = 16 + it, i = rr * ts + cc;
             const float gval = rgbgreen[i];
@@ -749,13 +812,51 @@ amaze_tiles_kernel(AmazeArgs a)
             a.blue[o] = sse_max(65535.f * b, 0.f);
             a.green[o] = sse_max(gval * 65535.f, 0.f);
         }
-        __syncthreads(); PROF();
+        if constexpr (G == 1) __syncthreads();   // fused kernel: the workgroup's next tile reuses the arena
     }
+#undef RUN
+#undef SYNC_AFTER
 }
+
+namespace {
+template <int K, int G>
+void launch_phase(const AmazeArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL((amaze_kernel<K, K, G, 1>), dim3(a.ntiles * G), dim3(AMAZE_THREADS), 0, stream, a);
+}
+} // namespace
 
 hipError_t launch_amaze(const AmazeArgs &a, int grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL(amaze_tiles_kernel, dim3(grid), dim3(AMAZE_THREADS), 0, stream, a);
+    // Default: the fused kernel (one workgroup walks a tile through all phases; 6.9 ms at 45 MP).  ARTGPU_AMAZE_SPLIT=1 launches
+    // one kernel per phase over all tiles instead (needs one arena per tile): bit-identical, 7.5 ms -- every phase then streams
+    // its planes of ALL tiles through HBM, which makes it the per-phase bandwidth profile of the algorithm
+    // (profiles/r1/amaze_split_phase_stats.csv) rather than the fast path.
+    const bool split = getenv("ARTGPU_AMAZE_SPLIT") != nullptr && grid >= a.ntiles;
+    if (!split) {
+        hipLaunchKernelGGL((amaze_kernel<0, AMAZE_NPHASES - 1, 1, AMAZE_MIN_WAVES>), dim3(grid), dim3(AMAZE_THREADS), 0, stream, a);
+        return hipGetLastError();
+    }
+    launch_phase<0, 1>(a, stream);    // clear + tile initialisation (ordered sub-steps)
+    launch_phase<1, 2>(a, stream);    // P1 gradients
+    launch_phase<2, 2>(a, stream);    // P2 colour differences
+    launch_phase<3, 2>(a, stream);    // P3a
+    launch_phase<4, 1>(a, stream);    // P3b + the vcd column walk
+    launch_phase<5, 2>(a, stream);    // P3d
+    launch_phase<6, 2>(a, stream);    // P4 + P5
+    launch_phase<7, 2>(a, stream);    // P6 flags + bounding box
+    launch_phase<8, 1>(a, stream);    // nyquist2 clear
+    launch_phase<9, 1>(a, stream);    // P7 vote
+    launch_phase<10, 1>(a, stream);   // P8 area interpolation (LDS site list)
+    launch_phase<11, 1>(a, stream);   // P9 hvwt row recurrence (LDS plane) + consumers
+    launch_phase<12, 2>(a, stream);   // P10
+    launch_phase<13, 2>(a, stream);   // P11
+    launch_phase<14, 2>(a, stream);   // P12
+    launch_phase<15, 1>(a, stream);   // P13 pmwt row recurrence (LDS plane) + consumers
+    launch_phase<16, 2>(a, stream);   // P14
+    launch_phase<17, 1>(a, stream);   // P15
+    launch_phase<18, 2>(a, stream);   // P16
+    launch_phase<19, 2>(a, stream);   // output
     return hipGetLastError();
 }
 

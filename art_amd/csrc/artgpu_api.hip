@@ -32,6 +32,8 @@ struct artgpu_ctx {
     float *pool[NPOOL] = {};
     size_t pool_bytes[NPOOL] = {};
     float fuse_pre = 0.f, fuse_post = 0.f;   // improc_denoise -> rgb_denoise: exposure compensation fused into rgb2yuv / yuv2rgb
+    float *bbox = nullptr; // AMaZE: per-tile nyquist bounding boxes
+    size_t bbox_bytes = 0;
     float *lut = nullptr; // 65536-entry tone LUT on the device
     size_t lut_bytes = 0;
     // timing
@@ -232,6 +234,7 @@ int artgpu_destroy(artgpu_ctx *ctx)
     for (int k = 0; k < artgpu_ctx::NSTAGE; ++k)
         if (ctx->stage[k]) (void)hipFree(ctx->stage[k]);
     if (ctx->lut) (void)hipFree(ctx->lut);
+    if (ctx->bbox) (void)hipFree(ctx->bbox);
     for (int k = 0; k < artgpu_ctx::NPOOL; ++k)
         if (ctx->pool[k]) (void)hipFree(ctx->pool[k]);
     for (int k = 0; k < 3; ++k)
@@ -316,33 +319,19 @@ int artgpu_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, 
         a.filters = filters;
         a.clip_pt = (float)(1.0 / initial_gain);   // amaze_demosaic_RT.cc:53-54
         a.clip_pt8 = (float)(0.8 / initial_gain);
-        a.prof = nullptr;
+        {
+            float *bb;
+            if ((rc = ensure(ctx, &ctx->bbox, &ctx->bbox_bytes, (size_t)grid * 4 * sizeof(int)))) return rc;
+            bb = ctx->bbox;
+            a.bbox = reinterpret_cast<int *>(bb);
+        }
         // Arena regions that have read-before-write positions on full tiles and therefore must be cleared per tile: vcd, hcd,
         // vcdalt, hcdalt, cddiffsq, nyquist (bits 4-8, 15).  Found by poisoning the arena and clearing all regions but one
         // (scripts/amaze_zmask.py; tests/test_gpu_demosaic.py re-checks it).  Partial edge tiles always clear everything.
         a.zero_mask = getenv("ARTGPU_AMAZE_ZMASK") ? (unsigned)strtoul(getenv("ARTGPU_AMAZE_ZMASK"), nullptr, 0) : 0x81f0u;
         if (getenv("ARTGPU_AMAZE_POISON"))   // test hook: fill the arenas with a byte pattern first
             HIPCHK(ctx, hipMemsetAsync(ctx->arena, (int)strtoul(getenv("ARTGPU_AMAZE_POISON"), nullptr, 0), (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float), ctx->stream));
-#ifdef ARTGPU_AMAZE_PROFILE
-        static long long *prof_dev = nullptr;
-        if (getenv("ARTGPU_AMAZE_PROF")) {
-            if (!prof_dev) HIPCHK(ctx, hipMalloc(&prof_dev, 1000 * 8));
-            HIPCHK(ctx, hipMemset(prof_dev, 0, 1000 * 8));
-            a.prof = prof_dev;
-        }
-#endif
         HIPCHK(ctx, launch_amaze(a, grid, ctx->stream));
-#ifdef ARTGPU_AMAZE_PROFILE
-        if (a.prof) {
-            static long long hp[1000];
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            HIPCHK(ctx, hipMemcpy(hp, prof_dev, sizeof(hp), hipMemcpyDeviceToHost));
-            if (FILE *f = fopen(getenv("ARTGPU_AMAZE_PROF"), "w")) {
-                for (int i = 0; i < 1000 && hp[i]; ++i) fprintf(f, "%d %lld\n", i, hp[i]);
-                fclose(f);
-            }
-        }
-#endif
         bord = border < 4 ? 3 : 0; // amaze_demosaic_RT.cc:1587-1589
     } else {
         const int tileSizeN = RCD_TS - 2 * RCD_BORDER;

@@ -26,10 +26,9 @@ struct AmazeArgs {
     int ntx, ntiles;
     unsigned filters;
     float clip_pt, clip_pt8;
-    long long *prof;
+    int *bbox;          // 4 ints per arena: nyquist bounding box of the tile
     unsigned zero_mask;
 };
-__global__ void amaze_tiles_kernel(AmazeArgs a);
 hipError_t launch_amaze(const AmazeArgs &a, int grid, hipStream_t stream);
 
 // ---- RCD (rcd.hip) ----

@@ -92,3 +92,16 @@ def test_amaze_selective_arena_clear_is_exact(gpu_ctx, monkeypatch):
         gpu_ctx.demosaic_bayer(capi.BAYER_AMAZE, capi.host_plane(raw), filt, 1.0, 4, capi.host_rgb(out))
         for o, r in zip(out, ref):
             assert np.array_equal(o.view(np.uint32), r.view(np.uint32))
+
+
+def test_amaze_phase_per_kernel_path_is_identical(gpu_ctx, monkeypatch):
+    """ARTGPU_AMAZE_SPLIT=1 runs the same 20 phases as one kernel launch each (profiling path): same bits."""
+    from art_amd import capi
+    w, h, filt = 904, 648, synth.FILTERS_GRBG
+    raw = synth.bayer_frame(w, h, filt, seed=23, noise=2500)
+    ref = oracle_lib.amaze(raw, filt, 1.0, 4)
+    monkeypatch.setenv("ARTGPU_AMAZE_SPLIT", "1")
+    out = [np.zeros((h, w), np.float32) for _ in range(3)]
+    gpu_ctx.demosaic_bayer(capi.BAYER_AMAZE, capi.host_plane(raw), filt, 1.0, 4, capi.host_rgb(out))
+    for o, r in zip(out, ref):
+        assert np.array_equal(o.view(np.uint32), r.view(np.uint32))
