@@ -192,7 +192,7 @@ def main() -> None:
             "completion_records": len(records),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "xtrans_tiles_kernel" if xtrans else "amaze_tiles_kernel" if method == capi.BAYER_AMAZE else "rcd_tiles_kernel",
+            "bound": "hbm", "kernel": "xtrans_tiles_kernel" if xtrans else "amaze_kernel<0, 19, 1, 6>" if method == capi.BAYER_AMAZE else "rcd_tiles_kernel",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": W * H * ALGO_BYTES_PER_PX,
