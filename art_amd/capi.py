@@ -119,6 +119,8 @@ def _load():
     lib.artgpu_nlmeans.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_float, C.c_int, C.c_int, C.c_float]
     lib.artgpu_improc_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseToolParams), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
                                           C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_uint32]
+    lib.artgpu_scale_colors.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_uint32,
+                                        C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Plane), C.POINTER(C.c_float)]
     lib.artgpu_pipeline_run.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
     lib.artgpu_batch_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
     lib.artgpu_demosaic_xtrans.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Plane), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(RGB)]
@@ -142,7 +144,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -241,6 +243,17 @@ class Context:
 
     def nlmeans(self, img: Plane, strength: int = 50, detail: int = 80, scale: float = 1.0, normcoeff: float = 65535.0):
         self._chk(LIB.artgpu_nlmeans(self._h, C.byref(img), normcoeff, strength, detail, scale))
+
+    def scale_colors(self, src: np.ndarray, filters: int, xtrans, cblacksom, scale_mul, dst: Plane):
+        """host uint16 / float32 sensor data -> scaled float CFA plane; returns chmax[4]"""
+        assert src.dtype in (np.uint16, np.float32) and src.flags.c_contiguous
+        h, w = src.shape
+        xt = None if xtrans is None else np.ascontiguousarray(xtrans, dtype=np.int32).reshape(36).ctypes.data_as(C.POINTER(C.c_int32))
+        cb = (C.c_float * 4)(*[float(v) for v in cblacksom]); sm = (C.c_float * 4)(*[float(v) for v in scale_mul])
+        mx = (C.c_float * 4)()
+        self._chk(LIB.artgpu_scale_colors(self._h, src.ctypes.data, w, h, src.strides[0], 1 if src.dtype == np.uint16 else 0, 0, filters, xt,
+                                          cb, sm, C.byref(dst), mx))
+        return [float(v) for v in mx]
 
     def pipeline_run(self, raw: Plane, params: PipelineParams, out: RGB):
         self._chk(LIB.artgpu_pipeline_run(self._h, C.byref(raw), C.byref(params), C.byref(out)))

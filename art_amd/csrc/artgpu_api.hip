@@ -1404,6 +1404,62 @@ int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise
 }
 
 // ---------------------------------------------------------------------------------------------
+// raw pre-stage (N2): copyOriginalPixels + scaleColors
+// ---------------------------------------------------------------------------------------------
+int artgpu_scale_colors(artgpu_ctx *ctx, const void *src, int32_t w, int32_t h, int64_t src_row_stride_bytes, int32_t src_is_u16,
+                        int32_t src_on_device, uint32_t filters, const int32_t *xtrans, const float cblacksom[4],
+                        const float scale_mul[4], artgpu_plane *dst, float chmax[4])
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    const int esz = src_is_u16 ? 2 : 4;
+    if (!src || !dst || !plane_ok(dst) || !cblacksom || !scale_mul || w <= 0 || h <= 0 || dst->w != w || dst->h != h ||
+        src_row_stride_bytes < (int64_t)w * esz || src_row_stride_bytes % esz)
+        return fail(ctx, ARTGPU_EINVAL, "scale_colors: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    ScaleArgs a = {};
+    a.w = w; a.h = h; a.src_u16 = src_is_u16 ? 1 : 0;
+    // source: device pointer as is, host buffer staged (2 or 4 bytes per pixel over PCIe)
+    if (src_on_device) { a.src = src; a.src_stride = (size_t)(src_row_stride_bytes / esz); }
+    else {
+        float *st;
+        if ((rc = pool_get(ctx, P_PIPE_B, (size_t)w * h * esz, &st))) return rc;
+        HIPCHK(ctx, hipMemcpy2DAsync(st, (size_t)w * esz, src, (size_t)src_row_stride_bytes, (size_t)w * esz, h, hipMemcpyHostToDevice, ctx->stream));
+        a.src = st; a.src_stride = w;
+    }
+    float *out;
+    if (dst->on_device) { out = dst->p; a.dst_stride = (size_t)(dst->row_stride_bytes / 4); }
+    else { if ((rc = pool_get(ctx, P_PIPE_G, (size_t)w * h * 4, &out))) return rc; a.dst_stride = w; }
+    a.dst = out;
+    a.bayer = xtrans ? 0 : 1;
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) {
+            int v;
+            if (xtrans) v = xtrans[r * 6 + c];
+            else v = (filters >> ((((r << 1) & 14) + (c & 1)) << 1)) & 3;      // RawImage::FC, period 2 tiles the 6x6 map
+            if (v < 0 || v > 2) return fail(ctx, ARTGPU_EUNSUPPORTED, "scale_colors: three-colour CFAs only");
+            a.cfa[r * 6 + c] = v;
+        }
+    for (int k = 0; k < 4; ++k) { a.cblacksom[k] = cblacksom[k]; a.scale_mul[k] = scale_mul[k]; }
+    float *mx;
+    if ((rc = pool_get(ctx, P_MAD, 3 * 32 * 4, &mx))) return rc;
+    a.chmax_bits = reinterpret_cast<int *>(mx);
+    HIPCHK(ctx, hipMemsetAsync(mx, 0, 4 * sizeof(int), ctx->stream));
+    HIPCHK(ctx, launch_scale_colors(a, ctx->stream));
+    if (!dst->on_device)
+        HIPCHK(ctx, hipMemcpy2DAsync(dst->p, (size_t)dst->row_stride_bytes, out, (size_t)w * 4, (size_t)w * 4, h, hipMemcpyDeviceToHost, ctx->stream));
+    if (chmax) {
+        float host[4];
+        HIPCHK(ctx, hipMemcpyAsync(host, mx, 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        chmax[0] = host[0]; chmax[1] = host[1]; chmax[2] = host[2]; chmax[3] = host[1];
+    } else if (!dst->on_device) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ARTGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // one frame / one batch share through the whole path
 // ---------------------------------------------------------------------------------------------
 int artgpu_pipeline_run(artgpu_ctx *ctx, const artgpu_plane *raw, const artgpu_pipeline_params *p, artgpu_rgb *out)

@@ -103,6 +103,18 @@ hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s);
 hipError_t launch_exposure(const PixArgs &a, hipStream_t s);
 hipError_t launch_tone_std(const PixArgs &a, hipStream_t s);
 hipError_t launch_yuv_mode(const PixArgs &a, hipStream_t s);
+// copyOriginalPixels (no dark frame / flat field) + scaleColors (rawimagesource.cc:2325-2428,2677-2859)
+struct ScaleArgs {
+    const void *src; size_t src_stride;   // elements; uint16 when src_u16 else float
+    int src_u16;
+    float *dst; size_t dst_stride;
+    int w, h;
+    int cfa[36];                          // colour (0..2) at [row % 6][col % 6]; Bayer maps are tiled into it
+    int bayer;                            // Bayer: the second green of each 2x2 uses black/scale index 3
+    float cblacksom[4], scale_mul[4];
+    int *chmax_bits;                      // [3] channel maxima as float bit patterns (values are >= 0)
+};
+hipError_t launch_scale_colors(const ScaleArgs &a, hipStream_t s);
 // NEUTRAL tone curve (curves.cc:854-1038)
 struct NeutralArgs {
     float *img[3]; size_t stride; int w, h;

@@ -131,6 +131,31 @@ __global__ void __launch_bounds__(256) yuv_mode_kernel(PixArgs a)
     }
 }
 
+// RawImageSource::copyOriginalPixels without dark frame / flat field (rawData = (float)src->data) followed by scaleColors
+// (rawimagesource.cc:2739-2760 Bayer, 2806-2813 X-Trans): val = max(0, raw - cblacksom[c4]) * scale_mul[c4]; chmax[c] = max.
+__global__ void __launch_bounds__(256) scale_colors_kernel(ScaleArgs a)
+{
+    __shared__ int s_max[3];
+    if (threadIdx.x < 3) s_max[threadIdx.x] = 0;
+    __syncthreads();
+    const long long n = (long long)a.w * a.h;
+    float m[3] = {0.f, 0.f, 0.f};
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(t / a.w), col = (int)(t - (long long)row * a.w);
+        const size_t si = (size_t)row * a.src_stride + col;
+        float val = a.src_u16 ? (float)static_cast<const unsigned short *>(a.src)[si] : static_cast<const float *>(a.src)[si];
+        const int c = a.cfa[(row % 6) * 6 + col % 6];
+        const int c4 = (a.bayer && c == 1 && !(row & 1)) ? 3 : c;
+        val = std_max(0.f, val - a.cblacksom[c4]) * a.scale_mul[c4];
+        a.dst[(size_t)row * a.dst_stride + col] = val;
+        m[c] = std_max(m[c], val);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) atomicMax(&s_max[c], __float_as_int(m[c]));     // non-negative floats order like their bit patterns
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMax(&a.chmax_bits[threadIdx.x], s_max[threadIdx.x]);
+}
+
 static int pix_grid(const PixArgs &a)
 {
     const long long n = (long long)a.w * a.h;
@@ -145,6 +170,13 @@ hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s)
 hipError_t launch_exposure(const PixArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(exposure_kernel, dim3(pix_grid(a)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_scale_colors(const ScaleArgs &a, hipStream_t s)
+{
+    const long long n = (long long)a.w * a.h;
+    long long g = (n + 255) / 256;
+    hipLaunchKernelGGL(scale_colors_kernel, dim3((unsigned)(g < 4096 ? (g ? g : 1) : 4096)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_yuv_mode(const PixArgs &a, hipStream_t s)

@@ -246,6 +246,16 @@ typedef struct {
 int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_tool_params *params, const double ws[9], const double *iws /* LAB mode only */,
                           double ecomp, double scale, const double *calclum_mat, const float *noise_c_curve, uint32_t flags);
 
+/* The step immediately before the path: RawImageSource::copyOriginalPixels without dark frame / flat
+ * field (rawimagesource.cc:2325-2428: rawData = (float)src->data) followed by RawImageSource::scaleColors (L2677-2859):
+ *   val = max(0, raw - cblacksom[c4]) * scale_mul[c4],  chmax[c] = max over the frame   (c4 = 3 for the second Bayer green).
+ * src: the sensor data as uint16 (src_is_u16 != 0, row stride in BYTES as usual) or float; dst: float CFA plane.
+ * cfa: Bayer `filters` word when xtrans == NULL, else the 6x6 X-Trans colour map.  The host keeps computing cblacksom /
+ * scale_mul (calculate_scale_mul, L753-779: a handful of scalars).  chmax[4]: channel maxima (chmax[3] = chmax[1], L2855). */
+int artgpu_scale_colors(artgpu_ctx *ctx, const void *src, int32_t w, int32_t h, int64_t src_row_stride_bytes, int32_t src_is_u16,
+                        int32_t src_on_device, uint32_t filters, const int32_t *xtrans, const float cblacksom[4],
+                        const float scale_mul[4], artgpu_plane *dst, float chmax[4]);
+
 /* The whole hot path for one frame in one call -- what ART's batch loop does per image between load and rgb2out
  * (simpleprocess.cc stage_init L215-259, stage_denoise L311-315, stage_finish L389-396):
  *   demosaic -> getImage (crop `border`, x mul, clip) + convertColorSpace matrix -> ImProcFunctions::denoise ->

@@ -145,3 +145,23 @@ void oracle_yuv_to_rgb(float *const img[3], size_t s, int w, int h, const float 
             img[0][o] = r; img[1][o] = g; img[2][o] = b;
         }
 }
+
+/* copyOriginalPixels (no dark frame / flat field) + scaleColors (rawimagesource.cc:2325-2428, 2739-2760, 2806-2813).
+ * cfa36: colour at [row % 6][col % 6]; bayer: the greens of even rows use index 3. */
+void oracle_scale_colors(const void *src, int src_u16, int w, int h, const int cfa36[36], int bayer, const float cblacksom[4],
+                         const float scale_mul[4], float *dst, float chmax[4])
+{
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma omp parallel for reduction(max : m0, m1, m2)
+    for (int row = 0; row < h; ++row)
+        for (int col = 0; col < w; ++col) {
+            const size_t i = (size_t)row * w + col;
+            float val = src_u16 ? (float)((const unsigned short *)src)[i] : ((const float *)src)[i];
+            const int c = cfa36[(row % 6) * 6 + col % 6];
+            const int c4 = (bayer && c == 1 && !(row & 1)) ? 3 : c;
+            val = rt_maxf(0.f, val - cblacksom[c4]) * scale_mul[c4];
+            dst[i] = val;
+            if (c == 0) m0 = rt_maxf(m0, val); else if (c == 1) m1 = rt_maxf(m1, val); else m2 = rt_maxf(m2, val);
+        }
+    chmax[0] = m0; chmax[1] = m1; chmax[2] = m2; chmax[3] = m1;
+}

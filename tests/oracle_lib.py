@@ -356,3 +356,14 @@ def xtrans_demosaic(raw, xtrans, rgb_cam, passes=1, use_cielab=False):
     lib().oracle_xtrans_demosaic(_ptr(raw), w, h, xt.ctypes.data_as(C.POINTER(C.c_int)), _ptr(cam), int(passes), int(use_cielab),
                                  _ptr(out[0]), _ptr(out[1]), _ptr(out[2]))
     return out
+
+
+def scale_colors(src, cfa36, bayer, cblacksom, scale_mul):
+    src = np.ascontiguousarray(src)
+    h, w = src.shape
+    out = np.zeros((h, w), np.float32)
+    mx = (C.c_float * 4)()
+    lib().oracle_scale_colors(src.ctypes.data_as(C.c_void_p), 1 if src.dtype == np.uint16 else 0, w, h,
+                              np.ascontiguousarray(cfa36, dtype=np.int32).reshape(36).ctypes.data_as(C.POINTER(C.c_int)), int(bayer),
+                              (C.c_float * 4)(*[float(v) for v in cblacksom]), (C.c_float * 4)(*[float(v) for v in scale_mul]), _ptr(out), mx)
+    return out, [float(v) for v in mx]

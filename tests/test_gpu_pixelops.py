@@ -66,3 +66,25 @@ def test_tone_unsupported(gpu_ctx):
         gpu_ctx.tone_curve(capi.host_rgb(img), None, 1.5, True)      # whitept > 1
     with pytest.raises(capi.ArtGpuError):
         gpu_ctx.tone_curve(capi.host_rgb(img), None, 1.0, True, mode=6)  # NEUTRAL: not built yet
+
+
+@pytest.mark.parametrize("kind", ["bayer_u16", "xtrans_u16", "bayer_f32"])
+def test_scale_colors_bit_exact(gpu_ctx, kind):
+    """N2: copyOriginalPixels + scaleColors (rawimagesource.cc:2739-2760,2806-2813): black subtraction, per-channel scale, maxima."""
+    from art_amd import capi, synth
+    import oracle_lib as O
+    w, h = 515, 389
+    rng = np.random.default_rng(7)
+    data = rng.integers(0, 16384, (h, w)).astype(np.uint16)
+    if kind == "bayer_f32":
+        data = data.astype(np.float32) + np.float32(0.25)
+    bayer = not kind.startswith("xtrans")
+    filt = synth.FILTERS_GRBG
+    cfa = synth.XTRANS_FUJI if not bayer else np.array([[synth.fc(filt, r, c) for c in range(6)] for r in range(6)], np.int32)
+    black = (511.0, 512.5, 509.0, 513.0)
+    mul = (2.31, 1.0, 1.57, 1.02)
+    out = np.zeros((h, w), np.float32)
+    mx = gpu_ctx.scale_colors(data, filt, None if bayer else synth.XTRANS_FUJI, black, mul, capi.host_plane(out))
+    ref, rmx = O.scale_colors(data, cfa, bayer, black, mul)
+    assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    assert [np.float32(v) for v in mx] == [np.float32(v) for v in rmx] and mx[3] == mx[1] and mx[0] > 0
