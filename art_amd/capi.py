@@ -121,6 +121,8 @@ def _load():
                                           C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_uint32]
     lib.artgpu_scale_colors.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_uint32,
                                         C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Plane), C.POINTER(C.c_float)]
+    lib.artgpu_channel_mixer.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float)]
+    lib.artgpu_rgb_curves.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_pipeline_run.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
     lib.artgpu_batch_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
     lib.artgpu_demosaic_xtrans.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Plane), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(RGB)]
@@ -144,7 +146,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -254,6 +256,14 @@ class Context:
         self._chk(LIB.artgpu_scale_colors(self._h, src.ctypes.data, w, h, src.strides[0], 1 if src.dtype == np.uint16 else 0, 0, filters, xt,
                                           cb, sm, C.byref(dst), mx))
         return [float(v) for v in mx]
+
+    def channel_mixer(self, image: RGB, m):
+        self._chk(LIB.artgpu_channel_mixer(self._h, C.byref(image), (C.c_float * 9)(*[float(v) for v in np.asarray(m, np.float32).reshape(9)])))
+
+    def rgb_curves(self, image: RGB, rcurve=None, gcurve=None, bcurve=None):
+        ptr = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(C.POINTER(C.c_float))
+        keep = [None if a is None else np.ascontiguousarray(a, dtype=np.float32) for a in (rcurve, gcurve, bcurve)]
+        self._chk(LIB.artgpu_rgb_curves(self._h, C.byref(image), *[None if k is None else k.ctypes.data_as(C.POINTER(C.c_float)) for k in keep]))
 
     def pipeline_run(self, raw: Plane, params: PipelineParams, out: RGB):
         self._chk(LIB.artgpu_pipeline_run(self._h, C.byref(raw), C.byref(params), C.byref(out)))

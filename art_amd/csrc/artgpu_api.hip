@@ -1404,6 +1404,53 @@ int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise
 }
 
 // ---------------------------------------------------------------------------------------------
+// N4: channel mixer, RGB curves
+// ---------------------------------------------------------------------------------------------
+int artgpu_channel_mixer(artgpu_ctx *ctx, artgpu_rgb *image, const float m[9])
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!image || !m) return fail(ctx, ARTGPU_EINVAL, "channel_mixer: null argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB d;
+    int rc = bind_rgb(ctx, image, 4, true, &d, "channel_mixer");
+    if (rc) return rc;
+    MixArgs a = {};
+    for (int k = 0; k < 3; ++k) a.dst[k] = d.p[k];
+    a.stride = d.stride; a.w = d.w; a.h = d.h;
+    for (int k = 0; k < 9; ++k) a.m[k] = m[k];
+    HIPCHK(ctx, launch_channel_mixer(a, ctx->stream));
+    return unbind_rgb(ctx, image, &d);
+}
+
+int artgpu_rgb_curves(artgpu_ctx *ctx, artgpu_rgb *image, const float *rcurve, const float *gcurve, const float *bcurve)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!image) return fail(ctx, ARTGPU_EINVAL, "rgb_curves: null argument");
+    if (!rcurve && !gcurve && !bcurve) return ARTGPU_OK;    // all identity: the reference skips the loop (iprgbcurves.cc:110)
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB d;
+    int rc = bind_rgb(ctx, image, 4, true, &d, "rgb_curves");
+    if (rc) return rc;
+    float *tabs;
+    if ((rc = pool_get(ctx, P_PIPE_R, 3 * 65536 * 4, &tabs))) return rc;
+    const float *host[3] = {rcurve, gcurve, bcurve};
+    MixArgs a = {};
+    for (int k = 0; k < 3; ++k) {
+        a.dst[k] = d.p[k];
+        if (host[k]) {
+            HIPCHK(ctx, hipMemcpyAsync(tabs + (size_t)k * 65536, host[k], 65536 * 4, hipMemcpyHostToDevice, ctx->stream));
+            a.lut[k] = tabs + (size_t)k * 65536;
+        }
+    }
+    a.stride = d.stride; a.w = d.w; a.h = d.h;
+    HIPCHK(ctx, launch_rgb_curves(a, ctx->stream));
+    rc = unbind_rgb(ctx, image, &d);
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // the caller's LUTs must outlive the copies
+    return ARTGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // raw pre-stage (N2): copyOriginalPixels + scaleColors
 // ---------------------------------------------------------------------------------------------
 int artgpu_scale_colors(artgpu_ctx *ctx, const void *src, int32_t w, int32_t h, int64_t src_row_stride_bytes, int32_t src_is_u16,

@@ -115,6 +115,10 @@ struct ScaleArgs {
     int *chmax_bits;                      // [3] channel maxima as float bit patterns (values are >= 0)
 };
 hipError_t launch_scale_colors(const ScaleArgs &a, hipStream_t s);
+// channelMixer (ipchmixer.cc:185-230) and rgbCurves (iprgbcurves.cc:116-143) on a PixArgs image; mat[9] as floats in `mixf`
+struct MixArgs { float *dst[3]; size_t stride; int w, h; float m[9]; const float *lut[3]; };
+hipError_t launch_channel_mixer(const MixArgs &a, hipStream_t s);
+hipError_t launch_rgb_curves(const MixArgs &a, hipStream_t s);
 // NEUTRAL tone curve (curves.cc:854-1038)
 struct NeutralArgs {
     float *img[3]; size_t stride; int w, h;

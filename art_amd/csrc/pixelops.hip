@@ -156,6 +156,54 @@ __global__ void __launch_bounds__(256) scale_colors_kernel(ScaleArgs a)
     if (threadIdx.x < 3) atomicMax(&a.chmax_bits[threadIdx.x], s_max[threadIdx.x]);
 }
 
+// ImProcFunctions::channelMixer pixel loop (ipchmixer.cc:200-230): 4-lane groups clamp with vmaxf, the row tail with max()
+__global__ void __launch_bounds__(256) channel_mixer_kernel(MixArgs a)
+{
+    const long long n = (long long)a.w * a.h;
+    const int wv = a.w - 3 > 0 ? ((a.w - 3 + 3) / 4) * 4 : 0;    // x < W-3 in steps of 4
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+        const size_t di = (size_t)y * a.stride + x;
+        const float r = a.dst[0][di], g = a.dst[1][di], b = a.dst[2][di];
+        const float rmix = (r * a.m[0] + g * a.m[1] + b * a.m[2]);
+        const float gmix = (r * a.m[3] + g * a.m[4] + b * a.m[5]);
+        const float bmix = (r * a.m[6] + g * a.m[7] + b * a.m[8]);
+        if (x < wv) { a.dst[0][di] = sse_max(rmix, 0.f); a.dst[1][di] = sse_max(gmix, 0.f); a.dst[2][di] = sse_max(bmix, 0.f); }
+        else { a.dst[0][di] = std_max(rmix, 0.f); a.dst[1][di] = std_max(gmix, 0.f); a.dst[2][di] = std_max(bmix, 0.f); }
+    }
+}
+// ImProcFunctions::rgbCurves pixel loop (iprgbcurves.cc:116-143): LUTf(65536, flags 0); 4-lane groups use the clamping vector
+// lookup (LUT.h:349-377), the row tail the scalar one, which extrapolates (LUT.h:436-459)
+__global__ void __launch_bounds__(256) rgb_curves_kernel(MixArgs a)
+{
+    const long long n = (long long)a.w * a.h;
+    const int wv = a.w - 3 > 0 ? ((a.w - 3 + 3) / 4) * 4 : 0;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+        const size_t di = (size_t)y * a.stride + x;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float *lut = a.lut[c];
+            if (!lut) continue;
+            const float v = a.dst[c][di];
+            float r;
+            if (x < wv) {
+                const float clamped = sse_max(sse_min(65534.f, v), 0.f);
+                const int idx = (int)clamped;
+                const float diff = sse_max(sse_min(65535.f, v), 0.f) - (float)idx;
+                r = intp(diff, lut[idx + 1], lut[idx]);
+            } else {
+                int idx = (int)v;
+                if (v < 0.f || !(v == v)) idx = 0;
+                else if (v > 65534.f) idx = 65534;
+                const float diff = v - (float)idx, p1 = lut[idx], p2 = lut[idx + 1] - p1;
+                r = p1 + p2 * diff;
+            }
+            a.dst[c][di] = r;
+        }
+    }
+}
+
 static int pix_grid(const PixArgs &a)
 {
     const long long n = (long long)a.w * a.h;
@@ -170,6 +218,17 @@ hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s)
 hipError_t launch_exposure(const PixArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(exposure_kernel, dim3(pix_grid(a)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+static unsigned mix_grid(const MixArgs &a) { long long g = ((long long)a.w * a.h + 255) / 256; return (unsigned)(g < 16384 ? (g ? g : 1) : 16384); }
+hipError_t launch_channel_mixer(const MixArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(channel_mixer_kernel, dim3(mix_grid(a)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_rgb_curves(const MixArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(rgb_curves_kernel, dim3(mix_grid(a)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_scale_colors(const ScaleArgs &a, hipStream_t s)

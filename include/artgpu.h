@@ -256,6 +256,15 @@ int artgpu_scale_colors(artgpu_ctx *ctx, const void *src, int32_t w, int32_t h, 
                         int32_t src_on_device, uint32_t filters, const int32_t *xtrans, const float cblacksom[4],
                         const float scale_mul[4], artgpu_plane *dst, float chmax[4]);
 
+/* Two of the default-off pixelwise steps of ImProcFunctions::process, so that a frame with these
+ * common edits stays on the device:
+ * artgpu_channel_mixer : the pixel loop of ImProcFunctions::channelMixer (ipchmixer.cc:185-230); m = {RR,RG,RB, GR,GG,GB,
+ *                        BR,BG,BB} as the function computes them (params/1000, or get_mixer_matrix for PRIMARIES_CHROMA).
+ * artgpu_rgb_curves    : the pixel loop of ImProcFunctions::rgbCurves (iprgbcurves.cc:116-143); each LUT is the 65536-entry
+ *                        `outCurve` RGBCurve() builds on the host (L41-53), NULL for an identity curve. */
+int artgpu_channel_mixer(artgpu_ctx *ctx, artgpu_rgb *img, const float m[9]);
+int artgpu_rgb_curves(artgpu_ctx *ctx, artgpu_rgb *img, const float *rcurve, const float *gcurve, const float *bcurve);
+
 /* The whole hot path for one frame in one call -- what ART's batch loop does per image between load and rgb2out
  * (simpleprocess.cc stage_init L215-259, stage_denoise L311-315, stage_finish L389-396):
  *   demosaic -> getImage (crop `border`, x mul, clip) + convertColorSpace matrix -> ImProcFunctions::denoise ->

@@ -69,6 +69,8 @@ void oracle_chroma_noise_map(const float *const img[3], size_t s, int w, int h, 
 void oracle_tone_curve_std(float *const img[3], size_t s, int w, int h, const float *lut65536);
 void oracle_scale_colors(const void *src, int src_u16, int w, int h, const int cfa36[36], int bayer, const float cblacksom[4],
                          const float scale_mul[4], float *dst, float chmax[4]);
+void oracle_channel_mixer(float *const img[3], size_t s, int w, int h, const float m[9]);
+void oracle_rgb_curves(float *const img[3], size_t s, int w, int h, const float *const luts[3]);
 void oracle_rgb_to_yuv(float *const img[3], size_t s, int w, int h, const float ws[9]);
 void oracle_yuv_to_rgb(float *const img[3], size_t s, int w, int h, const float ws[9]);
 

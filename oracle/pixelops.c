@@ -165,3 +165,40 @@ void oracle_scale_colors(const void *src, int src_u16, int w, int h, const int c
         }
     chmax[0] = m0; chmax[1] = m1; chmax[2] = m2; chmax[3] = m1;
 }
+
+/* channelMixer pixel loop (ipchmixer.cc:200-230) */
+void oracle_channel_mixer(float *const img[3], size_t s, int w, int h, const float m[9])
+{
+#pragma omp parallel for
+    for (int y = 0; y < h; ++y) {
+        int x = 0;
+        for (; x < w - 3; x += 4)
+            for (int k = 0; k < 4; ++k) {
+                const size_t o = (size_t)y * s + x + k;
+                const float r = img[0][o], g = img[1][o], b = img[2][o];
+                img[0][o] = sse_maxf((r * m[0] + g * m[1] + b * m[2]), 0.f);
+                img[1][o] = sse_maxf((r * m[3] + g * m[4] + b * m[5]), 0.f);
+                img[2][o] = sse_maxf((r * m[6] + g * m[7] + b * m[8]), 0.f);
+            }
+        for (; x < w; ++x) {
+            const size_t o = (size_t)y * s + x;
+            const float r = img[0][o], g = img[1][o], b = img[2][o];
+            img[0][o] = rt_maxf((r * m[0] + g * m[1] + b * m[2]), 0.f);
+            img[1][o] = rt_maxf((r * m[3] + g * m[4] + b * m[5]), 0.f);
+            img[2][o] = rt_maxf((r * m[6] + g * m[7] + b * m[8]), 0.f);
+        }
+    }
+}
+/* rgbCurves pixel loop (iprgbcurves.cc:116-143); luts[c] may be NULL */
+void oracle_rgb_curves(float *const img[3], size_t s, int w, int h, const float *const luts[3])
+{
+#pragma omp parallel for
+    for (int y = 0; y < h; ++y)
+        for (int c = 0; c < 3; ++c) {
+            if (!luts[c]) continue;
+            int x = 0;
+            for (; x < w - 3; x += 4)
+                for (int k = 0; k < 4; ++k) img[c][(size_t)y * s + x + k] = oracle_lutf_vec(luts[c], 65536, img[c][(size_t)y * s + x + k]);
+            for (; x < w; ++x) img[c][(size_t)y * s + x] = oracle_lutf_noclip(luts[c], 65536, img[c][(size_t)y * s + x]);
+        }
+}

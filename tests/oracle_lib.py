@@ -367,3 +367,19 @@ def scale_colors(src, cfa36, bayer, cblacksom, scale_mul):
                               np.ascontiguousarray(cfa36, dtype=np.int32).reshape(36).ctypes.data_as(C.POINTER(C.c_int)), int(bayer),
                               (C.c_float * 4)(*[float(v) for v in cblacksom]), (C.c_float * 4)(*[float(v) for v in scale_mul]), _ptr(out), mx)
     return out, [float(v) for v in mx]
+
+
+def channel_mixer(img, m):
+    img = [np.array(p, dtype=np.float32, order="C") for p in img]
+    h, w = img[0].shape
+    lib().oracle_channel_mixer(_p3(img), C.c_size_t(w), w, h, (C.c_float * 9)(*[float(v) for v in np.asarray(m, np.float32).reshape(9)]))
+    return img
+
+
+def rgb_curves(img, luts):
+    img = [np.array(p, dtype=np.float32, order="C") for p in img]
+    h, w = img[0].shape
+    keep = [None if l is None else np.ascontiguousarray(l, dtype=np.float32) for l in luts]
+    arr = (_fp * 3)(*[None if k is None else _ptr(k) for k in keep])
+    lib().oracle_rgb_curves(_p3(img), C.c_size_t(w), w, h, arr)
+    return img

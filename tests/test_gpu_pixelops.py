@@ -88,3 +88,27 @@ def test_scale_colors_bit_exact(gpu_ctx, kind):
     ref, rmx = O.scale_colors(data, cfa, bayer, black, mul)
     assert np.array_equal(out.view(np.uint32), ref.view(np.uint32))
     assert [np.float32(v) for v in mx] == [np.float32(v) for v in rmx] and mx[3] == mx[1] and mx[0] > 0
+
+
+def test_channel_mixer_and_rgb_curves_bit_exact(gpu_ctx):
+    """N4: pixel loops of ImProcFunctions::channelMixer (ipchmixer.cc:200-230) and rgbCurves (iprgbcurves.cc:116-143)."""
+    from art_amd import capi
+    import oracle_lib as O
+    w, h = 333, 127                                    # W % 4 != 0: vector groups + scalar tail
+    rng = np.random.default_rng(3)
+    img = [rng.uniform(-500.0, 70000.0, (h, w)).astype(np.float32) for _ in range(3)]
+    m = np.array([1.1, -0.2, 0.1, -0.05, 1.2, -0.15, 0.02, -0.3, 1.28], np.float32)
+    got = [p.copy() for p in img]
+    gpu_ctx.channel_mixer(capi.host_rgb(got), m)
+    ref = O.channel_mixer(img, m)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+    x = np.arange(65536, dtype=np.float64) / 65535.0
+    lr = (65535.0 * x ** 0.8).astype(np.float32)
+    lb = (65535.0 * (1.0 - (1.0 - x) ** 1.3)).astype(np.float32)
+    got = [p.copy() for p in img]
+    gpu_ctx.rgb_curves(capi.host_rgb(got), lr, None, lb)
+    ref = O.rgb_curves(img, (lr, None, lb))
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+    assert np.array_equal(got[1], img[1]) and not np.array_equal(got[0], img[0])
