@@ -37,6 +37,13 @@ class DenoiseParams(C.Structure):
                 ("gamma", C.c_double), ("aggressive", C.c_int32), ("color_space", C.c_int32), ("chrominance_method", C.c_int32)]
 
 
+class DenoiseInfoStore(C.Structure):
+    """DenoiseInfoStore (improcfun.h:117-131) + per-crop diagnostics"""
+    _fields_ = [("valid", C.c_int32), ("ch_M", C.c_float * 9), ("max_r", C.c_float * 9), ("max_b", C.c_float * 9),
+                ("chrominance", C.c_double), ("chrominance_red_green", C.c_double), ("chrominance_blue_yellow", C.c_double),
+                ("crop_info", (C.c_float * 16) * 9)]
+
+
 class NeutralState(C.Structure):
     _fields_ = [("ws", C.c_double * 9), ("iws", C.c_double * 9), ("to_out", C.c_float * 9), ("to_work", C.c_float * 9)]
 
@@ -57,7 +64,7 @@ PipelineParams._fields_ = [
     ("ws", C.c_double * 9), ("iws", C.c_double * 9), ("denoise_enabled", C.c_int32), ("denoise", DenoiseToolParams),
     ("exposure_enabled", C.c_int32), ("expcomp", C.c_double), ("black", C.c_double), ("tone_enabled", C.c_int32),
     ("tone_mode", C.c_int32), ("tone_lut", C.POINTER(C.c_float)), ("white_point", C.c_float), ("to_out", C.c_float * 9),
-    ("to_work", C.c_float * 9), ("scale", C.c_double)]
+    ("to_work", C.c_float * 9), ("scale", C.c_double), ("chrominance_auto_factor", C.c_double)]
 
 DN_SKIP_DETAIL_RECOVERY = 1
 # the chroma noise curve ImProcFunctions::denoise always installs (ipdenoise.cc:1139-1149)
@@ -121,6 +128,8 @@ def _load():
                                           C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_uint32]
     lib.artgpu_scale_colors.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_uint32,
                                         C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Plane), C.POINTER(C.c_float)]
+    lib.artgpu_denoise_compute_params.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_double),
+                                                  C.POINTER(C.c_double), C.c_double, C.POINTER(DenoiseInfoStore), C.POINTER(DenoiseParams)]
     lib.artgpu_channel_mixer.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float)]
     lib.artgpu_rgb_curves.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_pipeline_run.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
@@ -146,7 +155,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -256,6 +265,15 @@ class Context:
         self._chk(LIB.artgpu_scale_colors(self._h, src.ctypes.data, w, h, src.strides[0], 1 if src.dtype == np.uint16 else 0, 0, filters, xt,
                                           cb, sm, C.byref(dst), mx))
         return [float(v) for v in mx]
+
+    def denoise_compute_params(self, planes: RGB, border: int, mul, do_clip: bool, cam_to_work, ws, dn: DenoiseParams,
+                               auto_factor: float = 1.0, store: "DenoiseInfoStore" = None) -> "DenoiseInfoStore":
+        """ImProcFunctions::denoiseComputeParams; updates dn.chrominance* in place and returns the store"""
+        store = store if store is not None else DenoiseInfoStore()
+        d9 = lambda m: (C.c_double * 9)(*[float(v) for v in np.asarray(m, dtype=np.float64).reshape(9)])
+        self._chk(LIB.artgpu_denoise_compute_params(self._h, C.byref(planes), int(border), (C.c_float * 3)(*[float(v) for v in mul]),
+                                                    1 if do_clip else 0, d9(cam_to_work), d9(ws), float(auto_factor), C.byref(store), C.byref(dn)))
+        return store
 
     def channel_mixer(self, image: RGB, m):
         self._chk(LIB.artgpu_channel_mixer(self._h, C.byref(image), (C.c_float * 9)(*[float(v) for v in np.asarray(m, np.float32).reshape(9)])))

@@ -19,6 +19,8 @@ using namespace artgpu;
 struct artgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;      // second stream (serial statistics of the AUTOMATIC chroma estimation run beside the decompositions)
+    hipEvent_t aux_ev[2] = {nullptr, nullptr};
     std::string err;
     // per-workgroup work arenas (demosaic)
     float *arena = nullptr;
@@ -239,6 +241,9 @@ int artgpu_destroy(artgpu_ctx *ctx)
         if (ctx->pool[k]) (void)hipFree(ctx->pool[k]);
     for (int k = 0; k < 3; ++k)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+    for (int k = 0; k < 2; ++k)
+        if (ctx->aux_ev[k]) (void)hipEventDestroy(ctx->aux_ev[k]);
+    if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
     delete ctx;
     return ARTGPU_OK;
 }
@@ -621,7 +626,7 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_NSLOTS };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_NSLOTS };
 static_assert(P_NSLOTS <= artgpu_ctx::NPOOL, "grow artgpu_ctx::pool");
 
 struct DevDecomp {
@@ -1323,6 +1328,129 @@ static int chroma_map_dev(artgpu_ctx *ctx, float *const planes[3], size_t stride
     return ARTGPU_OK;
 }
 
+// Color::cachef / cachefy / denoiseGammaTab / denoiseIGammaTab on the device, built on the host like the reference's (color.cc:202-292)
+static int lab_tabs_dev(artgpu_ctx *ctx, float **tabs_out)
+{
+    float *tabs;
+    const bool fresh = ctx->pool[P_LABTABS] == nullptr;
+    int rc = pool_get(ctx, P_LABTABS, 4 * 65536 * 4, &tabs);
+    if (rc) return rc;
+    if (fresh) {
+        std::vector<float> host(4 * 65536);
+        build_cachef(host.data()); build_cachefy(host.data() + 65536);
+        build_denoise_gamma_tabs(host.data() + 2 * 65536, host.data() + 3 * 65536);
+        HIPCHK(ctx, hipMemcpyAsync(tabs, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *tabs_out = tabs;
+    return ARTGPU_OK;
+}
+
+int artgpu_denoise_compute_params(artgpu_ctx *ctx, const artgpu_rgb *planes, int border, const float mul[3], int do_clip,
+                                  const double cam_to_work[9], const double ws[9], double chrominance_auto_factor,
+                                  artgpu_denoise_info_store *store, artgpu_denoise_params *dn)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!planes || !mul || !cam_to_work || !ws || !store || !dn) return fail(ctx, ARTGPU_EINVAL, "denoise_compute_params: null argument");
+    const bool automatic = dn->chrominance_method == 1;
+    if (store->valid || !automatic) {                       // ipdenoise.cc:802-809
+        if (automatic) {
+            dn->chrominance = store->chrominance * chrominance_auto_factor;
+            dn->chrominance_red_green = store->chrominance_red_green * chrominance_auto_factor;
+            dn->chrominance_blue_yellow = store->chrominance_blue_yellow * chrominance_auto_factor;
+        }
+        return ARTGPU_OK;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB src;
+    int rc = bind_rgb(ctx, planes, 1, true, &src, "denoise_compute_params(planes)");
+    if (rc) return rc;
+    if (border < 0) return fail(ctx, ARTGPU_EINVAL, "denoise_compute_params: border %d", border);
+    const int widIm = src.w - 2 * border, heiIm = src.h - 2 * border;       // getFullSize
+    const int crW = widIm / 2, crH = heiIm / 2;                              // Tile_calc returns one tile: tileWskip = widIm (L836,875-876)
+    if (widIm < 100 || heiIm < 100)
+        return fail(ctx, ARTGPU_EUNSUPPORTED, "denoise_compute_params: %dx%d is too small for the nine-crop layout (crops start 50 px in)", widIm, heiIm);
+    const int coordW[3] = {50, widIm / 2 - crW / 2, widIm - crW - 50}, coordH[3] = {50, heiIm / 2 - crH / 2, heiIm - crH - 50};
+    const int wid = (crW + 1) / 2, hei = (crH + 1) / 2, levwav = 5, nsub = 3 * levwav;   // levwav = max(2, 5 - ceil(log(1)))
+    const size_t n = (size_t)crW * crH, n2 = (size_t)wid * hei;
+    if (!ctx->aux) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->aux_ev[0], hipEventDisableTiming));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->aux_ev[1], hipEventDisableTiming));
+    }
+
+    DnInfoArgs a = {};
+    float *tabs, *gamlut, *histo_f, *res;
+    DevDecomp Cd = {};
+    Cd.w = crW; Cd.h = crH; Cd.w2 = wid; Cd.h2 = hei; Cd.n = n2; Cd.nlevels = levwav;
+    if ((rc = lab_tabs_dev(ctx, &tabs)) || (rc = pool_get(ctx, P_A, n * 4, &a.A)) || (rc = pool_get(ctx, P_B, n * 4, &a.B)) ||
+        (rc = pool_get(ctx, P_CBANDS, (size_t)nsub * n2 * 4, &Cd.bands)) || (rc = pool_get(ctx, P_CLOW0, n2 * 4, &Cd.low[0])) ||
+        (rc = pool_get(ctx, P_CLOW1, n2 * 4, &Cd.low[1])) || (rc = pool_get(ctx, P_SF, (size_t)27 * n2 * 4, &a.maps)) ||
+        (rc = pool_get(ctx, P_HISTO, (size_t)nsub * 65536 * 4, &histo_f)) || (rc = pool_get(ctx, P_GAM, 2 * 65536 * 4, &gamlut)) ||
+        (rc = pool_get(ctx, P_DNINFO, (9 * 32 + 9 * 8) * 4, &res)))
+        return rc;
+    for (int k = 0; k < 3; ++k) { a.src[k] = src.p[k]; a.mul[k] = mul[k]; }
+    a.stride = src.stride; a.do_clip = do_clip ? 1 : 0;
+    for (int wcr = 0; wcr < 3; ++wcr)
+        for (int hcr = 0; hcr < 3; ++hcr) { a.sx[hcr * 3 + wcr] = coordW[wcr] + border; a.sy[hcr * 3 + wcr] = coordH[hcr] + border; }   // transformRect adds the border
+    a.crW = crW; a.crH = crH; a.wid = wid; a.hei = hei;
+    for (int k = 0; k < 9; ++k) { a.mat[k] = cam_to_work[k]; a.wp[k] = (float)ws[k]; }
+    a.cachef = tabs; a.cachefy = tabs + 65536; a.gamcurve = gamlut;
+    // RGB_denoise_infoGamCurve (ipdenoise.cc:209-224), raw: gamma as given
+    a.gam = (float)dn->gamma; a.gamthresh = 0.001f;
+    a.gamslope = (float)(std::exp(std::log(static_cast<double>(a.gamthresh)) / a.gam) / a.gamthresh);
+    { const double expcomp = std::log(5.f) / std::log(2.f); a.gain = std::pow(2.0f, float(expcomp)); }     // L936, L291
+    a.stats = res + 9 * 32;
+    HIPCHK(ctx, launch_gamma_lut(gamlut, a.gam, a.gamthresh, a.gamslope, 65535.f, 32768.f, ctx->stream));
+
+    // maps of all nine crops, then their serial statistics on the second stream while this one decomposes
+    HIPCHK(ctx, launch_dninfo_maps(a, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->aux_ev[0], ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->aux_ev[0], 0));
+    HIPCHK(ctx, launch_dninfo_stats(a, ctx->aux));
+    HIPCHK(ctx, hipEventRecord(ctx->aux_ev[1], ctx->aux));
+    int *histo = reinterpret_cast<int *>(histo_f);
+    for (int k = 0; k < 9; ++k) {
+        a.crop = k;
+        HIPCHK(ctx, launch_dninfo_ab(a, ctx->stream));
+        if ((rc = decompose_dev(ctx, Cd, a.A))) return rc;
+        HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, res + k * 32, ctx->stream));
+        if ((rc = decompose_dev(ctx, Cd, a.B))) return rc;
+        HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, res + k * 32 + 16, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1], 0));
+    float host[9 * 32 + 9 * 8];
+    HIPCHK(ctx, hipMemcpyAsync(host, res, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+
+    const bool aggressive = dn->aggressive != 0;
+    float info[9][16] = {};
+    for (int k = 0; k < 9; ++k) {
+        float bs[6];
+        dninfo_band_stats(host + k * 32, host + k * 32 + 16, nsub, aggressive, bs);
+        const float *st = host + 9 * 32 + k * 8;
+        int nry, nsk;
+        memcpy(&nry, st + 4, 4); memcpy(&nsk, st + 5, 4);
+        const int nc = (int)n2;                              // ShrinkAll_info, lvl == 1 (FTblockDN.cc:1266-1288)
+        for (int j = 0; j < 5; ++j) info[k][j] = bs[j];
+        info[k][5] = st[0] / nc;                             // chromina
+        info[k][6] = st[1] / nc;                             // lumema
+        info[k][7] = nry > 0 ? st[2] / nry : 0.f;            // redyel
+        info[k][8] = nsk > 0 ? st[3] / nsk : 0.f;            // skinc
+        info[k][9] = static_cast<float>(nsk) / static_cast<float>(nc);
+        info[k][10] = bs[5];
+    }
+    float out3[3];
+    dninfo_reduce(info, aggressive, store->ch_M, store->max_r, store->max_b, out3);
+    store->chrominance = out3[0]; store->chrominance_red_green = out3[1]; store->chrominance_blue_yellow = out3[2];
+    dn->chrominance = store->chrominance * chrominance_auto_factor;
+    dn->chrominance_red_green = store->chrominance_red_green * chrominance_auto_factor;
+    dn->chrominance_blue_yellow = store->chrominance_blue_yellow * chrominance_auto_factor;
+    store->valid = 1;
+    for (int k = 0; k < 9; ++k) memcpy(store->crop_info[k], info[k], sizeof info[k]);
+    return ARTGPU_OK;
+}
+
 int artgpu_denoise_chroma_map(artgpu_ctx *ctx, const artgpu_rgb *img, const double *calclum_mat, const double ws[9],
                               const float noise_c_curve[501], artgpu_plane *ccalc)
 {
@@ -1534,13 +1662,22 @@ int artgpu_pipeline_run(artgpu_ctx *ctx, const artgpu_plane *raw, const artgpu_p
     artgpu_rgb img;
     artgpu_plane *ip[3] = {&img.r, &img.g, &img.b};
     for (int k = 0; k < 3; ++k) { ip[k]->p = d.p[k]; ip[k]->w = d.w; ip[k]->h = d.h; ip[k]->row_stride_bytes = (int64_t)d.stride * 4; ip[k]->on_device = 1; }
+    artgpu_denoise_tool_params dnp = p->denoise;
+    if (p->denoise_enabled && dnp.dn.chrominance_method == 1) {
+        // ipf.denoiseComputeParams(imgsrc, currWB, dnstore, params.denoise) before getImage (simpleprocess.cc:254-256); a fresh store per frame
+        static const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        artgpu_denoise_info_store store = {};
+        if ((rc = artgpu_denoise_compute_params(ctx, &dem, b, p->mul, p->do_clip, p->has_cam_to_work ? p->cam_to_work : ident, p->ws,
+                                                p->chrominance_auto_factor != 0.0 ? p->chrominance_auto_factor : 1.0, &store, &dnp.dn)))
+            return rc;
+    }
     if ((rc = artgpu_get_image(ctx, &dem, b, b, p->mul, p->do_clip, p->has_cam_to_work ? p->cam_to_work : nullptr, &img))) return rc;
     if (p->denoise_enabled) {
         static const double curve_points[9] = {1 /*FCT_MinMaxCPoints*/, 0.05, 0.50, 0.35, 0.35, 0.35, 0.05, 0.35, 0.35};   // ipdenoise.cc:1139-1149
         float curve[501];
         (void)noise_curve_lut(curve_points, 9, curve);
         const double ecomp = p->exposure_enabled ? p->expcomp : 0.0;       // ipdenoise.cc:1155
-        if ((rc = artgpu_improc_denoise(ctx, &img, &p->denoise, p->ws, p->iws, ecomp, p->scale > 0 ? p->scale : 1.0,
+        if ((rc = artgpu_improc_denoise(ctx, &img, &dnp, p->ws, p->iws, ecomp, p->scale > 0 ? p->scale : 1.0,
                                         p->has_cam_to_work ? p->cam_to_work : nullptr, curve, 0u)))
             return rc;
     }

@@ -569,4 +569,128 @@ hipError_t launch_chroma_map(const ChromaMapArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- AUTOMATIC chrominance estimation (RGB_denoise_info)
+// getImage for one pixel of a crop (rawimagesource.cc:940-1025, skip 1): 0 + v, * mul, CLIP
+__device__ __forceinline__ float dninfo_fetch(const DnInfoArgs &a, int c, size_t si)
+{
+    float t = 0.f;
+    t += a.src[c][si];
+    t *= a.mul[c];
+    if (a.do_clip) t = std_max(0.f, std_min(t, 65535.f));
+    return t;
+}
+// hue / chroma / luminance maps of all nine crops: provicalc (every second pixel) -> convertColorSpace -> rgbxyz -> XYZ2Lab
+// (ipdenoise.cc:902-911,268-283), then L384-458.  The 4-lane xatan2f equals the scalar one bit for bit (tests/golden/sleef3.npz);
+// the chroma floor is vmaxf in the 4-lane columns and a compare in the tail.
+__global__ void __launch_bounds__(256) dninfo_maps_kernel(DnInfoArgs a)
+{
+    const int k = blockIdx.y;
+    const long long n2 = (long long)a.wid * a.hei;
+    const int nvec = 4 * (a.crW / 8);
+    float *hue = a.maps + (size_t)k * 3 * n2, *chrom = hue + n2, *lum = chrom + n2;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n2; t += (long long)gridDim.x * blockDim.x) {
+        const int ii = (int)(t / a.wid), jj = (int)(t - (long long)ii * a.wid);
+        const size_t si = (size_t)(a.sy[k] + 2 * ii) * a.stride + a.sx[k] + 2 * jj;
+        const double dr = dninfo_fetch(a, 0, si), dg = dninfo_fetch(a, 1, si), db = dninfo_fetch(a, 2, si);
+        const float RL = (float)(a.mat[0] * dr + a.mat[1] * dg + a.mat[2] * db);
+        const float GL = (float)(a.mat[3] * dr + a.mat[4] * dg + a.mat[5] * db);
+        const float BL = (float)(a.mat[6] * dr + a.mat[7] * dg + a.mat[8] * db);
+        const float X = a.wp[0] * RL + a.wp[1] * GL + a.wp[2] * BL, Y = a.wp[3] * RL + a.wp[4] * GL + a.wp[5] * BL, Z = a.wp[6] * RL + a.wp[7] * GL + a.wp[8] * BL;
+        const float x = X / 0.9642f, z = Z / 0.8249f, y = Y;
+        const float fx = xyz2lab_f(a.cachef, x), fy = xyz2lab_f(a.cachef, y), fz = xyz2lab_f(a.cachef, z);
+        float l;
+        if (y != y) l = y;
+        else if (y < 0.f) l = (float)(327.68 * ((24389.0 / 27.0) * (double)y / (double)65535.f));
+        else if (y > 65535.f) l = 327.68f * (116.f * xcbrtf_s(y / 65535.f) - 16.f);
+        else l = lutf_lookup<false>(a.cachefy, 65536, y);
+        const float la = 500.0f * (fx - fy), lb = 200.0f * (fy - fz);
+        hue[t] = xatan2f_s(lb, la);
+        float cN = sqrtf(la * la + lb * lb);
+        if (jj < nvec) cN = sse_max(cN, 100.f); else if (cN < 100.f) cN = 100.f;
+        chrom[t] = cN;
+        float Ll = l < 2.f ? 2.f : l;
+        Ll = Ll > 32768.f ? 32768.f : Ll;
+        lum[t] = Ll;
+    }
+}
+// ShrinkAll_info's lvl == 1 statistics (FTblockDN.cc:1237-1290): four float sums that the reference accumulates in scan order.
+// fp32 addition is not associative, so each sum is a serial chain; the four chains run in four lanes of one wave, fed from LDS
+// chunks the whole workgroup stages (the conditional sums add 0.f where the condition fails: exact, the sums are >= +0).
+// `sigma`/`sigma_L` are dead in the reference (ipdenoise.cc:935-937) and not computed.  One workgroup per crop.
+#define DNINFO_CHUNK 4096
+__global__ void __launch_bounds__(256) dninfo_stats_kernel(DnInfoArgs a)
+{
+    __shared__ __align__(16) float buf[4][DNINFO_CHUNK];
+    __shared__ int s_cnt[2];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    const long long n2 = (long long)a.wid * a.hei;
+    const float *hue = a.maps + (size_t)k * 3 * n2, *chrom = hue + n2, *lum = chrom + n2;
+    if (tid < 2) s_cnt[tid] = 0;
+    float acc = 0.f;           // lane c < 4 of wave 0: chain c (0 chro, 1 lume, 2 red_yel, 3 skin_c)
+    int nry = 0, nsk = 0;
+    for (long long base = 0; base < n2; base += DNINFO_CHUNK) {
+        const int m = (int)((n2 - base) < DNINFO_CHUNK ? (n2 - base) : DNINFO_CHUNK);
+        __syncthreads();
+        for (int e = tid; e < DNINFO_CHUNK; e += 256) {
+            float c = 0.f, l = 0.f, ry = 0.f, sk = 0.f;
+            if (e < m) {
+                const float h = hue[base + e];
+                c = chrom[base + e];
+                l = lum[base + e];
+                if (h > -0.8f && h < 2.0f && c > 10000.f) { ry = c; ++nry; }
+                if (h > 0.f && h < 1.6f && c < 10000.f) { sk = c; ++nsk; }
+            }
+            buf[0][e] = c; buf[1][e] = l; buf[2][e] = ry; buf[3][e] = sk;
+        }
+        __syncthreads();
+        if (tid < 4) {
+            const float4 *p = reinterpret_cast<const float4 *>(buf[tid]);
+            const int m4 = (m + 3) / 4;          // the padding of a partial chunk is 0.f
+#pragma unroll 8
+            for (int e = 0; e < m4; ++e) {
+                const float4 v = p[e];
+                acc += v.x; acc += v.y; acc += v.z; acc += v.w;
+            }
+        }
+    }
+    atomicAdd(&s_cnt[0], nry);
+    atomicAdd(&s_cnt[1], nsk);
+    __syncthreads();
+    if (tid < 4) a.stats[k * 8 + tid] = acc;
+    if (tid == 0) { a.stats[k * 8 + 4] = __int_as_float(s_cnt[0]); a.stats[k * 8 + 5] = __int_as_float(s_cnt[1]); }
+}
+// labdn->a / labdn->b of one crop: gain, gamma (LUT flags 0 below 65535, the analytic curve above; factor 32768), rgb2yuv
+// (ipdenoise.cc:460-482)
+__global__ void __launch_bounds__(256) dninfo_ab_kernel(DnInfoArgs a)
+{
+    const int k = a.crop;
+    const long long n = (long long)a.crW * a.crH;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(t / a.crW), j = (int)(t - (long long)i * a.crW);
+        const size_t si = (size_t)(a.sy[k] + i) * a.stride + a.sx[k] + j;
+        float X = a.gain * dninfo_fetch(a, 0, si), Y = a.gain * dninfo_fetch(a, 1, si), Z = a.gain * dninfo_fetch(a, 2, si);
+        X = X < 65535.f ? lutf_noclip(a.gamcurve, X) : (gammaf_s(X / 65535.f, a.gam, a.gamthresh, a.gamslope) * 32768.f);
+        Y = Y < 65535.f ? lutf_noclip(a.gamcurve, Y) : (gammaf_s(Y / 65535.f, a.gam, a.gamthresh, a.gamslope) * 32768.f);
+        Z = Z < 65535.f ? lutf_noclip(a.gamcurve, Z) : (gammaf_s(Z / 65535.f, a.gam, a.gamthresh, a.gamslope) * 32768.f);
+        const float l = X * a.wp[3] + Y * a.wp[4] + Z * a.wp[5];
+        a.A[t] = X - l;
+        a.B[t] = l - Z;
+    }
+}
+hipError_t launch_dninfo_maps(const DnInfoArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(dninfo_maps_kernel, dim3(flat_grid((long long)a.wid * a.hei, 512), 9), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_dninfo_stats(const DnInfoArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(dninfo_stats_kernel, dim3(9), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_dninfo_ab(const DnInfoArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(dninfo_ab_kernel, dim3(flat_grid((long long)a.crW * a.crH, 1024)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 } // namespace artgpu

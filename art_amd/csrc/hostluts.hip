@@ -195,4 +195,102 @@ void build_pq_luts(float *pq, float *pq_inv)
     }
 }
 
+// ---------------------------------------------------------------- AUTOMATIC chrominance: the scalar part of the estimation
+// ShrinkAll_info's per-band bookkeeping (FTblockDN.cc:1292-1334) over the 5 levels x 3 directions of one crop.
+// mad_a / mad_b: SQR(MadRgb) of the a / b subbands in level-major order (what launch_mad leaves on the device).  out: chaut, maxredaut, maxblueaut, minredaut, minblueaut, Nb
+void dninfo_band_stats(const float *mad_a, const float *mad_b, int nbands, bool aggressive, float out[6])
+{
+    const float reduc = aggressive ? static_cast<float>(0.9) : 1.f;
+    float chau = 0.f, maxchred = 0.f, maxchblue = 0.f, minchred = 100000000.f, minchblue = 100000000.f;
+    float chaut = 0.f, maxredaut = 0.f, maxblueaut = 0.f, minredaut = 0.f, minblueaut = 0.f;
+    int nb = 0;
+    for (int k = 0; k < nbands; ++k) {
+        const float mada = mad_a[k], madb = mad_b[k];
+        maxchred = mada > maxchred ? mada : maxchred;
+        minchred = mada < minchred ? mada : minchred;
+        maxredaut = std::sqrt(reduc * maxchred);
+        minredaut = std::sqrt(reduc * minchred);
+        maxchblue = madb > maxchblue ? madb : maxchblue;
+        minchblue = madb < minchblue ? madb : minchblue;
+        maxblueaut = std::sqrt(reduc * maxchblue);
+        minblueaut = std::sqrt(reduc * minchblue);
+        chau += (mada + madb);
+        ++nb;
+        chaut = std::sqrt(reduc * chau / (nb + nb));
+    }
+    out[0] = chaut; out[1] = maxredaut; out[2] = maxblueaut; out[3] = minredaut; out[4] = minblueaut; out[5] = (float)nb;
+}
+
+// calcautodn_info (ipdenoise.cc:66-206) for the arguments its one caller passes: levaut 0, mode 1 ("auto"), lissage 0
+// (ipdenoise.cc:893,1003-1004).  Returns delta; chaut is updated in place like the reference's by-reference argument.
+static float autodn_adjust(float &chaut, int Nb, float maxmax, float lumema, float chromina, float redyel, float skinc, float nsknc, bool aggressive)
+{
+    struct Step { float below; float scale; };
+    chaut = (chaut * Nb - maxmax) / (Nb - 1);                        // drop the maximum from the mean
+    const bool strong_colour = chromina > 3000.f;
+    if ((redyel > 5000.f || skinc > 1000.f) && nsknc < 0.4f && strong_colour) chaut *= 0.45f;
+    else if ((redyel > 12000.f || skinc > 1200.f) && nsknc < 0.3f && strong_colour) chaut *= 0.3f;
+    if (chromina > 10000.f) chaut *= 0.8f;
+    else if (chromina > 6000.f) chaut *= 0.9f;
+    else if (chromina < 3000.f) chaut *= 1.5f;
+    if (lumema < 2500.f) chaut *= 1.2f;
+    else if (lumema < 5000.f) chaut *= 1.1f;
+    else if (lumema > 20000.f) chaut *= 0.9f;
+    if (chaut > 300.f) chaut = 0.714286f * chaut + 85.71428f;      // "low denoise"
+    float delta = (maxmax - chaut) * (aggressive ? static_cast<float>(0.9) : 1.f);
+    if (chaut < 400.f) {
+        const bool low = chaut < 200.f;
+        const float knee = low ? 200.f : 400.f;
+        if (delta < knee) delta *= low ? 0.95f : 0.6f;
+        else if (low && delta < 400.f) delta *= 0.7f;
+        else delta = low ? 280.f : 200.f;
+    } else {
+        static const Step ladder[] = {{550.f, 0.3f}, {650.f, 0.2f}};
+        float sc = 0.15f;
+        for (const Step &st : ladder) if (chaut < st.below) { sc = st.scale; break; }
+        delta *= sc;
+    }
+    if (chromina < 6000.f) delta *= 1.2f;
+    if (lumema < 5000.f) delta *= 1.2f;
+    return delta;
+}
+
+// The reduction over the nine crops (ipdenoise.cc:960-1072): autoNR 10, autoNRmax 40, multip = adjustr = lowdenoise = 1 (raw).
+// info[k] = {chaut, maxredaut, maxblueaut, minredaut, minblueaut, chromina, lumema, redyel, skinc, nsknc, Nb}
+void dninfo_reduce(const float info[9][16], bool aggressive, float ch_M[9], float max_r[9], float max_b[9], float out3[3])
+{
+    const float nrmax = 40.f, nr = 10.f;
+    float up_r[9], up_b[9], dn_r[9], dn_b[9];
+    for (int k = 0; k < 9; ++k) {
+        ch_M[k] = 1.0f * info[k][0]; max_r[k] = 1.0f * info[k][1]; max_b[k] = 1.0f * info[k][2];
+        const float min_r = 1.0f * info[k][3], min_b = 1.0f * info[k][4];
+        const float delta = autodn_adjust(ch_M[k], (int)info[k][10], std::max(max_r[k], max_b[k]), info[k][6], info[k][5], info[k][7], info[k][8], info[k][9], aggressive);
+        const bool red = max_r[k] > max_b[k];
+        const float up = delta / (nrmax / 2.f);
+        up_r[k] = red ? up : 0.f;
+        up_b[k] = red ? 0.f : up;
+        dn_b[k] = red ? -(ch_M[k] - min_b) / nrmax : 0.f;
+        dn_r[k] = red ? 0.f : -(ch_M[k] - min_r) / nrmax;
+    }
+    float chM = 0.f, top_r = 0.f, top_b = 0.f, low_r = 100000000000.f, low_b = 100000000000.f;
+    float mean_up_r = 0.f, mean_up_b = 0.f, mean_dn_r = 0.f, mean_dn_b = 0.f;
+    for (int k = 0; k < 9; ++k) {
+        chM += ch_M[k]; mean_up_b += up_b[k]; mean_up_r += up_r[k]; mean_dn_r += dn_r[k]; mean_dn_b += dn_b[k];
+        if (up_r[k] > top_r) top_r = up_r[k];
+        if (up_b[k] > top_b) top_b = up_b[k];
+        if (dn_r[k] < low_r) low_r = dn_r[k];
+        if (dn_b[k] < low_b) low_b = dn_b[k];
+    }
+    chM /= 9; mean_up_b /= 9; mean_up_r /= 9; mean_dn_b /= 9; mean_dn_r /= 9;
+    float maxr, maxb;
+    if (top_r > top_b) {
+        maxr = mean_up_r + (top_r - mean_up_r) * 0.66f;
+        maxb = mean_dn_b + (low_b - mean_dn_b) * 0.66f;
+    } else {
+        maxb = mean_up_b + (top_b - mean_up_b) * 0.66f;
+        maxr = mean_dn_r + (low_r - mean_dn_r) * 0.66f;
+    }
+    out3[0] = chM / nr; out3[1] = maxr; out3[2] = maxb;
+}
+
 } // namespace artgpu

@@ -115,6 +115,26 @@ struct ScaleArgs {
     int *chmax_bits;                      // [3] channel maxima as float bit patterns (values are >= 0)
 };
 hipError_t launch_scale_colors(const ScaleArgs &a, hipStream_t s);
+// AUTOMATIC chrominance estimation (ipdenoise.cc:227-669,800-1093; FTblockDN.cc:1227-1362): the nine quarter-image crops
+struct DnInfoArgs {
+    const float *src[3];     // RawImageSource red/green/blue (full planes)
+    size_t stride;
+    float mul[3];
+    int do_clip;
+    int sx[9], sy[9];        // crop origins in plane coordinates (border included), crop k = hcr*3 + wcr
+    int crW, crH, wid, hei;  // crop size and its half-resolution size
+    double mat[9];           // camera -> working (convertColorSpace)
+    float wp[9];             // working space -> XYZ
+    const float *cachef, *cachefy, *gamcurve;
+    float gain, gam, gamthresh, gamslope;
+    float *maps;             // [9][3][wid*hei]: hue, chroma, luminance
+    float *A, *B;            // labdn->a / labdn->b of ONE crop (crW*crH)
+    int crop;                // which crop dninfo_ab fills
+    float *stats;            // [9][8]: chro, lume, red_yel, skin_c sums, then nry, nsk as int bits
+};
+hipError_t launch_dninfo_maps(const DnInfoArgs &a, hipStream_t s);
+hipError_t launch_dninfo_stats(const DnInfoArgs &a, hipStream_t s);
+hipError_t launch_dninfo_ab(const DnInfoArgs &a, hipStream_t s);
 // channelMixer (ipchmixer.cc:185-230) and rgbCurves (iprgbcurves.cc:116-143) on a PixArgs image; mat[9] as floats in `mixf`
 struct MixArgs { float *dst[3]; size_t stride; int w, h; float m[9]; const float *lut[3]; };
 hipError_t launch_channel_mixer(const MixArgs &a, hipStream_t s);
@@ -131,6 +151,8 @@ struct NeutralArgs {
 hipError_t launch_neutral_hues(const NeutralArgs &a, hipStream_t s);
 hipError_t launch_tone_neutral(const NeutralArgs &a, hipStream_t s);
 void build_pq_luts(float *pq65536, float *pq_inv65536);
+void dninfo_band_stats(const float *mad_a, const float *mad_b, int nbands, bool aggressive, float out[6]);
+void dninfo_reduce(const float info[9][16], bool aggressive, float ch_M[9], float max_r[9], float max_b[9], float out3[3]);
 
 // ---- wavelet_decomposition (wavelet.hip) ----
 struct WaveArgs {

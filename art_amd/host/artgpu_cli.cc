@@ -5,7 +5,7 @@
 // 16-bit PPM.  Input: raw little-endian float32 (values 0..65535) or uint16, W*H samples.
 //
 //   artgpu-cli --in frame.f32 --width 4000 --height 3000 [--u16] [--filters 0x94949494]
-//              [--method amaze|rcd] [--border 4] [--denoise L,C] [--expcomp 0.3] [--out out.ppm]
+//              [--method amaze|rcd] [--border 4] [--denoise L,C] [--chroma-auto] [--expcomp 0.3] [--out out.ppm]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -36,7 +36,7 @@ int main(int argc, char **argv)
     bool u16 = false;
     uint32_t filters = 0x94949494u;
     double lum = 0, chroma = 0, expcomp = 0;
-    bool dn = false, smoothing = false;
+    bool dn = false, smoothing = false, chroma_auto = false;
     int tone_mode = ARTGPU_TONE_STD;
     int xtrans_passes = 0;   // 0 = Bayer; 1 / 3 = X-Trans ONE_PASS / THREE_PASS with the Fuji colour map
     int gradius = 3, nlstrength = 0, nldetail = 80;
@@ -52,6 +52,7 @@ int main(int argc, char **argv)
         else if (a == "--border") border = std::atoi(next());
         else if (a == "--expcomp") expcomp = std::atof(next());
         else if (a == "--method") { std::string m = next(); method = (m == "rcd") ? ARTGPU_BAYER_RCD : ARTGPU_BAYER_AMAZE; }
+        else if (a == "--chroma-auto") { chroma_auto = true; }
         else if (a == "--denoise") { dn = true; if (std::sscanf(next(), "%lf,%lf", &lum, &chroma) != 2) { std::fprintf(stderr, "--denoise L,C\n"); return 2; } }
         else if (a == "--xtrans") { xtrans_passes = std::atoi(next()); border = 7; }
         else if (a == "--tone") { std::string m = next(); tone_mode = (m == "neutral") ? ARTGPU_TONE_NEUTRAL : ARTGPU_TONE_STD; }
@@ -95,11 +96,19 @@ int main(int argc, char **argv)
         imgsrc.getFullSize(fw, fh);
         Imagefloat img(fw, fh);
         const float mul[3] = {2.1374f, 1.0f, 1.5918f};
+        const double mat[9] = {0.6325, 0.2312, 0.0921, 0.2198, 0.7712, 0.0090, 0.0166, 0.0713, 0.7514};
+        ImProcFunctions ipf(ctx, &params, 1.0);
+        if (dn && chroma_auto) {    // simpleprocess.cc:254-256
+            ImProcFunctions::DenoiseInfoStore dnstore;
+            params.denoise.chrominanceMethod = 1;
+            imgsrc.setColorMatrix(mat);
+            ipf.denoiseComputeParams(&imgsrc, mul, true, dnstore, params.denoise);
+            std::fprintf(stderr, "auto chrominance: %.6f  red-green %.6f  blue-yellow %.6f\n", params.denoise.chrominance,
+                         params.denoise.chrominanceRedGreen, params.denoise.chrominanceBlueYellow);
+        }
         imgsrc.getImage(mul, true, &img);
         // stage_denoise (simpleprocess.cc:311-315)
-        const double mat[9] = {0.6325, 0.2312, 0.0921, 0.2198, 0.7712, 0.0090, 0.0166, 0.0713, 0.7514};
         imgsrc.convertColorSpace(&img, mat);
-        ImProcFunctions ipf(ctx, &params, 1.0);
         ipf.denoise(&imgsrc, &img);
         // stage_finish (simpleprocess.cc:389-396)
         ipf.process(ImProcFunctions::Pipeline::OUTPUT, ImProcFunctions::Stage::STAGE_1, &img);

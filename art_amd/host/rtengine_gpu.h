@@ -79,8 +79,8 @@ struct ProcParams {
     enum XTransMethod { ONE_PASS = 1, THREE_PASS = 3 };
     struct { int method = THREE_PASS; int border = 7; } xtranssensor;          // raw.xtranssensor.{method,border} (procparams.cc:3064)
     struct { bool enabled = false; double luminance = 0, luminanceDetail = 0; int luminanceDetailThreshold = 0; double chrominance = 15,
-             chrominanceRedGreen = 0, chrominanceBlueYellow = 0, gamma = 1.7; bool aggressive = false; int colorSpace = 0, chrominanceMethod = 0;
-             bool smoothingEnabled = false; int guidedChromaRadius = 3, nlDetail = 80, nlStrength = 0; } denoise;   // procparams.cc:1900-1918 (chrominanceMethod 0 = MANUAL here)
+             chrominanceRedGreen = 0, chrominanceBlueYellow = 0, gamma = 1.7, chrominanceAutoFactor = 1; bool aggressive = false; int colorSpace = 0, chrominanceMethod = 0;
+             bool smoothingEnabled = false; int guidedChromaRadius = 3, nlDetail = 80, nlStrength = 0; } denoise;   // procparams.cc:1900-1918 (chrominanceMethod: 0 MANUAL, 1 AUTOMATIC)
     struct { bool enabled = true; double expcomp = 0, black = 0; } exposure;
     struct { bool enabled = true; int curveMode = ARTGPU_TONE_STD; std::vector<float> lut; float whitePoint = 1.f; bool basecurveLinear = true; } toneCurve;
     // toneCurve.curveMode: ARTGPU_TONE_STD or ARTGPU_TONE_NEUTRAL (ART's default, procparams.cc:1585)
@@ -191,6 +191,24 @@ public:
             return;
         }
         ctx.check(artgpu_tone_curve(ctx.get(), &i, params->toneCurve.curveMode, lut, params->toneCurve.whitePoint, params->toneCurve.basecurveLinear ? 1 : 0));
+    }
+    // DenoiseInfoStore (improcfun.h:117-131)
+    struct DenoiseInfoStore : artgpu_denoise_info_store {
+        DenoiseInfoStore() { reset(); }
+        void reset() { *static_cast<artgpu_denoise_info_store *>(this) = artgpu_denoise_info_store{}; }
+    };
+    // ImProcFunctions::denoiseComputeParams (ipdenoise.cc:800-1093): AUTOMATIC chrominance from nine crops of the sensor planes.
+    // The reference pulls rm/gm/bm and the camera matrix out of imgsrc/currWB/params->icm; here the caller hands in the
+    // multipliers and must have called imgsrc->setColorMatrix().
+    void denoiseComputeParams(RawImageSource *imgsrc, const float mul[3], bool doClip, DenoiseInfoStore &store, decltype(ProcParams::denoise) &dnparams)
+    {
+        artgpu_denoise_params dn{dnparams.luminance, dnparams.luminanceDetail, dnparams.luminanceDetailThreshold, dnparams.chrominance,
+                                 dnparams.chrominanceRedGreen, dnparams.chrominanceBlueYellow, dnparams.gamma, dnparams.aggressive ? 1 : 0,
+                                 dnparams.colorSpace, dnparams.chrominanceMethod};
+        artgpu_rgb planes{imgsrc->red.view(), imgsrc->green.view(), imgsrc->blue.view()};
+        ctx.check(artgpu_denoise_compute_params(ctx.get(), &planes, imgsrc->border, mul, doClip ? 1 : 0, imgsrc->colorMatrix, params->workingSpace,
+                                                dnparams.chrominanceAutoFactor, &store, &dn));
+        dnparams.chrominance = dn.chrominance; dnparams.chrominanceRedGreen = dn.chrominance_red_green; dnparams.chrominanceBlueYellow = dn.chrominance_blue_yellow;
     }
     // ImProcFunctions::denoise (ipdenoise.cc:1096-1189): calclum/ccalc chroma noise map with the fixed noise curve
     // (L1139-1149), exposure pre-compensation, RGB_denoise, guided smoothing + NL-means, post-compensation.

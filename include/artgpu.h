@@ -256,6 +256,32 @@ int artgpu_scale_colors(artgpu_ctx *ctx, const void *src, int32_t w, int32_t h, 
                         int32_t src_on_device, uint32_t filters, const int32_t *xtrans, const float cblacksom[4],
                         const float scale_mul[4], artgpu_plane *dst, float chmax[4]);
 
+/* ImProcFunctions::denoiseComputeParams (rtengine/ipdenoise.cc:800-1093): the AUTOMATIC chrominance estimation (the default
+ * chrominanceMethod, procparams.cc:1909).  Nine crops of (widIm/2) x (heiIm/2) of the white-balanced sensor planes go through
+ * RGB_denoise_info (ipdenoise.cc:227-669): Lab hue/chroma/luminance statistics at half resolution, a 5-level wavelet
+ * decomposition of the gamma-encoded chroma planes and the MADs of its 30 subbands (WaveletDenoiseAll_info / ShrinkAll_info,
+ * FTblockDN.cc:1227-1362), calcautodn_info (ipdenoise.cc:66-206) per crop and the reduction of L960-1072.  Raw sources only
+ * (imgsrc->isRAW()).
+ *   planes        : RawImageSource red/green/blue after demosaic (what getImage reads)
+ *   border        : RawImageSource::border (getFullSize subtracts it twice, transformRect adds it to every crop origin)
+ *   mul, do_clip  : getImage's per-channel multipliers and clip flag, as for artgpu_get_image
+ *   cam_to_work   : the convertColorSpace matrix, as for artgpu_convert_color_space
+ *   ws            : ICCStore::workingSpaceMatrix(params->icm.workingProfile)
+ *   store         : DenoiseInfoStore (improcfun.h:117-131).  valid != 0 on entry: only dn is refreshed from it (L802-809).
+ *   dn            : in: gamma, aggressive, chrominance_method; out: chrominance, chrominance_red_green, chrominance_blue_yellow
+ *                   = store value x chrominance_auto_factor.  chrominance_method != AUTOMATIC: nothing happens. */
+typedef struct {
+    int32_t valid;
+    float   ch_M[9], max_r[9], max_b[9];
+    double  chrominance, chrominance_red_green, chrominance_blue_yellow;
+    /* diagnostics, not part of the reference's store: per crop (k = hcr*3 + wcr) {chaut, maxredaut, maxblueaut, minredaut,
+     * minblueaut, chromina, lumema, redyel, skinc, nsknc, Nb, 0...} as RGB_denoise_info returns them */
+    float   crop_info[9][16];
+} artgpu_denoise_info_store;
+int artgpu_denoise_compute_params(artgpu_ctx *ctx, const artgpu_rgb *planes, int border, const float mul[3], int do_clip,
+                                  const double cam_to_work[9], const double ws[9], double chrominance_auto_factor,
+                                  artgpu_denoise_info_store *store, artgpu_denoise_params *dn);
+
 /* Two of the default-off pixelwise steps of ImProcFunctions::process, so that a frame with these
  * common edits stays on the device:
  * artgpu_channel_mixer : the pixel loop of ImProcFunctions::channelMixer (ipchmixer.cc:185-230); m = {RR,RG,RB, GR,GG,GB,
@@ -295,6 +321,8 @@ typedef struct {
     float white_point;
     float to_out[9], to_work[9];    /* NEUTRAL only */
     double scale;
+    double chrominance_auto_factor; /* DenoiseParams::chrominanceAutoFactor; 0 means 1 (only read when denoise.dn.chrominance_method is AUTOMATIC:
+                                     * artgpu_denoise_compute_params then runs on the demosaiced planes, as simpleprocess.cc:254-256 does) */
 } artgpu_pipeline_params;
 int artgpu_pipeline_run(artgpu_ctx *ctx, const artgpu_plane *raw, const artgpu_pipeline_params *params, artgpu_rgb *out);
 

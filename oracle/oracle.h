@@ -71,6 +71,11 @@ void oracle_scale_colors(const void *src, int src_u16, int w, int h, const int c
                          const float scale_mul[4], float *dst, float chmax[4]);
 void oracle_channel_mixer(float *const img[3], size_t s, int w, int h, const float m[9]);
 void oracle_rgb_curves(float *const img[3], size_t s, int w, int h, const float *const luts[3]);
+/* AUTOMATIC chrominance estimation (oracle/dninfo.c) */
+float oracle_autodn_adjust(float *chaut_io, int Nb, float maxmax, float lumema, float chromina, float redyel, float skinc, float nsknc, int aggressive);
+void oracle_denoise_info_crop(const float *const crop[3], int crW, int crH, const double mat[9], const float wp[9], double gamma, int aggressive, float *info);
+int oracle_denoise_compute_params(const float *const planes[3], size_t ss, int W, int H, int border, const float mul[3], int do_clip,
+                                  const double mat[9], const float wp[9], double gamma, int aggressive, float *store_out, float *info_out);
 void oracle_rgb_to_yuv(float *const img[3], size_t s, int w, int h, const float ws[9]);
 void oracle_yuv_to_rgb(float *const img[3], size_t s, int w, int h, const float ws[9]);
 

@@ -45,6 +45,7 @@ void ref_vexpf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; i
 void ref_vlogf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, xlogf(_mm_loadu_ps(x + i))); }
 void ref_vexpf_nocheck(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, xexpfNoCheck(_mm_loadu_ps(x + i))); }
 void ref_vlogf_nocheck(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, xlogfNoCheck(_mm_loadu_ps(x + i))); }
+void ref_vatan2f(const float *a, const float *b, float *y, size_t n) { for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, xatan2f(_mm_loadu_ps(a + i), _mm_loadu_ps(b + i))); }
 void ref_vmedian3(const float *a, const float *b, const float *c, float *y, size_t n)
 {
     for (size_t i = 0; i < n; i += 4) _mm_storeu_ps(y + i, median(_mm_loadu_ps(a + i), _mm_loadu_ps(b + i), _mm_loadu_ps(c + i)));

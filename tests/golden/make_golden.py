@@ -114,6 +114,19 @@ def sleef2():
     np.savez_compressed(os.path.join(HERE, "sleef2.npz"), xc=xc, cbrt=y, ay=ay, ax=ax, atan2=at, sd=sd, sin=sn, cos=cs)
 
 
+def sleef3():
+    """4-lane xatan2f as RGB_denoise_info's hue map uses it (ipdenoise.cc:395-402): Lab a/b magnitudes, plus the special cases"""
+    rng = np.random.default_rng(12)
+    n = 8192
+    ay = np.concatenate([rng.uniform(-30000, 30000, n // 2), rng.uniform(-300, 300, n // 4), rng.uniform(-1e-3, 1e-3, n // 4)]).astype(np.float32)
+    ax = np.concatenate([rng.uniform(-30000, 30000, n // 2), rng.uniform(-300, 300, n // 4), rng.uniform(-1e-3, 1e-3, n // 4)]).astype(np.float32)
+    ay[:12] = [0.0, -0.0, 1.0, -1.0, 0.0, 1e-30, np.inf, 0.3, -np.inf, 5.0, -0.0, 0.0]
+    ax[:12] = [1.0, -1.0, 0.0, -0.0, 0.0, -1e-30, 1.0, np.nan, np.inf, -np.inf, -0.0, -2.0]
+    at = np.empty(n, np.float32)
+    R.ref_vatan2f(P(ay), P(ax), P(at), C.c_size_t(n))
+    np.savez_compressed(os.path.join(HERE, "sleef3.npz"), ay=ay, ax=ax, atan2_v=at)
+
+
 from make_golden_inputs import wavelet_input  # noqa: E402
 
 
@@ -160,4 +173,5 @@ if __name__ == "__main__":
     lutf()
     sleef()
     sleef2()
+    sleef3()
     print("golden vectors written to", HERE)

@@ -383,3 +383,19 @@ def rgb_curves(img, luts):
     arr = (_fp * 3)(*[None if k is None else _ptr(k) for k in keep])
     lib().oracle_rgb_curves(_p3(img), C.c_size_t(w), w, h, arr)
     return img
+
+
+def denoise_compute_params(planes, border, mul, do_clip, mat, ws, gamma=1.7, aggressive=False):
+    """ImProcFunctions::denoiseComputeParams (ipdenoise.cc:800-1093). Returns (store[30], info[9,16]) or None if too small."""
+    planes = [np.ascontiguousarray(p, dtype=np.float32) for p in planes]
+    h, w = planes[0].shape
+    store = np.zeros(30, np.float32)
+    info = np.zeros((9, 16), np.float32)
+    m = (C.c_double * 9)(*[float(v) for v in np.asarray(mat, dtype=np.float64).reshape(9)])
+    wp = np.ascontiguousarray(np.asarray(ws, dtype=np.float64).astype(np.float32)).reshape(9)
+    L = lib()
+    L.oracle_denoise_compute_params.argtypes = [C.POINTER(_fp), C.c_size_t, C.c_int, C.c_int, C.c_int, _fp, C.c_int, C.POINTER(C.c_double), _fp,
+                                                C.c_double, C.c_int, _fp, _fp]
+    rc = L.oracle_denoise_compute_params(_p3(planes), w, w, h, int(border), (C.c_float * 3)(*[float(v) for v in mul]), 1 if do_clip else 0, m,
+                                         _ptr(wp), float(gamma), 1 if aggressive else 0, _ptr(store), _ptr(info))
+    return None if rc else (store, info)

@@ -54,6 +54,7 @@ def run_cli(tmp_path, raw, method, extra=()):
     res = subprocess.run([CLI, "--in", str(inp), "--width", str(w), "--height", str(h), "--method", method, "--out", str(out), *extra],
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr
+    run_cli.last_stderr = res.stderr
     return json.loads(res.stdout.strip().splitlines()[-1]), read_ppm16(out)
 
 
@@ -120,3 +121,23 @@ def test_xtrans_three_pass_through_cli(tmp_path):
     img = O.tone_std(img, tone_lut(), 1.0, True)
     q = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.int32) for p in img], axis=-1)
     assert np.abs(ppm.astype(np.int32) - q).max() <= 3      # DCT detail recovery tolerance only
+
+
+def test_automatic_chroma_through_cli(tmp_path):
+    """--chroma-auto: denoiseComputeParams on the demosaiced planes (the default chrominanceMethod of ART), then the same pipe."""
+    w, h, filt = 648, 488, synth.FILTERS_RGGB
+    raw = synth.bayer_frame(w, h, filt, seed=5, noise=2600)
+    info, ppm = run_cli(tmp_path, raw, "amaze", ("--denoise", "40,15", "--chroma-auto"))
+    planes = O.amaze(raw, filt, 1.0, 4)
+    store, _ = O.denoise_compute_params(planes, 4, MUL, True, MAT, O.REC2020_WS_D)
+    line = [l for l in run_cli.last_stderr.splitlines() if l.startswith("auto chrominance")][0].split()
+    assert abs(float(line[2]) - float(store[0])) < 1e-5 and abs(float(line[4]) - float(store[1])) < 1e-5 and abs(float(line[6]) - float(store[2])) < 1e-5
+    img = O.get_image(planes, 4, 4, w - 8, h - 8, MUL, True)
+    img = O.convert_color_space(img, MAT)
+    curve, _ = O.noise_curve()
+    img = O.improc_denoise(img, dict(luminance=40.0, chrominance=float(store[0]), chrominanceRedGreen=float(store[1]), chrominanceBlueYellow=float(store[2]), autoch=1),
+                           calclum_mat=MAT, noise_c_curve=curve, smoothing=False, detail_recovery=True)
+    img = O.exposure(img, 1.0, 0.0)
+    img = O.tone_std(img, tone_lut(), 1.0, True)
+    q = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.int32) for p in img], axis=-1)
+    assert np.abs(ppm.astype(np.int32) - q).max() <= 3

@@ -85,3 +85,38 @@ def test_batch_run_two_frames(gpu_ctx):
         for a, s in zip(o, single):
             assert np.array_equal(a.view(np.uint32), s.view(np.uint32)) and a.max() > 0
     assert not np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_pipeline_automatic_chroma_equals_explicit_compute_params(gpu_ctx):
+    """chrominance_method AUTOMATIC inside artgpu_pipeline_run = denoiseComputeParams on the demosaiced planes, then the same
+    stages with the estimated values (simpleprocess.cc:254-256,311-315)."""
+    w, h = 520, 392
+    raw = synth.bayer_frame(w, h, synth.FILTERS_RGGB, seed=9, noise=2600)
+    lut = _lut()
+    p = _params(lut, 0)
+    p.denoise.dn.chrominance_method = 1
+    p.denoise.dn.chrominance = 0.0
+    p.chrominance_auto_factor = 1.5
+    got = [np.zeros((h - 8, w - 8), np.float32) for _ in range(3)]
+    gpu_ctx.pipeline_run(capi.host_plane(raw), p, capi.host_rgb(got))
+    d_raw = torch.from_numpy(raw).cuda()
+    d_dem = [torch.empty((h, w), dtype=torch.float32, device="cuda") for _ in range(3)]
+    dem = capi.RGB(*[capi.device_plane(t) for t in d_dem])
+    gpu_ctx.demosaic_bayer(capi.BAYER_AMAZE, capi.device_plane(d_raw), synth.FILTERS_RGGB, 1.0, 4, dem)
+    dn = capi.DenoiseParams(40.0, 50.0, 0, 0.0, 0.0, 0.0, 1.7, 0, 0, 1)
+    st = gpu_ctx.denoise_compute_params(dem, 4, MUL, True, MAT, O.REC2020_WS_D, dn, auto_factor=1.5)
+    assert st.valid == 1 and dn.chrominance > 0
+    # the oracle agrees on the estimate
+    ref = O.denoise_compute_params([t.cpu().numpy() for t in d_dem], 4, MUL, True, MAT, O.REC2020_WS_D)
+    assert np.float32(st.chrominance) == ref[0][0] and np.float32(st.chrominance_red_green) == ref[0][1]
+    d_img = [torch.empty((h - 8, w - 8), dtype=torch.float32, device="cuda") for _ in range(3)]
+    img = capi.RGB(*[capi.device_plane(t) for t in d_img])
+    gpu_ctx.get_image(dem, 4, 4, MUL, True, MAT, img)
+    curve, _ = capi.noise_curve_lut()
+    tp = capi.DenoiseToolParams(dn, 0, 3, 0, 80)
+    gpu_ctx.improc_denoise(img, tp, O.REC2020_WS_D, ecomp=0.3, calclum_mat=MAT, noise_c_curve=curve, iws=O.REC2020_IWS_D)
+    gpu_ctx.exposure(img, float(np.float32(2.0 ** 0.3)), 0.0)
+    gpu_ctx.tone_curve(img, lut, 1.0, True)
+    gpu_ctx.synchronize()
+    for g, t in zip(got, d_img):
+        assert np.array_equal(g.view(np.uint32), t.cpu().numpy().view(np.uint32))
