@@ -130,6 +130,7 @@ def _load():
                                         C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Plane), C.POINTER(C.c_float)]
     lib.artgpu_denoise_compute_params.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_double),
                                                   C.POINTER(C.c_double), C.c_double, C.POINTER(DenoiseInfoStore), C.POINTER(DenoiseParams)]
+    lib.artgpu_ordered_sum_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float)]
     lib.artgpu_channel_mixer.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float)]
     lib.artgpu_rgb_curves.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_pipeline_run.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
@@ -155,7 +156,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -274,6 +275,17 @@ class Context:
         self._chk(LIB.artgpu_denoise_compute_params(self._h, C.byref(planes), int(border), (C.c_float * 3)(*[float(v) for v in mul]),
                                                     1 if do_clip else 0, d9(cam_to_work), d9(ws), float(auto_factor), C.byref(store), C.byref(dn)))
         return store
+
+    def ordered_sum_f32(self, x) -> np.float32:
+        """acc = 0; for v in x: acc += v  (fp32), x a numpy array (host) or a CUDA torch tensor"""
+        r = C.c_float(0)
+        if isinstance(x, np.ndarray):
+            a = np.ascontiguousarray(x, dtype=np.float32)
+            self._chk(LIB.artgpu_ordered_sum_f32(self._h, a.ctypes.data, a.size, 0, C.byref(r)))
+        else:
+            assert x.is_contiguous() and x.dtype.itemsize == 4
+            self._chk(LIB.artgpu_ordered_sum_f32(self._h, x.data_ptr(), x.numel(), 1, C.byref(r)))
+        return np.float32(r.value)
 
     def channel_mixer(self, image: RGB, m):
         self._chk(LIB.artgpu_channel_mixer(self._h, C.byref(image), (C.c_float * 9)(*[float(v) for v in np.asarray(m, np.float32).reshape(9)])))

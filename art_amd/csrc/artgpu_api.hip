@@ -1451,6 +1451,26 @@ int artgpu_denoise_compute_params(artgpu_ctx *ctx, const artgpu_rgb *planes, int
     return ARTGPU_OK;
 }
 
+int artgpu_ordered_sum_f32(artgpu_ctx *ctx, const float *x, int64_t n, int on_device, float *result)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if ((!x && n > 0) || n < 0 || !result) return fail(ctx, ARTGPU_EINVAL, "ordered_sum_f32: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    float *res, *dev = nullptr;
+    int rc = pool_get(ctx, P_DNINFO, (9 * 32 + 9 * 8) * 4, &res);
+    if (rc) return rc;
+    const float *src = x;
+    if (!on_device && n > 0) {
+        if ((rc = pool_get(ctx, P_TMP, (size_t)n * 4, &dev))) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(dev, x, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        src = dev;
+    }
+    HIPCHK(ctx, launch_ordered_sum(src, (long long)n, res, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(result, res, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
 int artgpu_denoise_chroma_map(artgpu_ctx *ctx, const artgpu_rgb *img, const double *calclum_mat, const double ws[9],
                               const float noise_c_curve[501], artgpu_plane *ccalc)
 {

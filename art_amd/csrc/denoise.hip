@@ -613,52 +613,7 @@ __global__ void __launch_bounds__(256) dninfo_maps_kernel(DnInfoArgs a)
         lum[t] = Ll;
     }
 }
-// ShrinkAll_info's lvl == 1 statistics (FTblockDN.cc:1237-1290): four float sums that the reference accumulates in scan order.
-// fp32 addition is not associative, so each sum is a serial chain; the four chains run in four lanes of one wave, fed from LDS
-// chunks the whole workgroup stages (the conditional sums add 0.f where the condition fails: exact, the sums are >= +0).
-// `sigma`/`sigma_L` are dead in the reference (ipdenoise.cc:935-937) and not computed.  One workgroup per crop.
-#define DNINFO_CHUNK 4096
-__global__ void __launch_bounds__(256) dninfo_stats_kernel(DnInfoArgs a)
-{
-    __shared__ __align__(16) float buf[4][DNINFO_CHUNK];
-    __shared__ int s_cnt[2];
-    const int k = blockIdx.x, tid = threadIdx.x;
-    const long long n2 = (long long)a.wid * a.hei;
-    const float *hue = a.maps + (size_t)k * 3 * n2, *chrom = hue + n2, *lum = chrom + n2;
-    if (tid < 2) s_cnt[tid] = 0;
-    float acc = 0.f;           // lane c < 4 of wave 0: chain c (0 chro, 1 lume, 2 red_yel, 3 skin_c)
-    int nry = 0, nsk = 0;
-    for (long long base = 0; base < n2; base += DNINFO_CHUNK) {
-        const int m = (int)((n2 - base) < DNINFO_CHUNK ? (n2 - base) : DNINFO_CHUNK);
-        __syncthreads();
-        for (int e = tid; e < DNINFO_CHUNK; e += 256) {
-            float c = 0.f, l = 0.f, ry = 0.f, sk = 0.f;
-            if (e < m) {
-                const float h = hue[base + e];
-                c = chrom[base + e];
-                l = lum[base + e];
-                if (h > -0.8f && h < 2.0f && c > 10000.f) { ry = c; ++nry; }
-                if (h > 0.f && h < 1.6f && c < 10000.f) { sk = c; ++nsk; }
-            }
-            buf[0][e] = c; buf[1][e] = l; buf[2][e] = ry; buf[3][e] = sk;
-        }
-        __syncthreads();
-        if (tid < 4) {
-            const float4 *p = reinterpret_cast<const float4 *>(buf[tid]);
-            const int m4 = (m + 3) / 4;          // the padding of a partial chunk is 0.f
-#pragma unroll 8
-            for (int e = 0; e < m4; ++e) {
-                const float4 v = p[e];
-                acc += v.x; acc += v.y; acc += v.z; acc += v.w;
-            }
-        }
-    }
-    atomicAdd(&s_cnt[0], nry);
-    atomicAdd(&s_cnt[1], nsk);
-    __syncthreads();
-    if (tid < 4) a.stats[k * 8 + tid] = acc;
-    if (tid == 0) { a.stats[k * 8 + 4] = __int_as_float(s_cnt[0]); a.stats[k * 8 + 5] = __int_as_float(s_cnt[1]); }
-}
+// (ShrinkAll_info's statistics over these maps: orderedsum.hip)
 // labdn->a / labdn->b of one crop: gain, gamma (LUT flags 0 below 65535, the analytic curve above; factor 32768), rgb2yuv
 // (ipdenoise.cc:460-482)
 __global__ void __launch_bounds__(256) dninfo_ab_kernel(DnInfoArgs a)
@@ -680,11 +635,6 @@ __global__ void __launch_bounds__(256) dninfo_ab_kernel(DnInfoArgs a)
 hipError_t launch_dninfo_maps(const DnInfoArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(dninfo_maps_kernel, dim3(flat_grid((long long)a.wid * a.hei, 512), 9), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-hipError_t launch_dninfo_stats(const DnInfoArgs &a, hipStream_t s)
-{
-    hipLaunchKernelGGL(dninfo_stats_kernel, dim3(9), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_dninfo_ab(const DnInfoArgs &a, hipStream_t s)

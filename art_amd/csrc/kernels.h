@@ -135,6 +135,8 @@ struct DnInfoArgs {
 hipError_t launch_dninfo_maps(const DnInfoArgs &a, hipStream_t s);
 hipError_t launch_dninfo_stats(const DnInfoArgs &a, hipStream_t s);
 hipError_t launch_dninfo_ab(const DnInfoArgs &a, hipStream_t s);
+// fp32 sum of x[0..n) in index order, rounding at every step like `for (...) acc += x[i]`, evaluated by an exact scan (orderedsum.hip)
+hipError_t launch_ordered_sum(const float *x, long long n, float *out, hipStream_t s);
 // channelMixer (ipchmixer.cc:185-230) and rgbCurves (iprgbcurves.cc:116-143) on a PixArgs image; mat[9] as floats in `mixf`
 struct MixArgs { float *dst[3]; size_t stride; int w, h; float m[9]; const float *lut[3]; };
 hipError_t launch_channel_mixer(const MixArgs &a, hipStream_t s);

@@ -282,6 +282,12 @@ int artgpu_denoise_compute_params(artgpu_ctx *ctx, const artgpu_rgb *planes, int
                                   const double cam_to_work[9], const double ws[9], double chrominance_auto_factor,
                                   artgpu_denoise_info_store *store, artgpu_denoise_params *dn);
 
+/* acc = 0; for (i = 0; i < n; ++i) acc += x[i];  in fp32 -- the order-defined sum the reference uses for its image statistics
+ * (ShrinkAll_info, FTblockDN.cc:1237-1290), evaluated on the device by an exact parallel scan (values >= 0 take the fast path;
+ * anything else is still exact, one value at a time).  Exported because it is the building block of
+ * artgpu_denoise_compute_params that is worth testing on its own. */
+int artgpu_ordered_sum_f32(artgpu_ctx *ctx, const float *x, int64_t n, int on_device, float *result);
+
 /* Two of the default-off pixelwise steps of ImProcFunctions::process, so that a frame with these
  * common edits stays on the device:
  * artgpu_channel_mixer : the pixel loop of ImProcFunctions::channelMixer (ipchmixer.cc:185-230); m = {RR,RG,RB, GR,GG,GB,

@@ -74,3 +74,48 @@ def test_too_small_fails_loudly(gpu_ctx):
     z = [np.zeros((90, 90), np.float32) for _ in range(3)]
     with pytest.raises(capi.ArtGpuError):
         gpu_ctx.denoise_compute_params(capi.host_rgb(z), 0, (1, 1, 1), False, MAT, O.REC2020_WS_D, dn)
+
+
+def seq_sum(x):
+    """acc = 0; for v in x: acc += v in fp32 (numpy's accumulate is strictly sequential)"""
+    x = np.asarray(x, np.float32)
+    return np.float32(0.0) if x.size == 0 else np.add.accumulate(x, dtype=np.float32)[-1]
+
+
+def _cases():
+    rng = np.random.default_rng(5)
+    yield "uniform", rng.uniform(100, 1e5, 300_001).astype(np.float32)
+    yield "const100_ties", np.full(2_000_003, 100.0, np.float32)          # 100/8 = 12.5: a tie at every step while the sum is in [2^26, 2^27)
+    yield "const_2_and_32768", np.where(rng.random(700_000) < 0.5, 2.0, 32768.0).astype(np.float32)
+    yield "half_ulps", (np.float32(1.0) + rng.integers(0, 4, 500_000).astype(np.float32) * np.float32(0.5)).astype(np.float32)
+    z = rng.uniform(1e4, 2e5, 400_000).astype(np.float32)
+    z[rng.random(z.size) < 0.97] = 0.0
+    z[:50_000] = 0.0
+    yield "sparse_leading_zeros", z
+    yield "all_zero", np.zeros(10_000, np.float32)
+    yield "empty", np.zeros(0, np.float32)
+    yield "one", np.array([3.25], np.float32)
+    yield "wide_range", np.exp(rng.uniform(np.log(1e-3), np.log(1e6), 250_000)).astype(np.float32)
+    yield "growing", np.sort(np.exp(rng.uniform(0, 20, 100_000))).astype(np.float32)
+    yield "big_then_small", np.concatenate([[1e9], rng.uniform(0, 3, 200_000)]).astype(np.float32)
+    yield "lum_like", np.clip(rng.normal(9000, 6000, 1_000_000), 2, 32768).astype(np.float32)
+    neg = rng.uniform(-50, 100, 6000).astype(np.float32)
+    yield "with_negatives", neg
+    n = rng.uniform(1, 10, 5000).astype(np.float32); n[3000] = np.nan
+    yield "nan_inside", n
+    i = rng.uniform(1, 10, 5000).astype(np.float32); i[100] = np.inf
+    yield "inf_inside", i
+    i2 = i.copy(); i2[4000] = np.nan
+    yield "inf_then_nan", i2
+    yield "overflow_to_inf", np.full(3000, 3e38, np.float32)
+    yield "denormals", np.full(5000, 1e-41, np.float32)
+
+
+@pytest.mark.parametrize("name", [n for n, _ in _cases()])
+def test_ordered_sum_equals_sequential_fp32(gpu_ctx, name):
+    """The exact scan behind the image statistics (orderedsum.hip) against a strictly sequential fp32 accumulation."""
+    x = dict(_cases())[name]
+    with np.errstate(all="ignore"):
+        ref = seq_sum(x)
+    got = gpu_ctx.ordered_sum_f32(x)
+    assert got.view(np.uint32) == ref.view(np.uint32) or (np.isnan(got) and np.isnan(ref)), (name, got, ref)
