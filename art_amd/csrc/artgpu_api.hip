@@ -1508,6 +1508,24 @@ int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise
     float wsf[9];
     for (int k = 0; k < 9; ++k) wsf[k] = (float)ws[k];
     int rc;
+    // adjust_params (ipdenoise.cc:35-63): a preview at scale > 1 sees averaged-down noise, so the strengths shrink with it
+    artgpu_denoise_tool_params adj = *p;
+    if (scale > 1.0) {
+        const auto c = [](double x, double f) -> double {
+            const int sgn = (0.0 < x) - (x < 0.0);
+            const double y = std::max(0.0, std::min(std::abs(x) / 100.0, 1.0));
+            return sgn * (y * (y * f) + (1.0 - y) * y) * 100.0;      // intp(y, y*f, y)
+        };
+        const double scale_factor = 1.0 / scale;
+        const double noise_factor_c = std::pow(scale_factor, 0.46);
+        const double noise_factor_l = std::pow(scale_factor, 0.62) * scale_factor;
+        adj.dn.luminance = c(adj.dn.luminance, noise_factor_l);
+        adj.dn.luminance_detail *= (1.0 + std::pow(1.0 - scale_factor, 2.2));
+        adj.dn.chrominance = c(adj.dn.chrominance, noise_factor_c);
+        adj.dn.chrominance_red_green = c(adj.dn.chrominance_red_green, noise_factor_c);
+        adj.dn.chrominance_blue_yellow = c(adj.dn.chrominance_blue_yellow, noise_factor_c);
+    }
+    p = &adj;
     artgpu_plane ccalc = {}, *ccalc_p = nullptr;
     if (noise_c_curve) {
         float sum = 0.f;

@@ -301,7 +301,19 @@ def improc_denoise(img, dn_kw=None, calclum_mat=None, noise_c_curve=None, smooth
         ccalc = chroma_noise_map(img, calclum_mat, ws, noise_c_curve)
     if ecomp > 0:
         img = exposure(img, float(np.float32(2.0 ** ecomp)), 0.0)
-    img = rgb_denoise(img, default_denoise_params(scale=scale, **(dn_kw or {})), wsf, detail_recovery=detail_recovery, noisevarchrom=ccalc)
+    dnp = default_denoise_params(scale=scale, **(dn_kw or {}))
+    if scale > 1.0:      # adjust_params (ipdenoise.cc:35-63)
+        def c(x, f):
+            y = min(max(abs(x) / 100.0, 0.0), 1.0)
+            return ((0.0 < x) - (x < 0.0)) * (y * (y * f) + (1.0 - y) * y) * 100.0
+        sf = 1.0 / scale
+        nc, nl = sf ** 0.46, sf ** 0.62 * sf
+        dnp.luminance = c(dnp.luminance, nl)
+        dnp.luminanceDetail *= (1.0 + (1.0 - sf) ** 2.2)
+        dnp.chrominance = c(dnp.chrominance, nc)
+        dnp.chrominanceRedGreen = c(dnp.chrominanceRedGreen, nc)
+        dnp.chrominanceBlueYellow = c(dnp.chrominanceBlueYellow, nc)
+    img = rgb_denoise(img, dnp, wsf, detail_recovery=detail_recovery, noisevarchrom=ccalc)
     if smoothing:
         img = guided_smoothing(img, ws, radius, scale)
         if nl_strength:

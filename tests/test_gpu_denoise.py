@@ -188,3 +188,26 @@ def test_lab_colour_space_mode_bit_exact(gpu_ctx, w, h):
     plain = O.rgb_denoise(img, O.default_denoise_params())
     assert not np.array_equal(ref[0], plain[0])
     assert _same(got, ref) == [0, 0, 0]
+
+
+def test_improc_denoise_preview_scale_bit_exact(gpu_ctx):
+    """scale > 1 (dcrop.cc preview crops): adjust_params (ipdenoise.cc:35-63) rescales the strengths, RGB_denoise shortens
+    its blur radii, guided smoothing and NL-means shrink their radii; DCT stage skipped so everything must agree bit for bit."""
+    w, h = 400, 296
+    raw = synth.bayer_frame(w, h, synth.FILTERS_RGGB, seed=14, noise=2048)
+    img = O.amaze(raw, synth.FILTERS_RGGB, 1.0, 4)
+    mat = np.array([[0.6325, 0.2312, 0.0921], [0.2198, 0.7712, 0.0090], [0.0166, 0.0713, 0.7514]])
+    curve, _ = capi.noise_curve_lut()
+    tp = capi.DenoiseToolParams(capi.DenoiseParams(60.0, 50.0, 0, 25.0, 5.0, -8.0, 1.7, 0, 0, 0), 1, 3, 50, 80)
+    got = [p.copy() for p in img]
+    gpu_ctx.improc_denoise(capi.host_rgb(got), tp, O.REC2020_WS_D, ecomp=0.3, scale=2.0, calclum_mat=mat, noise_c_curve=curve,
+                           flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    ref = O.improc_denoise(img, dict(luminance=60.0, chrominance=25.0, chrominanceRedGreen=5.0, chrominanceBlueYellow=-8.0), calclum_mat=mat,
+                           noise_c_curve=curve, smoothing=True, radius=3, nl_strength=50, nl_detail=80, ecomp=0.3, scale=2.0, detail_recovery=False)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+    # and the strengths really were rescaled: the same call with scale 1 gives a different image
+    got1 = [p.copy() for p in img]
+    gpu_ctx.improc_denoise(capi.host_rgb(got1), tp, O.REC2020_WS_D, ecomp=0.3, scale=1.0, calclum_mat=mat, noise_c_curve=curve,
+                           flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    assert not np.array_equal(got1[1], got[1])
