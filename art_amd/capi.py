@@ -140,6 +140,8 @@ def _load():
     lib.artgpu_noise_curve_lut.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_denoise_chroma_map.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_float),
                                               C.POINTER(Plane)]
+    lib.artgpu_get_image_skip.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int,
+                                          C.POINTER(C.c_double), C.POINTER(RGB)]
     lib.artgpu_get_image.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int,
                                      C.POINTER(C.c_double), C.POINTER(RGB)]
     lib.artgpu_convert_color_space.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double)]
@@ -156,7 +158,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -212,10 +214,13 @@ class Context:
     def border_interpolate2(self, raw: Plane, filters: int, lborders: int, out: RGB):
         self._chk(LIB.artgpu_border_interpolate2(self._h, C.byref(raw), filters, lborders, C.byref(out)))
 
-    def get_image(self, planes: RGB, sx1: int, sy1: int, mul, do_clip: bool, mat, image: RGB):
+    def get_image(self, planes: RGB, sx1: int, sy1: int, mul, do_clip: bool, mat, image: RGB, skip: int = 1):
         m = (C.c_float * 3)(*[float(v) for v in mul])
         mp = None if mat is None else (C.c_double * 9)(*[float(v) for v in np.asarray(mat, dtype=np.float64).reshape(9)])
-        self._chk(LIB.artgpu_get_image(self._h, C.byref(planes), sx1, sy1, m, int(do_clip), mp, C.byref(image)))
+        if skip == 1:
+            self._chk(LIB.artgpu_get_image(self._h, C.byref(planes), sx1, sy1, m, int(do_clip), mp, C.byref(image)))
+        else:
+            self._chk(LIB.artgpu_get_image_skip(self._h, C.byref(planes), sx1, sy1, int(skip), m, int(do_clip), mp, C.byref(image)))
 
     def convert_color_space(self, image: RGB, mat):
         mp = (C.c_double * 9)(*[float(v) for v in np.asarray(mat, dtype=np.float64).reshape(9)])

@@ -393,6 +393,12 @@ int artgpu_border_interpolate2(artgpu_ctx *ctx, const artgpu_plane *raw, uint32_
 int artgpu_get_image(artgpu_ctx *ctx, const artgpu_rgb *planes, int sx1, int sy1, const float mul[3],
                      int do_clip, const double *mat, artgpu_rgb *image)
 {
+    return artgpu_get_image_skip(ctx, planes, sx1, sy1, 1, mul, do_clip, mat, image);
+}
+
+int artgpu_get_image_skip(artgpu_ctx *ctx, const artgpu_rgb *planes, int sx1, int sy1, int skip, const float mul[3],
+                          int do_clip, const double *mat, artgpu_rgb *image)
+{
     if (!ctx) return ARTGPU_EINVAL;
     if (!planes || !image || !mul) return fail(ctx, ARTGPU_EINVAL, "get_image: null argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -401,12 +407,15 @@ int artgpu_get_image(artgpu_ctx *ctx, const artgpu_rgb *planes, int sx1, int sy1
     if (rc) return rc;
     rc = bind_rgb(ctx, image, 4, false, &dst, "get_image(image)");
     if (rc) return rc;
-    if (sx1 < 0 || sy1 < 0 || sx1 + dst.w > src.w || sy1 + dst.h > src.h)
-        return fail(ctx, ARTGPU_EINVAL, "get_image: crop %dx%d+%d+%d outside the %dx%d planes", dst.w, dst.h, sx1, sy1, src.w, src.h);
+    if (skip < 1 || skip > src.w || skip > src.h) return fail(ctx, ARTGPU_EINVAL, "get_image: skip %d", skip);
+    // transformRect (rawimagesource.cc:745-747): the caller's image is ceil(crop / skip); the last window may be pulled back inside
+    if (sx1 < 0 || sy1 < 0 || sx1 + (dst.w - 1) * skip >= src.w || sy1 + (dst.h - 1) * skip >= src.h)
+        return fail(ctx, ARTGPU_EINVAL, "get_image: crop %dx%d+%d+%d (skip %d) outside the %dx%d planes", dst.w, dst.h, sx1, sy1, skip, src.w, src.h);
     PixArgs a = {};
     for (int k = 0; k < 3; ++k) { a.src[k] = src.p[k]; a.dst[k] = dst.p[k]; a.mul[k] = mul[k]; }
     a.src_stride = src.stride; a.dst_stride = dst.stride;
     a.sx1 = sx1; a.sy1 = sy1; a.w = dst.w; a.h = dst.h;
+    a.skip = skip; a.src_w = src.w; a.src_h = src.h;
     a.has_mul = 1; a.do_clip = do_clip ? 1 : 0;
     a.has_mat = mat ? 1 : 0;
     if (mat) for (int k = 0; k < 9; ++k) a.mat[k] = mat[k];

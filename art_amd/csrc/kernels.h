@@ -87,6 +87,7 @@ struct PixArgs {
     const float *src[3];   // get_image: demosaiced planes
     size_t src_stride;
     int sx1, sy1;          // crop origin in src (RawImageSource::border)
+    int skip, src_w, src_h; // get_image: PreviewProps::skip (0/1 = every pixel) and the plane size for its edge clamp
     float *dst[3];         // destination / in-place image
     size_t dst_stride;
     int w, h;

@@ -56,9 +56,20 @@ __global__ void __launch_bounds__(256) get_image_convert_kernel(PixArgs a)
     const long long n = (long long)a.w * a.h;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
         const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
-        const size_t si = (size_t)(a.sy1 + y) * a.src_stride + a.sx1 + x;
+        size_t si = (size_t)(a.sy1 + y) * a.src_stride + a.sx1 + x;
         float r, g, b;
-        if (a.has_mul) {
+        if (a.has_mul && a.skip > 1) {
+            // skip x skip box sums, rows outer (rawimagesource.cc:944-957); the window is pulled inside at the right/bottom edge
+            const int i = min(a.sy1 + a.skip * y, a.src_h - a.skip), jx = min(a.sx1 + a.skip * x, a.src_w - a.skip);
+            r = 0.f; g = 0.f; b = 0.f;
+            for (int m = 0; m < a.skip; ++m)
+                for (int n = 0; n < a.skip; ++n) {
+                    si = (size_t)(i + m) * a.src_stride + jx + n;
+                    r += a.src[0][si]; g += a.src[1][si]; b += a.src[2][si];
+                }
+            r *= a.mul[0]; g *= a.mul[1]; b *= a.mul[2];
+            if (a.do_clip) { r = clipf(r); g = clipf(g); b = clipf(b); }
+        } else if (a.has_mul) {
             r = 0.f; g = 0.f; b = 0.f;
             r += a.src[0][si]; g += a.src[1][si]; b += a.src[2][si];
             r *= a.mul[0]; g *= a.mul[1]; b *= a.mul[2];

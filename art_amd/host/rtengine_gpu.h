@@ -119,11 +119,14 @@ public:
     }
     void getFullSize(int &w, int &h) const { w = W - 2 * border; h = H - 2 * border; }   // computeFullSize (L1163-1193), tran = 0
     // RawImageSource::getImage (rawimagesource.cc:781-1104): tran = 0, skip = 1; rm/gm/bm as the caller computed them
-    void getImage(const float mul[3], bool doClip, Imagefloat *image)
+    void getImage(const float mul[3], bool doClip, Imagefloat *image, int x = 0, int y = 0, int skip = 1)
     {
         artgpu_rgb planes{red.view(), green.view(), blue.view()};
         artgpu_rgb img = image->view();
-        ctx.check(artgpu_get_image(ctx.get(), &planes, border, border, mul, doClip ? 1 : 0, nullptr, &img));
+        // PreviewProps(x, y, w, h, skip): transformRect adds the border; rm/gm/bm are divided by skip*skip (L922-926)
+        const float area = float(skip) * float(skip);
+        const float m[3] = {mul[0] / area, mul[1] / area, mul[2] / area};
+        ctx.check(artgpu_get_image_skip(ctx.get(), &planes, x + border, y + border, skip, skip > 1 ? m : mul, doClip ? 1 : 0, nullptr, &img));
     }
     // RawImageSource::convertColorSpace, matrix branch (rawimagesource.cc:1128-1143,3184-3213)
     void convertColorSpace(Imagefloat *image, const double mat[9])

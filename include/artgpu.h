@@ -112,6 +112,11 @@ int artgpu_demosaic_xtrans(artgpu_ctx *ctx, int passes, int use_cielab, const ar
  * image  : destination Imagefloat planes (w,h = cropped size), may not alias `planes`. */
 int artgpu_get_image(artgpu_ctx *ctx, const artgpu_rgb *planes, int sx1, int sy1, const float mul[3],
                      int do_clip, const double *mat, artgpu_rgb *image);
+/* The same with PreviewProps::skip > 1 (the editor's zoomed-out crops, dcrop.cc:204-205): every output pixel is the sum of a
+ * skip x skip window in row-major order (L944-957) times mul -- the caller divides rm/gm/bm by skip*skip as L922-926 does --
+ * with the window origin clamped to (W - skip, H - skip) (L945,949).  image is ceil(crop/skip) in each direction (L745-747). */
+int artgpu_get_image_skip(artgpu_ctx *ctx, const artgpu_rgb *planes, int sx1, int sy1, int skip, const float mul[3],
+                          int do_clip, const double *mat, artgpu_rgb *image);
 
 /* RawImageSource::convertColorSpace, default-camera-profile (matrix) branch, in place
  * (rtengine/rawimagesource.cc:1128-1143,3184-3213): double accumulation, float store. */

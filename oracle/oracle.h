@@ -32,6 +32,8 @@ int oracle_amaze_demosaic(const float *raw, size_t raw_stride, int W, int H, uns
 /* per-pixel stages (oracle/pixelops.c); strides in floats */
 void oracle_get_image(const float *const src[3], size_t ss, int sx1, int sy1,
                       float *const dst[3], size_t ds, int w, int h, const float mul[3], int do_clip);
+void oracle_get_image_skip(const float *const src[3], size_t ss, int W, int H, int sx1, int sy1, int skip,
+                           float *const dst[3], size_t ds, int w, int h, const float mul[3], int do_clip);
 void oracle_convert_color_space(float *const img[3], size_t s, int w, int h, const double mat[9]);
 void oracle_exposure(float *const img[3], size_t s, int w, int h, float exp_scale, float black);
 void oracle_filmlike_clip(float *const img[3], size_t s, int w, int h, float whitept);

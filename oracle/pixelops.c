@@ -202,3 +202,26 @@ void oracle_rgb_curves(float *const img[3], size_t s, int w, int h, const float 
             for (; x < w; ++x) img[c][(size_t)y * s + x] = oracle_lutf_noclip(luts[c], 65536, img[c][(size_t)y * s + x]);
         }
 }
+
+/* getImage with PreviewProps::skip > 1 (rawimagesource.cc:940-975): skip x skip sums, rows outer; W, H = plane size */
+void oracle_get_image_skip(const float *const src[3], size_t ss, int W, int H, int sx1, int sy1, int skip,
+                           float *const dst[3], size_t ds, int w, int h, const float mul[3], int do_clip)
+{
+#pragma omp parallel for
+    for (int ix = 0; ix < h; ++ix) {
+        int i = sy1 + skip * ix;
+        i = i < H - skip ? i : H - skip;
+        for (int j = 0, jx = sx1; j < w; j++, jx += skip) {
+            jx = jx < W - skip ? jx : W - skip;
+            float tot[3] = {0.f, 0.f, 0.f};
+            for (int m = 0; m < skip; m++)
+                for (int n = 0; n < skip; n++)
+                    for (int c = 0; c < 3; ++c) tot[c] += src[c][(size_t)(i + m) * ss + jx + n];
+            for (int c = 0; c < 3; ++c) {
+                float t = tot[c] * mul[c];
+                if (do_clip) t = rt_maxf(0.f, rt_minf(t, 65535.f));
+                dst[c][(size_t)ix * ds + j] = t;
+            }
+        }
+    }
+}

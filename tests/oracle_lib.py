@@ -411,3 +411,12 @@ def denoise_compute_params(planes, border, mul, do_clip, mat, ws, gamma=1.7, agg
     rc = L.oracle_denoise_compute_params(_p3(planes), w, w, h, int(border), (C.c_float * 3)(*[float(v) for v in mul]), 1 if do_clip else 0, m,
                                          _ptr(wp), float(gamma), 1 if aggressive else 0, _ptr(store), _ptr(info))
     return None if rc else (store, info)
+
+
+def get_image_skip(planes, sx1, sy1, w, h, skip, mul, do_clip):
+    planes = [np.ascontiguousarray(p, dtype=np.float32) for p in planes]
+    H, W = planes[0].shape
+    out = _planes(h, w)
+    lib().oracle_get_image_skip(_p3(planes), C.c_size_t(W), W, H, sx1, sy1, skip, _p3(out), C.c_size_t(w), w, h,
+                                (C.c_float * 3)(*[float(v) for v in mul]), 1 if do_clip else 0)
+    return out

@@ -112,3 +112,21 @@ def test_channel_mixer_and_rgb_curves_bit_exact(gpu_ctx):
     for g, r in zip(got, ref):
         assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
     assert np.array_equal(got[1], img[1]) and not np.array_equal(got[0], img[0])
+
+
+@pytest.mark.parametrize("skip,crop", [(2, (4, 4, 393, 289)), (3, (4, 4, 392, 288)), (4, (120, 60, 281, 233))])
+def test_get_image_skip_bit_exact(gpu_ctx, skip, crop):
+    """getImage with PreviewProps::skip > 1 (rawimagesource.cc:940-975): box sums in row-major order, window clamped at the edge."""
+    from art_amd import capi
+    import oracle_lib as O
+    rng = np.random.default_rng(skip)
+    H, W = 297, 401
+    planes = [rng.uniform(0, 30000, (H, W)).astype(np.float32) for _ in range(3)]
+    sx1, sy1, cw, ch = crop
+    w, h = (cw + skip - 1) // skip, (ch + skip - 1) // skip        # transformRect L745-747
+    mul = [m / (skip * skip) for m in (2.1374, 1.0, 1.5918)]
+    got = [np.zeros((h, w), np.float32) for _ in range(3)]
+    gpu_ctx.get_image(capi.host_rgb(planes), sx1, sy1, mul, True, None, capi.host_rgb(got), skip=skip)
+    ref = O.get_image_skip(planes, sx1, sy1, w, h, skip, mul, True)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
