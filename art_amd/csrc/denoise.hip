@@ -109,9 +109,8 @@ __device__ __forceinline__ void lab2rgb_dev(const DnPixArgs &a, float l, float l
 // ---------------------------------------------------------------- RGB -> gamma -> YUV (FTblockDN.cc:2084-2128)
 __global__ void __launch_bounds__(256) rgb2yuv_kernel(DnPixArgs a)
 {
-    const long long n = (long long)a.w * a.h;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+    FOR_IMAGE_XY(y, x, a.w, a.h) {
+        const long long t = (long long)y * a.w + x;
         const size_t si = (size_t)y * a.stride + x;
         float r0 = a.rgb[0][si], g0 = a.rgb[1][si], b0 = a.rgb[2][si];
         if (a.pre_scale != 0.f) {   // fused ImProcFunctions::expcomp(+ecomp) (ipexposure.cc:56-70): 4-lane groups then scalar tail
@@ -137,9 +136,8 @@ __global__ void __launch_bounds__(256) rgb2yuv_kernel(DnPixArgs a)
 // ---------------------------------------------------------------- YUV -> inverse gamma -> RGB (FTblockDN.cc:2502-2550)
 __global__ void __launch_bounds__(256) yuv2rgb_kernel(DnPixArgs a)
 {
-    const long long n = (long long)a.w * a.h;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+    FOR_IMAGE_XY(y, x, a.w, a.h) {
+        const long long t = (long long)y * a.w + x;
         float av = a.A[t], bv = a.B[t];
         const float Lv = a.L[t];
         const float c_h = sqrtf(sqr(av) + sqr(bv));
@@ -487,12 +485,12 @@ hipError_t launch_gamma_lut(float *lut, float gamma, float start, float slope, f
 }
 hipError_t launch_rgb2yuv(const DnPixArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(rgb2yuv_kernel, dim3(flat_grid((long long)a.w * a.h, 16384)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(rgb2yuv_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_yuv2rgb(const DnPixArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(yuv2rgb_kernel, dim3(flat_grid((long long)a.w * a.h, 16384)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(yuv2rgb_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_mad(const float *bands, size_t n, int nsub, int *histo, float *out, hipStream_t s)
@@ -534,11 +532,10 @@ hipError_t launch_vblur_combine(const BlurArgs &a, int nsub, hipStream_t s)
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) chroma_map_kernel(ChromaMapArgs a)
 {
-    const long long n = (long long)a.wid * a.hei;
     const float t0 = 1.f + 1.f * (4.f * lutf_lookup<true>(a.curve, 501, 100.f / 60.f));
     const float cn100 = t0 * t0;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-        const int ii = (int)(t / a.wid), jj = (int)(t - (long long)ii * a.wid);
+    FOR_IMAGE_XY(ii, jj, a.wid, a.hei) {
+        const long long t = (long long)ii * a.wid + jj;
         const size_t o = (size_t)(2 * ii) * a.stride + 2 * jj;
         float RL = a.src[0][o], GL = a.src[1][o], BL = a.src[2][o];
         if (a.has_mat) {
@@ -565,7 +562,8 @@ hipError_t launch_chroma_map(const ChromaMapArgs &a, hipStream_t s)
 {
     const long long n = (long long)a.wid * a.hei;
     long long g = (n + 255) / 256;
-    hipLaunchKernelGGL(chroma_map_kernel, dim3((unsigned)(g < 8192 ? (g ? g : 1) : 8192)), dim3(256), 0, s, a);
+    (void)g;
+    hipLaunchKernelGGL(chroma_map_kernel, image_grid(a.wid, a.hei), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -584,12 +582,12 @@ __device__ __forceinline__ float dninfo_fetch(const DnInfoArgs &a, int c, size_t
 // the chroma floor is vmaxf in the 4-lane columns and a compare in the tail.
 __global__ void __launch_bounds__(256) dninfo_maps_kernel(DnInfoArgs a)
 {
-    const int k = blockIdx.y;
+    const int k = blockIdx.z;
     const long long n2 = (long long)a.wid * a.hei;
     const int nvec = 4 * (a.crW / 8);
     float *hue = a.maps + (size_t)k * 3 * n2, *chrom = hue + n2, *lum = chrom + n2;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n2; t += (long long)gridDim.x * blockDim.x) {
-        const int ii = (int)(t / a.wid), jj = (int)(t - (long long)ii * a.wid);
+    FOR_IMAGE_XY(ii, jj, a.wid, a.hei) {
+        const long long t = (long long)ii * a.wid + jj;
         const size_t si = (size_t)(a.sy[k] + 2 * ii) * a.stride + a.sx[k] + 2 * jj;
         const double dr = dninfo_fetch(a, 0, si), dg = dninfo_fetch(a, 1, si), db = dninfo_fetch(a, 2, si);
         const float RL = (float)(a.mat[0] * dr + a.mat[1] * dg + a.mat[2] * db);
@@ -619,9 +617,8 @@ __global__ void __launch_bounds__(256) dninfo_maps_kernel(DnInfoArgs a)
 __global__ void __launch_bounds__(256) dninfo_ab_kernel(DnInfoArgs a)
 {
     const int k = a.crop;
-    const long long n = (long long)a.crW * a.crH;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-        const int i = (int)(t / a.crW), j = (int)(t - (long long)i * a.crW);
+    FOR_IMAGE_XY(i, j, a.crW, a.crH) {
+        const long long t = (long long)i * a.crW + j;
         const size_t si = (size_t)(a.sy[k] + i) * a.stride + a.sx[k] + j;
         float X = a.gain * dninfo_fetch(a, 0, si), Y = a.gain * dninfo_fetch(a, 1, si), Z = a.gain * dninfo_fetch(a, 2, si);
         X = X < 65535.f ? lutf_noclip(a.gamcurve, X) : (gammaf_s(X / 65535.f, a.gam, a.gamthresh, a.gamslope) * 32768.f);
@@ -634,12 +631,14 @@ __global__ void __launch_bounds__(256) dninfo_ab_kernel(DnInfoArgs a)
 }
 hipError_t launch_dninfo_maps(const DnInfoArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(dninfo_maps_kernel, dim3(flat_grid((long long)a.wid * a.hei, 512), 9), dim3(256), 0, s, a);
+    dim3 g = image_grid(a.wid, a.hei);
+    g.z = 9;
+    hipLaunchKernelGGL(dninfo_maps_kernel, g, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_dninfo_ab(const DnInfoArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(dninfo_ab_kernel, dim3(flat_grid((long long)a.crW * a.crH, 1024)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dninfo_ab_kernel, image_grid(a.crW, a.crH), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

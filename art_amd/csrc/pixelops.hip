@@ -53,9 +53,7 @@ __device__ __forceinline__ float lutf(const float *__restrict__ data, int size, 
 
 __global__ void __launch_bounds__(256) get_image_convert_kernel(PixArgs a)
 {
-    const long long n = (long long)a.w * a.h;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+    FOR_IMAGE_XY(y, x, a.w, a.h) {
         size_t si = (size_t)(a.sy1 + y) * a.src_stride + a.sx1 + x;
         float r, g, b;
         if (a.has_mul && a.skip > 1) {
@@ -90,10 +88,8 @@ __global__ void __launch_bounds__(256) get_image_convert_kernel(PixArgs a)
 
 __global__ void __launch_bounds__(256) exposure_kernel(PixArgs a)
 {
-    const long long n = (long long)a.w * a.h;
     const int wv = (a.w / 4) * 4;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+    FOR_IMAGE_XY(y, x, a.w, a.h) {
         const size_t di = (size_t)y * a.dst_stride + x;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -105,10 +101,8 @@ __global__ void __launch_bounds__(256) exposure_kernel(PixArgs a)
 
 __global__ void __launch_bounds__(256) tone_std_kernel(PixArgs a)
 {
-    const long long n = (long long)a.w * a.h;
     const float Lmax = 65535.f * a.whitept;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+    FOR_IMAGE_XY(y, x, a.w, a.h) {
         const size_t di = (size_t)y * a.dst_stride + x;
         float r = a.dst[0][di], g = a.dst[1][di], b = a.dst[2][di];
         if (a.do_clip) filmlike_clip_px(r, g, b, Lmax);
@@ -125,9 +119,7 @@ __global__ void __launch_bounds__(256) tone_std_kernel(PixArgs a)
 // YUV -> RGB (L779-804), float working-space row ws_[1][*]; in place.  a.do_clip: 0 = to YUV, 1 = to RGB.
 __global__ void __launch_bounds__(256) yuv_mode_kernel(PixArgs a)
 {
-    const long long n = (long long)a.w * a.h;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+    FOR_IMAGE_XY(y, x, a.w, a.h) {
         const size_t di = (size_t)y * a.dst_stride + x;
         if (!a.do_clip) {
             const float r = a.dst[0][di], g = a.dst[1][di], b = a.dst[2][di];
@@ -149,10 +141,8 @@ __global__ void __launch_bounds__(256) scale_colors_kernel(ScaleArgs a)
     __shared__ int s_max[3];
     if (threadIdx.x < 3) s_max[threadIdx.x] = 0;
     __syncthreads();
-    const long long n = (long long)a.w * a.h;
     float m[3] = {0.f, 0.f, 0.f};
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-        const int row = (int)(t / a.w), col = (int)(t - (long long)row * a.w);
+    FOR_IMAGE_XY(row, col, a.w, a.h) {
         const size_t si = (size_t)row * a.src_stride + col;
         float val = a.src_u16 ? (float)static_cast<const unsigned short *>(a.src)[si] : static_cast<const float *>(a.src)[si];
         const int c = a.cfa[(row % 6) * 6 + col % 6];
@@ -170,10 +160,8 @@ __global__ void __launch_bounds__(256) scale_colors_kernel(ScaleArgs a)
 // ImProcFunctions::channelMixer pixel loop (ipchmixer.cc:200-230): 4-lane groups clamp with vmaxf, the row tail with max()
 __global__ void __launch_bounds__(256) channel_mixer_kernel(MixArgs a)
 {
-    const long long n = (long long)a.w * a.h;
     const int wv = a.w - 3 > 0 ? ((a.w - 3 + 3) / 4) * 4 : 0;    // x < W-3 in steps of 4
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+    FOR_IMAGE_XY(y, x, a.w, a.h) {
         const size_t di = (size_t)y * a.stride + x;
         const float r = a.dst[0][di], g = a.dst[1][di], b = a.dst[2][di];
         const float rmix = (r * a.m[0] + g * a.m[1] + b * a.m[2]);
@@ -187,10 +175,8 @@ __global__ void __launch_bounds__(256) channel_mixer_kernel(MixArgs a)
 // lookup (LUT.h:349-377), the row tail the scalar one, which extrapolates (LUT.h:436-459)
 __global__ void __launch_bounds__(256) rgb_curves_kernel(MixArgs a)
 {
-    const long long n = (long long)a.w * a.h;
     const int wv = a.w - 3 > 0 ? ((a.w - 3 + 3) / 4) * 4 : 0;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+    FOR_IMAGE_XY(y, x, a.w, a.h) {
         const size_t di = (size_t)y * a.stride + x;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -223,40 +209,41 @@ static int pix_grid(const PixArgs &a)
 }
 hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(get_image_convert_kernel, dim3(pix_grid(a)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(get_image_convert_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_exposure(const PixArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(exposure_kernel, dim3(pix_grid(a)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(exposure_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 static unsigned mix_grid(const MixArgs &a) { long long g = ((long long)a.w * a.h + 255) / 256; return (unsigned)(g < 16384 ? (g ? g : 1) : 16384); }
 hipError_t launch_channel_mixer(const MixArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(channel_mixer_kernel, dim3(mix_grid(a)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(channel_mixer_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_rgb_curves(const MixArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(rgb_curves_kernel, dim3(mix_grid(a)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(rgb_curves_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_scale_colors(const ScaleArgs &a, hipStream_t s)
 {
     const long long n = (long long)a.w * a.h;
     long long g = (n + 255) / 256;
-    hipLaunchKernelGGL(scale_colors_kernel, dim3((unsigned)(g < 4096 ? (g ? g : 1) : 4096)), dim3(256), 0, s, a);
+    (void)g;
+    hipLaunchKernelGGL(scale_colors_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_yuv_mode(const PixArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(yuv_mode_kernel, dim3(pix_grid(a)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(yuv_mode_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_tone_std(const PixArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(tone_std_kernel, dim3(pix_grid(a)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(tone_std_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -122,7 +122,6 @@ __global__ void neutral_hues_kernel(NeutralArgs a)
 
 __global__ void __launch_bounds__(256) tone_neutral_kernel(NeutralArgs a)
 {
-    const long long n = (long long)a.w * a.h;
     const float whitept = 65535.f * a.whitecoeff;
     const float rhue = a.hues[0], bhue = a.hues[1], yhue = a.hues[2], ohue = a.hues[3];
     const float yrange = fabsf(ohue - yhue) * 0.8f, rrange = fabsf(ohue - rhue), brange = rrange;
@@ -131,8 +130,7 @@ __global__ void __launch_bounds__(256) tone_neutral_kernel(NeutralArgs a)
 #pragma unroll
     for (int i = 0; i < 3; ++i) sc[i] = (1.f - th[i]) / sqrtf(dl[i] - 1.f);
     const float PI_180 = (float)(3.14159265358979323846 / 180.0);
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+    FOR_IMAGE_XY(y, x, a.w, a.h) {
         const size_t o = (size_t)y * a.stride + x;
         float rgb[3], jch[3], tv[3];
         rgb[0] = std_max(a.img[0][o] / 65535.f, 0.f);
@@ -199,7 +197,8 @@ hipError_t launch_tone_neutral(const NeutralArgs &a, hipStream_t s)
 {
     const long long n = (long long)a.w * a.h;
     long long g = (n + 255) / 256;
-    hipLaunchKernelGGL(tone_neutral_kernel, dim3((unsigned)(g < 16384 ? (g ? g : 1) : 16384)), dim3(256), 0, s, a);
+    (void)g;
+    hipLaunchKernelGGL(tone_neutral_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
