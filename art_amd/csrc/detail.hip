@@ -30,15 +30,18 @@ __device__ __forceinline__ int reflect(int v, int n)
 }
 } // namespace
 
+template <int RAD>
 __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
 {
-    __shared__ float T[TS][TS + 1];
-    __shared__ float N[TS][TS + 1];
+    // One 64 x 65 LDS buffer (+4 spare rows) per wave: the coefficients themselves stay in registers between the forward and
+    // the inverse transform (lane = coefficient row), so nine blocks fit a CU instead of four.
+    constexpr int XR = 4;                       // spare rows, >= blur radius + 1
+    __shared__ float B[TS + XR][TS + 1];
     const int lane = threadIdx.x;
-    constexpr int wv = 0;
     const int blk = blockIdx.x;
     const int vblk = blk / a.numblox_W, hblk = blk - vblk * a.numblox_W;
     const int top = (vblk - BLKRAD) * OFF, left = (hblk - BLKRAD) * OFF;
+    constexpr int rad = RAD;                    // = a.blur_rad, 1..3 (XR - 1)
     float x[TS];
 
     // 1. load: lane = column j; x[i] = tilemask_in[i][j] * (Lin - L)(top+i, left+j), reflected
@@ -51,49 +54,52 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
             x[i] = a.tm_in[i * TS + lane] * (a.Lin[o] - a.L[o]);
         }
     }
-    // 2. REDFT10 along i (= 2 * DCT-II) -> T[k][j]
+    // 2. REDFT10 along i (= 2 * DCT-II) -> B[k][j]
     lee_fwd<TS>(x);
 #pragma unroll
-    for (int k = 0; k < TS; ++k) T[k][lane] = 2.f * x[k];
+    for (int k = 0; k < TS; ++k) B[k][lane] = 2.f * x[k];
     __syncthreads();
-    // 3. REDFT10 along j: lane = row k
+    // 3. REDFT10 along j: lane = row k; the coefficients T[k][m] stay in x[m]
 #pragma unroll
-    for (int j = 0; j < TS; ++j) x[j] = T[lane][j];
+    for (int j = 0; j < TS; ++j) x[j] = B[lane][j];
     lee_fwd<TS>(x);
 #pragma unroll
-    for (int m = 0; m < TS; ++m) T[lane][m] = 2.f * x[m];
-    __syncthreads();
-    // 4. boxabsblur of the coefficients, radius `rad` (boxblur.h:745-886): rows (lane = row), wave 0 only
-    const int rad = a.blur_rad;
-    if (wv == 0) {
-        const float *s = &T[lane][0];
+    for (int m = 0; m < TS; ++m) x[m] = 2.f * x[m];
+    // 4. boxabsblur of the coefficients, radius `rad` (boxblur.h:745-886): along the row, straight from the registers into
+    //    this lane's own row of B (which only this lane has read)
+    {
         int len = rad + 1;
-        float tempval = fabsf(s[0]);
-        for (int q = 1; q <= rad; q++) tempval += fabsf(s[q]);
+        float tempval = fabsf(x[0]);
+#pragma unroll
+        for (int q = 1; q <= rad; q++) tempval += fabsf(x[q]);
         tempval /= len;
-        N[lane][0] = tempval;
+        B[lane][0] = tempval;
+#pragma unroll
         for (int col = 1; col <= rad; col++) {
-            tempval = (tempval * len + fabsf(s[col + rad])) / (len + 1);
-            N[lane][col] = tempval;
+            tempval = (tempval * len + fabsf(x[col + rad])) / (len + 1);
+            B[lane][col] = tempval;
             len++;
         }
         const float rlen = 1.f / (float)len;
+#pragma unroll
         for (int col = rad + 1; col < TS - rad; col++) {
-            tempval = tempval + (fabsf(s[col + rad]) - fabsf(s[col - rad - 1])) * rlen;
-            N[lane][col] = tempval;
+            tempval = tempval + (fabsf(x[col + rad]) - fabsf(x[col - rad - 1])) * rlen;
+            B[lane][col] = tempval;
         }
+#pragma unroll
         for (int col = TS - rad; col < TS; col++) {
-            tempval = (tempval * len - fabsf(s[col - rad - 1])) / (len - 1);
-            N[lane][col] = tempval;
+            tempval = (tempval * len - fabsf(x[col - rad - 1])) / (len - 1);
+            B[lane][col] = tempval;
             len--;
         }
     }
     __syncthreads();
-    // ... then columns (lane = column m) and the shrink
-    if (wv == 0) {
+    // ... then down the columns (lane = column m) and the shrink factor 1 - exp(-blur^2 / factor).  The factor of row `row`
+    // is written where N[row - rad - 1] was (its last use is this step); the first rad + 1 rows use the spare rows.
+    {
         float lenf = (float)(rad + 1);
-        float tv = N[0][lane];
-        for (int i = 1; i <= rad; i++) tv = tv + N[i][lane];
+        float tv = B[0][lane];
+        for (int i = 1; i <= rad; i++) tv = tv + B[i][lane];
         tv = tv / lenf;
         float rlen = 0.f;
         const bool colin = (left + lane) >= 0 && (left + lane) < a.w;
@@ -101,13 +107,13 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
             if (row == 0) {
             } else if (row <= rad) {
                 const float lenp1 = lenf + 1.f;
-                tv = (tv * lenf + N[row + rad][lane]) / lenp1;
+                tv = (tv * lenf + B[row + rad][lane]) / lenp1;
                 lenf = lenp1;
             } else if (row < TS - rad) {
-                tv = tv + (N[row + rad][lane] - N[row - rad - 1][lane]) * rlen;
+                tv = tv + (B[row + rad][lane] - B[row - rad - 1][lane]) * rlen;
             } else {
                 const float lenm1 = lenf - 1.f;
-                tv = (tv * lenf - N[row - rad - 1][lane]) / lenm1;
+                tv = (tv * lenf - B[row - rad - 1][lane]) / lenm1;
                 lenf = lenm1;
             }
             if (row == rad) rlen = 1.f / lenf;
@@ -119,31 +125,32 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
                 const float t = static_cast<float>((100. - d) * (100. - d) + 50. * (100. - d)) * TS * 0.5f;
                 factor = t * t;
             }
-            const float y = T[row][lane];
-            T[row][lane] = y * (1.0f - xexpf_v(-sqr(tv) / factor));
+            const int slot = row > rad ? row - rad - 1 : TS + row;
+            B[slot][lane] = 1.0f - xexpf_v(-sqr(tv) / factor);
         }
     }
     __syncthreads();
-    // 5. REDFT01 along k (= DCT-III of (X0, 2 X1, 2 X2, ...)): lane = column m
-    x[0] = T[0][lane];
+    // 5. shrink (lane = row k again), then REDFT01 along m (= DCT-III of (X0, 2 X1, 2 X2, ...))
+    {
+        const int slot = lane > rad ? lane - rad - 1 : TS + lane;
 #pragma unroll
-    for (int k = 1; k < TS; ++k) x[k] = 2.f * T[k][lane];
+        for (int m = 0; m < TS; ++m) x[m] = x[m] * B[slot][m];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 1; m < TS; ++m) x[m] = 2.f * x[m];
     lee_inv<TS>(x);
 #pragma unroll
-    for (int i = 0; i < TS; ++i) T[i][lane] = x[i];
+    for (int j = 0; j < TS; ++j) B[lane][j] = x[j];
     __syncthreads();
-    // 6. REDFT01 along m: lane = row i
-    x[0] = T[lane][0];
+    // 6. REDFT01 along k: lane = column j; the result row i, column j goes straight to the block buffer (coalesced rows)
+    x[0] = B[0][lane];
 #pragma unroll
-    for (int m = 1; m < TS; ++m) x[m] = 2.f * T[lane][m];
+    for (int k = 1; k < TS; ++k) x[k] = 2.f * B[k][lane];
     lee_inv<TS>(x);
-#pragma unroll
-    for (int j = 0; j < TS; ++j) T[lane][j] = x[j];
-    __syncthreads();
-    // 7. store the block, coalesced rows
     float *out = a.blocks + (size_t)blk * TS * TS;
-#pragma unroll 8
-    for (int i = 0; i < TS; ++i) out[i * TS + lane] = T[i][lane];
+#pragma unroll
+    for (int i = 0; i < TS; ++i) out[i * TS + lane] = x[i];
 }
 
 // Sum the overlapping blocks per pixel in the reference's serial order and add the detail to L:
@@ -175,7 +182,14 @@ __global__ void __launch_bounds__(256) detail_gather_kernel(DetailArgs a)
 
 hipError_t launch_detail_blocks(const DetailArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(detail_blocks_kernel, dim3(a.numblox_W * a.numblox_H), dim3(64), 0, s, a);
+    // blur_rad = max(1, int(3 / scale)), scale >= 1 (FTblockDN.cc:1499): 1, 2 or 3
+    const dim3 grid(a.numblox_W * a.numblox_H);
+    switch (a.blur_rad) {
+    case 1: hipLaunchKernelGGL(detail_blocks_kernel<1>, grid, dim3(64), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(detail_blocks_kernel<2>, grid, dim3(64), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(detail_blocks_kernel<3>, grid, dim3(64), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 hipError_t launch_detail_gather(const DetailArgs &a, hipStream_t s)
