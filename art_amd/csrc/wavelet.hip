@@ -127,20 +127,29 @@ __global__ void __launch_bounds__(256) wavelet_synthesis0_kernel(WaveArgs a)
     const int c0 = blockIdx.x * S0_TW, r0 = blockIdx.y * S0_TH;
     constexpr int shift = 3; // taps - offset - 1
     const int srow0 = (r0 + shift) / 2 - 2; // first (unclamped) source row held in LDS
-    for (int t = threadIdx.x; t < S0_LH * S0_TW; t += 256) {
-        const int rr = t / S0_TW, cc = t - rr * S0_TW;
-        const int i = c0 + cc;
-        if (i >= w) continue;
+    // Horizontal pass.  Outputs i = 2q+1 and i = 2q+2 read the same three source columns (q, q+1, q+2: i_src = q+2 for both,
+    // the odd one takes taps 0,2,4 and the even one taps 1,3,5), so one item computes the pair from one set of loads.
+    // The tile starts at an even column: pair p covers tile columns 2p-1 and 2p, p = 0..S0_TW/2.
+    constexpr int NP = S0_TW / 2 + 1;
+    for (int t = threadIdx.x; t < S0_LH * NP; t += 256) {
+        const int rr = t / NP, p = t - rr * NP;
+        const int cc1 = 2 * p - 1, cc2 = 2 * p;                  // tile columns of the odd / even output
+        const int i1 = c0 + cc1;                                 // odd (c0 is even)
+        if (i1 >= w) continue;
         const int k = clampi(srow0 + rr, 0, h2 - 1);
-        const int i_src = (i + shift) / 2, begin = (i + shift) % 2;
-        float totLo = 0.f, totHi = 0.f;
-        for (int j = begin, l = 0; j < 6; j += 2, l += 1) {
+        const int i_src = (i1 + shift) / 2;                      // = (i1 + 1 + shift) / 2
+        float lo1 = 0.f, hi1 = 0.f, lo2 = 0.f, hi2 = 0.f;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
             const size_t arg = (size_t)k * w2 + clampi(i_src - l, 0, w2 - 1);
-            totLo += (SYN_LO[j] * a.src[arg] + SYN_HI[j] * a.b1[arg]);
-            totHi += (SYN_LO[j] * a.b2[arg] + SYN_HI[j] * a.b3[arg]);
+            const float s = a.src[arg], d1 = a.b1[arg], d2 = a.b2[arg], d3 = a.b3[arg];
+            lo1 += (SYN_LO[2 * l] * s + SYN_HI[2 * l] * d1);
+            hi1 += (SYN_LO[2 * l] * d2 + SYN_HI[2 * l] * d3);
+            lo2 += (SYN_LO[2 * l + 1] * s + SYN_HI[2 * l + 1] * d1);
+            hi2 += (SYN_LO[2 * l + 1] * d2 + SYN_HI[2 * l + 1] * d3);
         }
-        tLo[rr][cc] = totLo;
-        tHi[rr][cc] = totHi;
+        if (cc1 >= 0) { tLo[rr][cc1] = lo1; tHi[rr][cc1] = hi1; }
+        if (cc2 < S0_TW && i1 + 1 < w) { tLo[rr][cc2] = lo2; tHi[rr][cc2] = hi2; }
     }
     __syncthreads();
     const float srcFactor = 1.f - a.blend;
