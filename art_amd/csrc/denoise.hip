@@ -168,20 +168,37 @@ __global__ void __launch_bounds__(256) yuv2rgb_kernel(DnPixArgs a)
 }
 
 // ---------------------------------------------------------------- MadRgb (FTblockDN.cc:569-603)
-constexpr int MAD_LDS_BINS = 4096;
+#ifndef MAD_LDS_BINS_OVERRIDE
+#define MAD_LDS_BINS_OVERRIDE 4096
+#endif
+constexpr int MAD_LDS_BINS = MAD_LDS_BINS_OVERRIDE;
+#ifndef MAD_GRID
+#define MAD_GRID 192
+#endif
 __global__ void __launch_bounds__(256) mad_hist_kernel(const float *bands, size_t n, int *histo /*[nsub][65536]*/)
 {
+    // The first MAD_LDS_BINS bins live in LDS (16 KB: more LDS costs more in occupancy than it saves in global atomics); the
+    // long tail goes straight to global memory.  The loop is bound by the latency of its loads, so eight are kept in flight.
     __shared__ int h[MAD_LDS_BINS];
     const int sub = blockIdx.y;
     const float *data = bands + (size_t)sub * n;
     int *gh = histo + (size_t)sub * 65536;
     for (int i = threadIdx.x; i < MAD_LDS_BINS; i += 256) h[i] = 0;
     __syncthreads();
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        int v = abs((int)data[i]);
-        v = v < 65535 ? v : 65535;
-        if (v < MAD_LDS_BINS) atomicAdd(&h[v], 1);
-        else atomicAdd(&gh[v], 1);
+    constexpr int U = 8;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i0 = blockIdx.x * (size_t)256 + threadIdx.x; i0 < n; i0 += stride * U) {
+        float x[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) { const size_t i = i0 + k * stride; x[k] = i < n ? data[i] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            if (i0 + k * stride >= n) break;
+            int v = abs((int)x[k]);
+            v = v < 65535 ? v : 65535;
+            if (v < MAD_LDS_BINS) atomicAdd(&h[v], 1);
+            else atomicAdd(&gh[v], 1);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < MAD_LDS_BINS; i += 256)
@@ -497,7 +514,7 @@ hipError_t launch_mad(const float *bands, size_t n, int nsub, int *histo, float 
 {
     hipError_t e = hipMemsetAsync(histo, 0, (size_t)nsub * 65536 * sizeof(int), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mad_hist_kernel, dim3(flat_grid((long long)n, 512), nsub), dim3(256), 0, s, bands, n, histo);
+    hipLaunchKernelGGL(mad_hist_kernel, dim3(flat_grid((long long)n, MAD_GRID), nsub), dim3(256), 0, s, bands, n, histo);
     hipLaunchKernelGGL(mad_finish_kernel, dim3(nsub), dim3(256), 0, s, (const int *)histo, (int)n, out);
     return hipGetLastError();
 }
