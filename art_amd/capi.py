@@ -131,6 +131,7 @@ def _load():
     lib.artgpu_denoise_compute_params.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_double),
                                                   C.POINTER(C.c_double), C.c_double, C.POINTER(DenoiseInfoStore), C.POINTER(DenoiseParams)]
     lib.artgpu_ordered_sum_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float)]
+    lib.artgpu_saturation_vibrance.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.artgpu_channel_mixer.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float)]
     lib.artgpu_rgb_curves.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_pipeline_run.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
@@ -158,7 +159,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -291,6 +292,10 @@ class Context:
             assert x.is_contiguous() and x.dtype.itemsize == 4
             self._chk(LIB.artgpu_ordered_sum_f32(self._h, x.data_ptr(), x.numel(), 1, C.byref(r)))
         return np.float32(r.value)
+
+    def saturation_vibrance(self, image: RGB, saturation: int, vibrance: int, ws):
+        self._chk(LIB.artgpu_saturation_vibrance(self._h, C.byref(image), int(saturation), int(vibrance),
+                                                 (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)])))
 
     def channel_mixer(self, image: RGB, m):
         self._chk(LIB.artgpu_channel_mixer(self._h, C.byref(image), (C.c_float * 9)(*[float(v) for v in np.asarray(m, np.float32).reshape(9)])))

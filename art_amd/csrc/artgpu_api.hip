@@ -1597,6 +1597,25 @@ int artgpu_channel_mixer(artgpu_ctx *ctx, artgpu_rgb *image, const float m[9])
     return unbind_rgb(ctx, image, &d);
 }
 
+int artgpu_saturation_vibrance(artgpu_ctx *ctx, artgpu_rgb *image, int saturation, int vibrance, const double ws[9])
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!image || !ws) return fail(ctx, ARTGPU_EINVAL, "saturation_vibrance: null argument");
+    if (!saturation && !vibrance) return ARTGPU_OK;            // ipsaturation.cc:45-46
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB d;
+    int rc = bind_rgb(ctx, image, 4, true, &d, "saturation_vibrance");
+    if (rc) return rc;
+    SatArgs a = {};
+    for (int k = 0; k < 3; ++k) { a.dst[k] = d.p[k]; a.ws1[k] = ws[3 + k]; }
+    a.stride = d.stride; a.w = d.w; a.h = d.h;
+    a.saturation = 1.f + saturation / 100.f;
+    a.vibrance = 1.f - vibrance / 1000.f;
+    a.vib = vibrance ? 1 : 0;
+    HIPCHK(ctx, launch_saturation_vibrance(a, ctx->stream));
+    return unbind_rgb(ctx, image, &d);
+}
+
 int artgpu_rgb_curves(artgpu_ctx *ctx, artgpu_rgb *image, const float *rcurve, const float *gcurve, const float *bcurve)
 {
     if (!ctx) return ARTGPU_EINVAL;

@@ -142,6 +142,9 @@ hipError_t launch_ordered_sum(const float *x, long long n, float *out, hipStream
 struct MixArgs { float *dst[3]; size_t stride; int w, h; float m[9]; const float *lut[3]; };
 hipError_t launch_channel_mixer(const MixArgs &a, hipStream_t s);
 hipError_t launch_rgb_curves(const MixArgs &a, hipStream_t s);
+// saturationVibrance (ipsaturation.cc:43-83)
+struct SatArgs { float *dst[3]; size_t stride; int w, h; float saturation, vibrance; int vib; double ws1[3]; };
+hipError_t launch_saturation_vibrance(const SatArgs &a, hipStream_t s);
 // NEUTRAL tone curve (curves.cc:854-1038)
 struct NeutralArgs {
     float *img[3]; size_t stride; int w, h;

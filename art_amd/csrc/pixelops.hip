@@ -11,6 +11,7 @@
 //                        StandardToneCurve::Apply (curves.h:224-231,360-368; LUT.h:436-459)
 #include <hip/hip_runtime.h>
 #include "devmath.h"
+#include "devsleef.h"
 #include "kernels.h"
 
 namespace artgpu {
@@ -217,6 +218,42 @@ hipError_t launch_exposure(const PixArgs &a, hipStream_t s)
     hipLaunchKernelGGL(exposure_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
+// ImProcFunctions::saturationVibrance (ipsaturation.cc:29-83): chroma = rgb - luminance (double working-space row), optional
+// vibrance as a power law on |chroma| above 2^-16, then l + saturation * chroma floored at 2^-16
+__device__ __forceinline__ float pow_F(float a, float b) { return xexpf_s(b * xlogf_s(a)); }     // sleef.h:1309-1313
+__device__ __forceinline__ float apply_vibrance_px(float x, float vib, float noise)
+{
+    const float ax = fabsf(x / 65535.f);
+    if (ax > noise) {
+        const float sgn = (float)((0.f < x) - (x < 0.f));
+        return sgn * pow_F(ax, vib) * 65535.f;
+    }
+    return x;
+}
+__global__ void __launch_bounds__(256) saturation_vibrance_kernel(SatArgs a)
+{
+    const float noise = pow_F(2.f, -16.f);
+    FOR_IMAGE_XY(y, x, a.w, a.h) {
+        const size_t di = (size_t)y * a.stride + x;
+        const float r = a.dst[0][di], g = a.dst[1][di], b = a.dst[2][di];
+        const float l = (float)(r * a.ws1[0] + g * a.ws1[1] + b * a.ws1[2]);
+        float rl = r - l, gl = g - l, bl = b - l;
+        if (a.vib) {
+            rl = apply_vibrance_px(rl, a.vibrance, noise);
+            gl = apply_vibrance_px(gl, a.vibrance, noise);
+            bl = apply_vibrance_px(bl, a.vibrance, noise);
+        }
+        a.dst[0][di] = std_max(l + a.saturation * rl, noise);
+        a.dst[1][di] = std_max(l + a.saturation * gl, noise);
+        a.dst[2][di] = std_max(l + a.saturation * bl, noise);
+    }
+}
+hipError_t launch_saturation_vibrance(const SatArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(saturation_vibrance_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 static unsigned mix_grid(const MixArgs &a) { long long g = ((long long)a.w * a.h + 255) / 256; return (unsigned)(g < 16384 ? (g ? g : 1) : 16384); }
 hipError_t launch_channel_mixer(const MixArgs &a, hipStream_t s)
 {

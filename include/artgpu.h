@@ -301,6 +301,9 @@ int artgpu_ordered_sum_f32(artgpu_ctx *ctx, const float *x, int64_t n, int on_de
  *                        `outCurve` RGBCurve() builds on the host (L41-53), NULL for an identity curve. */
 int artgpu_channel_mixer(artgpu_ctx *ctx, artgpu_rgb *img, const float m[9]);
 int artgpu_rgb_curves(artgpu_ctx *ctx, artgpu_rgb *img, const float *rcurve, const float *gcurve, const float *bcurve);
+/* ImProcFunctions::saturationVibrance (ipsaturation.cc:43-83): saturation, vibrance = params->saturation.{saturation,vibrance}
+ * (integers; both 0 = nothing to do), ws = working-space matrix (row 1 is the luminance). */
+int artgpu_saturation_vibrance(artgpu_ctx *ctx, artgpu_rgb *img, int saturation, int vibrance, const double ws[9]);
 
 /* The whole hot path for one frame in one call -- what ART's batch loop does per image between load and rgb2out
  * (simpleprocess.cc stage_init L215-259, stage_denoise L311-315, stage_finish L389-396):

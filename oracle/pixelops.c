@@ -225,3 +225,29 @@ void oracle_get_image_skip(const float *const src[3], size_t ss, int W, int H, i
         }
     }
 }
+
+/* ImProcFunctions::saturationVibrance (ipsaturation.cc:29-83) */
+static float apply_vibrance(float x, float vib, float noise)
+{
+    const float ax = fabsf(x / 65535.f);
+    if (ax > noise) return (float)((0.f < x) - (x < 0.f)) * oracle_pow_F(ax, vib) * 65535.f;
+    return x;
+}
+void oracle_saturation_vibrance(float *const img[3], size_t s, int w, int h, int saturation_p, int vibrance_p, const double ws[9])
+{
+    const float saturation = 1.f + saturation_p / 100.f, vibrance = 1.f - vibrance_p / 1000.f;
+    const float noise = oracle_pow_F(2.f, -16.f);
+    if (!saturation_p && !vibrance_p) return;
+#pragma omp parallel for
+    for (int i = 0; i < h; ++i)
+        for (int j = 0; j < w; ++j) {
+            const size_t o = (size_t)i * s + j;
+            const float r = img[0][o], g = img[1][o], b = img[2][o];
+            const float l = r * ws[3] + g * ws[4] + b * ws[5];
+            float rl = r - l, gl = g - l, bl = b - l;
+            if (vibrance_p) { rl = apply_vibrance(rl, vibrance, noise); gl = apply_vibrance(gl, vibrance, noise); bl = apply_vibrance(bl, vibrance, noise); }
+            img[0][o] = rt_maxf(l + saturation * rl, noise);
+            img[1][o] = rt_maxf(l + saturation * gl, noise);
+            img[2][o] = rt_maxf(l + saturation * bl, noise);
+        }
+}

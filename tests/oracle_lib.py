@@ -420,3 +420,11 @@ def get_image_skip(planes, sx1, sy1, w, h, skip, mul, do_clip):
     lib().oracle_get_image_skip(_p3(planes), C.c_size_t(W), W, H, sx1, sy1, skip, _p3(out), C.c_size_t(w), w, h,
                                 (C.c_float * 3)(*[float(v) for v in mul]), 1 if do_clip else 0)
     return out
+
+
+def saturation_vibrance(img, saturation, vibrance, ws=None):
+    img = [np.array(p, dtype=np.float32, order="C") for p in img]
+    h, w = img[0].shape
+    wsd = (C.c_double * 9)(*[float(v) for v in np.asarray(REC2020_WS_D if ws is None else ws, dtype=np.float64).reshape(9)])
+    lib().oracle_saturation_vibrance(_p3(img), C.c_size_t(w), w, h, int(saturation), int(vibrance), wsd)
+    return img

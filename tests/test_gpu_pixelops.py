@@ -130,3 +130,20 @@ def test_get_image_skip_bit_exact(gpu_ctx, skip, crop):
     ref = O.get_image_skip(planes, sx1, sy1, w, h, skip, mul, True)
     for g, r in zip(got, ref):
         assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+
+
+@pytest.mark.parametrize("sat,vib", [(35, 0), (0, 40), (-20, -60), (0, 0)])
+def test_saturation_vibrance_bit_exact(gpu_ctx, sat, vib):
+    """N4: ImProcFunctions::saturationVibrance (ipsaturation.cc:29-83), sleef pow_F on |chroma|, double luminance row."""
+    from art_amd import capi
+    import oracle_lib as O
+    rng = np.random.default_rng(abs(sat * 100 + vib) + 7)
+    img = [rng.uniform(0.0, 66000.0, (131, 203)).astype(np.float32) for _ in range(3)]
+    img[0][:4, :4] = img[1][:4, :4] = img[2][:4, :4] = 1234.5          # grey: chroma exactly 0 (below the 2^-16 floor)
+    got = [p.copy() for p in img]
+    gpu_ctx.saturation_vibrance(capi.host_rgb(got), sat, vib, O.REC2020_WS_D)
+    ref = O.saturation_vibrance(img, sat, vib)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+    if sat or vib:
+        assert not np.array_equal(got[0], img[0])
