@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 #include <algorithm>
 
@@ -33,6 +34,10 @@ struct artgpu_ctx {
     static constexpr int NPOOL = 32;
     float *pool[NPOOL] = {};
     size_t pool_bytes[NPOOL] = {};
+    // artgpu_batch_run lanes: sibling contexts (own stream, arena, pools) that take every lanes-th frame on their own host thread
+    std::vector<artgpu_ctx *> lanes;
+    int batch_lanes = 1;
+    bool owns_stream = false;
     float fuse_pre = 0.f, fuse_post = 0.f;   // improc_denoise -> rgb_denoise: exposure compensation fused into rgb2yuv / yuv2rgb
     float *bbox = nullptr; // AMaZE: per-tile nyquist bounding boxes
     size_t bbox_bytes = 0;
@@ -241,6 +246,9 @@ int artgpu_destroy(artgpu_ctx *ctx)
         if (ctx->pool[k]) (void)hipFree(ctx->pool[k]);
     for (int k = 0; k < 3; ++k)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
+    for (artgpu_ctx *l : ctx->lanes) (void)artgpu_destroy(l);
+    ctx->lanes.clear();
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (int k = 0; k < 2; ++k)
         if (ctx->aux_ev[k]) (void)hipEventDestroy(ctx->aux_ev[k]);
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
@@ -1762,14 +1770,54 @@ int artgpu_pipeline_run(artgpu_ctx *ctx, const artgpu_plane *raw, const artgpu_p
     return unbind_rgb(ctx, out, &d);
 }
 
+int artgpu_set_batch_lanes(artgpu_ctx *ctx, int lanes)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (lanes < 1 || lanes > 8) return fail(ctx, ARTGPU_EINVAL, "set_batch_lanes: 1..8");
+    ctx->batch_lanes = lanes;
+    return ARTGPU_OK;
+}
+
 int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, const artgpu_pipeline_params *params, artgpu_rgb *outs)
 {
     if (!ctx) return ARTGPU_EINVAL;
     if (nframes < 0 || (nframes && (!raws || !params || !outs))) return fail(ctx, ARTGPU_EINVAL, "batch_run: null argument");
-    for (int f = 0; f < nframes; ++f) {
-        const int rc = artgpu_pipeline_run(ctx, &raws[f], params, &outs[f]);
-        if (rc) return rc;
+    const int L = std::min(ctx->batch_lanes, nframes);
+    if (L <= 1) {
+        for (int f = 0; f < nframes; ++f) {
+            const int rc = artgpu_pipeline_run(ctx, &raws[f], params, &outs[f]);
+            if (rc) return rc;
+        }
+        return ARTGPU_OK;
     }
+    // Frames are independent: lane k (its own context, stream and host thread) takes frames k, k+L, ...  The kernels of one frame
+    // are a mix of latency-bound (AMaZE) and bandwidth-bound (wavelet passes) work, so frames in flight on different streams fill
+    // each other's gaps (+11 % throughput with three lanes at 45 MP, scripts/overlap_time.py).
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    while ((int)ctx->lanes.size() < L - 1) {
+        artgpu_ctx *peer = nullptr;
+        int rc = artgpu_create(ctx->device, &peer);
+        if (rc) return fail(ctx, rc, "batch_run: cannot create lane %d", (int)ctx->lanes.size() + 1);
+        if (hipStreamCreateWithFlags(&peer->stream, hipStreamNonBlocking) != hipSuccess) { (void)artgpu_destroy(peer); return fail(ctx, ARTGPU_EHIP, "batch_run: stream"); }
+        peer->owns_stream = true;
+        ctx->lanes.push_back(peer);
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // inputs the caller produced on this context's stream
+    std::vector<int> rcs(L, ARTGPU_OK);
+    auto work = [&](int k) {
+        artgpu_ctx *c = k == 0 ? ctx : ctx->lanes[k - 1];
+        for (int f = k; f < nframes; f += L) {
+            const int rc = artgpu_pipeline_run(c, &raws[f], params, &outs[f]);
+            if (rc) { rcs[k] = rc; return; }
+        }
+        if (k > 0 && hipStreamSynchronize(c->stream) != hipSuccess) rcs[k] = ARTGPU_EHIP;
+    };
+    std::vector<std::thread> threads;
+    for (int k = 1; k < L; ++k) threads.emplace_back(work, k);
+    work(0);
+    for (std::thread &t : threads) t.join();
+    for (int k = 0; k < L; ++k)
+        if (rcs[k]) return fail(ctx, rcs[k], "batch_run: lane %d: %s", k, k == 0 ? ctx->err.c_str() : ctx->lanes[k - 1]->err.c_str());
     return ARTGPU_OK;
 }
 

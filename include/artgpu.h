@@ -344,6 +344,10 @@ int artgpu_pipeline_run(artgpu_ctx *ctx, const artgpu_plane *raw, const artgpu_p
  * simpleprocess.cc:586-612), so a multi-GPU batch is one context per GPU each running its own frames; the completion
  * barrier / gather lives in the host driver (bench.py, art_amd/batch.py), not in the data path. */
 int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, const artgpu_pipeline_params *params, artgpu_rgb *outs);
+/* Frames in flight per GPU for artgpu_batch_run (default 1 = one after another on the context's stream).  With lanes > 1 the
+ * context keeps lanes-1 sibling contexts (own stream, work arenas and host thread); frame f runs on lane f % lanes, the results are
+ * the same bits.  On return the secondary lanes have completed; lane 0 stays ordered on the context's stream as before. */
+int artgpu_set_batch_lanes(artgpu_ctx *ctx, int lanes);
 
 /* Bytes of device scratch the context currently holds (arena + staging). */
 size_t artgpu_scratch_bytes(const artgpu_ctx *ctx);

@@ -120,3 +120,37 @@ def test_pipeline_automatic_chroma_equals_explicit_compute_params(gpu_ctx):
     gpu_ctx.synchronize()
     for g, t in zip(got, d_img):
         assert np.array_equal(g.view(np.uint32), t.cpu().numpy().view(np.uint32))
+
+
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_batch_lanes_give_the_same_bits(lanes):
+    """artgpu_set_batch_lanes: frames in flight on sibling contexts / streams / host threads; results identical to one-by-one."""
+    w, h = 392, 296
+    lut = _lut()
+    p = _params(lut, 1)
+    seeds = (11, 12, 13, 14, 15)
+    raws = [synth.bayer_frame(w, h, synth.FILTERS_RGGB, seed=s, noise=1500) for s in seeds]
+    ctx = capi.Context(0)
+    try:
+        ref = [[np.zeros((h - 8, w - 8), np.float32) for _ in range(3)] for _ in raws]
+        ctx.batch_run([capi.host_plane(r) for r in raws], p, [capi.host_rgb(o) for o in ref])
+        ctx.set_batch_lanes(lanes)
+        for _ in range(2):          # twice: the lanes are created once and reused
+            outs = [[np.zeros((h - 8, w - 8), np.float32) for _ in range(3)] for _ in raws]
+            ctx.batch_run([capi.host_plane(r) for r in raws], p, [capi.host_rgb(o) for o in outs])
+            for o, r in zip(outs, ref):
+                for a, b in zip(o, r):
+                    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and a.max() > 0
+        # device-resident frames too
+        d_raws = [torch.from_numpy(r).cuda() for r in raws]
+        d_outs = [[torch.zeros((h - 8, w - 8), dtype=torch.float32, device="cuda") for _ in range(3)] for _ in raws]
+        torch.cuda.synchronize()
+        ctx.batch_run([capi.device_plane(t) for t in d_raws], p, [capi.RGB(*[capi.device_plane(t) for t in o]) for o in d_outs])
+        ctx.synchronize()
+        for o, r in zip(d_outs, ref):
+            for a, b in zip(o, r):
+                assert np.array_equal(a.cpu().numpy().view(np.uint32), b.view(np.uint32))
+        with pytest.raises(capi.ArtGpuError):
+            ctx.set_batch_lanes(0)
+    finally:
+        ctx.close()
