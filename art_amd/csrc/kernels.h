@@ -307,5 +307,7 @@ hipError_t launch_gaussian(const GaussArgs &a, hipStream_t s);
 hipError_t launch_nlm(const NlmArgs &a, hipStream_t s);
 bool nlm_sweep_supported(const NlmArgs &a);
 hipError_t launch_nlm_sweep(const NlmArgs &a, hipStream_t s);   // nlm_sweep.hip (flush-to-zero TU)
+bool nlm_group_supported(const NlmArgs &a);
+hipError_t launch_nlm_group(const NlmArgs &a, hipStream_t s);   // nlm_sweep.hip: workgroup per tile, a search row of offsets in flight
 
 } // namespace artgpu

@@ -200,6 +200,201 @@ __global__ void __launch_bounds__(WAVES * 64) nlm_sweep_kernel(NlmArgs a)
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v3: one WORKGROUP per reference tile, the 2*sr+1 offsets of one search row (same ty) in flight at once, one wave each.
+//
+// v2 above spends its time in memory round trips, not in the sweep: per offset it re-reads the source twice for the squared
+// differences and read-modify-writes both accumulators (32 B per pixel per offset, ~290 GB per 45 MP frame through L2).  Here
+//   * the source rows a chunk of anti-diagonals needs are staged ONCE per chunk in LDS (strip_a: the pixels themselves,
+//     strip_b: the rows shifted by ty with a 21-column window that covers every tx of the row and the patch-centre shift);
+//     all eleven waves take their squared differences and, later, the weighted sample from there;
+//   * each wave sweeps the integral image of its own offset exactly as in v2 (same association, same ring);
+//   * then ALL threads walk the chunk's pixels once: mask, SW and the weighted sum are loaded once, the eleven offsets are applied
+//     in the reference's order (tx ascending inside ty), and both accumulators are stored once -- 1/11 of the read-modify-writes.
+// Per offset that is ~3 B per pixel of global traffic instead of 32.  Same arithmetic per pixel, same order: bit-identical.
+namespace {
+constexpr int G_CH = 8;                 // anti-diagonal steps per chunk
+constexpr int G_NW = 11;                // waves per workgroup = offsets in flight (2 * 5 + 1)
+constexpr int G_NT = G_NW * 64;
+constexpr int G_SB = 21;                // strip_b columns: x from (d0 - row/RPL - 8)
+constexpr int G_LDS_FLOATS = 8192 + G_NW * G_CH * RP + G_NW * SCOLS * SP + TS * G_SB + TS * G_CH;
+} // namespace
+
+__global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
+{
+    extern __shared__ float g_lds[];
+    float *const explut = g_lds;
+    float *const cring_all = explut + 8192;
+    float *const sring_all = cring_all + G_NW * G_CH * RP;
+    float *const strip_b = sring_all + G_NW * SCOLS * SP;
+    float *const strip_a = strip_b + TS * G_SB;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < 8192; i += G_NT) explut[i] = a.explut[i];
+    float *const cring = cring_all + wave * (G_CH * RP), *const sring = sring_all + wave * (SCOLS * SP);
+    const float *__restrict__ src = a.src;
+    const float *__restrict__ mask = a.mask;
+    float *__restrict__ SW = a.SW;
+    float *__restrict__ img = a.img;
+
+    const int tile = blockIdx.x;
+    const int tile_y = tile / a.ntiles_x, tile_x = tile - tile_y * a.ntiles_x;
+    const int border = a.border, WW = a.WW, HH = a.HH, W = a.W;
+    const int step = TS - 2 * border;
+    const int start_y = tile_y * step, end_y = min(start_y + TS, HH), TH = end_y - start_y;
+    const int start_x = tile_x * step, end_x = min(start_x + TS, WW), TW = end_x - start_x;
+    const int pr = a.patch_radius, sr = a.search_radius, pr2 = 2 * pr, nt = 2 * sr + 1;
+    const int xx0 = start_x + border, xvec_end = end_x - border - 3;
+    const int nvec = xvec_end > xx0 ? (xvec_end - xx0 + 3) / 4 * 4 : 0;
+    const int nsteps = TW + (TH + RPL - 1) / RPL - 1;
+    const int row0 = lane * RPL;
+    const bool lane_has_rows = row0 < TH;
+    const bool has1 = row0 + 1 < TH, has2 = row0 + 2 < TH;
+    const bool sweeper = wave < nt;
+    const int tx = wave - sr;
+
+    for (int ty = -sr; ty <= sr; ++ty) {
+        float left0 = 0.f, left1 = 0.f, left2 = 0.f, upleft0 = 0.f, s2_latest = 0.f;
+        for (int d0 = 0; d0 < nsteps; d0 += G_CH) {
+            __syncthreads();        // the previous chunk's accumulate pass is done with the strips and the rings
+            // ---- stage the source rows of this chunk
+            for (int e = tid; e < TS * G_SB; e += G_NT) {
+                const int row = e / G_SB, k = e - row * G_SB;
+                float v = 0.f;
+                if (row < TH) {
+                    const int gy = min(max(row + ty + start_y, 0), HH - 1);
+                    const int gx = min(max(d0 - row / RPL - 8 + k + start_x, 0), WW - 1);
+                    v = src[(size_t)gy * WW + gx];
+                }
+                strip_b[e] = v;
+            }
+            for (int e = tid; e < TS * G_CH; e += G_NT) {
+                const int row = e / G_CH, s = e - row * G_CH;
+                const int xx = d0 + s - row / RPL;
+                float v = 0.f;
+                if (row < TH && xx >= 0 && xx < TW) {
+                    const int gy = min(max(row + start_y, 0), HH - 1), gx = min(max(xx + start_x, 0), WW - 1);
+                    v = src[(size_t)gy * WW + gx];
+                }
+                strip_a[e] = v;
+            }
+            __syncthreads();
+            if (sweeper) {
+                // ---- squared differences of this wave's offset, skewed ring coordinates [step][row]
+                for (int t = lane; t < TS * G_CH; t += 64) {
+                    const int row = t / G_CH, s = t - row * G_CH;
+                    const int xx = d0 + s - row / RPL;
+                    float sc = 0.f;
+                    if (row < TH && xx >= 0 && xx < TW) {
+                        const float df = strip_a[t] - strip_b[row * G_SB + s + tx + 8];
+                        sc = df * df;
+                    }
+                    cring[s * RP + row] = sc;
+                }
+                wave_fence();
+                // ---- sweep (as in v2)
+                for (int s = 0; s < G_CH; ++s) {
+                    const int xx = d0 + s - lane;
+                    const float up0 = __shfl_up(s2_latest, 1);
+                    const bool act = lane_has_rows && xx >= 0 && xx < TW;
+                    if (act) {
+                        float *cr = cring + s * RP + row0;
+                        const float sc0 = cr[0], sc1 = cr[1], sc2 = cr[2];
+                        float st0, st1 = 0.f, st2 = 0.f;
+                        if (row0 == 0) st0 = (xx == 0) ? 0.f : left0 + sc0;
+                        else if (xx == 0) st0 = up0 + sc0;
+                        else st0 = (left0 + up0) - (upleft0 - sc0);
+                        if (has1) st1 = (xx == 0) ? st0 + sc1 : (left1 + st0) - (left0 - sc1);
+                        if (has2) st2 = (xx == 0) ? st1 + sc2 : (left2 + st1) - (left1 - sc2);
+                        float *sw = sring + (xx & (SCOLS - 1)) * SP + row0;
+                        sw[0] = st0; sw[1] = st1; sw[2] = st2;
+                        if (xx >= pr2) {
+                            const float *sb = sring + ((xx - pr2) & (SCOLS - 1)) * SP + row0;
+                            if (row0 >= pr2) cr[0] = ((st0 + sb[-pr2]) - sb[0]) - sw[-pr2];
+                            if (has1 && row0 + 1 >= pr2) cr[1] = ((st1 + sb[1 - pr2]) - sb[1]) - sw[1 - pr2];
+                            if (has2 && row0 + 2 >= pr2) cr[2] = ((st2 + sb[2 - pr2]) - sb[2]) - sw[2 - pr2];
+                        }
+                        upleft0 = up0;
+                        left0 = st0; left1 = st1; left2 = st2;
+                        s2_latest = st2;
+                    }
+                    wave_fence();
+                }
+            }
+            __syncthreads();
+            // ---- accumulate: every thread, the chunk's pixels once, the row's offsets in order
+            for (int t = tid; t < TS * G_CH; t += G_NT) {
+                const int row = t / G_CH, s = t - row * G_CH;
+                const int xx = d0 + s - row / RPL;
+                const int sty = row - pr, stx = xx - pr;
+                if (!(row < TH && xx < TW && sty >= border && sty < TH - border && stx >= border && stx < TW - border)) continue;
+                const int py = sty + start_y, px = stx + start_x;
+                const int y = py - border, x = px - border;
+                const size_t oo = (size_t)y * W + x, io = (size_t)y * a.img_stride + x;
+                const bool vec = (px - xx0) < nvec;
+                const float m = mask[oo];
+                float swv = SW[oo], imv = img[io];
+                const float *sbp = strip_b + sty * G_SB + (s - row / RPL + sty / RPL - pr + 8 - sr);    // + w: the sample at offset w
+                const float *crp = cring_all + s * RP + row;
+                for (int w = 0; w < nt; ++w) {
+                    const float dist = crp[w * (G_CH * RP)];
+                    const float dist2 = vec ? sse_max(dist, 0.f) : std_max(dist, 0.f);
+                    const float dd = dist2 * m;
+                    float weight;
+                    if (vec) {
+                        const float clamped = sse_max(sse_min(8190.f, dd), 0.f);
+                        const int idx = (int)clamped;
+                        const float diff = sse_max(sse_min(8191.f, dd), 0.f) - (float)idx;
+                        weight = (diff * explut[idx + 1]) + ((1.f - diff) * explut[idx]);
+                    } else {
+                        if (dd < 0.f || !(dd == dd)) weight = explut[0];
+                        else if (dd > 8190.f) weight = explut[8191];
+                        else {
+                            const int idx = (int)dd;
+                            const float diff = dd - (float)idx;
+                            const float p1 = explut[idx], p2 = explut[idx + 1] - p1;
+                            weight = p1 + (p2 * diff);
+                        }
+                    }
+                    swv = swv + weight;
+                    imv = imv + (weight * sbp[w]);
+                }
+                SW[oo] = swv;
+                img[io] = imv;
+            }
+        }
+    }
+    __syncthreads();
+    // final estimate (nlmeans.cc:252-273)
+    const int ow = TW - 2 * border, oh = TH - 2 * border;
+    if (ow > 0 && oh > 0)
+        for (int t = tid; t < oh * ow; t += G_NT) {
+            const int ry = t / ow, rx = t - ry * ow;
+            const int y = start_y + ry, x = start_x + rx;
+            const size_t io = (size_t)y * a.img_stride + x;
+            const float f = 1e-5f + SW[(size_t)y * W + x];
+            img[io] = (img[io] / f) * a.factor;
+        }
+}
+
+bool nlm_group_supported(const NlmArgs &a)
+{
+    return 2 * a.patch_radius + 4 <= SCOLS && a.border * 2 < TS && a.search_radius <= 5 && a.patch_radius <= 2 && a.patch_radius >= 1;
+}
+
+hipError_t launch_nlm_group(const NlmArgs &a, hipStream_t s)
+{
+    constexpr size_t dyn = (size_t)G_LDS_FLOATS * sizeof(float);
+    static_assert(dyn <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&nlm_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(nlm_group_kernel, dim3(a.ntiles_x * a.ntiles_y), dim3(G_NT), dyn, s, a);
+    return hipGetLastError();
+}
+
 bool nlm_sweep_supported(const NlmArgs &a) { return 2 * a.patch_radius + 4 <= SCOLS && a.border * 2 < TS; }
 
 hipError_t launch_nlm_sweep(const NlmArgs &a, hipStream_t s)

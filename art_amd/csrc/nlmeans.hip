@@ -326,7 +326,8 @@ hipError_t launch_nlm(const NlmArgs &a, hipStream_t s)
     hipLaunchKernelGGL(nlm_zero_kernel, dim3(fgrid((long long)a.W * a.H)), dim3(256), 0, s, a);
     // v2 (one wave per tile, nlm_sweep.hip) handles patch radii up to 2 (scale >= 1); the v1 workgroup-per-tile kernel is
     // the exact general path (and ARTGPU_NLM_V1=1 forces it for A/B runs)
-    static const bool force_v1 = getenv("ARTGPU_NLM_V1") != nullptr;
+    static const bool force_v1 = getenv("ARTGPU_NLM_V1") != nullptr, force_v2 = getenv("ARTGPU_NLM_V2") != nullptr;
+    if (!force_v1 && !force_v2 && nlm_group_supported(a)) return launch_nlm_group(a, s);     // v3: a search row of offsets per workgroup pass
     if (!force_v1 && nlm_sweep_supported(a)) return launch_nlm_sweep(a, s);
     hipLaunchKernelGGL(nlm_tile_kernel, dim3(a.ntiles_x * a.ntiles_y), dim3(NLM_THREADS), 0, s, a);
     return hipGetLastError();
