@@ -252,115 +252,150 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
     const bool sweeper = wave < nt;
     const int tx = wave - sr;
 
-    for (int ty = -sr; ty <= sr; ++ty) {
-        float left0 = 0.f, left1 = 0.f, left2 = 0.f, upleft0 = 0.f, s2_latest = 0.f;
-        for (int d0 = 0; d0 < nsteps; d0 += G_CH) {
-            __syncthreads();        // the previous chunk's accumulate pass is done with the strips and the rings
-            // ---- stage the source rows of this chunk
-            for (int e = tid; e < TS * G_SB; e += G_NT) {
-                const int row = e / G_SB, k = e - row * G_SB;
-                float v = 0.f;
-                if (row < TH) {
-                    const int gy = min(max(row + ty + start_y, 0), HH - 1);
-                    const int gx = min(max(d0 - row / RPL - 8 + k + start_x, 0), WW - 1);
-                    v = src[(size_t)gy * WW + gx];
-                }
-                strip_b[e] = v;
+    // One flat loop over (ty, chunk) so that the global loads of iteration it+1 (its source strips) and the accumulator loads of
+    // iteration it are in flight while the waves sweep iteration it.
+    constexpr int NPB = (TS * G_SB + G_NT - 1) / G_NT, NPA = (TS * G_CH + G_NT - 1) / G_NT;
+    const int nchunks = (nsteps + G_CH - 1) / G_CH, niter = nt * nchunks;
+    float pb[NPB], pa[NPA];
+    auto fetch_strips = [&](int it) {
+        const int ty = it / nchunks - sr, d0 = (it % nchunks) * G_CH;
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) {
+            const int e = tid + q * G_NT;
+            const int row = e / G_SB, k = e - row * G_SB;
+            float v = 0.f;
+            if (e < TS * G_SB && row < TH) {
+                const int gy = min(max(row + ty + start_y, 0), HH - 1);
+                const int gx = min(max(d0 - row / RPL - 8 + k + start_x, 0), WW - 1);
+                v = src[(size_t)gy * WW + gx];
             }
-            for (int e = tid; e < TS * G_CH; e += G_NT) {
-                const int row = e / G_CH, s = e - row * G_CH;
-                const int xx = d0 + s - row / RPL;
-                float v = 0.f;
-                if (row < TH && xx >= 0 && xx < TW) {
-                    const int gy = min(max(row + start_y, 0), HH - 1), gx = min(max(xx + start_x, 0), WW - 1);
-                    v = src[(size_t)gy * WW + gx];
-                }
-                strip_a[e] = v;
+            pb[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) {
+            const int e = tid + q * G_NT;
+            const int row = e / G_CH, s = e - row * G_CH;
+            const int xx = d0 + s - row / RPL;
+            float v = 0.f;
+            if (e < TS * G_CH && row < TH && xx >= 0 && xx < TW) {
+                const int gy = min(max(row + start_y, 0), HH - 1), gx = min(max(xx + start_x, 0), WW - 1);
+                v = src[(size_t)gy * WW + gx];
             }
-            __syncthreads();
-            if (sweeper) {
-                // ---- squared differences of this wave's offset, skewed ring coordinates [step][row]
-                for (int t = lane; t < TS * G_CH; t += 64) {
-                    const int row = t / G_CH, s = t - row * G_CH;
-                    const int xx = d0 + s - row / RPL;
-                    float sc = 0.f;
-                    if (row < TH && xx >= 0 && xx < TW) {
-                        const float df = strip_a[t] - strip_b[row * G_SB + s + tx + 8];
-                        sc = df * df;
-                    }
-                    cring[s * RP + row] = sc;
-                }
-                wave_fence();
-                // ---- sweep (as in v2)
-                for (int s = 0; s < G_CH; ++s) {
-                    const int xx = d0 + s - lane;
-                    const float up0 = __shfl_up(s2_latest, 1);
-                    const bool act = lane_has_rows && xx >= 0 && xx < TW;
-                    if (act) {
-                        float *cr = cring + s * RP + row0;
-                        const float sc0 = cr[0], sc1 = cr[1], sc2 = cr[2];
-                        float st0, st1 = 0.f, st2 = 0.f;
-                        if (row0 == 0) st0 = (xx == 0) ? 0.f : left0 + sc0;
-                        else if (xx == 0) st0 = up0 + sc0;
-                        else st0 = (left0 + up0) - (upleft0 - sc0);
-                        if (has1) st1 = (xx == 0) ? st0 + sc1 : (left1 + st0) - (left0 - sc1);
-                        if (has2) st2 = (xx == 0) ? st1 + sc2 : (left2 + st1) - (left1 - sc2);
-                        float *sw = sring + (xx & (SCOLS - 1)) * SP + row0;
-                        sw[0] = st0; sw[1] = st1; sw[2] = st2;
-                        if (xx >= pr2) {
-                            const float *sb = sring + ((xx - pr2) & (SCOLS - 1)) * SP + row0;
-                            if (row0 >= pr2) cr[0] = ((st0 + sb[-pr2]) - sb[0]) - sw[-pr2];
-                            if (has1 && row0 + 1 >= pr2) cr[1] = ((st1 + sb[1 - pr2]) - sb[1]) - sw[1 - pr2];
-                            if (has2 && row0 + 2 >= pr2) cr[2] = ((st2 + sb[2 - pr2]) - sb[2]) - sw[2 - pr2];
-                        }
-                        upleft0 = up0;
-                        left0 = st0; left1 = st1; left2 = st2;
-                        s2_latest = st2;
-                    }
-                    wave_fence();
-                }
+            pa[q] = v;
+        }
+    };
+    fetch_strips(0);
+    float left0 = 0.f, left1 = 0.f, left2 = 0.f, upleft0 = 0.f, s2_latest = 0.f;
+    for (int it = 0; it < niter; ++it) {
+        const int d0 = (it % nchunks) * G_CH;
+        if (d0 == 0) { left0 = left1 = left2 = upleft0 = s2_latest = 0.f; }     // a new search row: new integral images
+        __syncthreads();            // the previous iteration's accumulate pass is done with the strips and the rings
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) { const int e = tid + q * G_NT; if (e < TS * G_SB) strip_b[e] = pb[q]; }
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) { const int e = tid + q * G_NT; if (e < TS * G_CH) strip_a[e] = pa[q]; }
+        __syncthreads();
+        // ---- loads that do not depend on the sweep: the next iteration's strips, this iteration's accumulators
+        if (it + 1 < niter) fetch_strips(it + 1);
+        bool aok[NPA];
+        float am[NPA], asw[NPA], aim[NPA];
+        size_t aoo[NPA], aio[NPA];
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) {
+            const int t = tid + q * G_NT;
+            const int row = t / G_CH, s = t - row * G_CH;
+            const int xx = d0 + s - row / RPL;
+            const int sty = row - pr, stx = xx - pr;
+            aok[q] = t < TS * G_CH && row < TH && xx < TW && sty >= border && sty < TH - border && stx >= border && stx < TW - border;
+            am[q] = asw[q] = aim[q] = 0.f; aoo[q] = aio[q] = 0;
+            if (aok[q]) {
+                const int y = sty + start_y - border, x = stx + start_x - border;
+                aoo[q] = (size_t)y * W + x;
+                aio[q] = (size_t)y * a.img_stride + x;
+                am[q] = mask[aoo[q]]; asw[q] = SW[aoo[q]]; aim[q] = img[aio[q]];
             }
-            __syncthreads();
-            // ---- accumulate: every thread, the chunk's pixels once, the row's offsets in order
-            for (int t = tid; t < TS * G_CH; t += G_NT) {
+        }
+        if (sweeper) {
+            // ---- squared differences of this wave's offset, skewed ring coordinates [step][row]
+            for (int t = lane; t < TS * G_CH; t += 64) {
                 const int row = t / G_CH, s = t - row * G_CH;
                 const int xx = d0 + s - row / RPL;
-                const int sty = row - pr, stx = xx - pr;
-                if (!(row < TH && xx < TW && sty >= border && sty < TH - border && stx >= border && stx < TW - border)) continue;
-                const int py = sty + start_y, px = stx + start_x;
-                const int y = py - border, x = px - border;
-                const size_t oo = (size_t)y * W + x, io = (size_t)y * a.img_stride + x;
-                const bool vec = (px - xx0) < nvec;
-                const float m = mask[oo];
-                float swv = SW[oo], imv = img[io];
-                const float *sbp = strip_b + sty * G_SB + (s - row / RPL + sty / RPL - pr + 8 - sr);    // + w: the sample at offset w
-                const float *crp = cring_all + s * RP + row;
-                for (int w = 0; w < nt; ++w) {
-                    const float dist = crp[w * (G_CH * RP)];
-                    const float dist2 = vec ? sse_max(dist, 0.f) : std_max(dist, 0.f);
-                    const float dd = dist2 * m;
-                    float weight;
-                    if (vec) {
-                        const float clamped = sse_max(sse_min(8190.f, dd), 0.f);
-                        const int idx = (int)clamped;
-                        const float diff = sse_max(sse_min(8191.f, dd), 0.f) - (float)idx;
-                        weight = (diff * explut[idx + 1]) + ((1.f - diff) * explut[idx]);
-                    } else {
-                        if (dd < 0.f || !(dd == dd)) weight = explut[0];
-                        else if (dd > 8190.f) weight = explut[8191];
-                        else {
-                            const int idx = (int)dd;
-                            const float diff = dd - (float)idx;
-                            const float p1 = explut[idx], p2 = explut[idx + 1] - p1;
-                            weight = p1 + (p2 * diff);
-                        }
-                    }
-                    swv = swv + weight;
-                    imv = imv + (weight * sbp[w]);
+                float sc = 0.f;
+                if (row < TH && xx >= 0 && xx < TW) {
+                    const float df = strip_a[t] - strip_b[row * G_SB + s + tx + 8];
+                    sc = df * df;
                 }
-                SW[oo] = swv;
-                img[io] = imv;
+                cring[s * RP + row] = sc;
             }
+            wave_fence();
+            // ---- sweep (as in v2)
+            for (int s = 0; s < G_CH; ++s) {
+                const int xx = d0 + s - lane;
+                const float up0 = __shfl_up(s2_latest, 1);
+                const bool act = lane_has_rows && xx >= 0 && xx < TW;
+                if (act) {
+                    float *cr = cring + s * RP + row0;
+                    const float sc0 = cr[0], sc1 = cr[1], sc2 = cr[2];
+                    float st0, st1 = 0.f, st2 = 0.f;
+                    if (row0 == 0) st0 = (xx == 0) ? 0.f : left0 + sc0;
+                    else if (xx == 0) st0 = up0 + sc0;
+                    else st0 = (left0 + up0) - (upleft0 - sc0);
+                    if (has1) st1 = (xx == 0) ? st0 + sc1 : (left1 + st0) - (left0 - sc1);
+                    if (has2) st2 = (xx == 0) ? st1 + sc2 : (left2 + st1) - (left1 - sc2);
+                    float *sw = sring + (xx & (SCOLS - 1)) * SP + row0;
+                    sw[0] = st0; sw[1] = st1; sw[2] = st2;
+                    if (xx >= pr2) {
+                        const float *sb = sring + ((xx - pr2) & (SCOLS - 1)) * SP + row0;
+                        if (row0 >= pr2) cr[0] = ((st0 + sb[-pr2]) - sb[0]) - sw[-pr2];
+                        if (has1 && row0 + 1 >= pr2) cr[1] = ((st1 + sb[1 - pr2]) - sb[1]) - sw[1 - pr2];
+                        if (has2 && row0 + 2 >= pr2) cr[2] = ((st2 + sb[2 - pr2]) - sb[2]) - sw[2 - pr2];
+                    }
+                    upleft0 = up0;
+                    left0 = st0; left1 = st1; left2 = st2;
+                    s2_latest = st2;
+                }
+                wave_fence();
+            }
+        }
+        __syncthreads();
+        // ---- accumulate: every thread, the chunk's pixels once, the row's offsets in order
+#pragma unroll
+        for (int q = 0; q < NPA; ++q) {
+            if (!aok[q]) continue;
+            const int t = tid + q * G_NT;
+            const int row = t / G_CH, s = t - row * G_CH;
+            const int xx = d0 + s - row / RPL;
+            const int sty = row - pr, px = xx - pr + start_x;
+            const bool vec = (px - xx0) < nvec;
+            const float m = am[q];
+            float swv = asw[q], imv = aim[q];
+            const float *sbp = strip_b + sty * G_SB + (s - row / RPL + sty / RPL - pr + 8 - sr);    // + w: the sample at offset w
+            const float *crp = cring_all + s * RP + row;
+            for (int w = 0; w < nt; ++w) {
+                const float dist = crp[w * (G_CH * RP)];
+                const float dist2 = vec ? sse_max(dist, 0.f) : std_max(dist, 0.f);
+                const float dd = dist2 * m;
+                float weight;
+                if (vec) {
+                    const float clamped = sse_max(sse_min(8190.f, dd), 0.f);
+                    const int idx = (int)clamped;
+                    const float diff = sse_max(sse_min(8191.f, dd), 0.f) - (float)idx;
+                    weight = (diff * explut[idx + 1]) + ((1.f - diff) * explut[idx]);
+                } else {
+                    if (dd < 0.f || !(dd == dd)) weight = explut[0];
+                    else if (dd > 8190.f) weight = explut[8191];
+                    else {
+                        const int idx = (int)dd;
+                        const float diff = dd - (float)idx;
+                        const float p1 = explut[idx], p2 = explut[idx + 1] - p1;
+                        weight = p1 + (p2 * diff);
+                    }
+                }
+                swv = swv + weight;
+                imv = imv + (weight * sbp[w]);
+            }
+            SW[aoo[q]] = swv;
+            img[aio[q]] = imv;
         }
     }
     __syncthreads();
