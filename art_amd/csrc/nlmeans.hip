@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256) dm_up_scurve_kernel(MaskArgs a)
 
 // ---------------------------------------------------------------- Young-van Vliet gaussian (gauss.cc:554-665,716-856)
 template <typename C>
-__device__ __forceinline__ void yvv_line(float *p, size_t st, float *tmp, size_t tst, int n, C B, C b1, C b2, C b3, const C *M)
+__device__ __forceinline__ void yvv_line(float *__restrict__ p, size_t st, float *__restrict__ tmp, size_t tst, int n, C B, C b1, C b2, C b3, const C *M)
 {
     // forward (tmp may alias nothing; float storage as in the reference's AlignedMatrix<float>)
     const float s0 = p[0], sl = p[(size_t)(n - 1) * st];
@@ -102,6 +102,8 @@ __device__ __forceinline__ void yvv_line(float *p, size_t st, float *tmp, size_t
     float t2 = sizeof(C) == 4 ? (float)(p[2 * st] * B + t1 * b1 + t0 * b2 + s0 * b3) : (float)(B * p[2 * st] + b1 * t1 + b2 * t0 + b3 * s0);
     tmp[0] = t0; tmp[tst] = t1; tmp[2 * tst] = t2;
     float m3 = t0, m2 = t1, m1 = t2;
+    // the loads do not depend on the recurrence: with p and tmp known not to alias, the unrolled loop keeps eight of them in flight
+#pragma unroll 8
     for (int j = 3; j < n; j++) {
         const float v = sizeof(C) == 4 ? (float)(p[(size_t)j * st] * B + m1 * b1 + m2 * b2 + m3 * b3) : (float)(B * p[(size_t)j * st] + b1 * m1 + b2 * m2 + b3 * m3);
         tmp[(size_t)j * tst] = v;
@@ -115,6 +117,7 @@ __device__ __forceinline__ void yvv_line(float *p, size_t st, float *tmp, size_t
     const float r3 = (float)(B * m3 + b1 * r2 + b2 * r1 + b3 * t2W);
     p[(size_t)(n - 1) * st] = r1; p[(size_t)(n - 2) * st] = r2; p[(size_t)(n - 3) * st] = r3;
     float a1 = r3, a2 = r2, a3 = r1; // outputs at j+1, j+2, j+3
+#pragma unroll 8
     for (int j = n - 4; j >= 0; j--) {
         const float tj = tmp[(size_t)j * tst];
         const float v = sizeof(C) == 4 ? (float)(tj * B + a1 * b1 + a2 * b2 + a3 * b3) : (float)(B * tj + b1 * a1 + b2 * a2 + b3 * a3);
