@@ -37,6 +37,12 @@ constexpr int WAVES = 10;
 constexpr int LB = 8;            // load-pass iterations in flight
 constexpr int AB = 4;            // accumulate-pass iterations in flight
 
+// c ? a : b on the bit patterns: always a select, never a branch
+__device__ __forceinline__ float bsel(bool c, float a, float b)
+{
+    const int m = -(int)c;
+    return __int_as_float((__float_as_int(a) & m) | (__float_as_int(b) & ~m));
+}
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 } // namespace
 
@@ -284,17 +290,38 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
             pa[q] = v;
         }
     };
+#ifdef NLM_PROFILE
+    long long tacc[6] = {0, 0, 0, 0, 0, 0}, tp = wall_clock64();
+#define TICK(k) do { long long now_ = wall_clock64(); tacc[k] += now_ - tp; tp = now_; } while (0)
+#else
+#define TICK(k) do { } while (0)
+#endif
     fetch_strips(0);
     float left0 = 0.f, left1 = 0.f, left2 = 0.f, upleft0 = 0.f, s2_latest = 0.f;
     for (int it = 0; it < niter; ++it) {
         const int d0 = (it % nchunks) * G_CH;
         if (d0 == 0) { left0 = left1 = left2 = upleft0 = s2_latest = 0.f; }     // a new search row: new integral images
         __syncthreads();            // the previous iteration's accumulate pass is done with the strips and the rings
+        TICK(0);
 #pragma unroll
         for (int q = 0; q < NPB; ++q) { const int e = tid + q * G_NT; if (e < TS * G_SB) strip_b[e] = pb[q]; }
 #pragma unroll
         for (int q = 0; q < NPA; ++q) { const int e = tid + q * G_NT; if (e < TS * G_CH) strip_a[e] = pa[q]; }
         __syncthreads();
+        TICK(1);
+        TICK(2);
+        if (sweeper) {
+            // ---- squared differences of this wave's offset, skewed ring coordinates [step][row]
+#pragma unroll 5
+            for (int t = lane; t < TS * G_CH; t += 64) {       // 1200 / 64 = 18.75 rounds; all reads of five rounds in flight
+                const int row = t / G_CH, s = t - row * G_CH;
+                const int xx = d0 + s - row / RPL;
+                const float df = strip_a[t] - strip_b[row * G_SB + s + tx + 8];     // rows >= TH / columns outside hold 0 or are masked
+                cring[s * RP + row] = (row < TH && xx >= 0 && xx < TW) ? df * df : 0.f;
+            }
+            wave_fence();
+        }
+        TICK(3);
         // ---- loads that do not depend on the sweep: the next iteration's strips, this iteration's accumulators
         if (it + 1 < niter) fetch_strips(it + 1);
         bool aok[NPA];
@@ -316,47 +343,45 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
             }
         }
         if (sweeper) {
-            // ---- squared differences of this wave's offset, skewed ring coordinates [step][row]
-            for (int t = lane; t < TS * G_CH; t += 64) {
-                const int row = t / G_CH, s = t - row * G_CH;
-                const int xx = d0 + s - row / RPL;
-                float sc = 0.f;
-                if (row < TH && xx >= 0 && xx < TW) {
-                    const float df = strip_a[t] - strip_b[row * G_SB + s + tx + 8];
-                    sc = df * df;
-                }
-                cring[s * RP + row] = sc;
-            }
-            wave_fence();
-            // ---- sweep (as in v2)
+            // ---- sweep (v2's recurrence, written without branches: every LDS read of a step is an unconditional load issued up
+            //      front -- any address stays inside this kernel's LDS block -- and conditions only select values or mask stores, so a
+            //      step is one LDS round trip; the row above comes from the previous lane through a DPP wave shift)
             for (int s = 0; s < G_CH; ++s) {
                 const int xx = d0 + s - lane;
-                const float up0 = __shfl_up(s2_latest, 1);
+                const float up0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2_latest), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
                 const bool act = lane_has_rows && xx >= 0 && xx < TW;
+                float *cr = cring + s * RP + row0;
+                float *sw = sring + (xx & (SCOLS - 1)) * SP + row0;
+                const float *sb = sring + ((xx - pr2) & (SCOLS - 1)) * SP + row0;
+                const float sc0 = cr[0], sc1 = cr[1], sc2 = cr[2];
+                // corners of the three box sums: column xx - 2pr at rows -2pr.. and 0.., and this column at the rows above
+                float ca[3], cb[3], cc[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { ca[k] = sb[k - pr2]; cb[k] = sb[k]; cc[k] = sw[k - pr2]; }
+                const bool first = xx == 0;
+                // every arm is computed, then chosen with bit masks (the compiler otherwise rebuilds a branch per condition)
+                const float st0 = bsel(row0 == 0, bsel(first, 0.f, left0 + sc0), bsel(first, up0 + sc0, (left0 + up0) - (upleft0 - sc0)));
+                const float st1 = bsel(has1, bsel(first, st0 + sc1, (left1 + st0) - (left0 - sc1)), 0.f);
+                const float st2 = bsel(has2, bsel(first, st1 + sc2, (left2 + st1) - (left1 - sc2)), 0.f);
+                if (pr2 == 2) cc[2] = st0;            // index 0 of this column is this step's own result (2pr >= 4: all rows above)
+                const float r0 = ((st0 + ca[0]) - cb[0]) - cc[0];
+                const float r1 = ((st1 + ca[1]) - cb[1]) - cc[1];
+                const float r2 = ((st2 + ca[2]) - cb[2]) - cc[2];
                 if (act) {
-                    float *cr = cring + s * RP + row0;
-                    const float sc0 = cr[0], sc1 = cr[1], sc2 = cr[2];
-                    float st0, st1 = 0.f, st2 = 0.f;
-                    if (row0 == 0) st0 = (xx == 0) ? 0.f : left0 + sc0;
-                    else if (xx == 0) st0 = up0 + sc0;
-                    else st0 = (left0 + up0) - (upleft0 - sc0);
-                    if (has1) st1 = (xx == 0) ? st0 + sc1 : (left1 + st0) - (left0 - sc1);
-                    if (has2) st2 = (xx == 0) ? st1 + sc2 : (left2 + st1) - (left1 - sc2);
-                    float *sw = sring + (xx & (SCOLS - 1)) * SP + row0;
                     sw[0] = st0; sw[1] = st1; sw[2] = st2;
                     if (xx >= pr2) {
-                        const float *sb = sring + ((xx - pr2) & (SCOLS - 1)) * SP + row0;
-                        if (row0 >= pr2) cr[0] = ((st0 + sb[-pr2]) - sb[0]) - sw[-pr2];
-                        if (has1 && row0 + 1 >= pr2) cr[1] = ((st1 + sb[1 - pr2]) - sb[1]) - sw[1 - pr2];
-                        if (has2 && row0 + 2 >= pr2) cr[2] = ((st2 + sb[2 - pr2]) - sb[2]) - sw[2 - pr2];
+                        if (row0 >= pr2) cr[0] = r0;
+                        if (has1 && row0 + 1 >= pr2) cr[1] = r1;
+                        if (has2 && row0 + 2 >= pr2) cr[2] = r2;
                     }
-                    upleft0 = up0;
-                    left0 = st0; left1 = st1; left2 = st2;
-                    s2_latest = st2;
                 }
+                upleft0 = bsel(act, up0, upleft0);
+                left0 = bsel(act, st0, left0); left1 = bsel(act, st1, left1); left2 = bsel(act, st2, left2);
+                s2_latest = bsel(act, st2, s2_latest);
                 wave_fence();
             }
         }
+        TICK(4);
         __syncthreads();
         // ---- accumulate: every thread, the chunk's pixels once, the row's offsets in order
 #pragma unroll
@@ -397,7 +422,14 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
             SW[aoo[q]] = swv;
             img[aio[q]] = imv;
         }
+        TICK(5);
     }
+#ifdef NLM_PROFILE
+    if (blockIdx.x == 700 && tid == 0)
+        printf("nlm tile 700, %d iterations, ticks (100 MHz): top-barrier %lld  strip-write+barrier %lld  prefetch-issue %lld  sc %lld  sweep %lld  barrier+accumulate %lld\n",
+               niter, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5]);
+#endif
+#undef TICK
     __syncthreads();
     // final estimate (nlmeans.cc:252-273)
     const int ow = TW - 2 * border, oh = TH - 2 * border;

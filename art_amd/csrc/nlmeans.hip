@@ -103,7 +103,7 @@ __device__ __forceinline__ void yvv_line(float *__restrict__ p, size_t st, float
     tmp[0] = t0; tmp[tst] = t1; tmp[2 * tst] = t2;
     float m3 = t0, m2 = t1, m1 = t2;
     // the loads do not depend on the recurrence: with p and tmp known not to alias, the unrolled loop keeps eight of them in flight
-#pragma unroll 8
+#pragma unroll 16
     for (int j = 3; j < n; j++) {
         const float v = sizeof(C) == 4 ? (float)(p[(size_t)j * st] * B + m1 * b1 + m2 * b2 + m3 * b3) : (float)(B * p[(size_t)j * st] + b1 * m1 + b2 * m2 + b3 * m3);
         tmp[(size_t)j * tst] = v;
@@ -117,7 +117,7 @@ __device__ __forceinline__ void yvv_line(float *__restrict__ p, size_t st, float
     const float r3 = (float)(B * m3 + b1 * r2 + b2 * r1 + b3 * t2W);
     p[(size_t)(n - 1) * st] = r1; p[(size_t)(n - 2) * st] = r2; p[(size_t)(n - 3) * st] = r3;
     float a1 = r3, a2 = r2, a3 = r1; // outputs at j+1, j+2, j+3
-#pragma unroll 8
+#pragma unroll 16
     for (int j = n - 4; j >= 0; j--) {
         const float tj = tmp[(size_t)j * tst];
         const float v = sizeof(C) == 4 ? (float)(tj * B + a1 * b1 + a2 * b2 + a3 * b3) : (float)(B * tj + b1 * a1 + b2 * a2 + b3 * a3);
