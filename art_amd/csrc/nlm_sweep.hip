@@ -358,11 +358,12 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
                 float ca[3], cb[3], cc[3];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { ca[k] = sb[k - pr2]; cb[k] = sb[k]; cc[k] = sw[k - pr2]; }
-                const bool first = xx == 0;
-                // every arm is computed, then chosen with bit masks (the compiler otherwise rebuilds a branch per condition)
-                const float st0 = bsel(row0 == 0, bsel(first, 0.f, left0 + sc0), bsel(first, up0 + sc0, (left0 + up0) - (upleft0 - sc0)));
-                const float st1 = bsel(has1, bsel(first, st0 + sc1, (left1 + st0) - (left0 - sc1)), 0.f);
-                const float st2 = bsel(has2, bsel(first, st1 + sc2, (left2 + st1) - (left1 - sc2)), 0.f);
+                // The reference's first-column forms (up + s, above + s) are what the general form gives when everything to the left is
+                // +0: (0 + u) - (0 - s) = u + s with the same single rounding.  The state of a lane that has not started (xx < 0) is
+                // kept at 0 below, so only S(0,0) = 0 needs its own case.  Arms are chosen with bit masks (no branches).
+                const float st0 = bsel(row0 == 0, bsel(xx == 0, 0.f, left0 + sc0), (left0 + up0) - (upleft0 - sc0));
+                const float st1 = bsel(has1, (left1 + st0) - (left0 - sc1), 0.f);
+                const float st2 = bsel(has2, (left2 + st1) - (left1 - sc2), 0.f);
                 if (pr2 == 2) cc[2] = st0;            // index 0 of this column is this step's own result (2pr >= 4: all rows above)
                 const float r0 = ((st0 + ca[0]) - cb[0]) - cc[0];
                 const float r1 = ((st1 + ca[1]) - cb[1]) - cc[1];
@@ -375,9 +376,13 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
                         if (has2 && row0 + 2 >= pr2) cr[2] = r2;
                     }
                 }
-                upleft0 = bsel(act, up0, upleft0);
-                left0 = bsel(act, st0, left0); left1 = bsel(act, st1, left1); left2 = bsel(act, st2, left2);
-                s2_latest = bsel(act, st2, s2_latest);
+                // state: zero until the lane starts; what a lane holds after its last column is never read
+                const int started = -(int)(xx >= 0);
+                upleft0 = __int_as_float(__float_as_int(up0) & started);
+                left0 = __int_as_float(__float_as_int(st0) & started);
+                left1 = __int_as_float(__float_as_int(st1) & started);
+                left2 = __int_as_float(__float_as_int(st2) & started);
+                s2_latest = left2;
                 wave_fence();
             }
         }
