@@ -57,3 +57,17 @@ def test_config5_xtrans_100mp_bit_exact(gpu_ctx):
     ref = O.xtrans_demosaic(raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, 3, True)
     for t, r in zip(d_out, ref):
         assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))
+
+
+def test_nlmeans_12mp_bit_exact(gpu_ctx):
+    """NL-means (v3 kernel: workgroup per 150x150 reference tile, 27x20 tiles incl. partial ones) on a 12 MP luminance plane."""
+    W, H = 4000, 3000
+    rng = np.random.default_rng(17)
+    y, x = np.mgrid[0:H, 0:W].astype(np.float32)
+    img = (18000 + 9000 * np.sin(0.004 * x) * np.cos(0.005 * y) + 5000 * ((x.astype(np.int32) // 96 + y.astype(np.int32) // 96) % 2)
+           + rng.normal(0, 900, (H, W))).clip(0, 65535).astype(np.float32)
+    got = img.copy()
+    gpu_ctx.nlmeans(capi.host_plane(got), 50, 80, 1.0)
+    ref = O.nlmeans(img, 50, 80, 1.0)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert np.abs(got - img).mean() > 1.0
