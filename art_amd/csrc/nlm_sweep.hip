@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(WAVES * 64) nlm_sweep_kernel(NlmArgs a)
 //   * the source rows a chunk of anti-diagonals needs are staged ONCE per chunk in LDS (strip_a: the pixels themselves,
 //     strip_b: the rows shifted by ty with a 21-column window that covers every tx of the row and the patch-centre shift);
 //     all eleven waves take their squared differences and, later, the weighted sample from there;
-//   * each wave sweeps the integral image of its own offset exactly as in v2 (same association, same ring);
+//   * each wave sweeps the integral image of its own offset exactly as in v2 (same association, same ring), taking the squared
+//     differences straight from the strips (v2's separate pass that filled the ring with them is gone);
 //   * then ALL threads walk the chunk's pixels once: mask, SW and the weighted sum are loaded once, the eleven offsets are applied
 //     in the reference's order (tx ascending inside ty), and both accumulators are stored once -- 1/11 of the read-modify-writes.
 // Per offset that is ~3 B per pixel of global traffic instead of 32.  Same arithmetic per pixel, same order: bit-identical.
@@ -223,7 +224,8 @@ constexpr int G_CH = 8;                 // anti-diagonal steps per chunk
 constexpr int G_NW = 11;                // waves per workgroup = offsets in flight (2 * 5 + 1)
 constexpr int G_NT = G_NW * 64;
 constexpr int G_SB = 21;                // strip_b columns: x from (d0 - row/RPL - 8)
-constexpr int G_LDS_FLOATS = 8192 + G_NW * G_CH * RP + G_NW * SCOLS * SP + TS * G_SB + TS * G_CH;
+constexpr int G_SA = G_CH + 1;          // strip_a row pitch (odd: the sweep reads three rows per lane)
+constexpr int G_LDS_FLOATS = 8192 + G_NW * G_CH * RP + G_NW * SCOLS * SP + TS * G_SB + (TS + 42) * G_SA;
 } // namespace
 
 __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
@@ -306,21 +308,10 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
 #pragma unroll
         for (int q = 0; q < NPB; ++q) { const int e = tid + q * G_NT; if (e < TS * G_SB) strip_b[e] = pb[q]; }
 #pragma unroll
-        for (int q = 0; q < NPA; ++q) { const int e = tid + q * G_NT; if (e < TS * G_CH) strip_a[e] = pa[q]; }
+        for (int q = 0; q < NPA; ++q) { const int e = tid + q * G_NT; if (e < TS * G_CH) strip_a[(e / G_CH) * G_SA + (e % G_CH)] = pa[q]; }
         __syncthreads();
         TICK(1);
         TICK(2);
-        if (sweeper) {
-            // ---- squared differences of this wave's offset, skewed ring coordinates [step][row]
-#pragma unroll 5
-            for (int t = lane; t < TS * G_CH; t += 64) {       // 1200 / 64 = 18.75 rounds; all reads of five rounds in flight
-                const int row = t / G_CH, s = t - row * G_CH;
-                const int xx = d0 + s - row / RPL;
-                const float df = strip_a[t] - strip_b[row * G_SB + s + tx + 8];     // rows >= TH / columns outside hold 0 or are masked
-                cring[s * RP + row] = (row < TH && xx >= 0 && xx < TW) ? df * df : 0.f;
-            }
-            wave_fence();
-        }
         TICK(3);
         // ---- loads that do not depend on the sweep: the next iteration's strips, this iteration's accumulators
         if (it + 1 < niter) fetch_strips(it + 1);
@@ -353,7 +344,11 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
                 float *cr = cring + s * RP + row0;
                 float *sw = sring + (xx & (SCOLS - 1)) * SP + row0;
                 const float *sb = sring + ((xx - pr2) & (SCOLS - 1)) * SP + row0;
-                const float sc0 = cr[0], sc1 = cr[1], sc2 = cr[2];
+                // squared differences of this wave's offset straight from the staged source rows (strip_a: the pixel, strip_b: the
+                // pixel at the offset); positions outside the tile are only ever computed by lanes whose results are discarded
+                const float *pa0 = strip_a + row0 * G_SA + s, *pb0 = strip_b + row0 * G_SB + s + tx + 8;
+                const float df0 = pa0[0] - pb0[0], df1 = pa0[G_SA] - pb0[G_SB], df2 = pa0[2 * G_SA] - pb0[2 * G_SB];
+                const float sc0 = df0 * df0, sc1 = df1 * df1, sc2 = df2 * df2;
                 // corners of the three box sums: column xx - 2pr at rows -2pr.. and 0.., and this column at the rows above
                 float ca[3], cb[3], cc[3];
 #pragma unroll
