@@ -1605,6 +1605,70 @@ int artgpu_channel_mixer(artgpu_ctx *ctx, artgpu_rgb *image, const float m[9])
     return unbind_rgb(ctx, image, &d);
 }
 
+int artgpu_rgb2out_matrix(artgpu_ctx *ctx, const artgpu_rgb *src, artgpu_rgb *dst, const float matrix[9], int trc_linear,
+                          const float *lut, int lutsz)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!src || !dst || !matrix) return fail(ctx, ARTGPU_EINVAL, "rgb2out_matrix: null argument");
+    if (!trc_linear && (!lut || lutsz < 2)) return fail(ctx, ARTGPU_EINVAL, "rgb2out_matrix: a non-linear TRC needs its LUT");
+    if (lut && (lutsz < 2 || lutsz > 65536)) return fail(ctx, ARTGPU_EINVAL, "rgb2out_matrix: lutsz %d", lutsz);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB s, d;
+    int rc = bind_rgb(ctx, src, 1, true, &s, "rgb2out_matrix(src)");
+    if (rc) return rc;
+    if ((rc = bind_rgb(ctx, dst, 4, false, &d, "rgb2out_matrix(dst)"))) return rc;
+    if (s.w != d.w || s.h != d.h) return fail(ctx, ARTGPU_EINVAL, "rgb2out_matrix: size mismatch");
+    float *tab;
+    if ((rc = pool_get(ctx, P_PIPE_R, (65536 + 16) * 4, &tab))) return rc;
+    OutArgs a = {};
+    for (int k = 0; k < 3; ++k) { a.src[k] = s.p[k]; a.dst[k] = d.p[k]; }
+    a.src_stride = s.stride; a.dst_stride = d.stride; a.w = s.w; a.h = s.h;
+    for (int k = 0; k < 9; ++k) a.m[k] = matrix[k];
+    a.linear = trc_linear ? 1 : 0;
+    a.unsupported = reinterpret_cast<int *>(tab + 65536);
+    HIPCHK(ctx, hipMemsetAsync(a.unsupported, 0, 4, ctx->stream));
+    if (lut) {
+        HIPCHK(ctx, hipMemcpyAsync(tab, lut, (size_t)lutsz * 4, hipMemcpyHostToDevice, ctx->stream));
+        a.lut = tab; a.lutsz = lutsz;
+    }
+    HIPCHK(ctx, launch_rgb2out_matrix(a, ctx->stream));
+    int bad = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&bad, a.unsupported, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = unbind_rgb(ctx, dst, &d))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad) return fail(ctx, ARTGPU_EUNSUPPORTED, "rgb2out_matrix: %d channel values above 1 need ARTOutputProfile::eval (lcms2/libm) on the host", bad);
+    return ARTGPU_OK;
+}
+
+int artgpu_get_scanlines(artgpu_ctx *ctx, const artgpu_rgb *img, int bps, int is_float, void *dst, int64_t dst_row_stride_bytes, int dst_on_device)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!img || !dst) return fail(ctx, ARTGPU_EINVAL, "get_scanlines: null argument");
+    const bool okfmt = is_float ? (bps == 16 || bps == 32) : (bps == 8 || bps == 16);
+    if (!okfmt) return fail(ctx, ARTGPU_EINVAL, "get_scanlines: bps %d / is_float %d", bps, is_float);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB s;
+    int rc = bind_rgb(ctx, img, 4, true, &s, "get_scanlines");
+    if (rc) return rc;
+    const size_t rowb = (size_t)s.w * 3 * (bps / 8);
+    if (dst_row_stride_bytes < (int64_t)rowb) return fail(ctx, ARTGPU_EINVAL, "get_scanlines: row stride %lld < %zu", (long long)dst_row_stride_bytes, rowb);
+    OutArgs a = {};
+    for (int k = 0; k < 3; ++k) a.src[k] = s.p[k];
+    a.src_stride = s.stride; a.w = s.w; a.h = s.h; a.bps = bps; a.is_float = is_float ? 1 : 0;
+    float *stage = nullptr;
+    if (dst_on_device) { a.out = static_cast<unsigned char *>(dst); a.out_stride_bytes = (size_t)dst_row_stride_bytes; }
+    else {
+        if ((rc = pool_get(ctx, P_TMP, rowb * s.h + 16, &stage))) return rc;
+        a.out = reinterpret_cast<unsigned char *>(stage); a.out_stride_bytes = rowb;
+    }
+    HIPCHK(ctx, launch_scanlines(a, ctx->stream));
+    if (!dst_on_device) {
+        HIPCHK(ctx, hipMemcpy2DAsync(dst, (size_t)dst_row_stride_bytes, stage, rowb, rowb, s.h, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return ARTGPU_OK;
+}
+
 int artgpu_saturation_vibrance(artgpu_ctx *ctx, artgpu_rgb *image, int saturation, int vibrance, const double ws[9])
 {
     if (!ctx) return ARTGPU_EINVAL;

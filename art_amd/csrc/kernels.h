@@ -142,6 +142,14 @@ hipError_t launch_ordered_sum(const float *x, long long n, float *out, hipStream
 struct MixArgs { float *dst[3]; size_t stride; int w, h; float m[9]; const float *lut[3]; };
 hipError_t launch_channel_mixer(const MixArgs &a, hipStream_t s);
 hipError_t launch_rgb_curves(const MixArgs &a, hipStream_t s);
+// N1: ARTOutputProfile fast path (iprgb2out.cc:152-172) and Imagefloat::getScanline (imagefloat.cc:125-170)
+struct OutArgs {
+    const float *src[3]; size_t src_stride; float *dst[3]; size_t dst_stride; int w, h;
+    float m[9]; int linear; const float *lut; int lutsz; int *unsupported;       // rgb2out
+    unsigned char *out; size_t out_stride_bytes; int bps, is_float;             // scanlines
+};
+hipError_t launch_rgb2out_matrix(const OutArgs &a, hipStream_t s);
+hipError_t launch_scanlines(const OutArgs &a, hipStream_t s);
 // saturationVibrance (ipsaturation.cc:43-83)
 struct SatArgs { float *dst[3]; size_t stride; int w, h; float saturation, vibrance; int vib; double ws1[3]; };
 hipError_t launch_saturation_vibrance(const SatArgs &a, hipStream_t s);

@@ -254,6 +254,82 @@ hipError_t launch_saturation_vibrance(const SatArgs &a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ARTOutputProfile::operator()(const Imagefloat*, Imagefloat*) (iprgb2out.cc:152-172): /65535, 3x3 float matrix (accumulated from 0
+// in column order like linalgebra.h:227-239), per channel the TRC from a LUT for values <= 1 (LUTf, clipped both ways) or, in
+// linear mode, the value itself; x65535.  A value that would need ARTOutputProfile::eval's lcms2 / libm curve is counted.
+__global__ void __launch_bounds__(256) rgb2out_matrix_kernel(OutArgs a)
+{
+    const float factor = (float)(a.lutsz - 1);
+    int bad = 0;
+    FOR_IMAGE_XY(y, x, a.w, a.h) {
+        const size_t si = (size_t)y * a.src_stride + x, di = (size_t)y * a.dst_stride + x;
+        const float r = a.src[0][si] / 65535.f, g = a.src[1][si] / 65535.f, b = a.src[2][si] / 65535.f;
+        float v[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float acc = 0.f;
+            acc += a.m[3 * i] * r; acc += a.m[3 * i + 1] * g; acc += a.m[3 * i + 2] * b;
+            if (a.lutsz > 0 && acc <= 1.f) acc = lutf(a.lut, a.lutsz, acc * factor);
+            else if (!a.linear) ++bad;
+            v[i] = acc;
+        }
+        a.dst[0][di] = v[0] * 65535.f; a.dst[1][di] = v[1] * 65535.f; a.dst[2][di] = v[2] * 65535.f;
+    }
+    if (bad) atomicAdd(a.unsupported, bad);
+}
+// DNG_FloatToHalf (halffloat.h:9-46)
+__device__ __forceinline__ unsigned short float_to_half_dng(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    const int sign = (u >> 16) & 0x8000;
+    int exponent = (int)((u >> 23) & 0xff) - (127 - 15);
+    int mantissa = u & 0x007fffff;
+    if (exponent <= 0) {
+        if (exponent < -10) return (unsigned short)sign;
+        mantissa = (mantissa | 0x00800000) >> (1 - exponent);
+        if (mantissa & 0x00001000) mantissa += 0x00002000;
+        return (unsigned short)(sign | (mantissa >> 13));
+    } else if (exponent == 0xff - (127 - 15)) {
+        return (unsigned short)(mantissa == 0 ? (sign | 0x7c00) : (sign | 0x7c00 | (mantissa >> 13)));
+    }
+    if (mantissa & 0x00001000) {
+        mantissa += 0x00002000;
+        if (mantissa & 0x00800000) { mantissa = 0; exponent += 1; }
+    }
+    if (exponent > 30) return (unsigned short)(sign | 0x7c00);
+    return (unsigned short)(sign | (exponent << 10) | (mantissa >> 13));
+}
+// Imagefloat::getScanline for every row (imagefloat.cc:125-170): interleaved RGB, 8/16-bit integer, half or float
+__global__ void __launch_bounds__(256) scanlines_kernel(OutArgs a)
+{
+    FOR_IMAGE_XY(y, x, a.w, a.h) {
+        const size_t si = (size_t)y * a.src_stride + x;
+        unsigned char *row = a.out + (size_t)y * a.out_stride_bytes;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = a.src[c][si];
+            if (a.is_float) {
+                if (a.bps == 32) reinterpret_cast<float *>(row)[3 * x + c] = v / 65535.f;
+                else reinterpret_cast<unsigned short *>(row)[3 * x + c] = float_to_half_dng(v / 65535.f);
+            } else {
+                const unsigned short q = (unsigned short)clipf(v);                       // CLIP, then the implicit float -> uint16 conversion
+                if (a.bps == 16) reinterpret_cast<unsigned short *>(row)[3 * x + c] = q;
+                else row[3 * x + c] = (unsigned char)((((int)q + 128) - (((int)q + 128) >> 8)) >> 8);     // uint16ToUint8Rounded
+            }
+        }
+    }
+}
+hipError_t launch_rgb2out_matrix(const OutArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(rgb2out_matrix_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_scanlines(const OutArgs &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(scanlines_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 static unsigned mix_grid(const MixArgs &a) { long long g = ((long long)a.w * a.h + 255) / 256; return (unsigned)(g < 16384 ? (g ? g : 1) : 16384); }
 hipError_t launch_channel_mixer(const MixArgs &a, hipStream_t s)
 {

@@ -287,6 +287,21 @@ int artgpu_denoise_compute_params(artgpu_ctx *ctx, const artgpu_rgb *planes, int
                                   const double cam_to_work[9], const double ws[9], double chrominance_auto_factor,
                                   artgpu_denoise_info_store *store, artgpu_denoise_params *dn);
 
+/* SURVEY section 8f N1, the parts of the output stage that are plain arithmetic (everything lcms2 evaluates stays on the host):
+ * artgpu_rgb2out_matrix : ARTOutputProfile::operator()(const Imagefloat*, Imagefloat*), the matrix + TRC fast path of
+ *                         ImProcFunctions::rgb2out for matrix output profiles (iprgb2out.cc:94-172,452-461).  matrix = the host's
+ *                         `matrix_` (inverse profile matrix x working space, L119); trc_linear != 0 for MODE_LINEAR; otherwise
+ *                         lut/lutsz = the host's `lut_` (compute_lut, L207-215; preview pipelines use 65536 / 1024 / 256 entries).
+ *                         Values > 1 in a non-linear mode need ARTOutputProfile::eval (lcms2 / libm): the call then fails with
+ *                         ARTGPU_EUNSUPPORTED after counting them (dst is complete for all other pixels).
+ * artgpu_get_scanlines  : Imagefloat::getScanline for all rows (imagefloat.cc:125-170): interleaved RGB as the TIFF/PNG/JPEG
+ *                         writers consume it; (bps, is_float) = (8,0), (16,0), (16,1: half, DNG_FloatToHalf), (32,1).  Moves 3-6 B/px
+ *                         to the host instead of 12. */
+int artgpu_rgb2out_matrix(artgpu_ctx *ctx, const artgpu_rgb *src, artgpu_rgb *dst, const float matrix[9], int trc_linear,
+                          const float *lut, int lutsz);
+int artgpu_get_scanlines(artgpu_ctx *ctx, const artgpu_rgb *img, int bps, int is_float, void *dst, int64_t dst_row_stride_bytes,
+                         int dst_on_device);
+
 /* acc = 0; for (i = 0; i < n; ++i) acc += x[i];  in fp32 -- the order-defined sum the reference uses for its image statistics
  * (ShrinkAll_info, FTblockDN.cc:1237-1290), evaluated on the device by an exact parallel scan (values >= 0 take the fast path;
  * anything else is still exact, one value at a time).  Exported because it is the building block of

@@ -72,6 +72,8 @@ void oracle_tone_curve_std(float *const img[3], size_t s, int w, int h, const fl
 void oracle_scale_colors(const void *src, int src_u16, int w, int h, const int cfa36[36], int bayer, const float cblacksom[4],
                          const float scale_mul[4], float *dst, float chmax[4]);
 void oracle_channel_mixer(float *const img[3], size_t s, int w, int h, const float m[9]);
+int oracle_rgb2out_matrix(const float *const src[3], float *const dst[3], size_t s, int w, int h, const float m[9], int linear, const float *lut, int lutsz);
+void oracle_get_scanlines(const float *const img[3], size_t s, int w, int h, int bps, int is_float, void *out);
 void oracle_saturation_vibrance(float *const img[3], size_t s, int w, int h, int saturation_p, int vibrance_p, const double ws[9]);
 void oracle_rgb_curves(float *const img[3], size_t s, int w, int h, const float *const luts[3]);
 /* AUTOMATIC chrominance estimation (oracle/dninfo.c) */

@@ -251,3 +251,68 @@ void oracle_saturation_vibrance(float *const img[3], size_t s, int w, int h, int
             img[2][o] = rt_maxf(l + saturation * bl, noise);
         }
 }
+
+/* ARTOutputProfile::operator()(const Imagefloat*, Imagefloat*) (iprgb2out.cc:152-172): matrix (float, accumulated from 0 in column
+ * order: linalgebra.h:227-239) + TRC from a LUT for values <= 1; linear mode passes values through.  Returns the number of channel
+ * values that would need ARTOutputProfile::eval (lcms2 / libm); they are left as the matrix output. */
+int oracle_rgb2out_matrix(const float *const src[3], float *const dst[3], size_t s, int w, int h, const float m[9], int linear,
+                          const float *lut, int lutsz)
+{
+    const float factor = (float)(lutsz - 1);
+    int bad = 0;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const size_t o = (size_t)y * s + x;
+            const float rgb[3] = {src[0][o] / 65535.f, src[1][o] / 65535.f, src[2][o] / 65535.f};
+            for (int i = 0; i < 3; ++i) {
+                float acc = 0;
+                for (int k = 0; k < 3; ++k) acc += m[3 * i + k] * rgb[k];
+                if (lutsz > 0 && acc <= 1.f) acc = oracle_lutf(lut, lutsz, acc * factor);
+                else if (!linear) ++bad;
+                dst[i][o] = acc * 65535.f;
+            }
+        }
+    return bad;
+}
+/* DNG_FloatToHalf (halffloat.h:9-46) */
+static unsigned short float_to_half_dng(float f)
+{
+    union { float f; uint32_t i; } tmp;
+    tmp.f = f;
+    int32_t sign = (tmp.i >> 16) & 0x00008000;
+    int32_t exponent = ((tmp.i >> 23) & 0x000000ff) - (127 - 15);
+    int32_t mantissa = tmp.i & 0x007fffff;
+    if (exponent <= 0) {
+        if (exponent < -10) return (unsigned short)sign;
+        mantissa = (mantissa | 0x00800000) >> (1 - exponent);
+        if (mantissa & 0x00001000) mantissa += 0x00002000;
+        return (unsigned short)(sign | (mantissa >> 13));
+    } else if (exponent == 0xff - (127 - 15)) {
+        if (mantissa == 0) return (unsigned short)(sign | 0x7c00);
+        return (unsigned short)(sign | 0x7c00 | (mantissa >> 13));
+    }
+    if (mantissa & 0x00001000) {
+        mantissa += 0x00002000;
+        if (mantissa & 0x00800000) { mantissa = 0; exponent += 1; }
+    }
+    if (exponent > 30) return (unsigned short)(sign | 0x7c00);
+    return (unsigned short)(sign | (exponent << 10) | (mantissa >> 13));
+}
+/* Imagefloat::getScanline for every row (imagefloat.cc:125-170); out: h rows of w*3 samples */
+void oracle_get_scanlines(const float *const img[3], size_t s, int w, int h, int bps, int is_float, void *out)
+{
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            for (int c = 0; c < 3; ++c) {
+                const float v = img[c][(size_t)y * s + x];
+                const size_t k = ((size_t)y * w + x) * 3 + c;
+                if (is_float) {
+                    if (bps == 32) ((float *)out)[k] = v / 65535.f;
+                    else ((unsigned short *)out)[k] = float_to_half_dng(v / 65535.f);
+                } else {
+                    const unsigned short q = (unsigned short)rt_maxf(0.f, rt_minf(v, 65535.f));
+                    if (bps == 16) ((unsigned short *)out)[k] = q;
+                    else ((unsigned char *)out)[k] = (unsigned char)(((q + 128) - ((q + 128) >> 8)) >> 8);
+                }
+            }
+}

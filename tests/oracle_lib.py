@@ -428,3 +428,23 @@ def saturation_vibrance(img, saturation, vibrance, ws=None):
     wsd = (C.c_double * 9)(*[float(v) for v in np.asarray(REC2020_WS_D if ws is None else ws, dtype=np.float64).reshape(9)])
     lib().oracle_saturation_vibrance(_p3(img), C.c_size_t(w), w, h, int(saturation), int(vibrance), wsd)
     return img
+
+
+def rgb2out_matrix(img, m, linear, lut=None):
+    img = [np.ascontiguousarray(p, dtype=np.float32) for p in img]
+    h, w = img[0].shape
+    out = _planes(h, w)
+    la = None if lut is None else np.ascontiguousarray(lut, dtype=np.float32)
+    L = lib(); L.oracle_rgb2out_matrix.restype = C.c_int
+    bad = L.oracle_rgb2out_matrix(_p3(img), _p3(out), C.c_size_t(w), w, h, (C.c_float * 9)(*[float(v) for v in np.asarray(m, np.float32).reshape(9)]),
+                                  1 if linear else 0, None if la is None else _ptr(la), 0 if la is None else la.size)
+    return out, bad
+
+
+def get_scanlines(img, bps, is_float=False):
+    img = [np.ascontiguousarray(p, dtype=np.float32) for p in img]
+    h, w = img[0].shape
+    dt = np.float32 if (is_float and bps == 32) else (np.uint8 if bps == 8 else np.uint16)
+    out = np.zeros((h, w, 3), dt)
+    lib().oracle_get_scanlines(_p3(img), C.c_size_t(w), w, h, bps, 1 if is_float else 0, out.ctypes.data_as(C.c_void_p))
+    return out

@@ -147,3 +147,43 @@ def test_saturation_vibrance_bit_exact(gpu_ctx, sat, vib):
         assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
     if sat or vib:
         assert not np.array_equal(got[0], img[0])
+
+
+def test_rgb2out_fast_path_and_scanlines_bit_exact(gpu_ctx):
+    """N1: ARTOutputProfile's matrix + TRC fast path (iprgb2out.cc:152-172) and Imagefloat::getScanline (imagefloat.cc:125-170)."""
+    from art_amd import capi
+    import oracle_lib as O
+    rng = np.random.default_rng(21)
+    h, w = 97, 211
+    img = [rng.uniform(-200.0, 60000.0, (h, w)).astype(np.float32) for _ in range(3)]
+    m = np.array([[1.66, -0.59, -0.07], [-0.12, 1.13, -0.01], [-0.02, -0.10, 1.12]], np.float32)
+    # linear profile: exact for every value
+    got = [np.zeros((h, w), np.float32) for _ in range(3)]
+    gpu_ctx.rgb2out_matrix(capi.host_rgb(img), capi.host_rgb(got), m, True)
+    ref, bad = O.rgb2out_matrix(img, m, True)
+    assert bad == 0
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+    # TRC through a 1024-entry LUT (the preview pipeline's size); dim image so that nothing exceeds 1
+    x = np.arange(1024, dtype=np.float64) / 1023.0
+    lut = np.where(x <= 0.0031308, 12.92 * x, 1.055 * x ** (1 / 2.4) - 0.055).astype(np.float32)
+    dim = [(p * 0.5).astype(np.float32) for p in img]
+    got = [np.zeros((h, w), np.float32) for _ in range(3)]
+    gpu_ctx.rgb2out_matrix(capi.host_rgb(dim), capi.host_rgb(got), m, False, lut)
+    ref, bad = O.rgb2out_matrix(dim, m, False, lut)
+    assert bad == 0
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+    # values above 1 with a non-linear TRC need lcms2 on the host: loud failure, not a silent approximation
+    with pytest.raises(capi.ArtGpuError):
+        gpu_ctx.rgb2out_matrix(capi.host_rgb([p * 3 for p in img]), capi.host_rgb(got), m, False, lut)
+    # scanlines in all four sample formats
+    test = [p.copy() for p in img]
+    test[0][0, :8] = [np.nan, -1.0, 0.49, 0.5, 65534.6, 65535.0, 70000.0, 1e-3]
+    for bps, fl in ((8, False), (16, False), (16, True), (32, True)):
+        a = gpu_ctx.get_scanlines(capi.host_rgb(test), bps, fl)
+        b = O.get_scanlines(test, bps, fl)
+        if a.dtype == np.float32:
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        else:
+            assert np.array_equal(a, b)
