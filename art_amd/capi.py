@@ -135,6 +135,7 @@ def _load():
     lib.artgpu_set_batch_lanes.argtypes = [C.c_void_p, C.c_int]
     lib.artgpu_rgb2out_matrix.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(RGB), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]
     lib.artgpu_get_scanlines.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int]
+    lib.artgpu_guided_filter.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(Plane), C.POINTER(Plane), C.c_int, C.c_float, C.c_int]
     lib.artgpu_channel_mixer.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float)]
     lib.artgpu_rgb_curves.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_pipeline_run.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
@@ -162,7 +163,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_rgb2out_matrix", "artgpu_get_scanlines"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -312,6 +313,9 @@ class Context:
         out = np.zeros((image.r.h, image.r.w, 3), dt)
         self._chk(LIB.artgpu_get_scanlines(self._h, C.byref(image), bps, 1 if is_float else 0, out.ctypes.data, out.strides[0], 0))
         return out
+
+    def guided_filter(self, guide: Plane, src: Plane, dst: Plane, r: int, epsilon: float, subsampling: int = 0):
+        self._chk(LIB.artgpu_guided_filter(self._h, C.byref(guide), C.byref(src), C.byref(dst), int(r), float(epsilon), int(subsampling)))
 
     def channel_mixer(self, image: RGB, m):
         self._chk(LIB.artgpu_channel_mixer(self._h, C.byref(image), (C.c_float * 9)(*[float(v) for v in np.asarray(m, np.float32).reshape(9)])))

@@ -1022,6 +1022,51 @@ int artgpu_denoise_guided_smoothing(artgpu_ctx *ctx, artgpu_rgb *img, const doub
     return unbind_rgb(ctx, img, &d);
 }
 
+int artgpu_guided_filter(artgpu_ctx *ctx, const artgpu_plane *guide, const artgpu_plane *src, artgpu_plane *dst, int r, float epsilon, int subsampling)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!guide || !src || !dst || !plane_ok(guide) || !plane_ok(src) || !plane_ok(dst)) return fail(ctx, ARTGPU_EINVAL, "guided_filter: bad plane");
+    const int W = src->w, H = src->h;
+    if (guide->w != W || guide->h != H || dst->w != W || dst->h != H || r < 0) return fail(ctx, ARTGPU_EINVAL, "guided_filter: size mismatch / negative radius");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int sub = subsampling > 0 ? subsampling : gf_subsampling(W, H, r);
+    GuidedArgs g = {};
+    g.W = W; g.H = H; g.w = W / sub; g.h = H / sub; g.epsilon = epsilon; g.nch = 1;
+    if (g.w < 1 || g.h < 1) return fail(ctx, ARTGPU_EINVAL, "guided_filter: subsampling %d leaves no pixels", sub);
+    const size_t n = (size_t)W * H, nl = (size_t)g.w * g.h;
+    float *big, *low, *tmp;
+    int rc;
+    if ((rc = pool_get(ctx, P_SF, 3 * n * 4, &big)) || (rc = pool_get(ctx, P_TMP, 8 * nl * 4, &low)) || (rc = pool_get(ctx, P_LIN, 8 * nl * 4, &tmp))) return rc;
+    g.guide = big; g.chan[0] = big + n; g.q = big + 2 * n; g.q_stride = W;
+    const size_t rowb = (size_t)W * 4;
+    HIPCHK(ctx, hipMemcpy2DAsync(g.guide, rowb, guide->p, (size_t)guide->row_stride_bytes, rowb, H, guide->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpy2DAsync(g.chan[0], rowb, src->p, (size_t)src->row_stride_bytes, rowb, H, src->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    for (int k = 0; k < 8; ++k) g.low[k] = low + k * nl;
+    HIPCHK(ctx, launch_gf_subsample(g, ctx->stream));
+    const float r1 = float(r) / sub;
+    int rad = (int)r1;
+    { const int hi = ((g.w < g.h ? g.w : g.h) - 1) / 2 - 1; rad = rad < hi ? rad : hi; rad = rad > 0 ? rad : 0; }     // f_mean's LIM (L160-164)
+    BlurArgs bl = {};
+    bl.n = nl; bl.w = g.w; bl.h = g.h; bl.steady_div = 1; bl.plain = 1;
+    for (int l = 0; l < 10; ++l) bl.rad[l] = rad;
+    auto blur_plane = [&](float *plane) -> int {
+        if (rad == 0) return ARTGPU_OK;
+        bl.src = plane; bl.dst = tmp;
+        HIPCHK(ctx, launch_hblur(bl, 1, ctx->stream));
+        bl.src = tmp; bl.dst = plane; bl.sfave = nullptr; bl.coef = nullptr;
+        HIPCHK(ctx, launch_vblur_combine(bl, 1, ctx->stream));
+        return ARTGPU_OK;
+    };
+    // low[0] I1 -> meanI, low[1] I1*I1 -> corrI, low[2] p1 -> meanp, low[5] I1*p1 -> corrIp
+    if ((rc = blur_plane(g.low[0])) || (rc = blur_plane(g.low[1])) || (rc = blur_plane(g.low[2])) || (rc = blur_plane(g.low[5]))) return rc;
+    HIPCHK(ctx, launch_gf_ab(g, ctx->stream));
+    if ((rc = blur_plane(g.low[2])) || (rc = blur_plane(g.low[5]))) return rc;       // mean a, mean b
+    HIPCHK(ctx, launch_gf_finish_plain(g, ctx->stream));
+    HIPCHK(ctx, hipMemcpy2DAsync(dst->p, (size_t)dst->row_stride_bytes, g.q, rowb, rowb, H, dst->on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    if (!dst->on_device) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // gaussian blur, detail mask, NL-means
 // ---------------------------------------------------------------------------------------------

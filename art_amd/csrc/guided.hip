@@ -63,8 +63,10 @@ __global__ void __launch_bounds__(256) gf_subsample_kernel(GuidedArgs a)
         const float I1 = same ? a.guide[t] : bilinear(a.guide, a.W, a.H, fx, fy);
         a.low[0][t] = I1;
         a.low[1][t] = I1 * I1;
+        const int nch = a.nch == 1 ? 1 : 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+            if (c >= nch) break;
             const float p1 = same ? a.chan[c][t] : bilinear(a.chan[c], a.W, a.H, fx, fy);
             a.low[2 + c][t] = p1;
             a.low[5 + c][t] = I1 * p1;
@@ -80,8 +82,10 @@ __global__ void __launch_bounds__(256) gf_ab_kernel(GuidedArgs a)
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
         const float meanI = a.low[0][t], corrI = a.low[1][t];
         const float varI = corrI - (meanI * meanI);
+        const int nch = a.nch == 1 ? 1 : 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
+            if (c >= nch) break;
             const float meanp = a.low[2 + c][t], corrIp = a.low[5 + c][t];
             const float covIp = corrIp - (meanI * meanp);
             const float av = covIp / (varI + a.epsilon);
@@ -126,10 +130,22 @@ __global__ void __launch_bounds__(256) gf_finish_kernel(GuidedArgs a)
     }
 }
 
+// 4'. plain guidedFilter: q = bilinear(mean a) * I + bilinear(mean b) (guidedfilter.cc:225-240); q may be the src or guide plane
+__global__ void __launch_bounds__(256) gf_finish_plain_kernel(GuidedArgs a)
+{
+    const float col_scale = (float)a.w / (float)a.W, row_scale = (float)a.h / (float)a.H;
+    FOR_IMAGE_XY(y, x, a.W, a.H) {
+        const float ymrs = y * row_scale;
+        const float I = a.guide[(size_t)y * a.W + x];
+        a.q[(size_t)y * a.q_stride + x] = bilinear(a.low[2], a.w, a.h, x * col_scale, ymrs) * I + bilinear(a.low[5], a.w, a.h, x * col_scale, ymrs);
+    }
+}
+
 static int fgrid(long long n) { long long g = (n + 255) / 256; return (int)(g < 16384 ? g : 16384); }
 hipError_t launch_gf_prepare(const GuidedArgs &a, hipStream_t s) { hipLaunchKernelGGL(gf_prepare_kernel, dim3(fgrid((long long)a.W * a.H)), dim3(256), 0, s, a); return hipGetLastError(); }
 hipError_t launch_gf_subsample(const GuidedArgs &a, hipStream_t s) { hipLaunchKernelGGL(gf_subsample_kernel, dim3(fgrid((long long)a.w * a.h)), dim3(256), 0, s, a); return hipGetLastError(); }
 hipError_t launch_gf_ab(const GuidedArgs &a, hipStream_t s) { hipLaunchKernelGGL(gf_ab_kernel, dim3(fgrid((long long)a.w * a.h)), dim3(256), 0, s, a); return hipGetLastError(); }
+hipError_t launch_gf_finish_plain(const GuidedArgs &a, hipStream_t s) { hipLaunchKernelGGL(gf_finish_plain_kernel, image_grid(a.W, a.H), dim3(256), 0, s, a); return hipGetLastError(); }
 hipError_t launch_gf_finish(const GuidedArgs &a, hipStream_t s) { hipLaunchKernelGGL(gf_finish_kernel, dim3(fgrid((long long)a.W * a.H)), dim3(256), 0, s, a); return hipGetLastError(); }
 
 } // namespace artgpu

@@ -280,11 +280,14 @@ struct GuidedArgs {
     float *low[8];         // w*h planes: I1/meanI, corrI, p1/meanp/a[3], corrIp/b[3]
     double ws1[3];         // working-space matrix row 1 (double, TMatrix)
     float epsilon;
+    int nch;               // 0 / 3: the three log channels of the smoothing tool; 1: plain single-channel guidedFilter (chan[0] = src)
+    float *q; size_t q_stride;   // plain mode: destination plane
 };
 hipError_t launch_gf_prepare(const GuidedArgs &a, hipStream_t s);
 hipError_t launch_gf_subsample(const GuidedArgs &a, hipStream_t s);
 hipError_t launch_gf_ab(const GuidedArgs &a, hipStream_t s);
 hipError_t launch_gf_finish(const GuidedArgs &a, hipStream_t s);
+hipError_t launch_gf_finish_plain(const GuidedArgs &a, hipStream_t s);   // q = bilinear(mean a) * I + bilinear(mean b) (guidedfilter.cc:225-240)
 
 // ---- NL-means stage (nlmeans.hip) ----
 struct MaskArgs {

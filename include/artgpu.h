@@ -287,6 +287,13 @@ int artgpu_denoise_compute_params(artgpu_ctx *ctx, const artgpu_rgb *planes, int
                                   const double cam_to_work[9], const double ws[9], double chrominance_auto_factor,
                                   artgpu_denoise_info_store *store, artgpu_denoise_params *dn);
 
+/* rtengine::guidedFilter(guide, src, dst, r, epsilon, multithread, subsampling) (guidedfilter.cc:78-241), the single-channel fast guided
+ * filter behind several tools (hslEqualizer, guided smoothing, dehaze, local contrast masks): bilinear subsample by
+ * calculate_subsampling (subsampling <= 0: L58-75), four box means, a / b, their means, bilinear upsample.  guide, src and dst are
+ * planes of one size; dst may be src or guide.  The denoise tool's three-channel log variant is artgpu_denoise_guided_smoothing. */
+int artgpu_guided_filter(artgpu_ctx *ctx, const artgpu_plane *guide, const artgpu_plane *src, artgpu_plane *dst, int r, float epsilon,
+                         int subsampling);
+
 /* SURVEY section 8f N1, the parts of the output stage that are plain arithmetic (everything lcms2 evaluates stays on the host):
  * artgpu_rgb2out_matrix : ARTOutputProfile::operator()(const Imagefloat*, Imagefloat*), the matrix + TRC fast path of
  *                         ImProcFunctions::rgb2out for matrix output profiles (iprgb2out.cc:94-172,452-461).  matrix = the host's

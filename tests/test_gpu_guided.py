@@ -36,3 +36,23 @@ def test_radius_zero_is_identity(gpu_ctx):
     got = [p.copy() for p in img]
     gpu_ctx.denoise_guided_smoothing(capi.host_rgb(got), O.REC2020_WS_D, 0, 1.0)
     assert _same(got, img) == [0, 0, 0]
+
+
+@pytest.mark.parametrize("w,h,r,eps", [(300, 200, 3, 0.001), (700, 500, 4, 0.001), (1203, 801, 25, 0.0001), (911, 640, 7, 0.01), (640, 912, 1, 0.001), (801, 603, 10, 0.001)])
+def test_plain_guided_filter_bit_exact(gpu_ctx, w, h, r, eps):
+    """rtengine::guidedFilter (guidedfilter.cc:78-241), single channel, automatic subsampling (1, 4, 5, 3, 1, 5 here)."""
+    from art_amd import capi
+    rng = np.random.default_rng(w + r)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    guide = (0.4 + 0.3 * np.sin(0.02 * x) * np.cos(0.017 * y) + 0.15 * ((x.astype(np.int32) // 40 + y.astype(np.int32) // 40) % 2)).astype(np.float32)
+    src = (guide * 0.8 + rng.normal(0, 0.05, (h, w))).astype(np.float32)
+    ref = O.guided_filter(guide, src, r, eps)
+    got = np.zeros_like(src)
+    gpu_ctx.guided_filter(capi.host_plane(guide), capi.host_plane(src), capi.host_plane(got), r, eps)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # in place on the source plane, as hslEqualizer calls it (mask -> mask)
+    inplace = src.copy()
+    pl = capi.host_plane(inplace)
+    gpu_ctx.guided_filter(capi.host_plane(guide), pl, pl, r, eps)
+    assert np.array_equal(inplace.view(np.uint32), ref.view(np.uint32))
+    assert np.abs(ref - src).mean() > 1e-3
