@@ -136,6 +136,8 @@ def _load():
     lib.artgpu_rgb2out_matrix.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(RGB), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]
     lib.artgpu_get_scanlines.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int]
     lib.artgpu_guided_filter.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(Plane), C.POINTER(Plane), C.c_int, C.c_float, C.c_int]
+    lib.artgpu_hsl_equalizer.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int,
+                                         C.c_int, C.POINTER(C.c_double), C.c_double, C.c_int]
     lib.artgpu_channel_mixer.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float)]
     lib.artgpu_rgb_curves.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_pipeline_run.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
@@ -163,7 +165,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter", "artgpu_hsl_equalizer"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -316,6 +318,16 @@ class Context:
 
     def guided_filter(self, guide: Plane, src: Plane, dst: Plane, r: int, epsilon: float, subsampling: int = 0):
         self._chk(LIB.artgpu_guided_filter(self._h, C.byref(guide), C.byref(src), C.byref(dst), int(r), float(epsilon), int(subsampling)))
+
+    def hsl_equalizer(self, image: RGB, hcurve, scurve, lcurve, smoothing: int, ws, scale: float = 1.0, to_rgb: bool = True):
+        def arr(c):
+            if c is None:
+                return None, 0
+            a = (C.c_double * len(c))(*[float(v) for v in c])
+            return a, len(c)
+        (h, nh), (s, ns), (l, nl) = arr(hcurve), arr(scurve), arr(lcurve)
+        self._chk(LIB.artgpu_hsl_equalizer(self._h, C.byref(image), h, nh, s, ns, l, nl, int(smoothing),
+                                           (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)]), float(scale), 1 if to_rgb else 0))
 
     def channel_mixer(self, image: RGB, m):
         self._chk(LIB.artgpu_channel_mixer(self._h, C.byref(image), (C.c_float * 9)(*[float(v) for v in np.asarray(m, np.float32).reshape(9)])))

@@ -1046,6 +1046,7 @@ int artgpu_guided_filter(artgpu_ctx *ctx, const artgpu_plane *guide, const artgp
     const float r1 = float(r) / sub;
     int rad = (int)r1;
     { const int hi = ((g.w < g.h ? g.w : g.h) - 1) / 2 - 1; rad = rad < hi ? rad : hi; rad = rad > 0 ? rad : 0; }     // f_mean's LIM (L160-164)
+    if (rad > 63) return fail(ctx, ARTGPU_EUNSUPPORTED, "guided_filter: box radius %d (r / subsampling) is above the 63 the blur kernels hold in LDS", rad);
     BlurArgs bl = {};
     bl.n = nl; bl.w = g.w; bl.h = g.h; bl.steady_div = 1; bl.plain = 1;
     for (int l = 0; l < 10; ++l) bl.rad[l] = rad;
@@ -1064,6 +1065,68 @@ int artgpu_guided_filter(artgpu_ctx *ctx, const artgpu_plane *guide, const artgp
     HIPCHK(ctx, launch_gf_finish_plain(g, ctx->stream));
     HIPCHK(ctx, hipMemcpy2DAsync(dst->p, (size_t)dst->row_stride_bytes, g.q, rowb, rowb, H, dst->on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     if (!dst->on_device) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
+int artgpu_hsl_equalizer(artgpu_ctx *ctx, artgpu_rgb *img, const double *hcurve, int nh, const double *scurve, int ns,
+                         const double *lcurve, int nl, int smoothing, const double ws[9], double scale, int to_rgb)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!img || !ws || !(scale >= 1.0)) return fail(ctx, ARTGPU_EINVAL, "hsl_equalizer: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // the four polylines: saturation, luminance, hue (periodic, 1000 / scale points) and the fixed coefficient curve of L125-129
+    static const double coeff_pts[9] = {1 /* FCT_MinMaxCPoints */, 0.25, 0.0, 0.5, 0.18, 1, 1, 0, 0.35};
+    const double *pts[4] = {scurve, lcurve, hcurve, coeff_pts};
+    const int npts[4] = {ns, nl, nh, 9};
+    std::vector<double> px[4], py[4], ps[4];
+    bool active[4];
+    const int ppn = (int)(1000 / scale);
+    for (int k = 0; k < 4; ++k) active[k] = pts[k] && flat_curve_polyline(pts[k], npts[k], true, k == 3 ? 1000 : ppn, 0.5, px[k], py[k], ps[k]);
+    if (!active[3]) return fail(ctx, ARTGPU_EHIP, "hsl_equalizer: internal curve");
+    DevRGB d;
+    int rc = bind_rgb(ctx, img, 4, true, &d, "hsl_equalizer");
+    if (rc) return rc;
+    size_t total = 0;
+    for (int k = 0; k < 4; ++k) if (active[k]) total += px[k].size() * 2 + ps[k].size();
+    float *tabf, *mask;
+    if ((rc = pool_get(ctx, P_PIPE_G, total * 8 + 64, &tabf)) || (rc = pool_get(ctx, P_DMASK, (size_t)d.w * d.h * 4, &mask))) return rc;
+    std::vector<double> host(total);
+    HslArgs a = {};
+    {
+        size_t off = 0;
+        double *dev = reinterpret_cast<double *>(tabf);
+        for (int k = 0; k < 4; ++k) {
+            if (!active[k]) continue;
+            const size_t n = px[k].size();
+            std::copy(px[k].begin(), px[k].end(), host.begin() + off); a.curve[k].x = dev + off; off += n;
+            std::copy(py[k].begin(), py[k].end(), host.begin() + off); a.curve[k].y = dev + off; off += n;
+            std::copy(ps[k].begin(), ps[k].end(), host.begin() + off); a.curve[k].slope = dev + off; off += ps[k].size();
+            a.curve[k].n = (int)n;
+        }
+        HIPCHK(ctx, hipMemcpyAsync(dev, host.data(), total * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    for (int k = 0; k < 3; ++k) { a.img[k] = d.p[k]; a.ws1[k] = (float)ws[3 + k]; }
+    a.stride = d.stride; a.w = d.w; a.h = d.h; a.mask = mask; a.to_rgb = to_rgb ? 1 : 0;
+    HIPCHK(ctx, launch_hsl_prepare(a, ctx->stream));
+    const float sm = smoothing / 10.f;
+    const float smooth = std::pow(10.f, sm < 0.f ? 0.f : (sm > 1.f ? 1.f : sm)) - 1.f;            // L93
+    const int radius_small = (int)(4 / scale * smooth + 0.5), radius_large = (int)(25 / scale * smooth + 0.5);
+    artgpu_plane guide = {d.p[1], d.w, d.h, (int64_t)d.stride * 4, 1};                             // Y
+    artgpu_plane mpl = {mask, d.w, d.h, (int64_t)d.w * 4, 1};
+    const int order[3] = {0, 1, 2};                 // saturation, luminance, hue: the reference's order
+    for (int k : order) {
+        if (!active[k]) continue;
+        a.which = k;
+        HIPCHK(ctx, launch_hsl_mask(a, ctx->stream));
+        const int radius = k == 1 ? radius_large : radius_small;
+        const float eps = k == 1 ? 0.0001f : 0.001f;
+        if (radius > 0 && (rc = artgpu_guided_filter(ctx, &guide, &mpl, &mpl, radius, eps, 0))) return rc;
+        HIPCHK(ctx, launch_hsl_apply(a, ctx->stream));
+    }
+    HIPCHK(ctx, launch_hsl_finish(a, ctx->stream));
+    rc = unbind_rgb(ctx, img, &d);
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host vector with the polylines goes out of scope
     return ARTGPU_OK;
 }
 

@@ -314,10 +314,13 @@ __global__ void __launch_bounds__(256) bishrink_AB_kernel(ShrinkArgs a)
 // ---------------------------------------------------------------- horizontal box blur (boxblur.h:565-600)
 // 16 rows per wave (not 64): the running sum is serial along the row, so rows are the only parallelism; 16-row groups give
 // 10 waves per CU at 45 MP instead of 2.5 and keep ~24 loads per lane in flight (the stage is HBM-latency bound otherwise)
-constexpr int HB_ROWS = 16, HB_COLS = 64, HB_MAXR = 15;
-constexpr int HB_TW = HB_COLS + 2 * HB_MAXR + 2; // source window held in LDS
+// HB_MAXR: 15 for the wavelet-level radii (window of two 64-column groups); 63 for the large radii of rtengine::guidedFilter
+// callers (three groups).  Same arithmetic, only the LDS window differs.
+constexpr int HB_ROWS = 16, HB_COLS = 64;
+template <int HB_MAXR>
 __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
 {
+    constexpr int HB_TW = HB_COLS + 2 * HB_MAXR + 2; // source window held in LDS
     __shared__ float sT[HB_ROWS][HB_TW + 1];
     __shared__ float oT[HB_ROWS][HB_COLS + 1];
     const int sub = blockIdx.y, level = a.level0 + sub / 3;
@@ -336,21 +339,24 @@ __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
         // window columns [c0 - rad - 1, c0 + HB_COLS + rad): coalesced row segments -> LDS,
         // 8 rows (16 independent loads) in flight per lane before the LDS stores
         const int wc0 = c0 - rad - 1, wn = HB_COLS + 2 * rad + 1;
-        const int colA = wc0 + lane, colB = wc0 + lane + 64;
+        const int colA = wc0 + lane, colB = wc0 + lane + 64, colC = wc0 + lane + 128;
         const bool okA = colA >= 0 && colA < W, okB = (lane + 64 < wn) && colB >= 0 && colB < W;
+        const bool okC = HB_MAXR > 31 && (lane + 128 < wn) && colC >= 0 && colC < W;
         for (int k0 = 0; k0 < HB_ROWS; k0 += 8) {
-            float va[8], vb[8];
+            float va[8], vb[8], vc[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int k = k0 + i;
                 const size_t ro = (size_t)(r0 + k) * W;
                 va[i] = (okA && k < nrows) ? src[ro + colA] : 0.f;
                 vb[i] = (okB && k < nrows) ? src[ro + colB] : 0.f;
+                if constexpr (HB_MAXR > 31) vc[i] = (okC && k < nrows) ? src[ro + colC] : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 sT[k0 + i][lane] = va[i];
                 if (lane + 64 < wn) sT[k0 + i][lane + 64] = vb[i];
+                if constexpr (HB_MAXR > 31) { if (lane + 128 < wn) sT[k0 + i][lane + 128] = vc[i]; }
             }
         }
         __syncthreads();
@@ -532,7 +538,11 @@ hipError_t launch_bishrink_AB(const ShrinkArgs &a, int nsub, hipStream_t s)
 }
 hipError_t launch_hblur(const BlurArgs &a, int nsub, hipStream_t s)
 {
-    hipLaunchKernelGGL(hblur_kernel, dim3((a.h + HB_ROWS - 1) / HB_ROWS, nsub), dim3(64), 0, s, a);
+    int maxr = 0;
+    for (int l = 0; l < 10; ++l) maxr = a.rad[l] > maxr ? a.rad[l] : maxr;
+    if (maxr > 63) return hipErrorInvalidValue;
+    if (maxr <= 15) hipLaunchKernelGGL(hblur_kernel<15>, dim3((a.h + HB_ROWS - 1) / HB_ROWS, nsub), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(hblur_kernel<63>, dim3((a.h + HB_ROWS - 1) / HB_ROWS, nsub), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_vblur_combine(const BlurArgs &a, int nsub, hipStream_t s)

@@ -110,6 +110,24 @@ bool build_polyline(const std::vector<Knot> &k, bool periodic, int ppn, Polyline
 
 } // namespace
 
+// FlatCurve(points, periodic, ppn): the polyline FlatCurve::getVal works on.  Returns false for an identity / empty curve.
+bool flat_curve_polyline(const double *pts, int npts, bool periodic, int ppn, double identity, std::vector<double> &x, std::vector<double> &y, std::vector<double> &slope)
+{
+    if (!(npts > 4 && (int)pts[0] == 1 /* FCT_MinMaxCPoints */)) return false;
+    const int n = (npts - 1) / 4;
+    std::vector<Knot> k;
+    for (int i = 0; i < n; ++i) k.push_back({pts[1 + 4 * i], pts[2 + 4 * i], pts[3 + 4 * i], pts[4 + 4 * i]});
+    if (periodic) k.push_back({pts[1] + 1.0, pts[2], pts[3], pts[4]});
+    bool identity_curve = true;
+    for (const Knot &q : k)
+        if (q.y >= identity + 1.e-7 || q.y <= identity - 1.e-7) { identity_curve = false; break; }
+    if (identity_curve || n <= (periodic ? 1 : 0)) return false;
+    Polyline poly;
+    if (!build_polyline(k, periodic, ppn > 65500 ? 65500 : ppn, poly)) return false;
+    x = poly.x; y = poly.y; slope = poly.slope;
+    return true;
+}
+
 // FlatCurve(points, periodic, ppn) + setIdentityValue(identity), sampled at i/(nout-1).  Returns true if identity.
 bool flat_curve_sample(const double *pts, int npts, bool periodic, int ppn, double identity, int nout, double *out)
 {

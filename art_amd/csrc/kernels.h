@@ -2,6 +2,7 @@
 // .hip kernels and the C-ABI host code (artgpu_api.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -142,6 +143,21 @@ hipError_t launch_ordered_sum(const float *x, long long n, float *out, hipStream
 struct MixArgs { float *dst[3]; size_t stride; int w, h; float m[9]; const float *lut[3]; };
 hipError_t launch_channel_mixer(const MixArgs &a, hipStream_t s);
 hipError_t launch_rgb_curves(const MixArgs &a, hipStream_t s);
+// ---- hslEqualizer (hsl.hip; iphsl.cc:29-221) ----
+struct HslCurve { const double *x, *y, *slope; int n; };      // FlatCurve's polyline (poly_x, poly_y, dyByDx) on the device
+struct HslArgs {
+    float *img[3]; size_t stride; int w, h;
+    float ws1[3];                 // working-space row 1 as floats (Imagefloat::ws_)
+    HslCurve curve[4];            // 0 saturation, 1 luminance, 2 hue curve over hue; 3 the fixed `coeff` curve of the saturation step
+    float *mask;                  // w*h
+    int which, to_rgb;
+};
+hipError_t launch_hsl_prepare(const HslArgs &a, hipStream_t s);
+hipError_t launch_hsl_mask(const HslArgs &a, hipStream_t s);
+hipError_t launch_hsl_apply(const HslArgs &a, hipStream_t s);
+hipError_t launch_hsl_finish(const HslArgs &a, hipStream_t s);
+// FlatCurve(points, periodic, ppn): the polyline getVal searches (x, y, slope[n-1]); false = identity / empty curve
+bool flat_curve_polyline(const double *pts, int npts, bool periodic, int ppn, double identity, std::vector<double> &x, std::vector<double> &y, std::vector<double> &slope);
 // N1: ARTOutputProfile fast path (iprgb2out.cc:152-172) and Imagefloat::getScanline (imagefloat.cc:125-170)
 struct OutArgs {
     const float *src[3]; size_t src_stride; float *dst[3]; size_t dst_stride; int w, h;

@@ -294,6 +294,15 @@ int artgpu_denoise_compute_params(artgpu_ctx *ctx, const artgpu_rgb *planes, int
 int artgpu_guided_filter(artgpu_ctx *ctx, const artgpu_plane *guide, const artgpu_plane *src, artgpu_plane *dst, int r, float epsilon,
                          int subsampling);
 
+/* ImProcFunctions::hslEqualizer (rtengine/iphsl.cc:29-221): hue / saturation / luminance adjustments as FlatCurves
+ * over hue.  Each curve is the `std::vector<double>` of ProcParams (hsl.hCurve / sCurve / lCurve: {FCT_MinMaxCPoints, x, y, left
+ * tangent, right tangent, ...}; NULL / n <= 4 or an identity curve = not applied), built into its polyline on the host exactly as
+ * FlatCurve's constructor does (periodic, CURVES_MIN_POLY_POINTS / scale points) and evaluated per pixel on the device; the masks
+ * are smoothed with rtengine::guidedFilter (radius from `smoothing` and scale, L118-123).  img is RGB on entry.  The reference leaves
+ * the Imagefloat in YUV mode (g = Y, b = u, r = v); to_rgb != 0 applies Imagefloat::setMode(RGB) on top so that the planes are RGB again. */
+int artgpu_hsl_equalizer(artgpu_ctx *ctx, artgpu_rgb *img, const double *hcurve, int nh, const double *scurve, int ns,
+                         const double *lcurve, int nl, int smoothing, const double ws[9], double scale, int to_rgb);
+
 /* SURVEY section 8f N1, the parts of the output stage that are plain arithmetic (everything lcms2 evaluates stays on the host):
  * artgpu_rgb2out_matrix : ARTOutputProfile::operator()(const Imagefloat*, Imagefloat*), the matrix + TRC fast path of
  *                         ImProcFunctions::rgb2out for matrix output profiles (iprgb2out.cc:94-172,452-461).  matrix = the host's

@@ -48,8 +48,10 @@ static void add_polygons(poly_t *p, int nbr_points, double increment, double x1,
 
 /* Samples FlatCurve(points, periodic, ppn) after setIdentityValue(identity) at t = i/(nout-1), i = 0..nout-1.
  * points: {kind, x0, y0, lt0, rt0, x1, ...}.  Returns 1 when the curve is the identity (kind FCT_Empty), else 0. */
-int oracle_flat_curve_sample(const double *pts, int npts, int periodic, int ppn_in, double identity, int nout, double *out)
+/* FlatCurve's constructor: builds the polyline getVal works on; returns 1 for an identity / empty curve (then *pout is empty) */
+static int flat_curve_build(const double *pts, int npts, int periodic, int ppn_in, double identity, poly_t *pout, double **dydx_out)
 {
+    pout->x = pout->y = NULL; pout->n = pout->cap = 0; *dydx_out = NULL;
     const int FCT_MinMaxCPoints = 1;
     int is_identity = 1;
     if (npts > 4 && (int)pts[0] == FCT_MinMaxCPoints) {
@@ -149,25 +151,56 @@ int oracle_flat_curve_sample(const double *pts, int npts, int periodic, int ppn_
             poly_push(&p, 3.0, sc_y[j - 1]);
             double *dy_by_dx = (double *)malloc(sizeof(double) * (p.n - 1));
             for (int i = 0; i < p.n - 1; i++) dy_by_dx[i] = (p.y[i + 1] - p.y[i]) / (p.x[i + 1] - p.x[i]);
-            for (int s = 0; s < nout; ++s) {
-                double t = (double)s / (double)(nout - 1);
-                if (t < p.x[0]) t += 1.0;
-                unsigned k_lo = 0, k_hi = (unsigned)p.n - 1;
-                while (k_hi > 1 + k_lo) {
-                    const unsigned m = (k_hi + k_lo) / 2;
-                    if (p.x[m] > t) k_hi = m; else k_lo = m;
-                }
-                out[s] = p.y[k_lo] + (t - p.x[k_lo]) * dy_by_dx[k_lo];
-            }
-            free(dy_by_dx); free(p.x); free(p.y); free(sc_x); free(sc_y); free(sc_len); free(sc_lin);
+            *pout = p; *dydx_out = dy_by_dx;
+            free(sc_x); free(sc_y); free(sc_len); free(sc_lin);
         } else {
             is_identity = 1;
         }
         free(x); free(y); free(lt); free(rt);
     }
-    if (is_identity)
-        for (int s = 0; s < nout; ++s) out[s] = identity;
     return is_identity;
+}
+
+
+
+/* FlatCurve::getVal, FCT_MinMaxCPoints (flatcurves.cc:344-365) */
+static double flat_curve_val(const poly_t *p, const double *dydx, double t)
+{
+    if (t < p->x[0]) t += 1.0;
+    unsigned k_lo = 0, k_hi = (unsigned)p->n - 1;
+    while (k_hi > 1 + k_lo) {
+        const unsigned m = (k_hi + k_lo) / 2;
+        if (p->x[m] > t) k_hi = m; else k_lo = m;
+    }
+    return p->y[k_lo] + (t - p->x[k_lo]) * dydx[k_lo];
+}
+int oracle_flat_curve_sample(const double *pts, int npts, int periodic, int ppn_in, double identity, int nout, double *out)
+{
+    poly_t p; double *dydx;
+    const int is_identity = flat_curve_build(pts, npts, periodic, ppn_in, identity, &p, &dydx);
+    for (int s = 0; s < nout; ++s) out[s] = is_identity ? identity : flat_curve_val(&p, dydx, (double)s / (double)(nout - 1));
+    free(dydx); free(p.x); free(p.y);
+    return is_identity;
+}
+/* handle form for per-pixel evaluation (hslEqualizer) */
+typedef struct { poly_t p; double *dydx; int identity; double identity_value; } oracle_flat_curve;
+void *oracle_flat_curve_new(const double *pts, int npts, int periodic, int ppn, double identity)
+{
+    oracle_flat_curve *c = (oracle_flat_curve *)calloc(1, sizeof *c);
+    c->identity_value = identity;
+    c->identity = (pts == NULL) ? 1 : flat_curve_build(pts, npts, periodic, ppn, identity, &c->p, &c->dydx);
+    return c;
+}
+int oracle_flat_curve_is_identity(const void *h) { return ((const oracle_flat_curve *)h)->identity; }
+double oracle_flat_curve_get(const void *h, double t)
+{
+    const oracle_flat_curve *c = (const oracle_flat_curve *)h;
+    return c->identity ? c->identity_value : flat_curve_val(&c->p, c->dydx, t);
+}
+void oracle_flat_curve_free(void *h)
+{
+    oracle_flat_curve *c = (oracle_flat_curve *)h;
+    free(c->dydx); free(c->p.x); free(c->p.y); free(c);
 }
 
 /* NoiseCurve::Set(const std::vector<double>&) (ipdenoise.cc:705-716 -> 684-703): non-periodic FlatCurve with

@@ -74,6 +74,8 @@ void oracle_scale_colors(const void *src, int src_u16, int w, int h, const int c
 void oracle_channel_mixer(float *const img[3], size_t s, int w, int h, const float m[9]);
 int oracle_rgb2out_matrix(const float *const src[3], float *const dst[3], size_t s, int w, int h, const float m[9], int linear, const float *lut, int lutsz);
 void oracle_get_scanlines(const float *const img[3], size_t s, int w, int h, int bps, int is_float, void *out);
+void oracle_hsl_equalizer(float *const img[3], int W, int H, const double *hcurve, int nh, const double *scurve, int ns, const double *lcurve, int nl,
+                          int smoothing, const double ws[9], double scale, int to_rgb);
 void oracle_saturation_vibrance(float *const img[3], size_t s, int w, int h, int saturation_p, int vibrance_p, const double ws[9]);
 void oracle_rgb_curves(float *const img[3], size_t s, int w, int h, const float *const luts[3]);
 /* AUTOMATIC chrominance estimation (oracle/dninfo.c) */

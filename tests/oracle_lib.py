@@ -448,3 +448,17 @@ def get_scanlines(img, bps, is_float=False):
     out = np.zeros((h, w, 3), dt)
     lib().oracle_get_scanlines(_p3(img), C.c_size_t(w), w, h, bps, 1 if is_float else 0, out.ctypes.data_as(C.c_void_p))
     return out
+
+
+def hsl_equalizer(img, hcurve, scurve, lcurve, smoothing, ws=None, scale=1.0, to_rgb=True):
+    img = [np.array(p, dtype=np.float32, order="C") for p in img]
+    h, w = img[0].shape
+    def arr(c):
+        return (None, 0) if c is None else ((C.c_double * len(c))(*[float(v) for v in c]), len(c))
+    (hc, nh), (sc, ns), (lc, nl) = arr(hcurve), arr(scurve), arr(lcurve)
+    wsd = (C.c_double * 9)(*[float(v) for v in np.asarray(REC2020_WS_D if ws is None else ws, dtype=np.float64).reshape(9)])
+    L = lib()
+    L.oracle_hsl_equalizer.argtypes = [C.POINTER(_fp), C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int,
+                                       C.c_int, C.POINTER(C.c_double), C.c_double, C.c_int]
+    L.oracle_hsl_equalizer(_p3(img), w, h, hc, nh, sc, ns, lc, nl, int(smoothing), wsd, float(scale), 1 if to_rgb else 0)
+    return img
