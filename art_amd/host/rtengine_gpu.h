@@ -82,6 +82,10 @@ struct ProcParams {
              chrominanceRedGreen = 0, chrominanceBlueYellow = 0, gamma = 1.7, chrominanceAutoFactor = 1; bool aggressive = false; int colorSpace = 0, chrominanceMethod = 0;
              bool smoothingEnabled = false; int guidedChromaRadius = 3, nlDetail = 80, nlStrength = 0; } denoise;   // procparams.cc:1900-1918 (chrominanceMethod: 0 MANUAL, 1 AUTOMATIC)
     struct { bool enabled = true; double expcomp = 0, black = 0; } exposure;
+    struct { bool enabled = false; int red[3] = {1000, 0, 0}, green[3] = {0, 1000, 0}, blue[3] = {0, 0, 1000}; } chmixer;        // procparams.cc (ChannelMixerParams)
+    struct { bool enabled = false; std::vector<double> hCurve, sCurve, lCurve; int smoothing = 0; } hsl;                         // HSLEqualizerParams
+    struct { bool enabled = false; int saturation = 0, vibrance = 0; } saturation;                                               // SaturationParams
+    struct { bool enabled = false; std::vector<float> rlut, glut, blut; } rgbCurves;                                             // RGBCurvesParams, as outCurve LUTs
     struct { bool enabled = true; int curveMode = ARTGPU_TONE_STD; std::vector<float> lut; float whitePoint = 1.f; bool basecurveLinear = true; } toneCurve;
     // toneCurve.curveMode: ARTGPU_TONE_STD or ARTGPU_TONE_NEUTRAL (ART's default, procparams.cc:1585)
     double workingSpace[9] = {0.6734241, 0.1656411, 0.1251286, 0.2790177, 0.6753402, 0.0456377, -0.0019300, 0.0299784, 0.7973330}; // Rec2020 TMatrix (iccmatrices.h:151-155)
@@ -164,11 +168,46 @@ public:
     {
         switch (stage) {
         case Stage::STAGE_0: break;
-        case Stage::STAGE_1: exposure(img); break;
+        case Stage::STAGE_1: channelMixer(img); exposure(img); hslEqualizer(img); break;      // improcfun.cc:581-585
         case Stage::STAGE_2: break;
-        case Stage::STAGE_3: toneCurve(img); break;
+        case Stage::STAGE_3: saturationVibrance(img); toneCurve(img); rgbCurves(img); break;  // improcfun.cc:607-623 (the steps this library has)
         }
         return false;
+    }
+    // ImProcFunctions::channelMixer (ipchmixer.cc:152-234), RGB_MATRIX mode: the nine percentages / 1000 (L185-199)
+    void channelMixer(Imagefloat *img)
+    {
+        if (!params->chmixer.enabled) return;
+        float m[9];
+        for (int k = 0; k < 3; ++k) { m[k] = params->chmixer.red[k] / 1000.f; m[3 + k] = params->chmixer.green[k] / 1000.f; m[6 + k] = params->chmixer.blue[k] / 1000.f; }
+        artgpu_rgb i = img->view();
+        ctx.check(artgpu_channel_mixer(ctx.get(), &i, m));
+    }
+    // ImProcFunctions::hslEqualizer (iphsl.cc:29-221); leaves the image in YUV mode like the reference unless the caller's Imagefloat
+    // has no mode tracking (this mirror's has none: planes are converted back to RGB)
+    void hslEqualizer(Imagefloat *img)
+    {
+        const auto &p = params->hsl;
+        if (!p.enabled) return;
+        artgpu_rgb i = img->view();
+        ctx.check(artgpu_hsl_equalizer(ctx.get(), &i, p.hCurve.empty() ? nullptr : p.hCurve.data(), (int)p.hCurve.size(), p.sCurve.empty() ? nullptr : p.sCurve.data(),
+                                       (int)p.sCurve.size(), p.lCurve.empty() ? nullptr : p.lCurve.data(), (int)p.lCurve.size(), p.smoothing, params->workingSpace, scale, 1));
+    }
+    // ImProcFunctions::saturationVibrance (ipsaturation.cc:43-83)
+    void saturationVibrance(Imagefloat *img)
+    {
+        if (!params->saturation.enabled) return;
+        artgpu_rgb i = img->view();
+        ctx.check(artgpu_saturation_vibrance(ctx.get(), &i, params->saturation.saturation, params->saturation.vibrance, params->workingSpace));
+    }
+    // ImProcFunctions::rgbCurves (iprgbcurves.cc:30-148): the three 65536-entry outCurve LUTs are built by the caller (RGBCurve, L41-53)
+    void rgbCurves(Imagefloat *img)
+    {
+        const auto &p = params->rgbCurves;
+        if (!p.enabled) return;
+        artgpu_rgb i = img->view();
+        ctx.check(artgpu_rgb_curves(ctx.get(), &i, p.rlut.size() == 65536 ? p.rlut.data() : nullptr, p.glut.size() == 65536 ? p.glut.data() : nullptr,
+                                    p.blut.size() == 65536 ? p.blut.data() : nullptr));
     }
     // ImProcFunctions::exposure -> expcomp (ipexposure.cc:28-79)
     void exposure(Imagefloat *img) { expcomp(img, params->exposure.expcomp, params->exposure.black, params->exposure.enabled); }
