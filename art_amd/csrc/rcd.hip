@@ -18,9 +18,12 @@ constexpr int w1 = ts, w2 = 2 * ts, w3 = 3 * ts, w4 = 4 * ts;
 constexpr int NT = RCD_THREADS;
 constexpr float eps = 1e-5f, epssq = 1e-10f, scale = 65536.f;
 
-#define FOR_ITEMS(R0, R1, N)                                                         \
-    for (int _n = (N), _tot = ((R1) > (R0) ? ((R1) - (R0)) : 0) * _n, _t = tid; _t < _tot; _t += NT) \
-        for (int row = (R0) + _t / _n, it = _t - (row - (R0)) * _n, _once = 1; _once; _once = 0)
+// (row, it) advance incrementally: one integer division per phase and thread instead of one per item.
+#define FOR_ITEMS(R0, R1, N)                                                                                                     \
+    for (int _n = (N), _tot = ((R1) > (R0) ? ((R1) - (R0)) : 0) * _n, _t = tid, _d = _n > 0 ? _n : 1, _q = NT / _d, _r = NT - _q * _d, \
+             row = (R0) + tid / _d, it = tid - (row - (R0)) * _d;                                                                \
+         _t < _tot; _t += NT, row += _q, it += _r, row += (it >= _d), it -= (it >= _d) ? _d : 0)                                  \
+        for (int _once = 1; _once; _once = 0)
 
 __device__ __forceinline__ float hpf(const float *c, int i, int s1)
 {
