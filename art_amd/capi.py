@@ -37,6 +37,11 @@ class DenoiseParams(C.Structure):
                 ("gamma", C.c_double), ("aggressive", C.c_int32), ("color_space", C.c_int32), ("chrominance_method", C.c_int32)]
 
 
+class LogEncParams(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("regularization", C.c_int32), ("satcontrol", C.c_int32), ("highlight_compression", C.c_int32),
+                ("gain", C.c_double), ("target_gray", C.c_double), ("black_ev", C.c_double), ("white_ev", C.c_double)]
+
+
 class DenoiseInfoStore(C.Structure):
     """DenoiseInfoStore (improcfun.h:117-131) + per-crop diagnostics"""
     _fields_ = [("valid", C.c_int32), ("ch_M", C.c_float * 9), ("max_r", C.c_float * 9), ("max_b", C.c_float * 9),
@@ -138,6 +143,7 @@ def _load():
     lib.artgpu_guided_filter.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(Plane), C.POINTER(Plane), C.c_int, C.c_float, C.c_int]
     lib.artgpu_hsl_equalizer.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.c_int,
                                          C.c_int, C.POINTER(C.c_double), C.c_double, C.c_int]
+    lib.artgpu_log_encoding.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(LogEncParams), C.POINTER(C.c_double), C.c_int, C.c_int]
     lib.artgpu_channel_mixer.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float)]
     lib.artgpu_rgb_curves.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_pipeline_run.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
@@ -165,7 +171,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter", "artgpu_hsl_equalizer"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter", "artgpu_hsl_equalizer", "artgpu_log_encoding"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -328,6 +334,13 @@ class Context:
         (h, nh), (s, ns), (l, nl) = arr(hcurve), arr(scurve), arr(lcurve)
         self._chk(LIB.artgpu_hsl_equalizer(self._h, C.byref(image), h, nh, s, ns, l, nl, int(smoothing),
                                            (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)]), float(scale), 1 if to_rgb else 0))
+
+    def log_encoding(self, image: RGB, ws, gain=0.0, target_gray=18.0, black_ev=-13.5, white_ev=2.5, regularization=60, satcontrol=True,
+                     highlight_compression=0, full_width=0, full_height=0, enabled=True):
+        p = LogEncParams(1 if enabled else 0, int(regularization), 1 if satcontrol else 0, int(highlight_compression),
+                         float(gain), float(target_gray), float(black_ev), float(white_ev))
+        self._chk(LIB.artgpu_log_encoding(self._h, C.byref(image), C.byref(p), (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)]),
+                                          int(full_width), int(full_height)))
 
     def channel_mixer(self, image: RGB, m):
         self._chk(LIB.artgpu_channel_mixer(self._h, C.byref(image), (C.c_float * 9)(*[float(v) for v in np.asarray(m, np.float32).reshape(9)])))

@@ -1046,7 +1046,7 @@ int artgpu_guided_filter(artgpu_ctx *ctx, const artgpu_plane *guide, const artgp
     const float r1 = float(r) / sub;
     int rad = (int)r1;
     { const int hi = ((g.w < g.h ? g.w : g.h) - 1) / 2 - 1; rad = rad < hi ? rad : hi; rad = rad > 0 ? rad : 0; }     // f_mean's LIM (L160-164)
-    if (rad > 63) return fail(ctx, ARTGPU_EUNSUPPORTED, "guided_filter: box radius %d (r / subsampling) is above the 63 the blur kernels hold in LDS", rad);
+    if (rad > HBLUR_MAX_RADIUS) return fail(ctx, ARTGPU_EUNSUPPORTED, "guided_filter: box radius %d (r / subsampling) is above the %d the blur kernels hold in LDS", rad, HBLUR_MAX_RADIUS);
     BlurArgs bl = {};
     bl.n = nl; bl.w = g.w; bl.h = g.h; bl.steady_div = 1; bl.plain = 1;
     for (int l = 0; l < 10; ++l) bl.rad[l] = rad;
@@ -1066,6 +1066,45 @@ int artgpu_guided_filter(artgpu_ctx *ctx, const artgpu_plane *guide, const artgp
     HIPCHK(ctx, hipMemcpy2DAsync(dst->p, (size_t)dst->row_stride_bytes, g.q, rowb, rowb, H, dst->on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     if (!dst->on_device) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return ARTGPU_OK;
+}
+
+int artgpu_log_encoding(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_logenc_params *p, const double ws[9], int full_width, int full_height)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!img || !p || !ws) return fail(ctx, ARTGPU_EINVAL, "log_encoding: null argument");
+    if (!p->enabled) return ARTGPU_OK;
+    if (p->highlight_compression > 0) return fail(ctx, ARTGPU_EUNSUPPORTED, "log_encoding: highlight compression evaluates the C library's powf per pixel; not on the device path");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    LogEncArgs a = {};
+    a.gray = std::pow(2.f, -(float)p->gain + std::log2(0.18f));                                   // ev2gray (L119-122)
+    a.shadows_range = (float)p->black_ev;
+    a.dynamic_range = (float)std::max(p->white_ev - p->black_ev, 0.5);
+    const float b = p->target_gray > 1 && p->target_gray < 100 && a.dynamic_range > 0
+        ? logenc_find_gray((float)(std::abs(p->black_ev) / a.dynamic_range), (float)(p->target_gray / 100.f)) : 0.f;
+    a.linbase = b < 0.f ? 0.f : b;
+    a.satcontrol = p->satcontrol ? 1 : 0;
+    { const float bl = float(p->regularization) / 100.f; a.blend = bl < 0.f ? 0.f : (bl > 1.f ? 1.f : bl); }
+    for (int k = 0; k < 3; ++k) a.ws1[k] = ws[3 + k];
+    DevRGB d;
+    int rc = bind_rgb(ctx, img, 4, true, &d, "log_encoding");
+    if (rc) return rc;
+    for (int k = 0; k < 3; ++k) a.img[k] = d.p[k];
+    a.stride = d.stride; a.w = d.w; a.h = d.h;
+    if (p->regularization == 0) {
+        HIPCHK(ctx, launch_logenc_direct(a, ctx->stream));
+    } else {
+        const size_t n = (size_t)d.w * d.h;
+        float *Y, *Y2;
+        if ((rc = pool_get(ctx, P_DMASK, n * 4, &Y)) || (rc = pool_get(ctx, P_CCMAP, n * 4, &Y2))) return rc;
+        a.Y = Y; a.Y2 = Y2;
+        HIPCHK(ctx, launch_logenc_prepare(a, ctx->stream));
+        const int m1 = full_width > d.w ? full_width : d.w, m2 = full_height > d.h ? full_height : d.h;
+        const float radius = (m1 > m2 ? m1 : m2) / 30.f;
+        artgpu_plane guide = {Y2, d.w, d.h, (int64_t)d.w * 4, 1}, ypl = {Y, d.w, d.h, (int64_t)d.w * 4, 1};
+        if ((rc = artgpu_guided_filter(ctx, &guide, &ypl, &ypl, (int)radius, 0.005f, 0))) return rc;
+        HIPCHK(ctx, launch_logenc_blend(a, ctx->stream));
+    }
+    return unbind_rgb(ctx, img, &d);
 }
 
 int artgpu_hsl_equalizer(artgpu_ctx *ctx, artgpu_rgb *img, const double *hcurve, int nh, const double *scurve, int ns,

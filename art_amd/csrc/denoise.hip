@@ -411,6 +411,64 @@ __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
     }
 }
 
+// Radii above 63 (rtengine::guidedFilter callers with image-sized radii: log encoding's regularisation, the hsl equaliser at
+// scale 1): the same running sum over 256-column chunks with the window in dynamic LDS.  Only used on one plane at a time.
+constexpr int HBB_COLS = 256;
+__global__ void __launch_bounds__(64) hblur_big_kernel(BlurArgs a)
+{
+    extern __shared__ float hbb_lds[];
+    const int sub = blockIdx.y, level = a.level0 + sub / 3;
+    const int rad = a.rad[level];
+    const int W = a.w, H = a.h;
+    const int TS_ = HBB_COLS + 2 * rad + 3, OS_ = HBB_COLS + 1;   // odd strides
+    float *const sT = hbb_lds, *const oT = hbb_lds + (size_t)HB_ROWS * TS_;
+    const float *src = a.src + (size_t)sub * a.n;
+    float *dst = a.dst + (size_t)sub * a.n;
+    const int r0 = blockIdx.x * HB_ROWS;
+    const int lane = threadIdx.x;
+    const int myrow = r0 + lane;
+    const int nrows = min(HB_ROWS, H - r0);
+    float tempval = 0.f;
+    int len = rad + 1;
+    float reclen = 0.f;
+    for (int c0 = 0; c0 < W; c0 += HBB_COLS) {
+        const int wc0 = c0 - rad - 1, wn = HBB_COLS + 2 * rad + 1;
+        for (int k = 0; k < nrows; ++k)
+            for (int x = lane; x < wn; x += 64) {
+                const int col = wc0 + x;
+                sT[(size_t)k * TS_ + x] = (col >= 0 && col < W) ? src[(size_t)(r0 + k) * W + col] : 0.f;
+            }
+        __syncthreads();
+        const int cend = min(HBB_COLS, W - c0);
+        if (lane < HB_ROWS && myrow < H) {
+            const float *s = sT + (size_t)lane * TS_ + rad + 1; // s[j] = src[row][c0 + j]
+            float *o = oT + lane * OS_;
+            for (int j = 0; j < cend; ++j) {
+                const int col = c0 + j;
+                if (col == 0) {
+                    tempval = s[0];
+                    for (int q = 1; q <= rad; q++) tempval += s[q];
+                    tempval = tempval / len;
+                } else if (col <= rad) {
+                    tempval = (tempval * len + s[j + rad]) / (len + 1);
+                    len++;
+                    if (col == rad) reclen = 1.f / len;
+                } else if (col < W - rad) {
+                    tempval = a.steady_div ? tempval + (s[j + rad] - s[j - rad - 1]) / (float)len : tempval + (s[j + rad] - s[j - rad - 1]) * reclen;
+                } else {
+                    tempval = (tempval * len - s[j - rad - 1]) / (len - 1);
+                    len--;
+                }
+                o[j] = tempval;
+            }
+        }
+        __syncthreads();
+        for (int k = 0; k < nrows; ++k)
+            for (int x = lane; x < cend; x += 64) dst[(size_t)(r0 + k) * W + c0 + x] = oT[k * OS_ + x];
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- vertical box blur + coefficient update (boxblur.h:602-742)
 __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
 {
@@ -540,7 +598,14 @@ hipError_t launch_hblur(const BlurArgs &a, int nsub, hipStream_t s)
 {
     int maxr = 0;
     for (int l = 0; l < 10; ++l) maxr = a.rad[l] > maxr ? a.rad[l] : maxr;
-    if (maxr > 63) return hipErrorInvalidValue;
+    if (maxr > HBLUR_MAX_RADIUS) return hipErrorInvalidValue;
+    if (maxr > 63) {
+        const size_t lds = ((size_t)HB_ROWS * (HBB_COLS + 2 * maxr + 3) + (size_t)HB_ROWS * (HBB_COLS + 1)) * sizeof(float);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(hblur_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(hblur_big_kernel, dim3((a.h + HB_ROWS - 1) / HB_ROWS, nsub), dim3(64), lds, s, a);
+        return hipGetLastError();
+    }
     if (maxr <= 15) hipLaunchKernelGGL(hblur_kernel<15>, dim3((a.h + HB_ROWS - 1) / HB_ROWS, nsub), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(hblur_kernel<63>, dim3((a.h + HB_ROWS - 1) / HB_ROWS, nsub), dim3(64), 0, s, a);
     return hipGetLastError();

@@ -156,6 +156,18 @@ hipError_t launch_hsl_prepare(const HslArgs &a, hipStream_t s);
 hipError_t launch_hsl_mask(const HslArgs &a, hipStream_t s);
 hipError_t launch_hsl_apply(const HslArgs &a, hipStream_t s);
 hipError_t launch_hsl_finish(const HslArgs &a, hipStream_t s);
+// ---- logEncoding (logenc.hip; iplogenc.cc:132-316) ----
+struct LogEncArgs {
+    float *img[3]; size_t stride; int w, h;
+    double ws1[3];                // working-space row 1 (Color::rgbLuminance<double>)
+    float gray, shadows_range, dynamic_range, linbase, blend;
+    int satcontrol;
+    float *Y, *Y2;                // w*h: smoothed norm / its guide
+};
+hipError_t launch_logenc_direct(const LogEncArgs &a, hipStream_t s);
+hipError_t launch_logenc_prepare(const LogEncArgs &a, hipStream_t s);
+hipError_t launch_logenc_blend(const LogEncArgs &a, hipStream_t s);
+float logenc_find_gray(float source_gray, float target_gray);
 // FlatCurve(points, periodic, ppn): the polyline getVal searches (x, y, slope[n-1]); false = identity / empty curve
 bool flat_curve_polyline(const double *pts, int npts, bool periodic, int ppn, double identity, std::vector<double> &x, std::vector<double> &y, std::vector<double> &slope);
 // N1: ARTOutputProfile fast path (iprgb2out.cc:152-172) and Imagefloat::getScanline (imagefloat.cc:125-170)
@@ -259,6 +271,7 @@ struct BlurArgs {
     int plain;              // vblur: store the blurred value to dst (all columns take the vector form); no coefficient update
     int level0;             // level of the first band passed (blockIdx.y = 0)
 };
+constexpr int HBLUR_MAX_RADIUS = 900;   // window of 256 + 2 * radius columns x 16 rows in the CU's 160 KB LDS
 hipError_t launch_gamma_lut(float *lut, float gamma, float start, float slope, float divisor, float factor, hipStream_t s);
 hipError_t launch_rgb2yuv(const DnPixArgs &a, hipStream_t s);
 hipError_t launch_yuv2rgb(const DnPixArgs &a, hipStream_t s);

@@ -84,6 +84,8 @@ struct ProcParams {
     struct { bool enabled = true; double expcomp = 0, black = 0; } exposure;
     struct { bool enabled = false; int red[3] = {1000, 0, 0}, green[3] = {0, 1000, 0}, blue[3] = {0, 0, 1000}; } chmixer;        // procparams.cc (ChannelMixerParams)
     struct { bool enabled = false; std::vector<double> hCurve, sCurve, lCurve; int smoothing = 0; } hsl;                         // HSLEqualizerParams
+    struct { bool enabled = false; double gain = 0, targetGray = 18, blackEv = -13.5, whiteEv = 2.5; int regularization = 60; bool satcontrol = true;
+             int highlightCompression = 0; } logenc;                                                                               // LogEncodingParams (procparams.cc:2039-2051)
     struct { bool enabled = false; int saturation = 0, vibrance = 0; } saturation;                                               // SaturationParams
     struct { bool enabled = false; std::vector<float> rlut, glut, blut; } rgbCurves;                                             // RGBCurvesParams, as outCurve LUTs
     struct { bool enabled = true; int curveMode = ARTGPU_TONE_STD; std::vector<float> lut; float whitePoint = 1.f; bool basecurveLinear = true; } toneCurve;
@@ -170,7 +172,7 @@ public:
         case Stage::STAGE_0: break;
         case Stage::STAGE_1: channelMixer(img); exposure(img); hslEqualizer(img); break;      // improcfun.cc:581-585
         case Stage::STAGE_2: break;
-        case Stage::STAGE_3: saturationVibrance(img); toneCurve(img); rgbCurves(img); break;  // improcfun.cc:607-623 (the steps this library has)
+        case Stage::STAGE_3: logEncoding(img); saturationVibrance(img); toneCurve(img); rgbCurves(img); break;  // improcfun.cc:607-623 (the steps this library has)
         }
         return false;
     }
@@ -192,6 +194,16 @@ public:
         artgpu_rgb i = img->view();
         ctx.check(artgpu_hsl_equalizer(ctx.get(), &i, p.hCurve.empty() ? nullptr : p.hCurve.data(), (int)p.hCurve.size(), p.sCurve.empty() ? nullptr : p.sCurve.data(),
                                        (int)p.sCurve.size(), p.lCurve.empty() ? nullptr : p.lCurve.data(), (int)p.lCurve.size(), p.smoothing, params->workingSpace, scale, 1));
+    }
+    // ImProcFunctions::logEncoding (iplogenc.cc:395-402); full_width/full_height as set by ImProcFunctions::setViewport (0 = the image itself)
+    int full_width = 0, full_height = 0;
+    void logEncoding(Imagefloat *img)
+    {
+        const auto &p = params->logenc;
+        if (!p.enabled) return;
+        artgpu_logenc_params lp = {1, p.regularization, p.satcontrol ? 1 : 0, p.highlightCompression, p.gain, p.targetGray, p.blackEv, p.whiteEv};
+        artgpu_rgb i = img->view();
+        ctx.check(artgpu_log_encoding(ctx.get(), &i, &lp, params->workingSpace, full_width, full_height));
     }
     // ImProcFunctions::saturationVibrance (ipsaturation.cc:43-83)
     void saturationVibrance(Imagefloat *img)

@@ -303,6 +303,21 @@ int artgpu_guided_filter(artgpu_ctx *ctx, const artgpu_plane *guide, const artgp
 int artgpu_hsl_equalizer(artgpu_ctx *ctx, artgpu_rgb *img, const double *hcurve, int nh, const double *scurve, int ns,
                          const double *lcurve, int nl, int smoothing, const double ws[9], double scale, int to_rgb);
 
+/* ImProcFunctions::logEncoding (rtengine/iplogenc.cc:132-316,395-402): brightness-norm log tone mapping.
+ * The struct holds the LogEncodingParams fields the function reads (procparams.h; defaults procparams.cc:2039-2051); `enabled == 0`
+ * returns at once like the reference.  regularization > 0 smooths the posterised log-norm with rtengine::guidedFilter at radius
+ * max(full_width, W, full_height, H) / 30 (full_width/height = ImProcFunctions::full_width/full_height, the uncropped image size).
+ * highlight_compression > 0 evaluates std::pow per pixel (the C library's powf); that branch is not restated on the device:
+ * ARTGPU_EUNSUPPORTED, the caller keeps its CPU path for it. */
+typedef struct artgpu_logenc_params {
+    int32_t enabled;
+    int32_t regularization;          /* 0..100 */
+    int32_t satcontrol;
+    int32_t highlight_compression;   /* 0..100 */
+    double gain, target_gray, black_ev, white_ev;
+} artgpu_logenc_params;
+int artgpu_log_encoding(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_logenc_params *p, const double ws[9], int full_width, int full_height);
+
 /* SURVEY section 8f N1, the parts of the output stage that are plain arithmetic (everything lcms2 evaluates stays on the host):
  * artgpu_rgb2out_matrix : ARTOutputProfile::operator()(const Imagefloat*, Imagefloat*), the matrix + TRC fast path of
  *                         ImProcFunctions::rgb2out for matrix output profiles (iprgb2out.cc:94-172,452-461).  matrix = the host's

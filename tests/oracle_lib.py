@@ -462,3 +462,18 @@ def hsl_equalizer(img, hcurve, scurve, lcurve, smoothing, ws=None, scale=1.0, to
                                        C.c_int, C.POINTER(C.c_double), C.c_double, C.c_int]
     L.oracle_hsl_equalizer(_p3(img), w, h, hc, nh, sc, ns, lc, nl, int(smoothing), wsd, float(scale), 1 if to_rgb else 0)
     return img
+
+
+def log_encoding(img, ws=None, gain=0.0, target_gray=18.0, black_ev=-13.5, white_ev=2.5, regularization=60, satcontrol=True,
+                 highlight_compression=0, full_width=0, full_height=0):
+    """ImProcFunctions::logEncoding (iplogenc.cc:132-316) on three contiguous planes; returns new planes."""
+    L = lib()
+    out = [np.ascontiguousarray(p, dtype=np.float32).copy() for p in img]
+    h, w = out[0].shape
+    wsd = (C.c_double * 9)(*[float(v) for v in np.asarray(REC2020_WS_D if ws is None else ws, dtype=np.float64).reshape(9)])
+    L.oracle_log_encoding.argtypes = [C.POINTER(_fp), C.c_int, C.c_int, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, C.c_double,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.oracle_log_encoding.restype = None
+    L.oracle_log_encoding(_p3(out), w, h, wsd, float(gain), float(target_gray), float(black_ev), float(white_ev), int(regularization),
+                          1 if satcontrol else 0, int(highlight_compression), int(full_width), int(full_height))
+    return out

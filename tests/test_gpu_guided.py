@@ -38,9 +38,9 @@ def test_radius_zero_is_identity(gpu_ctx):
     assert _same(got, img) == [0, 0, 0]
 
 
-@pytest.mark.parametrize("w,h,r,eps", [(300, 200, 3, 0.001), (700, 500, 4, 0.001), (1203, 801, 25, 0.0001), (911, 640, 7, 0.01), (640, 912, 1, 0.001), (801, 603, 10, 0.001), (700, 501, 54, 0.0001), (500, 420, 40, 0.001)])
+@pytest.mark.parametrize("w,h,r,eps", [(300, 200, 3, 0.001), (700, 500, 4, 0.001), (1203, 801, 25, 0.0001), (911, 640, 7, 0.01), (640, 912, 1, 0.001), (801, 603, 10, 0.001), (700, 501, 54, 0.0001), (500, 420, 40, 0.001), (900, 700, 97, 0.005), (1290, 610, 211, 0.005)])
 def test_plain_guided_filter_bit_exact(gpu_ctx, w, h, r, eps):
-    """rtengine::guidedFilter (guidedfilter.cc:78-241), single channel, automatic subsampling (1, 4, 5, 3, 1, 5, 3, 1 here; the last two have box radii 18 and 40: the wide-window blur kernel)."""
+    """rtengine::guidedFilter (guidedfilter.cc:78-241), single channel, automatic subsampling (1, 4, 5, 3, 1, 5, 3, 1 here; then box radii 18 and 40: the wide-window blur kernel; 97 and 211 are prime, so no subsampling: the dynamic-LDS blur kernel for image-sized radii)."""
     from art_amd import capi
     rng = np.random.default_rng(w + r)
     y, x = np.mgrid[0:h, 0:w].astype(np.float32)
