@@ -1068,6 +1068,74 @@ int artgpu_guided_filter(artgpu_ctx *ctx, const artgpu_plane *guide, const artgp
     return ARTGPU_OK;
 }
 
+static int lab_tabs_dev(artgpu_ctx *ctx, float **tabs_out);
+static int lab_mode_switch(artgpu_ctx *ctx, artgpu_rgb *img, const double m[9], bool to_lab, const char *who)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!img || !m) return fail(ctx, ARTGPU_EINVAL, "%s: null argument", who);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    float *tabs;
+    int rc = lab_tabs_dev(ctx, &tabs);
+    if (rc) return rc;
+    DevRGB d;
+    if ((rc = bind_rgb(ctx, img, 4, true, &d, who))) return rc;
+    LabArgs a = {};
+    for (int k = 0; k < 3; ++k) a.img[k] = d.p[k];
+    a.stride = d.stride; a.w = d.w; a.h = d.h;
+    for (int k = 0; k < 9; ++k) { a.ws[k] = (float)m[k]; a.iws[k] = (float)m[k]; }
+    a.cachef = tabs; a.cachefy = tabs + 65536;
+    HIPCHK(ctx, to_lab ? launch_rgb_to_lab(a, ctx->stream) : launch_lab_to_rgb(a, ctx->stream));
+    return unbind_rgb(ctx, img, &d);
+}
+int artgpu_rgb_to_lab(artgpu_ctx *ctx, artgpu_rgb *img, const double ws[9]) { return lab_mode_switch(ctx, img, ws, true, "rgb_to_lab"); }
+int artgpu_lab_to_rgb(artgpu_ctx *ctx, artgpu_rgb *img, const double iws[9]) { return lab_mode_switch(ctx, img, iws, false, "lab_to_rgb"); }
+
+int artgpu_lab_histogram(artgpu_ctx *ctx, const artgpu_rgb *img, uint32_t hist[65536])
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!img || !hist) return fail(ctx, ARTGPU_EINVAL, "lab_histogram: null argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB d;
+    artgpu_rgb tmp = *img;
+    int rc = bind_rgb(ctx, &tmp, 4, true, &d, "lab_histogram");
+    if (rc) return rc;
+    float *h;
+    if ((rc = pool_get(ctx, P_HISTO, 65536 * 4, &h))) return rc;
+    LabArgs a = {};
+    for (int k = 0; k < 3; ++k) a.img[k] = d.p[k];
+    a.stride = d.stride; a.w = d.w; a.h = d.h; a.hist = reinterpret_cast<unsigned *>(h);
+    HIPCHK(ctx, hipMemsetAsync(h, 0, 65536 * 4, ctx->stream));
+    HIPCHK(ctx, launch_lab_hist(a, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hist, h, 65536 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
+int artgpu_lab_adjustments(artgpu_ctx *ctx, artgpu_rgb *img, const float *lcurve, const float *acurve, const float *bcurve, float chroma)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!img || !lcurve || !acurve || !bcurve) return fail(ctx, ARTGPU_EINVAL, "lab_adjustments: null argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevRGB d;
+    int rc = bind_rgb(ctx, img, 4, true, &d, "lab_adjustments");
+    if (rc) return rc;
+    float *luts;
+    constexpr size_t NL = 32772;       // lcurve padded to a multiple of four floats
+    if ((rc = pool_get(ctx, P_PIPE_R, (NL + 2 * 65536) * 4, &luts))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(luts, lcurve, 32770 * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(luts + NL, acurve, 65536 * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(luts + NL + 65536, bcurve, 65536 * 4, hipMemcpyHostToDevice, ctx->stream));
+    LabArgs a = {};
+    for (int k = 0; k < 3; ++k) a.img[k] = d.p[k];
+    a.stride = d.stride; a.w = d.w; a.h = d.h;
+    a.lcurve = luts; a.acurve = luts + NL; a.bcurve = luts + NL + 65536; a.chroma = chroma;
+    HIPCHK(ctx, launch_lab_adjust(a, ctx->stream));
+    rc = unbind_rgb(ctx, img, &d);
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // the caller's LUTs may go out of scope
+    return ARTGPU_OK;
+}
+
 int artgpu_log_encoding(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_logenc_params *p, const double ws[9], int full_width, int full_height)
 {
     if (!ctx) return ARTGPU_EINVAL;

@@ -156,6 +156,19 @@ hipError_t launch_hsl_prepare(const HslArgs &a, hipStream_t s);
 hipError_t launch_hsl_mask(const HslArgs &a, hipStream_t s);
 hipError_t launch_hsl_apply(const HslArgs &a, hipStream_t s);
 hipError_t launch_hsl_finish(const HslArgs &a, hipStream_t s);
+// ---- Imagefloat RGB <-> LAB and labAdjustments (lab.hip; imagefloat.cc:841-970, iplabadjustments.cc:236-345) ----
+struct LabArgs {
+    float *img[3]; size_t stride; int w, h;      // r = a, g = L, b = b in LAB mode
+    float ws[9], iws[9];                         // Imagefloat::ws_ / iws_
+    const float *cachef, *cachefy;               // Color::cachef / cachefy
+    const float *lcurve, *acurve, *bcurve;       // 32770 / 65536 / 65536 entries
+    float chroma;
+    unsigned *hist;                              // 65536 bins
+};
+hipError_t launch_rgb_to_lab(const LabArgs &a, hipStream_t s);
+hipError_t launch_lab_to_rgb(const LabArgs &a, hipStream_t s);
+hipError_t launch_lab_hist(const LabArgs &a, hipStream_t s);
+hipError_t launch_lab_adjust(const LabArgs &a, hipStream_t s);
 // ---- logEncoding (logenc.hip; iplogenc.cc:132-316) ----
 struct LogEncArgs {
     float *img[3]; size_t stride; int w, h;

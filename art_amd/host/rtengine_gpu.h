@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <stdexcept>
 #include <string>
+#include <functional>
 #include <vector>
 #include "../../include/artgpu.h"
 
@@ -86,6 +87,10 @@ struct ProcParams {
     struct { bool enabled = false; std::vector<double> hCurve, sCurve, lCurve; int smoothing = 0; } hsl;                         // HSLEqualizerParams
     struct { bool enabled = false; double gain = 0, targetGray = 18, blackEv = -13.5, whiteEv = 2.5; int regularization = 60; bool satcontrol = true;
              int highlightCompression = 0; } logenc;                                                                               // LogEncodingParams (procparams.cc:2039-2051)
+    // LabCurveParams: brightness / contrast / the three DiagonalCurves stay host code (get_L_curve / get_ab_curves, iplabadjustments.cc:67-191);
+    // `curves` is that code: it receives hist16 (nullptr unless contrast != 0) and fills lcurve[32770], acurve[65536], bcurve[65536]
+    struct { bool enabled = false; int chromaticity = 0, contrast = 0;
+             std::function<void(const uint32_t *hist16, std::vector<float> &lcurve, std::vector<float> &acurve, std::vector<float> &bcurve)> curves; } labCurve;
     struct { bool enabled = false; int saturation = 0, vibrance = 0; } saturation;                                               // SaturationParams
     struct { bool enabled = false; std::vector<float> rlut, glut, blut; } rgbCurves;                                             // RGBCurvesParams, as outCurve LUTs
     struct { bool enabled = true; int curveMode = ARTGPU_TONE_STD; std::vector<float> lut; float whitePoint = 1.f; bool basecurveLinear = true; } toneCurve;
@@ -172,7 +177,7 @@ public:
         case Stage::STAGE_0: break;
         case Stage::STAGE_1: channelMixer(img); exposure(img); hslEqualizer(img); break;      // improcfun.cc:581-585
         case Stage::STAGE_2: break;
-        case Stage::STAGE_3: logEncoding(img); saturationVibrance(img); toneCurve(img); rgbCurves(img); break;  // improcfun.cc:607-623 (the steps this library has)
+        case Stage::STAGE_3: logEncoding(img); saturationVibrance(img); toneCurve(img); rgbCurves(img); labAdjustments(img); break;  // improcfun.cc:607-623 (the steps this library has)
         }
         return false;
     }
@@ -204,6 +209,23 @@ public:
         artgpu_logenc_params lp = {1, p.regularization, p.satcontrol ? 1 : 0, p.highlightCompression, p.gain, p.targetGray, p.blackEv, p.whiteEv};
         artgpu_rgb i = img->view();
         ctx.check(artgpu_log_encoding(ctx.get(), &i, &lp, params->workingSpace, full_width, full_height));
+    }
+    // ImProcFunctions::labAdjustments (iplabadjustments.cc:277-345): setMode(LAB), hist16 when contrast != 0, the caller's curve builders,
+    // the curve loop; the reference leaves the image in LAB mode for the next step's setMode -- this mirror has no mode tracking and
+    // converts back at once (Imagefloat::lab_to_rgb)
+    void labAdjustments(Imagefloat *img)
+    {
+        const auto &p = params->labCurve;
+        if (!p.enabled || !p.curves) return;
+        artgpu_rgb i = img->view();
+        ctx.check(artgpu_rgb_to_lab(ctx.get(), &i, params->workingSpace));
+        std::vector<uint32_t> hist16;
+        if (p.contrast != 0) { hist16.resize(65536); ctx.check(artgpu_lab_histogram(ctx.get(), &i, hist16.data())); }
+        std::vector<float> lc, ac, bc;
+        p.curves(hist16.empty() ? nullptr : hist16.data(), lc, ac, bc);
+        if (lc.size() != 32770 || ac.size() != 65536 || bc.size() != 65536) throw std::runtime_error("labAdjustments: curve LUT sizes");
+        ctx.check(artgpu_lab_adjustments(ctx.get(), &i, lc.data(), ac.data(), bc.data(), (p.chromaticity + 100.0f) / 100.0f));
+        ctx.check(artgpu_lab_to_rgb(ctx.get(), &i, params->workingSpaceInverse));
     }
     // ImProcFunctions::saturationVibrance (ipsaturation.cc:43-83)
     void saturationVibrance(Imagefloat *img)

@@ -318,6 +318,22 @@ typedef struct artgpu_logenc_params {
 } artgpu_logenc_params;
 int artgpu_log_encoding(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_logenc_params *p, const double ws[9], int full_width, int full_height);
 
+/* ImProcFunctions::labAdjustments (rtengine/iplabadjustments.cc:277-345) as the four device steps the function is
+ * made of; the caller keeps building the three curves (get_L_curve / get_ab_curves, DiagonalCurve: host code), exactly where it does now:
+ *   artgpu_rgb_to_lab      Imagefloat::setMode(LAB) from RGB = rgb_to_lab (imagefloat.cc:841-876): in place, afterwards g = L, r = a, b = b.
+ *                          ws = the working-space TMatrix (narrowed to float like Imagefloat::get_ws).
+ *   artgpu_lab_histogram   hist16[(int)L]++ over the L plane (L300-327; 65536 bins, index clamped like LUTu::operator[]) - only needed
+ *                          when labCurve.contrast != 0.
+ *   artgpu_lab_adjustments lab_adjustments' curve loop (L236-264): L = lcurve[L], a = (acurve[a + 32768] - 32768) * chroma, same for b.
+ *                          lcurve has 32770 entries (LUTf(32770, 0)), acurve / bcurve 65536; chroma = (chromaticity + 100) / 100.
+ *   artgpu_lab_to_rgb      the next setMode(RGB) = lab_to_rgb (imagefloat.cc:941-970), iws = the inverse working-space matrix.
+ * The reference runs all of them four pixels at a time with a scalar tail and the two forms round differently; the device follows the
+ * form of each pixel's column (and, for XYZ2Lab, of its group of four). */
+int artgpu_rgb_to_lab(artgpu_ctx *ctx, artgpu_rgb *img, const double ws[9]);
+int artgpu_lab_to_rgb(artgpu_ctx *ctx, artgpu_rgb *img, const double iws[9]);
+int artgpu_lab_histogram(artgpu_ctx *ctx, const artgpu_rgb *img, uint32_t hist[65536]);
+int artgpu_lab_adjustments(artgpu_ctx *ctx, artgpu_rgb *img, const float *lcurve, const float *acurve, const float *bcurve, float chroma);
+
 /* SURVEY section 8f N1, the parts of the output stage that are plain arithmetic (everything lcms2 evaluates stays on the host):
  * artgpu_rgb2out_matrix : ARTOutputProfile::operator()(const Imagefloat*, Imagefloat*), the matrix + TRC fast path of
  *                         ImProcFunctions::rgb2out for matrix output profiles (iprgb2out.cc:94-172,452-461).  matrix = the host's

@@ -76,6 +76,10 @@ int oracle_rgb2out_matrix(const float *const src[3], float *const dst[3], size_t
 void oracle_get_scanlines(const float *const img[3], size_t s, int w, int h, int bps, int is_float, void *out);
 void oracle_hsl_equalizer(float *const img[3], int W, int H, const double *hcurve, int nh, const double *scurve, int ns, const double *lcurve, int nl,
                           int smoothing, const double ws[9], double scale, int to_rgb);
+void oracle_image_rgb_to_lab(float *const img[3], int W, int H, const double ws[9]);
+void oracle_image_lab_to_rgb(float *const img[3], int W, int H, const double iws[9]);
+void oracle_lab_histogram(const float *L, int W, int H, unsigned hist[65536]);
+void oracle_lab_adjustments(float *const img[3], int W, int H, const float *lcurve, const float *acurve, const float *bcurve, float chroma);
 float oracle_logenc_find_gray(float source_gray, float target_gray);
 void oracle_log_encoding(float *const img[3], int W, int H, const double ws[9], double gain, double targetGray, double blackEv, double whiteEv,
                          int regularization, int satcontrol, int highlightCompression, int full_width, int full_height);

@@ -477,3 +477,47 @@ def log_encoding(img, ws=None, gain=0.0, target_gray=18.0, black_ev=-13.5, white
     L.oracle_log_encoding(_p3(out), w, h, wsd, float(gain), float(target_gray), float(black_ev), float(white_ev), int(regularization),
                           1 if satcontrol else 0, int(highlight_compression), int(full_width), int(full_height))
     return out
+
+
+def image_rgb_to_lab(img, ws=None):
+    """Imagefloat::rgb_to_lab (imagefloat.cc:841-876): returns [a, L, b] planes in the r, g, b slots."""
+    out = [np.ascontiguousarray(p, dtype=np.float32).copy() for p in img]
+    h, w = out[0].shape
+    wsd = (C.c_double * 9)(*[float(v) for v in np.asarray(REC2020_WS_D if ws is None else ws, dtype=np.float64).reshape(9)])
+    L = lib()
+    L.oracle_image_rgb_to_lab.argtypes = [C.POINTER(_fp), C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.oracle_image_rgb_to_lab.restype = None
+    L.oracle_image_rgb_to_lab(_p3(out), w, h, wsd)
+    return out
+
+
+def image_lab_to_rgb(img, iws):
+    out = [np.ascontiguousarray(p, dtype=np.float32).copy() for p in img]
+    h, w = out[0].shape
+    m = (C.c_double * 9)(*[float(v) for v in np.asarray(iws, dtype=np.float64).reshape(9)])
+    L = lib()
+    L.oracle_image_lab_to_rgb.argtypes = [C.POINTER(_fp), C.c_int, C.c_int, C.POINTER(C.c_double)]
+    L.oracle_image_lab_to_rgb.restype = None
+    L.oracle_image_lab_to_rgb(_p3(out), w, h, m)
+    return out
+
+
+def lab_histogram(Lplane):
+    Lp = np.ascontiguousarray(Lplane, dtype=np.float32)
+    hist = np.zeros(65536, np.uint32)
+    L = lib()
+    L.oracle_lab_histogram.argtypes = [_fp, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
+    L.oracle_lab_histogram.restype = None
+    L.oracle_lab_histogram(_ptr(Lp), Lp.shape[1], Lp.shape[0], hist.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return hist
+
+
+def lab_adjustments(img, lcurve, acurve, bcurve, chroma):
+    out = [np.ascontiguousarray(p, dtype=np.float32).copy() for p in img]
+    h, w = out[0].shape
+    cs = [np.ascontiguousarray(c, dtype=np.float32) for c in (lcurve, acurve, bcurve)]
+    L = lib()
+    L.oracle_lab_adjustments.argtypes = [C.POINTER(_fp), C.c_int, C.c_int, _fp, _fp, _fp, C.c_float]
+    L.oracle_lab_adjustments.restype = None
+    L.oracle_lab_adjustments(_p3(out), w, h, _ptr(cs[0]), _ptr(cs[1]), _ptr(cs[2]), C.c_float(chroma))
+    return out
