@@ -565,7 +565,19 @@ amaze_kernel(AmazeArgs a)
             for (int r = 0; r < NREG; ++r)
                 if ((zmask >> r) & 1u) {
                     float4 *A4 = reinterpret_cast<float4 *>(A + reg_off[r]);
-                    for (int i = tid; i < (reg_off[r + 1] - reg_off[r]) / 4; i += NTT) A4[i] = z;
+                    const int kf = a.zero_frame;
+                    if (kf > 0 && zmask != 0xffffffffu && r >= 4 && r <= 8) {
+                        // full-size float planes: only a frame of kf rows / columns (and the gap behind the plane) is read before it is written
+                        const int nrow4 = kf * ts / 4, tail0 = (ts - kf) * ts / 4, tail1 = (reg_off[r + 1] - reg_off[r]) / 4;
+                        for (int i = tid; i < nrow4; i += NTT) A4[i] = z;
+                        for (int i = tail0 + tid; i < tail1; i += NTT) A4[i] = z;
+                        float *P = A + reg_off[r];
+                        for (int i = tid; i < (ts - 2 * kf) * 2 * kf; i += NTT) {
+                            const int rr = kf + i / (2 * kf), c = i % (2 * kf);
+                            P[rr * ts + (c < kf ? c : ts - 2 * kf + c)] = 0.f;
+                        }
+                    } else
+                        for (int i = tid; i < (reg_off[r + 1] - reg_off[r]) / 4; i += NTT) A4[i] = z;
                 }
             if (tid == 0) { bbox[0] = 1 << 30; bbox[1] = 0; bbox[2] = ts + 1; bbox[3] = 0; }
         }

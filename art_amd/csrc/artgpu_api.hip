@@ -342,6 +342,9 @@ int artgpu_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, 
         // vcdalt, hcdalt, cddiffsq, nyquist (bits 4-8, 15).  Found by poisoning the arena and clearing all regions but one
         // (scripts/amaze_zmask.py; tests/test_gpu_demosaic.py re-checks it).  Partial edge tiles always clear everything.
         a.zero_mask = getenv("ARTGPU_AMAZE_ZMASK") ? (unsigned)strtoul(getenv("ARTGPU_AMAZE_ZMASK"), nullptr, 0) : 0x81f0u;
+        // ... and of the five full-size planes among them only positions within a few pixels of the tile edge (plus the gap behind each
+        // plane): a frame of 4 already passes the poison test, 16 (the discarded tile border) is used.  ARTGPU_AMAZE_ZFRAME=0: whole planes.
+        a.zero_frame = getenv("ARTGPU_AMAZE_ZFRAME") ? atoi(getenv("ARTGPU_AMAZE_ZFRAME")) : 16;
         if (getenv("ARTGPU_AMAZE_POISON"))   // test hook: fill the arenas with a byte pattern first
             HIPCHK(ctx, hipMemsetAsync(ctx->arena, (int)strtoul(getenv("ARTGPU_AMAZE_POISON"), nullptr, 0), (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float), ctx->stream));
         HIPCHK(ctx, launch_amaze(a, grid, ctx->stream));

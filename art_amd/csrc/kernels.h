@@ -29,6 +29,7 @@ struct AmazeArgs {
     float clip_pt, clip_pt8;
     int *bbox;          // 4 ints per arena: nyquist bounding box of the tile
     unsigned zero_mask;
+    int zero_frame;     // > 0: regions 4-8 of full tiles are cleared only in a frame of this many rows / columns
 };
 hipError_t launch_amaze(const AmazeArgs &a, int grid, hipStream_t stream);
 

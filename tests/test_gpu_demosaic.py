@@ -80,8 +80,9 @@ def test_errors(gpu_ctx):
 
 
 def test_amaze_selective_arena_clear_is_exact(gpu_ctx, monkeypatch):
-    """Only six of the 17 arena regions are cleared per full tile (artgpu_api.hip: zero_mask).  With the arenas pre-filled
-    with different byte patterns the result must not move: no other region is read before it is written."""
+    """Only six of the 17 arena regions are cleared per full tile (artgpu_api.hip: zero_mask), and of the five full-size planes among
+    them only a 16-pixel frame (zero_frame).  With the arenas pre-filled with different byte patterns the result must not move: nothing
+    else is read before it is written."""
     from art_amd import capi
     w, h, filt = 1152, 896, synth.FILTERS_RGGB
     raw = synth.bayer_frame(w, h, filt, seed=21, noise=3000)
