@@ -107,64 +107,118 @@ __device__ __forceinline__ void lab2rgb_dev(const DnPixArgs &a, float l, float l
 }
 
 // ---------------------------------------------------------------- RGB -> gamma -> YUV (FTblockDN.cc:2084-2128)
+// Two launch shapes of each pixel pass: the plain 2-D grid, and (large frames, gamma LUT in use) one persistent 1024-thread
+// workgroup per CU with the lower part of the 65536-entry gamma LUT in LDS (lutf_lookup_lds): 0.61 -> ~0.35 ms at 45 MP.
+template <bool LDS>
+__device__ __forceinline__ float gam_lookup(const float *lds, const float *__restrict__ lut, float v)
+{
+    return LDS ? lutf_lookup_lds<false>(lds, lut, 65536, v) : lutf_lookup<false>(lut, 65536, v);
+}
+template <bool LDS>
+__device__ __forceinline__ void rgb2yuv_px(const DnPixArgs &a, const float *lds, int y, int x, float r0, float g0, float b0)
+{
+    const long long t = (long long)y * a.w + x;
+    if (a.pre_scale != 0.f) {   // fused ImProcFunctions::expcomp(+ecomp) (ipexposure.cc:56-70): 4-lane groups then scalar tail
+        if (x < (a.w / 4) * 4) { r0 = sse_max(r0 * a.pre_scale - 0.f, 0.f); g0 = sse_max(g0 * a.pre_scale - 0.f, 0.f); b0 = sse_max(b0 * a.pre_scale - 0.f, 0.f); }
+        else { r0 = std_max(r0 * a.pre_scale - 0.f, 0.f); g0 = std_max(g0 * a.pre_scale - 0.f, 0.f); b0 = std_max(b0 * a.pre_scale - 0.f, 0.f); }
+    }
+    float X = a.gain * r0, Y = a.gain * g0, Z = a.gain * b0;
+    if (a.lab_mode) { X = lutf_noclip(a.dn_igamma, X); Y = lutf_noclip(a.dn_igamma, Y); Z = lutf_noclip(a.dn_igamma, Z); }   // L2094-2098
+    if (a.gam > 1.f) {
+        if (X > 0.f) X = X < 65535.f ? gam_lookup<LDS>(lds, a.gamcurve, X) : (gammaf_s(X / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
+        if (Y > 0.f) Y = Y < 65535.f ? gam_lookup<LDS>(lds, a.gamcurve, Y) : (gammaf_s(Y / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
+        if (Z > 0.f) Z = Z < 65535.f ? gam_lookup<LDS>(lds, a.gamcurve, Z) : (gammaf_s(Z / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
+    }
+    float l = X * a.ws1[0] + Y * a.ws1[1] + Z * a.ws1[2];
+    float va = X - l, ub = l - Z;   // v -> labdn->a, u -> labdn->b
+    if (a.lab_mode) rgb2lab_dev(a, X, Y, Z, l, va, ub);    // rgb2lab(X, Y, Z, l, v, u, wpi), L2114-2116
+    a.L[t] = l;
+    a.A[t] = va;
+    a.B[t] = ub;
+}
 __global__ void __launch_bounds__(256) rgb2yuv_kernel(DnPixArgs a)
 {
     FOR_IMAGE_XY(y, x, a.w, a.h) {
-        const long long t = (long long)y * a.w + x;
         const size_t si = (size_t)y * a.stride + x;
-        float r0 = a.rgb[0][si], g0 = a.rgb[1][si], b0 = a.rgb[2][si];
-        if (a.pre_scale != 0.f) {   // fused ImProcFunctions::expcomp(+ecomp) (ipexposure.cc:56-70): 4-lane groups then scalar tail
-            if (x < (a.w / 4) * 4) { r0 = sse_max(r0 * a.pre_scale - 0.f, 0.f); g0 = sse_max(g0 * a.pre_scale - 0.f, 0.f); b0 = sse_max(b0 * a.pre_scale - 0.f, 0.f); }
-            else { r0 = std_max(r0 * a.pre_scale - 0.f, 0.f); g0 = std_max(g0 * a.pre_scale - 0.f, 0.f); b0 = std_max(b0 * a.pre_scale - 0.f, 0.f); }
-        }
-        float X = a.gain * r0, Y = a.gain * g0, Z = a.gain * b0;
-        if (a.lab_mode) { X = lutf_noclip(a.dn_igamma, X); Y = lutf_noclip(a.dn_igamma, Y); Z = lutf_noclip(a.dn_igamma, Z); }   // L2094-2098
-        if (a.gam > 1.f) {
-            if (X > 0.f) X = X < 65535.f ? lutf_lookup<false>(a.gamcurve, 65536, X) : (gammaf_s(X / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
-            if (Y > 0.f) Y = Y < 65535.f ? lutf_lookup<false>(a.gamcurve, 65536, Y) : (gammaf_s(Y / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
-            if (Z > 0.f) Z = Z < 65535.f ? lutf_lookup<false>(a.gamcurve, 65536, Z) : (gammaf_s(Z / 65535.f, a.gam, a.gamthresh, a.gamslope) * 65535.f);
-        }
-        float l = X * a.ws1[0] + Y * a.ws1[1] + Z * a.ws1[2];
-        float va = X - l, ub = l - Z;   // v -> labdn->a, u -> labdn->b
-        if (a.lab_mode) rgb2lab_dev(a, X, Y, Z, l, va, ub);    // rgb2lab(X, Y, Z, l, v, u, wpi), L2114-2116
-        a.L[t] = l;
-        a.A[t] = va;
-        a.B[t] = ub;
+        rgb2yuv_px<false>(a, nullptr, y, x, a.rgb[0][si], a.rgb[1][si], a.rgb[2][si]);
     }
+}
+__global__ void __launch_bounds__(1024) rgb2yuv_lds_kernel(DnPixArgs a)
+{
+    extern __shared__ float dn_lut_lds[];
+    lut_lds_fill(dn_lut_lds, a.gamcurve, 1024);
+    for (int y = blockIdx.x; y < a.h; y += gridDim.x)
+        for (int x0 = 0; x0 < a.w; x0 += 4096) {
+            float r[4], g[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = x0 + k * 1024 + (int)threadIdx.x;
+                const size_t si = (size_t)y * a.stride + (x < a.w ? x : a.w - 1);
+                r[k] = a.rgb[0][si]; g[k] = a.rgb[1][si]; b[k] = a.rgb[2][si];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = x0 + k * 1024 + (int)threadIdx.x;
+                if (x < a.w) rgb2yuv_px<true>(a, dn_lut_lds, y, x, r[k], g[k], b[k]);
+            }
+        }
 }
 
 // ---------------------------------------------------------------- YUV -> inverse gamma -> RGB (FTblockDN.cc:2502-2550)
+template <bool LDS>
+__device__ __forceinline__ void yuv2rgb_px(const DnPixArgs &a, const float *lds, int y, int x, float Lv, float av, float bv)
+{
+    const float c_h = sqrtf(sqr(av) + sqr(bv));
+    if (c_h > 3000.f) {
+        av *= 1.f + a.qhighFactor * a.realred / 100.f;
+        bv *= 1.f + a.qhighFactor * a.realblue / 100.f;
+    }
+    float Z = Lv - bv;
+    float X = av + Lv;
+    float Y = (Lv - X * a.ws1[0] - Z * a.ws1[2]) / a.ws1[1];
+    if (a.lab_mode) lab2rgb_dev(a, Lv, av, bv, X, Y, Z);    // L2522-2524
+    if (a.gam > 1.f) {
+        if (X > 0.f) X = X < 65536.f ? gam_lookup<LDS>(lds, a.igamcurve, X) : (gammaf_s(X / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
+        if (Y > 0.f) Y = Y < 65536.f ? gam_lookup<LDS>(lds, a.igamcurve, Y) : (gammaf_s(Y / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
+        if (Z > 0.f) Z = Z < 65536.f ? gam_lookup<LDS>(lds, a.igamcurve, Z) : (gammaf_s(Z / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
+    }
+    const size_t di = (size_t)y * a.stride + x;
+    if (a.lab_mode) { X = lutf_noclip(a.dn_gamma, X); Y = lutf_noclip(a.dn_gamma, Y); Z = lutf_noclip(a.dn_gamma, Z); }   // L2533-2537
+    float ro = a.newGain * X, go = a.newGain * Y, bo = a.newGain * Z;
+    if (a.post_scale != 0.f) {  // fused ImProcFunctions::expcomp(-ecomp)
+        if (x < (a.w / 4) * 4) { ro = sse_max(ro * a.post_scale - 0.f, 0.f); go = sse_max(go * a.post_scale - 0.f, 0.f); bo = sse_max(bo * a.post_scale - 0.f, 0.f); }
+        else { ro = std_max(ro * a.post_scale - 0.f, 0.f); go = std_max(go * a.post_scale - 0.f, 0.f); bo = std_max(bo * a.post_scale - 0.f, 0.f); }
+    }
+    a.rgb[0][di] = ro;
+    a.rgb[1][di] = go;
+    a.rgb[2][di] = bo;
+}
 __global__ void __launch_bounds__(256) yuv2rgb_kernel(DnPixArgs a)
 {
     FOR_IMAGE_XY(y, x, a.w, a.h) {
         const long long t = (long long)y * a.w + x;
-        float av = a.A[t], bv = a.B[t];
-        const float Lv = a.L[t];
-        const float c_h = sqrtf(sqr(av) + sqr(bv));
-        if (c_h > 3000.f) {
-            av *= 1.f + a.qhighFactor * a.realred / 100.f;
-            bv *= 1.f + a.qhighFactor * a.realblue / 100.f;
-        }
-        float Z = Lv - bv;
-        float X = av + Lv;
-        float Y = (Lv - X * a.ws1[0] - Z * a.ws1[2]) / a.ws1[1];
-        if (a.lab_mode) lab2rgb_dev(a, Lv, av, bv, X, Y, Z);    // L2522-2524
-        if (a.gam > 1.f) {
-            if (X > 0.f) X = X < 65536.f ? lutf_lookup<false>(a.igamcurve, 65536, X) : (gammaf_s(X / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
-            if (Y > 0.f) Y = Y < 65536.f ? lutf_lookup<false>(a.igamcurve, 65536, Y) : (gammaf_s(Y / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
-            if (Z > 0.f) Z = Z < 65536.f ? lutf_lookup<false>(a.igamcurve, 65536, Z) : (gammaf_s(Z / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
-        }
-        const size_t di = (size_t)y * a.stride + x;
-        if (a.lab_mode) { X = lutf_noclip(a.dn_gamma, X); Y = lutf_noclip(a.dn_gamma, Y); Z = lutf_noclip(a.dn_gamma, Z); }   // L2533-2537
-        float ro = a.newGain * X, go = a.newGain * Y, bo = a.newGain * Z;
-        if (a.post_scale != 0.f) {  // fused ImProcFunctions::expcomp(-ecomp)
-            if (x < (a.w / 4) * 4) { ro = sse_max(ro * a.post_scale - 0.f, 0.f); go = sse_max(go * a.post_scale - 0.f, 0.f); bo = sse_max(bo * a.post_scale - 0.f, 0.f); }
-            else { ro = std_max(ro * a.post_scale - 0.f, 0.f); go = std_max(go * a.post_scale - 0.f, 0.f); bo = std_max(bo * a.post_scale - 0.f, 0.f); }
-        }
-        a.rgb[0][di] = ro;
-        a.rgb[1][di] = go;
-        a.rgb[2][di] = bo;
+        yuv2rgb_px<false>(a, nullptr, y, x, a.L[t], a.A[t], a.B[t]);
     }
+}
+__global__ void __launch_bounds__(1024) yuv2rgb_lds_kernel(DnPixArgs a)
+{
+    extern __shared__ float dn_lut_lds[];
+    lut_lds_fill(dn_lut_lds, a.igamcurve, 1024);
+    for (int y = blockIdx.x; y < a.h; y += gridDim.x)
+        for (int x0 = 0; x0 < a.w; x0 += 4096) {
+            float l[4], av[4], bv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = x0 + k * 1024 + (int)threadIdx.x;
+                const long long t = (long long)y * a.w + (x < a.w ? x : a.w - 1);
+                l[k] = a.L[t]; av[k] = a.A[t]; bv[k] = a.B[t];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = x0 + k * 1024 + (int)threadIdx.x;
+                if (x < a.w) yuv2rgb_px<true>(a, dn_lut_lds, y, x, l[k], av[k], bv[k]);
+            }
+        }
 }
 
 // ---------------------------------------------------------------- MadRgb (FTblockDN.cc:569-603)
@@ -564,13 +618,38 @@ hipError_t launch_gamma_lut(float *lut, float gamma, float start, float slope, f
     hipLaunchKernelGGL(gamma_lut_kernel, dim3(256), dim3(256), 0, s, lut, gamma, start, slope, divisor, factor);
     return hipGetLastError();
 }
+// the LDS-table shape: large frames with the gamma LUTs in use (their pool memory is 16-byte aligned)
+static bool dn_lds_shape(const DnPixArgs &a, const float *lut, int *cus)
+{
+    if (a.lab_mode || !(a.gam > 1.f) || (long long)a.w * a.h < (1 << 22) || (reinterpret_cast<uintptr_t>(lut) & 15) || getenv("ARTGPU_DN_NOLDS")) return false;
+    int dev = 0;
+    *cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return true;
+}
 hipError_t launch_rgb2yuv(const DnPixArgs &a, hipStream_t s)
 {
+    int cus;
+    if (dn_lds_shape(a, a.gamcurve, &cus)) {
+        const size_t lds = (size_t)LUT_LDS_N * sizeof(float);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(rgb2yuv_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(rgb2yuv_lds_kernel, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(rgb2yuv_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_yuv2rgb(const DnPixArgs &a, hipStream_t s)
 {
+    int cus;
+    if (dn_lds_shape(a, a.igamcurve, &cus)) {
+        const size_t lds = (size_t)LUT_LDS_N * sizeof(float);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(yuv2rgb_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(yuv2rgb_lds_kernel, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(yuv2rgb_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -186,4 +186,33 @@ __device__ __forceinline__ float lutf_lookup(const float *__restrict__ data, int
     return p1 + p2 * diff;
 }
 
+// The same lookup with entries [0, LUT_LDS_N) of the table resident in LDS (`lds`), the rest read from `data` as before.  A 65536-entry
+// table (256 KB) does not fit L1, so each lookup of a streaming kernel is otherwise an L2 line gather; linear scene data sit mostly in
+// the lower part of the range.  159 KB of the CU's 160 KB LDS: one workgroup per CU.
+constexpr int LUT_LDS_N = 40704;
+template <bool CLIP_ABOVE>
+__device__ __forceinline__ float lutf_lookup_lds(const float *lds, const float *__restrict__ data, int size, float index)
+{
+    const int maxs = size - 2;
+    if (index < 0.f || !(index == index)) return lds[0];
+    int idx = (int)index;
+    if (index > (float)maxs) {
+        if (CLIP_ABOVE) return data[size - 1];
+        idx = maxs;
+    }
+    const float diff = index - (float)idx;
+    float p1, q;
+    if (idx + 1 < LUT_LDS_N) { p1 = lds[idx]; q = lds[idx + 1]; }
+    else { p1 = data[idx]; q = data[idx + 1]; }
+    const float p2 = q - p1;
+    return p1 + p2 * diff;
+}
+__device__ __forceinline__ void lut_lds_fill(float *lds, const float *__restrict__ data, int nthreads)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(data);
+    float4 *dst = reinterpret_cast<float4 *>(lds);
+    for (int i = threadIdx.x; i < LUT_LDS_N / 4; i += nthreads) dst[i] = src[i];
+    __syncthreads();
+}
+
 } // namespace artgpu

@@ -116,6 +116,39 @@ __global__ void __launch_bounds__(256) tone_std_kernel(PixArgs a)
     }
 }
 
+// The same with the lower LUT_LDS_N entries of the curve resident in LDS (lutf_lookup_lds, devsleef.h; 159 KB of the CU's 160 KB): the 65536-entry LUT
+// (256 KB) does not fit L1, so every lookup of the kernel above is an L2 line gather (6 per pixel, ~1.5 TB/s effective); linear
+// scene data sit mostly in the lower part of the range, and those lookups become LDS reads.  Entries above come from L2 as before.
+// One persistent workgroup of 1024 threads per CU, rows strided over the workgroups.
+__global__ void __launch_bounds__(1024) tone_std_lds_kernel(PixArgs a)
+{
+    extern __shared__ float tone_lds[];
+    lut_lds_fill(tone_lds, a.lut, 1024);
+    const float Lmax = 65535.f * a.whitept;
+    for (int y = blockIdx.x; y < a.h; y += gridDim.x)
+        for (int x0 = 0; x0 < a.w; x0 += 4096) {
+            float r[4], g[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = x0 + k * 1024 + (int)threadIdx.x;
+                const size_t di = (size_t)y * a.dst_stride + (x < a.w ? x : a.w - 1);
+                r[k] = a.dst[0][di]; g[k] = a.dst[1][di]; b[k] = a.dst[2][di];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = x0 + k * 1024 + (int)threadIdx.x;
+                if (x >= a.w) continue;
+                const size_t di = (size_t)y * a.dst_stride + x;
+                float rr = r[k], gg = g[k], bb = b[k];
+                if (a.do_clip) filmlike_clip_px(rr, gg, bb, Lmax);
+                rr = lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(rr, 0.f));
+                gg = lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(gg, 0.f));
+                bb = lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(bb, 0.f));
+                a.dst[0][di] = rr; a.dst[1][di] = gg; a.dst[2][di] = bb;
+            }
+        }
+}
+
 // Imagefloat::setMode RGB -> YUV (imagefloat.cc:700-725: Y -> g plane, u = Y-b -> b plane, v = r-Y -> r plane) and
 // YUV -> RGB (L779-804), float working-space row ws_[1][*]; in place.  a.do_clip: 0 = to YUV, 1 = to RGB.
 __global__ void __launch_bounds__(256) yuv_mode_kernel(PixArgs a)
@@ -356,6 +389,16 @@ hipError_t launch_yuv_mode(const PixArgs &a, hipStream_t s)
 }
 hipError_t launch_tone_std(const PixArgs &a, hipStream_t s)
 {
+    // large frames with a curve: the LDS-resident variant (the curve pointer is 16-byte aligned: pool or hipMalloc memory)
+    if (a.lut && (long long)a.w * a.h >= (1 << 22) && (reinterpret_cast<uintptr_t>(a.lut) & 15) == 0 && !getenv("ARTGPU_TONE_NOLDS")) {
+        const size_t lds = (size_t)LUT_LDS_N * sizeof(float);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tone_std_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        hipLaunchKernelGGL(tone_std_lds_kernel, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(tone_std_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -202,11 +202,29 @@ def main() -> None:
     # launch of the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command, committed under
     # profiles/ (KB units; uncorrected -- the kernel's accesses are 4 B per lane, see profiles/r1/README.md)
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r1", "amaze_v15_pmc_summary.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r1", "amaze_final_pmc_summary.json")
     if method == capi.BAYER_AMAZE and not xtrans and (W, H) == (W45, H45) and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
         traffic = int((pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024)
-        traffic_src = "profiles/r1/amaze_v15_pmc_summary.json"
+        traffic_src = "profiles/r1/amaze_final_pmc_summary.json"
+
+    # measured device-copy bandwidth in the same run (the practical HBM ceiling next to the 8 TB/s datasheet peak):
+    # a 716 MB device-to-device copy, read + write bytes over its HIP-event time
+    copy_gbs = None
+    if rank == 0:
+        nb = W * H * 4
+        src_t = torch.empty(nb, dtype=torch.float32, device=dev).normal_()
+        dst_t = torch.empty_like(src_t)
+        ce = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        for _ in range(2):
+            dst_t.copy_(src_t)
+        ce[0].record()
+        for _ in range(5):
+            dst_t.copy_(src_t)
+        ce[1].record()
+        torch.cuda.synchronize(dev)
+        copy_gbs = 5 * 2 * nb * 4 / 1e9 / (ce[0].elapsed_time(ce[1]) / 1e3)
+        del src_t, dst_t
 
     result = {
         "metric": ("megapixels/sec end-to-end (X-Trans+FTblockDN+tone), 100 MP X-Trans" if xtrans else
@@ -239,6 +257,8 @@ def main() -> None:
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
             "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": W * H * ALGO_BYTES_PER_PX,
+            "device_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
+            "traffic_rate_frac_of_copy": None if (copy_gbs is None or traffic is None) else round(traffic / 1e9 / (kern_ms / 1e3) / copy_gbs, 4),
         },
     }
 

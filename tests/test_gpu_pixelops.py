@@ -187,3 +187,26 @@ def test_rgb2out_fast_path_and_scanlines_bit_exact(gpu_ctx):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
         else:
             assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("w,h,clip", [(2304, 1900, True), (4099, 1031, False)])
+def test_tone_std_large_frame_lds_curve_bit_exact(gpu_ctx, monkeypatch, w, h, clip):
+    """frames of >= 4 Mpx take the kernel that keeps the lower 40704 curve entries in LDS: values on both sides of that split, at the
+    curve's ends, negative, above 65535 and NaN; same bits as the oracle and as the plain kernel (ARTGPU_TONE_NOLDS)"""
+    from art_amd import capi
+    import oracle_lib as O
+    rng = np.random.default_rng(w)
+    img = [rng.uniform(-2000, 70000, (h, w)).astype(np.float32) for _ in range(3)]
+    img[0][0, :8] = [40702.5, 40703.0, 40703.5, 40704.0, 65534.0, 65534.5, 65535.0, np.nan]
+    img[1][1, :4] = [0.0, -0.0, 1e-30, 3e38]
+    x = np.arange(65536, dtype=np.float64) / 65535.0
+    lut = ((1.0 - np.cos(np.pi * x ** 0.7)) / 2.0 * 65535.0 + rng.normal(0, 3, x.size)).astype(np.float32)
+    ref = O.tone_std(img, lut, 1.0, clip)
+    got = [p.copy() for p in img]
+    gpu_ctx.tone_curve(capi.host_rgb(got), lut, 1.0, clip)
+    monkeypatch.setenv("ARTGPU_TONE_NOLDS", "1")
+    plain = [p.copy() for p in img]
+    gpu_ctx.tone_curve(capi.host_rgb(plain), lut, 1.0, clip)
+    for g, p, r in zip(got, plain, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+        assert np.array_equal(p.view(np.uint32), r.view(np.uint32))
