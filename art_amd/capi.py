@@ -148,6 +148,7 @@ def _load():
     lib.artgpu_lab_to_rgb.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double)]
     lib.artgpu_lab_histogram.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_uint32)]
     lib.artgpu_lab_adjustments.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float]
+    lib.artgpu_dual_demosaic_bayer.argtypes = [C.c_void_p, C.c_int, C.POINTER(Plane), C.c_uint32, C.c_double, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(RGB)]
     lib.artgpu_channel_mixer.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float)]
     lib.artgpu_rgb_curves.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_pipeline_run.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
@@ -175,7 +176,7 @@ EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_versi
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter", "artgpu_hsl_equalizer", "artgpu_log_encoding", "artgpu_rgb_to_lab", "artgpu_lab_to_rgb", "artgpu_lab_histogram", "artgpu_lab_adjustments"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter", "artgpu_hsl_equalizer", "artgpu_log_encoding", "artgpu_rgb_to_lab", "artgpu_lab_to_rgb", "artgpu_lab_histogram", "artgpu_lab_adjustments", "artgpu_dual_demosaic_bayer"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -361,6 +362,12 @@ class Context:
         keep = [np.ascontiguousarray(c, dtype=np.float32) for c in (lcurve, acurve, bcurve)]
         assert keep[0].size == 32770 and keep[1].size == 65536 and keep[2].size == 65536
         self._chk(LIB.artgpu_lab_adjustments(self._h, C.byref(image), *[k.ctypes.data_as(C.POINTER(C.c_float)) for k in keep], float(chroma)))
+
+    def dual_demosaic_bayer(self, method: int, raw: Plane, filters: int, initial_gain: float, border: int, contrast: float, auto_contrast: bool, out: RGB):
+        """returns the contrast threshold in percent (searched when auto_contrast)"""
+        c = C.c_double(float(contrast))
+        self._chk(LIB.artgpu_dual_demosaic_bayer(self._h, method, C.byref(raw), filters, float(initial_gain), border, C.byref(c), 1 if auto_contrast else 0, C.byref(out)))
+        return c.value
 
     def channel_mixer(self, image: RGB, m):
         self._chk(LIB.artgpu_channel_mixer(self._h, C.byref(image), (C.c_float * 9)(*[float(v) for v in np.asarray(m, np.float32).reshape(9)])))

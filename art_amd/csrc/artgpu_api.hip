@@ -297,8 +297,10 @@ size_t artgpu_scratch_bytes(const artgpu_ctx *ctx)
     return s;
 }
 
-int artgpu_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, uint32_t filters,
-                          double initial_gain, int border, artgpu_rgb *out)
+struct DualReq { double *contrast; int auto_contrast; };
+static int dual_blend_dev(artgpu_ctx *ctx, const DevImage &d, int W, int H, uint32_t filters, DualReq *req);
+static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *raw, uint32_t filters,
+                               double initial_gain, int border, artgpu_rgb *out, DualReq *dual)
 {
     if (!ctx) return ARTGPU_EINVAL;
     if (!plane_ok(raw) || !out) return fail(ctx, ARTGPU_EINVAL, "demosaic_bayer: bad raw plane or null output");
@@ -368,6 +370,7 @@ int artgpu_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, 
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     rc = launch_border(ctx, d, W, H, filters, bord);
     if (rc) return rc;
+    if (dual && (rc = dual_blend_dev(ctx, d, W, H, filters, dual))) return rc;
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     rc = unbind_images(ctx, out, &d);
     if (rc) return rc;
@@ -378,6 +381,21 @@ int artgpu_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, 
         HIPCHK(ctx, hipEventElapsedTime(&ctx->last.total_ms, ctx->ev[0], ctx->ev[2]));
     }
     return ARTGPU_OK;
+}
+int artgpu_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, uint32_t filters,
+                          double initial_gain, int border, artgpu_rgb *out)
+{
+    return demosaic_bayer_impl(ctx, method, raw, filters, initial_gain, border, out, nullptr);
+}
+int artgpu_dual_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, uint32_t filters, double initial_gain, int border,
+                               double *contrast, int auto_contrast, artgpu_rgb *out)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!contrast || !(*contrast >= 0.0)) return fail(ctx, ARTGPU_EINVAL, "dual_demosaic_bayer: contrast must be >= 0");
+    if (raw && (raw->w < 96 || raw->h < 96)) return fail(ctx, ARTGPU_EUNSUPPORTED, "dual_demosaic_bayer: image smaller than 96x96");
+    DualReq req = {contrast, auto_contrast};
+    // contrast == 0 without the automatic threshold: only the first demosaicer runs (dual_demosaic_RT.cc:43-71)
+    return demosaic_bayer_impl(ctx, method, raw, filters, initial_gain, border, out, (*contrast == 0.0 && !auto_contrast) ? nullptr : &req);
 }
 
 int artgpu_border_interpolate2(artgpu_ctx *ctx, const artgpu_plane *raw, uint32_t filters, int lborders, artgpu_rgb *out)
@@ -1072,6 +1090,77 @@ int artgpu_guided_filter(artgpu_ctx *ctx, const artgpu_plane *guide, const artgp
 }
 
 static int lab_tabs_dev(artgpu_ctx *ctx, float **tabs_out);
+// dual_demosaic_RT.cc:99-152 after the first demosaicer: L, buildBlendMask (rt_algo.cc:315-498), bilinear blend
+static int dual_blend_dev(artgpu_ctx *ctx, const DevImage &d, int W, int H, uint32_t filters, DualReq *req)
+{
+    const size_t n = (size_t)W * H;
+    float *tabs, *L, *blend, *var;
+    int rc;
+    if ((rc = lab_tabs_dev(ctx, &tabs)) || (rc = pool_get(ctx, P_DMASK, n * 4, &L)) || (rc = pool_get(ctx, P_CCMAP, n * 4, &blend))) return rc;
+    DualArgs a = {};
+    a.rgb[0] = d.r; a.rgb[1] = d.g; a.rgb[2] = d.b; a.stride = d.out_stride;
+    a.raw = d.raw; a.raw_stride = d.raw_stride; a.w = W; a.h = H; a.filters = filters;
+    a.cachefy = tabs + 65536; a.L = L; a.blend = blend;
+    HIPCHK(ctx, launch_rgb2l(a, ctx->stream));
+    float thr = (float)(*req->contrast / 100.0);
+    if (req->auto_contrast) {
+        // the reference's two-pass search for the flattest tile (rt_algo.cc:317-432): tile statistics on the device, the serial
+        // first-minimum scan over them on the host
+        std::vector<float> host;
+        float *res;
+        auto stats = [&](int nH, int nW, int y0, int x0, int step, int ts, int *mi, int *mj, float *minvar) -> int {
+            *mi = *mj = 0; *minvar = INFINITY;
+            if (nH <= 0 || nW <= 0) return ARTGPU_OK;
+            const size_t cnt = (size_t)nH * nW;
+            int rc2 = pool_get(ctx, P_TMP, cnt * 4, &var);
+            if (rc2) return rc2;
+            HIPCHK(ctx, launch_tile_stats(a, nH, nW, y0, x0, step, ts, var, ctx->stream));
+            host.resize(cnt);
+            HIPCHK(ctx, hipMemcpyAsync(host.data(), var, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            for (int i = 0; i < nH; ++i)
+                for (int j = 0; j < nW; ++j)
+                    if (host[(size_t)i * nW + j] < *minvar) { *minvar = host[(size_t)i * nW + j]; *mi = i; *mj = j; }
+            return ARTGPU_OK;
+        };
+        auto threshold_of = [&](int ty, int tx, int ts, float *out_thr) -> int {
+            int rc2 = pool_get(ctx, P_MAD, 64, &res);
+            if (rc2) return rc2;
+            HIPCHK(ctx, launch_contrast_threshold(a, ty, tx, ts, res, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(out_thr, res, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            return ARTGPU_OK;
+        };
+        for (int pass = 0; pass < 2; ++pass) {
+            const int ts = 80 / (pass + 1), skip = pass == 0 ? ts : ts / 4;
+            const int nW = W / skip - 3 * pass, nH = H / skip - 3 * pass;
+            int mi, mj; float minvar;
+            if ((rc = stats(nH, nW, 0, 0, skip, ts, &mi, &mj, &minvar))) return rc;
+            if (minvar <= 1.f || pass == 1) {
+                const int minY = skip * mi, minX = skip * mj;
+                if (pass == 0) {
+                    if ((rc = threshold_of(minY, minX, ts, &thr))) return rc;
+                    break;
+                }
+                const int y0 = std::max(minY - skip, 0), x0 = std::max(minX - skip, 0);
+                const int y1 = std::min(minY + skip, H - ts), x1 = std::min(minX + skip, W - ts);
+                int mi2, mj2; float minvar2;
+                if ((rc = stats(y1 - y0 + 1, x1 - x0 + 1, y0, x0, 1, ts, &mi2, &mj2, &minvar2))) return rc;
+                if (minvar2 <= 8.f) { if ((rc = threshold_of(y0 + mi2, x0 + mj2, ts, &thr))) return rc; }
+                else thr = 0.f;
+            }
+        }
+    }
+    *req->contrast = thr * 100.f;
+    a.threshold = thr;
+    HIPCHK(ctx, launch_blend_mask(a, ctx->stream));
+    if (thr != 0.f) {
+        artgpu_plane bp = {blend, W, H, (int64_t)W * 4, 1};
+        if ((rc = artgpu_gaussian_blur(ctx, &bp, 2.0))) return rc;      // rt_algo.cc:492
+    }
+    HIPCHK(ctx, launch_bilinear_blend(a, ctx->stream));
+    return ARTGPU_OK;
+}
 static int lab_mode_switch(artgpu_ctx *ctx, artgpu_rgb *img, const double m[9], bool to_lab, const char *who)
 {
     if (!ctx) return ARTGPU_EINVAL;

@@ -170,6 +170,20 @@ hipError_t launch_rgb_to_lab(const LabArgs &a, hipStream_t s);
 hipError_t launch_lab_to_rgb(const LabArgs &a, hipStream_t s);
 hipError_t launch_lab_hist(const LabArgs &a, hipStream_t s);
 hipError_t launch_lab_adjust(const LabArgs &a, hipStream_t s);
+// ---- dual demosaic blend (dualdemosaic.hip; dual_demosaic_RT.cc:73-152, rt_algo.cc:315-498) ----
+struct DualArgs {
+    float *rgb[3]; size_t stride;                // first demosaicer's output, blended in place
+    const float *raw; size_t raw_stride;
+    int w, h; unsigned filters;
+    const float *cachefy;
+    float *L, *blend;                            // w*h each
+    float threshold;
+};
+hipError_t launch_rgb2l(const DualArgs &a, hipStream_t s);
+hipError_t launch_blend_mask(const DualArgs &a, hipStream_t s);
+hipError_t launch_tile_stats(const DualArgs &a, int nH, int nW, int y0, int x0, int step, int ts, float *var, hipStream_t s);
+hipError_t launch_contrast_threshold(const DualArgs &a, int ty, int tx, int ts, float *result, hipStream_t s);
+hipError_t launch_bilinear_blend(const DualArgs &a, hipStream_t s);
 // ---- logEncoding (logenc.hip; iplogenc.cc:132-316) ----
 struct LogEncArgs {
     float *img[3]; size_t stride; int w, h;

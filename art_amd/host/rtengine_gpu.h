@@ -76,7 +76,9 @@ public:
 
 // The fields of ProcParams the path reads (procparams.cc:1528-3335 for the defaults)
 struct ProcParams {
-    struct { int method = ARTGPU_BAYER_AMAZE; int border = 4; } bayersensor;  // raw.bayersensor.{method,border}
+    // raw.bayersensor.{method,border,dualDemosaicContrast,dualDemosaicAutoContrast}; dual = the AMAZEBILINEAR / RCDBILINEAR methods
+    // (first demosaicer `method`, bilinear in flat regions; rawimagesource.cc:1876-1886 -> dual_demosaic_RT)
+    struct { int method = ARTGPU_BAYER_AMAZE; int border = 4; bool dual = false; double dualDemosaicContrast = 20; bool dualDemosaicAutoContrast = true; } bayersensor;
     enum XTransMethod { ONE_PASS = 1, THREE_PASS = 3 };
     struct { int method = THREE_PASS; int border = 7; } xtranssensor;          // raw.xtranssensor.{method,border} (procparams.cc:3064)
     struct { bool enabled = false; double luminance = 0, luminanceDetail = 0; int luminanceDetailThreshold = 0; double chrominance = 15,
@@ -126,8 +128,15 @@ public:
             ctx.check(artgpu_demosaic_xtrans(ctx.get(), passes, passes > 1 ? 1 : 0, &raw, xtrans, rgb_cam, &out));
             return;
         }
+        if (p.bayersensor.dual) {       // `contrast` comes back as the threshold in use (the reference's `double &contrast`)
+            dualDemosaicContrastUsed = p.bayersensor.dualDemosaicContrast;
+            ctx.check(artgpu_dual_demosaic_bayer(ctx.get(), p.bayersensor.method, &raw, filters, initialGain, border, &dualDemosaicContrastUsed,
+                                                 p.bayersensor.dualDemosaicAutoContrast ? 1 : 0, &out));
+            return;
+        }
         ctx.check(artgpu_demosaic_bayer(ctx.get(), p.bayersensor.method, &raw, filters, initialGain, border, &out));
     }
+    double dualDemosaicContrastUsed = 0;
     void getFullSize(int &w, int &h) const { w = W - 2 * border; h = H - 2 * border; }   // computeFullSize (L1163-1193), tran = 0
     // RawImageSource::getImage (rawimagesource.cc:781-1104): tran = 0, skip = 1; rm/gm/bm as the caller computed them
     void getImage(const float mul[3], bool doClip, Imagefloat *image, int x = 0, int y = 0, int skip = 1)

@@ -44,6 +44,9 @@ def main() -> None:
                     help="frames in flight per GPU (each on its own context, stream and host thread; a step is then `lanes` frames). "
                          "Default 1 = BASELINE's one frame per GPU; 3 gives +11 %% throughput at 45 MP (independent frames fill each "
                          "other's latency gaps).  Pipeline workloads only.")
+    ap.add_argument("--tone", default="std", choices=["std", "neutral"],
+                    help="tone-curve mode of the last stage: STD (3 LUT lookups per pixel; the headline line) or NEUTRAL, ART's default mode "
+                         "(Jzazbz hue-preserving curve, curves.cc:854-1038)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     args = ap.parse_args()
@@ -88,6 +91,7 @@ def main() -> None:
         mul = (2.1374, 1.0, 1.5918)                            # rm, gm, bm of a daylight WB
         mat = np.array([[0.6325, 0.2312, 0.0921], [0.2198, 0.7712, 0.0090], [0.0166, 0.0713, 0.7514]])  # raw -> Rec2020
         ws = np.array([[0.6734241, 0.1656411, 0.1251286], [0.2790177, 0.6753402, 0.0456377], [-0.0019300, 0.0299784, 0.7973330]])  # Rec2020
+        iws_n = np.array([[1.6473376, -0.3935675, -0.2359961], [-0.6826036, 1.6475887, 0.0128190], [0.0296524, -0.0628993, 1.2531279]])  # its inverse (iccmatrices.h:157-161)
         dn = capi.DenoiseToolParams(capi.DenoiseParams(40.0, 50.0, 0, 15.0, 0.0, 0.0, 1.7, 0, 0, 0), 1 if smoothing else 0, 3,
                                     50 if smoothing else 0, 80)
         ccurve, _ = capi.noise_curve_lut()                     # the chroma noise curve ImProcFunctions::denoise always installs
@@ -159,7 +163,10 @@ def main() -> None:
             mark(3)
             ctx.exposure(img, exp_scale, 0.0)
             mark(4)
-            ctx.tone_curve(img, lut, 1.0, True)
+            if args.tone == "neutral":
+                ctx.tone_curve_neutral(img, lut, 1.0, ws, iws_n)
+            else:
+                ctx.tone_curve(img, lut, 1.0, True)
             mark(5)
 
     def barrier():
@@ -244,7 +251,7 @@ def main() -> None:
             "workload": (("X-Trans 3-pass Markesteijn (CIELab)" if xtrans else "AMaZE") + f" + getImage/matrix + ImProcFunctions::denoise (chroma noise-curve map, FTblockDN wavelet shrinkage luma 40 / "
                          f"chroma 15 / gamma 1.7 + DCT detail recovery 50"
                          + (", guided chroma smoothing r=3, NL-means 50/80" if smoothing else "")
-                         + f") + exposure 0.3 EV + tone curve STD, {W}x{H} " + ("X-Trans" if xtrans else "Bayer RGGB") + f" fp32, {args.lanes} frame{'s' if args.lanes > 1 else ''} per GPU per step "
+                         + f") + exposure 0.3 EV + tone curve {args.tone.upper()}, {W}x{H} " + ("X-Trans" if xtrans else "Bayer RGGB") + f" fp32, {args.lanes} frame{'s' if args.lanes > 1 else ''} per GPU per step "
                          + ("(BASELINE configs[4])" if xtrans else "(per-frame pipe of BASELINE configs[3])" if smoothing else "(BASELINE configs[2])"))
                         if pipeline else f"{args.workload.upper()} demosaic only, {W}x{H} Bayer RGGB fp32 (BASELINE configs[1])",
             "stage_ms": stage_ms,
@@ -283,7 +290,7 @@ def main() -> None:
                 im = oracle_lib.improc_denoise(im, calclum_mat=mat, noise_c_curve=ccurve, smoothing=smoothing, radius=3,
                                                nl_strength=50 if smoothing else 0, nl_detail=80, ecomp=expcomp, ws=ws, detail_recovery=True)
                 im = oracle_lib.exposure(im, exp_scale, 0.0)
-                return oracle_lib.tone_std(im, lut, 1.0, True)
+                return oracle_lib.tone_neutral(im, lut, 1.0) if args.tone == "neutral" else oracle_lib.tone_std(im, lut, 1.0, True)
         else:
             fn = (lambda: oracle_lib.amaze(raw, filt, 1.0, 4)) if method == capi.BAYER_AMAZE else (lambda: oracle_lib.rcd(raw, filt))
         fn()  # warm-up (page faults)

@@ -303,6 +303,17 @@ int artgpu_guided_filter(artgpu_ctx *ctx, const artgpu_plane *guide, const artgp
 int artgpu_hsl_equalizer(artgpu_ctx *ctx, artgpu_rgb *img, const double *hcurve, int nh, const double *scurve, int ns,
                          const double *lcurve, int nl, int smoothing, const double ws[9], double scale, int to_rgb);
 
+/* RawImageSource::dual_demosaic_RT (rtengine/dual_demosaic_RT.cc:39-155), Bayer methods AMAZEBILINEAR / RCDBILINEAR:
+ * the first demosaicer (method = ARTGPU_BAYER_AMAZE or ARTGPU_BAYER_RCD, exactly artgpu_demosaic_bayer), then L* of its output
+ * (Color::RGB2L, color.cc:1343-1379), the contrast blend mask (buildBlendMask, rt_algo.cc:315-498: sigmoid of the 8-neighbour contrast
+ * against the threshold, 2-pixel frame, gaussian blur sigma 2) and the blend with a bilinear interpolation in flat regions
+ * (bayer_bilinear_demosaic.cc:33-77).  *contrast is RAWParams::BayerSensor::dualDemosaicContrast in percent, in/out like the reference's
+ * `double &contrast`: with auto_contrast != 0 the threshold is searched (flattest 80 / 40-pixel tile, calcContrastThreshold) and written
+ * back.  contrast == 0 without auto_contrast runs only the first demosaicer.  The *VNG4 variants (vng4_demosaic as second demosaicer)
+ * and X-Trans (fast_xtrans_interpolate_blend) are not on the device path. */
+int artgpu_dual_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, uint32_t filters, double initial_gain, int border,
+                               double *contrast, int auto_contrast, artgpu_rgb *out);
+
 /* ImProcFunctions::logEncoding (rtengine/iplogenc.cc:132-316,395-402): brightness-norm log tone mapping.
  * The struct holds the LogEncodingParams fields the function reads (procparams.h; defaults procparams.cc:2039-2051); `enabled == 0`
  * returns at once like the reference.  regularization > 0 smooths the posterised log-norm with rtengine::guidedFilter at radius

@@ -80,6 +80,11 @@ void oracle_image_rgb_to_lab(float *const img[3], int W, int H, const double ws[
 void oracle_image_lab_to_rgb(float *const img[3], int W, int H, const double iws[9]);
 void oracle_lab_histogram(const float *L, int W, int H, unsigned hist[65536]);
 void oracle_lab_adjustments(float *const img[3], int W, int H, const float *lcurve, const float *acurve, const float *bcurve, float chroma);
+void oracle_rgb2l(const float *R, const float *G, const float *B, float *L, int W, int H);
+float oracle_calc_contrast_threshold(const float *L, int W, int tileY, int tileX, int ts, float factor);
+float oracle_build_blend_mask(const float *L, float *blend, int W, int H, float contrastThreshold, int autoContrast);
+void oracle_bayer_bilinear_blend(const float *blend, const float *raw, float *red, float *green, float *blue, int W, int H, unsigned filters);
+void oracle_dual_demosaic_blend(const float *raw, float *red, float *green, float *blue, int W, int H, unsigned filters, double *contrast, int autoContrast);
 float oracle_logenc_find_gray(float source_gray, float target_gray);
 void oracle_log_encoding(float *const img[3], int W, int H, const double ws[9], double gain, double targetGray, double blackEv, double whiteEv,
                          int regularization, int satcontrol, int highlightCompression, int full_width, int full_height);

@@ -521,3 +521,30 @@ def lab_adjustments(img, lcurve, acurve, bcurve, chroma):
     L.oracle_lab_adjustments.restype = None
     L.oracle_lab_adjustments(_p3(out), w, h, _ptr(cs[0]), _ptr(cs[1]), _ptr(cs[2]), C.c_float(chroma))
     return out
+
+
+def dual_demosaic_blend(raw, planes, filters, contrast, auto_contrast=False):
+    """the blend half of RawImageSource::dual_demosaic_RT (dual_demosaic_RT.cc:73-152, bilinear second demosaicer) on demosaiced
+    planes; returns (planes, contrast in percent)."""
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    out = [np.ascontiguousarray(p, dtype=np.float32).copy() for p in planes]
+    h, w = raw.shape
+    c = C.c_double(float(contrast))
+    L = lib()
+    L.oracle_dual_demosaic_blend.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_double), C.c_int]
+    L.oracle_dual_demosaic_blend.restype = None
+    L.oracle_dual_demosaic_blend(_ptr(raw), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), w, h, C.c_uint(filters), C.byref(c), 1 if auto_contrast else 0)
+    return out, c.value
+
+
+def blend_mask(planes, contrast, auto_contrast=False):
+    """Color::RGB2L + buildBlendMask: returns (L, blend, threshold)"""
+    pl = [np.ascontiguousarray(p, dtype=np.float32) for p in planes]
+    h, w = pl[0].shape
+    Lp = np.zeros((h, w), np.float32); bl = np.zeros((h, w), np.float32)
+    L = lib()
+    L.oracle_rgb2l.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int]; L.oracle_rgb2l.restype = None
+    L.oracle_build_blend_mask.argtypes = [_fp, _fp, C.c_int, C.c_int, C.c_float, C.c_int]; L.oracle_build_blend_mask.restype = C.c_float
+    L.oracle_rgb2l(_ptr(pl[0]), _ptr(pl[1]), _ptr(pl[2]), _ptr(Lp), w, h)
+    thr = L.oracle_build_blend_mask(_ptr(Lp), _ptr(bl), w, h, C.c_float(contrast), 1 if auto_contrast else 0)
+    return Lp, bl, float(thr)

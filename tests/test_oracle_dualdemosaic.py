@@ -1,0 +1,54 @@
+"""CPU: the dual-demosaic oracle (oracle/dualdemosaic.c; dual_demosaic_RT.cc, rt_algo.cc buildBlendMask) against float64 models and its
+own invariants."""
+import numpy as np
+
+import oracle_lib as O
+from art_amd import synth
+
+
+def test_rgb2l_is_cie_lightness():
+    rng = np.random.default_rng(1)
+    pl = [rng.uniform(10, 60000, (33, 67)).astype(np.float32) for _ in range(3)]
+    Lp, _, _ = O.blend_mask(pl, 0.2)
+    y = (0.212671 * pl[0].astype(np.float64) + 0.715160 * pl[1] + 0.072169 * pl[2]) / 65535.0
+    ref = 327.68 * np.where(y > 216.0 / 24389.0, 116.0 * np.cbrt(y) - 16.0, 24389.0 / 27.0 * y)
+    assert np.allclose(Lp, ref, rtol=1e-4, atol=0.5)
+
+
+def test_blend_mask_is_a_blurred_sigmoid_of_contrast():
+    rng = np.random.default_rng(2)
+    h, w = 120, 161
+    y, x = np.mgrid[0:h, 0:w]
+    base = 20000 + 8000 * ((x // 20 + y // 20) % 2)            # checker: edges have contrast, the squares are flat
+    pl = [(base + rng.normal(0, 20, (h, w))).astype(np.float32) for _ in range(3)]
+    Lp, bl, thr = O.blend_mask(pl, 0.3)
+    assert thr == np.float32(0.3)
+    assert bl.min() >= 0.0 and bl.max() <= 1.0001
+    flat = bl[30:31, 30:31].item()                              # centre of a square
+    edge = bl[40:41, 30:31].item()                              # on a horizontal edge
+    assert flat < 0.05 < 0.5 < edge
+    # the model: sigmoid(16 * c / thr - 16) of the 8-neighbour contrast, sigma-2 gaussian
+    L = Lp.astype(np.float64)
+    c = np.zeros_like(L)
+    c[2:-2, 2:-2] = np.sqrt((L[2:-2, 3:-1] - L[2:-2, 1:-3]) ** 2 + (L[3:-1, 2:-2] - L[1:-3, 2:-2]) ** 2 +
+                            (L[2:-2, 4:] - L[2:-2, :-4]) ** 2 + (L[4:, 2:-2] - L[:-4, 2:-2]) ** 2) * (0.0625 / 327.68)
+    m = 1.0 / (1.0 + np.exp(16.0 - 16.0 * c / 0.3))
+    m[:2] = m[2]; m[-2:] = m[-3]; m[:, :2] = m[:, 2:3]; m[:, -2:] = m[:, -3:-2]
+    from scipy.ndimage import gaussian_filter
+    mod = gaussian_filter(m, 2.0, mode="nearest")
+    d = np.abs(bl[8:-8, 8:-8] - mod[8:-8, 8:-8])
+    assert d.max() < 0.08 and d.mean() < 0.03, (d.max(), d.mean())      # the recursive (Young - van Vliet) gaussian vs the sampled one
+
+
+def test_blend_keeps_the_first_demosaicer_on_edges_and_goes_bilinear_in_flat_regions():
+    filt = synth.FILTERS_RGGB
+    raw = synth.bayer_frame(400, 300, filt, seed=5, noise=200)
+    first = O.amaze(raw, filt, 1.0, 4)
+    out0, c0 = O.dual_demosaic_blend(raw, first, filt, 0.0, False)
+    assert c0 == 0.0 and all(np.array_equal(a, b) for a, b in zip(out0, first))        # contrast 0, no auto: untouched
+    out, c = O.dual_demosaic_blend(raw, first, filt, 100.0, False)                    # a huge threshold: bilinear almost everywhere
+    g = out[1]
+    yy, xx = 100, 101                                                                   # RGGB: (even, odd) is a green site
+    assert abs(g[yy, xx] - raw[yy, xx]) < abs(first[1][yy, xx] - raw[yy, xx]) + 1e-3   # green at a green site tends to the raw value
+    auto, ca = O.dual_demosaic_blend(raw, first, filt, 0.0, True)
+    assert 0.0 <= ca <= 100.0
