@@ -16,6 +16,9 @@ LIB_PATH = os.environ.get("ARTGPU_LIB", os.path.join(_HERE, "libartgpu.so"))  # 
 
 BAYER_AMAZE = 0
 BAYER_RCD = 1
+BAYER_VNG4 = 2
+DUAL_BILINEAR = 0
+DUAL_VNG4 = 1
 
 
 class Plane(C.Structure):
@@ -148,7 +151,7 @@ def _load():
     lib.artgpu_lab_to_rgb.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_double)]
     lib.artgpu_lab_histogram.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_uint32)]
     lib.artgpu_lab_adjustments.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float]
-    lib.artgpu_dual_demosaic_bayer.argtypes = [C.c_void_p, C.c_int, C.POINTER(Plane), C.c_uint32, C.c_double, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(RGB)]
+    lib.artgpu_dual_demosaic_bayer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Plane), C.c_uint32, C.c_double, C.c_int, C.POINTER(C.c_double), C.c_int, C.POINTER(RGB)]
     lib.artgpu_channel_mixer.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float)]
     lib.artgpu_rgb_curves.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_pipeline_run.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
@@ -363,10 +366,11 @@ class Context:
         assert keep[0].size == 32770 and keep[1].size == 65536 and keep[2].size == 65536
         self._chk(LIB.artgpu_lab_adjustments(self._h, C.byref(image), *[k.ctypes.data_as(C.POINTER(C.c_float)) for k in keep], float(chroma)))
 
-    def dual_demosaic_bayer(self, method: int, raw: Plane, filters: int, initial_gain: float, border: int, contrast: float, auto_contrast: bool, out: RGB):
+    def dual_demosaic_bayer(self, method: int, raw: Plane, filters: int, initial_gain: float, border: int, contrast: float, auto_contrast: bool, out: RGB,
+                            second: int = DUAL_BILINEAR):
         """returns the contrast threshold in percent (searched when auto_contrast)"""
         c = C.c_double(float(contrast))
-        self._chk(LIB.artgpu_dual_demosaic_bayer(self._h, method, C.byref(raw), filters, float(initial_gain), border, C.byref(c), 1 if auto_contrast else 0, C.byref(out)))
+        self._chk(LIB.artgpu_dual_demosaic_bayer(self._h, method, second, C.byref(raw), filters, float(initial_gain), border, C.byref(c), 1 if auto_contrast else 0, C.byref(out)))
         return c.value
 
     def channel_mixer(self, image: RGB, m):

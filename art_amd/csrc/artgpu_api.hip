@@ -297,14 +297,15 @@ size_t artgpu_scratch_bytes(const artgpu_ctx *ctx)
     return s;
 }
 
-struct DualReq { double *contrast; int auto_contrast; };
+struct DualReq { double *contrast; int auto_contrast; int second; };
+static int vng4_dev(artgpu_ctx *ctx, const float *raw, size_t raw_stride, float *r, float *g, float *b, size_t out_stride, int W, int H, uint32_t filters);
 static int dual_blend_dev(artgpu_ctx *ctx, const DevImage &d, int W, int H, uint32_t filters, DualReq *req);
 static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *raw, uint32_t filters,
                                double initial_gain, int border, artgpu_rgb *out, DualReq *dual)
 {
     if (!ctx) return ARTGPU_EINVAL;
     if (!plane_ok(raw) || !out) return fail(ctx, ARTGPU_EINVAL, "demosaic_bayer: bad raw plane or null output");
-    if (method != ARTGPU_BAYER_AMAZE && method != ARTGPU_BAYER_RCD) return fail(ctx, ARTGPU_EUNSUPPORTED, "demosaic_bayer: method %d is not on the device path", method);
+    if (method != ARTGPU_BAYER_AMAZE && method != ARTGPU_BAYER_RCD && method != ARTGPU_BAYER_VNG4) return fail(ctx, ARTGPU_EUNSUPPORTED, "demosaic_bayer: method %d is not on the device path", method);
     if (!(initial_gain > 0.0)) return fail(ctx, ARTGPU_EINVAL, "demosaic_bayer: initial_gain must be > 0");
     // RGB Bayer only: the reference falls back to igv_interpolate for 4-colour CFAs (rcd_demosaic.cc:57-66)
     for (unsigned r = 0; r < 2; ++r)
@@ -351,6 +352,9 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
             HIPCHK(ctx, hipMemsetAsync(ctx->arena, (int)strtoul(getenv("ARTGPU_AMAZE_POISON"), nullptr, 0), (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float), ctx->stream));
         HIPCHK(ctx, launch_amaze(a, grid, ctx->stream));
         bord = border < 4 ? 3 : 0; // amaze_demosaic_RT.cc:1587-1589
+    } else if (method == ARTGPU_BAYER_VNG4) {
+        if ((rc = vng4_dev(ctx, d.raw, d.raw_stride, d.r, d.g, d.b, d.out_stride, W, H, filters))) return rc;
+        bord = 3; // vng4_demosaic_RT.cc:384
     } else {
         const int tileSizeN = RCD_TS - 2 * RCD_BORDER;
         const int numTh = H / tileSizeN + ((H % tileSizeN) ? 1 : 0), numTw = W / tileSizeN + ((W % tileSizeN) ? 1 : 0);
@@ -387,13 +391,15 @@ int artgpu_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, 
 {
     return demosaic_bayer_impl(ctx, method, raw, filters, initial_gain, border, out, nullptr);
 }
-int artgpu_dual_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, uint32_t filters, double initial_gain, int border,
+int artgpu_dual_demosaic_bayer(artgpu_ctx *ctx, int method, int second, const artgpu_plane *raw, uint32_t filters, double initial_gain, int border,
                                double *contrast, int auto_contrast, artgpu_rgb *out)
 {
     if (!ctx) return ARTGPU_EINVAL;
+    if (method == ARTGPU_BAYER_VNG4 || (second != ARTGPU_DUAL_BILINEAR && second != ARTGPU_DUAL_VNG4))
+        return fail(ctx, ARTGPU_EUNSUPPORTED, "dual_demosaic_bayer: first demosaicer AMAZE or RCD, second BILINEAR or VNG4");
     if (!contrast || !(*contrast >= 0.0)) return fail(ctx, ARTGPU_EINVAL, "dual_demosaic_bayer: contrast must be >= 0");
     if (raw && (raw->w < 96 || raw->h < 96)) return fail(ctx, ARTGPU_EUNSUPPORTED, "dual_demosaic_bayer: image smaller than 96x96");
-    DualReq req = {contrast, auto_contrast};
+    DualReq req = {contrast, auto_contrast, second};
     // contrast == 0 without the automatic threshold: only the first demosaicer runs (dual_demosaic_RT.cc:43-71)
     return demosaic_bayer_impl(ctx, method, raw, filters, initial_gain, border, out, (*contrast == 0.0 && !auto_contrast) ? nullptr : &req);
 }
@@ -1090,6 +1096,23 @@ int artgpu_guided_filter(artgpu_ctx *ctx, const artgpu_plane *guide, const artgp
 }
 
 static int lab_tabs_dev(artgpu_ctx *ctx, float **tabs_out);
+// RawImageSource::vng4_demosaic on device planes (vng4_demosaic_RT.cc:62-397)
+static int vng4_dev(artgpu_ctx *ctx, const float *raw, size_t raw_stride, float *r, float *g, float *b, size_t out_stride, int W, int H, uint32_t filters)
+{
+    if (W < 16 || H < 16) return fail(ctx, ARTGPU_EUNSUPPORTED, "vng4: image %dx%d smaller than 16x16", W, H);
+    float *image, *codef;
+    int rc;
+    if ((rc = pool_get(ctx, P_BLOCKS, (size_t)W * H * 16, &image)) || (rc = pool_get(ctx, P_DTAB, 16 * VNG4_CODE_INTS * 4, &codef))) return rc;
+    Vng4Args a = {};
+    a.raw = raw; a.raw_stride = raw_stride; a.red = r; a.green = g; a.blue = b; a.out_stride = out_stride;
+    a.image = image; a.code = reinterpret_cast<const int *>(codef); a.w = W; a.h = H; a.filters = filters; a.prefilters = vng4_prefilters(filters);
+    std::vector<int> codes(16 * VNG4_CODE_INTS, 0);
+    vng4_build_code(a.prefilters, W, codes.data());
+    HIPCHK(ctx, hipMemcpyAsync(codef, codes.data(), codes.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // `codes` goes out of scope
+    HIPCHK(ctx, launch_vng4(a, ctx->stream));
+    return ARTGPU_OK;
+}
 // dual_demosaic_RT.cc:99-152 after the first demosaicer: L, buildBlendMask (rt_algo.cc:315-498), bilinear blend
 static int dual_blend_dev(artgpu_ctx *ctx, const DevImage &d, int W, int H, uint32_t filters, DualReq *req)
 {
@@ -1157,6 +1180,16 @@ static int dual_blend_dev(artgpu_ctx *ctx, const DevImage &d, int W, int H, uint
     if (thr != 0.f) {
         artgpu_plane bp = {blend, W, H, (int64_t)W * 4, 1};
         if ((rc = artgpu_gaussian_blur(ctx, &bp, 2.0))) return rc;      // rt_algo.cc:492
+    }
+    if (req->second == ARTGPU_DUAL_VNG4) {
+        // vng4_demosaic into temporaries, then all three channels of every pixel (dual_demosaic_RT.cc:128-148)
+        float *t;
+        if ((rc = pool_get(ctx, P_SF, 3 * n * 4, &t))) return rc;
+        if ((rc = vng4_dev(ctx, d.raw, d.raw_stride, t, t + n, t + 2 * n, (size_t)W, W, H, filters))) return rc;
+        DevImage tmp = {d.raw, d.raw_stride, t, t + n, t + 2 * n, (size_t)W, false};
+        if ((rc = launch_border(ctx, tmp, W, H, filters, 3))) return rc;
+        HIPCHK(ctx, launch_dual_blend_planes(a, t, t + n, t + 2 * n, (size_t)W, ctx->stream));
+        return ARTGPU_OK;
     }
     HIPCHK(ctx, launch_bilinear_blend(a, ctx->stream));
     return ARTGPU_OK;

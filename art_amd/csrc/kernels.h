@@ -184,6 +184,19 @@ hipError_t launch_blend_mask(const DualArgs &a, hipStream_t s);
 hipError_t launch_tile_stats(const DualArgs &a, int nH, int nW, int y0, int x0, int step, int ts, float *var, hipStream_t s);
 hipError_t launch_contrast_threshold(const DualArgs &a, int ty, int tx, int ts, float *result, hipStream_t s);
 hipError_t launch_bilinear_blend(const DualArgs &a, hipStream_t s);
+// ---- VNG4 (vng4.hip; vng4_demosaic_RT.cc:32-397) ----
+constexpr int VNG4_CODE_INTS = 320;              // per (row & 7, col & 1) cell, like the reference's 1280-byte slots
+struct Vng4Args {
+    const float *raw; size_t raw_stride;
+    float *red, *green, *blue; size_t out_stride;
+    float *image;                                // w*h*4: the four-colour image
+    const int *code;                             // 16 * VNG4_CODE_INTS
+    int w, h; unsigned filters, prefilters;
+};
+unsigned vng4_prefilters(unsigned filters);
+void vng4_build_code(unsigned pf, int width, int *codes);
+hipError_t launch_vng4(const Vng4Args &a, hipStream_t s);
+hipError_t launch_dual_blend_planes(const DualArgs &a, const float *r2, const float *g2, const float *b2, size_t s2, hipStream_t s);
 // ---- logEncoding (logenc.hip; iplogenc.cc:132-316) ----
 struct LogEncArgs {
     float *img[3]; size_t stride; int w, h;

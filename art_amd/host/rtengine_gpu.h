@@ -76,9 +76,9 @@ public:
 
 // The fields of ProcParams the path reads (procparams.cc:1528-3335 for the defaults)
 struct ProcParams {
-    // raw.bayersensor.{method,border,dualDemosaicContrast,dualDemosaicAutoContrast}; dual = the AMAZEBILINEAR / RCDBILINEAR methods
-    // (first demosaicer `method`, bilinear in flat regions; rawimagesource.cc:1876-1886 -> dual_demosaic_RT)
-    struct { int method = ARTGPU_BAYER_AMAZE; int border = 4; bool dual = false; double dualDemosaicContrast = 20; bool dualDemosaicAutoContrast = true; } bayersensor;
+    // raw.bayersensor.{method,border,dualDemosaicContrast,dualDemosaicAutoContrast}; dual = the AMAZEBILINEAR / RCDBILINEAR / AMAZEVNG4 / RCDVNG4 methods
+    // (first demosaicer `method`, dualSecond in flat regions; rawimagesource.cc:1876-1886 -> dual_demosaic_RT)
+    struct { int method = ARTGPU_BAYER_AMAZE; int border = 4; bool dual = false; int dualSecond = ARTGPU_DUAL_BILINEAR; double dualDemosaicContrast = 20; bool dualDemosaicAutoContrast = true; } bayersensor;
     enum XTransMethod { ONE_PASS = 1, THREE_PASS = 3 };
     struct { int method = THREE_PASS; int border = 7; } xtranssensor;          // raw.xtranssensor.{method,border} (procparams.cc:3064)
     struct { bool enabled = false; double luminance = 0, luminanceDetail = 0; int luminanceDetailThreshold = 0; double chrominance = 15,
@@ -130,7 +130,7 @@ public:
         }
         if (p.bayersensor.dual) {       // `contrast` comes back as the threshold in use (the reference's `double &contrast`)
             dualDemosaicContrastUsed = p.bayersensor.dualDemosaicContrast;
-            ctx.check(artgpu_dual_demosaic_bayer(ctx.get(), p.bayersensor.method, &raw, filters, initialGain, border, &dualDemosaicContrastUsed,
+            ctx.check(artgpu_dual_demosaic_bayer(ctx.get(), p.bayersensor.method, p.bayersensor.dualSecond, &raw, filters, initialGain, border, &dualDemosaicContrastUsed,
                                                  p.bayersensor.dualDemosaicAutoContrast ? 1 : 0, &out));
             return;
         }

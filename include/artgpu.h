@@ -40,6 +40,10 @@ extern "C" {
  * rtengine/rawimagesource.cc:1862-1912). */
 #define ARTGPU_BAYER_AMAZE 0
 #define ARTGPU_BAYER_RCD   1
+#define ARTGPU_BAYER_VNG4  2
+/* second demosaicer of artgpu_dual_demosaic_bayer */
+#define ARTGPU_DUAL_BILINEAR 0
+#define ARTGPU_DUAL_VNG4     1
 
 typedef struct artgpu_ctx artgpu_ctx;
 
@@ -80,6 +84,9 @@ int artgpu_get_timings(const artgpu_ctx *ctx, artgpu_timings *out);
  *                         border_interpolate2(W,H,3,...) when border < 4 (L1587-1589);
  *   ARTGPU_BAYER_RCD   -> rcd_demosaic() (rtengine/rcd_demosaic.cc:51-347) including its
  *                         border_interpolate2(W,H,9,...) (L342).
+ *   ARTGPU_BAYER_VNG4  -> vng4_demosaic(rawData, red, green, blue) (rtengine/vng4_demosaic_RT.cc:62-397) including its
+ *                         border_interpolate2(W,H,3,...) (L384).  The four-colour pattern it works on (RawImage::prefilters: the second
+ *                         green is colour 3) is derived from `filters` the way dcraw's identify() does.
  * raw      : the CFA plane (RawImageSource::rawData), values 0..65535
  * filters  : RawImage::filters bit pattern (rtengine/rawimage.h:186-189), RGB Bayer only
  * initial_gain : RawImageSource::initialGain (clip_pt = 1/initialGain, amaze L53-54)
@@ -303,15 +310,16 @@ int artgpu_guided_filter(artgpu_ctx *ctx, const artgpu_plane *guide, const artgp
 int artgpu_hsl_equalizer(artgpu_ctx *ctx, artgpu_rgb *img, const double *hcurve, int nh, const double *scurve, int ns,
                          const double *lcurve, int nl, int smoothing, const double ws[9], double scale, int to_rgb);
 
-/* RawImageSource::dual_demosaic_RT (rtengine/dual_demosaic_RT.cc:39-155), Bayer methods AMAZEBILINEAR / RCDBILINEAR:
+/* RawImageSource::dual_demosaic_RT (rtengine/dual_demosaic_RT.cc:39-155), Bayer methods AMAZEBILINEAR / RCDBILINEAR / AMAZEVNG4 / RCDVNG4:
  * the first demosaicer (method = ARTGPU_BAYER_AMAZE or ARTGPU_BAYER_RCD, exactly artgpu_demosaic_bayer), then L* of its output
  * (Color::RGB2L, color.cc:1343-1379), the contrast blend mask (buildBlendMask, rt_algo.cc:315-498: sigmoid of the 8-neighbour contrast
  * against the threshold, 2-pixel frame, gaussian blur sigma 2) and the blend with a bilinear interpolation in flat regions
  * (bayer_bilinear_demosaic.cc:33-77).  *contrast is RAWParams::BayerSensor::dualDemosaicContrast in percent, in/out like the reference's
  * `double &contrast`: with auto_contrast != 0 the threshold is searched (flattest 80 / 40-pixel tile, calcContrastThreshold) and written
- * back.  contrast == 0 without auto_contrast runs only the first demosaicer.  The *VNG4 variants (vng4_demosaic as second demosaicer)
+ * back.  contrast == 0 without auto_contrast runs only the first demosaicer.  second = ARTGPU_DUAL_VNG4 (AMAZEVNG4 / RCDVNG4): the flat
+ * regions come from vng4_demosaic instead (all three channels of every pixel, dual_demosaic_RT.cc:128-148).  DCB as first demosaicer
  * and X-Trans (fast_xtrans_interpolate_blend) are not on the device path. */
-int artgpu_dual_demosaic_bayer(artgpu_ctx *ctx, int method, const artgpu_plane *raw, uint32_t filters, double initial_gain, int border,
+int artgpu_dual_demosaic_bayer(artgpu_ctx *ctx, int method, int second, const artgpu_plane *raw, uint32_t filters, double initial_gain, int border,
                                double *contrast, int auto_contrast, artgpu_rgb *out);
 
 /* ImProcFunctions::logEncoding (rtengine/iplogenc.cc:132-316,395-402): brightness-norm log tone mapping.

@@ -207,7 +207,13 @@ void oracle_bayer_bilinear_blend(const float *blend, const float *raw, float *re
 }
 
 /* the blend half of dual_demosaic_RT on already demosaiced planes; *contrast in percent in/out like the reference's `double &contrast` */
+void oracle_dual_demosaic_blend2(const float *raw, float *red, float *green, float *blue, int W, int H, unsigned filters, double *contrast, int autoContrast, int vng4);
 void oracle_dual_demosaic_blend(const float *raw, float *red, float *green, float *blue, int W, int H, unsigned filters, double *contrast, int autoContrast)
+{
+    oracle_dual_demosaic_blend2(raw, red, green, blue, W, H, filters, contrast, autoContrast, 0);
+}
+/* vng4 != 0: the second demosaicer is vng4_demosaic, blended over all three channels of every pixel (dual_demosaic_RT.cc:128-148) */
+void oracle_dual_demosaic_blend2(const float *raw, float *red, float *green, float *blue, int W, int H, unsigned filters, double *contrast, int autoContrast, int vng4)
 {
     if (*contrast == 0.0 && !autoContrast) return;
     const size_t n = (size_t)W * H;
@@ -216,6 +222,17 @@ void oracle_dual_demosaic_blend(const float *raw, float *red, float *green, floa
     float cf = (float)(*contrast / 100.0);
     cf = oracle_build_blend_mask(L, blend, W, H, cf, autoContrast);
     *contrast = cf * 100.f;
-    oracle_bayer_bilinear_blend(blend, raw, red, green, blue, W, H, filters);
+    if (vng4) {
+        float *t = (float *)malloc(sizeof(float) * 3 * n);
+        oracle_vng4_demosaic(raw, W, H, filters, 0, t, t + n, t + 2 * n);
+#pragma omp parallel for
+        for (size_t k = 0; k < n; ++k) {
+            red[k] = intpf(blend[k], red[k], t[k]);
+            green[k] = intpf(blend[k], green[k], t[n + k]);
+            blue[k] = intpf(blend[k], blue[k], t[2 * n + k]);
+        }
+        free(t);
+    } else
+        oracle_bayer_bilinear_blend(blend, raw, red, green, blue, W, H, filters);
     free(L); free(blend);
 }

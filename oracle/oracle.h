@@ -84,7 +84,11 @@ void oracle_rgb2l(const float *R, const float *G, const float *B, float *L, int 
 float oracle_calc_contrast_threshold(const float *L, int W, int tileY, int tileX, int ts, float factor);
 float oracle_build_blend_mask(const float *L, float *blend, int W, int H, float contrastThreshold, int autoContrast);
 void oracle_bayer_bilinear_blend(const float *blend, const float *raw, float *red, float *green, float *blue, int W, int H, unsigned filters);
+void oracle_dual_demosaic_blend2(const float *raw, float *red, float *green, float *blue, int W, int H, unsigned filters, double *contrast, int autoContrast, int vng4);
 void oracle_dual_demosaic_blend(const float *raw, float *red, float *green, float *blue, int W, int H, unsigned filters, double *contrast, int autoContrast);
+unsigned oracle_prefilters(unsigned filters);
+int oracle_vng4_code(unsigned pf, int width, int row, int col, int32_t *ip0);
+void oracle_vng4_demosaic(const float *raw, int W, int H, unsigned filters, unsigned prefilters, float *red, float *green, float *blue);
 float oracle_logenc_find_gray(float source_gray, float target_gray);
 void oracle_log_encoding(float *const img[3], int W, int H, const double ws[9], double gain, double targetGray, double blackEv, double whiteEv,
                          int regularization, int satcontrol, int highlightCompression, int full_width, int full_height);

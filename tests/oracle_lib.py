@@ -523,7 +523,7 @@ def lab_adjustments(img, lcurve, acurve, bcurve, chroma):
     return out
 
 
-def dual_demosaic_blend(raw, planes, filters, contrast, auto_contrast=False):
+def dual_demosaic_blend(raw, planes, filters, contrast, auto_contrast=False, vng4=False):
     """the blend half of RawImageSource::dual_demosaic_RT (dual_demosaic_RT.cc:73-152, bilinear second demosaicer) on demosaiced
     planes; returns (planes, contrast in percent)."""
     raw = np.ascontiguousarray(raw, dtype=np.float32)
@@ -531,9 +531,9 @@ def dual_demosaic_blend(raw, planes, filters, contrast, auto_contrast=False):
     h, w = raw.shape
     c = C.c_double(float(contrast))
     L = lib()
-    L.oracle_dual_demosaic_blend.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_double), C.c_int]
-    L.oracle_dual_demosaic_blend.restype = None
-    L.oracle_dual_demosaic_blend(_ptr(raw), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), w, h, C.c_uint(filters), C.byref(c), 1 if auto_contrast else 0)
+    L.oracle_dual_demosaic_blend2.argtypes = [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_double), C.c_int, C.c_int]
+    L.oracle_dual_demosaic_blend2.restype = None
+    L.oracle_dual_demosaic_blend2(_ptr(raw), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), w, h, C.c_uint(filters), C.byref(c), 1 if auto_contrast else 0, 1 if vng4 else 0)
     return out, c.value
 
 
@@ -548,3 +548,15 @@ def blend_mask(planes, contrast, auto_contrast=False):
     L.oracle_rgb2l(_ptr(pl[0]), _ptr(pl[1]), _ptr(pl[2]), _ptr(Lp), w, h)
     thr = L.oracle_build_blend_mask(_ptr(Lp), _ptr(bl), w, h, C.c_float(contrast), 1 if auto_contrast else 0)
     return Lp, bl, float(thr)
+
+
+def vng4(raw, filters, prefilters=0):
+    """RawImageSource::vng4_demosaic (vng4_demosaic_RT.cc:62-397)"""
+    raw = np.ascontiguousarray(raw, dtype=np.float32)
+    h, w = raw.shape
+    out = [np.zeros((h, w), np.float32) for _ in range(3)]
+    L = lib()
+    L.oracle_vng4_demosaic.argtypes = [_fp, C.c_int, C.c_int, C.c_uint, C.c_uint, _fp, _fp, _fp]
+    L.oracle_vng4_demosaic.restype = None
+    L.oracle_vng4_demosaic(_ptr(raw), w, h, C.c_uint(filters), C.c_uint(prefilters), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]))
+    return out

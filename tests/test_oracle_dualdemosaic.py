@@ -52,3 +52,26 @@ def test_blend_keeps_the_first_demosaicer_on_edges_and_goes_bilinear_in_flat_reg
     assert abs(g[yy, xx] - raw[yy, xx]) < abs(first[1][yy, xx] - raw[yy, xx]) + 1e-3   # green at a green site tends to the raw value
     auto, ca = O.dual_demosaic_blend(raw, first, filt, 0.0, True)
     assert 0.0 <= ca <= 100.0
+
+
+def test_vng4_reconstructs_a_smooth_scene_and_code_tables_are_well_formed():
+    """vng4_demosaic (oracle/vng4.c): a band-limited scene comes back to a few parts in 10^4, for all four CFA phases; the 4-colour
+    pattern marks exactly one green per 2x2 as colour 3"""
+    import ctypes as C
+    L = O.lib()
+    L.oracle_prefilters.restype = C.c_uint
+    h, w = 200, 260
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    truth = [20000 + 8000 * np.sin(0.02 * x) * np.cos(0.03 * y), 25000 + 6000 * np.cos(0.025 * x + 0.01 * y), 15000 + 5000 * np.sin(0.03 * y)]
+    for filt in (0x94949494, 0x16161616, 0x61616161, 0x49494949):
+        pf = L.oracle_prefilters(C.c_uint(filt))
+        cells = [[synth.fc(pf, r, c) for c in range(2)] for r in range(2)]
+        assert sorted(sum(cells, [])) == [0, 1, 2, 3]
+        assert all((synth.fc(pf, r, c) in (1, 3)) == (synth.fc(filt, r, c) == 1) for r in range(8) for c in range(2))
+        raw = np.zeros((h, w), np.float32)
+        for r in range(2):
+            for c in range(2):
+                raw[r::2, c::2] = truth[synth.fc(filt, r, c)][r::2, c::2]
+        out = O.vng4(raw, filt)
+        for o, t in zip(out, truth):
+            assert np.abs(o - t)[8:-8, 8:-8].mean() < 8.0 and np.abs(o - t)[8:-8, 8:-8].max() < 200.0
