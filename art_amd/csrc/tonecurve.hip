@@ -31,7 +31,23 @@ __device__ __forceinline__ float lut_noclip(const float *__restrict__ data, floa
     const float p1 = data[idx], p2 = data[idx + 1] - p1;
     return p1 + p2 * diff;
 }
-__device__ __forceinline__ float get_pq(const float *__restrict__ pq, float x) { return (x >= 0.f && x <= 1.f) ? lut_noclip(pq, x * 65535.f) : dev_PQ(x); }
+// the forward PQ table: six lookups per pixel, the hottest of the kernel's three 256 KB tables.  `lds` != nullptr: entries
+// [0, LUT_LDS_N) are resident in LDS (the persistent launch shape below), the rest and the other two tables come from L2.
+struct PqTab { const float *g; const float *lds; };
+__device__ __forceinline__ float get_pq(const PqTab pq, float x)
+{
+    if (!(x >= 0.f && x <= 1.f)) return dev_PQ(x);
+    if (!pq.lds) return lut_noclip(pq.g, x * 65535.f);
+    const float index = x * 65535.f;
+    int idx = (int)index;
+    if (index > 65534.f) idx = 65534;
+    const float diff = index - (float)idx;
+    float p1, q;
+    if (idx + 1 < LUT_LDS_N) { p1 = pq.lds[idx]; q = pq.lds[idx + 1]; }
+    else { p1 = pq.g[idx]; q = pq.g[idx + 1]; }
+    const float p2 = q - p1;
+    return p1 + p2 * diff;
+}
 __device__ __forceinline__ float get_pq_inv(const float *__restrict__ pqi, float x) { return (x >= 0.f && x <= 1.f) ? lut_noclip(pqi, x * 65535.f) : dev_PQ_inv(x); }
 
 // dot_product(Mat33, Vec3) (linalgebra.h:226-239): accumulates from 0
@@ -46,7 +62,7 @@ __device__ __forceinline__ void mat_vec(const float *m, const float v[3], float 
         r[i] = acc;
     }
 }
-__device__ __forceinline__ void rgb2jzczhz(const float *__restrict__ pq, float R, float G, float B, float &Jz, float &cz, float &hz, const float *ws)
+__device__ __forceinline__ void rgb2jzczhz(const PqTab pq, float R, float G, float B, float &Jz, float &cz, float &hz, const float *ws)
 {
     const float D[9] = {0.9555766f, -0.0230393f, 0.0631636f, -0.0282895f, 1.0099416f, 0.0210077f, 0.0122982f, -0.0204830f, 1.3299098f};
     float v[3] = {ws[0] * R + ws[1] * G + ws[2] * B, ws[3] * R + ws[4] * G + ws[5] * B, ws[6] * R + ws[7] * G + ws[8] * B}, d[3];
@@ -115,28 +131,36 @@ __global__ void neutral_hues_kernel(NeutralArgs a)
     const float c[4][3] = {{1, 0, 0}, {0, 0, 1}, {1, 1, 0}, {1, 0.5f, 0}};
     for (int k = 0; k < 4; ++k) {
         float j, ch, hz;
-        rgb2jzczhz(a.pq, c[k][0], c[k][1], c[k][2], j, ch, hz, hws);
+        rgb2jzczhz(PqTab{a.pq, nullptr}, c[k][0], c[k][1], c[k][2], j, ch, hz, hws);
         a.hues[k] = hz;
     }
 }
 
-__global__ void __launch_bounds__(256) tone_neutral_kernel(NeutralArgs a)
+struct NeutralConsts { float whitept, rhue, bhue, yhue, yrange, rrange, brange, sc[3]; };
+__device__ __forceinline__ NeutralConsts neutral_consts(const NeutralArgs &a)
 {
-    const float whitept = 65535.f * a.whitecoeff;
-    const float rhue = a.hues[0], bhue = a.hues[1], yhue = a.hues[2], ohue = a.hues[3];
-    const float yrange = fabsf(ohue - yhue) * 0.8f, rrange = fabsf(ohue - rhue), brange = rrange;
+    NeutralConsts k;
+    k.whitept = 65535.f * a.whitecoeff;
+    k.rhue = a.hues[0]; k.bhue = a.hues[1]; k.yhue = a.hues[2];
+    const float ohue = a.hues[3];
+    k.yrange = fabsf(ohue - k.yhue) * 0.8f; k.rrange = fabsf(ohue - k.rhue); k.brange = k.rrange;
     const float dl[3] = {1.1f, 1.2f, 1.5f}, th[3] = {0.85f, 0.75f, 0.95f};
-    float sc[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) sc[i] = (1.f - th[i]) / sqrtf(dl[i] - 1.f);
+    for (int i = 0; i < 3; ++i) k.sc[i] = (1.f - th[i]) / sqrtf(dl[i] - 1.f);
+    return k;
+}
+__device__ __forceinline__ void neutral_px(const NeutralArgs &a, const NeutralConsts &k, const PqTab pq, size_t o, float r0, float g0, float b0)
+{
+    const float whitept = k.whitept, rhue = k.rhue, bhue = k.bhue, yhue = k.yhue, yrange = k.yrange, rrange = k.rrange, brange = k.brange;
+    const float th[3] = {0.85f, 0.75f, 0.95f};
+    const float *sc = k.sc;
     const float PI_180 = (float)(3.14159265358979323846 / 180.0);
-    FOR_IMAGE_XY(y, x, a.w, a.h) {
-        const size_t o = (size_t)y * a.stride + x;
+    {
         float rgb[3], jch[3], tv[3];
-        rgb[0] = std_max(a.img[0][o] / 65535.f, 0.f);
-        rgb[1] = std_max(a.img[1][o] / 65535.f, 0.f);
-        rgb[2] = std_max(a.img[2][o] / 65535.f, 0.f);
-        rgb2jzczhz(a.pq, rgb[0], rgb[1], rgb[2], jch[0], jch[1], jch[2], a.ws);
+        rgb[0] = std_max(r0 / 65535.f, 0.f);
+        rgb[1] = std_max(g0 / 65535.f, 0.f);
+        rgb[2] = std_max(b0 / 65535.f, 0.f);
+        rgb2jzczhz(pq, rgb[0], rgb[1], rgb[2], jch[0], jch[1], jch[2], a.ws);
         const float ilum = jch[0];
         float hue = jch[2];
         const float iY = (rgb[0] + rgb[1] + rgb[2]) / 3.f;
@@ -169,7 +193,7 @@ __global__ void __launch_bounds__(256) tone_neutral_kernel(NeutralArgs a)
             nt = lutf_lookup<true>(a.lut, 65536, std_max(nt, 0.f));   // setLutVal; above 65535 the LUT's clip value
             rgb[j] = nt / 65535.f;
         }
-        rgb2jzczhz(a.pq, rgb[0], rgb[1], rgb[2], jch[0], jch[1], jch[2], a.ws);
+        rgb2jzczhz(pq, rgb[0], rgb[1], rgb[2], jch[0], jch[1], jch[2], a.ws);
         float hue_shift = 15.f * PI_180 * gauss(hue, rhue, rrange);
         hue_shift += -5.f * PI_180 * gauss(hue, bhue, brange);
         hue_shift *= lim01((rgb[0] + rgb[1] + rgb[2]) / (3.f * a.whitecoeff));
@@ -187,6 +211,37 @@ __global__ void __launch_bounds__(256) tone_neutral_kernel(NeutralArgs a)
         a.img[2][o] = std_max(0.f, std_min(rgb[2] * 65535.f, whitept));
     }
 }
+__global__ void __launch_bounds__(256) tone_neutral_kernel(NeutralArgs a)
+{
+    const NeutralConsts k = neutral_consts(a);
+    FOR_IMAGE_XY(y, x, a.w, a.h) {
+        const size_t o = (size_t)y * a.stride + x;
+        neutral_px(a, k, PqTab{a.pq, nullptr}, o, a.img[0][o], a.img[1][o], a.img[2][o]);
+    }
+}
+// large frames: one persistent 1024-thread workgroup per CU, the lower 40 704 entries of the forward PQ table in LDS
+__global__ void __launch_bounds__(1024) tone_neutral_lds_kernel(NeutralArgs a)
+{
+    extern __shared__ float pq_lds[];
+    lut_lds_fill(pq_lds, a.pq, 1024);
+    const NeutralConsts k = neutral_consts(a);
+    const PqTab pq = {a.pq, pq_lds};
+    for (int y = blockIdx.x; y < a.h; y += gridDim.x)
+        for (int x0 = 0; x0 < a.w; x0 += 2048) {
+            float r[2], g[2], b[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int x = x0 + q * 1024 + (int)threadIdx.x;
+                const size_t o = (size_t)y * a.stride + (x < a.w ? x : a.w - 1);
+                r[q] = a.img[0][o]; g[q] = a.img[1][o]; b[q] = a.img[2][o];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int x = x0 + q * 1024 + (int)threadIdx.x;
+                if (x < a.w) neutral_px(a, k, pq, (size_t)y * a.stride + x, r[q], g[q], b[q]);
+            }
+        }
+}
 
 hipError_t launch_neutral_hues(const NeutralArgs &a, hipStream_t s)
 {
@@ -195,9 +250,15 @@ hipError_t launch_neutral_hues(const NeutralArgs &a, hipStream_t s)
 }
 hipError_t launch_tone_neutral(const NeutralArgs &a, hipStream_t s)
 {
-    const long long n = (long long)a.w * a.h;
-    long long g = (n + 255) / 256;
-    (void)g;
+    if ((long long)a.w * a.h >= (1 << 22) && (reinterpret_cast<uintptr_t>(a.pq) & 15) == 0 && !getenv("ARTGPU_TONE_NOLDS")) {
+        const size_t lds = (size_t)LUT_LDS_N * sizeof(float);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tone_neutral_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        hipLaunchKernelGGL(tone_neutral_lds_kernel, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(tone_neutral_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }

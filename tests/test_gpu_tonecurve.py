@@ -53,3 +53,20 @@ def test_neutral_tone_curve_super_white_within_tolerance(gpu_ctx):
     for g, r in zip(got, ref):
         assert np.array_equal(g[~oor].view(np.uint32), r[~oor].view(np.uint32))
         assert np.allclose(g[oor], r[oor], rtol=2e-4, atol=0.5)
+
+
+def test_neutral_large_frame_lds_pq_table_bit_exact(gpu_ctx, monkeypatch):
+    """frames of >= 4 Mpx keep the lower 40704 entries of the forward PQ table in LDS: same bits as the plain kernel everywhere and as
+    the oracle on the in-range pixels"""
+    w, h = 2310, 1840
+    img = frame(w, h, 5, 65535.0)
+    lut = s_curve()
+    ref, oor = O.tone_neutral(img, lut, 1.0, want_oor=True)
+    got = [p.copy() for p in img]
+    gpu_ctx.tone_curve_neutral(capi.host_rgb(got), lut, 1.0, O.REC2020_WS_D, O.REC2020_IWS_D)
+    monkeypatch.setenv("ARTGPU_TONE_NOLDS", "1")
+    plain = [p.copy() for p in img]
+    gpu_ctx.tone_curve_neutral(capi.host_rgb(plain), lut, 1.0, O.REC2020_WS_D, O.REC2020_IWS_D)
+    for g, p, r in zip(got, plain, ref):
+        assert np.array_equal(g.view(np.uint32), p.view(np.uint32))
+        assert np.array_equal(g[~oor].view(np.uint32), r[~oor].view(np.uint32))
