@@ -6,6 +6,7 @@
 //
 //   artgpu-cli --in frame.f32 --width 4000 --height 3000 [--u16] [--filters 0x94949494]
 //              [--method amaze|rcd] [--border 4] [--denoise L,C] [--chroma-auto] [--expcomp 0.3] [--out out.ppm]
+//              [--dual bilinear|vng4] [--dual-contrast C] [--logenc REG] [--saturation S,V] [--labchroma C]   (SURVEY 8f N4 tools)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +41,9 @@ int main(int argc, char **argv)
     int tone_mode = ARTGPU_TONE_STD;
     int xtrans_passes = 0;   // 0 = Bayer; 1 / 3 = X-Trans ONE_PASS / THREE_PASS with the Fuji colour map
     int gradius = 3, nlstrength = 0, nldetail = 80;
+    bool dual = false, dual_auto = true, logenc = false, labcurve = false;
+    int dual_second = ARTGPU_DUAL_BILINEAR, logenc_reg = 60, sat = 0, vib = 0, labchroma = 0;
+    double dual_contrast = 20;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -57,6 +61,11 @@ int main(int argc, char **argv)
         else if (a == "--xtrans") { xtrans_passes = std::atoi(next()); border = 7; }
         else if (a == "--tone") { std::string m = next(); tone_mode = (m == "neutral") ? ARTGPU_TONE_NEUTRAL : ARTGPU_TONE_STD; }
         else if (a == "--smoothing") { smoothing = true; if (std::sscanf(next(), "%d,%d,%d", &gradius, &nlstrength, &nldetail) != 3) { std::fprintf(stderr, "--smoothing radius,nlStrength,nlDetail\n"); return 2; } }
+        else if (a == "--dual") { std::string m = next(); dual = true; dual_second = (m == "vng4") ? ARTGPU_DUAL_VNG4 : ARTGPU_DUAL_BILINEAR; }
+        else if (a == "--dual-contrast") { dual_contrast = std::atof(next()); dual_auto = false; }
+        else if (a == "--logenc") { logenc = true; logenc_reg = std::atoi(next()); }
+        else if (a == "--saturation") { if (std::sscanf(next(), "%d,%d", &sat, &vib) != 2) { std::fprintf(stderr, "--saturation S,V\n"); return 2; } }
+        else if (a == "--labchroma") { labchroma = std::atoi(next()); labcurve = true; }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     if (in.empty() || W <= 0 || H <= 0) { std::fprintf(stderr, "usage: artgpu-cli --in frame.f32 --width W --height H [options]\n"); return 2; }
@@ -82,6 +91,18 @@ int main(int argc, char **argv)
         params.exposure.expcomp = expcomp;
         params.toneCurve.lut = default_tone_lut();
         params.toneCurve.curveMode = tone_mode;
+        // the default-off tools of SURVEY 8f N4, driven through the same ImProcFunctions mirror
+        params.bayersensor.dual = dual; params.bayersensor.dualSecond = dual_second;
+        params.bayersensor.dualDemosaicContrast = dual_contrast; params.bayersensor.dualDemosaicAutoContrast = dual_auto;
+        params.logenc.enabled = logenc; params.logenc.regularization = logenc_reg;
+        params.saturation.enabled = sat != 0 || vib != 0; params.saturation.saturation = sat; params.saturation.vibrance = vib;
+        params.labCurve.enabled = labcurve; params.labCurve.chromaticity = labchroma;
+        params.labCurve.curves = [](const uint32_t *, std::vector<float> &lc, std::vector<float> &ac, std::vector<float> &bc) {
+            // stands in for get_L_curve / get_ab_curves (DiagonalCurve, host code of the application): identity curves, so only chromaticity acts
+            lc.resize(32770); ac.resize(65536); bc.resize(65536);
+            for (int i = 0; i < 32770; ++i) lc[i] = (float)i;
+            for (int i = 0; i < 65536; ++i) ac[i] = bc[i] = (float)i;
+        };
 
         auto t0 = std::chrono::steady_clock::now();
         // stage_init (simpleprocess.cc:215-259)

@@ -141,3 +141,29 @@ def test_automatic_chroma_through_cli(tmp_path):
     img = O.tone_std(img, tone_lut(), 1.0, True)
     q = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.int32) for p in img], axis=-1)
     assert np.abs(ppm.astype(np.int32) - q).max() <= 3
+
+
+def test_n4_tools_through_the_cpp_mirror(tmp_path):
+    """dual demosaic (RCD + VNG4, automatic contrast), log encoding, saturation / vibrance and Lab chromaticity driven through
+    rtengine_gpu.h's RawImageSource::demosaic / ImProcFunctions::process, against the same chain of oracle calls"""
+    w, h, filt = 1000, 760, synth.FILTERS_RGGB
+    raw = synth.bayer_frame(w, h, filt, seed=31, noise=300)
+    rng = np.random.default_rng(8)
+    raw[300:370, 400:470] = (9000.0 + rng.normal(0, 200.0, (70, 70))).astype(np.float32)      # a flat tile for the threshold search
+    info, got = run_cli(tmp_path, raw, "rcd", ["--dual", "vng4", "--logenc", "60", "--saturation", "25,-30", "--labchroma", "20", "--expcomp", "0.2"])
+    planes, contrast = O.dual_demosaic_blend(raw, O.rcd(raw, filt), filt, 20.0, True, vng4=True)
+    assert 0.0 < contrast < 100.0
+    img = O.get_image(planes, 4, 4, w - 8, h - 8, MUL, True)
+    img = O.convert_color_space(img, MAT)
+    img = O.exposure(img, float(np.float32(2.0 ** 0.2)), 0.0)                                   # STAGE_1
+    img = O.log_encoding(img, regularization=60, full_width=0, full_height=0)                  # STAGE_3: logEncoding, saturationVibrance, toneCurve, labAdjustments
+    img = O.saturation_vibrance(img, 25, -30)
+    img = O.tone_std(img, tone_lut(), 1.0, True)
+    lab = O.image_rgb_to_lab(img)
+    ident_l = np.arange(32770, dtype=np.float32)
+    ident = np.arange(65536, dtype=np.float32)
+    lab = O.lab_adjustments(lab, ident_l, ident, ident, np.float32((20 + 100.0) / 100.0))
+    img = O.image_lab_to_rgb(lab, O.REC2020_IWS_D)
+    ref = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.uint16) for p in img], axis=-1)
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)
