@@ -102,18 +102,26 @@ __device__ __forceinline__ void yvv_line(float *__restrict__ p, size_t st, float
     float t2 = sizeof(C) == 4 ? (float)(p[2 * st] * B + t1 * b1 + t0 * b2 + s0 * b3) : (float)(B * p[2 * st] + b1 * t1 + b2 * t0 + b3 * s0);
     tmp[0] = t0; tmp[tst] = t1; tmp[2 * tst] = t2;
     float m3 = t0, m2 = t1, m1 = t2;
-    // the loads do not depend on the recurrence: sixteen of them are issued before the sixteen steps that consume them
+    // the loads do not depend on the recurrence: sixteen of them are issued before the sixteen steps that consume them -- and one batch
+    // AHEAD of the stores of the current batch: vmcnt retires in order, so a wait for loads issued after stores would wait for the stores too
     int j = 3;
-    for (; j + 16 <= n; j += 16) {
-        float x[16];
+    float x[16], xn[16];
+    if (j + 16 <= n) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = p[(size_t)(j + k) * st];
+    }
+    for (; j + 16 <= n; j += 16) {
+        const bool more = j + 32 <= n;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) xn[k] = p[(size_t)(more ? j + 16 + k : j + k) * st];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const float v = sizeof(C) == 4 ? (float)(x[k] * B + m1 * b1 + m2 * b2 + m3 * b3) : (float)(B * x[k] + b1 * m1 + b2 * m2 + b3 * m3);
             tmp[(size_t)(j + k) * tst] = v;
             m3 = m2; m2 = m1; m1 = v;
         }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = xn[k];
     }
     for (; j < n; j++) {
         const float v = sizeof(C) == 4 ? (float)(p[(size_t)j * st] * B + m1 * b1 + m2 * b2 + m3 * b3) : (float)(B * p[(size_t)j * st] + b1 * m1 + b2 * m2 + b3 * m3);
@@ -129,16 +137,22 @@ __device__ __forceinline__ void yvv_line(float *__restrict__ p, size_t st, float
     p[(size_t)(n - 1) * st] = r1; p[(size_t)(n - 2) * st] = r2; p[(size_t)(n - 3) * st] = r3;
     float a1 = r3, a2 = r2, a3 = r1; // outputs at j+1, j+2, j+3
     int jb = n - 4;
-    for (; jb - 15 >= 0; jb -= 16) {
-        float x[16];
+    if (jb - 15 >= 0) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) x[k] = tmp[(size_t)(jb - k) * tst];
+    }
+    for (; jb - 15 >= 0; jb -= 16) {
+        const bool more = jb - 31 >= 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) xn[k] = tmp[(size_t)(more ? jb - 16 - k : jb - k) * tst];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const float v = sizeof(C) == 4 ? (float)(x[k] * B + a1 * b1 + a2 * b2 + a3 * b3) : (float)(B * x[k] + b1 * a1 + b2 * a2 + b3 * a3);
             p[(size_t)(jb - k) * st] = v;
             a3 = a2; a2 = a1; a1 = v;
         }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x[k] = xn[k];
     }
     for (; jb >= 0; jb--) {
         const float tj = tmp[(size_t)jb * tst];
