@@ -574,21 +574,32 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
     rlen = 1.f / lenf;
     // steady state, 8 rows of independent loads in flight
     const int steady_end = H - rad;
-    for (; row + 8 <= steady_end; row += 8) {
-        float hi[8], lo[8], sf[8], c[8];
+    // One wave owns 64 columns for the whole height, and there are only W / 64 x bands of them (fewer than four per CU), so a batch's
+    // memory latency is not hidden by other waves: the next batch is loaded while this one is computed, and its loads are issued BEFORE
+    // this batch's stores (vmcnt retires in order: a wait for loads issued after stores waits for the stores as well).
+    constexpr int VB = 8;       // rows per batch: 4 x 8 loads in flight per lane, two batches deep (16 rows per batch measured no better)
+    float hi[VB], lo[VB], sf[VB], c[VB], nhi[VB], nlo[VB], nsf[VB], nc[VB];
+    auto fetch = [&](int r, float *h_, float *l_, float *s_, float *c_) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            hi[k] = t[(size_t)(row + k + rad) * W + col];
-            lo[k] = t[(size_t)(row + k - rad - 1) * W + col];
-            sf[k] = a.plain ? 0.f : sfave[(size_t)(row + k) * W + col];
-            c[k] = a.plain ? 0.f : coef[(size_t)(row + k) * W + col];
+        for (int k = 0; k < VB; ++k) {
+            h_[k] = t[(size_t)(r + k + rad) * W + col];
+            l_[k] = t[(size_t)(r + k - rad - 1) * W + col];
+            s_[k] = a.plain ? 0.f : sfave[(size_t)(r + k) * W + col];
+            c_[k] = a.plain ? 0.f : coef[(size_t)(r + k) * W + col];
         }
+    };
+    if (row + VB <= steady_end) fetch(row, hi, lo, sf, c);
+    for (; row + VB <= steady_end; row += VB) {
+        const bool more = row + 2 * VB <= steady_end;
+        fetch(more ? row + VB : row, nhi, nlo, nsf, nc);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < VB; ++k) {
             const float d = hi[k] - lo[k];
             tv = vec ? tv + d * rlen : tv + d / leni;
             commit(row + k, tv, sf[k], c[k]);
         }
+#pragma unroll
+        for (int k = 0; k < VB; ++k) { hi[k] = nhi[k]; lo[k] = nlo[k]; sf[k] = nsf[k]; c[k] = nc[k]; }
     }
     for (; row < steady_end; ++row) {
         const float d = t[(size_t)(row + rad) * W + col] - t[(size_t)(row - rad - 1) * W + col];
