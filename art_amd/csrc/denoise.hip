@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(256) bishrink_AB_kernel(ShrinkArgs a)
 // HB_MAXR: 15 for the wavelet-level radii (window of two 64-column groups); 63 for the large radii of rtengine::guidedFilter
 // callers (three groups).  Same arithmetic, only the LDS window differs.
 constexpr int HB_ROWS = 16, HB_COLS = 64;
-template <int HB_MAXR>
+template <int HB_MAXR, bool SDIV>
 __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
 {
     constexpr int HB_TW = HB_COLS + 2 * HB_MAXR + 2; // source window held in LDS
@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
                     for (int i = 0; i < 8; ++i) { hi[i] = s[j0 + i + rad]; lo[i] = s[j0 + i - rad - 1]; }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        tempval = a.steady_div ? tempval + (hi[i] - lo[i]) / (float)len : tempval + (hi[i] - lo[i]) * reclen;
+                        if constexpr (SDIV) tempval = tempval + (hi[i] - lo[i]) / (float)len; else tempval = tempval + (hi[i] - lo[i]) * reclen;
                         oT[lane][j0 + i] = tempval;
                     }
                 }
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
                         len++;
                         if (col == rad) reclen = 1.f / len;
                     } else if (col < W - rad) {
-                        tempval = a.steady_div ? tempval + (s[j + rad] - s[j - rad - 1]) / (float)len : tempval + (s[j + rad] - s[j - rad - 1]) * reclen;
+                        if constexpr (SDIV) tempval = tempval + (s[j + rad] - s[j - rad - 1]) / (float)len; else tempval = tempval + (s[j + rad] - s[j - rad - 1]) * reclen;
                     } else {
                         tempval = (tempval * len - s[j - rad - 1]) / (len - 1);
                         len--;
@@ -696,8 +696,15 @@ hipError_t launch_hblur(const BlurArgs &a, int nsub, hipStream_t s)
         hipLaunchKernelGGL(hblur_big_kernel, dim3((a.h + HB_ROWS - 1) / HB_ROWS, nsub), dim3(64), lds, s, a);
         return hipGetLastError();
     }
-    if (maxr <= 15) hipLaunchKernelGGL(hblur_kernel<15>, dim3((a.h + HB_ROWS - 1) / HB_ROWS, nsub), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(hblur_kernel<63>, dim3((a.h + HB_ROWS - 1) / HB_ROWS, nsub), dim3(64), 0, s, a);
+    // steady_div (the boxblur.h:318 variant of the guided filter) is a template parameter: as a run-time select both forms were evaluated
+    const dim3 grid((a.h + HB_ROWS - 1) / HB_ROWS, nsub);
+    if (maxr <= 15) {
+        if (a.steady_div) hipLaunchKernelGGL((hblur_kernel<15, true>), grid, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((hblur_kernel<15, false>), grid, dim3(64), 0, s, a);
+    } else {
+        if (a.steady_div) hipLaunchKernelGGL((hblur_kernel<63, true>), grid, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((hblur_kernel<63, false>), grid, dim3(64), 0, s, a);
+    }
     return hipGetLastError();
 }
 hipError_t launch_vblur_combine(const BlurArgs &a, int nsub, hipStream_t s)
