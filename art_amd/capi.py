@@ -114,6 +114,7 @@ def _load():
     lib.artgpu_version.restype = C.c_char_p
     lib.artgpu_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.artgpu_synchronize.argtypes = [C.c_void_p]
+    lib.artgpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
     lib.artgpu_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.artgpu_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
     lib.artgpu_scratch_bytes.argtypes = [C.c_void_p]
@@ -173,7 +174,7 @@ def _load():
 
 LIB = _load()
 
-EXPORTS = ["artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
+EXPORTS = ["artgpu_set_option", "artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
            "artgpu_synchronize", "artgpu_enable_timing", "artgpu_get_timings", "artgpu_scratch_bytes",
            "artgpu_demosaic_bayer", "artgpu_border_interpolate2", "artgpu_get_image",
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
@@ -217,6 +218,9 @@ class Context:
 
     def synchronize(self):
         self._chk(LIB.artgpu_synchronize(self._h))
+
+    def set_option(self, name: str, value: int):
+        self._chk(LIB.artgpu_set_option(self._h, name.encode(), C.c_long(int(value))))
 
     def enable_timing(self, on: bool = True):
         self._chk(LIB.artgpu_enable_timing(self._h, int(on)))

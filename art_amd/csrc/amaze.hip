@@ -532,7 +532,9 @@ amaze_kernel(AmazeArgs a)
         if (fc(filters, 0, 0) == 0) { ey = 0; ex = 0; } else { ey = 1; ex = 1; }
     }
 
-    for (int tile = blockIdx.x / G; tile < a.ntiles; tile += gridDim.x / G) {
+    const int nlisted = a.tile_count ? *a.tile_count : a.ntiles;
+    for (int kt = blockIdx.x / G; kt < nlisted; kt += gridDim.x / G) {
+        const int tile = a.tile_list ? a.tile_list[kt] : kt;
         const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
         const int top = -16 + ty * (ts - 32), left = -16 + tx * (ts - 32);
         const int bottom = min(top + ts, height + 16), right = min(left + ts, width + 16);
@@ -1212,7 +1214,7 @@ hipError_t launch_amaze(const AmazeArgs &a, int grid, hipStream_t stream)
     // one kernel per phase over all tiles instead (needs one arena per tile): bit-identical, 7.5 ms -- every phase then streams
     // its planes of ALL tiles through HBM, which makes it the per-phase bandwidth profile of the algorithm
     // (profiles/r1/amaze_split_phase_stats.csv) rather than the fast path.
-    const bool split = getenv("ARTGPU_AMAZE_SPLIT") != nullptr && grid >= a.ntiles;
+    const bool split = a.split && !a.tile_list && grid >= a.ntiles;
     if (!split) {
 #if AMAZE_STREAM_FRONT
         constexpr size_t dyn = (size_t)SF_LDS_FLOATS * sizeof(float);

@@ -1,0 +1,972 @@
+// art_amd/csrc/amaze_stream_core.h -- AMaZE v2: the tile state lives in LDS.
+//
+// Replaces RawImageSource::amaze_demosaic_RT (reference: rtengine/amaze_demosaic_RT.cc:41-1595) for FULL tiles
+// (160x160, the reference's tile grid).  One 1024-thread workgroup walks a tile top to bottom ONCE, two rows per step.
+// Every phase of the reference runs a fixed number of rows ("off") behind the load front on ring buffers in LDS, so the
+// CFA is read once from memory, R/G/B are written once, and no intermediate plane ever leaves the CU.
+//
+//   step t, sub-step a:  load rows (2t,2t+1) | P2 @6 | P4 @14 | P5+P6 @12 | P8 @22 (window rows -6..0) | P10+P14+P15 @30 | P12 @24
+//   ---- LDS barrier ----
+//   step t, sub-step b:  P1 @2 | P3 @8 | P7 @14 | P8 @22 (window rows 2..6) | P9 @26 | P11 @20 | P13 @26 | P16 @34 | output @38 | P8 site list @20
+//   ---- LDS barrier ----
+//
+// A stage at offset "off" handles tile rows (2t-off, 2t-off+1).  A stage of sub-step b may read what sub-step a of the SAME
+// step wrote; everything else reads rows completed in earlier steps, so the two barriers per step are the only
+// synchronisation.  The three row recurrences of the reference (vcd L540-583: stride 2, so the two rows of a step are
+// independent; hvwt L958-974 and pmwt L1213-1223: one wave walks the two rows in order) keep their exact order.
+//
+// What the arena formulation (amaze.hip, v1) got for free from the reference's plane layout is reproduced explicitly:
+//   * positions the reference never writes but reads as 0 (cleared per tile): columns 0-3/156-159 and rows 2,3,156,157 of
+//     vcd/hcd/vcdalt/hcdalt, the nyquist flag bytes without a site, nyquist2 rows 2-7 and 152-157;
+//   * pmwt aliases delhvsqsum (L169): P13's over-run sites read pmwt half-columns 76..79 that P12 never writes, i.e.
+//     delhvsqsum(rr/2, (rr&1)*80 + 76..79) -- kept in a side table when P1 produces those rows;
+//   * nyquist2 aliases cddiffsq and its memset (L879) stops at row 155: rows 156,157 are the bytes of cddiffsq(19, 80..119);
+//   * Dgrb2 aliases dgintv, Dgrb1 aliases vcdalt: only positions outside what any output depends on.
+// The Nyquist bounding box (L806-876) is tile-global and only known after the whole tile went through P6.  The stream
+// assumes "every nyquist2 site lies inside the box"; it records the box and the extent of the sites it processed, and a
+// tile where that does not hold is re-done by the arena kernel (exact fallback, amaze.hip).
+//
+// The same source compiles for the device (amaze_stream.hip) and, with AMZ_EMUL, as a sequential CPU emulation used by
+// tests/test_amaze_stream_emul.py to check the schedule against the oracle without a GPU (test harness only).
+#pragma once
+
+#ifdef AMZ_EMUL
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#define AMZ_DEV static inline
+typedef float *amz_lf;
+typedef unsigned char *amz_lb;
+typedef int *amz_li;
+typedef const float *amz_gcf;
+typedef float *amz_gf;
+namespace amz {
+static inline unsigned fc(unsigned filters, unsigned row, unsigned col) { return (filters >> (((((row) << 1) & 14u) + ((col) & 1u)) << 1)) & 3u; }
+static inline float sse_min(float x, float y) { return x < y ? x : y; }
+static inline float sse_max(float x, float y) { return x > y ? x : y; }
+static inline float sqr(float x) { return x * x; }
+static inline float intp(float a, float b, float c) { return a * b + (1.f - a) * c; }
+static inline float median3(float a, float b, float c) { return sse_max(sse_min(a, b), sse_min(c, sse_max(a, b))); }
+static inline float xdiv2f(float d) { int32_t i; memcpy(&i, &d, 4); if (i & 0x7FFFFFFF) i -= 1 << 23; memcpy(&d, &i, 4); return d; }
+static inline float xdivf(float d, int n) { int32_t i; memcpy(&i, &d, 4); if (i & 0x7FFFFFFF) i -= n << 23; memcpy(&d, &i, 4); return d; }
+static inline int ngroups(int start, int bound, int step) { return bound > start ? (bound - start + step - 1) / step : 0; }
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+}
+#else
+#include <hip/hip_runtime.h>
+#include "devmath.h"
+#define AMZ_DEV __device__ __forceinline__
+typedef __attribute__((address_space(3))) float *amz_lf;
+typedef __attribute__((address_space(3))) unsigned char *amz_lb;
+typedef __attribute__((address_space(3))) int *amz_li;
+typedef const __attribute__((address_space(1))) float *amz_gcf;
+typedef __attribute__((address_space(1))) float *amz_gf;
+namespace amz {
+using artgpu::fc; using artgpu::sse_min; using artgpu::sse_max; using artgpu::sqr; using artgpu::intp; using artgpu::median3;
+using artgpu::xdiv2f; using artgpu::xdivf; using artgpu::ngroups;
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+}
+#endif
+
+namespace amz {
+
+constexpr int TS = 160, TSH = 80;
+constexpr float eps = 1e-5f, epssq = 1e-10f, arthresh = 0.75f;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Ring buffers: name, depth in rows, row stride in floats.  depth >= (offset of the last reader + its upward reach)
+// - (offset of the writer) + 2; the emulation checks every read against a row tag (AMZ_EMUL).
+// ---------------------------------------------------------------------------------------------------------------------
+#define AMZ_RINGS(X)                                                                                                     \
+    X(CFA, 40, 160)  /* load @0 .. output @38 */                                                                       \
+    X(D0, 8, 160)    /* dirwts0: P1 @2 -> P2 @6 (+-2 rows) */                                                          \
+    X(D1, 6, 160)    /* dirwts1: P1 @2 -> P2 @6 */                                                                     \
+    X(DHV, 14, 160)  /* delhvsqsum: P1 @2 -> P5 @12 (+-2) */                                                           \
+    X(HCA, 4, 160)   /* hcdalt: P2 @6 -> P3 @8 */                                                                      \
+    X(VCA, 6, 160)   /* vcdalt: P2 @6 -> P3 @8 (+-2) */                                                                \
+    X(VCD, 14, 160)  /* vcd: P2 @6, updated in place by P3 @8 -> P4 @14 (+-3) */                                       \
+    X(HCO, 4, 160)   /* hcd as P2 leaves it -> P3 @8 */                                                                \
+    X(HCN, 8, 160)   /* hcd after P3 @8 -> P4 @14 */                                                                   \
+    X(CDD, 8, 160)   /* cddiffsq: P3 @8 -> P5 @12 (+-2) */                                                             \
+    X(DGV, 12, 160)  /* dgintv: P2 @6 -> P4 @14 (+-2) */                                                               \
+    X(DGH, 10, 160)  /* dginth: P2 @6 -> P4 @14 */                                                                     \
+    X(HVW, 10, 160)  /* hwt [idx], vwt [80+idx] at R/B sites: P2 @6 -> P4 @14 */                                       \
+    X(VH, 18, 160)   /* vcd [idx], hcd [80+idx] at R/B sites: P4 @14 -> P9 @26, P10 @30 */                             \
+    X(HVWT, 28, 80)  /* hvwt: P4 @14, P8 @22, P9 @26 in place -> P14 @30, output @38 (+-1) */                          \
+    X(NYQ, 6, 20)    /* nyquist flag bytes: P5 @12 -> P7 @14 (+-2) */                                                  \
+    X(NYQ2, 16, 20)  /* nyquist2 bytes: P7 @14 -> P8 @22 (+-6), P9 @24, P10 @28 */                                     \
+    X(DG2, 8, 160)   /* Dgrb2 {h,v} pairs: P9 @24 -> P10 @28 (+-2) */                                                  \
+    X(DG0, 16, 80)   /* Dgrb[0]: P9 @24, P10/P14/P15 @28, P16 @32 -> output @36 (+-1) */                               \
+    X(DG1, 12, 80)   /* Dgrb[1]: P15 @28, P16 @32 -> output @36 (+-1) */                                               \
+    X(RGBG, 14, 80)  /* rgbgreen at R/B sites: P9 @24, P10/P14 @28 -> output @36 */                                    \
+    X(DELP, 8, 80)   /* P11 @18 -> P12 @22 (+-2) */                                                                    \
+    X(DELM, 8, 80)                                                                                                      \
+    X(DM, 8, 80)     /* Dgrbsq1m */                                                                                     \
+    X(DP, 8, 80)     /* Dgrbsq1p */                                                                                     \
+    X(RBM, 4, 80)    /* P12 @22 -> P13 @24 */                                                                          \
+    X(RBP, 4, 80)                                                                                                       \
+    X(PMWT, 8, 80)   /* P12 @22, P13 @24 in place -> P14 @28 */                                                        \
+    X(RBINT, 8, 80)  /* P13 @24 -> P14 @28 (+-2 rows) */
+
+enum RingId {
+#define X(n, d, s) R_##n,
+    AMZ_RINGS(X)
+#undef X
+    R_COUNT
+};
+#define X(n, d, s) constexpr int n##_D = d, n##_S = s;
+AMZ_RINGS(X)
+#undef X
+// float offsets of the rings inside the workgroup's LDS block
+struct RingLayout {
+    int off[R_COUNT + 1];
+    constexpr RingLayout() : off()
+    {
+        int o = 0, k = 0;
+#define X(n, d, s) off[k++] = o; o += d * s;
+        AMZ_RINGS(X)
+#undef X
+        off[k] = o;
+    }
+};
+constexpr RingLayout LAYOUT{};
+#define X(n, d, s) constexpr int n##_OFF = LAYOUT.off[R_##n];
+AMZ_RINGS(X)
+#undef X
+constexpr int SIDE_OFF = LAYOUT.off[R_COUNT];   // delhvsqsum(row 4..75, cols 76..79 and 156..159): what pmwt[.., 76..79] aliases
+constexpr int SIDE_FLOATS = 72 * 8;
+constexpr int NQA_OFF = SIDE_OFF + SIDE_FLOATS;  // cddiffsq(row 19, cols 80..119): the bytes nyquist2 rows 156,157 alias (never memset, L879)
+constexpr int NQA_FLOATS = 40;
+constexpr int LIST_OFF = NQA_OFF + NQA_FLOATS;   // P8 site list of one step (row << 8 | col), at most 144 entries
+constexpr int LIST_INTS = 160;                   // two lists: the one step t consumes is rebuilt (for step t+2) only after step t
+constexpr int RED_OFF = LIST_OFF + 2 * LIST_INTS;    // int words: [0..3] flag box (min row, max row, min col, max col), [4..7] extent of the
+constexpr int RED_INTS = 16;                     // nyquist2 sites P8 processed, [8], [9] list counts
+constexpr int LDS_FLOATS = RED_OFF + RED_INTS;
+static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+
+constexpr int NTHREADS = 1024;
+constexpr int LAST_OFF = 38;
+constexpr int NSTEPS = (TS + LAST_OFF) / 2;
+
+#ifdef AMZ_EMUL
+// row tags: which tile row a ring slot holds (emulation only)
+struct Tags { int row[R_COUNT][64]; long long errors; int first_ring, first_want, first_have; };
+static Tags g_tags;
+static inline void tag_write(int ring, int depth, int row) { g_tags.row[ring][(unsigned)row % depth] = row; }
+static inline void tag_read(int ring, int depth, int row)
+{
+    const int have = g_tags.row[ring][(unsigned)row % depth];
+    if (have != row) {
+        if (!g_tags.errors) { g_tags.first_ring = ring; g_tags.first_want = row; g_tags.first_have = have; }
+        g_tags.errors++;
+    }
+}
+#define AMZ_TAGW(n, row) amz::tag_write(amz::R_##n, amz::n##_D, (row))
+#define AMZ_TAGR(n, row) amz::tag_read(amz::R_##n, amz::n##_D, (row))
+#else
+#define AMZ_TAGW(n, row) ((void)0)
+#define AMZ_TAGR(n, row) ((void)0)
+#endif
+// row pointers: W = this stage writes the row, R = it reads a row that must hold exactly that tile row,
+// X = it reads a row whose content cannot reach an output (no check)
+#define ROWW(n, row) (AMZ_TAGW(n, row), lds + (amz::n##_OFF + (int)((unsigned)(row) % amz::n##_D) * amz::n##_S))
+#define ROWR(n, row) (AMZ_TAGR(n, row), lds + (amz::n##_OFF + (int)((unsigned)(row) % amz::n##_D) * amz::n##_S))
+#define ROWX(n, row) (lds + (amz::n##_OFF + (int)((unsigned)(row) % amz::n##_D) * amz::n##_S))
+// the same for a row r + k + s where r is uniform over the wave and s (0 or 1) differs per lane: both candidates are scalar
+// computations (a per-lane modulo costs five VALU instructions per row pointer), the lane only selects
+#define AMZ_SLOT(n, row) (amz::n##_OFF + (int)((unsigned)(row) % amz::n##_D) * amz::n##_S)
+#define SROWW(n, r, k, s) (AMZ_TAGW(n, (r) + (k) + (s)), lds + ((s) ? AMZ_SLOT(n, (r) + (k) + 1) : AMZ_SLOT(n, (r) + (k))))
+#define SROWR(n, r, k, s) (AMZ_TAGR(n, (r) + (k) + (s)), lds + ((s) ? AMZ_SLOT(n, (r) + (k) + 1) : AMZ_SLOT(n, (r) + (k))))
+#define SROWX(n, r, k, s) (lds + ((s) ? AMZ_SLOT(n, (r) + (k) + 1) : AMZ_SLOT(n, (r) + (k))))
+
+struct TileArgs {
+    amz_gcf raw;        // CFA plane
+    long rs;            // row stride in floats
+    amz_gf red, green, blue;
+    long os;
+    int top, left;      // tile origin in the frame (may be negative: mirrored border, L205-334)
+    int W, H;
+    unsigned filters;
+    float clip_pt, clip_pt8;
+    int g00;            // 1 if (0,0) is a green site
+    int ey;             // row parity of the red sites (L1381: ey, ex)
+};
+
+// parity helpers: site (r,c) is green iff ((r + c) & 1) ^ g00; the R/B sites of row r are the columns cc = par(r) mod 2
+AMZ_DEV int row_par(const TileArgs &a, int r) { return (r & 1) ^ a.g00; }
+AMZ_DEV bool is_green(const TileArgs &a, int r, int c) { return (((r + c) & 1) ^ a.g00) != 0; }
+
+// highlight bounding of a colour difference (amaze_demosaic_RT.cc:555-581)
+AMZ_DEV float bound_cd(float cdv, float sgn, float c, float nA, float nB, float clip_pt)
+{
+    const float nsgn = -sgn, sgn3 = sgn + sgn + sgn;
+    const float Gint = sgn * cdv + c;
+    const float temp2 = sgn3 * cdv;
+    const float wt = 1.f + temp2 / (eps + Gint + c);
+    const bool mask = (nsgn * cdv) > 0.f;
+    const float old = cdv;
+    const float temp = nsgn * (c - median3(Gint, nA, nB));
+    cdv = (temp2 < -(c + Gint)) ? temp : intp(wt, cdv, temp);
+    cdv = mask ? cdv : old;
+    cdv = (Gint > clip_pt) ? temp : cdv;
+    return cdv;
+}
+AMZ_DEV float var3(float a, float b, float c) { return sqr(a - b) + sqr(a - c) + sqr(b - c); }
+AMZ_DEV float rb_ratio(float cfav, float t1, float t2)
+{
+    float r = (t1 + t1) / (eps + cfav + t2);
+    return fabsf(1.f - r) < arthresh ? cfav * r : t1 + 0.5f * (cfav - t2);
+}
+AMZ_DEV float rb_bound(float rbv, float cfav, float nA, float nB, float clip_pt)
+{
+    float t1 = median3(rbv, nA, nB);
+    float wt = ((cfav - rbv) + (cfav - rbv)) / (eps + rbv + cfav);
+    float t2 = intp(wt, rbv, t1);
+    t2 = (rbv + rbv < cfav) ? t1 : t2;
+    t2 = (rbv < cfav) ? t2 : rbv;
+    return (t2 > clip_pt) ? median3(t2, nA, nB) : t2;
+}
+AMZ_DEV float g_dir(float rb, float cn, float rbn)
+{
+    float cr = (cn + cn) / (eps + rb + rbn);
+    float g = rb * cr;
+    float g2 = cn + 0.5f * (rb - rbn);
+    return fabsf(1.f - cr) < arthresh ? g : g2;
+}
+AMZ_DEV float g_bound(float Gint, float rb, float nA, float nB, float clip_pt)
+{
+    float G1 = median3(Gint, nA, nB);
+    float wt = ((rb - Gint) + (rb - Gint)) / (eps + Gint + rb);
+    float G2 = intp(wt, Gint, G1);
+    G1 = ((Gint + Gint) < rb) ? G1 : G2;
+    Gint = (Gint < rb) ? G1 : Gint;
+    return (Gint > clip_pt) ? median3(Gint, nA, nB) : Gint;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// source pixel of tile position (rr, cc): the reference's mirrored 16-pixel image border (L205-334)
+// ---------------------------------------------------------------------------------------------------------------------
+// (the four corner blocks use 32 - rr / 32 - cc WITHOUT the tile origin, L282-334, the edge strips 32 - rr + top)
+AMZ_DEV int src_row(const TileArgs &a, int rr, int cc)
+{
+    const int y = a.top + rr, x = a.left + cc;
+    if (y < 0) return (x < 0 || x >= a.W) ? 32 - rr : 32 - rr + a.top;
+    if (y >= a.H) return 2 * a.H - 2 - y;      // below the frame: H - (rr - rrmax) - 2
+    return y;
+}
+AMZ_DEV int src_col(const TileArgs &a, int rr, int cc)
+{
+    const int y = a.top + rr, x = a.left + cc;
+    if (x < 0) return (y < 0 || y >= a.H) ? 32 - cc : 32 - cc + a.left;
+    if (x >= a.W) return 2 * a.W - 2 - x;
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Stages.  "r" is the first (even) row of the pair a stage handles in this step; c is the thread's column 0..159
+// (or 160..191 for the helper lanes of a 192-thread group).
+// ---------------------------------------------------------------------------------------------------------------------
+
+// P1 (L342-351): gradients of row r, all 160 columns (4-lane groups over [0, cc1)); neighbours past a row end continue in
+// the adjacent row of the flat tile
+AMZ_DEV void st_p1(amz_lf lds, const TileArgs &a, int r, int c)
+{
+    if (r < 2 || r >= TS - 2 || c >= TS) return;
+    amz_lf cm2 = ROWR(CFA, r - 2), cm1 = ROWR(CFA, r - 1), c0r = ROWR(CFA, r), cp1 = ROWR(CFA, r + 1), cp2 = ROWR(CFA, r + 2);
+    const float cl1 = c >= 1 ? c0r[c - 1] : cm1[TS + c - 1];
+    const float cl2 = c >= 2 ? c0r[c - 2] : cm1[TS + c - 2];
+    const float cr1 = c + 1 < TS ? c0r[c + 1] : cp1[c + 1 - TS];
+    const float cr2 = c + 2 < TS ? c0r[c + 2] : cp1[c + 2 - TS];
+    const float c0 = c0r[c];
+    const float cu1 = cm1[c], cu2 = cm2[c], cd1 = cp1[c], cd2 = cp2[c];
+    const float delh = fabsf(cr1 - cl1);
+    const float delv = fabsf(cd1 - cu1);
+    const float w1 = eps + fabsf(cr2 - c0) + fabsf(c0 - cl2) + delh;
+    const float w0 = eps + fabsf(cd2 - c0) + fabsf(c0 - cu2) + delv;
+    const float dq = sqr(delh) + sqr(delv);
+    ROWW(D0, r)[c] = w0;
+    ROWW(D1, r)[c] = w1;
+    ROWW(DHV, r)[c] = dq;
+    if (r >= 4 && r < 76) {
+        if (c >= 76 && c < 80) lds[SIDE_OFF + (r - 4) * 8 + (c - 76)] = dq;
+        if (c >= 156) lds[SIDE_OFF + (r - 4) * 8 + 4 + (c - 156)] = dq;
+    }
+}
+
+// P2 (L380-434): colour differences of row r, columns 4..155; zero where the reference's cleared planes are read unwritten
+AMZ_DEV void st_p2(amz_lf lds, const TileArgs &a, int r, int c)
+{
+    if (r < 2 || r >= TS - 2 || c >= TS) return;
+    float o_hcdalt = 0.f, o_vcdalt = 0.f, o_vcd = 0.f, o_hcd = 0.f;
+    if (r >= 4 && r < TS - 4 && c >= 4 && c < TS - 4) {
+        amz_lf cr = ROWR(CFA, r), d0r = ROWR(D0, r), d1r = ROWR(D1, r);
+        const float sgn = is_green(a, r, c) ? -1.f : 1.f;
+        const float cfav = cr[c];
+        const float cu1 = ROWR(CFA, r - 1)[c], cu2 = ROWR(CFA, r - 2)[c];
+        const float cd1 = ROWR(CFA, r + 1)[c], cd2 = ROWR(CFA, r + 2)[c];
+        const float cl1 = cr[c - 1], cl2 = cr[c - 2], cr1 = cr[c + 1], cr2 = cr[c + 2];
+        const float d0c = d0r[c], d1c = d1r[c];
+        const float d0u2 = ROWR(D0, r - 2)[c], d0d2 = ROWR(D0, r + 2)[c], d1l2 = d1r[c - 2], d1r2 = d1r[c + 2];
+        const float cru = cu1 * (d0u2 + d0c) / (d0u2 * (eps + cfav) + d0c * (eps + cu2));
+        const float crd = cd1 * (d0d2 + d0c) / (d0d2 * (eps + cfav) + d0c * (eps + cd2));
+        const float crl = cl1 * (d1l2 + d1c) / (d1l2 * (eps + cfav) + d1c * (eps + cl2));
+        const float crr = cr1 * (d1r2 + d1c) / (d1r2 * (eps + cfav) + d1c * (eps + cr2));
+        const float guha = cu1 + 0.5f * (cfav - cu2);
+        const float gdha = cd1 + 0.5f * (cfav - cd2);
+        const float glha = cl1 + 0.5f * (cfav - cl2);
+        const float grha = cr1 + 0.5f * (cfav - cr2);
+        float guar = fabsf(1.f - cru) < arthresh ? cfav * cru : guha;
+        float gdar = fabsf(1.f - crd) < arthresh ? cfav * crd : gdha;
+        float glar = fabsf(1.f - crl) < arthresh ? cfav * crl : glha;
+        float grar = fabsf(1.f - crr) < arthresh ? cfav * crr : grha;
+        const float d1l = d1r[c - 1], d1rr = d1r[c + 1], d0u = ROWR(D0, r - 1)[c], d0d = ROWR(D0, r + 1)[c];
+        const float hwt = d1l / (d1l + d1rr);
+        const float vwt = d0u / (d0d + d0u);
+        const float Ginthha = intp(hwt, grha, glha);
+        const float Gintvha = intp(vwt, gdha, guha);
+        o_hcdalt = sgn * (Ginthha - cfav);
+        o_vcdalt = sgn * (Gintvha - cfav);
+        const bool clip = (cfav > a.clip_pt8) || (Gintvha > a.clip_pt8) || (Ginthha > a.clip_pt8);
+        if (clip) { guar = guha; gdar = gdha; glar = glha; grar = grha; }
+        o_vcd = clip ? o_vcdalt : sgn * (intp(vwt, gdar, guar) - cfav);
+        o_hcd = clip ? o_hcdalt : sgn * (intp(hwt, grar, glar) - cfav);
+        ROWW(DGV, r)[c] = sse_min(sqr(guha - gdha), sqr(guar - gdar));
+        ROWW(DGH, r)[c] = sse_min(sqr(glha - grha), sqr(glar - grar));
+        if (!is_green(a, r, c)) {
+            // P4 (L698-699) forms the same two quotients from the same operands (a + b == b + a): hand them over instead of the weights
+            amz_lf hv = ROWW(HVW, r);
+            hv[c >> 1] = hwt;
+            hv[TSH + (c >> 1)] = vwt;
+        }
+    }
+    ROWW(HCA, r)[c] = o_hcdalt;
+    ROWW(VCA, r)[c] = o_vcdalt;
+    ROWW(VCD, r)[c] = o_vcd;
+    ROWW(HCO, r)[c] = o_hcd;
+}
+
+// new hcd of a column whose 4-lane-group lane is 2 or 3: reads original values only (L540-583)
+AMZ_DEV float p3_hcd_pure(amz_lf ho, amz_lf ha, amz_lf cf, const TileArgs &a, int r, int c)
+{
+    const float sgn = is_green(a, r, c) ? -1.f : 1.f;
+    float hcdv = ho[c];
+    const float hv = var3(ho[c - 2], hcdv, ho[c + 2]);
+    const float a0 = ha[c];
+    const float hav = var3(ha[c - 2], a0, ha[c + 2]);
+    hcdv = hav < hv ? a0 : hcdv;
+    return bound_cd(hcdv, sgn, cf[c], cf[c - 1], cf[c + 1], a.clip_pt);
+}
+// P3 (L540-583): variance choice + highlight bounding of row r.  hcd: lanes 0,1 of a 4-lane group read the UPDATED lanes 2,3 of
+// the group to their left (recomputed here: they only depend on original values); vcd: row r reads the updated row r-2.
+AMZ_DEV void st_p3(amz_lf lds, const TileArgs &a, int r, int c)
+{
+    if (r < 4 || r >= TS - 4 || c >= TS) return;
+    float nh = 0.f;
+    if (c >= 4 && c < TS - 4) {
+        amz_lf ho = ROWR(HCO, r), ha = ROWR(HCA, r), cf = ROWR(CFA, r);
+        const int idx = c - 4, k = idx & 3, g = idx >> 2;
+        if (k >= 2) {
+            nh = p3_hcd_pure(ho, ha, cf, a, r, c);
+        } else {
+            const float hm2 = g > 0 ? p3_hcd_pure(ho, ha, cf, a, r, c - 2) : ho[c - 2];
+            const float sgn = is_green(a, r, c) ? -1.f : 1.f;
+            float hcdv = ho[c];
+            const float hv = var3(hm2, hcdv, ho[c + 2]);
+            const float a0 = ha[c];
+            const float hav = var3(ha[c - 2], a0, ha[c + 2]);
+            hcdv = hav < hv ? a0 : hcdv;
+            nh = bound_cd(hcdv, sgn, cf[c], cf[c - 1], cf[c + 1], a.clip_pt);
+        }
+        const float sgn = is_green(a, r, c) ? -1.f : 1.f;
+        amz_lf vr = ROWR(VCD, r);
+        const float n2 = ROWR(VCD, r - 2)[c];
+        const float o0 = vr[c], o2 = ROWR(VCD, r + 2)[c];
+        const float am2 = ROWR(VCA, r - 2)[c], a0 = ROWR(VCA, r)[c], a2 = ROWR(VCA, r + 2)[c];
+        const float cm1 = ROWR(CFA, r - 1)[c], c0 = cf[c], cp1 = ROWR(CFA, r + 1)[c];
+        float vcdv = o0;
+        const float vv = var3(n2, vcdv, o2);
+        const float vav = var3(am2, a0, a2);
+        vcdv = vav < vv ? a0 : vcdv;
+        const float nv = bound_cd(vcdv, sgn, c0, cm1, cp1, a.clip_pt);
+        vr[c] = nv;
+        const float cdq = sqr(nv - nh);
+        ROWW(CDD, r)[c] = cdq;
+        if (r == 19 && c >= 80 && c < 120) lds[NQA_OFF + (c - 80)] = cdq;
+    }
+    ROWW(HCN, r)[c] = nh;      // columns 0-3 and 156-159: the cleared plane
+}
+
+// the R/B site a column thread owns in the row pair (r, r+1): row r + site_sel
+AMZ_DEV int site_sel(const TileArgs &a, int r, int c) { return (c ^ row_par(a, r)) & 1; }
+
+// P4 (L680-728): h/v weight at the R/B site of column c
+AMZ_DEV void st_p4(amz_lf lds, const TileArgs &a, int r, int c)
+{
+    if (c >= TS) return;
+    const int sl = site_sel(a, r, c), rr = r + sl;
+    if (rr < 6 || rr >= TS - 6) return;
+    const int par = row_par(a, rr);
+    if (c < 6 + par || c > 156 + par) return;          // 4 * ngroups(6 + par, 154, 8) = 76 sites: the last group overruns
+    amz_lf hn = SROWR(HCN, r, 0, sl), dh = SROWR(DGH, r, 0, sl);
+    float tv = SROWR(VCD, r, 0, sl)[c];
+    const float vu1 = SROWR(VCD, r, -1, sl)[c], vu2 = SROWR(VCD, r, -2, sl)[c], vu3 = SROWR(VCD, r, -3, sl)[c];
+    const float vd1 = SROWR(VCD, r, +1, sl)[c], vd2 = SROWR(VCD, r, +2, sl)[c], vd3 = SROWR(VCD, r, +3, sl)[c];
+    const float uave = tv + vu1 + vu2 + vu3;
+    const float dave = tv + vd1 + vd2 + vd3;
+    float Dvu = sqr(tv - uave) + sqr(vu1 - uave) + sqr(vu2 - uave) + sqr(vu3 - uave);
+    float Dvd = sqr(tv - dave) + sqr(vd1 - dave) + sqr(vd2 - dave) + sqr(vd3 - dave);
+    amz_lf hv = SROWR(HVW, r, 0, sl);                         // (over-run sites read slots P2 does not write: never used)
+    const float hwt = hv[c >> 1], vwt = hv[TSH + (c >> 1)];
+    const float vcd_c = tv;
+    tv = hn[c];
+    // columns past the row end (over-run sites only): what the flat tile holds there never reaches a site anyone reads
+#define COLZ(row, cc) ((cc) < TS ? (row)[cc] : 0.f)
+    const float hl1 = hn[c - 1], hl2 = hn[c - 2], hl3 = hn[c - 3];
+    const float hr1 = COLZ(hn, c + 1), hr2 = COLZ(hn, c + 2), hr3 = COLZ(hn, c + 3);
+    const float lave = tv + (hl3 + hl2) + hl1;
+    const float rave = tv + (hr1 + hr2) + hr3;
+    float Dhl = sqr(tv - lave) + sqr(hl1 - lave) + sqr(hl2 - lave) + sqr(hl3 - lave);
+    float Dhr = sqr(tv - rave) + sqr(hr1 - rave) + sqr(hr2 - rave) + sqr(hr3 - rave);
+    const float vcdvar = epssq + intp(vwt, Dvd, Dvu);
+    const float hcdvar = epssq + intp(hwt, Dhr, Dhl);
+    Dvu = SROWR(DGV, r, -1, sl)[c] + SROWR(DGV, r, -2, sl)[c];
+    Dvd = SROWR(DGV, r, +1, sl)[c] + SROWR(DGV, r, +2, sl)[c];
+    Dhl = dh[c - 2] + dh[c - 1];
+    Dhr = COLZ(dh, c + 1) + COLZ(dh, c + 2);
+#undef COLZ
+    const float vcdvar1 = epssq + SROWR(DGV, r, 0, sl)[c] + intp(vwt, Dvd, Dvu);
+    const float hcdvar1 = epssq + dh[c] + intp(hwt, Dhr, Dhl);
+    const float varwt = hcdvar / (vcdvar + hcdvar);
+    const float diffwt = hcdvar1 / (vcdvar1 + hcdvar1);
+    const bool dec = ((0.5f - varwt) * (0.5f - diffwt) > 0.f) && (fabsf(0.5f - diffwt) < fabsf(0.5f - varwt));
+    SROWW(HVWT, r, 0, sl)[c >> 1] = dec ? varwt : diffwt;
+    amz_lf vh = SROWW(VH, r, 0, sl);
+    vh[c >> 1] = vcd_c;
+    vh[TSH + (c >> 1)] = tv;
+}
+
+// per-thread registers that live across the steps of a tile: the CFA rows in flight (loader threads) and the thread's own
+// bounding box of the Nyquist flags it set / the nyquist2 sites it processed (min row, max row, min col, max col), merged into the
+// workgroup's boxes once per tile.  (An LDS atomic per flag would be turned into a scalar loop over the active lanes by the
+// compiler: four such loops per step cost more than the stage itself.)
+struct ThreadRegs { float pf0, pf1; int bb[4]; };
+AMZ_DEV void bb_reset(int *bb) { bb[0] = 1 << 30; bb[1] = 0; bb[2] = 1 << 30; bb[3] = 0; }
+AMZ_DEV void bb_add(int *bb, int rr, int cc) { bb[0] = imin(bb[0], rr); bb[1] = imax(bb[1], rr); bb[2] = imin(bb[2], cc); bb[3] = imax(bb[3], cc); }
+AMZ_DEV void bb_flush(amz_lf lds, int base, const int *bb)
+{
+    if (bb[1] == 0 && bb[3] == 0) return;
+    amz_li red = (amz_li)(lds + RED_OFF) + base;
+#ifdef AMZ_EMUL
+    red[0] = imin(red[0], bb[0]); red[1] = imax(red[1], bb[1]); red[2] = imin(red[2], bb[2]); red[3] = imax(red[3], bb[3]);
+#else
+    __hip_atomic_fetch_min(&red[0], bb[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_max(&red[1], bb[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_min(&red[2], bb[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_max(&red[3], bb[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+
+// P5 + P6 (L746-825): nyquist test value and flag of the site of column c; helper lanes 160..171 clear the flag bytes without a site
+AMZ_DEV void st_p5(amz_lf lds, const TileArgs &a, int r, int c, ThreadRegs &rg)
+{
+    if (r < 6 || r >= TS - 6) return;
+    if (c >= TS) {
+        const int h = c - TS;
+        if (h < 12) {
+            const int sl = h >= 6, k = h % 6;
+            amz_lb nb = (amz_lb)SROWW(NYQ, r, 0, sl);
+            nb[k < 3 ? k : 74 + k] = 0;                 // bytes 0,1,2 and 77,78,79
+        }
+        return;
+    }
+    const int sl = site_sel(a, r, c), rr = r + sl;
+    const int par = row_par(a, rr);
+    if (c < 6 + par) return;
+    amz_lb nb = (amz_lb)SROWW(NYQ, r, 0, sl);
+    if (c >= TS - 6) { nb[c >> 1] = 0; return; }        // sites 154..159: no test (L806-808), the byte stays cleared
+    const float go0 = 0.14659727707323927f, go1 = 0.103592713382435f, go2 = 0.0732036125103057f, go3 = 0.0365543548389495f;
+    const float nyqthresh = 0.5f;
+    const float gg0 = nyqthresh * 0.07384411893421103f, gg1 = nyqthresh * 0.06207511968171489f, gg2 = nyqthresh * 0.0521818194747806f;
+    const float gg3 = nyqthresh * 0.03687419286733595f, gg4 = nyqthresh * 0.03099732204057846f, gg5 = nyqthresh * 0.018413194161458882f;
+    const int si = (c - 6 - par) >> 1;
+    const bool vec = si < 4 * ngroups(6 + par, TS - 7, 8);
+    amz_lf c0 = SROWR(CDD, r, 0, sl), cu1 = SROWR(CDD, r, -1, sl), cu2 = SROWR(CDD, r, -2, sl), cd1 = SROWR(CDD, r, +1, sl), cd2 = SROWR(CDD, r, +2, sl);
+    amz_lf d0 = SROWR(DHV, r, 0, sl), du1 = SROWR(DHV, r, -1, sl), du2 = SROWR(DHV, r, -2, sl), dd1 = SROWR(DHV, r, +1, sl), dd2 = SROWR(DHV, r, +2, sl);
+    const float gA = go0 * c0[c] +
+                     go1 * (cu1[c - 1] + cu1[c + 1] + cd1[c - 1] + cd1[c + 1]) +
+                     go2 * (cu2[c] + c0[c - 2] + c0[c + 2] + cd2[c]) +
+                     go3 * (cu2[c - 2] + cu2[c + 2] + cd2[c - 2] + cd2[c + 2]);
+    const float s1 = vec ? (du1[c] + d0[c - 1] + d0[c + 1] + dd1[c])
+                         : (du1[c] + d0[c + 1] + d0[c - 1] + dd1[c]);
+    const float gB = gg0 * d0[c] + gg1 * s1 +
+                     gg2 * (du1[c - 1] + du1[c + 1] + dd1[c - 1] + dd1[c + 1]) +
+                     gg3 * (du2[c] + d0[c - 2] + d0[c + 2] + dd2[c]) +
+                     gg4 * (du2[c - 1] + du2[c + 1] + du1[c - 2] + du1[c + 2] +
+                            dd1[c - 2] + dd1[c + 2] + dd2[c - 1] + dd2[c + 1]) +
+                     gg5 * (du2[c - 2] + du2[c + 2] + dd2[c - 2] + dd2[c + 2]);
+    const bool flag = gA - gB > 0.f;
+    nb[c >> 1] = flag ? 1 : 0;
+    if (flag) bb_add(rg.bb, rr, c);
+}
+
+// P7 (L888-901): majority vote, item = one byte of rows (r, r+1); byte offsets independent of the row parity.  Rows 2..7 and
+// 152..157 are the memset (L879) / never-written part of nyquist2 that P8's window reads.
+AMZ_DEV void st_p7(amz_lf lds, const TileArgs &a, int r, int item)
+{
+    if (item >= 2 * TSH) return;
+    const int sl = item >= TSH, rr = r + sl, b = item - (sl ? TSH : 0);
+    if (rr < 2 || rr >= TS - 2) return;
+    amz_lb out = (amz_lb)SROWW(NYQ2, r, 0, sl);
+    if (rr < 8 || rr >= TS - 8) {
+        // rows 156..159 lie behind the memset (L879): they still hold the bytes of cddiffsq(19, 80..159), and P8's window at rows
+        // 150, 151 tests them
+        out[b] = rr >= TS - 4 ? ((amz_lb)(lds + NQA_OFF))[(rr - (TS - 4)) * TSH + b] : 0;
+        return;
+    }
+    amz_lb n0 = (amz_lb)SROWR(NYQ, r, 0, sl), nu1 = (amz_lb)SROWR(NYQ, r, -1, sl), nu2 = (amz_lb)SROWR(NYQ, r, -2, sl);
+    amz_lb nd1 = (amz_lb)SROWR(NYQ, r, +1, sl), nd2 = (amz_lb)SROWR(NYQ, r, +2, sl);
+    // bytes before/after a row belong to the neighbouring rows of the flat map; those bytes (site index 79 / 0) are never set
+    const int bl = b - 1, br = b + 1;
+    const int t = (int)nu2[b] + (bl >= 0 ? (int)nu1[bl] : 0) + (int)nu1[b] + (bl >= 0 ? (int)n0[bl] : 0) +
+                  (br < TSH ? (int)n0[br] : 0) + (bl >= 0 ? (int)nd1[bl] : 0) + (int)nd1[b] + (int)nd2[b];
+    unsigned char val = n0[b];
+    if (t > 4) val = 1;
+    if (t < 4) val = 0;
+    out[b] = val;
+}
+
+// is column c's site in rows (r, r+1) one that P8 / P10 process under the full bounding box [8,152) x [8,152)?
+AMZ_DEV bool nyq_site(amz_lf lds, const TileArgs &a, int r, int c, int *prr)
+{
+    if (c >= TS) return false;
+    const int sl = site_sel(a, r, c), rr = r + sl;
+    *prr = rr;
+    if (rr < 8 || rr >= TS - 8 || c < 8 + row_par(a, rr) || c >= TS - 8) return false;
+    return ((amz_lb)SROWR(NYQ2, r, 0, sl))[c >> 1] != 0;
+}
+
+// P8 (L914-951): area interpolation at one flagged site.  The 49 window sites are visited in the reference's order; a site that is
+// not flagged contributes +0 to every sum (exact: the sums are non-negative), so the window is a straight-line, branch-free block
+// whose loads the compiler can batch.  One wave owns the step's sites; the window rows -6..0 are summed in sub-step a, rows 2..6 in
+// sub-step b (the partial sums stay in registers across the barrier), which halves the longest serial chain of a sub-step.
+struct P8Acc { float sumcfa, sumh, sumv, sumsqh, sumsqv, areawt; };
+template <int A0, int A1>
+AMZ_DEV void p8_accumulate(amz_lf lds, int r, int sl, int cc, P8Acc &s)
+{
+    const int idx0 = (cc - 6) >> 1;
+#pragma unroll
+    for (int ai = A0; ai <= A1; ai += 2) {
+        amz_lb nq = (amz_lb)SROWR(NYQ2, r, ai, sl);
+        amz_lf cr = SROWR(CFA, r, ai, sl), cu = SROWR(CFA, r, ai - 1, sl), cd = SROWR(CFA, r, ai + 1, sl);
+#pragma unroll
+        for (int bj = 0; bj < 7; ++bj) {
+            const bool f = nq[idx0 + bj] != 0;
+            const int col = cc - 6 + 2 * bj;
+            const float ct = cr[col], cl = cr[col - 1], cq = cr[col + 1], cn = cu[col], cs = cd[col];
+            const float t1 = f ? ct : 0.f;
+            const float t2 = f ? (cl + cq) : 0.f;
+            const float t3 = f ? (cn + cs) : 0.f;
+            const float t4 = f ? (sqr(ct - cl) + sqr(ct - cq)) : 0.f;
+            const float t5 = f ? (sqr(ct - cn) + sqr(ct - cs)) : 0.f;
+            s.sumcfa += t1;
+            s.sumh += t2;
+            s.sumv += t3;
+            s.sumsqh += t4;
+            s.sumsqv += t5;
+            s.areawt += f ? 1.f : 0.f;
+        }
+    }
+}
+AMZ_DEV void p8_finish(amz_lf lds, int r, int sl, int cc, const P8Acc &s, int *bb)
+{
+    const int rr = r + sl;
+    const float sumh = s.sumcfa - xdiv2f(s.sumh);
+    const float sumv = s.sumcfa - xdiv2f(s.sumv);
+    const float areawt = xdiv2f(s.areawt);
+    const float hcdvar = epssq + fabsf(areawt * s.sumsqh - sumh * sumh);
+    const float vcdvar = epssq + fabsf(areawt * s.sumsqv - sumv * sumv);
+    SROWR(HVWT, r, 0, sl)[cc >> 1] = hcdvar / (vcdvar + hcdvar);
+    bb_add(bb, rr, cc);
+}
+// the P8 wave, lane 0..63: first half of the window for list entry `lane` (sub-step a) ...
+struct P8Regs { P8Acc acc; int sl, cc; int bb[4]; };
+AMZ_DEV void p8_wave_a(amz_lf lds, int t, int lane, P8Regs &pr)
+{
+    amz_li red = (amz_li)(lds + RED_OFF);
+    amz_li list = (amz_li)(lds + LIST_OFF + (t & 1) * LIST_INTS);
+    const int n = red[8 + (t & 1)], r = 2 * t - 22;
+    pr.cc = -1;
+    if (lane < n) {
+        const int e = list[lane];
+        pr.sl = (e >> 8) - r; pr.cc = e & 255;
+        pr.acc = P8Acc{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        p8_accumulate<-6, 0>(lds, r, pr.sl, pr.cc, pr.acc);
+    }
+}
+// ... second half and the result (sub-step b); list entries beyond the wave width (dense Nyquist regions) are done here in full
+AMZ_DEV void p8_wave_b(amz_lf lds, int t, int lane, P8Regs &pr)
+{
+    amz_li red = (amz_li)(lds + RED_OFF);
+    amz_li list = (amz_li)(lds + LIST_OFF + (t & 1) * LIST_INTS);
+    const int n = red[8 + (t & 1)], r = 2 * t - 22;
+    if (pr.cc >= 0) {
+        p8_accumulate<2, 6>(lds, r, pr.sl, pr.cc, pr.acc);
+        p8_finish(lds, r, pr.sl, pr.cc, pr.acc, pr.bb);
+    }
+    for (int q = 64 + lane; q < n; q += 64) {
+        const int e = list[q];
+        const int sl = (e >> 8) - r, cc = e & 255;
+        P8Acc acc{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        p8_accumulate<-6, 0>(lds, r, sl, cc, acc);
+        p8_accumulate<2, 6>(lds, r, sl, cc, acc);
+        p8_finish(lds, r, sl, cc, acc, pr.bb);
+    }
+}
+
+// P9 (L957-974), part 1: the refined weight of site j (0..71) of row rr; reads the UPDATED row rr-1 and the old row rr+1
+AMZ_DEV float p9_new_weight(amz_lf lds, const TileArgs &a, int rr, int j)
+{
+    const int cc = 8 + row_par(a, rr) + 2 * j;
+    amz_lf hu = ROWR(HVWT, rr - 1), hd = ROWR(HVWT, rr + 1);
+    const float hvwtalt = xdivf(hu[(cc - 1) >> 1] + hu[(cc + 1) >> 1] + hd[(cc - 1) >> 1] + hd[(cc + 1) >> 1], 2);
+    const float h0 = ROWR(HVWT, rr)[cc >> 1];
+    return fabsf(0.5f - h0) < fabsf(0.5f - hvwtalt) ? hvwtalt : h0;
+}
+// part 2: everything that merely consumes the refined weight of the site
+AMZ_DEV void p9_site(amz_lf lds, const TileArgs &a, int rr, int j, float h)
+{
+    const int cc = 8 + row_par(a, rr) + 2 * j, idx = cc >> 1;
+    ROWR(HVWT, rr)[idx] = h;
+    amz_lf vh = ROWR(VH, rr), cr = ROWR(CFA, rr);
+    const float dg = intp(h, vh[idx], vh[TSH + idx]);
+    ROWW(DG0, rr)[idx] = dg;
+    const float gval = cr[cc] + dg;
+    ROWW(RGBG, rr)[idx] = gval;
+    const bool ny = ((amz_lb)ROWR(NYQ2, rr))[idx] != 0;
+    amz_lf d2 = ROWW(DG2, rr);
+    d2[2 * idx] = ny ? sqr(gval - xdiv2f(cr[cc - 1] + cr[cc + 1])) : 0.f;
+    d2[2 * idx + 1] = ny ? sqr(gval - xdiv2f(ROWR(CFA, rr - 1)[cc] + ROWR(CFA, rr + 1)[cc])) : 0.f;
+}
+
+// P11 (L1004-1027): diagonal gradients; item = one (even column, odd column) pair of rows (r, r+1)
+AMZ_DEV void st_p11(amz_lf lds, const TileArgs &a, int r, int item)
+{
+    if (item >= 152) return;
+    const int sl = item >= 76, rr = r + sl, j = item - (sl ? 76 : 0);
+    if (rr < 6 || rr >= TS - 6) return;
+    const int e = 6 + 2 * j, idx = e >> 1;
+    const bool rbEven = row_par(a, rr) == 0;
+    const int g = rbEven ? e + 1 : e; // green site of the pair
+    const int q = rbEven ? e : e + 1; // red/blue site of the pair
+    amz_lf cr = SROWR(CFA, r, 0, sl), cu = SROWR(CFA, r, -1, sl), cd = SROWR(CFA, r, +1, sl);
+    const float t = cr[g];
+    const float sp = sqr(t - cd[g - 1]) + sqr(t - cu[g + 1]);
+    const float sm = sqr(t - cu[g - 1]) + sqr(t - cd[g + 1]);
+    SROWW(DELP, r, 0, sl)[idx] = fabsf(cu[q + 1] - cd[q - 1]);
+    SROWW(DELM, r, 0, sl)[idx] = fabsf(cd[q + 1] - cu[q - 1]);
+    SROWW(DM, r, 0, sl)[idx] = sm;
+    SROWW(DP, r, 0, sl)[idx] = sp;
+}
+
+// P12 (L1061-1121): diagonal interpolation of R+B and plus/minus weight at the site of column c; helper lanes 160..167 put what
+// pmwt[.., 76..79] aliases (delhvsqsum, L169) into the ring row
+AMZ_DEV void st_p12(amz_lf lds, const TileArgs &a, int r, int c)
+{
+    if (r < 8 || r >= TS - 8) return;
+    if (c >= TS) {
+        const int h = c - TS;
+        if (h < 8) {
+            const int sl = h >= 4, rr = r + sl, k = h & 3;
+            SROWW(PMWT, r, 0, sl)[76 + k] = lds[SIDE_OFF + ((rr >> 1) - 4) * 8 + (rr & 1) * 4 + k];
+        }
+        return;
+    }
+    const int sl = site_sel(a, r, c), rr = r + sl;
+    const int par = row_par(a, rr);
+    if (c < 8 + par || c > 150 + par) return;
+    const int idx = c >> 1;
+    const float ge0 = 0.13719494435797422f, ge1 = 0.05640252782101291f;
+    amz_lf c0 = SROWR(CFA, r, 0, sl), cu1 = SROWR(CFA, r, -1, sl), cu2 = SROWR(CFA, r, -2, sl), cd1 = SROWR(CFA, r, +1, sl), cd2 = SROWR(CFA, r, +2, sl);
+    const float cfav = c0[c];
+    const float cse = cd1[c + 1], cnw = cu1[c - 1], cne = cu1[c + 1], csw = cd1[c - 1];
+    const float rbse = rb_ratio(cfav, cse, cd2[c + 2]);
+    const float rbnw = rb_ratio(cfav, cnw, cu2[c - 2]);
+    amz_lf dm0 = SROWR(DELM, r, 0, sl), dmu1 = SROWR(DELM, r, -1, sl), dmu2 = SROWR(DELM, r, -2, sl), dmd1 = SROWR(DELM, r, +1, sl), dmd2 = SROWR(DELM, r, +2, sl);
+    float t1 = eps + dm0[idx];
+    const float wtse = t1 + dmd1[(c + 1) >> 1] + dmd2[(c + 2) >> 1];
+    const float wtnw = t1 + dmu1[(c - 1) >> 1] + dmu2[(c - 2) >> 1];
+    const float rbmv = (wtse * rbnw + wtnw * rbse) / (wtse + wtnw);
+    const float rbm_out = rb_bound(rbmv, cfav, cnw, cse, a.clip_pt);
+    const float rbne = rb_ratio(cfav, cne, cu2[c + 2]);
+    const float rbsw = rb_ratio(cfav, csw, cd2[c - 2]);
+    amz_lf dp0 = SROWR(DELP, r, 0, sl), dpu1 = SROWR(DELP, r, -1, sl), dpu2 = SROWR(DELP, r, -2, sl), dpd1 = SROWR(DELP, r, +1, sl), dpd2 = SROWR(DELP, r, +2, sl);
+    t1 = eps + dp0[idx];
+    const float wtne = t1 + dpu1[(c + 1) >> 1] + dpu2[(c + 2) >> 1];
+    const float wtsw = t1 + dpd1[(c - 1) >> 1] + dpd2[(c - 2) >> 1];
+    const float rbpv = (wtne * rbsw + wtsw * rbne) / (wtne + wtsw);
+    const float rbp_out = rb_bound(rbpv, cfav, csw, cne, a.clip_pt);
+    amz_lf m0 = SROWR(DM, r, 0, sl), mu1 = SROWR(DM, r, -1, sl), mu2 = SROWR(DM, r, -2, sl), md1 = SROWR(DM, r, +1, sl), md2 = SROWR(DM, r, +2, sl);
+    amz_lf q0 = SROWR(DP, r, 0, sl), qu1 = SROWR(DP, r, -1, sl), qu2 = SROWR(DP, r, -2, sl), qd1 = SROWR(DP, r, +1, sl), qd2 = SROWR(DP, r, +2, sl);
+    const float rbvarm = epssq + (ge0 * (mu1[c >> 1] + m0[(c - 1) >> 1] + m0[(c + 1) >> 1] + md1[c >> 1]) +
+                                  ge1 * (mu2[(c - 1) >> 1] + mu2[(c + 1) >> 1] + mu1[(c - 2) >> 1] + mu1[(c + 2) >> 1] +
+                                         md1[(c - 2) >> 1] + md1[(c + 2) >> 1] + md2[(c - 1) >> 1] + md2[(c + 1) >> 1]));
+    const float rbvarp = epssq + (ge0 * (qu1[c >> 1] + q0[(c - 1) >> 1] + q0[(c + 1) >> 1] + qd1[c >> 1]) +
+                                  ge1 * (qu2[(c - 1) >> 1] + qu2[(c + 1) >> 1] + qu1[(c - 2) >> 1] + qu1[(c + 2) >> 1] +
+                                         qd1[(c - 2) >> 1] + qd1[(c + 2) >> 1] + qd2[(c - 1) >> 1] + qd2[(c + 1) >> 1]));
+    SROWW(RBM, r, 0, sl)[idx] = rbm_out;
+    SROWW(RBP, r, 0, sl)[idx] = rbp_out;
+    SROWW(PMWT, r, 0, sl)[idx] = rbvarm / (rbvarp + rbvarm);
+}
+
+// P13 (L1213-1223), part 1: refined pmwt of site j (0..71; the last group of four over-runs the scalar bound) of row rr
+AMZ_DEV float p13_new_weight(amz_lf lds, const TileArgs &a, int rr, int j)
+{
+    const int cc = 10 + row_par(a, rr) + 2 * j;
+    amz_lf pu = ROWR(PMWT, rr - 1), pd = ROWR(PMWT, rr + 1);
+    const float alt = 0.25f * (pu[(cc - 1) >> 1] + pu[(cc + 1) >> 1] + pd[(cc - 1) >> 1] + pd[(cc + 1) >> 1]);
+    const float t = ROWR(PMWT, rr)[cc >> 1];
+    return fabsf(0.5f - t) < fabsf(0.5f - alt) ? alt : t;
+}
+AMZ_DEV void p13_site(amz_lf lds, const TileArgs &a, int rr, int j, float nt)
+{
+    const int cc = 10 + row_par(a, rr) + 2 * j, idx = cc >> 1;
+    ROWR(PMWT, rr)[idx] = nt;
+    ROWW(RBINT, rr)[idx] = 0.5f * (ROWR(CFA, rr)[cc] + intp(nt, ROWX(RBP, rr)[idx], ROWX(RBM, rr)[idx]));
+}
+
+// dirwts0 / dirwts1 of P1 (L342-351) re-evaluated where P14 needs them (the planes are long gone)
+AMZ_DEV float dirwt_v(amz_lf cm2, amz_lf cm1, amz_lf c0r, amz_lf cp1, amz_lf cp2, int c)
+{
+    const float c0 = c0r[c];
+    const float delv = fabsf(cp1[c] - cm1[c]);
+    return eps + fabsf(cp2[c] - c0) + fabsf(c0 - cm2[c]) + delv;
+}
+AMZ_DEV float dirwt_h(amz_lf cr, int c)
+{
+    const float c0 = cr[c];
+    const float delh = fabsf(cr[c + 1] - cr[c - 1]);
+    return eps + fabsf(cr[c + 2] - c0) + fabsf(c0 - cr[c - 2]) + delh;
+}
+
+// P10 (L979-999) + P14 (L1241-1297) + P15 (L1381-1386) at the site of column c: all three only touch the site's own Dgrb / rgbgreen
+AMZ_DEV void st_p10_14_15(amz_lf lds, const TileArgs &a, int r, int c)
+{
+    if (c >= TS) return;
+    const int sl = site_sel(a, r, c), rr = r + sl;
+    if (rr < 8 || rr >= TS - 8) return;
+    const int par = row_par(a, rr), idx = c >> 1;
+    if (c < 8 + par || c >= TS - 8) return;
+    float dg = SROWR(DG0, r, 0, sl)[idx];
+    float gval = SROWR(RGBG, r, 0, sl)[idx];
+    const float cfav = SROWR(CFA, r, 0, sl)[c];
+    if (((amz_lb)SROWR(NYQ2, r, 0, sl))[idx]) {
+        const float gq0 = 0.169917f, gq1 = 0.108947f, gq2 = 0.069855f, gq3 = 0.0287182f;
+        // Dgrb2 rows 6,7,152,153 and columns < 8 / >= 152 alias dgintv in the reference: only sites no output depends on read them
+        amz_lf e0 = SROWX(DG2, r, 0, sl), eu1 = SROWX(DG2, r, -1, sl), eu2 = SROWX(DG2, r, -2, sl), ed1 = SROWX(DG2, r, +1, sl), ed2 = SROWX(DG2, r, +2, sl);
+#define DH(row, col) (row)[(col) & ~1]
+#define DV(row, col) (row)[(col) | 1]
+        const float gvarh = epssq + (gq0 * DH(e0, c) +
+                                     gq1 * (DH(eu1, c - 1) + DH(eu1, c + 1) + DH(ed1, c - 1) + DH(ed1, c + 1)) +
+                                     gq2 * (DH(eu2, c) + DH(e0, c - 2) + DH(e0, c + 2) + DH(ed2, c)) +
+                                     gq3 * (DH(eu2, c - 2) + DH(eu2, c + 2) + DH(ed2, c - 2) + DH(ed2, c + 2)));
+        const float gvarv = epssq + (gq0 * DV(e0, c) +
+                                     gq1 * (DV(eu1, c - 1) + DV(eu1, c + 1) + DV(ed1, c - 1) + DV(ed1, c + 1)) +
+                                     gq2 * (DV(eu2, c) + DV(e0, c - 2) + DV(e0, c + 2) + DV(ed2, c)) +
+                                     gq3 * (DV(eu2, c - 2) + DV(eu2, c + 2) + DV(ed2, c - 2) + DV(ed2, c + 2)));
+#undef DH
+#undef DV
+        amz_lf vh = SROWR(VH, r, 0, sl);
+        dg = (vh[TSH + idx] * gvarv + vh[idx] * gvarh) / (gvarv + gvarh);
+        gval = cfav + dg;
+    }
+    const bool in14 = rr >= 12 && rr < TS - 12 && c >= 12 + par && c <= 146 + par;
+    if (in14) {
+        const float hw = SROWR(HVWT, r, 0, sl)[idx];
+        if (fabsf(0.5f - SROWR(PMWT, r, 0, sl)[idx]) >= fabsf(0.5f - hw)) {
+            amz_lf rb0 = SROWR(RBINT, r, 0, sl);
+            const float rb = rb0[idx];
+            amz_lf f3u = SROWR(CFA, r, -3, sl), f2u = SROWR(CFA, r, -2, sl), f1u = SROWR(CFA, r, -1, sl), f0 = SROWR(CFA, r, 0, sl);
+            amz_lf f1d = SROWR(CFA, r, +1, sl), f2d = SROWR(CFA, r, +2, sl), f3d = SROWR(CFA, r, +3, sl);
+            const float cu = f1u[c], cd = f1d[c], cl = f0[c - 1], cr = f0[c + 1];
+            const float gu = g_dir(rb, cu, SROWR(RBINT, r, -2, sl)[idx]);      // rbint[indx1 -+ v1] is two rows away (L1253-1260)
+            const float gd = g_dir(rb, cd, SROWR(RBINT, r, +2, sl)[idx]);
+            const float d0u = dirwt_v(f3u, f2u, f1u, f0, f1d, c), d0d = dirwt_v(f1u, f0, f1d, f2d, f3d, c);
+            float Gintv = (d0u * gd + d0d * gu) / (d0d + d0u);
+            Gintv = g_bound(Gintv, rb, cu, cd, a.clip_pt);
+            const float gl = g_dir(rb, cl, rb0[idx - 1]);
+            const float gr = g_dir(rb, cr, rb0[idx + 1]);
+            const float d1l = dirwt_h(f0, c - 1), d1r = dirwt_h(f0, c + 1);
+            float Ginth = (d1l * gr + d1r * gl) / (d1l + d1r);
+            Ginth = g_bound(Ginth, rb, cl, cr, a.clip_pt);
+            gval = intp(hw, Gintv, Ginth);
+            dg = gval - cfav;
+        }
+    }
+    SROWR(RGBG, r, 0, sl)[idx] = gval;
+    if (in14 && (rr & 1) != a.ey) {       // a blue row: G-B moves to Dgrb[1] (L1381-1386)
+        SROWW(DG1, r, 0, sl)[idx] = dg;
+        SROWR(DG0, r, 0, sl)[idx] = 0.f;
+    } else {
+        SROWR(DG0, r, 0, sl)[idx] = dg;
+    }
+}
+
+// P16 (L1394-1408): chrominance of the opposite colour at the site of column c
+AMZ_DEV void st_p16(amz_lf lds, const TileArgs &a, int r, int c)
+{
+    if (c >= TS) return;
+    const int sl = site_sel(a, r, c), rr = r + sl;
+    if (rr < 14 || rr >= TS - 14) return;
+    const int par = row_par(a, rr);
+    if (c < 14 + par || c > 148 + par) return;
+    const bool red_row = (rr & 1) == a.ey;   // c = 1 - FC/2: red sites get G-B from the blue rows above and below
+    // rows rr+-1, rr+-3 hold the native differences; Dgrb[1] positions P15 never wrote alias vcdalt in the reference and
+    // only reach sites no output depends on
+#define DROW(k) (red_row ? SROWX(DG1, r, (k), sl) : SROWX(DG0, r, (k), sl))
+    amz_lf u1 = DROW(-1), u3 = DROW(-3), d1 = DROW(1), d3 = DROW(3);
+#undef DROW
+#define AT(row, col) (row)[(col) >> 1]
+    const float dnw = AT(u1, c - 1), dse = AT(d1, c + 1), dne = AT(u1, c + 1), dsw = AT(d1, c - 1);
+    const float dnw3 = AT(u3, c - 3), dse3 = AT(d3, c + 3), dne3 = AT(u3, c + 3), dsw3 = AT(d3, c - 3);
+    const float temp = eps + fabsf(dnw - dse);
+    const float temp2 = eps + fabsf(dne - dsw);
+    const float wtnw = 1.f / (temp + fabsf(dnw - dnw3) + fabsf(dse - dnw3));
+    const float wtne = 1.f / (temp2 + fabsf(dne - dne3) + fabsf(dsw - dne3));
+    const float wtsw = 1.f / (temp2 + fabsf(dsw - dse3) + fabsf(dne - dsw3));
+    const float wtse = 1.f / (temp + fabsf(dse - dsw3) + fabsf(dnw - dse3));
+    // DG(i-m1-2), DG(i-m1-v2); DG(i+p1+2), DG(i+p1+v2); DG(i-p1-2), DG(i-p1-v2); DG(i+m1+2), DG(i+m1+v2)
+    const float val = (wtnw * (1.325f * dnw - 0.175f * dnw3 - 0.075f * (AT(u1, c - 3) + AT(u3, c - 1))) +
+                       wtne * (1.325f * dne - 0.175f * dne3 - 0.075f * (AT(u1, c + 3) + AT(d1, c + 1))) +
+                       wtsw * (1.325f * dsw - 0.175f * dsw3 - 0.075f * (AT(d1, c - 3) + AT(u1, c - 1))) +
+                       wtse * (1.325f * dse - 0.175f * dse3 - 0.075f * (AT(d1, c + 3) + AT(d3, c + 1)))) /
+                      (wtnw + wtne + wtsw + wtse);
+#undef AT
+    if (red_row) SROWW(DG1, r, 0, sl)[c >> 1] = val; else SROWR(DG0, r, 0, sl)[c >> 1] = val;
+}
+
+// P17/P18 (L1441-1565): R, G, B of tile row rr, column c
+AMZ_DEV void st_out(amz_lf lds, const TileArgs &a, int rr, int c)
+{
+    if (rr < 16 || rr >= TS - 16 || c < 16 || c >= TS - 16) return;
+    float gval, rv, bv;
+    if (is_green(a, rr, c)) {
+        gval = ROWR(CFA, rr)[c];
+        amz_lf hu = ROWR(HVWT, rr - 1), h0 = ROWR(HVWT, rr), hd = ROWR(HVWT, rr + 1);
+        const float h_up = hu[c >> 1], h_dn = hd[c >> 1], h_r = h0[(c + 1) >> 1], h_l = h0[(c - 1) >> 1];
+        const float temp = 1.f / (h_up + 2.f - h_r - h_l + h_dn);
+        amz_lf a0u = ROWR(DG0, rr - 1), a00 = ROWR(DG0, rr), a0d = ROWR(DG0, rr + 1);
+        amz_lf a1u = ROWR(DG1, rr - 1), a10 = ROWR(DG1, rr), a1d = ROWR(DG1, rr + 1);
+        rv = gval - (h_up * a0u[c >> 1] + (1.f - h_r) * a00[(c + 1) >> 1] + (1.f - h_l) * a00[(c - 1) >> 1] + h_dn * a0d[c >> 1]) * temp;
+        bv = gval - (h_up * a1u[c >> 1] + (1.f - h_r) * a10[(c + 1) >> 1] + (1.f - h_l) * a10[(c - 1) >> 1] + h_dn * a1d[c >> 1]) * temp;
+    } else {
+        gval = ROWR(RGBG, rr)[c >> 1];
+        rv = gval - ROWR(DG0, rr)[c >> 1];
+        bv = gval - ROWR(DG1, rr)[c >> 1];
+    }
+    const long o = (long)(rr + a.top) * a.os + (a.left + c);
+    a.red[o] = sse_max(65535.f * rv, 0.f);
+    a.blue[o] = sse_max(65535.f * bv, 0.f);
+    a.green[o] = sse_max(gval * 65535.f, 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The schedule.  Groups of 192 threads (three waves) G0..G4 = tid / 192 for tid < 960; wave 15 (tid >= 960) = U.
+// ---------------------------------------------------------------------------------------------------------------------
+
+
+// tile validity: every nyquist2 site the stream processed lies inside the reference's bounding box (L827-876)
+AMZ_DEV bool tile_valid(amz_lf lds)
+{
+    amz_li red = (amz_li)(lds + RED_OFF);
+    if (red[5] == 0 && red[7] == 0) return true;                 // no nyquist2 site at all
+    int nystartrow = red[0] == (1 << 30) ? 0 : red[0], nyendrow = red[1], nystartcol = red[2], nyendcol = red[3];
+    if (!(nystartrow != nyendrow && nystartcol != nyendcol)) return false;
+    nyendrow++;
+    nyendcol++;
+    nystartcol -= (nystartcol & 1);
+    nystartrow = imax(8, nystartrow);
+    nyendrow = imin(TS - 8, nyendrow);
+    nystartcol = imax(8, nystartcol);
+    nyendcol = imin(TS - 8, nyendcol);
+    return red[4] >= nystartrow && red[5] < nyendrow && red[6] >= nystartcol && red[7] < nyendcol;
+}
+
+AMZ_DEV void tile_begin(amz_lf lds, int tid)
+{
+    amz_li red = (amz_li)(lds + RED_OFF);
+    if (tid == 0) {
+        red[0] = 1 << 30; red[1] = 0; red[2] = TS + 1; red[3] = 0;
+        red[4] = 1 << 30; red[5] = 0; red[6] = 1 << 30; red[7] = 0;
+        red[8] = 0; red[9] = 0;
+    }
+}
+
+// load: thread c of the loader group puts the two rows it fetched during the previous step into the ring and fetches the next two
+AMZ_DEV void st_load(amz_lf lds, const TileArgs &a, int t, int c, ThreadRegs &rg)
+{
+    if (c >= TS) return;
+    const int r = 2 * t;
+    if (r < TS) {
+        ROWW(CFA, r)[c] = rg.pf0 / 65535.f;
+        ROWW(CFA, r + 1)[c] = rg.pf1 / 65535.f;
+    }
+    // unconditional (row index clamped): a branch would put a wait between the loads
+    const int n0 = imin(r + 2, TS - 1), n1 = imin(r + 3, TS - 1);
+    rg.pf0 = a.raw[(long)src_row(a, n0, c) * a.rs + src_col(a, n0, c)];
+    rg.pf1 = a.raw[(long)src_row(a, n1, c) * a.rs + src_col(a, n1, c)];
+}
+AMZ_DEV void st_load_first(const TileArgs &a, int c, ThreadRegs &rg)
+{
+    if (c >= TS) return;
+    rg.pf0 = a.raw[(long)src_row(a, 0, c) * a.rs + src_col(a, 0, c)];
+    rg.pf1 = a.raw[(long)src_row(a, 1, c) * a.rs + src_col(a, 1, c)];
+}
+
+// grp = tid / 192 (0..4; 5 = wave U), c = tid - 192 * grp: uniform over a wave, so the caller passes grp as a scalar
+AMZ_DEV void substep_a(amz_lf lds, const TileArgs &a, int t, int grp, int c, ThreadRegs &rg)
+{
+    switch (grp) {
+    case 0:
+        st_p2(lds, a, 2 * t - 6, c);
+        st_p2(lds, a, 2 * t - 5, c);
+        break;
+    case 1:
+        st_p5(lds, a, 2 * t - 12, c, rg);
+        st_load(lds, a, t, c, rg);
+        break;
+    case 2:
+        st_p12(lds, a, 2 * t - 24, c);
+        break;
+    case 3:
+        st_p10_14_15(lds, a, 2 * t - 30, c);
+        break;
+    case 4:
+        st_p4(lds, a, 2 * t - 14, c);
+        break;
+    default: break;     // wave 15: p8_wave_a (it carries registers into sub-step b, so the driver calls it)
+    }
+}
+
+// the part of sub-step b that ordinary column threads do
+AMZ_DEV void substep_b_threads(amz_lf lds, const TileArgs &a, int t, int grp, int c)
+{
+    switch (grp) {
+    case 0: st_p3(lds, a, 2 * t - 8, c); break;
+    case 1: st_p3(lds, a, 2 * t - 7, c); break;
+    case 2:
+        st_p16(lds, a, 2 * t - 34, c);
+        st_out(lds, a, 2 * t - 38, c);
+        st_out(lds, a, 2 * t - 37, c);
+        break;
+    case 3:
+        st_p1(lds, a, 2 * t - 2, c);
+        st_p1(lds, a, 2 * t - 1, c);
+        st_p11(lds, a, 2 * t - 20, c);
+        break;
+    default: break;
+    }
+}
+
+} // namespace amz

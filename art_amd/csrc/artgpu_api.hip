@@ -41,6 +41,17 @@ struct artgpu_ctx {
     float fuse_pre = 0.f, fuse_post = 0.f;   // improc_denoise -> rgb_denoise: exposure compensation fused into rgb2yuv / yuv2rgb
     float *bbox = nullptr; // AMaZE: per-tile nyquist bounding boxes
     size_t bbox_bytes = 0;
+    // AMaZE v2: tile lists on the device (ints).  [stream tiles | arena-tile template: count, tiles | working copy: count, tiles + room
+    // for every streamed tile the stream kernel hands back]
+    float *amz_lists = nullptr;
+    size_t amz_lists_bytes = 0;
+    int amz_w = 0, amz_h = 0, amz_nstream = 0, amz_narena = 0, amz_mode = -1;
+    // options (artgpu_set_option): test / profiling switches that used to be environment variables
+    int opt_amaze_path = 0;        // 0: LDS streaming kernel for full tiles + arena kernel for the rest; 1: arena kernel for every tile
+    int opt_amaze_split = 0;       // 1 (with path 1): one launch per phase
+    long opt_amaze_zero_mask = 0x81f0;
+    int opt_amaze_zero_frame = 16;
+    int opt_amaze_poison = -1;     // >= 0: byte pattern the arenas are filled with before the launch
     float *lut = nullptr; // 65536-entry tone LUT on the device
     size_t lut_bytes = 0;
     // timing
@@ -242,6 +253,7 @@ int artgpu_destroy(artgpu_ctx *ctx)
         if (ctx->stage[k]) (void)hipFree(ctx->stage[k]);
     if (ctx->lut) (void)hipFree(ctx->lut);
     if (ctx->bbox) (void)hipFree(ctx->bbox);
+    if (ctx->amz_lists) (void)hipFree(ctx->amz_lists);
     for (int k = 0; k < artgpu_ctx::NPOOL; ++k)
         if (ctx->pool[k]) (void)hipFree(ctx->pool[k]);
     for (int k = 0; k < 3; ++k)
@@ -270,6 +282,19 @@ int artgpu_synchronize(artgpu_ctx *ctx)
     if (!ctx) return ARTGPU_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
+int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value)
+{
+    if (!ctx || !name) return ARTGPU_EINVAL;
+    const std::string n(name);
+    if (n == "amaze_path") { if (value < 0 || value > 1) return fail(ctx, ARTGPU_EINVAL, "amaze_path: 0 or 1"); ctx->opt_amaze_path = (int)value; }
+    else if (n == "amaze_split") ctx->opt_amaze_split = value != 0;
+    else if (n == "amaze_zero_mask") ctx->opt_amaze_zero_mask = value;
+    else if (n == "amaze_zero_frame") ctx->opt_amaze_zero_frame = (int)value;
+    else if (n == "amaze_poison") ctx->opt_amaze_poison = (int)value;
+    else return fail(ctx, ARTGPU_EINVAL, "set_option: unknown option '%s'", name);
     return ARTGPU_OK;
 }
 
@@ -324,7 +349,60 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
     if (method == ARTGPU_BAYER_AMAZE) {
         const int nty = (H + 16 + AMAZE_STEP - 1) / AMAZE_STEP, ntx = (W + 16 + AMAZE_STEP - 1) / AMAZE_STEP;
         const int ntiles = nty * ntx;
-        const int grid = ntiles < MAX_TILE_WORKGROUPS ? ntiles : MAX_TILE_WORKGROUPS;
+        // Tile classes (amaze_demosaic_RT.cc:182-334).  Tiles that write no pixel (the clipped tile is at most 32 wide / high) are
+        // skipped.  Full 160x160 tiles go to the LDS streaming kernel (amaze_stream.hip) unless their mirrored bottom / right border
+        // fill over-runs the tile row or the cfa plane in the reference (it always writes 16 rows / columns from the frame edge: exact
+        // only when the tile ends 16 pixels past the frame); everything else -- partial tiles, those over-run tiles and streamed tiles
+        // whose Nyquist sites do not fit the stream's assumption -- is done by the arena kernel (amaze.hip), which reproduces the
+        // reference's buffer layout literally.
+        const int mode = ctx->opt_amaze_path;
+        if (ctx->amz_w != W || ctx->amz_h != H || ctx->amz_mode != mode) {
+            std::vector<int> st, ar;
+            for (int ty = 0; ty < nty; ++ty)
+                for (int tx = 0; tx < ntx; ++tx) {
+                    const int top = -16 + ty * AMAZE_STEP, left = -16 + tx * AMAZE_STEP;
+                    const int rr1 = std::min(top + AMAZE_TS, H + 16) - top, cc1 = std::min(left + AMAZE_TS, W + 16) - left;
+                    if (rr1 <= 32 || cc1 <= 32) continue;
+                    const bool full = rr1 == AMAZE_TS && cc1 == AMAZE_TS;
+                    const bool exact_fill = (top + AMAZE_TS <= H || top + AMAZE_TS == H + 16) && (left + AMAZE_TS <= W || left + AMAZE_TS == W + 16);
+                    (mode == 0 && full && exact_fill ? st : ar).push_back(ty * ntx + tx);
+                }
+            const size_t nints = st.size() + (1 + ar.size()) + (1 + ar.size() + st.size()) + 8;
+            if ((rc = ensure(ctx, &ctx->amz_lists, &ctx->amz_lists_bytes, nints * sizeof(int)))) return rc;
+            std::vector<int> hostbuf;
+            hostbuf.insert(hostbuf.end(), st.begin(), st.end());
+            hostbuf.push_back((int)ar.size());
+            hostbuf.insert(hostbuf.end(), ar.begin(), ar.end());
+            HIPCHK(ctx, hipMemcpyAsync(ctx->amz_lists, hostbuf.data(), hostbuf.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // hostbuf goes out of scope
+            ctx->amz_w = W; ctx->amz_h = H; ctx->amz_mode = mode;
+            ctx->amz_nstream = (int)st.size(); ctx->amz_narena = (int)ar.size();
+        }
+        int *const d_stream = reinterpret_cast<int *>(ctx->amz_lists);
+        int *const d_templ = d_stream + ctx->amz_nstream;
+        int *const d_work = d_templ + 1 + ctx->amz_narena;
+        HIPCHK(ctx, hipMemcpyAsync(d_work, d_templ, (size_t)(1 + ctx->amz_narena) * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        const float clip_pt = (float)(1.0 / initial_gain);   // amaze_demosaic_RT.cc:53-54
+        const float clip_pt8 = (float)(0.8 / initial_gain);
+        if (ctx->amz_nstream > 0) {
+            AmazeStreamArgs sa;
+            sa.raw = d.raw; sa.raw_stride = d.raw_stride;
+            sa.red = d.r; sa.green = d.g; sa.blue = d.b; sa.out_stride = d.out_stride;
+            sa.W = W; sa.H = H; sa.ntx = ntx;
+            sa.filters = filters;
+            sa.clip_pt = clip_pt; sa.clip_pt8 = clip_pt8;
+            const unsigned f00 = (filters >> 0) & 3, f01 = (filters >> 2) & 3;   // FC(0,0), FC(0,1)
+            sa.g00 = (int)(f00 & 1);
+            sa.ey = f00 == 1 ? (f01 == 0 ? 0 : 1) : (f00 == 0 ? 0 : 1);        // row of the red sites (L1381-1386: ey)
+            sa.tiles = d_stream; sa.ntiles = ctx->amz_nstream;
+            sa.fallback = d_work;
+            HIPCHK(ctx, launch_amaze_stream(sa, ctx->amz_nstream, ctx->stream));
+        }
+        // arena kernel over the listed tiles (the static ones plus whatever the stream handed back; the count is read on the device)
+        const int nlist_max = ctx->amz_narena + ctx->amz_nstream;
+        const bool split = mode == 1 && ctx->opt_amaze_split;
+        const int cap = split ? MAX_TILE_WORKGROUPS : 768;
+        const int grid = std::max(1, std::min(nlist_max, cap));
         rc = ensure(ctx, &ctx->arena, &ctx->arena_bytes, (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float));
         if (rc) return rc;
         AmazeArgs a;
@@ -333,8 +411,8 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
         a.arena = ctx->arena;
         a.W = W; a.H = H; a.ntx = ntx; a.ntiles = ntiles;
         a.filters = filters;
-        a.clip_pt = (float)(1.0 / initial_gain);   // amaze_demosaic_RT.cc:53-54
-        a.clip_pt8 = (float)(0.8 / initial_gain);
+        a.clip_pt = clip_pt;
+        a.clip_pt8 = clip_pt8;
         {
             float *bb;
             if ((rc = ensure(ctx, &ctx->bbox, &ctx->bbox_bytes, (size_t)grid * 4 * sizeof(int)))) return rc;
@@ -342,15 +420,23 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
             a.bbox = reinterpret_cast<int *>(bb);
         }
         // Arena regions that have read-before-write positions on full tiles and therefore must be cleared per tile: vcd, hcd,
-        // vcdalt, hcdalt, cddiffsq, nyquist (bits 4-8, 15).  Found by poisoning the arena and clearing all regions but one
-        // (scripts/amaze_zmask.py; tests/test_gpu_demosaic.py re-checks it).  Partial edge tiles always clear everything.
-        a.zero_mask = getenv("ARTGPU_AMAZE_ZMASK") ? (unsigned)strtoul(getenv("ARTGPU_AMAZE_ZMASK"), nullptr, 0) : 0x81f0u;
+        // vcdalt, hcdalt, cddiffsq, nyquist (bits 4-8, 15): on a full tile every other position is written before it is read, for
+        // every CFA phase, because the phase loops cover fixed index ranges (derivation: DESIGN.md section 10).
+        // tests/test_gpu_demosaic.py re-checks it with poisoned arenas (artgpu_set_option "amaze_poison").  Partial tiles clear everything.
+        a.zero_mask = (unsigned)ctx->opt_amaze_zero_mask;
         // ... and of the five full-size planes among them only positions within a few pixels of the tile edge (plus the gap behind each
-        // plane): a frame of 4 already passes the poison test, 16 (the discarded tile border) is used.  ARTGPU_AMAZE_ZFRAME=0: whole planes.
-        a.zero_frame = getenv("ARTGPU_AMAZE_ZFRAME") ? atoi(getenv("ARTGPU_AMAZE_ZFRAME")) : 16;
-        if (getenv("ARTGPU_AMAZE_POISON"))   // test hook: fill the arenas with a byte pattern first
-            HIPCHK(ctx, hipMemsetAsync(ctx->arena, (int)strtoul(getenv("ARTGPU_AMAZE_POISON"), nullptr, 0), (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float), ctx->stream));
-        HIPCHK(ctx, launch_amaze(a, grid, ctx->stream));
+        // plane): a frame of 4 already passes the poison test, 16 (the discarded tile border) is used.  0: whole planes.
+        a.zero_frame = ctx->opt_amaze_zero_frame;
+        a.split = split ? 1 : 0;
+        if (split) {               // one arena per tile, tiles 0..ntiles-1 (the empty ones write nothing)
+            a.tile_list = nullptr; a.tile_count = nullptr;
+            if (grid < ntiles) return fail(ctx, ARTGPU_EUNSUPPORTED, "amaze_split needs one arena per tile (%d tiles)", ntiles);
+        } else {
+            a.tile_list = d_work + 1; a.tile_count = d_work;
+        }
+        if (ctx->opt_amaze_poison >= 0)   // test hook: fill the arenas with a byte pattern first
+            HIPCHK(ctx, hipMemsetAsync(ctx->arena, ctx->opt_amaze_poison, (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float), ctx->stream));
+        HIPCHK(ctx, launch_amaze(a, split ? ntiles : grid, ctx->stream));
         bord = border < 4 ? 3 : 0; // amaze_demosaic_RT.cc:1587-1589
     } else if (method == ARTGPU_BAYER_VNG4) {
         if ((rc = vng4_dev(ctx, d.raw, d.raw_stride, d.r, d.g, d.b, d.out_stride, W, H, filters))) return rc;

@@ -30,8 +30,27 @@ struct AmazeArgs {
     int *bbox;          // 4 ints per arena: nyquist bounding box of the tile
     unsigned zero_mask;
     int zero_frame;     // > 0: regions 4-8 of full tiles are cleared only in a frame of this many rows / columns
+    const int *tile_list;   // device: the tiles this launch processes (nullptr: tiles 0..ntiles-1)
+    const int *tile_count;  // device: how many entries of tile_list are valid (read when the kernel starts)
+    int split;              // 1: one launch per phase over all tiles (profiling mode; needs one arena per tile)
 };
 hipError_t launch_amaze(const AmazeArgs &a, int grid, hipStream_t stream);
+
+// ---- AMaZE v2, LDS row streaming (amaze_stream.hip): full 160x160 tiles only ----
+struct AmazeStreamArgs {
+    const float *raw;
+    size_t raw_stride;  // floats
+    float *red, *green, *blue;
+    size_t out_stride;  // floats
+    int W, H, ntx;
+    unsigned filters;
+    float clip_pt, clip_pt8;
+    int g00, ey;        // (0,0) is green; row parity of the red sites
+    const int *tiles;   // device: tile indices to stream
+    int ntiles;
+    int *fallback;      // device: [0] = count, [1..] = tiles the arena kernel has to (re)do
+};
+hipError_t launch_amaze_stream(const AmazeStreamArgs &s, int grid, hipStream_t stream);
 
 // ---- RCD (rcd.hip) ----
 constexpr int RCD_THREADS = 256;

@@ -75,6 +75,13 @@ const char *artgpu_version(void);
 /* Launch all work of this context on `hip_stream` (a hipStream_t; NULL = default stream). */
 int artgpu_set_stream(artgpu_ctx *ctx, void *hip_stream);
 int artgpu_synchronize(artgpu_ctx *ctx);
+/* Test / profiling switches of the context (they never change what a call computes, only which of two bit-identical device
+ * paths runs or how scratch memory is prepared).  Unknown names return ARTGPU_EINVAL.
+ *   "amaze_path"        0 (default): full AMaZE tiles are streamed through LDS (amaze_stream.hip), partial tiles and tiles the
+ *                       stream hands back run on the per-tile arena kernel (amaze.hip); 1: arena kernel for every tile
+ *   "amaze_split"       1 (with amaze_path 1): one kernel launch per AMaZE phase (per-phase profile)
+ *   "amaze_zero_mask" / "amaze_zero_frame" / "amaze_poison"   arena-clearing experiments of tests/test_gpu_demosaic.py */
+int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value);
 int artgpu_enable_timing(artgpu_ctx *ctx, int enable);
 int artgpu_get_timings(const artgpu_ctx *ctx, artgpu_timings *out);
 

@@ -79,6 +79,8 @@ static void carve(float *base, amaze_planes *p)
 }
 
 int oracle_amaze_debug_stop = 0; /* test hook: return after phase N (0 = run all) */
+/* test hook: tiles seen, tiles with doNyquist, nyquist flags, nyquist2 sites, P14 sites taken, P14 sites tested */
+long long oracle_amaze_stats[6] = {0, 0, 0, 0, 0, 0};
 #define STOP_AFTER(n) do { if (oracle_amaze_debug_stop == (n)) return; } while (0)
 
 static inline int sat_add_i8(int a, int b) { int s = a + b; return s > 127 ? 127 : s; }
@@ -338,6 +340,17 @@ void oracle_amaze_tile(const float *raw, size_t rs, int width, int height, unsig
                 nyendcol = nyendcol < cc ? cc : nyendcol;
             }
     const int doNyquist = nystartrow != nyendrow && nystartcol != nyendcol;
+    {
+        long long nfl_ = 0;
+        for (int rr = 6; rr < rr1 - 6; rr++)
+            for (int cc = 6 + (FCT(rr, 2) & 1), i = rr * ts + cc; cc < cc1 - 6; cc += 2, i += 2) nfl_ += P.nyquist[i >> 1];
+#pragma omp atomic
+        oracle_amaze_stats[0] += 1;
+#pragma omp atomic
+        oracle_amaze_stats[1] += doNyquist;
+#pragma omp atomic
+        oracle_amaze_stats[2] += nfl_;
+    }
 
     if (doNyquist) {
         nyendrow++;
@@ -373,6 +386,8 @@ void oracle_amaze_tile(const float *raw, size_t rs, int width, int height, unsig
         for (int rr = nystartrow; rr < nyendrow; rr++)
             for (int i = rr * ts + nystartcol + (FCT(rr, 2) & 1); i < rr * ts + nyendcol; i += 2)
                 if (P.nyquist2[i >> 1]) {
+#pragma omp atomic
+                    oracle_amaze_stats[3] += 1;
                     float sumcfa = 0.f, sumh = 0.f, sumv = 0.f, sumsqh = 0.f, sumsqv = 0.f, areawt = 0.f;
                     for (int a = -6; a < 7; a += 2) {
                         int i1 = i + (a * ts) - 6;
@@ -537,7 +552,11 @@ void oracle_amaze_tile(const float *raw, size_t rs, int width, int height, unsig
             for (int k = 0; k < 4; ++k) {
                 int i = i0 + 2 * k, i1 = i >> 1;
                 const float *rbint = P.rbint, *d0 = P.dirwts0, *d1 = P.dirwts1;
+#pragma omp atomic
+                oracle_amaze_stats[5] += 1;
                 if (!(fabsf(0.5f - P.pmwt[i1]) >= fabsf(0.5f - P.hvwt[i1]))) continue;
+#pragma omp atomic
+                oracle_amaze_stats[4] += 1;
                 float rb = rbint[i1];
                 float cru = (cfa[i - v1] + cfa[i - v1]) / (eps + rb + rbint[i1 - v1]);
                 float gu = rb * cru;

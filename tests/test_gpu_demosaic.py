@@ -79,29 +79,67 @@ def test_errors(gpu_ctx):
         gpu_ctx.demosaic_bayer_host(capi.BAYER_RCD, raw, 0xFFFFFFFF)     # 4-colour CFA
 
 
-def test_amaze_selective_arena_clear_is_exact(gpu_ctx, monkeypatch):
-    """Only six of the 17 arena regions are cleared per full tile (artgpu_api.hip: zero_mask), and of the five full-size planes among
-    them only a 16-pixel frame (zero_frame).  With the arenas pre-filled with different byte patterns the result must not move: nothing
-    else is read before it is written."""
+@pytest.fixture
+def amaze_options(gpu_ctx):
+    """artgpu_set_option switches for one test; the shared context goes back to its defaults afterwards."""
+    def set_(**kw):
+        for k, v in kw.items():
+            gpu_ctx.set_option(k, v)
+    yield set_
+    for k, v in (("amaze_path", 0), ("amaze_split", 0), ("amaze_poison", -1), ("amaze_zero_mask", 0x81f0), ("amaze_zero_frame", 16)):
+        gpu_ctx.set_option(k, v)
+
+
+@pytest.mark.parametrize("filt", [synth.FILTERS_RGGB, synth.FILTERS_BGGR, synth.FILTERS_GRBG, synth.FILTERS_GBRG])
+def test_amaze_selective_arena_clear_is_exact(gpu_ctx, amaze_options, filt):
+    """Arena kernel: only six of the 17 arena regions are cleared per full tile (artgpu_api.hip: zero_mask), and of the five full-size
+    planes among them only a 16-pixel frame (zero_frame).  With the arenas pre-filled with different byte patterns (0xFF.. = NaN) the
+    result must not move, for every CFA phase and with partial and full tiles: nothing else is read before it is written."""
     from art_amd import capi
-    w, h, filt = 1152, 896, synth.FILTERS_RGGB
+    w, h = 1100, 870
     raw = synth.bayer_frame(w, h, filt, seed=21, noise=3000)
     ref = oracle_lib.amaze(raw, filt, 1.0, 4)
-    for pattern in ("0xFF", "0x7F", "0xC0"):
-        monkeypatch.setenv("ARTGPU_AMAZE_POISON", pattern)
+    for pattern in (0xFF, 0x7F, 0xC0):
+        amaze_options(amaze_path=1, amaze_poison=pattern)
         out = [np.zeros((h, w), np.float32) for _ in range(3)]
         gpu_ctx.demosaic_bayer(capi.BAYER_AMAZE, capi.host_plane(raw), filt, 1.0, 4, capi.host_rgb(out))
         for o, r in zip(out, ref):
             assert np.array_equal(o.view(np.uint32), r.view(np.uint32))
 
 
-def test_amaze_phase_per_kernel_path_is_identical(gpu_ctx, monkeypatch):
-    """ARTGPU_AMAZE_SPLIT=1 runs the same 20 phases as one kernel launch each (profiling path): same bits."""
+STREAM_CASES = [
+    # w, h, filters, gain, noise: full interior tiles, mirrored top/left tiles, exactly aligned mirrored right/bottom tiles (640x512),
+    # tiles whose border fill over-runs in the reference (650x520 -> arena kernel), noise-free frames (partial Nyquist boxes ->
+    # tiles handed back to the arena kernel)
+    (1040, 784, synth.FILTERS_RGGB, 1.0, 1024),
+    (640, 512, synth.FILTERS_BGGR, 1.0, 1024),
+    (650, 520, synth.FILTERS_GRBG, 1.0, 512),
+    (1296, 1040, synth.FILTERS_GBRG, 1.0, 0),
+    (1296, 1040, synth.FILTERS_RGGB, 2.5, 32),
+    (784, 656, synth.FILTERS_GBRG, 0.7, 4096),
+]
+
+
+@pytest.mark.parametrize("w,h,filt,gain,noise", STREAM_CASES)
+def test_amaze_stream_matches_oracle_and_arena_kernel(gpu_ctx, amaze_options, w, h, filt, gain, noise):
+    """The LDS streaming kernel (default path) and the arena kernel (amaze_path 1) give the oracle's bits."""
+    from art_amd import capi
+    raw = synth.bayer_frame(w, h, filt, seed=w + noise, noise=noise)
+    ref = oracle_lib.amaze(raw, filt, gain, 4)
+    got = gpu_ctx.demosaic_bayer_host(capi.BAYER_AMAZE, raw, filt, gain, 4)
+    assert _diff(got, ref) == [0, 0, 0]
+    amaze_options(amaze_path=1)
+    got1 = gpu_ctx.demosaic_bayer_host(capi.BAYER_AMAZE, raw, filt, gain, 4)
+    assert _diff(got1, ref) == [0, 0, 0]
+
+
+def test_amaze_phase_per_kernel_path_is_identical(gpu_ctx, amaze_options):
+    """amaze_path 1 + amaze_split 1 runs the arena kernel's 20 phases as one kernel launch each (profiling path): same bits."""
     from art_amd import capi
     w, h, filt = 904, 648, synth.FILTERS_GRBG
     raw = synth.bayer_frame(w, h, filt, seed=23, noise=2500)
     ref = oracle_lib.amaze(raw, filt, 1.0, 4)
-    monkeypatch.setenv("ARTGPU_AMAZE_SPLIT", "1")
+    amaze_options(amaze_path=1, amaze_split=1)
     out = [np.zeros((h, w), np.float32) for _ in range(3)]
     gpu_ctx.demosaic_bayer(capi.BAYER_AMAZE, capi.host_plane(raw), filt, 1.0, 4, capi.host_rgb(out))
     for o, r in zip(out, ref):
