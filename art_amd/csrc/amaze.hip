@@ -532,9 +532,11 @@ amaze_kernel(AmazeArgs a)
         if (fc(filters, 0, 0) == 0) { ey = 0; ex = 0; } else { ey = 1; ex = 1; }
     }
 
-    const int nlisted = a.tile_count ? *a.tile_count : a.ntiles;
+    const int nlist = a.tile_count ? *a.tile_count : a.ntiles;
+    const int qtaken = a.queue_hdr ? a.queue_hdr[1] : 0, qleft = a.queue_hdr ? max(a.queue_hdr[0] - qtaken, 0) : 0;
+    const int nlisted = nlist + qleft;
     for (int kt = blockIdx.x / G; kt < nlisted; kt += gridDim.x / G) {
-        const int tile = a.tile_list ? a.tile_list[kt] : kt;
+        const int tile = kt >= nlist ? (int)(a.queue_words[qtaken + kt - nlist] & 0xffffffu) : (a.tile_list ? a.tile_list[kt] : kt);
         const int ty = tile / a.ntx, tx = tile - ty * a.ntx;
         const int top = -16 + ty * (ts - 32), left = -16 + tx * (ts - 32);
         const int bottom = min(top + ts, height + 16), right = min(left + ts, width + 16);

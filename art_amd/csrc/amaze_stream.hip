@@ -35,7 +35,7 @@ __device__ __forceinline__ void wave_p9(amz_lf lds, const TileArgs &a, int r, in
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int rr = r + k;
-        if (rr < 8 || rr >= TS - 8) continue;
+        if (rr < 8 || rr >= a.rr1 - 8) continue;
         const float h0 = p9_new_weight(lds, a, rr, lane);
         float h1 = 0.f;
         if (lane < 8) h1 = p9_new_weight(lds, a, rr, 64 + lane);
@@ -50,7 +50,7 @@ __device__ __forceinline__ void wave_p13(amz_lf lds, const TileArgs &a, int r, i
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int rr = r + k;
-        if (rr < 10 || rr >= TS - 10) continue;
+        if (rr < 10 || rr >= a.rr1 - 10) continue;
         const float h0 = p13_new_weight(lds, a, rr, lane);
         float h1 = 0.f;
         if (lane < 8) h1 = p13_new_weight(lds, a, rr, 64 + lane);
@@ -59,13 +59,13 @@ __device__ __forceinline__ void wave_p13(amz_lf lds, const TileArgs &a, int r, i
         wave_order();
     }
 }
-// the nyquist2 sites of rows (r, r+1), compacted for P8 of the next step
-__device__ __forceinline__ void wave_list(amz_lf lds, const TileArgs &a, int t, int lane)
+// the nyquist2 sites of tile rows (r, r+1), compacted for P8 of the next step
+__device__ __forceinline__ void wave_list(amz_lf lds, const TileArgs &a, int T, int r, int lane)
 {
-    const int r = 2 * t - 20, buf = (t + 1) & 1;     // the list step t+1 consumes
+    const int buf = (T + 1) & 1;     // the list step T+1 consumes
     amz_li red = (amz_li)(lds + RED_OFF), list = (amz_li)(lds + LIST_OFF + buf * LIST_INTS);
     int n = 0;
-    if (r >= 8 && r < TS - 8) {
+    if (r + 1 >= 8 && r < a.rr1 - 8) {
 #pragma unroll
         for (int pass = 0; pass < 3; ++pass) {
             const int c = pass * 64 + lane;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void wave_list(amz_lf lds, const TileArgs &a, int t, 
             n += __popcll(m);
         }
     }
-    if (lane == 0) red[8 + buf] = n;
+    if (lane == 0) red[16 + buf] = n;
 }
 
 } // namespace
@@ -97,70 +97,147 @@ amaze_stream_kernel(AmazeStreamArgs s)
     // issue arbitration on their SIMD, the column roles fill the gaps
     if (wave >= 12) __builtin_amdgcn_s_setprio(2);
 
-    TileArgs a;
-    a.raw = (amz_gcf)s.raw; a.rs = (long)s.raw_stride;
-    a.red = (amz_gf)s.red; a.green = (amz_gf)s.green; a.blue = (amz_gf)s.blue; a.os = (long)s.out_stride;
-    a.W = s.W; a.H = s.H; a.filters = s.filters; a.clip_pt = s.clip_pt; a.clip_pt8 = s.clip_pt8; a.g00 = s.g00; a.ey = s.ey;
+    TileArgs frame;
+    frame.raw = (amz_gcf)s.raw; frame.rs = (long)s.raw_stride;
+    frame.red = (amz_gf)s.red; frame.green = (amz_gf)s.green; frame.blue = (amz_gf)s.blue; frame.os = (long)s.out_stride;
+    frame.W = s.W; frame.H = s.H; frame.filters = s.filters; frame.clip_pt = s.clip_pt; frame.clip_pt8 = s.clip_pt8; frame.g00 = s.g00; frame.ey = s.ey;
+    frame.top = 0; frame.left = 0; frame.rr1 = 0; frame.gbase = 0;
 
-    for (int k = blockIdx.x; k < s.ntiles; k += gridDim.x) {
-        const int tile = s.tiles[k];
-        const int ty = tile / s.ntx, tx = tile - ty * s.ntx;
-        a.top = -16 + ty * (TS - 32);
-        a.left = -16 + tx * (TS - 32);
-        ThreadRegs rg;
-        rg.pf0 = rg.pf1 = 0.f;
-        bb_reset(rg.bb);
-        P8Regs p8;
-        p8.cc = -1;
-        bb_reset(p8.bb);
-        tile_begin(lds, tid);
-        if (grp == 1) st_load_first(a, c_, rg);
-        lds_barrier();
+    // this workgroup's tile sequence: tiles blockIdx.x, blockIdx.x + gridDim.x, ... and then whatever the redo queue holds
+    int nk = ((int)blockIdx.x < s.ntiles) ? (s.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int nk_static = nk;
+    amz_li dyn = (amz_li)(lds + DYN_OFF);          // the redo entry tid 0 pulled for sequence position dyn[0]
+    auto tile_ref = [&](int k) -> TileRef {
+        TileRef t;
+        if (k < nk_static) {
+            const int tile = s.tiles[blockIdx.x + k * gridDim.x];
+            const int ty = tile / s.ntx, tx = tile - ty * s.ntx;
+            const int top = -16 + ty * (TS - 32);
+            tile_ref_set(t, k, tile, top, -16 + tx * (TS - 32), min(top + TS, s.H + 16) - top);
+        } else if (dyn[0] == k && dyn[1] >= 0) {
+            const int tile = dyn[1];
+            const int ty = tile / s.ntx, tx = tile - ty * s.ntx;
+            const int top = -16 + ty * (TS - 32);
+            tile_ref_set(t, k, tile, top, -16 + tx * (TS - 32), min(top + TS, s.H + 16) - top);
+            t.redo = 1; t.r0 = dyn[2]; t.r1 = dyn[3]; t.c0 = dyn[4]; t.c1 = dyn[5];
+        } else {
+            tile_ref_none(t, k);
+        }
+        return t;
+    };
+    // tid 0: take one entry of the redo queue for sequence position k (none: dyn[1] = -1)
+    auto pull = [&](int k) {
+        int tile = -1;
+        unsigned long long w = 0;
+        const int taken = __hip_atomic_load(&s.queue_hdr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int reserved = __hip_atomic_load(&s.queue_hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (taken < reserved) {
+            int expect = taken;
+            if (__hip_atomic_compare_exchange_strong(&s.queue_hdr[1], &expect, taken + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                // the producer publishes the word right after reserving the slot; if it does not show up, abandon the slot (the
+                // producer's publishing compare-and-swap then fails and it hands the tile to the arena kernel instead)
+                for (int spin = 0; spin < 4096; ++spin) {
+                    w = __hip_atomic_load(&s.queue_words[taken], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (w) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (!w) {
+                    unsigned long long zero = 0;
+                    if (!__hip_atomic_compare_exchange_strong(&s.queue_words[taken], &zero, ~0ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        w = zero;      // published in the meantime
+                }
+                if (w && w != ~0ull) tile = (int)(w & 0xffffffu);
+            }
+        }
+        dyn[0] = k; dyn[1] = tile;
+        dyn[2] = (int)((w >> 24) & 0xff); dyn[3] = (int)((w >> 32) & 0xff); dyn[4] = (int)((w >> 40) & 0xff); dyn[5] = (int)((w >> 48) & 0xff);
+    };
+    if (nk == 0) return;       // (more workgroups than tiles)
+    if (tid == 0) { dyn[0] = -1; dyn[1] = -1; if (nk_static == 1) pull(1); }
+    seq_begin(lds, tid);
+    lds_barrier();
+    TileSeq q;
+    tile_ref_none(q.back, -1);
+    q.front = tile_ref(0);
+    q.next = tile_ref(1);
+    if (q.next.rr1 > 0 && nk < 2) nk = 2;
+
+    ThreadRegs rg;
+    rg.pf0 = rg.pf1 = 0.f;
+    bb_reset(rg.bb);
+    P8Regs p8;
+    p8.cc = -1;
+    if (grp == 1) st_load_first(frame, q, c_, rg);
 #ifdef AMZ_PROFILE
-        long long ta = 0, tb = 0, tw = 0;
+    long long ta = 0, tb = 0, tw = 0;
 #define AMZ_T0 const long long t0_ = __builtin_amdgcn_s_memtime();
 #define AMZ_T1(acc) { const long long t1_ = __builtin_amdgcn_s_memtime(); acc += t1_ - t0_; }
 #else
 #define AMZ_T0
 #define AMZ_T1(acc)
 #endif
-        for (int t = 0; t < NSTEPS; ++t) {
-            // the column / lane are made opaque per step: otherwise every role's column-derived addresses are hoisted out of the
-            // step loop and kept live across all the other roles (the kernel then spills into scratch inside the loop)
-            int c = c_, lane = lane_;
-            asm volatile("" : "+v"(c), "+v"(lane));
-            { AMZ_T0 if (grp < 5) substep_a(lds, a, t, grp, c, rg); else p8_wave_a(lds, t, lane, p8); AMZ_T1(ta) }
-            { AMZ_T0 lds_barrier(); AMZ_T1(tw) }
-            AMZ_T0
-            if (grp < 4) {
-                substep_b_threads(lds, a, t, grp, c);
-            } else if (wave == 12) {
-                wave_p9(lds, a, 2 * t - 26, lane);
-            } else if (wave == 13) {
-                wave_p13(lds, a, 2 * t - 26, lane);
-            } else if (wave == 14) {
-                st_p7(lds, a, 2 * t - 14, lane);
-                st_p7(lds, a, 2 * t - 14, 64 + lane);
-                st_p7(lds, a, 2 * t - 14, 128 + lane);
-                wave_list(lds, a, t, lane);
-            } else {
-                p8_wave_b(lds, t, lane, p8);
+    for (int T = 0; T < STEPS_PER_TILE * nk + TAIL_STEPS; ++T) {
+        if (T > 0 && T % STEPS_PER_TILE == 0) {      // the load front enters the next tile
+            q.back = q.front;
+            q.front = q.next;
+            const int kn = T / STEPS_PER_TILE + 1;
+            q.next = tile_ref(kn);
+            if (q.next.rr1 > 0 && nk < kn + 1) nk = kn + 1;
+        }
+        // the column / lane are made opaque per step: otherwise every role's column-derived addresses are hoisted out of the
+        // step loop and kept live across all the other roles (the kernel then spills into scratch inside the loop)
+        int c = c_, lane = lane_;
+        asm volatile("" : "+v"(c), "+v"(lane));
+        if (tid == 0) {
+            if (tile_done(q, T)) {                   // every stage has left tile q.back
+                const int par = (q.back.gbase / TS) & 1;
+                int box[4];
+                if (!tile_valid(lds, par, q.back.rr1, box) && !q.back.redo) {
+                    // stream it again with the true box: publish a queue entry; if the slot was abandoned, the arena kernel takes the tile
+                    const unsigned long long w = (unsigned long long)q.back.tile | ((unsigned long long)box[0] << 24) | ((unsigned long long)box[1] << 32) |
+                                                 ((unsigned long long)box[2] << 40) | ((unsigned long long)box[3] << 48) | (1ull << 63);
+                    const int slot = atomicAdd(&s.queue_hdr[0], 1);
+                    unsigned long long zero = 0;
+                    if (!__hip_atomic_compare_exchange_strong(&s.queue_words[slot], &zero, w, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        const int fs = atomicAdd(&s.fallback[0], 1);
+                        s.fallback[1 + fs] = q.back.tile;
+                    }
+                }
+                red_reset(lds, par);
             }
-            AMZ_T1(tb)
-            { AMZ_T0 lds_barrier(); AMZ_T1(tw) }
+            // one step before the load front needs a sequence position beyond the static tiles: look into the redo queue
+            const int kn = (T + 1) / STEPS_PER_TILE + 1;
+            if ((T + 1) % STEPS_PER_TILE == 0 && kn >= nk_static) pull(kn);
         }
-#ifdef AMZ_PROFILE
-        if (blockIdx.x == 1000 && lane_ == 0) printf("wave %2d: a %8lld  b %8lld  barrier-wait %8lld cycles (%d steps)\n", wave, ta, tb, tw, NSTEPS);
-#endif
-        if (grp == 1) bb_flush(lds, 0, rg.bb);
-        if (grp == 5) bb_flush(lds, 4, p8.bb);
-        lds_barrier();
-        if (tid == 0 && !tile_valid(lds)) {
-            const int slot = atomicAdd(&s.fallback[0], 1);
-            s.fallback[1 + slot] = tile;
+        { AMZ_T0 if (grp < 5) substep_a(lds, frame, q, T, grp, c, rg); else p8_step_a(lds, frame, q, T, lane, p8, rg.bb); AMZ_T1(ta) }
+        { AMZ_T0 lds_barrier(); AMZ_T1(tw) }
+        AMZ_T0
+        if (grp < 4) {
+            substep_b_threads(lds, frame, q, T, grp, c);
+        } else if (wave == 12) {
+            const TileArgs a = stage_tile(frame, q, 2 * T - 26);
+            wave_p9(lds, a, 2 * T - 26 - a.gbase, lane);
+        } else if (wave == 13) {
+            const TileArgs a = stage_tile(frame, q, 2 * T - 26);
+            wave_p13(lds, a, 2 * T - 26 - a.gbase, lane);
+        } else if (wave == 14) {
+            {
+                const TileArgs a = stage_tile(frame, q, 2 * T - 14);
+                st_p7(lds, a, 2 * T - 14 - a.gbase, lane);
+                st_p7(lds, a, 2 * T - 14 - a.gbase, 64 + lane);
+                st_p7(lds, a, 2 * T - 14 - a.gbase, 128 + lane);
+            }
+            const TileArgs a = stage_tile(frame, q, 2 * T - 20);
+            wave_list(lds, a, T, 2 * T - 20 - a.gbase, lane);
+        } else {
+            p8_step_b(lds, frame, q, T, lane, p8, rg.bb);
         }
-        lds_barrier();      // the next tile's tile_begin rewrites the reduction words
+        AMZ_T1(tb)
+        { AMZ_T0 lds_barrier(); AMZ_T1(tw) }
     }
+#ifdef AMZ_PROFILE
+    if (blockIdx.x == 100 && lane_ == 0) printf("wave %2d: a %8lld  b %8lld  barrier-wait %8lld cycles (%d tiles)\n", wave, ta, tb, tw, nk);
+#endif
 }
 
 hipError_t launch_amaze_stream(const AmazeStreamArgs &s, int grid, hipStream_t stream)

@@ -142,13 +142,15 @@ constexpr int NQA_FLOATS = 40;
 constexpr int LIST_OFF = NQA_OFF + NQA_FLOATS;   // P8 site list of one step (row << 8 | col), at most 144 entries
 constexpr int LIST_INTS = 160;                   // two lists: the one step t consumes is rebuilt (for step t+2) only after step t
 constexpr int RED_OFF = LIST_OFF + 2 * LIST_INTS;    // int words: [0..3] flag box (min row, max row, min col, max col), [4..7] extent of the
-constexpr int RED_INTS = 16;                     // nyquist2 sites P8 processed, [8], [9] list counts
-constexpr int LDS_FLOATS = RED_OFF + RED_INTS;
+constexpr int RED_INTS = 24;                     // nyquist2 sites P8 processed; [8..15]: the same for the other tile in flight; [16], [17] list counts
+constexpr int DYN_OFF = RED_OFF + RED_INTS;      // the redo-queue entry pulled for the next sequence position (position, tile, box)
+constexpr int DYN_INTS = 8;
+constexpr int LDS_FLOATS = DYN_OFF + DYN_INTS;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
 constexpr int NTHREADS = 1024;
 constexpr int LAST_OFF = 38;
-constexpr int NSTEPS = (TS + LAST_OFF) / 2;
+
 
 #ifdef AMZ_EMUL
 // row tags: which tile row a ring slot holds (emulation only)
@@ -169,16 +171,18 @@ static inline void tag_read(int ring, int depth, int row)
 #define AMZ_TAGW(n, row) ((void)0)
 #define AMZ_TAGR(n, row) ((void)0)
 #endif
+// the workgroup streams a SEQUENCE of tiles: tile k of the sequence occupies the global rows 160 k .. 160 k + 159 of the rings
+#define AMZ_GB (a.gbase)
 // row pointers: W = this stage writes the row, R = it reads a row that must hold exactly that tile row,
 // X = it reads a row whose content cannot reach an output (no check)
-#define ROWW(n, row) (AMZ_TAGW(n, row), lds + (amz::n##_OFF + (int)((unsigned)(row) % amz::n##_D) * amz::n##_S))
-#define ROWR(n, row) (AMZ_TAGR(n, row), lds + (amz::n##_OFF + (int)((unsigned)(row) % amz::n##_D) * amz::n##_S))
-#define ROWX(n, row) (lds + (amz::n##_OFF + (int)((unsigned)(row) % amz::n##_D) * amz::n##_S))
+#define ROWW(n, row) (AMZ_TAGW(n, AMZ_GB + (row)), lds + (amz::n##_OFF + (int)((unsigned)(AMZ_GB + (row)) % amz::n##_D) * amz::n##_S))
+#define ROWR(n, row) (AMZ_TAGR(n, AMZ_GB + (row)), lds + (amz::n##_OFF + (int)((unsigned)(AMZ_GB + (row)) % amz::n##_D) * amz::n##_S))
+#define ROWX(n, row) (lds + (amz::n##_OFF + (int)((unsigned)(AMZ_GB + (row)) % amz::n##_D) * amz::n##_S))
 // the same for a row r + k + s where r is uniform over the wave and s (0 or 1) differs per lane: both candidates are scalar
 // computations (a per-lane modulo costs five VALU instructions per row pointer), the lane only selects
-#define AMZ_SLOT(n, row) (amz::n##_OFF + (int)((unsigned)(row) % amz::n##_D) * amz::n##_S)
-#define SROWW(n, r, k, s) (AMZ_TAGW(n, (r) + (k) + (s)), lds + ((s) ? AMZ_SLOT(n, (r) + (k) + 1) : AMZ_SLOT(n, (r) + (k))))
-#define SROWR(n, r, k, s) (AMZ_TAGR(n, (r) + (k) + (s)), lds + ((s) ? AMZ_SLOT(n, (r) + (k) + 1) : AMZ_SLOT(n, (r) + (k))))
+#define AMZ_SLOT(n, row) (amz::n##_OFF + (int)((unsigned)(AMZ_GB + (row)) % amz::n##_D) * amz::n##_S)
+#define SROWW(n, r, k, s) (AMZ_TAGW(n, AMZ_GB + (r) + (k) + (s)), lds + ((s) ? AMZ_SLOT(n, (r) + (k) + 1) : AMZ_SLOT(n, (r) + (k))))
+#define SROWR(n, r, k, s) (AMZ_TAGR(n, AMZ_GB + (r) + (k) + (s)), lds + ((s) ? AMZ_SLOT(n, (r) + (k) + 1) : AMZ_SLOT(n, (r) + (k))))
 #define SROWX(n, r, k, s) (lds + ((s) ? AMZ_SLOT(n, (r) + (k) + 1) : AMZ_SLOT(n, (r) + (k))))
 
 struct TileArgs {
@@ -187,6 +191,9 @@ struct TileArgs {
     amz_gf red, green, blue;
     long os;
     int top, left;      // tile origin in the frame (may be negative: mirrored border, L205-334)
+    int rr1;            // rows of the tile (160, less at the bottom edge of the frame; 0: no tile)
+    int gbase;          // 160 * (position of the tile in the workgroup's sequence): ring rows are gbase + tile row
+    int ny_r0, ny_r1, ny_c0, ny_c1;   // the Nyquist box P7 / P8 / P10 work in (L827-876): [8, rr1-8) x [8, 152) on the first attempt
     int W, H;
     unsigned filters;
     float clip_pt, clip_pt8;
@@ -273,7 +280,7 @@ AMZ_DEV int src_col(const TileArgs &a, int rr, int cc)
 // the adjacent row of the flat tile
 AMZ_DEV void st_p1(amz_lf lds, const TileArgs &a, int r, int c)
 {
-    if (r < 2 || r >= TS - 2 || c >= TS) return;
+    if (r < 2 || r >= a.rr1 - 2 || c >= TS) return;
     amz_lf cm2 = ROWR(CFA, r - 2), cm1 = ROWR(CFA, r - 1), c0r = ROWR(CFA, r), cp1 = ROWR(CFA, r + 1), cp2 = ROWR(CFA, r + 2);
     const float cl1 = c >= 1 ? c0r[c - 1] : cm1[TS + c - 1];
     const float cl2 = c >= 2 ? c0r[c - 2] : cm1[TS + c - 2];
@@ -298,9 +305,9 @@ AMZ_DEV void st_p1(amz_lf lds, const TileArgs &a, int r, int c)
 // P2 (L380-434): colour differences of row r, columns 4..155; zero where the reference's cleared planes are read unwritten
 AMZ_DEV void st_p2(amz_lf lds, const TileArgs &a, int r, int c)
 {
-    if (r < 2 || r >= TS - 2 || c >= TS) return;
+    if (r < 2 || r >= a.rr1 - 2 || c >= TS) return;
     float o_hcdalt = 0.f, o_vcdalt = 0.f, o_vcd = 0.f, o_hcd = 0.f;
-    if (r >= 4 && r < TS - 4 && c >= 4 && c < TS - 4) {
+    if (r >= 4 && r < a.rr1 - 4 && c >= 4 && c < TS - 4) {
         amz_lf cr = ROWR(CFA, r), d0r = ROWR(D0, r), d1r = ROWR(D1, r);
         const float sgn = is_green(a, r, c) ? -1.f : 1.f;
         const float cfav = cr[c];
@@ -362,7 +369,7 @@ AMZ_DEV float p3_hcd_pure(amz_lf ho, amz_lf ha, amz_lf cf, const TileArgs &a, in
 // the group to their left (recomputed here: they only depend on original values); vcd: row r reads the updated row r-2.
 AMZ_DEV void st_p3(amz_lf lds, const TileArgs &a, int r, int c)
 {
-    if (r < 4 || r >= TS - 4 || c >= TS) return;
+    if (r < 4 || r >= a.rr1 - 4 || c >= TS) return;
     float nh = 0.f;
     if (c >= 4 && c < TS - 4) {
         amz_lf ho = ROWR(HCO, r), ha = ROWR(HCA, r), cf = ROWR(CFA, r);
@@ -406,7 +413,7 @@ AMZ_DEV void st_p4(amz_lf lds, const TileArgs &a, int r, int c)
 {
     if (c >= TS) return;
     const int sl = site_sel(a, r, c), rr = r + sl;
-    if (rr < 6 || rr >= TS - 6) return;
+    if (rr < 6 || rr >= a.rr1 - 6) return;
     const int par = row_par(a, rr);
     if (c < 6 + par || c > 156 + par) return;          // 4 * ngroups(6 + par, 154, 8) = 76 sites: the last group overruns
     amz_lf hn = SROWR(HCN, r, 0, sl), dh = SROWR(DGH, r, 0, sl);
@@ -471,17 +478,19 @@ AMZ_DEV void bb_flush(amz_lf lds, int base, const int *bb)
 // P5 + P6 (L746-825): nyquist test value and flag of the site of column c; helper lanes 160..171 clear the flag bytes without a site
 AMZ_DEV void st_p5(amz_lf lds, const TileArgs &a, int r, int c, ThreadRegs &rg)
 {
-    if (r < 6 || r >= TS - 6) return;
+    if (r + 1 < 6 || r >= a.rr1 - 6) return;
     if (c >= TS) {
         const int h = c - TS;
         if (h < 12) {
             const int sl = h >= 6, k = h % 6;
+            if (r + sl < 6 || r + sl >= a.rr1 - 6) return;
             amz_lb nb = (amz_lb)SROWW(NYQ, r, 0, sl);
             nb[k < 3 ? k : 74 + k] = 0;                 // bytes 0,1,2 and 77,78,79
         }
         return;
     }
     const int sl = site_sel(a, r, c), rr = r + sl;
+    if (rr < 6 || rr >= a.rr1 - 6) return;
     const int par = row_par(a, rr);
     if (c < 6 + par) return;
     amz_lb nb = (amz_lb)SROWW(NYQ, r, 0, sl);
@@ -517,12 +526,12 @@ AMZ_DEV void st_p7(amz_lf lds, const TileArgs &a, int r, int item)
 {
     if (item >= 2 * TSH) return;
     const int sl = item >= TSH, rr = r + sl, b = item - (sl ? TSH : 0);
-    if (rr < 2 || rr >= TS - 2) return;
+    if (rr < 2 || rr >= a.rr1 - 2) return;
     amz_lb out = (amz_lb)SROWW(NYQ2, r, 0, sl);
-    if (rr < 8 || rr >= TS - 8) {
-        // rows 156..159 lie behind the memset (L879): they still hold the bytes of cddiffsq(19, 80..159), and P8's window at rows
+    if (rr < a.ny_r0 || rr >= a.ny_r1) {
+        // outside [nystartrow, nyendrow): the memset value (L879); rows 156..159 lie behind the memset (L879): they still hold the bytes of cddiffsq(19, 80..159), and P8's window at rows
         // 150, 151 tests them
-        out[b] = rr >= TS - 4 ? ((amz_lb)(lds + NQA_OFF))[(rr - (TS - 4)) * TSH + b] : 0;
+        out[b] = rr >= TS - 4 ? ((amz_lb)(lds + NQA_OFF))[(rr - (TS - 4)) * TSH + b] : 0;   // (only tiles of 159 / 160 rows get there)
         return;
     }
     amz_lb n0 = (amz_lb)SROWR(NYQ, r, 0, sl), nu1 = (amz_lb)SROWR(NYQ, r, -1, sl), nu2 = (amz_lb)SROWR(NYQ, r, -2, sl);
@@ -537,13 +546,13 @@ AMZ_DEV void st_p7(amz_lf lds, const TileArgs &a, int r, int item)
     out[b] = val;
 }
 
-// is column c's site in rows (r, r+1) one that P8 / P10 process under the full bounding box [8,152) x [8,152)?
+// is column c's site in rows (r, r+1) one that P8 / P10 process (inside the tile's Nyquist box, nyquist2 set)?
 AMZ_DEV bool nyq_site(amz_lf lds, const TileArgs &a, int r, int c, int *prr)
 {
     if (c >= TS) return false;
     const int sl = site_sel(a, r, c), rr = r + sl;
     *prr = rr;
-    if (rr < 8 || rr >= TS - 8 || c < 8 + row_par(a, rr) || c >= TS - 8) return false;
+    if (rr < a.ny_r0 || rr >= a.ny_r1 || c < a.ny_c0 + row_par(a, rr) || c >= a.ny_c1) return false;     // L914-915, L980-981
     return ((amz_lb)SROWR(NYQ2, r, 0, sl))[c >> 1] != 0;
 }
 
@@ -553,7 +562,7 @@ AMZ_DEV bool nyq_site(amz_lf lds, const TileArgs &a, int r, int c, int *prr)
 // sub-step b (the partial sums stay in registers across the barrier), which halves the longest serial chain of a sub-step.
 struct P8Acc { float sumcfa, sumh, sumv, sumsqh, sumsqv, areawt; };
 template <int A0, int A1>
-AMZ_DEV void p8_accumulate(amz_lf lds, int r, int sl, int cc, P8Acc &s)
+AMZ_DEV void p8_accumulate(amz_lf lds, const TileArgs &a, int r, int sl, int cc, P8Acc &s)
 {
     const int idx0 = (cc - 6) >> 1;
 #pragma unroll
@@ -579,7 +588,7 @@ AMZ_DEV void p8_accumulate(amz_lf lds, int r, int sl, int cc, P8Acc &s)
         }
     }
 }
-AMZ_DEV void p8_finish(amz_lf lds, int r, int sl, int cc, const P8Acc &s, int *bb)
+AMZ_DEV void p8_finish(amz_lf lds, const TileArgs &a, int r, int sl, int cc, const P8Acc &s, int *bb)
 {
     const int rr = r + sl;
     const float sumh = s.sumcfa - xdiv2f(s.sumh);
@@ -591,37 +600,37 @@ AMZ_DEV void p8_finish(amz_lf lds, int r, int sl, int cc, const P8Acc &s, int *b
     bb_add(bb, rr, cc);
 }
 // the P8 wave, lane 0..63: first half of the window for list entry `lane` (sub-step a) ...
-struct P8Regs { P8Acc acc; int sl, cc; int bb[4]; };
-AMZ_DEV void p8_wave_a(amz_lf lds, int t, int lane, P8Regs &pr)
+struct P8Regs { P8Acc acc; int sl, cc; };
+AMZ_DEV void p8_wave_a(amz_lf lds, const TileArgs &a, int t, int r, int lane, P8Regs &pr)
 {
     amz_li red = (amz_li)(lds + RED_OFF);
     amz_li list = (amz_li)(lds + LIST_OFF + (t & 1) * LIST_INTS);
-    const int n = red[8 + (t & 1)], r = 2 * t - 22;
+    const int n = red[16 + (t & 1)];
     pr.cc = -1;
     if (lane < n) {
         const int e = list[lane];
         pr.sl = (e >> 8) - r; pr.cc = e & 255;
         pr.acc = P8Acc{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        p8_accumulate<-6, 0>(lds, r, pr.sl, pr.cc, pr.acc);
+        p8_accumulate<-6, 0>(lds, a, r, pr.sl, pr.cc, pr.acc);
     }
 }
 // ... second half and the result (sub-step b); list entries beyond the wave width (dense Nyquist regions) are done here in full
-AMZ_DEV void p8_wave_b(amz_lf lds, int t, int lane, P8Regs &pr)
+AMZ_DEV void p8_wave_b(amz_lf lds, const TileArgs &a, int t, int r, int lane, P8Regs &pr, int *bb)
 {
     amz_li red = (amz_li)(lds + RED_OFF);
     amz_li list = (amz_li)(lds + LIST_OFF + (t & 1) * LIST_INTS);
-    const int n = red[8 + (t & 1)], r = 2 * t - 22;
+    const int n = red[16 + (t & 1)];
     if (pr.cc >= 0) {
-        p8_accumulate<2, 6>(lds, r, pr.sl, pr.cc, pr.acc);
-        p8_finish(lds, r, pr.sl, pr.cc, pr.acc, pr.bb);
+        p8_accumulate<2, 6>(lds, a, r, pr.sl, pr.cc, pr.acc);
+        p8_finish(lds, a, r, pr.sl, pr.cc, pr.acc, bb);
     }
     for (int q = 64 + lane; q < n; q += 64) {
         const int e = list[q];
         const int sl = (e >> 8) - r, cc = e & 255;
         P8Acc acc{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        p8_accumulate<-6, 0>(lds, r, sl, cc, acc);
-        p8_accumulate<2, 6>(lds, r, sl, cc, acc);
-        p8_finish(lds, r, sl, cc, acc, pr.bb);
+        p8_accumulate<-6, 0>(lds, a, r, sl, cc, acc);
+        p8_accumulate<2, 6>(lds, a, r, sl, cc, acc);
+        p8_finish(lds, a, r, sl, cc, acc, bb);
     }
 }
 
@@ -655,7 +664,7 @@ AMZ_DEV void st_p11(amz_lf lds, const TileArgs &a, int r, int item)
 {
     if (item >= 152) return;
     const int sl = item >= 76, rr = r + sl, j = item - (sl ? 76 : 0);
-    if (rr < 6 || rr >= TS - 6) return;
+    if (rr < 6 || rr >= a.rr1 - 6) return;
     const int e = 6 + 2 * j, idx = e >> 1;
     const bool rbEven = row_par(a, rr) == 0;
     const int g = rbEven ? e + 1 : e; // green site of the pair
@@ -674,16 +683,18 @@ AMZ_DEV void st_p11(amz_lf lds, const TileArgs &a, int r, int item)
 // pmwt[.., 76..79] aliases (delhvsqsum, L169) into the ring row
 AMZ_DEV void st_p12(amz_lf lds, const TileArgs &a, int r, int c)
 {
-    if (r < 8 || r >= TS - 8) return;
+    if (r + 1 < 8 || r >= a.rr1 - 8) return;
     if (c >= TS) {
         const int h = c - TS;
         if (h < 8) {
             const int sl = h >= 4, rr = r + sl, k = h & 3;
+            if (rr < 8 || rr >= a.rr1 - 8) return;
             SROWW(PMWT, r, 0, sl)[76 + k] = lds[SIDE_OFF + ((rr >> 1) - 4) * 8 + (rr & 1) * 4 + k];
         }
         return;
     }
     const int sl = site_sel(a, r, c), rr = r + sl;
+    if (rr < 8 || rr >= a.rr1 - 8) return;
     const int par = row_par(a, rr);
     if (c < 8 + par || c > 150 + par) return;
     const int idx = c >> 1;
@@ -755,13 +766,13 @@ AMZ_DEV void st_p10_14_15(amz_lf lds, const TileArgs &a, int r, int c)
 {
     if (c >= TS) return;
     const int sl = site_sel(a, r, c), rr = r + sl;
-    if (rr < 8 || rr >= TS - 8) return;
+    if (rr < 8 || rr >= a.rr1 - 8) return;
     const int par = row_par(a, rr), idx = c >> 1;
     if (c < 8 + par || c >= TS - 8) return;
     float dg = SROWR(DG0, r, 0, sl)[idx];
     float gval = SROWR(RGBG, r, 0, sl)[idx];
     const float cfav = SROWR(CFA, r, 0, sl)[c];
-    if (((amz_lb)SROWR(NYQ2, r, 0, sl))[idx]) {
+    if (rr >= a.ny_r0 && rr < a.ny_r1 && c >= a.ny_c0 + par && c < a.ny_c1 && ((amz_lb)SROWR(NYQ2, r, 0, sl))[idx]) {
         const float gq0 = 0.169917f, gq1 = 0.108947f, gq2 = 0.069855f, gq3 = 0.0287182f;
         // Dgrb2 rows 6,7,152,153 and columns < 8 / >= 152 alias dgintv in the reference: only sites no output depends on read them
         amz_lf e0 = SROWX(DG2, r, 0, sl), eu1 = SROWX(DG2, r, -1, sl), eu2 = SROWX(DG2, r, -2, sl), ed1 = SROWX(DG2, r, +1, sl), ed2 = SROWX(DG2, r, +2, sl);
@@ -781,7 +792,7 @@ AMZ_DEV void st_p10_14_15(amz_lf lds, const TileArgs &a, int r, int c)
         dg = (vh[TSH + idx] * gvarv + vh[idx] * gvarh) / (gvarv + gvarh);
         gval = cfav + dg;
     }
-    const bool in14 = rr >= 12 && rr < TS - 12 && c >= 12 + par && c <= 146 + par;
+    const bool in14 = rr >= 12 && rr < a.rr1 - 12 && c >= 12 + par && c <= 146 + par;
     if (in14) {
         const float hw = SROWR(HVWT, r, 0, sl)[idx];
         if (fabsf(0.5f - SROWR(PMWT, r, 0, sl)[idx]) >= fabsf(0.5f - hw)) {
@@ -818,7 +829,7 @@ AMZ_DEV void st_p16(amz_lf lds, const TileArgs &a, int r, int c)
 {
     if (c >= TS) return;
     const int sl = site_sel(a, r, c), rr = r + sl;
-    if (rr < 14 || rr >= TS - 14) return;
+    if (rr < 14 || rr >= a.rr1 - 14) return;
     const int par = row_par(a, rr);
     if (c < 14 + par || c > 148 + par) return;
     const bool red_row = (rr & 1) == a.ey;   // c = 1 - FC/2: red sites get G-B from the blue rows above and below
@@ -849,7 +860,7 @@ AMZ_DEV void st_p16(amz_lf lds, const TileArgs &a, int r, int c)
 // P17/P18 (L1441-1565): R, G, B of tile row rr, column c
 AMZ_DEV void st_out(amz_lf lds, const TileArgs &a, int rr, int c)
 {
-    if (rr < 16 || rr >= TS - 16 || c < 16 || c >= TS - 16) return;
+    if (rr < 16 || rr >= a.rr1 - 16 || c < 16 || c >= TS - 16) return;
     float gval, rv, bv;
     if (is_green(a, rr, c)) {
         gval = ROWR(CFA, rr)[c];
@@ -877,96 +888,173 @@ AMZ_DEV void st_out(amz_lf lds, const TileArgs &a, int rr, int c)
 
 
 // tile validity: every nyquist2 site the stream processed lies inside the reference's bounding box (L827-876)
-AMZ_DEV bool tile_valid(amz_lf lds)
+AMZ_DEV bool tile_valid(amz_lf lds, int par, int rr1, int *box)
 {
-    amz_li red = (amz_li)(lds + RED_OFF);
-    if (red[5] == 0 && red[7] == 0) return true;                 // no nyquist2 site at all
+    amz_li red = (amz_li)(lds + RED_OFF) + 8 * par;
     int nystartrow = red[0] == (1 << 30) ? 0 : red[0], nyendrow = red[1], nystartcol = red[2], nyendcol = red[3];
-    if (!(nystartrow != nyendrow && nystartcol != nyendcol)) return false;
-    nyendrow++;
-    nyendcol++;
-    nystartcol -= (nystartcol & 1);
-    nystartrow = imax(8, nystartrow);
-    nyendrow = imin(TS - 8, nyendrow);
-    nystartcol = imax(8, nystartcol);
-    nyendcol = imin(TS - 8, nyendcol);
+    const bool doNyquist = nystartrow != nyendrow && nystartcol != nyendcol;
+    if (doNyquist) {
+        nyendrow++;
+        nyendcol++;
+        nystartcol -= (nystartcol & 1);
+        nystartrow = imax(8, nystartrow);
+        nyendrow = imin(rr1 - 8, nyendrow);
+        nystartcol = imax(8, nystartcol);
+        nyendcol = imin(TS - 8, nyendcol);
+    } else {
+        nystartrow = nyendrow = nystartcol = nyendcol = 0;       // P7, P8 and P10 do not run at all (L844)
+    }
+    box[0] = nystartrow; box[1] = nyendrow; box[2] = nystartcol; box[3] = nyendcol;
+    if (red[5] == 0 && red[7] == 0) return true;                 // no nyquist2 site at all
     return red[4] >= nystartrow && red[5] < nyendrow && red[6] >= nystartcol && red[7] < nyendcol;
 }
 
-AMZ_DEV void tile_begin(amz_lf lds, int tid)
+// reduction words of the tile with sequence parity `par` (flag box, extent of the processed nyquist2 sites)
+AMZ_DEV void red_reset(amz_lf lds, int par)
 {
-    amz_li red = (amz_li)(lds + RED_OFF);
+    amz_li red = (amz_li)(lds + RED_OFF) + 8 * par;
+    red[0] = 1 << 30; red[1] = 0; red[2] = TS + 1; red[3] = 0;
+    red[4] = 1 << 30; red[5] = 0; red[6] = 1 << 30; red[7] = 0;
+}
+AMZ_DEV void seq_begin(amz_lf lds, int tid)
+{
     if (tid == 0) {
-        red[0] = 1 << 30; red[1] = 0; red[2] = TS + 1; red[3] = 0;
-        red[4] = 1 << 30; red[5] = 0; red[6] = 1 << 30; red[7] = 0;
-        red[8] = 0; red[9] = 0;
+        red_reset(lds, 0);
+        red_reset(lds, 1);
+        amz_li red = (amz_li)(lds + RED_OFF);
+        red[16] = 0; red[17] = 0;
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The tile sequence.  A workgroup streams its tiles back to back: tile k occupies the global rows 160 k .. 160 k + 159, and a
+// stage at offset "off" handles global rows (2T - off, 2T - off + 1) at global step T -- so while the late stages finish tile k
+// the early stages already work on tile k + 1 (no pipeline fill / drain per tile: 80 steps per tile instead of 99).  At most
+// two tiles are in flight (the deepest offset is 38 rows); the loader prefetches one step ahead and needs the next one too.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TileRef { int top, left, rr1, gbase, tile, redo, r0, r1, c0, c1; };   // tile: index in the frame; redo: second attempt, the box is the true one
+struct TileSeq { TileRef back, front, next; };
+AMZ_DEV TileArgs with_tile(const TileArgs &frame, const TileRef &t)
+{
+    TileArgs a = frame;
+    a.top = t.top; a.left = t.left; a.rr1 = t.rr1; a.gbase = t.gbase;
+    a.ny_r0 = t.r0; a.ny_r1 = t.r1; a.ny_c0 = t.c0; a.ny_c1 = t.c1;
+    return a;
+}
+// the tile a stage at global row G works on
+AMZ_DEV TileArgs stage_tile(const TileArgs &frame, const TileSeq &q, int G) { return with_tile(frame, G >= q.front.gbase ? q.front : q.back); }
+#define AMZ_STAGE(fn, off, ...)                                              \
+    {                                                                        \
+        const int G_ = 2 * T - (off);                                        \
+        const TileArgs A_ = stage_tile(frame, q, G_);                        \
+        fn(lds, A_, G_ - A_.gbase, __VA_ARGS__);                             \
+    }
+
 // load: thread c of the loader group puts the two rows it fetched during the previous step into the ring and fetches the next two
-AMZ_DEV void st_load(amz_lf lds, const TileArgs &a, int t, int c, ThreadRegs &rg)
+// (of this tile or, at its end, the first two of the next tile)
+AMZ_DEV void st_load(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T, int c, ThreadRegs &rg)
 {
     if (c >= TS) return;
-    const int r = 2 * t;
-    if (r < TS) {
+    const TileArgs a = with_tile(frame, q.front);
+    const int r = 2 * T - a.gbase;
+    if (r < a.rr1) {
         ROWW(CFA, r)[c] = rg.pf0 / 65535.f;
-        ROWW(CFA, r + 1)[c] = rg.pf1 / 65535.f;
+        if (r + 1 < a.rr1) ROWW(CFA, r + 1)[c] = rg.pf1 / 65535.f;
     }
     // unconditional (row index clamped): a branch would put a wait between the loads
-    const int n0 = imin(r + 2, TS - 1), n1 = imin(r + 3, TS - 1);
-    rg.pf0 = a.raw[(long)src_row(a, n0, c) * a.rs + src_col(a, n0, c)];
-    rg.pf1 = a.raw[(long)src_row(a, n1, c) * a.rs + src_col(a, n1, c)];
+    const bool nxt = r + 2 >= TS;
+    const TileArgs b = with_tile(frame, nxt ? q.next : q.front);
+    const int lim = b.rr1 > 0 ? b.rr1 - 1 : 0;
+    const int n0 = imin(nxt ? 0 : r + 2, lim), n1 = imin(nxt ? 1 : r + 3, lim);
+    rg.pf0 = b.raw[(long)src_row(b, n0, c) * b.rs + src_col(b, n0, c)];
+    rg.pf1 = b.raw[(long)src_row(b, n1, c) * b.rs + src_col(b, n1, c)];
 }
-AMZ_DEV void st_load_first(const TileArgs &a, int c, ThreadRegs &rg)
+AMZ_DEV void st_load_first(const TileArgs &frame, const TileSeq &q, int c, ThreadRegs &rg)
 {
     if (c >= TS) return;
+    const TileArgs a = with_tile(frame, q.front);
     rg.pf0 = a.raw[(long)src_row(a, 0, c) * a.rs + src_col(a, 0, c)];
     rg.pf1 = a.raw[(long)src_row(a, 1, c) * a.rs + src_col(a, 1, c)];
 }
 
-// grp = tid / 192 (0..4; 5 = wave U), c = tid - 192 * grp: uniform over a wave, so the caller passes grp as a scalar
-AMZ_DEV void substep_a(amz_lf lds, const TileArgs &a, int t, int grp, int c, ThreadRegs &rg)
+// a stage that keeps a per-thread box enters a new tile (its global row reaches the front tile's first row): merge the box into
+// the finished tile's reduction words
+AMZ_DEV void bb_tile_change(amz_lf lds, const TileSeq &q, int T, int off, int base, int *bb)
+{
+    if (2 * T - off == q.front.gbase && q.front.gbase > 0) {
+        bb_flush(lds, base + 8 * ((q.back.gbase / TS) & 1), bb);
+        bb_reset(bb);
+    }
+}
+
+// grp = tid / 192 (0..4; 5 = wave 15), c = tid - 192 * grp: uniform over a wave, so the caller passes grp as a scalar
+AMZ_DEV void substep_a(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T, int grp, int c, ThreadRegs &rg)
 {
     switch (grp) {
     case 0:
-        st_p2(lds, a, 2 * t - 6, c);
-        st_p2(lds, a, 2 * t - 5, c);
+        AMZ_STAGE(st_p2, 6, c)
+        AMZ_STAGE(st_p2, 5, c)
         break;
     case 1:
-        st_p5(lds, a, 2 * t - 12, c, rg);
-        st_load(lds, a, t, c, rg);
+        bb_tile_change(lds, q, T, 12, 0, rg.bb);
+        AMZ_STAGE(st_p5, 12, c, rg)
+        st_load(lds, frame, q, T, c, rg);
         break;
     case 2:
-        st_p12(lds, a, 2 * t - 24, c);
+        AMZ_STAGE(st_p12, 24, c)
         break;
     case 3:
-        st_p10_14_15(lds, a, 2 * t - 30, c);
+        AMZ_STAGE(st_p10_14_15, 30, c)
         break;
     case 4:
-        st_p4(lds, a, 2 * t - 14, c);
+        AMZ_STAGE(st_p4, 14, c)
         break;
     default: break;     // wave 15: p8_wave_a (it carries registers into sub-step b, so the driver calls it)
     }
 }
 
 // the part of sub-step b that ordinary column threads do
-AMZ_DEV void substep_b_threads(amz_lf lds, const TileArgs &a, int t, int grp, int c)
+AMZ_DEV void substep_b_threads(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T, int grp, int c)
 {
     switch (grp) {
-    case 0: st_p3(lds, a, 2 * t - 8, c); break;
-    case 1: st_p3(lds, a, 2 * t - 7, c); break;
+    case 0: AMZ_STAGE(st_p3, 8, c) break;
+    case 1: AMZ_STAGE(st_p3, 7, c) break;
     case 2:
-        st_p16(lds, a, 2 * t - 34, c);
-        st_out(lds, a, 2 * t - 38, c);
-        st_out(lds, a, 2 * t - 37, c);
+        AMZ_STAGE(st_p16, 34, c)
+        AMZ_STAGE(st_out, 38, c)
+        AMZ_STAGE(st_out, 37, c)
         break;
     case 3:
-        st_p1(lds, a, 2 * t - 2, c);
-        st_p1(lds, a, 2 * t - 1, c);
-        st_p11(lds, a, 2 * t - 20, c);
+        AMZ_STAGE(st_p1, 2, c)
+        AMZ_STAGE(st_p1, 1, c)
+        AMZ_STAGE(st_p11, 20, c)
         break;
     default: break;
     }
 }
+// wave 15
+AMZ_DEV void p8_step_a(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T, int lane, P8Regs &pr, int *bb)
+{
+    bb_tile_change(lds, q, T, 22, 4, bb);
+    const int G = 2 * T - 22;
+    const TileArgs a = stage_tile(frame, q, G);
+    p8_wave_a(lds, a, T, G - a.gbase, lane, pr);
+}
+AMZ_DEV void p8_step_b(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T, int lane, P8Regs &pr, int *bb)
+{
+    const int G = 2 * T - 22;
+    const TileArgs a = stage_tile(frame, q, G);
+    p8_wave_b(lds, a, T, G - a.gbase, lane, pr, bb);
+}
+// the last stage (output, offset 38) has just left tile q.back: is the tile valid?  (called by one thread, between barriers)
+AMZ_DEV bool tile_done(const TileSeq &q, int T) { return 2 * T - LAST_OFF == q.front.gbase && q.front.gbase > 0 && q.back.rr1 > 0; }
+AMZ_DEV void tile_ref_set(TileRef &t, int k, int tile, int top, int left, int rr1)
+{
+    t.gbase = TS * k; t.tile = tile; t.top = top; t.left = left; t.rr1 = rr1; t.redo = 0;
+    t.r0 = 8; t.r1 = rr1 - 8; t.c0 = 8; t.c1 = TS - 8;
+}
+AMZ_DEV void tile_ref_none(TileRef &t, int k) { tile_ref_set(t, k, -1, 0, 0, 0); }
+constexpr int STEPS_PER_TILE = TS / 2;
+constexpr int TAIL_STEPS = LAST_OFF / 2 + 1;   // after the last tile's rows were loaded: the deepest stage and the last validity check
 
 } // namespace amz

@@ -46,6 +46,7 @@ struct artgpu_ctx {
     float *amz_lists = nullptr;
     size_t amz_lists_bytes = 0;
     int amz_w = 0, amz_h = 0, amz_nstream = 0, amz_narena = 0, amz_mode = -1;
+    int num_cus = 0;
     // options (artgpu_set_option): test / profiling switches that used to be environment variables
     int opt_amaze_path = 0;        // 0: LDS streaming kernel for full tiles + arena kernel for the rest; 1: arena kernel for every tile
     int opt_amaze_split = 0;       // 1 (with path 1): one launch per phase
@@ -350,11 +351,11 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
         const int nty = (H + 16 + AMAZE_STEP - 1) / AMAZE_STEP, ntx = (W + 16 + AMAZE_STEP - 1) / AMAZE_STEP;
         const int ntiles = nty * ntx;
         // Tile classes (amaze_demosaic_RT.cc:182-334).  Tiles that write no pixel (the clipped tile is at most 32 wide / high) are
-        // skipped.  Full 160x160 tiles go to the LDS streaming kernel (amaze_stream.hip) unless their mirrored bottom / right border
-        // fill over-runs the tile row or the cfa plane in the reference (it always writes 16 rows / columns from the frame edge: exact
-        // only when the tile ends 16 pixels past the frame); everything else -- partial tiles, those over-run tiles and streamed tiles
-        // whose Nyquist sites do not fit the stream's assumption -- is done by the arena kernel (amaze.hip), which reproduces the
-        // reference's buffer layout literally.
+        // skipped.  Tiles that are 160 columns wide go to the LDS streaming kernel (amaze_stream.hip) unless their mirrored bottom /
+        // right border fill over-runs the tile row or the cfa plane in the reference (it always writes 16 rows / columns from the
+        // frame edge: exact only when a full-size tile ends 16 pixels past the frame); everything else -- narrower tiles, those
+        // over-run tiles and streamed tiles whose Nyquist sites do not fit the stream's assumption -- is done by the arena kernel
+        // (amaze.hip), which reproduces the reference's buffer layout literally.
         const int mode = ctx->opt_amaze_path;
         if (ctx->amz_w != W || ctx->amz_h != H || ctx->amz_mode != mode) {
             std::vector<int> st, ar;
@@ -363,11 +364,15 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
                     const int top = -16 + ty * AMAZE_STEP, left = -16 + tx * AMAZE_STEP;
                     const int rr1 = std::min(top + AMAZE_TS, H + 16) - top, cc1 = std::min(left + AMAZE_TS, W + 16) - left;
                     if (rr1 <= 32 || cc1 <= 32) continue;
-                    const bool full = rr1 == AMAZE_TS && cc1 == AMAZE_TS;
-                    const bool exact_fill = (top + AMAZE_TS <= H || top + AMAZE_TS == H + 16) && (left + AMAZE_TS <= W || left + AMAZE_TS == W + 16);
-                    (mode == 0 && full && exact_fill ? st : ar).push_back(ty * ntx + tx);
+                    // streamable: 160 columns wide (any height), and the 16 mirrored rows / columns the reference appends at the
+                    // bottom / right frame edge end exactly at the tile's edge
+                    const bool wide = cc1 == AMAZE_TS && (left + AMAZE_TS <= W || left + AMAZE_TS == W + 16);
+                    const bool rows_ok = rr1 < AMAZE_TS || top + AMAZE_TS <= H || top + AMAZE_TS == H + 16;
+                    (mode == 0 && wide && rows_ok ? st : ar).push_back(ty * ntx + tx);
                 }
-            const size_t nints = st.size() + (1 + ar.size()) + (1 + ar.size() + st.size()) + 8;
+            // ... + the redo queue: 4 header ints (reserved, taken, pad) and one 64-bit word per streamed tile, 16-byte aligned
+            const size_t nfixed = ((st.size() + (1 + ar.size()) + (1 + ar.size() + st.size()) + 3) / 4) * 4;
+            const size_t nints = nfixed + 4 + 2 * st.size() + 8;
             if ((rc = ensure(ctx, &ctx->amz_lists, &ctx->amz_lists_bytes, nints * sizeof(int)))) return rc;
             std::vector<int> hostbuf;
             hostbuf.insert(hostbuf.end(), st.begin(), st.end());
@@ -381,7 +386,11 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
         int *const d_stream = reinterpret_cast<int *>(ctx->amz_lists);
         int *const d_templ = d_stream + ctx->amz_nstream;
         int *const d_work = d_templ + 1 + ctx->amz_narena;
+        const size_t nfixed = (((size_t)ctx->amz_nstream + (1 + ctx->amz_narena) + (1 + ctx->amz_narena + ctx->amz_nstream) + 3) / 4) * 4;
+        int *const d_queue = d_stream + nfixed;                                          // header (4 ints), then the 64-bit entries
+        unsigned long long *const d_qwords = reinterpret_cast<unsigned long long *>(d_queue + 4);
         HIPCHK(ctx, hipMemcpyAsync(d_work, d_templ, (size_t)(1 + ctx->amz_narena) * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_queue, 0, (4 + 2 * (size_t)ctx->amz_nstream) * sizeof(int), ctx->stream));
         const float clip_pt = (float)(1.0 / initial_gain);   // amaze_demosaic_RT.cc:53-54
         const float clip_pt8 = (float)(0.8 / initial_gain);
         if (ctx->amz_nstream > 0) {
@@ -396,7 +405,15 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
             sa.ey = f00 == 1 ? (f01 == 0 ? 0 : 1) : (f00 == 0 ? 0 : 1);        // row of the red sites (L1381-1386: ey)
             sa.tiles = d_stream; sa.ntiles = ctx->amz_nstream;
             sa.fallback = d_work;
-            HIPCHK(ctx, launch_amaze_stream(sa, ctx->amz_nstream, ctx->stream));
+            sa.queue_hdr = d_queue; sa.queue_words = d_qwords;
+            // persistent workgroups, one per CU (the kernel needs almost all of a CU's LDS): each streams its share of the tiles
+            // back to back
+            if (ctx->num_cus <= 0) {
+                hipDeviceProp_t prop;
+                HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+                ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            }
+            HIPCHK(ctx, launch_amaze_stream(sa, std::min(ctx->amz_nstream, ctx->num_cus), ctx->stream));
         }
         // arena kernel over the listed tiles (the static ones plus whatever the stream handed back; the count is read on the device)
         const int nlist_max = ctx->amz_narena + ctx->amz_nstream;
@@ -434,6 +451,8 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
         } else {
             a.tile_list = d_work + 1; a.tile_count = d_work;
         }
+        a.queue_hdr = (!split && ctx->amz_nstream > 0) ? d_queue : nullptr;
+        a.queue_words = d_qwords;
         if (ctx->opt_amaze_poison >= 0)   // test hook: fill the arenas with a byte pattern first
             HIPCHK(ctx, hipMemsetAsync(ctx->arena, ctx->opt_amaze_poison, (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float), ctx->stream));
         HIPCHK(ctx, launch_amaze(a, split ? ntiles : grid, ctx->stream));

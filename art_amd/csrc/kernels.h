@@ -32,6 +32,8 @@ struct AmazeArgs {
     int zero_frame;     // > 0: regions 4-8 of full tiles are cleared only in a frame of this many rows / columns
     const int *tile_list;   // device: the tiles this launch processes (nullptr: tiles 0..ntiles-1)
     const int *tile_count;  // device: how many entries of tile_list are valid (read when the kernel starts)
+    const int *queue_hdr;   // device (optional): redo-queue entries [hdr[1], hdr[0]) nobody streamed again are processed as well
+    const unsigned long long *queue_words;
     int split;              // 1: one launch per phase over all tiles (profiling mode; needs one arena per tile)
 };
 hipError_t launch_amaze(const AmazeArgs &a, int grid, hipStream_t stream);
@@ -49,6 +51,12 @@ struct AmazeStreamArgs {
     const int *tiles;   // device: tile indices to stream
     int ntiles;
     int *fallback;      // device: [0] = count, [1..] = tiles the arena kernel has to (re)do
+    // Redo queue: a streamed tile whose Nyquist sites did not all lie inside its bounding box (known only at the end of the tile)
+    // is streamed a second time with the true box, by whichever workgroup runs out of tiles first.  hdr[0] = entries reserved,
+    // hdr[1] = entries taken; words[k] = one 64-bit entry (0: not published yet), published / abandoned by compare-and-swap so that
+    // every entry is either streamed again or lands in `fallback`.
+    int *queue_hdr;
+    unsigned long long *queue_words;
 };
 hipError_t launch_amaze_stream(const AmazeStreamArgs &s, int grid, hipStream_t stream);
 

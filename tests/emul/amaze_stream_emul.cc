@@ -15,7 +15,7 @@ using namespace amz;
 static void wave_p9(float *lds, const TileArgs &a, int r)
 {
     for (int rr = r; rr < r + 2; ++rr) {
-        if (rr < 8 || rr >= TS - 8) continue;
+        if (rr < 8 || rr >= a.rr1 - 8) continue;
         float h[72];
         for (int j = 0; j < 72; ++j) h[j] = p9_new_weight(lds, a, rr, j);
         for (int j = 0; j < 72; ++j) p9_site(lds, a, rr, j, h[j]);
@@ -24,23 +24,23 @@ static void wave_p9(float *lds, const TileArgs &a, int r)
 static void wave_p13(float *lds, const TileArgs &a, int r)
 {
     for (int rr = r; rr < r + 2; ++rr) {
-        if (rr < 10 || rr >= TS - 10) continue;
+        if (rr < 10 || rr >= a.rr1 - 10) continue;
         float h[72];
         for (int j = 0; j < 72; ++j) h[j] = p13_new_weight(lds, a, rr, j);
         for (int j = 0; j < 72; ++j) p13_site(lds, a, rr, j, h[j]);
     }
 }
-static void wave_list(float *lds, const TileArgs &a, int t)
+static void wave_list(float *lds, const TileArgs &a, int T, int r)
 {
-    const int r = 2 * t - 20, buf = (t + 1) & 1;
+    const int buf = (T + 1) & 1;
     int *red = (int *)(lds + RED_OFF), *list = (int *)(lds + LIST_OFF + buf * LIST_INTS);
     int n = 0;
-    if (r + 1 >= 8 && r < TS - 8)
+    if (r + 1 >= 8 && r < a.rr1 - 8)
         for (int c = 0; c < TS; ++c) {
             int rr;
             if (nyq_site(lds, a, r, c, &rr)) list[n++] = (rr << 8) | c;
         }
-    red[8 + buf] = n;
+    red[16 + buf] = n;
 }
 
 static float g_shadow[R_COUNT][TS][TS];
@@ -71,59 +71,83 @@ static void shadow_update(const float *lds)
 extern "C" {
 const float *amaze_stream_emul_shadow(int ring) { return &g_shadow[ring][0][0]; }
 
-// info[0] = 1 if the tile is valid for the stream (else the arena kernel has to redo it), info[1] = ring tag errors,
-// info[2..4] = first tag error (ring, wanted row, row found)
-int amaze_stream_emul_tile(const float *raw, long rs, int W, int H, unsigned filters, float clip_pt, float clip_pt8,
-                           int top, int left, float *red, float *green, float *blue, long os, int order, long long *info)
+// Streams the tiles (tops[k], lefts[k]), k < ntiles, as ONE workgroup's sequence.  redo_box: nullptr, or four ints per tile -- a tile
+// whose box is not all zero... see redo[]: redo[k] != 0 streams tile k with the given TRUE Nyquist box (second attempt).
+// valid[k] = 1 if every Nyquist site tile k processed lies inside its true box, box_out[4k..] = that box;
+// info[1] = ring tag errors, info[2..4] = first tag error (ring, wanted row, row found)
+int amaze_stream_emul_seq(const float *raw, long rs, int W, int H, unsigned filters, float clip_pt, float clip_pt8,
+                          int ntiles, const int *tops, const int *lefts, const int *redo, const int *redo_box,
+                          float *red, float *green, float *blue, long os, int order, int *valid, int *box_out, long long *info)
 {
-    TileArgs a;
-    a.raw = raw; a.rs = rs; a.red = red; a.green = green; a.blue = blue; a.os = os;
-    a.top = top; a.left = left; a.W = W; a.H = H; a.filters = filters; a.clip_pt = clip_pt; a.clip_pt8 = clip_pt8;
-    a.g00 = (int)(fc(filters, 0, 0) & 1);
-    if (fc(filters, 0, 0) == 1) a.ey = fc(filters, 0, 1) == 0 ? 0 : 1;
-    else a.ey = fc(filters, 0, 0) == 0 ? 0 : 1;
+    TileArgs frame;
+    frame.raw = raw; frame.rs = rs; frame.red = red; frame.green = green; frame.blue = blue; frame.os = os;
+    frame.top = 0; frame.left = 0; frame.rr1 = 0; frame.gbase = 0;
+    frame.ny_r0 = frame.ny_r1 = frame.ny_c0 = frame.ny_c1 = 0;
+    frame.W = W; frame.H = H; frame.filters = filters; frame.clip_pt = clip_pt; frame.clip_pt8 = clip_pt8;
+    frame.g00 = (int)(fc(filters, 0, 0) & 1);
+    if (fc(filters, 0, 0) == 1) frame.ey = fc(filters, 0, 1) == 0 ? 0 : 1;
+    else frame.ey = fc(filters, 0, 0) == 0 ? 0 : 1;
     std::vector<float> ldsv(LDS_FLOATS);
     float *lds = ldsv.data();
     for (int i = 0; i < LDS_FLOATS; ++i) lds[i] = NAN;
     memset(&g_tags, 0, sizeof g_tags);
-    for (int k = 0; k < R_COUNT; ++k) for (int s = 0; s < 64; ++s) g_tags.row[k][s] = -1000;
+    for (int k = 0; k < R_COUNT; ++k) for (int sl = 0; sl < 64; ++sl) g_tags.row[k][sl] = -1000;
     std::vector<ThreadRegs> regs(NTHREADS);
     std::vector<P8Regs> p8(64);
-    for (auto &q : p8) { q.cc = -1; bb_reset(q.bb); }
-    for (auto &q : regs) bb_reset(q.bb);
+    for (auto &x : p8) x.cc = -1;
+    for (auto &x : regs) bb_reset(x.bb);
     std::vector<int> ord(NTHREADS);
     for (int i = 0; i < NTHREADS; ++i) ord[i] = order == 1 ? NTHREADS - 1 - i : i;
     if (order >= 2) {
-        unsigned s = 12345u + (unsigned)order;
-        for (int i = NTHREADS - 1; i > 0; --i) { s = s * 1664525u + 1013904223u; int j = (int)((s >> 8) % (unsigned)(i + 1)); int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
+        unsigned sd = 12345u + (unsigned)order;
+        for (int i = NTHREADS - 1; i > 0; --i) { sd = sd * 1664525u + 1013904223u; int j = (int)((sd >> 8) % (unsigned)(i + 1)); int t = ord[i]; ord[i] = ord[j]; ord[j] = t; }
     }
-    tile_begin(lds, 0);
-    for (int tid = 192; tid < 192 + 192; ++tid) st_load_first(a, tid - 192, regs[tid]);
-    for (int t = 0; t < NSTEPS; ++t) {
+    auto tile_ref = [&](int k) {
+        TileRef t;
+        if (k < ntiles) {
+            tile_ref_set(t, k, k, tops[k], lefts[k], (tops[k] + TS < H + 16 ? tops[k] + TS : H + 16) - tops[k]);
+            if (redo && redo[k]) { t.redo = 1; t.r0 = redo_box[4 * k]; t.r1 = redo_box[4 * k + 1]; t.c0 = redo_box[4 * k + 2]; t.c1 = redo_box[4 * k + 3]; }
+        } else {
+            tile_ref_none(t, k);
+        }
+        return t;
+    };
+    TileSeq q;
+    tile_ref_none(q.back, -1);
+    q.front = tile_ref(0);
+    q.next = tile_ref(1);
+    seq_begin(lds, 0);
+    for (int tid = 192; tid < 192 + 192; ++tid) st_load_first(frame, q, tid - 192, regs[tid]);
+    const int nsteps = STEPS_PER_TILE * ntiles + TAIL_STEPS;
+    for (int T = 0; T < nsteps; ++T) {
+        if (T > 0 && T % STEPS_PER_TILE == 0) { q.back = q.front; q.front = q.next; q.next = tile_ref(T / STEPS_PER_TILE + 1); }
+        if (tile_done(q, T)) {
+            const int kb = q.back.gbase / TS, par = kb & 1;
+            valid[kb] = tile_valid(lds, par, q.back.rr1, box_out + 4 * kb) ? 1 : 0;
+            red_reset(lds, par);
+        }
         for (int i = 0; i < NTHREADS; ++i) {
-            if (ord[i] < 960) substep_a(lds, a, t, ord[i] / 192, ord[i] % 192, regs[ord[i]]);
-            else p8_wave_a(lds, t, ord[i] - 960, p8[ord[i] - 960]);
+            if (ord[i] < 960) substep_a(lds, frame, q, T, ord[i] / 192, ord[i] % 192, regs[ord[i]]);
+            else p8_step_a(lds, frame, q, T, ord[i] - 960, p8[ord[i] - 960], regs[ord[i]].bb);
         }
         // ---- barrier ----
+        const TileArgs a9 = stage_tile(frame, q, 2 * T - 26), a7 = stage_tile(frame, q, 2 * T - 14), al = stage_tile(frame, q, 2 * T - 20);
         if (order & 1) {
-            wave_list(lds, a, t);
-            for (int l = 63; l >= 0; --l) p8_wave_b(lds, t, l, p8[l]);
-            wave_p13(lds, a, 2 * t - 26); wave_p9(lds, a, 2 * t - 26);
-            for (int i = 0; i < 192; ++i) st_p7(lds, a, 2 * t - 14, i);
+            wave_list(lds, al, T, 2 * T - 20 - al.gbase);
+            for (int l = 63; l >= 0; --l) p8_step_b(lds, frame, q, T, l, p8[l], regs[960 + l].bb);
+            wave_p13(lds, a9, 2 * T - 26 - a9.gbase); wave_p9(lds, a9, 2 * T - 26 - a9.gbase);
+            for (int i = 0; i < 192; ++i) st_p7(lds, a7, 2 * T - 14 - a7.gbase, i);
         }
-        for (int i = 0; i < NTHREADS; ++i) if (ord[i] < 768) substep_b_threads(lds, a, t, ord[i] / 192, ord[i] % 192);
+        for (int i = 0; i < NTHREADS; ++i) if (ord[i] < 768) substep_b_threads(lds, frame, q, T, ord[i] / 192, ord[i] % 192);
         if (!(order & 1)) {
-            for (int i = 0; i < 192; ++i) st_p7(lds, a, 2 * t - 14, i);
-            wave_p9(lds, a, 2 * t - 26); wave_p13(lds, a, 2 * t - 26);
-            for (int l = 0; l < 64; ++l) p8_wave_b(lds, t, l, p8[l]);
-            wave_list(lds, a, t);
+            for (int i = 0; i < 192; ++i) st_p7(lds, a7, 2 * T - 14 - a7.gbase, i);
+            wave_p9(lds, a9, 2 * T - 26 - a9.gbase); wave_p13(lds, a9, 2 * T - 26 - a9.gbase);
+            for (int l = 0; l < 64; ++l) p8_step_b(lds, frame, q, T, l, p8[l], regs[960 + l].bb);
+            wave_list(lds, al, T, 2 * T - 20 - al.gbase);
         }
         // ---- barrier ----
-        shadow_update(lds);
+        if (ntiles == 1) shadow_update(lds);
     }
-    for (int tid = 192; tid < 384; ++tid) bb_flush(lds, 0, regs[tid].bb);
-    for (int l = 0; l < 64; ++l) bb_flush(lds, 4, p8[l].bb);
-    info[0] = tile_valid(lds) ? 1 : 0;
     info[1] = g_tags.errors; info[2] = g_tags.first_ring; info[3] = g_tags.first_want; info[4] = g_tags.first_have;
     return 0;
 }
