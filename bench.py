@@ -28,6 +28,47 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_PX = 16         # 4 B CFA in + 12 B RGB out
 
 
+def dry_main(args, rank, world, dist, torch, synth) -> None:
+    """The rank-side control flow of a real run -- frame `rank` of the batch, warm-up, barrier, K timed steps, barrier, completion
+    all-gather with MAX of the elapsed time, one JSON line from rank 0 -- with gloo and without a device (no kernel is called)."""
+    dev = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from art_amd import batch
+    W, H = args.width, args.height
+    raw = synth.bayer_frame(W, H, synth.FILTERS_RGGB, seed=rank)
+    mine = batch.frames_for_rank(world, rank, world)            # one frame per rank per step
+    assert mine == [rank]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def step():
+        return int(raw[H // 2, W // 2])                          # stands in for the device work on this rank's frame
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    probe = 0
+    for _ in range(args.steps):
+        probe = step()
+    barrier()
+    t1 = time.perf_counter()
+    records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, args.steps, 0, batch.checksum64([probe]), t1 - t0)
+    if rank == 0:
+        print(json.dumps({"metric": "megapixels/sec end-to-end (AMaZE+FTblockDN+tone), 45 MP Bayer", "dry": True,
+                          "value": round(world * args.lanes * args.steps * W * H / 1e6 / max(elapsed, 1e-9), 2), "unit": "MP/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak", "data": "synthetic",
+                          "config": {"workload": "dry run (no device work)", "frames_per_step": world * args.lanes,
+                                     "parallelism": f"frame-per-gpu x{world}", "completion_records": len(records),
+                                     "records": records}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -47,21 +88,44 @@ def main() -> None:
     ap.add_argument("--tone", default="std", choices=["std", "neutral"],
                     help="tone-curve mode of the last stage: STD (3 LUT lookups per pixel; the headline line) or NEUTRAL, ART's default mode "
                          "(Jzazbz hue-preserving curve, curves.cc:854-1038)")
+    ap.add_argument("--dry", action="store_true",
+                    help="run the rank / sharding / completion code path without a GPU: gloo instead of RCCL, every device call replaced by a "
+                         "no-op (tests/test_multiproc.py drives `bench.py --gpus 2 --dry` on the CPU); the printed line carries \"dry\": true "
+                         "and is not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the same command the driver
+    # uses: torch.distributed.run on 127.0.0.1) and hand over to them.  Under a launcher WORLD_SIZE is set and we are one rank.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    from art_amd import capi, synth
+    from art_amd import synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry:
+        dry_main(args, rank, world, dist, torch, synth)
+        return
+    from art_amd import capi
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -178,8 +242,10 @@ def main() -> None:
         step()
     barrier()
     # per-launch duration of the dominant kernel, HIP events on the launch stream.  For AMaZE with border >= 4 the demosaic call launches
-    # exactly one kernel (no border_interpolate2), so the stage events recorded around the call bracket that kernel and are read after the
-    # timed region; the other demosaicers use the library's own event pair, which the host has to wait for once per step.
+    # amaze_stream_kernel plus ~20 us of bookkeeping (a 2-KB memset / copy of the tile lists and the arena kernel over the tiles the
+    # stream could not take: none at this frame size), no border_interpolate2 -- so the stage events recorded around the call bracket
+    # that kernel (+0.5 %) and are read after the timed region; the other demosaicers use the library's own event pair, which the host
+    # has to wait for once per step.
     lib_timing = xtrans or method != capi.BAYER_AMAZE or border < 4
     if lib_timing:
         ctx.enable_timing(True)
@@ -216,12 +282,16 @@ def main() -> None:
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the figure is the mean per
     # launch of the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command, committed under
     # profiles/ (KB units; uncorrected -- the kernel's accesses are 4 B per lane, see profiles/r1/README.md)
-    traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r1", "amaze_final_pmc_summary.json")
+    traffic, traffic_src, traffic_raw = None, None, None
+    pmc_rel = os.path.join("profiles", "r2", "amaze_v2_pmc_summary.json")
+    pmc_path = os.path.join(ROOT, pmc_rel)
     if method == capi.BAYER_AMAZE and not xtrans and (W, H) == (W45, H45) and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
-        traffic = int((pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024)
-        traffic_src = "profiles/r1/amaze_final_pmc_summary.json"
+        # FETCH_SIZE on gfx950 reports half the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM section): doubled here.
+        # (Sanity check: the raw figure, 156 MB, is less than the 179 MB CFA plane that has to be read at least once.)
+        traffic_raw = {"FETCH_SIZE_KB": pmc["FETCH_SIZE"]["mean_per_launch"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"]["mean_per_launch"]}
+        traffic = int((2 * pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024)
+        traffic_src = pmc_rel + " (rocprofv3 --pmc passes of `bench.py --workload amaze`, kernel amaze_stream_kernel; FETCH_SIZE doubled)"
 
     # measured device-copy bandwidth in the same run (the practical HBM ceiling next to the 8 TB/s datasheet peak):
     # a 716 MB device-to-device copy, read + write bytes over its HIP-event time
@@ -268,14 +338,34 @@ def main() -> None:
             "completion_records": len(records),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "xtrans_tiles_kernel" if xtrans else "amaze_kernel<0, 19, 1, 6>" if method == capi.BAYER_AMAZE else "rcd_tiles_kernel",
+            "bound": "hbm", "kernel": "xtrans_tiles_kernel" if xtrans else "amaze_stream_kernel" if method == capi.BAYER_AMAZE else "rcd_tiles_kernel",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "traffic_raw_counters": traffic_raw,
+            # the whole step against the same contract (MP/s x 16 B / 8 TB/s), next to the dominant kernel's fraction
+            "end_to_end_frac": round(value * 1e6 * ALGO_BYTES_PER_PX / 1e9 / HBM_PEAK_GBS / max(world, 1), 5),
             "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": W * H * ALGO_BYTES_PER_PX,
             "device_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
             "traffic_rate_frac_of_copy": None if (copy_gbs is None or traffic is None) else round(traffic / 1e9 / (kern_ms / 1e3) / copy_gbs, 4),
         },
     }
+
+    # ART's default tone-curve mode is NEUTRAL (curves.cc:854-1038), the headline line uses STD: report the NEUTRAL step beside it
+    if pipeline and world == 1 and args.tone == "std" and args.lanes == 1:
+        def step_neutral():
+            ctx.demosaic_xtrans(3, True, p_raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, out) if xtrans else ctx.demosaic_bayer(method, p_raw, filt, 1.0, border, out)
+            ctx.get_image(out, border, border, mul, True, mat, img)
+            ctx.improc_denoise(img, dn, ws, ecomp=expcomp, calclum_mat=mat, noise_c_curve=ccurve)
+            ctx.exposure(img, exp_scale, 0.0)
+            ctx.tone_curve_neutral(img, lut, 1.0, ws, iws_n)
+        step_neutral()
+        barrier()
+        n0 = time.perf_counter()
+        nn = max(1, min(args.steps, 5))
+        for _ in range(nn):
+            step_neutral()
+        barrier()
+        n_ms = 1e3 * (time.perf_counter() - n0) / nn
+        result["neutral_tone"] = {"ms_per_step": round(n_ms, 4), "value": round(mp / (n_ms / 1e3), 2), "unit": "MP/s", "steps": nn}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_lib
@@ -308,6 +398,10 @@ def main() -> None:
         result["cpu_baseline"] = {
             "value": round(cw * ch / 1e6 / statistics.median(ts), 2), "unit": "MP/s", "cores": ncores, "kind": "port",
             "sample": f"{args.cpu_repeats} x {cw}x{ch} region of the frame through the same stages of the CPU oracle (oracle/*.c, OpenMP), median",
+            "note": "a port written for checking, not for speed: its detail-recovery DCT is the direct O(n^2) double-precision form (the "
+                    "reference calls FFTW) and the histogram medians are serial, so it is several times slower than the reference itself "
+                    "(SURVEY probe: the reference's AMaZE alone runs 38.9 MP/s on 8 vCPU).  The GPU/CPU ratio is not a quality measure; "
+                    "roofline.frac and roofline.end_to_end_frac are.",
         }
     if rank == 0:
         print(json.dumps(result), flush=True)

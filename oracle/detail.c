@@ -45,8 +45,36 @@ float oracle_detail_factor(float d)
     return t * t;
 }
 
+/* test hook: 0 = double accumulation (the checker's default: the mathematically exact DCT rounded once per 1-D pass);
+   1 = plain fp32 direct form (float products and float running sums in index order): what a straightforward single-precision
+   implementation gives -- the yardstick tests/test_gpu_denoise.py measures the device's fp32 fast DCT against */
+int oracle_detail_dct_f32 = 0;
+
+static void dct2d_f32(float *blk, const double *costab, int inverse)
+{
+    float tmp[DTS * DTS];
+    for (int pass = 0; pass < 2; ++pass) {
+        const float *src = pass == 0 ? blk : tmp;
+        float *dst = pass == 0 ? tmp : blk;
+        for (int r = 0; r < DTS; ++r)
+            for (int k = 0; k < DTS; ++k) {
+                float acc;
+                if (!inverse) {
+                    acc = 0.f;
+                    for (int j = 0; j < DTS; ++j) acc += (pass == 0 ? src[r * DTS + j] : src[j * DTS + r]) * (float)costab[k * DTS + j];
+                    acc *= 2.f;
+                } else {
+                    acc = pass == 0 ? src[r * DTS] : src[r];
+                    for (int j = 1; j < DTS; ++j) acc += 2.f * (pass == 0 ? src[r * DTS + j] : src[j * DTS + r]) * (float)costab[j * DTS + k];
+                }
+                if (pass == 0) dst[r * DTS + k] = acc; else dst[k * DTS + r] = acc;
+            }
+    }
+}
+
 static void dct2d(float *blk, const double *costab, int inverse)
 {
+    if (oracle_detail_dct_f32) { dct2d_f32(blk, costab, inverse); return; }
     /* costab[k*64+j] = cos(pi*(j+0.5)*k/64).  Rows then columns; float storage between passes. */
     float tmp[DTS * DTS];
     for (int pass = 0; pass < 2; ++pass) {

@@ -184,9 +184,13 @@ def rgb_denoise(img, params=None, wpi=REC2020_WS, noisevarchrom=None, want_L=Fal
     Lin = np.zeros((h, w), np.float32) if want_L else None
     Lden = np.zeros((h, w), np.float32) if want_L else None
     resid = np.zeros(2, np.float32)
+    # detail_recovery="f32": the DCT of the detail-recovery stage in plain fp32 direct form instead of double accumulation
+    C.c_int.in_dll(lib(), "oracle_detail_dct_f32").value = 1 if detail_recovery == "f32" else 0
+    detail_recovery = bool(detail_recovery)
     rc = lib().oracle_rgb_denoise_ex(_p3(img), C.c_size_t(w), w, h, C.byref(params), _ptr(wp), nvc,
                                      _ptr(Lin) if want_L else None, _ptr(Lden) if want_L else None, int(detail_recovery),
                                      _ptr(resid) if want_resid else None)
+    C.c_int.in_dll(lib(), "oracle_detail_dct_f32").value = 0
     assert rc == 0
     if want_resid:
         return img, float(resid[0]), float(resid[1])

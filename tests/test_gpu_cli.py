@@ -31,7 +31,7 @@ def read_ppm16(path):
     return data
 
 
-def oracle_pipeline(raw, filt, method, border, denoise=None, smoothing=None, expcomp=0.0):
+def oracle_pipeline(raw, filt, method, border, denoise=None, smoothing=None, expcomp=0.0, dct=True):
     planes = O.rcd(raw, filt) if method == "rcd" else O.amaze(raw, filt, 1.0, border)
     h, w = raw.shape
     img = O.get_image(planes, border, border, w - 2 * border, h - 2 * border, MUL, True)
@@ -40,7 +40,7 @@ def oracle_pipeline(raw, filt, method, border, denoise=None, smoothing=None, exp
         curve, _ = O.noise_curve()
         img = O.improc_denoise(img, dict(luminance=denoise[0], chrominance=denoise[1]), calclum_mat=MAT, noise_c_curve=curve,
                                smoothing=smoothing is not None, radius=(smoothing or (3, 0, 0))[0], nl_strength=(smoothing or (3, 0, 0))[1],
-                               nl_detail=(smoothing or (3, 0, 80))[2], ecomp=expcomp, detail_recovery=True)
+                               nl_detail=(smoothing or (3, 0, 80))[2], ecomp=expcomp, detail_recovery=dct)
     img = O.exposure(img, float(np.float32(2.0 ** expcomp)), 0.0)
     img = O.tone_std(img, tone_lut(), 1.0, True)
     return img
@@ -86,8 +86,18 @@ def test_config4_stages_through_cli(tmp_path):
     ref = oracle_pipeline(raw, filt, "amaze", 4, denoise=(40.0, 15.0), smoothing=(3, 50, 80), expcomp=0.3)
     q = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.int32) for p in ref], axis=-1)
     err = np.abs(ppm.astype(np.int32) - q)
-    # DCT round-off (tolerance-checked stage) -> NL-means weights -> S-curve slope; on the 16-bit output scale
-    assert err.max() <= 512 and np.percentile(err, 99.9) <= 64 and np.median(err) <= 1, (err.max(), np.percentile(err, 99.9))
+    # The DCT stage's round-off (<= 0.0625 on this scale, tests/test_gpu_denoise.py) passes through NL-means, whose weights are
+    # exp(-distance) table look-ups of patch distances: a rounding-level change of L flips table indices, and the differences are no
+    # longer rounding-sized.  That is a property of the pipeline, not of the device: the checker itself, run with a plain fp32
+    # direct-form DCT instead of the double-accumulated one, moves the 16-bit output by the same amount -- that run is the yardstick
+    # here.  (Everything but the DCT stage is compared bit for bit at full size in tests/test_gpu_fullsize.py.)
+    ref32 = oracle_pipeline(raw, filt, "amaze", 4, denoise=(40.0, 15.0), smoothing=(3, 50, 80), expcomp=0.3, dct="f32")
+    q32 = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.int32) for p in ref32], axis=-1)
+    err32 = np.abs(q32 - q)
+    print(f"config-4 CLI, 16-bit output vs the double-DCT checker: device max {err.max()} p99.9 {np.percentile(err, 99.9):.0f} differing {100.0 * (err > 0).mean():.1f} % | "
+          f"checker with fp32 direct-form DCT max {err32.max()} p99.9 {np.percentile(err32, 99.9):.0f} differing {100.0 * (err32 > 0).mean():.1f} %")
+    assert np.median(err) <= 1
+    assert np.percentile(err, 99.9) <= 2 * np.percentile(err32, 99.9) + 2 and err.max() <= 2 * err32.max() + 8, (err.max(), err32.max())
 
 
 def test_neutral_tone_mode_through_cli(tmp_path):

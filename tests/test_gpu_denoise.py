@@ -66,21 +66,43 @@ def test_unsupported_modes_fail_loudly(gpu_ctx):
         gpu_ctx.rgb_denoise(capi.host_rgb(img), _params(chrominance_method=2), O.REC2020_WS)   # not MANUAL / AUTOMATIC
 
 
+# detail_recovery (FTblockDN.cc:1479-1635) is the one stage of the path that cannot be compared bit for bit: the reference calls
+# FFTW's single-precision REDFT10 / REDFT01 plans (planner-dependent round-off, library not part of the reference tree).  The checker
+# evaluates FFTW's documented transform definitions with double accumulation; the device uses an fp32 Lee fast DCT.  What can be
+# asserted: (i) the device is as close to the exact transform as a plain fp32 direct-form evaluation is (its error distribution is
+# measured against that yardstick in the same test), (ii) an absolute bound on the final R, G, B, stated in DESIGN.md section 3.
+# Measured on MI355X (this test prints the figures): max |device - exact| = 0.031 on the 0..65535 output scale (16 ulp of a mid-scale
+# value; the fp32 direct form has the same maximum), 99.9th percentile 0.012, median 0 (most values come out bit-identical).
+DCT_ABS_BOUND = 0.0625      # 2 x the measured maximum; the same number is in DESIGN.md section 3 and tests/test_gpu_fullsize.py
+DCT_MEDIAN_BOUND = 0.002
+
+
+def _ulp(x):
+    """ulp of the value's binade, floored at the ulp of 256 (a relative figure is meaningless for the few near-zero outputs)"""
+    return np.spacing(np.maximum(np.abs(x), 256.0).astype(np.float32)).astype(np.float64)
+
+
 @pytest.mark.parametrize("w,h,detail", [(640, 480, 50.0), (517, 389, 80.0), (330, 260, 0.0)])
 def test_rgb_denoise_with_detail_recovery_tolerance(gpu_ctx, w, h, detail):
-    """detail_recovery goes through a third-party DCT in the reference (FFTW, not reproducible);
-    the device evaluates the same DCT-II/III definitions in fp32, the oracle with double
-    accumulation: agreement to <= 2e-5 of full scale and identical everywhere the stage is exact."""
     from art_amd import capi
     img = _rgb(w, h, w + 1)
     got = [p.copy() for p in img]
     gpu_ctx.rgb_denoise(capi.host_rgb(got), _params(luminance_detail=detail), O.REC2020_WS, flags=0)
     ref = O.rgb_denoise(img, O.default_denoise_params(luminanceDetail=detail), detail_recovery=True)
+    f32 = O.rgb_denoise(img, O.default_denoise_params(luminanceDetail=detail), detail_recovery="f32")
     nodetail = O.rgb_denoise(img, O.default_denoise_params(luminanceDetail=detail), detail_recovery=False)
-    for g, r, nd in zip(got, ref, nodetail):
+    for g, r, d32, nd in zip(got, ref, f32, nodetail):
         err = np.abs(g.astype(np.float64) - r.astype(np.float64))
-        assert err.max() <= 65535.0 * 2e-5, err.max()
-        assert np.median(err) <= 0.02
+        err32 = np.abs(d32.astype(np.float64) - r.astype(np.float64))
+        u = _ulp(r)
+        print(f"detail {detail} {w}x{h}: device max {err.max():.4f} ({(err / u).max():.0f} ulp) median {np.median(err):.5f} ({np.median(err / u):.2f} ulp) p99.9 "
+              f"{np.percentile(err, 99.9):.4f} | fp32 direct form max {err32.max():.4f} ({(err32 / u).max():.0f} ulp) median {np.median(err32):.5f} "
+              f"({np.median(err32 / u):.2f} ulp) p99.9 {np.percentile(err32, 99.9):.4f}")
+        assert err.max() <= DCT_ABS_BOUND, err.max()
+        assert np.median(err) <= DCT_MEDIAN_BOUND
+        # no worse than a straightforward fp32 evaluation of the same transforms (the 1.5 covers the different error pattern)
+        assert np.percentile(err, 99.9) <= 1.5 * np.percentile(err32, 99.9) + 1e-3
+        assert np.median(err) <= 1.5 * np.median(err32) + 1e-4
         # the stage really ran: result is far from the no-detail-recovery image
         assert np.abs(r - nd).max() > 50.0
 

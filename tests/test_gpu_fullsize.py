@@ -45,6 +45,52 @@ def test_config2_and_3_stages_45mp_bit_exact(gpu_ctx):
     o = O.tone_std(o, lut, 1.0, True)
     for t, r in zip(d_img, o):
         assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))
+    del d_img, o
+
+    # ... and the stage the benchmark times but the check above skips: ImProcFunctions::denoise WITH the DCT detail recovery at full
+    # size, against the checker's double-accumulated DCT, under the bound of tests/test_gpu_denoise.py
+    from test_gpu_denoise import DCT_ABS_BOUND, DCT_MEDIAN_BOUND
+    d_img, img = _dev_planes(H - 8, W - 8)
+    gpu_ctx.get_image(out, 4, 4, MUL, True, MAT, img)
+    gpu_ctx.improc_denoise(img, tp, O.REC2020_WS_D, ecomp=0.3, calclum_mat=MAT, noise_c_curve=curve)
+    gpu_ctx.synchronize()
+    o = O.get_image(ref, 4, 4, W - 8, H - 8, MUL, True)
+    o = O.convert_color_space(o, MAT)
+    o = O.improc_denoise(o, calclum_mat=MAT, noise_c_curve=curve, smoothing=False, ecomp=0.3, detail_recovery=True)
+    for t, r in zip(d_img, o):
+        err = np.abs(t.cpu().numpy().astype(np.float64) - r.astype(np.float64))
+        print(f"45 MP denoise incl. detail recovery: max |device - exact| {err.max():.4f}, p99.9 {np.percentile(err[::7, ::5], 99.9):.4f}, "
+              f"bit-identical {100.0 * (err == 0).mean():.1f} %")
+        assert err.max() <= DCT_ABS_BOUND and np.median(err[::7, ::5]) <= DCT_MEDIAN_BOUND
+
+
+def test_config4_stages_45mp_bit_exact_without_dct(gpu_ctx):
+    """BASELINE configs[3]'s per-frame pipe at full size -- AMaZE, getImage + matrix, ImProcFunctions::denoise with guided chroma smoothing
+    and NL-means, exposure, tone curve -- with the DCT detail-recovery stage switched off on both sides: everything else is bit for bit."""
+    W, H = 8192, 5464
+    raw = synth.bayer_frame(W, H, synth.FILTERS_RGGB, seed=1)
+    d_raw = torch.from_numpy(raw).cuda()
+    d_out, out = _dev_planes(H, W)
+    gpu_ctx.demosaic_bayer(capi.BAYER_AMAZE, capi.device_plane(d_raw), synth.FILTERS_RGGB, 1.0, 4, out)
+    d_img, img = _dev_planes(H - 8, W - 8)
+    gpu_ctx.get_image(out, 4, 4, MUL, True, MAT, img)
+    curve, _ = capi.noise_curve_lut()
+    tp = capi.DenoiseToolParams(capi.DenoiseParams(40.0, 50.0, 0, 15.0, 0.0, 0.0, 1.7, 0, 0, 0), 1, 3, 50, 80)
+    gpu_ctx.improc_denoise(img, tp, O.REC2020_WS_D, ecomp=0.3, calclum_mat=MAT, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    gpu_ctx.exposure(img, float(np.float32(2.0 ** 0.3)), 0.0)
+    x = np.arange(65536, dtype=np.float64) / 65535.0
+    lut = ((1.0 - np.cos(np.pi * x ** 0.7)) / 2.0 * 65535.0).astype(np.float32)
+    gpu_ctx.tone_curve(img, lut, 1.0, True)
+    gpu_ctx.synchronize()
+    ref = O.amaze(raw, synth.FILTERS_RGGB, 1.0, 4)
+    o = O.get_image(ref, 4, 4, W - 8, H - 8, MUL, True)
+    o = O.convert_color_space(o, MAT)
+    o = O.improc_denoise(o, calclum_mat=MAT, noise_c_curve=curve, smoothing=True, radius=3, nl_strength=50, nl_detail=80, ecomp=0.3,
+                         detail_recovery=False)
+    o = O.exposure(o, float(np.float32(2.0 ** 0.3)), 0.0)
+    o = O.tone_std(o, lut, 1.0, True)
+    for t, r in zip(d_img, o):
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))
 
 
 def test_config5_xtrans_100mp_bit_exact(gpu_ctx):

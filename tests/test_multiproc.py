@@ -61,3 +61,24 @@ def test_two_rank_completion_gather():
     assert res[0][2] == res[1][2]
     exp0 = batch.checksum64([w for f in (0, 2, 4) for w in (f, f * 2654435761 + 12345)])
     assert res[0][2][0]["checksum"] == exp0
+
+
+def test_bench_py_two_rank_path_dry():
+    """`python bench.py --gpus 2` has to start its own two ranks (no launcher, no WORLD_SIZE) and print ONE line with n_gpus 2 and two
+    completion records; --dry swaps RCCL for gloo and the device work for a no-op, everything else is bench.py's own N>1 code path."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry", "--steps", "3", "--warmup", "1",
+                        "--width", "256", "--height", "192"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry"] is True and d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["config"]["completion_records"] == 2 and d["config"]["frames_per_step"] == 2
+    recs = d["config"]["records"]
+    assert [x["rank"] for x in recs] == [0, 1] and all(x["frames"] == 3 and x["status"] == 0 for x in recs)
+    assert recs[0]["checksum"] != recs[1]["checksum"]        # rank r works on frame r of the batch (different seeds)
