@@ -53,6 +53,8 @@ struct artgpu_ctx {
     long opt_amaze_zero_mask = 0x81f0;
     int opt_amaze_zero_frame = 16;
     int opt_amaze_poison = -1;     // >= 0: byte pattern the arenas are filled with before the launch
+    int curve_tail_kind = ARTGPU_CURVE_TAIL_HOST;   // artgpu_set_curve_tail
+    double curve_tail_y = 1.0;
     float *lut = nullptr; // 65536-entry tone LUT on the device
     size_t lut_bytes = 0;
     // timing
@@ -283,6 +285,15 @@ int artgpu_synchronize(artgpu_ctx *ctx)
     if (!ctx) return ARTGPU_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
+int artgpu_set_curve_tail(artgpu_ctx *ctx, int kind, double y_last)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (kind < ARTGPU_CURVE_TAIL_LUT || kind > ARTGPU_CURVE_TAIL_HOST) return fail(ctx, ARTGPU_EINVAL, "set_curve_tail: kind %d", kind);
+    ctx->curve_tail_kind = kind;
+    ctx->curve_tail_y = y_last;
     return ARTGPU_OK;
 }
 
@@ -601,7 +612,9 @@ int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float 
     if (!ctx) return ARTGPU_EINVAL;
     if (!image) return fail(ctx, ARTGPU_EINVAL, "tone_curve: null image");
     if (mode != ARTGPU_TONE_STD) return fail(ctx, ARTGPU_EUNSUPPORTED, "tone_curve: curve mode %d is not on the device path", mode);
-    if (!(whitept > 0.f) || whitept > 1.f) return fail(ctx, ARTGPU_EUNSUPPORTED, "tone_curve: whitept %g needs the analytic curve beyond the LUT", (double)whitept);
+    if (!(whitept > 0.f)) return fail(ctx, ARTGPU_EINVAL, "tone_curve: whitept %g", (double)whitept);
+    if (whitept > 1.f && ctx->curve_tail_kind == ARTGPU_CURVE_TAIL_HOST)
+        return fail(ctx, ARTGPU_EUNSUPPORTED, "tone_curve: whitept %g needs the curve beyond the LUT (artgpu_set_curve_tail)", (double)whitept);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     DevRGB d;
     int rc = bind_rgb(ctx, image, 4, true, &d, "tone_curve");
@@ -610,6 +623,7 @@ int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float 
     for (int k = 0; k < 3; ++k) a.dst[k] = d.p[k];
     a.dst_stride = d.stride; a.w = d.w; a.h = d.h;
     a.do_clip = filmlike_clip ? 1 : 0; a.whitept = whitept;
+    a.tail_kind = ctx->curve_tail_kind == ARTGPU_CURVE_TAIL_HOST ? 0 : ctx->curve_tail_kind; a.tail_y = ctx->curve_tail_y;
     if (lut65536) {
         rc = ensure(ctx, &ctx->lut, &ctx->lut_bytes, 65536 * sizeof(float));
         if (rc) return rc;
@@ -1528,7 +1542,18 @@ int pool_to_plane(artgpu_ctx *ctx, const float *src, artgpu_plane *pl)
 
 int gaussian_dev(artgpu_ctx *ctx, float *img, float *tmp, int W, int H, double sigma)
 {
-    if (!(sigma >= 0.6) || W < 8 || H < 8) return fail(ctx, ARTGPU_EUNSUPPORTED, "gaussian_blur: sigma %g / size %dx%d not on the device path", sigma, W, H);
+    // gaussianBlur's dispatch for src == dst (gauss.cc:1436-1523; the box-blur approximation above it is only taken for
+    // sigma > 2 of the frame width, far off this path)
+    if (!(sigma == sigma) || W < 8 || H < 8) return fail(ctx, ARTGPU_EUNSUPPORTED, "gaussian_blur: sigma %g / size %dx%d not on the device path", sigma, W, H);
+    if (sigma < 0.25) return ARTGPU_OK;                 // GAUSS_SKIP: no filtering
+    if (sigma < 0.6) {                                  // GAUSS_3X3_LIMIT: separated 3-tap kernel, coefficients in double, passed as float
+        double c1 = exp(-1.0 / (2.0 * sigma * sigma));
+        const double csum = 2.0 * c1 + 1.0;
+        c1 /= csum;
+        const double c0 = 1.0 / csum;
+        HIPCHK(ctx, launch_gaussian3(img, tmp, W, H, (float)c0, (float)c1, ctx->stream));
+        return ARTGPU_OK;
+    }
     GaussArgs g = {};
     g.img = img; g.tmp = tmp; g.W = W; g.H = H;
     if (sigma >= 25.0) {                    // GAUSS_DOUBLE (gauss.cc:1393,1520-1523): all-double recursion
@@ -1746,6 +1771,7 @@ int artgpu_tone_curve_neutral(artgpu_ctx *ctx, artgpu_rgb *image, const float *l
     a.lut = ctx->lut; a.pq = pq; a.pq_inv = pq + 65536; a.hues = pq + 2 * 65536;
     for (int k = 0; k < 9; ++k) { a.ws[k] = (float)st->ws[k]; a.iws[k] = (float)st->iws[k]; a.to_out[k] = st->to_out[k]; a.to_work[k] = st->to_work[k]; }
     a.whitecoeff = whitecoeff;
+    a.tail_kind = ctx->curve_tail_kind == ARTGPU_CURVE_TAIL_HOST ? 0 : ctx->curve_tail_kind; a.tail_y = ctx->curve_tail_y;
     if (fresh) HIPCHK(ctx, launch_neutral_hues(a, ctx->stream));
     HIPCHK(ctx, launch_tone_neutral(a, ctx->stream));
     return unbind_rgb(ctx, image, &d);

@@ -42,6 +42,13 @@ __device__ __forceinline__ float xdivf(float d, int n)
     if (i & 0x7FFFFFFF) i -= n << 23;
     return __int_as_float(i);
 }
+// curves::setLutVal above the LUT (curves.h:228-230): curve->getVal(val / 65535.f) * 65535.f with getVal = the last point's y
+// (kind 1: DCT_Linear / DCT_Spline / DCT_CatmullRom) or t (kind 2: DCT_Empty, DCT_NURBS beyond its hash), diagonalcurves.cc:443-561
+__device__ __forceinline__ float curve_tail(int kind, double y_last, float val)
+{
+    const double t = (double)(val / 65535.f);
+    return (float)((kind == 1 ? y_last : t) * (double)65535.f);
+}
 __device__ __forceinline__ int ngroups(int start, int bound, int step)
 {
     return bound > start ? (bound - start + step - 1) / step : 0;

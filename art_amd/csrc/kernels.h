@@ -128,6 +128,8 @@ struct PixArgs {
     float exp_scale, black;
     const float *lut;      // tone: 65536-entry LUT on the device (nullable)
     float whitept;
+    int tail_kind;         // curves::setLutVal above 65535 (artgpu_set_curve_tail): 0 LUT clip, 1 constant, 2 identity
+    double tail_y;
 };
 hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s);
 hipError_t launch_exposure(const PixArgs &a, hipStream_t s);
@@ -257,6 +259,8 @@ struct NeutralArgs {
     float *hues;                 // [4] rhue, bhue, yhue, ohue (device; written by launch_neutral_hues)
     float ws[9], iws[9], to_out[9], to_work[9];
     float whitecoeff;
+    int tail_kind;               // as in PixArgs
+    double tail_y;
 };
 hipError_t launch_neutral_hues(const NeutralArgs &a, hipStream_t s);
 hipError_t launch_tone_neutral(const NeutralArgs &a, hipStream_t s);
@@ -412,6 +416,7 @@ struct NlmArgs {
 };
 hipError_t launch_detail_mask(const MaskArgs &a, hipStream_t s);
 hipError_t launch_gaussian(const GaussArgs &a, hipStream_t s);
+hipError_t launch_gaussian3(float *img, float *tmp, int W, int H, float c0, float c1, hipStream_t s);   // 0.25 <= sigma < 0.6, in place
 hipError_t launch_nlm(const NlmArgs &a, hipStream_t s);
 bool nlm_sweep_supported(const NlmArgs &a);
 hipError_t launch_nlm_sweep(const NlmArgs &a, hipStream_t s);   // nlm_sweep.hip (flush-to-zero TU)

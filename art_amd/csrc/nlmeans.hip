@@ -347,6 +347,30 @@ hipError_t launch_detail_mask(const MaskArgs &a, hipStream_t s)
     hipLaunchKernelGGL(dm_up_scurve_kernel, dim3(fgrid((long long)a.W * a.H)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
+// gaussianBlur with 0.25 <= sigma < 0.6 and src == dst (gauss.cc:1474-1483): separated 3-tap filter, gaussHorizontal3 (L446-465) into
+// a line buffer, then gaussVertical3 (L467-526; its 8-column vector loop and its scalar tail evaluate the same expression up to the
+// order of one commutative addition); the first / last column (row) of each pass is copied.
+__global__ void gauss3_h_kernel(const float *img, float *tmp, int W, int H, float c0, float c1)
+{
+    FOR_IMAGE_XY(y, x, W, H) {
+        const float *r = img + (size_t)y * W;
+        tmp[(size_t)y * W + x] = (x == 0 || x == W - 1) ? r[x] : c1 * (r[x - 1] + r[x + 1]) + c0 * r[x];
+    }
+}
+__global__ void gauss3_v_kernel(const float *tmp, float *img, int W, int H, float c0, float c1)
+{
+    FOR_IMAGE_XY(y, x, W, H) {
+        const size_t i = (size_t)y * W + x;
+        img[i] = (y == 0 || y == H - 1) ? tmp[i] : c1 * (tmp[i + W] + tmp[i - W]) + tmp[i] * c0;
+    }
+}
+hipError_t launch_gaussian3(float *img, float *tmp, int W, int H, float c0, float c1, hipStream_t s)
+{
+    hipLaunchKernelGGL(gauss3_h_kernel, image_grid(W, H), dim3(256), 0, s, img, tmp, W, H, c0, c1);
+    hipLaunchKernelGGL(gauss3_v_kernel, image_grid(W, H), dim3(256), 0, s, tmp, img, W, H, c0, c1);
+    return hipGetLastError();
+}
+
 hipError_t launch_gaussian(const GaussArgs &a, hipStream_t s)
 {
     if (a.tmp64) {

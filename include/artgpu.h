@@ -153,6 +153,22 @@ int artgpu_exposure(artgpu_ctx *ctx, artgpu_rgb *image, float exp_scale, float b
 int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float *lut65536,
                       float whitept, int filmlike_clip);
 
+/* curves::setLutVal (rtengine/curves.h:224-231): a value above 65535 does not go through the LUT but through the Curve object,
+ * curve->getVal(val / 65535.f) * 65535.f.  The LUT is all that crosses this boundary, so the adapter states what its Curve returns
+ * above 1.0 (rtengine/diagonalcurves.cc:443-561); the setting applies to the following artgpu_tone_curve / artgpu_tone_curve_neutral
+ * calls of the context:
+ *   ARTGPU_CURVE_TAIL_LUT       no Curve object (ToneCurve::curve == nullptr): the LUT's last entry
+ *   ARTGPU_CURVE_TAIL_CONSTANT  DCT_Linear / DCT_Spline / DCT_CatmullRom: the last point's y (`y_last`, L476-477, L514-515)
+ *   ARTGPU_CURVE_TAIL_IDENTITY  DCT_Empty, DCT_NURBS beyond its hash table: t itself (L529-535, L557-560)
+ *   ARTGPU_CURVE_TAIL_HOST      (default) anything else, e.g. DCT_Parametric: not evaluated on the device -- artgpu_tone_curve then
+ *                               returns ARTGPU_EUNSUPPORTED for whitept > 1; values above 65535 that reach the curve because
+ *                               filmlike_clip is off take the LUT's last entry (set the tail if the image can hold such values). */
+#define ARTGPU_CURVE_TAIL_LUT 0
+#define ARTGPU_CURVE_TAIL_CONSTANT 1
+#define ARTGPU_CURVE_TAIL_IDENTITY 2
+#define ARTGPU_CURVE_TAIL_HOST 3
+int artgpu_set_curve_tail(artgpu_ctx *ctx, int kind, double y_last);
+
 /* rtengine::wavelet_decomposition with subsampling == 1 and the 6-tap Daub4 filters, the only
  * configuration the denoise path uses (rtengine/cplx_wavelet_dec.h:97-270; constructed at
  * rtengine/FTblockDN.cc:2296,2328,2365).  The object owns its coefficients in HBM.

@@ -127,6 +127,29 @@ static void yvv_line_64(float *p, size_t st, int n, double *tmp, double B, doubl
 
 void oracle_gaussian_blur(float *img, int W, int H, double sigma_d)
 {
+    if (sigma_d < 0.25) return;             /* GAUSS_SKIP (gauss.cc:1389,1437-1443): src == dst, nothing to do */
+    if (sigma_d < 0.6) {                    /* GAUSS_3X3_LIMIT, src == dst: gaussHorizontal3 + gaussVertical3 (gauss.cc:1474-1483,446-526) */
+        double c1d = exp(-1.0 / (2.0 * sigma_d * sigma_d));
+        const double csum = 2.0 * c1d + 1.0;
+        c1d /= csum;
+        const float c0 = (float)(1.0 / csum), c1 = (float)c1d;
+        float *temp = (float *)malloc(sizeof(float) * (size_t)(W > H ? W : H));
+        for (int i = 0; i < H; ++i) {
+            float *r = img + (size_t)i * W;
+            for (int j = 1; j < W - 1; ++j) temp[j] = c1 * (r[j - 1] + r[j + 1]) + c0 * r[j];
+            for (int j = 1; j < W - 1; ++j) r[j] = temp[j];
+        }
+        const int wv = W - (W % 8);
+        for (int i = 0; i < W; ++i) {
+            for (int j = 1; j < H - 1; ++j) {
+                const float up = img[(size_t)(j - 1) * W + i], dn = img[(size_t)(j + 1) * W + i], c = img[(size_t)j * W + i];
+                temp[j] = i < wv ? c1 * (dn + up) + c * c0 : c1 * (up + dn) + c0 * c;   /* vector loop (L479-505) / scalar tail (L508-525) */
+            }
+            for (int j = 1; j < H - 1; ++j) img[(size_t)j * W + i] = temp[j];
+        }
+        free(temp);
+        return;
+    }
     if (sigma_d >= 25.0) {
         double b1, b2, b3, B, M[9];
         oracle_yvv_factors_raw(sigma_d, &b1, &b2, &b3, &B, M);

@@ -69,6 +69,9 @@ void oracle_lab2rgb(float l, float a, float b, float *R, float *G, float *B, con
 void oracle_chroma_noise_map(const float *const img[3], size_t s, int w, int h, const double *mat, const float wpi[9],
                              const float curve[501], float *out);
 void oracle_tone_curve_std(float *const img[3], size_t s, int w, int h, const float *lut65536);
+extern int oracle_curve_tail_kind;      /* test hook, see pixelops.c */
+extern double oracle_curve_tail_y;
+float oracle_set_lut_val(const float *lut65536, float val);
 void oracle_scale_colors(const void *src, int src_u16, int w, int h, const int cfa36[36], int bayer, const float cblacksom[4],
                          const float scale_mul[4], float *dst, float chmax[4]);
 void oracle_channel_mixer(float *const img[3], size_t s, int w, int h, const float m[9]);

@@ -108,6 +108,19 @@ float oracle_lutf(const float *data, int size, float index)
     return p1 + p2 * diff;
 }
 
+/* curves::setLutVal (curves.h:224-231): val <= 65535 or no Curve object -> lut[max(val, 0)]; above, curve->getVal(val / 65535.f) *
+   65535.f.  What getVal returns above 1.0 depends on the curve kind (diagonalcurves.cc:443-561): the last point's y for DCT_Linear /
+   DCT_Spline / DCT_CatmullRom (L476-477, L514-515), t itself for DCT_Empty and DCT_NURBS beyond its hash table (L529-535, L557-560);
+   DCT_Parametric continues analytically (not restated).  oracle_curve_tail_kind: 0 no Curve object, 1 constant, 2 identity. */
+int oracle_curve_tail_kind = 0;
+double oracle_curve_tail_y = 1.0;
+float oracle_set_lut_val(const float *lut65536, float val)
+{
+    if (val <= 65535.f || oracle_curve_tail_kind == 0) return oracle_lutf(lut65536, 65536, std_maxf(val, 0.f));
+    const double t = (double)(val / 65535.f);
+    return (float)((oracle_curve_tail_kind == 1 ? oracle_curve_tail_y : t) * (double)65535.f);
+}
+
 void oracle_tone_curve_std(float *const img[3], size_t s, int w, int h, const float *lut65536)
 {
 #pragma omp parallel for
@@ -115,8 +128,7 @@ void oracle_tone_curve_std(float *const img[3], size_t s, int w, int h, const fl
         for (int c = 0; c < 3; ++c) {
             float *p = img[c] + (size_t)y * s;
             for (int x = 0; x < w; ++x) {
-                /* setLutVal: val <= 65535 (always true after filmlike_clip with whitept <= 1) */
-                p[x] = oracle_lutf(lut65536, 65536, std_maxf(p[x], 0.f));
+                p[x] = oracle_set_lut_val(lut65536, p[x]);
             }
         }
 }

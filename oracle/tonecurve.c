@@ -215,9 +215,7 @@ void oracle_tone_curve_neutral(float *const img[3], size_t s, int w, int h, cons
             }
             for (int j = 0; j < 3; ++j) {
                 float nt = rgb[j] * 65535.f;
-                /* setLutVal: val <= 65535 -> lut[max(val, 0)]; above, the reference evaluates the Curve object on the
-                 * host -- the LUT's clip-above value is used instead (documented deviation) */
-                nt = oracle_lutf(lut, 65536, std_maxf(nt, 0.f));
+                nt = oracle_set_lut_val(lut, nt);      /* curves::setLutVal (curves.h:224-231) */
                 rgb[j] = nt / 65535.f;
             }
             rgb2jzczhz(&c, rgb[0], rgb[1], rgb[2], &jch[0], &jch[1], &jch[2], st->ws);

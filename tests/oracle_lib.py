@@ -103,6 +103,12 @@ def exposure(img, exp_scale, black):
     return img
 
 
+def set_curve_tail(kind=0, y_last=1.0):
+    """What the tone curve's Curve object returns above 1.0 (curves::setLutVal): 0 no Curve object (LUT clip), 1 constant y_last, 2 identity."""
+    C.c_int.in_dll(lib(), "oracle_curve_tail_kind").value = int(kind)
+    C.c_double.in_dll(lib(), "oracle_curve_tail_y").value = float(y_last)
+
+
 def tone_std(img, lut, whitept=1.0, filmlike_clip=True):
     img = [np.array(p, dtype=np.float32, order="C") for p in img]
     h, w = img[0].shape

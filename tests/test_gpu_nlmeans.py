@@ -17,7 +17,8 @@ def _Y(w, h, seed):
     return O.amaze(raw, synth.FILTERS_RGGB, 1.0, 4)[1]
 
 
-@pytest.mark.parametrize("w,h,sigma", [(320, 240, 2.0), (323, 241, 2.0), (326, 243, 1.0), (200, 150, 0.8), (257, 129, 7.5), (323, 241, 25.0), (200, 151, 40.0)])
+@pytest.mark.parametrize("w,h,sigma", [(320, 240, 2.0), (323, 241, 2.0), (326, 243, 1.0), (200, 150, 0.8), (257, 129, 7.5), (323, 241, 25.0), (200, 151, 40.0),
+                                         (323, 241, 0.1), (323, 241, 0.25), (326, 243, 0.4), (200, 151, 0.59)])   # GAUSS_SKIP / the 3-tap branch
 def test_gaussian_blur(gpu_ctx, w, h, sigma):
     from art_amd import capi
     img = _Y(w, h, w)

@@ -59,11 +59,39 @@ def test_convert_exposure_tone(gpu_ctx):
     assert _same(img, ref) == [0, 0, 0]
 
 
+@pytest.mark.parametrize("kind,y_last", [(0, 1.0), (1, 0.93), (2, 1.0)])
+@pytest.mark.parametrize("w,h", [(333, 201), (2304, 1800)])          # plain kernel / the kernel with the curve in LDS
+def test_tone_std_above_the_lut(gpu_ctx, kind, y_last, w, h):
+    """curves::setLutVal for values above 65535 (whitePoint > 1): what the Curve object returns there -- nothing (no Curve: LUT clip),
+    the last point's y (Linear / Spline / CatmullRom) or t (Empty / NURBS) -- reaches the device through artgpu_set_curve_tail."""
+    from art_amd import capi
+    import oracle_lib as O
+    rng = np.random.default_rng(kind + w)
+    img = [rng.uniform(-500, 110000, (h, w)).astype(np.float32) for _ in range(3)]
+    img[0][0, :6] = [65535.0, 65535.004, 65536.0, 98302.5, 98303.0, 3e6]
+    x = np.arange(65536, dtype=np.float64) / 65535.0
+    lut = ((1.0 - np.cos(np.pi * x ** 0.7)) / 2.0 * 0.93 * 65535.0).astype(np.float32)
+    for clip in (True, False):
+        O.set_curve_tail(kind, y_last)
+        try:
+            ref = O.tone_std(img, lut, 1.5, clip)
+        finally:
+            O.set_curve_tail(0)
+        got = [p.copy() for p in img]
+        gpu_ctx.set_curve_tail(kind, y_last)
+        try:
+            gpu_ctx.tone_curve(capi.host_rgb(got), lut, 1.5, clip)
+        finally:
+            gpu_ctx.set_curve_tail(3)
+        assert _same(got, ref) == [0, 0, 0]
+        assert (np.array(ref) > 65535.0).any() == (kind == 2)        # only the identity tail leaves values above the LUT range
+
+
 def test_tone_unsupported(gpu_ctx):
     from art_amd import capi
     img = _img(64, 64, 3)
     with pytest.raises(capi.ArtGpuError):
-        gpu_ctx.tone_curve(capi.host_rgb(img), None, 1.5, True)      # whitept > 1
+        gpu_ctx.tone_curve(capi.host_rgb(img), None, 1.5, True)      # whitept > 1 and a Curve the device cannot evaluate (default)
     with pytest.raises(capi.ArtGpuError):
         gpu_ctx.tone_curve(capi.host_rgb(img), None, 1.0, True, mode=6)  # NEUTRAL: not built yet
 

@@ -70,3 +70,28 @@ def test_neutral_large_frame_lds_pq_table_bit_exact(gpu_ctx, monkeypatch):
     for g, p, r in zip(got, plain, ref):
         assert np.array_equal(g.view(np.uint32), p.view(np.uint32))
         assert np.array_equal(g[~oor].view(np.uint32), r[~oor].view(np.uint32))
+
+
+@pytest.mark.parametrize("kind,y_last", [(1, 0.95), (2, 1.0)])      # (0.95: not the LUT's last entry, so the constant tail is visible)
+def test_neutral_tone_curve_above_the_lut(gpu_ctx, kind, y_last):
+    """NeutralToneCurve::BatchApply applies the curve through curves::setLutVal too (curves.cc:1003): with whitecoeff > 1 the values
+    above 65535 take the Curve object's value (artgpu_set_curve_tail) instead of the LUT's last entry."""
+    w, h = 389, 150
+    img = frame(w, h, 33, 65535.0 * 1.4)
+    lut = (s_curve() * np.float32(0.9)).astype(np.float32)
+    O.set_curve_tail(kind, y_last)
+    try:
+        ref, oor = O.tone_neutral(img, lut, 1.5, want_oor=True)
+    finally:
+        O.set_curve_tail(0)
+    base = O.tone_neutral(img, lut, 1.5)                         # LUT clip: must differ somewhere, or the tail was never reached
+    got = [p.copy() for p in img]
+    gpu_ctx.set_curve_tail(kind, y_last)
+    try:
+        gpu_ctx.tone_curve_neutral(capi.host_rgb(got), lut, 1.5, O.REC2020_WS_D, O.REC2020_IWS_D)
+    finally:
+        gpu_ctx.set_curve_tail(3)
+    assert any((b != r).any() for b, r in zip(base, ref))
+    for g, r in zip(got, ref):
+        assert np.array_equal(g[~oor].view(np.uint32), r[~oor].view(np.uint32))
+        assert np.allclose(g[oor], r[oor], rtol=2e-4, atol=0.5)
