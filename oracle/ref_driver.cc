@@ -1,7 +1,7 @@
 // oracle/ref_driver.cc -- thin extern "C" shim over the parts of the REFERENCE that compile in
 // this image from the sources where they lie (no stand-in headers): the sleef scalar and SSE
 // math (rtengine/sleef.h, sleefsseavx.h, helpersse2.h), LUTf (rtengine/LUT.h, with -DNDEBUG),
-// median.h, rt_math.h.  Built by oracle/Makefile.ref into oracle/_ref/libartref.so (git-ignored)
+// median.h, rt_math.h, rescale.h (+ array2D.h), iccmatrices.h.  Built by oracle/Makefile.ref into oracle/_ref/libartref.so (git-ignored)
 // and used ONLY by tests to pin the oracle's restatement of these primitives.
 // Everything that needs rtengine.h / rawimagesource.h / StopWatch.h (-> glibmm, lcms2) is
 // unbuildable here: amaze_demosaic_RT.cc, rcd_demosaic.cc, demosaic_algos.cc, boxblur.h,
@@ -12,6 +12,8 @@
 #include "median.h"
 #include "rt_math.h"
 #include "cplx_wavelet_dec.h"
+#include "rescale.h"
+#include "iccmatrices.h"
 
 extern "C" {
 
@@ -25,6 +27,20 @@ float *ref_wavelet_band(void *p, int l, int dir) { return static_cast<rtengine::
 float *ref_wavelet_coeff0(void *p) { return static_cast<rtengine::wavelet_decomposition *>(p)->coeff0; }
 void ref_wavelet_reconstruct(void *p, float *dst, float blend) { static_cast<rtengine::wavelet_decomposition *>(p)->reconstruct(dst, blend); }
 void ref_wavelet_delete(void *p) { delete static_cast<rtengine::wavelet_decomposition *>(p); }
+
+// ---- rescaleBilinear / getBilinearValue (rescale.h:27-74), used by guidedFilter and detail_mask ----
+void ref_rescale_bilinear(const float *src, int Ws, int Hs, float *dst, int Wd, int Hd)
+{
+    rtengine::array2D<float> s(Ws, Hs), d(Wd, Hd);
+    for (int y = 0; y < Hs; ++y) for (int x = 0; x < Ws; ++x) s[y][x] = src[(size_t)y * Ws + x];
+    rtengine::rescaleBilinear(s, d, false);
+    for (int y = 0; y < Hd; ++y) for (int x = 0; x < Wd; ++x) dst[(size_t)y * Wd + x] = d[y][x];
+}
+// ---- the Rec2020 working-space matrices (iccmatrices.h:151-161) ----
+void ref_rec2020_matrices(float *xyz_rec2020_9, float *rec2020_xyz_9)
+{
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { xyz_rec2020_9[3 * i + j] = rtengine::xyz_rec2020[i][j]; rec2020_xyz_9[3 * i + j] = rtengine::rec2020_xyz[i][j]; }
+}
 
 void ref_xexpf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xexpf(x[i]); }
 void ref_xcbrtf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xcbrtf(x[i]); }

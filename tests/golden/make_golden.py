@@ -167,7 +167,26 @@ def wavelet():
     np.savez_compressed(os.path.join(HERE, "wavelet.npz"), **out)
 
 
+def rescale_and_matrices():
+    """rescaleBilinear (rescale.h:53-74; guidedFilter's sub-sampling and detail_mask's quarter-resolution plane go through it) for
+    down- and up-scaling with non-integer ratios, and the Rec2020 working-space matrices (iccmatrices.h:151-161)."""
+    rng = np.random.default_rng(77)
+    out = {}
+    for k, (ws, hs, wd, hd) in enumerate(((97, 61, 33, 21), (33, 21, 97, 61), (128, 96, 32, 24), (50, 37, 149, 111), (40, 40, 40, 40))):
+        src = (rng.uniform(0.0, 65535.0, (hs, ws)) * rng.uniform(0.2, 1.0, (hs, ws))).astype(np.float32)
+        dst = np.empty((hd, wd), np.float32)
+        R.ref_rescale_bilinear(P(src), ws, hs, P(dst), wd, hd)
+        out[f"src{k}"] = src
+        out[f"dst{k}"] = dst
+    a, b = np.empty(9, np.float32), np.empty(9, np.float32)
+    R.ref_rec2020_matrices(P(a), P(b))
+    out["xyz_rec2020"] = a.reshape(3, 3)
+    out["rec2020_xyz"] = b.reshape(3, 3)
+    np.savez_compressed(os.path.join(HERE, "rescale.npz"), **out)
+
+
 if __name__ == "__main__":
+    rescale_and_matrices()
     wavelet()
     helpers()
     lutf()

@@ -99,3 +99,30 @@ def test_wavelet_matches_reference_decomposition():
         else:
             sha = np.frombuffer(hashlib.sha256(bands.tobytes() + c0.tobytes() + rec.tobytes()).digest(), dtype=np.uint8)
             assert np.array_equal(sha, g[key + "_sha"])
+
+
+def test_rescale_bilinear_matches_reference_rescale_h():
+    """oracle_rescale_bilinear against the reference's own rescaleBilinear (rescale.h:53-74, compiled in place into oracle/_ref)."""
+    g = np.load(os.path.join(G, "rescale.npz"))
+    L = O.lib()
+    k = 0
+    while f"src{k}" in g:
+        src, ref = np.ascontiguousarray(g[f"src{k}"]), g[f"dst{k}"]
+        dst = np.empty_like(ref)
+        L.oracle_rescale_bilinear(P(src), src.shape[1], src.shape[0], P(dst), ref.shape[1], ref.shape[0])
+        assert same_bits(dst, ref), k
+        k += 1
+    assert k == 5
+
+
+def test_working_space_matrices_are_the_reference_constants():
+    """The Rec2020 matrices the tests and bench.py feed to both sides are typed by hand; they have to be iccmatrices.h:151-161."""
+    g = np.load(os.path.join(G, "rescale.npz"))
+    assert np.array_equal(O.REC2020_WS.astype(np.float32), g["xyz_rec2020"])
+    assert np.array_equal(O.REC2020_WS_D.astype(np.float32), g["xyz_rec2020"])
+    assert np.array_equal(O.REC2020_IWS_D.astype(np.float32), g["rec2020_xyz"])
+    import re
+    src = open(os.path.join(os.path.dirname(G), "..", "bench.py")).read()
+    for m, name in ((g["xyz_rec2020"], "ws"), (g["rec2020_xyz"], "iws_n")):
+        txt = re.search(name + r" = np\.array\((\[\[.*?\]\])\)", src, re.S).group(1)
+        assert np.array_equal(np.array(eval(txt), dtype=np.float32), m), name
