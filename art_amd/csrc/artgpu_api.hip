@@ -241,7 +241,11 @@ int artgpu_create(int hip_device, artgpu_ctx **out)
     ctx->device = hip_device;
     if (hipSetDevice(hip_device) != hipSuccess) { delete ctx; return ARTGPU_EHIP; }
     for (int k = 0; k < 3; ++k)
-        if (hipEventCreate(&ctx->ev[k]) != hipSuccess) { delete ctx; return ARTGPU_EHIP; }
+        if (hipEventCreate(&ctx->ev[k]) != hipSuccess) {
+            for (int j = 0; j < k; ++j) (void)hipEventDestroy(ctx->ev[j]);     // the events created so far
+            delete ctx;
+            return ARTGPU_EHIP;
+        }
     *out = ctx;
     return ARTGPU_OK;
 }
@@ -701,7 +705,13 @@ int artgpu_wavelet_decompose(artgpu_ctx *ctx, const artgpu_plane *src, int maxlv
             return fail(ctx, ARTGPU_EHIP, "wavelet_decompose: launch failed: %s", hipGetErrorString(le));
         }
     }
-    if (!src->on_device) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!src->on_device) {
+        const hipError_t se = hipStreamSynchronize(ctx->stream);
+        if (se != hipSuccess) {
+            artgpu_wavelet_free(ctx, wv);
+            return fail(ctx, ARTGPU_EHIP, "wavelet_decompose: %s", hipGetErrorString(se));
+        }
+    }
     *out = wv;
     return ARTGPU_OK;
 }
@@ -2183,8 +2193,7 @@ int artgpu_rgb_curves(artgpu_ctx *ctx, artgpu_rgb *image, const float *rcurve, c
     HIPCHK(ctx, launch_rgb_curves(a, ctx->stream));
     rc = unbind_rgb(ctx, image, &d);
     if (rc) return rc;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // the caller's LUTs must outlive the copies
-    return ARTGPU_OK;
+    return ARTGPU_OK;      // (host LUT lifetime: see "Host look-up tables" in artgpu.h)
 }
 
 // ---------------------------------------------------------------------------------------------

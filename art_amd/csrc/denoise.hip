@@ -248,8 +248,10 @@ __global__ void __launch_bounds__(256) mad_hist_kernel(const float *bands, size_
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             if (i0 + k * stride >= n) break;
-            int v = abs((int)x[k]);
-            v = v < 65535 ? v : 65535;
+            // min(65535, abs((int)x)) of the reference (FTblockDN.cc:587) for every x an int can hold; beyond that (|x| >= 2^31, Inf,
+            // NaN) the reference's conversion is undefined and its index out of range -- here those coefficients land in the top bin
+            // (clamping in float first; fminf returns the number when one operand is NaN)
+            const int v = (int)fminf(fabsf(x[k]), 65535.f);
             if (v < MAD_LDS_BINS) atomicAdd(&h[v], 1);
             else atomicAdd(&gh[v], 1);
         }

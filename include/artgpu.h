@@ -153,6 +153,12 @@ int artgpu_exposure(artgpu_ctx *ctx, artgpu_rgb *image, float exp_scale, float b
 int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float *lut65536,
                       float whitept, int filmlike_clip);
 
+/* Host look-up tables.  Every entry point that takes a LUT (artgpu_tone_curve, artgpu_tone_curve_neutral, artgpu_rgb_curves,
+ * artgpu_rgb2out_matrix, artgpu_lab_adjustments, ...) copies it to the device with an asynchronous copy on the context's stream.
+ * With pageable host memory that copy has left the caller's buffer when the call returns; a LUT in PINNED host memory
+ * (hipHostMalloc / hipHostRegister) is read later, when the stream gets there: keep it unchanged until artgpu_synchronize() or the
+ * next call that downloads a result to the host.  (Calls on host-resident images synchronise before they return.) */
+
 /* curves::setLutVal (rtengine/curves.h:224-231): a value above 65535 does not go through the LUT but through the Curve object,
  * curve->getVal(val / 65535.f) * 65535.f.  The LUT is all that crosses this boundary, so the adapter states what its Curve returns
  * above 1.0 (rtengine/diagonalcurves.cc:443-561); the setting applies to the following artgpu_tone_curve / artgpu_tone_curve_neutral
@@ -195,9 +201,10 @@ typedef struct {
     double  chrominance_red_green;
     double  chrominance_blue_yellow;
     double  gamma;
-    int32_t aggressive;                /* QUALITY_HIGH: not on the device path yet */
-    int32_t color_space;               /* 0 = RGB (device path), 1 = LAB (unsupported) */
-    int32_t chrominance_method;        /* 0 = MANUAL, 1 = AUTOMATIC (only sets `autoch`) */
+    int32_t aggressive;                /* 0 = standard, 1 = QUALITY_HIGH (BiShrinkL / BiShrinkAB, FTblockDN.cc:2406-2449): both on the device */
+    int32_t color_space;               /* 0 = RGB, 1 = LAB (needs the inverse working-space matrix `iwpi`): both on the device */
+    int32_t chrominance_method;        /* 0 = MANUAL, 1 = AUTOMATIC: artgpu_rgb_denoise only takes `autoch` from it; the estimation itself
+                                          (denoiseComputeParams) is artgpu_denoise_compute_params, which artgpu_pipeline_run calls */
 } artgpu_denoise_params;
 
 #define ARTGPU_DN_SKIP_DETAIL_RECOVERY 1u  /* leave out detail_recovery (FTblockDN.cc:1479-1635) */

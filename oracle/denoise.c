@@ -24,8 +24,9 @@ float oracle_madrgb(const float *data, int datalen)
     if (datalen <= 1) return 0;
     int *histo = (int *)calloc(65536, sizeof(int));
     for (int i = 0; i < datalen; ++i) {
-        int v = abs((int)data[i]);
-        histo[v < 65535 ? v : 65535]++;
+        /* FTblockDN.cc:587: histo[min(65535, abs(static_cast<int>(x)))]; for |x| >= 2^31, Inf and NaN that conversion is undefined
+           (x86 gives INT_MIN and an out-of-range index): clamped in float first, which is the same bin for every x an int can hold */
+        histo[(int)fminf(fabsf(data[i]), 65535.f)]++;
     }
     int median = 0, count = 0;
     while (count < datalen / 2) {

@@ -107,6 +107,28 @@ def test_rgb_denoise_with_detail_recovery_tolerance(gpu_ctx, w, h, detail):
         assert np.abs(r - nd).max() > 50.0
 
 
+def test_rgb_denoise_survives_non_finite_pixels(gpu_ctx):
+    """An Inf / NaN / 1e30 pixel makes wavelet coefficients the MAD histogram (MadRgb, FTblockDN.cc:569-603) cannot bin as an int: they
+    go to the top bin instead of indexing out of range (the reference's own conversion is undefined there; its running-sum box blurs
+    then spread the non-finite values along whole rows and columns, so the frame itself is not comparable).  The call has to
+    complete without touching memory it does not own: the next frame through the same context is the oracle's bit for bit."""
+    from art_amd import capi
+    w, h = 384, 320
+    img = _rgb(w, h, 5)
+    clean = [p.copy() for p in img]
+    img[0][40, 50] = np.inf
+    img[1][41, 300] = np.nan
+    img[2][200, 60] = -1e30
+    got = [p.copy() for p in img]
+    gpu_ctx.rgb_denoise(capi.host_rgb(got), _params(), O.REC2020_WS, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    gpu_ctx.synchronize()
+    got = [p.copy() for p in clean]
+    gpu_ctx.rgb_denoise(capi.host_rgb(got), _params(), O.REC2020_WS, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    ref = O.rgb_denoise(clean, O.default_denoise_params(), detail_recovery=False)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+
+
 def test_chroma_noise_map_bit_exact(gpu_ctx):
     """calclum + ccalc (ipdenoise.cc:1113-1131, FTblockDN.cc:1716-1777) incl. the f<0 and f>65535 branches of XYZ2Lab."""
     w, h = 333, 251
