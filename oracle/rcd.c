@@ -28,6 +28,10 @@
 #define RCD_TS 194
 #define RCD_BORDER 9
 
+/* test hook: 1 = what ONE reference thread does -- the work buffer is calloc'ed once and never cleared again (rcd_demosaic.cc:99-105),
+   tiles in raster order -- instead of this restatement's "every tile starts from zeroed planes" */
+int oracle_rcd_stale = 0;
+
 void oracle_rcd_tile(const float *raw, size_t rs, int W, int H, unsigned filters,
                      int tr, int tc, int numTh, int numTw,
                      float *red, float *green, float *blue, size_t os, float *work)
@@ -49,7 +53,7 @@ void oracle_rcd_tile(const float *raw, size_t rs, int W, int H, unsigned filters
 
     /* work planes: cfa, rgb[3], VH_Dir (full) ; PQ_Dir(=lpf), P, Q (half) -- all zeroed */
     const size_t full = (size_t)ts * ts, half = full / 2;
-    memset(work, 0, sizeof(float) * (5 * full + 3 * half));
+    if (!oracle_rcd_stale) memset(work, 0, sizeof(float) * (5 * full + 3 * half));
     float *cfa = work;
     float *rgb[3] = {work + full, work + 2 * full, work + 3 * full};
     float *VH_Dir = work + 4 * full;
@@ -213,9 +217,9 @@ int oracle_rcd_demosaic(const float *raw, size_t raw_stride, int W, int H, unsig
     const int numTh = H / tileSizeN + ((H % tileSizeN) ? 1 : 0);
     const int numTw = W / tileSizeN + ((W % tileSizeN) ? 1 : 0);
     int fail = 0;
-#pragma omp parallel
+#pragma omp parallel if (!oracle_rcd_stale)
     {
-        float *work = (float *)malloc(sizeof(float) * ((size_t)RCD_TS * RCD_TS * 13 / 2));
+        float *work = (float *)calloc((size_t)RCD_TS * RCD_TS * 13 / 2, sizeof(float));
         if (!work) {
 #pragma omp atomic write
             fail = 1;

@@ -445,6 +445,10 @@ void oracle_xtrans_border(const float *raw, int width, int height, const int xtr
         }
 }
 
+/* test hook: 1 = what ONE reference thread does -- the tile buffer is allocated once and never cleared (xtrans_demosaic.cc:295-315),
+   tiles in raster order -- instead of this restatement's "every tile starts from a zeroed buffer" */
+int oracle_xtrans_stale = 0;
+
 /* rgb_cam: 3x4 row-major (RawImage::getRgbCam).  Output planes are W x H, fully written (tiles + border). */
 void oracle_xtrans_demosaic(const float *raw, int width, int height, const int xtrans[36], const float rgb_cam[12], int passes, int use_cielab,
                             float *red, float *green, float *blue)
@@ -455,13 +459,13 @@ void oracle_xtrans_demosaic(const float *raw, int width, int height, const int x
     const int ndir = 4 << (passes > 1);
     const size_t nbuf = (size_t)TS * TS * (ndir * 4 + 3) + 128;
     const int ntx = (width - 19 - 3 + (TS - 16) - 1) / (TS - 16), nty = (height - 19 - 3 + (TS - 16) - 1) / (TS - 16);
-#pragma omp parallel
+#pragma omp parallel if (!oracle_xtrans_stale)
     {
-        float *buffer = (float *)malloc(nbuf * sizeof(float));
+        float *buffer = (float *)calloc(nbuf, sizeof(float));
 #pragma omp for collapse(2) schedule(dynamic, 2)
         for (int ty = 0; ty < nty; ++ty)
             for (int tx = 0; tx < ntx; ++tx) {
-                memset(buffer, 0, nbuf * sizeof(float));
+                if (!oracle_xtrans_stale) memset(buffer, 0, nbuf * sizeof(float));
                 process_tile(&s, raw, width, height, 3 + ty * (TS - 16), 3 + tx * (TS - 16), passes, use_cielab, buffer, red, green, blue);
             }
         free(buffer);
