@@ -115,6 +115,7 @@ def _load():
     lib.artgpu_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     lib.artgpu_synchronize.argtypes = [C.c_void_p]
     lib.artgpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
+    lib.artgpu_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_long)]
     lib.artgpu_set_curve_tail.argtypes = [C.c_void_p, C.c_int, C.c_double]
     lib.artgpu_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.artgpu_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
@@ -175,7 +176,7 @@ def _load():
 
 LIB = _load()
 
-EXPORTS = ["artgpu_set_option", "artgpu_set_curve_tail", "artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
+EXPORTS = ["artgpu_set_option", "artgpu_get_option", "artgpu_set_curve_tail", "artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
            "artgpu_synchronize", "artgpu_enable_timing", "artgpu_get_timings", "artgpu_scratch_bytes",
            "artgpu_demosaic_bayer", "artgpu_border_interpolate2", "artgpu_get_image",
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
@@ -222,6 +223,11 @@ class Context:
 
     def set_option(self, name: str, value: int):
         self._chk(LIB.artgpu_set_option(self._h, name.encode(), C.c_long(int(value))))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_long(0)
+        self._chk(LIB.artgpu_get_option(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def set_curve_tail(self, kind: int, y_last: float = 1.0):
         """0 LUT clip (no Curve object), 1 constant y_last, 2 identity, 3 host (default): curves::setLutVal above 65535"""

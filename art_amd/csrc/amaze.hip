@@ -535,6 +535,7 @@ amaze_kernel(AmazeArgs a)
     const int nlist = a.tile_count ? *a.tile_count : a.ntiles;
     const int qtaken = a.queue_hdr ? a.queue_hdr[1] : 0, qleft = a.queue_hdr ? max(a.queue_hdr[0] - qtaken, 0) : 0;
     const int nlisted = nlist + qleft;
+    if (a.queue_hdr && blockIdx.x == 0 && threadIdx.x == 0 && a.queue_counters) { a.queue_counters[4] = nlist; a.queue_counters[5] = qtaken; a.queue_counters[6] = a.queue_hdr[0]; }
     for (int kt = blockIdx.x / G; kt < nlisted; kt += gridDim.x / G) {
         const int tile = kt >= nlist ? (int)(a.queue_words[qtaken + kt - nlist] & 0xffffffu) : (a.tile_list ? a.tile_list[kt] : kt);
         const int ty = tile / a.ntx, tx = tile - ty * a.ntx;

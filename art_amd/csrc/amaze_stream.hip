@@ -126,18 +126,22 @@ amaze_stream_kernel(AmazeStreamArgs s)
         return t;
     };
     // tid 0: take one entry of the redo queue for sequence position k (none: dyn[1] = -1)
+    int *const cnt = reinterpret_cast<int *>(s.queue_words + s.ntiles);    // eight bookkeeping counters behind the queue (artgpu_get_option)
     auto pull = [&](int k) {
         int tile = -1;
         unsigned long long w = 0;
-        const int taken = __hip_atomic_load(&s.queue_hdr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int reserved = __hip_atomic_load(&s.queue_hdr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // every read of the queue is a read-modify-write (+0): the per-XCD L2s are not coherent with each other, and a plain or sc1
+        // load can return what an earlier launch left in this XCD's L2 -- a consumer that trusted a stale "reserved" count took a
+        // slot that was never published in this launch, and the real entry published there later was lost
+        const int taken = __hip_atomic_fetch_add(&s.queue_hdr[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int reserved = __hip_atomic_fetch_add(&s.queue_hdr[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (taken < reserved) {
             int expect = taken;
             if (__hip_atomic_compare_exchange_strong(&s.queue_hdr[1], &expect, taken + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 // the producer publishes the word right after reserving the slot; if it does not show up, abandon the slot (the
                 // producer's publishing compare-and-swap then fails and it hands the tile to the arena kernel instead)
                 for (int spin = 0; spin < 4096; ++spin) {
-                    w = __hip_atomic_load(&s.queue_words[taken], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w = __hip_atomic_fetch_or(&s.queue_words[taken], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (w) break;
                     __builtin_amdgcn_s_sleep(8);
                 }
@@ -149,6 +153,7 @@ amaze_stream_kernel(AmazeStreamArgs s)
                 if (w && w != ~0ull) tile = (int)(w & 0xffffffu);
             }
         }
+        atomicAdd(&cnt[tile >= 0 ? 0 : 1], 1);
         dyn[0] = k; dyn[1] = tile;
         dyn[2] = (int)((w >> 24) & 0xff); dyn[3] = (int)((w >> 32) & 0xff); dyn[4] = (int)((w >> 40) & 0xff); dyn[5] = (int)((w >> 48) & 0xff);
     };
@@ -176,6 +181,9 @@ amaze_stream_kernel(AmazeStreamArgs s)
 #define AMZ_T0
 #define AMZ_T1(acc)
 #endif
+#ifdef AMZ_DEBUG
+    int dbg[3][8]; int ndbg = 0;
+#endif
     for (int T = 0; T < STEPS_PER_TILE * nk + TAIL_STEPS; ++T) {
         if (T > 0 && T % STEPS_PER_TILE == 0) {      // the load front enters the next tile
             q.back = q.front;
@@ -188,19 +196,32 @@ amaze_stream_kernel(AmazeStreamArgs s)
         // step loop and kept live across all the other roles (the kernel then spills into scratch inside the loop)
         int c = c_, lane = lane_;
         asm volatile("" : "+v"(c), "+v"(lane));
+        // The per-XCD L2s are not coherent with each other: if tile q.back has to be streamed again, the second attempt runs on another
+        // CU, possibly another XCD, and BOTH L2s would hold dirty copies of the tile's output lines -- whichever is written back last
+        // wins.  So before the tile is offered again its pixels leave this XCD's L2: every wave drains its stores one step ahead
+        // (the output stage finished the tile eight steps ago), then thread 0 writes the L2 back (release, agent scope) and publishes.
+        if (tile_drain(q, T)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) {
             if (tile_done(q, T)) {                   // every stage has left tile q.back
                 const int par = (q.back.gbase / TS) & 1;
                 int box[4];
+#ifdef AMZ_DEBUG
+                { amz_li red = (amz_li)(lds + RED_OFF) + 8 * par; const bool v_ = tile_valid(lds, par, q.back.rr1, box);
+                  if ((!v_ || q.back.redo) && ndbg < 3) { dbg[ndbg][0] = q.back.tile; dbg[ndbg][1] = q.back.redo; dbg[ndbg][2] = (int)v_; dbg[ndbg][3] = box[2]; dbg[ndbg][4] = box[3]; dbg[ndbg][5] = red[6]; dbg[ndbg][6] = red[7]; dbg[ndbg][7] = T; ++ndbg; } }
+#endif
                 if (!tile_valid(lds, par, q.back.rr1, box) && !q.back.redo) {
                     // stream it again with the true box: publish a queue entry; if the slot was abandoned, the arena kernel takes the tile
                     const unsigned long long w = (unsigned long long)q.back.tile | ((unsigned long long)box[0] << 24) | ((unsigned long long)box[1] << 32) |
                                                  ((unsigned long long)box[2] << 40) | ((unsigned long long)box[3] << 48) | (1ull << 63);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const int slot = atomicAdd(&s.queue_hdr[0], 1);
                     unsigned long long zero = 0;
+                    atomicAdd(&cnt[2], 1);
                     if (!__hip_atomic_compare_exchange_strong(&s.queue_words[slot], &zero, w, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                         const int fs = atomicAdd(&s.fallback[0], 1);
                         s.fallback[1 + fs] = q.back.tile;
+                        atomicAdd(&cnt[3], 1);
                     }
                 }
                 red_reset(lds, par);
@@ -223,7 +244,7 @@ amaze_stream_kernel(AmazeStreamArgs s)
         } else if (wave == 14) {
             {
                 const TileArgs a = stage_tile(frame, q, 2 * T - 14);
-                st_p7(lds, a, 2 * T - 14 - a.gbase, lane);
+st_p7(lds, a, 2 * T - 14 - a.gbase, lane);
                 st_p7(lds, a, 2 * T - 14 - a.gbase, 64 + lane);
                 st_p7(lds, a, 2 * T - 14 - a.gbase, 128 + lane);
             }
@@ -235,6 +256,9 @@ amaze_stream_kernel(AmazeStreamArgs s)
         AMZ_T1(tb)
         { AMZ_T0 lds_barrier(); AMZ_T1(tw) }
     }
+#ifdef AMZ_DEBUG
+    if (tid == 0) for (int k = 0; k < ndbg; ++k) printf("wg %d: tile %d redo %d valid %d box cols %d %d sites cols %d %d at T %d (nk %d)\n", (int)blockIdx.x, dbg[k][0], dbg[k][1], dbg[k][2], dbg[k][3], dbg[k][4], dbg[k][5], dbg[k][6], dbg[k][7], nk);
+#endif
 #ifdef AMZ_PROFILE
     if (blockIdx.x == 100 && lane_ == 0) printf("wave %2d: a %8lld  b %8lld  barrier-wait %8lld cycles (%d tiles)\n", wave, ta, tb, tw, nk);
 #endif

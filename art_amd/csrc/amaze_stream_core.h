@@ -1047,7 +1047,10 @@ AMZ_DEV void p8_step_b(amz_lf lds, const TileArgs &frame, const TileSeq &q, int 
     p8_wave_b(lds, a, T, G - a.gbase, lane, pr, bb);
 }
 // the last stage (output, offset 38) has just left tile q.back: is the tile valid?  (called by one thread, between barriers)
-AMZ_DEV bool tile_done(const TileSeq &q, int T) { return 2 * T - LAST_OFF == q.front.gbase && q.front.gbase > 0 && q.back.rr1 > 0; }
+// (one step after the output stage wrote its last rows of q.back: at that earlier step every wave drains its global stores, see the
+// driver -- the tile's pixels must have left this XCD's L2 before another workgroup may write them again)
+AMZ_DEV bool tile_done(const TileSeq &q, int T) { return 2 * T - LAST_OFF - 2 == q.front.gbase && q.front.gbase > 0 && q.back.rr1 > 0; }
+AMZ_DEV bool tile_drain(const TileSeq &q, int T) { return 2 * T - LAST_OFF == q.front.gbase && q.front.gbase > 0 && q.back.rr1 > 0; }
 AMZ_DEV void tile_ref_set(TileRef &t, int k, int tile, int top, int left, int rr1)
 {
     t.gbase = TS * k; t.tile = tile; t.top = top; t.left = left; t.rr1 = rr1; t.redo = 0;
@@ -1055,6 +1058,6 @@ AMZ_DEV void tile_ref_set(TileRef &t, int k, int tile, int top, int left, int rr
 }
 AMZ_DEV void tile_ref_none(TileRef &t, int k) { tile_ref_set(t, k, -1, 0, 0, 0); }
 constexpr int STEPS_PER_TILE = TS / 2;
-constexpr int TAIL_STEPS = LAST_OFF / 2 + 1;   // after the last tile's rows were loaded: the deepest stage and the last validity check
+constexpr int TAIL_STEPS = LAST_OFF / 2 + 2;   // after the last tile's rows were loaded: the deepest stage, the store drain, the last validity check
 
 } // namespace amz

@@ -301,6 +301,25 @@ int artgpu_set_curve_tail(artgpu_ctx *ctx, int kind, double y_last)
     return ARTGPU_OK;
 }
 
+int artgpu_get_option(artgpu_ctx *ctx, const char *name, long *value)
+{
+    if (!ctx || !name || !value) return ARTGPU_EINVAL;
+    const std::string n(name);
+    if (n.rfind("amaze_counter", 0) == 0 && n.size() == 14 && n[13] >= '0' && n[13] <= '7') {
+        // counters of the last AMaZE call (0 entries pulled by stream workgroups, 1 pulls that found nothing, 2 entries published,
+        // 3 tiles handed to the arena list, 4-6 what the arena kernel saw: listed tiles, queue taken, queue reserved)
+        if (!ctx->amz_lists || ctx->amz_nstream <= 0) { *value = 0; return ARTGPU_OK; }
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        const size_t nfixed = (((size_t)ctx->amz_nstream + (1 + ctx->amz_narena) + (1 + ctx->amz_narena + ctx->amz_nstream) + 3) / 4) * 4;
+        int v = 0;
+        HIPCHK(ctx, hipMemcpy(&v, reinterpret_cast<int *>(ctx->amz_lists) + nfixed + 4 + 2 * (size_t)ctx->amz_nstream + (n[13] - '0'), sizeof(int), hipMemcpyDeviceToHost));
+        *value = v;
+        return ARTGPU_OK;
+    }
+    return fail(ctx, ARTGPU_EINVAL, "get_option: unknown option '%s'", name);
+}
+
 int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value)
 {
     if (!ctx || !name) return ARTGPU_EINVAL;
@@ -405,7 +424,7 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
         int *const d_queue = d_stream + nfixed;                                          // header (4 ints), then the 64-bit entries
         unsigned long long *const d_qwords = reinterpret_cast<unsigned long long *>(d_queue + 4);
         HIPCHK(ctx, hipMemcpyAsync(d_work, d_templ, (size_t)(1 + ctx->amz_narena) * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(d_queue, 0, (4 + 2 * (size_t)ctx->amz_nstream) * sizeof(int), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_queue, 0, (4 + 2 * (size_t)ctx->amz_nstream + 8) * sizeof(int), ctx->stream));   // + the 8 counters behind it
         const float clip_pt = (float)(1.0 / initial_gain);   // amaze_demosaic_RT.cc:53-54
         const float clip_pt8 = (float)(0.8 / initial_gain);
         if (ctx->amz_nstream > 0) {
@@ -468,6 +487,7 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
         }
         a.queue_hdr = (!split && ctx->amz_nstream > 0) ? d_queue : nullptr;
         a.queue_words = d_qwords;
+        a.queue_counters = reinterpret_cast<int *>(d_qwords + ctx->amz_nstream);
         if (ctx->opt_amaze_poison >= 0)   // test hook: fill the arenas with a byte pattern first
             HIPCHK(ctx, hipMemsetAsync(ctx->arena, ctx->opt_amaze_poison, (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float), ctx->stream));
         HIPCHK(ctx, launch_amaze(a, split ? ntiles : grid, ctx->stream));

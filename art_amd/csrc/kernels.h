@@ -34,6 +34,7 @@ struct AmazeArgs {
     const int *tile_count;  // device: how many entries of tile_list are valid (read when the kernel starts)
     const int *queue_hdr;   // device (optional): redo-queue entries [hdr[1], hdr[0]) nobody streamed again are processed as well
     const unsigned long long *queue_words;
+    int *queue_counters;    // device (optional): bookkeeping for artgpu_get_option
     int split;              // 1: one launch per phase over all tiles (profiling mode; needs one arena per tile)
 };
 hipError_t launch_amaze(const AmazeArgs &a, int grid, hipStream_t stream);

@@ -82,6 +82,9 @@ int artgpu_synchronize(artgpu_ctx *ctx);
  *   "amaze_split"       1 (with amaze_path 1): one kernel launch per AMaZE phase (per-phase profile)
  *   "amaze_zero_mask" / "amaze_zero_frame" / "amaze_poison"   arena-clearing experiments of tests/test_gpu_demosaic.py */
 int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value);
+/* read-only counterparts: "amaze_counter0" .. "amaze_counter7" = bookkeeping of the last AMaZE call (how many tiles were streamed a
+ * second time, handed to the arena kernel, ...); synchronises the context's stream */
+int artgpu_get_option(artgpu_ctx *ctx, const char *name, long *value);
 int artgpu_enable_timing(artgpu_ctx *ctx, int enable);
 int artgpu_get_timings(const artgpu_ctx *ctx, artgpu_timings *out);
 

@@ -87,9 +87,16 @@ int amaze_stream_emul_seq(const float *raw, long rs, int W, int H, unsigned filt
     frame.g00 = (int)(fc(filters, 0, 0) & 1);
     if (fc(filters, 0, 0) == 1) frame.ey = fc(filters, 0, 1) == 0 ? 0 : 1;
     else frame.ey = fc(filters, 0, 0) == 0 ? 0 : 1;
-    std::vector<float> ldsv(LDS_FLOATS);
+    // order & 256: keep the LDS contents of the previous call (what a second kernel launch on the same CU sees) instead of NaN
+    static std::vector<float> ldsv(LDS_FLOATS, NAN);
     float *lds = ldsv.data();
-    for (int i = 0; i < LDS_FLOATS; ++i) lds[i] = NAN;
+    if (!(order & 256)) for (int i = 0; i < LDS_FLOATS; ++i) lds[i] = NAN;
+    if (order & 512) {      // arbitrary garbage (what another kernel left in the CU's LDS)
+        unsigned sd = 777u + (unsigned)order;
+        unsigned *u = (unsigned *)lds;
+        for (int i = 0; i < LDS_FLOATS; ++i) { sd = sd * 1664525u + 1013904223u; u[i] = (sd >> 3) & 1 ? sd : (sd & 0x0101ffffu); }
+    }
+    order &= 255;
     memset(&g_tags, 0, sizeof g_tags);
     for (int k = 0; k < R_COUNT; ++k) for (int sl = 0; sl < 64; ++sl) g_tags.row[k][sl] = -1000;
     std::vector<ThreadRegs> regs(NTHREADS);
@@ -104,7 +111,7 @@ int amaze_stream_emul_seq(const float *raw, long rs, int W, int H, unsigned filt
     }
     auto tile_ref = [&](int k) {
         TileRef t;
-        if (k < ntiles) {
+        if (k < ntiles && tops[k] > -1000) {           // (top <= -1000: an empty position, as when the redo queue had nothing to offer)
             tile_ref_set(t, k, k, tops[k], lefts[k], (tops[k] + TS < H + 16 ? tops[k] + TS : H + 16) - tops[k]);
             if (redo && redo[k]) { t.redo = 1; t.r0 = redo_box[4 * k]; t.r1 = redo_box[4 * k + 1]; t.c0 = redo_box[4 * k + 2]; t.c1 = redo_box[4 * k + 3]; }
         } else {

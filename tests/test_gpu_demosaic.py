@@ -126,8 +126,9 @@ def test_amaze_stream_matches_oracle_and_arena_kernel(gpu_ctx, amaze_options, w,
     from art_amd import capi
     raw = synth.bayer_frame(w, h, filt, seed=w + noise, noise=noise)
     ref = oracle_lib.amaze(raw, filt, gain, 4)
-    got = gpu_ctx.demosaic_bayer_host(capi.BAYER_AMAZE, raw, filt, gain, 4)
-    assert _diff(got, ref) == [0, 0, 0]
+    for _ in range(4):      # repeated: a second attempt at a tile runs on whichever workgroup is free first (cross-XCD hand-over)
+        got = gpu_ctx.demosaic_bayer_host(capi.BAYER_AMAZE, raw, filt, gain, 4)
+        assert _diff(got, ref) == [0, 0, 0]
     amaze_options(amaze_path=1)
     got1 = gpu_ctx.demosaic_bayer_host(capi.BAYER_AMAZE, raw, filt, gain, 4)
     assert _diff(got1, ref) == [0, 0, 0]
