@@ -90,12 +90,12 @@ amaze_stream_kernel(AmazeStreamArgs s)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane_ = tid & 63;
-    const int grp = wave / 3;                    // 0..4: column groups of three waves; 5: wave 15
-    const int c_ = tid - grp * 192;              // column 0..159 (160..191: helper lanes); wave 15: the lane
+    const WaveRole role = wave_role(wave);       // what this wave does in sub-step a / b, and which 64 columns of a column role
+    const int ca_ = role.apart * 64 + lane_, cb_ = role.bpart * 64 + lane_;
 
     // the single-wave roles (row recurrences, the Nyquist area sums) are the longest serial chains of a sub-step: they win the
     // issue arbitration on their SIMD, the column roles fill the gaps
-    if (wave >= 12) __builtin_amdgcn_s_setprio(2);
+    if (role.b >= B_P9 || role.a == A_P8) __builtin_amdgcn_s_setprio(2);
 
     TileArgs frame;
     frame.raw = (amz_gcf)s.raw; frame.rs = (long)s.raw_stride;
@@ -168,11 +168,10 @@ amaze_stream_kernel(AmazeStreamArgs s)
     if (q.next.rr1 > 0 && nk < 2) nk = 2;
 
     ThreadRegs rg;
-    rg.pf0 = rg.pf1 = 0.f;
     bb_reset(rg.bb);
     P8Regs p8;
     p8.cc = -1;
-    if (grp == 1) st_load_first(frame, q, c_, rg);
+    if (role.a == LOADER_ROLE) st_load_first(lds, frame, q, ca_);
 #ifdef AMZ_PROFILE
     long long ta = 0, tb = 0, tw = 0;
 #define AMZ_T0 const long long t0_ = __builtin_amdgcn_s_memtime();
@@ -194,8 +193,8 @@ amaze_stream_kernel(AmazeStreamArgs s)
         }
         // the column / lane are made opaque per step: otherwise every role's column-derived addresses are hoisted out of the
         // step loop and kept live across all the other roles (the kernel then spills into scratch inside the loop)
-        int c = c_, lane = lane_;
-        asm volatile("" : "+v"(c), "+v"(lane));
+        int ca = ca_, cb = cb_, lane = lane_;
+        asm volatile("" : "+v"(ca), "+v"(cb), "+v"(lane));
         // The per-XCD L2s are not coherent with each other: if tile q.back has to be streamed again, the second attempt runs on another
         // CU, possibly another XCD, and BOTH L2s would hold dirty copies of the tile's output lines -- whichever is written back last
         // wins.  So before the tile is offered again its pixels leave this XCD's L2: every wave drains its stores one step ahead
@@ -230,26 +229,38 @@ amaze_stream_kernel(AmazeStreamArgs s)
             const int kn = (T + 1) / STEPS_PER_TILE + 1;
             if ((T + 1) % STEPS_PER_TILE == 0 && kn >= nk_static) pull(kn);
         }
-        { AMZ_T0 if (grp < 5) substep_a(lds, frame, q, T, grp, c, rg); else p8_step_a(lds, frame, q, T, lane, p8, rg.bb); AMZ_T1(ta) }
+        { AMZ_T0 if (role.a != A_P8) substep_a(lds, frame, q, T, role.a, ca, rg); else p8_step_a(lds, frame, q, T, lane, p8, rg.bb); AMZ_T1(ta) }
         { AMZ_T0 lds_barrier(); AMZ_T1(tw) }
         AMZ_T0
-        if (grp < 4) {
-            substep_b_threads(lds, frame, q, T, grp, c);
-        } else if (wave == 12) {
+        if (role.b < B_P9) {
+            substep_b_threads(lds, frame, q, T, role.b, cb);
+        } else if (role.b == B_P9) {
             const TileArgs a = stage_tile(frame, q, 2 * T - 26);
             wave_p9(lds, a, 2 * T - 26 - a.gbase, lane);
-        } else if (wave == 13) {
-            const TileArgs a = stage_tile(frame, q, 2 * T - 26);
-            wave_p13(lds, a, 2 * T - 26 - a.gbase, lane);
-        } else if (wave == 14) {
+        } else if (role.b == B_P13_P14) {
+            {
+                const TileArgs a = stage_tile(frame, q, 2 * T - 26);
+                wave_p13(lds, a, 2 * T - 26 - a.gbase, lane);
+            }
+            const TileArgs a = stage_tile(frame, q, 2 * T - 30);
+            p14_worker(lds, a, 2 * T - 30 - a.gbase, lane);
+            wave_order();
+            if (lane == 0) hot_reset(lds, 1);
+        } else if (role.b == B_P7_P10) {
             {
                 const TileArgs a = stage_tile(frame, q, 2 * T - 14);
 st_p7(lds, a, 2 * T - 14 - a.gbase, lane);
                 st_p7(lds, a, 2 * T - 14 - a.gbase, 64 + lane);
                 st_p7(lds, a, 2 * T - 14 - a.gbase, 128 + lane);
             }
-            const TileArgs a = stage_tile(frame, q, 2 * T - 20);
-            wave_list(lds, a, T, 2 * T - 20 - a.gbase, lane);
+            {
+                const TileArgs a = stage_tile(frame, q, 2 * T - 20);
+                wave_list(lds, a, T, 2 * T - 20 - a.gbase, lane);
+            }
+            const TileArgs a = stage_tile(frame, q, 2 * T - 30);
+            p10_worker(lds, a, 2 * T - 30 - a.gbase, lane);
+            wave_order();
+            if (lane == 0) hot_reset(lds, 0);
         } else {
             p8_step_b(lds, frame, q, T, lane, p8, rg.bb);
         }

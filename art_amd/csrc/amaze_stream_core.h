@@ -5,9 +5,9 @@
 // Every phase of the reference runs a fixed number of rows ("off") behind the load front on ring buffers in LDS, so the
 // CFA is read once from memory, R/G/B are written once, and no intermediate plane ever leaves the CU.
 //
-//   step t, sub-step a:  load rows (2t,2t+1) | P2 @6 | P4 @14 | P5+P6 @12 | P8 @22 (window rows -6..0) | P10+P14+P15 @30 | P12 @24
+//   step t, sub-step a:  load rows (2t,2t+1) | P2 @6 | P4 @14 | P5+P6 @12 | P8 @22 (window rows -6..0) | P10/P14/P15 site classification @30 | P12 @24
 //   ---- LDS barrier ----
-//   step t, sub-step b:  P1 @2 | P3 @8 | P7 @14 | P8 @22 (window rows 2..6) | P9 @26 | P11 @20 | P13 @26 | P16 @34 | output @38 | P8 site list @20
+//   step t, sub-step b:  P1 @2 | P3 @8 | P7 @14 | P8 @22 (window rows 2..6) | P9 @26 | P11 @20 | P13 @26 | P10, P14 at the listed sites @30 | P16 @36 | output @40 | P8 site list @20
 //   ---- LDS barrier ----
 //
 // A stage at offset "off" handles tile rows (2t-off, 2t-off+1).  A stage of sub-step b may read what sub-step a of the SAME
@@ -80,7 +80,7 @@ constexpr float eps = 1e-5f, epssq = 1e-10f, arthresh = 0.75f;
 // - (offset of the writer) + 2; the emulation checks every read against a row tag (AMZ_EMUL).
 // ---------------------------------------------------------------------------------------------------------------------
 #define AMZ_RINGS(X)                                                                                                     \
-    X(CFA, 40, 160)  /* load @0 .. output @38 */                                                                       \
+    X(CFA, 42, 160)  /* load @0 .. output @40 */                                                                       \
     X(D0, 8, 160)    /* dirwts0: P1 @2 -> P2 @6 (+-2 rows) */                                                          \
     X(D1, 6, 160)    /* dirwts1: P1 @2 -> P2 @6 */                                                                     \
     X(DHV, 14, 160)  /* delhvsqsum: P1 @2 -> P5 @12 (+-2) */                                                           \
@@ -94,13 +94,13 @@ constexpr float eps = 1e-5f, epssq = 1e-10f, arthresh = 0.75f;
     X(DGH, 10, 160)  /* dginth: P2 @6 -> P4 @14 */                                                                     \
     X(HVW, 10, 160)  /* hwt [idx], vwt [80+idx] at R/B sites: P2 @6 -> P4 @14 */                                       \
     X(VH, 18, 160)   /* vcd [idx], hcd [80+idx] at R/B sites: P4 @14 -> P9 @26, P10 @30 */                             \
-    X(HVWT, 28, 80)  /* hvwt: P4 @14, P8 @22, P9 @26 in place -> P14 @30, output @38 (+-1) */                          \
+    X(HVWT, 30, 80)  /* hvwt: P4 @14, P8 @22, P9 @26 in place -> P14 @30, output @40 (+-1) */                          \
     X(NYQ, 6, 20)    /* nyquist flag bytes: P5 @12 -> P7 @14 (+-2) */                                                  \
     X(NYQ2, 16, 20)  /* nyquist2 bytes: P7 @14 -> P8 @22 (+-6), P9 @24, P10 @28 */                                     \
     X(DG2, 8, 160)   /* Dgrb2 {h,v} pairs: P9 @24 -> P10 @28 (+-2) */                                                  \
-    X(DG0, 16, 80)   /* Dgrb[0]: P9 @24, P10/P14/P15 @28, P16 @32 -> output @36 (+-1) */                               \
-    X(DG1, 12, 80)   /* Dgrb[1]: P15 @28, P16 @32 -> output @36 (+-1) */                                               \
-    X(RGBG, 14, 80)  /* rgbgreen at R/B sites: P9 @24, P10/P14 @28 -> output @36 */                                    \
+    X(DG0, 18, 80)   /* Dgrb[0]: P9 @26, P10/P14/P15 @30, P16 @36 -> output @40 (+-1) */                               \
+    X(DG1, 14, 80)   /* Dgrb[1]: P15 @30, P16 @36 -> output @40 (+-1) */                                               \
+    X(RGBG, 16, 80)  /* rgbgreen at R/B sites: P9 @26, P10/P14 @30 -> output @40 */                                    \
     X(DELP, 8, 80)   /* P11 @18 -> P12 @22 (+-2) */                                                                    \
     X(DELM, 8, 80)                                                                                                      \
     X(DM, 8, 80)     /* Dgrbsq1m */                                                                                     \
@@ -143,13 +143,17 @@ constexpr int LIST_OFF = NQA_OFF + NQA_FLOATS;   // P8 site list of one step (ro
 constexpr int LIST_INTS = 160;                   // two lists: the one step t consumes is rebuilt (for step t+2) only after step t
 constexpr int RED_OFF = LIST_OFF + 2 * LIST_INTS;    // int words: [0..3] flag box (min row, max row, min col, max col), [4..7] extent of the
 constexpr int RED_INTS = 24;                     // nyquist2 sites P8 processed; [8..15]: the same for the other tile in flight; [16], [17] list counts
-constexpr int DYN_OFF = RED_OFF + RED_INTS;      // the redo-queue entry pulled for the next sequence position (position, tile, box)
+constexpr int STG_OFF = RED_OFF + RED_INTS;      // CFA staging: the raw values of the next step's two rows, written by LDS-DMA (two buffers)
+constexpr int STG_ROW = 192, STG_FLOATS = 2 * 2 * STG_ROW;
+constexpr int HOT_OFF = STG_OFF + STG_FLOATS;      // P10 / P14 site lists of one step: [0] n10, [1] n14, [2..161] list10, [162..321] list14
+constexpr int HOT_INTS = 2 + 2 * 160;
+constexpr int DYN_OFF = HOT_OFF + HOT_INTS;      // the redo-queue entry pulled for the next sequence position (position, tile, box)
 constexpr int DYN_INTS = 8;
 constexpr int LDS_FLOATS = DYN_OFF + DYN_INTS;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
 constexpr int NTHREADS = 1024;
-constexpr int LAST_OFF = 38;
+constexpr int LAST_OFF = 40;
 
 
 #ifdef AMZ_EMUL
@@ -458,7 +462,7 @@ AMZ_DEV void st_p4(amz_lf lds, const TileArgs &a, int r, int c)
 // bounding box of the Nyquist flags it set / the nyquist2 sites it processed (min row, max row, min col, max col), merged into the
 // workgroup's boxes once per tile.  (An LDS atomic per flag would be turned into a scalar loop over the active lanes by the
 // compiler: four such loops per step cost more than the stage itself.)
-struct ThreadRegs { float pf0, pf1; int bb[4]; };
+struct ThreadRegs { int bb[4]; };
 AMZ_DEV void bb_reset(int *bb) { bb[0] = 1 << 30; bb[1] = 0; bb[2] = 1 << 30; bb[3] = 0; }
 AMZ_DEV void bb_add(int *bb, int rr, int cc) { bb[0] = imin(bb[0], rr); bb[1] = imax(bb[1], rr); bb[2] = imin(bb[2], cc); bb[3] = imax(bb[3], cc); }
 AMZ_DEV void bb_flush(amz_lf lds, int base, const int *bb)
@@ -761,60 +765,14 @@ AMZ_DEV float dirwt_h(amz_lf cr, int c)
     return eps + fabsf(cr[c + 2] - c0) + fabsf(c0 - cr[c - 2]) + delh;
 }
 
-// P10 (L979-999) + P14 (L1241-1297) + P15 (L1381-1386) at the site of column c: all three only touch the site's own Dgrb / rgbgreen
-AMZ_DEV void st_p10_14_15(amz_lf lds, const TileArgs &a, int r, int c)
+// P10 (L979-999) + P14 (L1241-1297) + P15 (L1381-1386): all three only touch the site's own Dgrb / rgbgreen.  P10 (sites with
+// nyquist2 set) and P14 (sites where the diagonal weight is the more decisive one) are expensive and apply to ~1 site in 8 each:
+// the column threads only classify their site (sub-step a) and put the ones that need work into two lists; ONE wave per list then
+// does the arithmetic with full lanes (sub-step b).  P14 overrides whatever P10 produced for the site, so a site that passes P14's
+// test goes to that list only.
+AMZ_DEV void p15_store(amz_lf lds, const TileArgs &a, int r, int sl, int c, bool in14, float dg, float gval)
 {
-    if (c >= TS) return;
-    const int sl = site_sel(a, r, c), rr = r + sl;
-    if (rr < 8 || rr >= a.rr1 - 8) return;
-    const int par = row_par(a, rr), idx = c >> 1;
-    if (c < 8 + par || c >= TS - 8) return;
-    float dg = SROWR(DG0, r, 0, sl)[idx];
-    float gval = SROWR(RGBG, r, 0, sl)[idx];
-    const float cfav = SROWR(CFA, r, 0, sl)[c];
-    if (rr >= a.ny_r0 && rr < a.ny_r1 && c >= a.ny_c0 + par && c < a.ny_c1 && ((amz_lb)SROWR(NYQ2, r, 0, sl))[idx]) {
-        const float gq0 = 0.169917f, gq1 = 0.108947f, gq2 = 0.069855f, gq3 = 0.0287182f;
-        // Dgrb2 rows 6,7,152,153 and columns < 8 / >= 152 alias dgintv in the reference: only sites no output depends on read them
-        amz_lf e0 = SROWX(DG2, r, 0, sl), eu1 = SROWX(DG2, r, -1, sl), eu2 = SROWX(DG2, r, -2, sl), ed1 = SROWX(DG2, r, +1, sl), ed2 = SROWX(DG2, r, +2, sl);
-#define DH(row, col) (row)[(col) & ~1]
-#define DV(row, col) (row)[(col) | 1]
-        const float gvarh = epssq + (gq0 * DH(e0, c) +
-                                     gq1 * (DH(eu1, c - 1) + DH(eu1, c + 1) + DH(ed1, c - 1) + DH(ed1, c + 1)) +
-                                     gq2 * (DH(eu2, c) + DH(e0, c - 2) + DH(e0, c + 2) + DH(ed2, c)) +
-                                     gq3 * (DH(eu2, c - 2) + DH(eu2, c + 2) + DH(ed2, c - 2) + DH(ed2, c + 2)));
-        const float gvarv = epssq + (gq0 * DV(e0, c) +
-                                     gq1 * (DV(eu1, c - 1) + DV(eu1, c + 1) + DV(ed1, c - 1) + DV(ed1, c + 1)) +
-                                     gq2 * (DV(eu2, c) + DV(e0, c - 2) + DV(e0, c + 2) + DV(ed2, c)) +
-                                     gq3 * (DV(eu2, c - 2) + DV(eu2, c + 2) + DV(ed2, c - 2) + DV(ed2, c + 2)));
-#undef DH
-#undef DV
-        amz_lf vh = SROWR(VH, r, 0, sl);
-        dg = (vh[TSH + idx] * gvarv + vh[idx] * gvarh) / (gvarv + gvarh);
-        gval = cfav + dg;
-    }
-    const bool in14 = rr >= 12 && rr < a.rr1 - 12 && c >= 12 + par && c <= 146 + par;
-    if (in14) {
-        const float hw = SROWR(HVWT, r, 0, sl)[idx];
-        if (fabsf(0.5f - SROWR(PMWT, r, 0, sl)[idx]) >= fabsf(0.5f - hw)) {
-            amz_lf rb0 = SROWR(RBINT, r, 0, sl);
-            const float rb = rb0[idx];
-            amz_lf f3u = SROWR(CFA, r, -3, sl), f2u = SROWR(CFA, r, -2, sl), f1u = SROWR(CFA, r, -1, sl), f0 = SROWR(CFA, r, 0, sl);
-            amz_lf f1d = SROWR(CFA, r, +1, sl), f2d = SROWR(CFA, r, +2, sl), f3d = SROWR(CFA, r, +3, sl);
-            const float cu = f1u[c], cd = f1d[c], cl = f0[c - 1], cr = f0[c + 1];
-            const float gu = g_dir(rb, cu, SROWR(RBINT, r, -2, sl)[idx]);      // rbint[indx1 -+ v1] is two rows away (L1253-1260)
-            const float gd = g_dir(rb, cd, SROWR(RBINT, r, +2, sl)[idx]);
-            const float d0u = dirwt_v(f3u, f2u, f1u, f0, f1d, c), d0d = dirwt_v(f1u, f0, f1d, f2d, f3d, c);
-            float Gintv = (d0u * gd + d0d * gu) / (d0d + d0u);
-            Gintv = g_bound(Gintv, rb, cu, cd, a.clip_pt);
-            const float gl = g_dir(rb, cl, rb0[idx - 1]);
-            const float gr = g_dir(rb, cr, rb0[idx + 1]);
-            const float d1l = dirwt_h(f0, c - 1), d1r = dirwt_h(f0, c + 1);
-            float Ginth = (d1l * gr + d1r * gl) / (d1l + d1r);
-            Ginth = g_bound(Ginth, rb, cl, cr, a.clip_pt);
-            gval = intp(hw, Gintv, Ginth);
-            dg = gval - cfav;
-        }
-    }
+    const int rr = r + sl, idx = c >> 1;
     SROWR(RGBG, r, 0, sl)[idx] = gval;
     if (in14 && (rr & 1) != a.ey) {       // a blue row: G-B moves to Dgrb[1] (L1381-1386)
         SROWW(DG1, r, 0, sl)[idx] = dg;
@@ -823,6 +781,108 @@ AMZ_DEV void st_p10_14_15(amz_lf lds, const TileArgs &a, int r, int c)
         SROWR(DG0, r, 0, sl)[idx] = dg;
     }
 }
+AMZ_DEV bool p14_in_range(const TileArgs &a, int rr, int c) { const int par = row_par(a, rr); return rr >= 12 && rr < a.rr1 - 12 && c >= 12 + par && c <= 146 + par; }
+// classification of the site of column c in rows (r, r+1): 0 nothing to compute (P15's bookkeeping is done here), 1 P10, 2 P14
+AMZ_DEV int st_p1014_classify(amz_lf lds, const TileArgs &a, int r, int c, int *entry)
+{
+    *entry = 0;
+    if (c >= TS) return 0;
+    const int sl = site_sel(a, r, c), rr = r + sl;
+    *entry = (sl << 8) | c;
+    if (rr < 8 || rr >= a.rr1 - 8) return 0;
+    const int par = row_par(a, rr), idx = c >> 1;
+    if (c < 8 + par || c >= TS - 8) return 0;
+    const bool in14 = p14_in_range(a, rr, c);
+    if (in14 && fabsf(0.5f - SROWR(PMWT, r, 0, sl)[idx]) >= fabsf(0.5f - SROWR(HVWT, r, 0, sl)[idx])) return 2;
+    if (rr >= a.ny_r0 && rr < a.ny_r1 && c >= a.ny_c0 + par && c < a.ny_c1 && ((amz_lb)SROWR(NYQ2, r, 0, sl))[idx]) return 1;
+    p15_store(lds, a, r, sl, c, in14, SROWR(DG0, r, 0, sl)[idx], SROWR(RGBG, r, 0, sl)[idx]);
+    return 0;
+}
+// P10 at one listed site (L979-999)
+AMZ_DEV void p10_site(amz_lf lds, const TileArgs &a, int r, int sl, int c)
+{
+    const int idx = c >> 1;
+    const float gq0 = 0.169917f, gq1 = 0.108947f, gq2 = 0.069855f, gq3 = 0.0287182f;
+    // Dgrb2 rows 6,7,152,153 and columns < 8 / >= 152 alias dgintv in the reference: only sites no output depends on read them
+    amz_lf e0 = SROWX(DG2, r, 0, sl), eu1 = SROWX(DG2, r, -1, sl), eu2 = SROWX(DG2, r, -2, sl), ed1 = SROWX(DG2, r, +1, sl), ed2 = SROWX(DG2, r, +2, sl);
+#define DH(row, col) (row)[(col) & ~1]
+#define DV(row, col) (row)[(col) | 1]
+    const float gvarh = epssq + (gq0 * DH(e0, c) +
+                                 gq1 * (DH(eu1, c - 1) + DH(eu1, c + 1) + DH(ed1, c - 1) + DH(ed1, c + 1)) +
+                                 gq2 * (DH(eu2, c) + DH(e0, c - 2) + DH(e0, c + 2) + DH(ed2, c)) +
+                                 gq3 * (DH(eu2, c - 2) + DH(eu2, c + 2) + DH(ed2, c - 2) + DH(ed2, c + 2)));
+    const float gvarv = epssq + (gq0 * DV(e0, c) +
+                                 gq1 * (DV(eu1, c - 1) + DV(eu1, c + 1) + DV(ed1, c - 1) + DV(ed1, c + 1)) +
+                                 gq2 * (DV(eu2, c) + DV(e0, c - 2) + DV(e0, c + 2) + DV(ed2, c)) +
+                                 gq3 * (DV(eu2, c - 2) + DV(eu2, c + 2) + DV(ed2, c - 2) + DV(ed2, c + 2)));
+#undef DH
+#undef DV
+    amz_lf vh = SROWR(VH, r, 0, sl);
+    const float dg = (vh[TSH + idx] * gvarv + vh[idx] * gvarh) / (gvarv + gvarh);
+    p15_store(lds, a, r, sl, c, p14_in_range(a, r + sl, c), dg, SROWR(CFA, r, 0, sl)[c] + dg);
+}
+// P14 at one listed site (L1241-1297)
+AMZ_DEV void p14_site(amz_lf lds, const TileArgs &a, int r, int sl, int c)
+{
+    const int idx = c >> 1;
+    const float hw = SROWR(HVWT, r, 0, sl)[idx];
+    amz_lf rb0 = SROWR(RBINT, r, 0, sl);
+    const float rb = rb0[idx];
+    amz_lf f3u = SROWR(CFA, r, -3, sl), f2u = SROWR(CFA, r, -2, sl), f1u = SROWR(CFA, r, -1, sl), f0 = SROWR(CFA, r, 0, sl);
+    amz_lf f1d = SROWR(CFA, r, +1, sl), f2d = SROWR(CFA, r, +2, sl), f3d = SROWR(CFA, r, +3, sl);
+    const float cfav = f0[c];
+    const float cu = f1u[c], cd = f1d[c], cl = f0[c - 1], cr = f0[c + 1];
+    const float gu = g_dir(rb, cu, SROWR(RBINT, r, -2, sl)[idx]);      // rbint[indx1 -+ v1] is two rows away (L1253-1260)
+    const float gd = g_dir(rb, cd, SROWR(RBINT, r, +2, sl)[idx]);
+    const float d0u = dirwt_v(f3u, f2u, f1u, f0, f1d, c), d0d = dirwt_v(f1u, f0, f1d, f2d, f3d, c);
+    float Gintv = (d0u * gd + d0d * gu) / (d0d + d0u);
+    Gintv = g_bound(Gintv, rb, cu, cd, a.clip_pt);
+    const float gl = g_dir(rb, cl, rb0[idx - 1]);
+    const float gr = g_dir(rb, cr, rb0[idx + 1]);
+    const float d1l = dirwt_h(f0, c - 1), d1r = dirwt_h(f0, c + 1);
+    float Ginth = (d1l * gr + d1r * gl) / (d1l + d1r);
+    Ginth = g_bound(Ginth, rb, cl, cr, a.clip_pt);
+    const float gval = intp(hw, Gintv, Ginth);
+    p15_store(lds, a, r, sl, c, true, gval - cfav, gval);
+}
+// appending to a list: a thread at a time in the emulation, one LDS atomic per wave on the device (every lane of the wave calls it)
+AMZ_DEV void hot_append(amz_lf lds, int which, bool flag, int entry)
+{
+    amz_li hot = (amz_li)(lds + HOT_OFF);
+#ifdef AMZ_EMUL
+    if (flag) hot[2 + which * 160 + hot[which]++] = entry;
+#else
+    const unsigned long long m = __ballot(flag);
+    if (m) {
+        const int lane = (int)(threadIdx.x & 63u);
+        int base = 0;
+        if (lane == 0) base = __hip_atomic_fetch_add(&hot[which], __popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (flag) hot[2 + which * 160 + base + __popcll(m & ((1ull << lane) - 1ull))] = entry;
+    }
+#endif
+}
+AMZ_DEV void st_p1014_light(amz_lf lds, const TileArgs &a, int r, int c)
+{
+    int entry;
+    const int kind = st_p1014_classify(lds, a, r, c, &entry);
+    hot_append(lds, 0, kind == 1, entry);
+    hot_append(lds, 1, kind == 2, entry);
+}
+// the worker waves of sub-step b: lane-strided over a list; lane 0 empties the list afterwards
+AMZ_DEV void p10_worker(amz_lf lds, const TileArgs &a, int r, int lane)
+{
+    amz_li hot = (amz_li)(lds + HOT_OFF);
+    const int n = hot[0];
+    for (int q = lane; q < n; q += 64) { const int e = hot[2 + q]; p10_site(lds, a, r, e >> 8, e & 255); }
+}
+AMZ_DEV void p14_worker(amz_lf lds, const TileArgs &a, int r, int lane)
+{
+    amz_li hot = (amz_li)(lds + HOT_OFF);
+    const int n = hot[1];
+    for (int q = lane; q < n; q += 64) { const int e = hot[2 + 160 + q]; p14_site(lds, a, r, e >> 8, e & 255); }
+}
+AMZ_DEV void hot_reset(amz_lf lds, int which) { ((amz_li)(lds + HOT_OFF))[which] = 0; }
 
 // P16 (L1394-1408): chrominance of the opposite colour at the site of column c
 AMZ_DEV void st_p16(amz_lf lds, const TileArgs &a, int r, int c)
@@ -923,6 +983,7 @@ AMZ_DEV void seq_begin(amz_lf lds, int tid)
         red_reset(lds, 1);
         amz_li red = (amz_li)(lds + RED_OFF);
         red[16] = 0; red[17] = 0;
+        hot_reset(lds, 0); hot_reset(lds, 1);
     }
 }
 
@@ -950,31 +1011,47 @@ AMZ_DEV TileArgs stage_tile(const TileArgs &frame, const TileSeq &q, int G) { re
         fn(lds, A_, G_ - A_.gbase, __VA_ARGS__);                             \
     }
 
-// load: thread c of the loader group puts the two rows it fetched during the previous step into the ring and fetches the next two
-// (of this tile or, at its end, the first two of the next tile)
+// load: the CFA rows travel global memory -> LDS staging buffer (asynchronous LDS-DMA, issued one step ahead, no register in
+// between: values kept in registers across the step loop made the compiler wait for the loads in the step that issued them) ->
+// ring (scaled by 1/65535, L205-334).  Thread c of the loader role puts the two rows fetched during the previous step into the ring
+// and starts the fetch of the next two (of this tile or, at its end, the first two of the next tile).
+AMZ_DEV void stage_fetch(amz_lf lds, const TileArgs &b, int buf, int n0, int n1, int c)
+{
+    amz_gcf p0 = b.raw + ((long)src_row(b, n0, c) * b.rs + src_col(b, n0, c));
+    amz_gcf p1 = b.raw + ((long)src_row(b, n1, c) * b.rs + src_col(b, n1, c));
+#ifdef AMZ_EMUL
+    lds[STG_OFF + (buf * 2 + 0) * STG_ROW + c] = *p0;
+    lds[STG_OFF + (buf * 2 + 1) * STG_ROW + c] = *p1;
+#else
+    // one dword per lane to (wave-uniform LDS base) + 4 * lane
+    const int base = STG_OFF + buf * 2 * STG_ROW + (c & ~63);
+    __builtin_amdgcn_global_load_lds(p0, lds + base, 4, 0, 0);
+    __builtin_amdgcn_global_load_lds(p1, lds + base + STG_ROW, 4, 0, 0);
+#endif
+}
 AMZ_DEV void st_load(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T, int c, ThreadRegs &rg)
 {
     if (c >= TS) return;
     const TileArgs a = with_tile(frame, q.front);
     const int r = 2 * T - a.gbase;
+#ifndef AMZ_EMUL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's own DMA of the previous step has landed
+#endif
     if (r < a.rr1) {
-        ROWW(CFA, r)[c] = rg.pf0 / 65535.f;
-        if (r + 1 < a.rr1) ROWW(CFA, r + 1)[c] = rg.pf1 / 65535.f;
+        const int sb = STG_OFF + (T & 1) * 2 * STG_ROW;
+        ROWW(CFA, r)[c] = lds[sb + c] / 65535.f;
+        if (r + 1 < a.rr1) ROWW(CFA, r + 1)[c] = lds[sb + STG_ROW + c] / 65535.f;
     }
-    // unconditional (row index clamped): a branch would put a wait between the loads
+    // unconditional (row index clamped)
     const bool nxt = r + 2 >= TS;
     const TileArgs b = with_tile(frame, nxt ? q.next : q.front);
     const int lim = b.rr1 > 0 ? b.rr1 - 1 : 0;
-    const int n0 = imin(nxt ? 0 : r + 2, lim), n1 = imin(nxt ? 1 : r + 3, lim);
-    rg.pf0 = b.raw[(long)src_row(b, n0, c) * b.rs + src_col(b, n0, c)];
-    rg.pf1 = b.raw[(long)src_row(b, n1, c) * b.rs + src_col(b, n1, c)];
+    stage_fetch(lds, b, (T + 1) & 1, imin(nxt ? 0 : r + 2, lim), imin(nxt ? 1 : r + 3, lim), c);
 }
-AMZ_DEV void st_load_first(const TileArgs &frame, const TileSeq &q, int c, ThreadRegs &rg)
+AMZ_DEV void st_load_first(amz_lf lds, const TileArgs &frame, const TileSeq &q, int c)
 {
     if (c >= TS) return;
-    const TileArgs a = with_tile(frame, q.front);
-    rg.pf0 = a.raw[(long)src_row(a, 0, c) * a.rs + src_col(a, 0, c)];
-    rg.pf1 = a.raw[(long)src_row(a, 1, c) * a.rs + src_col(a, 1, c)];
+    stage_fetch(lds, with_tile(frame, q.front), 0, 0, 1, c);
 }
 
 // a stage that keeps a per-thread box enters a new tile (its global row reaches the front tile's first row): merge the box into
@@ -987,44 +1064,69 @@ AMZ_DEV void bb_tile_change(amz_lf lds, const TileSeq &q, int T, int off, int ba
     }
 }
 
-// grp = tid / 192 (0..4; 5 = wave 15), c = tid - 192 * grp: uniform over a wave, so the caller passes grp as a scalar
-AMZ_DEV void substep_a(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T, int grp, int c, ThreadRegs &rg)
+// Roles.  A column role needs three waves (columns 0..63, 64..127, 128..191: part 0..2); a few roles are one wave.  Waves w, w+4,
+// w+8, w+12 of a workgroup share a SIMD, and a sub-step lasts as long as its busiest SIMD issues VALU instructions, so the table
+// spreads each sub-step's roles such that the four SIMDs carry about the same number of instructions (counts per wave and step
+// in DESIGN.md section 10: P2 358, P5+load 291, P12 390, P4 267, site classification 150, P8 766 / 650; P3 304 per row,
+// P16+output 351, P1+P11 163, P9 272, P13 + P14 sites 486, P7 + lists + P10 sites 365).
+enum RoleA { A_P2 = 0, A_P5L, A_P12, A_P4, A_LIGHT, A_P8 };
+enum RoleB { B_P3R0 = 0, B_P3R1, B_P16OUT, B_P1P11, B_P9, B_P13_P14, B_P7_P10, B_P8 };
+struct WaveRole { int a, apart, b, bpart; };
+AMZ_DEV WaveRole wave_role(int wave)
 {
-    switch (grp) {
-    case 0:
+    //                      SIMD class 0                 1                          2                          3
+    // a: 0,4,8,12 / 1,5,9,13 / 2,6,10,14 = P2, P5+L, P12, P4 (part 0 / 1 / 2);   3,7,11 = classification parts 0..2, 15 = P8
+    // b: class 0: w0 P1P11.2, w4 P3r0.0, w8 P16OUT.0, w12 P13+P14 | class 1: w1 P3r0.1, w5 P3r0.2, w9 P3r1.0, w13 P7+P10
+    //    class 2: w2 P16OUT.1, w6 P16OUT.2, w10 P3r1.1, w14 P9     | class 3: w3 P1P11.0, w7 P1P11.1, w11 P3r1.2, w15 P8
+    const int cls = wave & 3, row = wave >> 2;
+    WaveRole r;
+    if (cls == 3) { r.a = row == 3 ? A_P8 : A_LIGHT; r.apart = row; }
+    else { r.a = row == 0 ? A_P2 : (row == 1 ? A_P5L : (row == 2 ? A_P12 : A_P4)); r.apart = cls; }
+    const int btab[16] = {B_P1P11, B_P3R0, B_P16OUT, B_P1P11, B_P3R0, B_P3R0, B_P16OUT, B_P1P11, B_P16OUT, B_P3R1, B_P3R1, B_P3R1, B_P13_P14, B_P7_P10, B_P9, B_P8};
+    const int bpar[16] = {2, 1, 1, 0, 0, 2, 2, 1, 0, 0, 1, 2, 0, 0, 0, 0};
+    r.b = btab[wave]; r.bpart = bpar[wave];
+    return r;
+}
+constexpr int LOADER_ROLE = A_P5L;
+
+// sub-step a of a column role; c = 64 * part + lane
+AMZ_DEV void substep_a(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T, int role, int c, ThreadRegs &rg)
+{
+    switch (role) {
+    case A_P2:
         AMZ_STAGE(st_p2, 6, c)
         AMZ_STAGE(st_p2, 5, c)
         break;
-    case 1:
+    case A_P5L:
         bb_tile_change(lds, q, T, 12, 0, rg.bb);
         AMZ_STAGE(st_p5, 12, c, rg)
         st_load(lds, frame, q, T, c, rg);
         break;
-    case 2:
+    case A_P12:
         AMZ_STAGE(st_p12, 24, c)
         break;
-    case 3:
-        AMZ_STAGE(st_p10_14_15, 30, c)
+    case A_LIGHT:
+        AMZ_STAGE(st_p1014_light, 30, c)
         break;
-    case 4:
+    case A_P4:
         AMZ_STAGE(st_p4, 14, c)
         break;
-    default: break;     // wave 15: p8_wave_a (it carries registers into sub-step b, so the driver calls it)
+    default: break;     // A_P8: p8_step_a (it carries registers into sub-step b, so the driver calls it)
     }
 }
 
-// the part of sub-step b that ordinary column threads do
-AMZ_DEV void substep_b_threads(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T, int grp, int c)
+// the column roles of sub-step b
+AMZ_DEV void substep_b_threads(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T, int role, int c)
 {
-    switch (grp) {
-    case 0: AMZ_STAGE(st_p3, 8, c) break;
-    case 1: AMZ_STAGE(st_p3, 7, c) break;
-    case 2:
-        AMZ_STAGE(st_p16, 34, c)
-        AMZ_STAGE(st_out, 38, c)
-        AMZ_STAGE(st_out, 37, c)
+    switch (role) {
+    case B_P3R0: AMZ_STAGE(st_p3, 8, c) break;
+    case B_P3R1: AMZ_STAGE(st_p3, 7, c) break;
+    case B_P16OUT:
+        AMZ_STAGE(st_p16, 36, c)
+        AMZ_STAGE(st_out, 40, c)
+        AMZ_STAGE(st_out, 39, c)
         break;
-    case 3:
+    case B_P1P11:
         AMZ_STAGE(st_p1, 2, c)
         AMZ_STAGE(st_p1, 1, c)
         AMZ_STAGE(st_p11, 20, c)

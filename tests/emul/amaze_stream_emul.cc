@@ -124,7 +124,7 @@ int amaze_stream_emul_seq(const float *raw, long rs, int W, int H, unsigned filt
     q.front = tile_ref(0);
     q.next = tile_ref(1);
     seq_begin(lds, 0);
-    for (int tid = 192; tid < 192 + 192; ++tid) st_load_first(frame, q, tid - 192, regs[tid]);
+    for (int tid = 0; tid < NTHREADS; ++tid) { const WaveRole wr = wave_role(tid >> 6); if (wr.a == LOADER_ROLE) st_load_first(lds, frame, q, wr.apart * 64 + (tid & 63)); }
     const int nsteps = STEPS_PER_TILE * ntiles + TAIL_STEPS;
     for (int T = 0; T < nsteps; ++T) {
         if (T > 0 && T % STEPS_PER_TILE == 0) { q.back = q.front; q.front = q.next; q.next = tile_ref(T / STEPS_PER_TILE + 1); }
@@ -134,23 +134,32 @@ int amaze_stream_emul_seq(const float *raw, long rs, int W, int H, unsigned filt
             red_reset(lds, par);
         }
         for (int i = 0; i < NTHREADS; ++i) {
-            if (ord[i] < 960) substep_a(lds, frame, q, T, ord[i] / 192, ord[i] % 192, regs[ord[i]]);
-            else p8_step_a(lds, frame, q, T, ord[i] - 960, p8[ord[i] - 960], regs[ord[i]].bb);
+            const WaveRole wr = wave_role(ord[i] >> 6);
+            if (wr.a != A_P8) substep_a(lds, frame, q, T, wr.a, wr.apart * 64 + (ord[i] & 63), regs[ord[i]]);
+            else p8_step_a(lds, frame, q, T, ord[i] & 63, p8[ord[i] & 63], regs[ord[i]].bb);
         }
         // ---- barrier ----
         const TileArgs a9 = stage_tile(frame, q, 2 * T - 26), a7 = stage_tile(frame, q, 2 * T - 14), al = stage_tile(frame, q, 2 * T - 20);
+        const TileArgs ah = stage_tile(frame, q, 2 * T - 30);
+        auto workers = [&]() {
+            for (int l = 0; l < 64; ++l) p14_worker(lds, ah, 2 * T - 30 - ah.gbase, order & 1 ? 63 - l : l);
+            for (int l = 0; l < 64; ++l) p10_worker(lds, ah, 2 * T - 30 - ah.gbase, order & 1 ? 63 - l : l);
+            hot_reset(lds, 0); hot_reset(lds, 1);
+        };
         if (order & 1) {
+            workers();
             wave_list(lds, al, T, 2 * T - 20 - al.gbase);
             for (int l = 63; l >= 0; --l) p8_step_b(lds, frame, q, T, l, p8[l], regs[960 + l].bb);
             wave_p13(lds, a9, 2 * T - 26 - a9.gbase); wave_p9(lds, a9, 2 * T - 26 - a9.gbase);
             for (int i = 0; i < 192; ++i) st_p7(lds, a7, 2 * T - 14 - a7.gbase, i);
         }
-        for (int i = 0; i < NTHREADS; ++i) if (ord[i] < 768) substep_b_threads(lds, frame, q, T, ord[i] / 192, ord[i] % 192);
+        for (int i = 0; i < NTHREADS; ++i) { const WaveRole wr = wave_role(ord[i] >> 6); if (wr.b < B_P9) substep_b_threads(lds, frame, q, T, wr.b, wr.bpart * 64 + (ord[i] & 63)); }
         if (!(order & 1)) {
             for (int i = 0; i < 192; ++i) st_p7(lds, a7, 2 * T - 14 - a7.gbase, i);
             wave_p9(lds, a9, 2 * T - 26 - a9.gbase); wave_p13(lds, a9, 2 * T - 26 - a9.gbase);
             for (int l = 0; l < 64; ++l) p8_step_b(lds, frame, q, T, l, p8[l], regs[960 + l].bb);
             wave_list(lds, al, T, 2 * T - 20 - al.gbase);
+            workers();
         }
         // ---- barrier ----
         if (ntiles == 1) shadow_update(lds);
