@@ -119,356 +119,6 @@ __device__ __forceinline__ float g_bound(float Gint, float rb, float nA, float n
 } // namespace
 
 
-// =====================================================================================================================
-// Streaming front end (phases 0-7 of a full interior tile): the tile is walked top to bottom ONCE; every phase works a
-// fixed number of rows behind the load front on ring buffers in LDS, so the CFA is read once and no intermediate plane
-// is read back from memory.  What later phases (or their aliases) read is written to the arena exactly as the phase
-// kernels would have left it: values where a phase writes, zero where it does not and the region is one that is cleared
-// per tile (vcd, hcd, vcdalt, hcdalt, cddiffsq, nyquist).  Lags (rows behind the load front): P1 3, P2 6, P3 hcd 7,
-// P3 vcd 9 (row r reads the new row r-2), cddiffsq 10, P4 and P5/P6 13.  One workgroup barrier per row step; a step's
-// phases touch rows that were completed in earlier steps only.  The hcd pass of P3 needs no exchange: a lane of the
-// "lanes 0,1" kind recomputes the new value of its left neighbour pair (which only reads original values).
-// =====================================================================================================================
-constexpr int SF_CFA = 32;          // cfa ring: 10 rows behind the load front for the slowest reader + up to 16 rows loaded ahead
-constexpr int SF_ROWS = SF_CFA + 16 * 4 + 4 + 8 + 4 + 4 + 8 + 8 + 16 + 8;      // ring rows in LDS
-constexpr int SF_LDS_FLOATS = SF_ROWS * ts;
-#define SF_ROW(p, D, r) ((p) + (((r) & ((D) - 1)) * ts))
-
-// workgroup barrier that orders LDS traffic only: a __syncthreads() also waits for every outstanding global store of the row just
-// written (vmcnt(0)), which costs a memory round trip per row step
-__device__ __forceinline__ void lds_barrier()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-// new hcd value of column cc (lanes 2,3 of a 4-lane group): variance choice on ORIGINAL values + highlight bounding
-// Inside a non-inlined function pointers are generic, and FLAT accesses count on the LDS counter as well: every wait for an LDS
-// read would also wait for the arena stores in flight.  The front end therefore works on address-space-qualified pointers.
-typedef __attribute__((address_space(1))) float gfloat;
-typedef __attribute__((address_space(1))) unsigned char gbyte;
-typedef __attribute__((address_space(3))) float lfloat;
-typedef __attribute__((address_space(3))) int lint;
-
-__device__ __forceinline__ float sf_hcd_pure(const lfloat *ho, const lfloat *ha, const lfloat *cf, unsigned filters, int rr, int cc, float clip_pt)
-{
-    const float sgn = (fc(filters, rr, cc) & 1) ? -1.f : 1.f;
-    float hcdv = ho[cc];
-    const float hv = var3(ho[cc - 2], hcdv, ho[cc + 2]);
-    const float a0 = ha[cc];
-    const float hav = var3(ha[cc - 2], a0, ha[cc + 2]);
-    hcdv = hav < hv ? a0 : hcdv;
-    return bound_cd(hcdv, sgn, cf[cc], cf[cc - 1], cf[cc + 1], clip_pt);
-}
-
-// (not inlined on purpose: inside the 20-phase kernel its loop inherits that kernel's register pressure, and every spill reload
-// is an s_waitcnt vmcnt(0) that also waits for the arena stores in flight)
-__device__ __noinline__ void amaze_stream_front(float *lds_generic, float *A_generic, int *bbox, int *s_red_generic, const float *raw_generic, size_t rs, int top, int left,
-                                                   unsigned filters, float clip_pt, float clip_pt8, int tid, int nthreads)
-{
-    lfloat *const lds = (lfloat *)lds_generic;
-    gfloat *const A = (gfloat *)A_generic;
-    const gfloat *const raw = (const gfloat *)raw_generic;
-    lint *const s_red = (lint *)s_red_generic;
-    lfloat *const r_cfa = lds, *const r_d0 = r_cfa + SF_CFA * ts, *const r_d1 = r_d0 + 16 * ts, *const r_dhv = r_d1 + 16 * ts;
-    lfloat *const r_hcdalt = r_dhv + 16 * ts;      // 4 rows
-    lfloat *const r_vcdalt = r_hcdalt + 4 * ts;    // 8
-    lfloat *const r_vcdo = r_vcdalt + 8 * ts;      // 4   vcd as P2 leaves it
-    lfloat *const r_hcdo = r_vcdo + 4 * ts;        // 4   hcd as P2 leaves it
-    lfloat *const r_dgv = r_hcdo + 4 * ts;         // 16
-    lfloat *const r_dgh = r_dgv + 16 * ts;         // 8
-    lfloat *const r_hcdn = r_dgh + 8 * ts;         // 8   hcd after P3
-    lfloat *const r_vcdn = r_hcdn + 8 * ts;        // 16  vcd after P3
-    lfloat *const r_cdd = r_vcdn + 16 * ts;        // 8
-    gfloat *const a_rgbgreen = A + O_rgbgreen, *const a_dhv = A + O_delhvsqsum, *const a_d0 = A + O_dirwts0, *const a_d1 = A + O_dirwts1;
-    gfloat *const a_vcd = A + O_vcd, *const a_hcd = A + O_hcd, *const a_vcdalt = A + O_vcdalt, *const a_hcdalt = A + O_hcdalt;
-    gfloat *const a_cdd = A + O_cddiffsq, *const a_hvwt = A + O_hvwt, *const a_dgv = A + O_dgintv, *const a_cfa = A + O_cfa;
-    gbyte *const a_nyq = (gbyte *)(A + O_nyquist);
-
-    // ---- start of tile: empty rings; the margins / gaps of the per-tile-cleared regions that no row pass writes
-    for (int i = tid; i < SF_LDS_FLOATS; i += nthreads) lds[i] = 0.f;
-    {
-        gfloat *const cleared[5] = {a_vcd, a_hcd, a_vcdalt, a_hcdalt, a_cdd};
-        for (int i = tid; i < 5 * ts * 8; i += nthreads) {
-            const int pl = i / (ts * 8), q = i - pl * (ts * 8), rr = q >> 3, k = q & 7;
-            cleared[pl][rr * ts + (k < 4 ? k : ts - 8 + k)] = 0.f;                      // columns 0-3 and 156-159
-        }
-        for (int i = tid; i < 5 * 2 * GAP; i += nthreads) {
-            const int pl = i / (2 * GAP), q = i - pl * (2 * GAP);
-            if (q < (pl == 4 ? 2 * GAP : GAP)) cleared[pl][F + q] = 0.f;               // the gap behind the plane (two gaps behind cddiffsq)
-        }
-        for (int i = tid; i < GAP; i += nthreads) (A + O_nyquist)[Hh / 4 + i] = 0.f;
-    }
-    if (tid == 0) { s_red[0] = 1 << 30; s_red[1] = 0; s_red[2] = ts + 1; s_red[3] = 0; bbox[0] = 1 << 30; bbox[1] = 0; bbox[2] = ts + 1; bbox[3] = 0; }
-    __syncthreads();
-
-    const int wave = tid >> 6;
-    float pf[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // CFA rows in flight (threads 0..159)
-    if (tid < ts) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float v = raw[(size_t)(q + top) * rs + (tid + left)] / 65535.f;
-            SF_ROW(r_cfa, SF_CFA, q)[tid] = v;
-            a_cfa[q * ts + tid] = v;
-            a_rgbgreen[q * ts + tid] = v;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) pf[q] = raw[(size_t)(8 + q + top) * rs + (tid + left)];
-    }
-    __syncthreads();
-#ifdef SF_PROFILE
-    long long tbody = 0, tloop0 = wall_clock64();
-#endif
-    for (int t = 0; t < ts + 13; ++t) {
-#ifdef SF_PROFILE
-        const long long tb0 = wall_clock64();
-#endif
-        if (wave < 3) {
-            // ---- load row t (L205-334, interior tile: no mirroring) and P1 gradients of row t-3 (L342-351)
-            const int cc = tid;
-            if (cc < ts) {
-                // the CFA arrives in batches of eight rows, loaded one batch (eight steps) before they are put into the ring, which is
-                // again at least eight steps before their first reader: no step waits for a global load
-                if ((t & 7) == 0) {
-                    const int r0 = t + 8;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (r0 + q < ts) {
-                            const float v = pf[q] / 65535.f;
-                            SF_ROW(r_cfa, SF_CFA, r0 + q)[cc] = v;
-                            a_cfa[(r0 + q) * ts + cc] = v;
-                            a_rgbgreen[(r0 + q) * ts + cc] = v;
-                        }
-                    // unconditional (row index clamped): a branch per row would put a wait between the loads
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) pf[q] = raw[(size_t)(min(r0 + 8 + q, ts - 1) + top) * rs + (cc + left)];
-                }
-                const int r = t - 3;
-                if (r >= 0 && r < ts) {
-                    float w0 = 0.f, w1 = 0.f, dq = 0.f;
-                    if (r >= 2 && r < ts - 2) {
-                        const lfloat *c = SF_ROW(r_cfa, SF_CFA, r);
-                        // i-1, i-2 / i+1, i+2 in the flat tile: columns past a row end continue in the neighbouring row
-                        const float cl1 = cc >= 1 ? c[cc - 1] : SF_ROW(r_cfa, SF_CFA, r - 1)[ts + cc - 1];
-                        const float cl2 = cc >= 2 ? c[cc - 2] : SF_ROW(r_cfa, SF_CFA, r - 1)[ts + cc - 2];
-                        const float cr1 = cc + 1 < ts ? c[cc + 1] : SF_ROW(r_cfa, SF_CFA, r + 1)[cc + 1 - ts];
-                        const float cr2 = cc + 2 < ts ? c[cc + 2] : SF_ROW(r_cfa, SF_CFA, r + 1)[cc + 2 - ts];
-                        const float c0 = c[cc];
-                        const float cu1 = SF_ROW(r_cfa, SF_CFA, r - 1)[cc], cu2 = SF_ROW(r_cfa, SF_CFA, r - 2)[cc];
-                        const float cd1 = SF_ROW(r_cfa, SF_CFA, r + 1)[cc], cd2 = SF_ROW(r_cfa, SF_CFA, r + 2)[cc];
-                        const float delh = fabsf(cr1 - cl1);
-                        const float delv = fabsf(cd1 - cu1);
-                        w1 = eps + fabsf(cr2 - c0) + fabsf(c0 - cl2) + delh;
-                        w0 = eps + fabsf(cd2 - c0) + fabsf(c0 - cu2) + delv;
-                        dq = sqr(delh) + sqr(delv);
-                    }
-                    SF_ROW(r_d0, 16, r)[cc] = w0; SF_ROW(r_d1, 16, r)[cc] = w1; SF_ROW(r_dhv, 16, r)[cc] = dq;
-                    a_d0[r * ts + cc] = w0; a_d1[r * ts + cc] = w1; a_dhv[r * ts + cc] = dq;
-                }
-            }
-        } else if (wave < 6) {
-            // ---- P2: vertical / horizontal colour differences of row t-6 (L380-434), columns 4..155
-            const int r = t - 6, cc = 4 + (tid - 192);
-            if (r >= 0 && r < ts && cc < ts - 4) {
-                float o_hcdalt = 0.f, o_vcdalt = 0.f, o_vcd = 0.f, o_hcd = 0.f, o_dgv = 0.f, o_dgh = 0.f;
-                if (r >= 4 && r < ts - 4) {
-                    const lfloat *c = SF_ROW(r_cfa, SF_CFA, r), *d0r = SF_ROW(r_d0, 16, r), *d1r = SF_ROW(r_d1, 16, r);
-                    const float sgn = (fc(filters, r, cc) & 1) ? -1.f : 1.f;
-                    const float cfav = c[cc];
-                    const float cu1 = SF_ROW(r_cfa, SF_CFA, r - 1)[cc], cu2 = SF_ROW(r_cfa, SF_CFA, r - 2)[cc];
-                    const float cd1 = SF_ROW(r_cfa, SF_CFA, r + 1)[cc], cd2 = SF_ROW(r_cfa, SF_CFA, r + 2)[cc];
-                    const float cl1 = c[cc - 1], cl2 = c[cc - 2], cr1 = c[cc + 1], cr2 = c[cc + 2];
-                    const float d0c = d0r[cc], d1c = d1r[cc];
-                    const float d0u2 = SF_ROW(r_d0, 16, r - 2)[cc], d0d2 = SF_ROW(r_d0, 16, r + 2)[cc], d1l2 = d1r[cc - 2], d1r2 = d1r[cc + 2];
-                    const float cru = cu1 * (d0u2 + d0c) / (d0u2 * (eps + cfav) + d0c * (eps + cu2));
-                    const float crd = cd1 * (d0d2 + d0c) / (d0d2 * (eps + cfav) + d0c * (eps + cd2));
-                    const float crl = cl1 * (d1l2 + d1c) / (d1l2 * (eps + cfav) + d1c * (eps + cl2));
-                    const float crr = cr1 * (d1r2 + d1c) / (d1r2 * (eps + cfav) + d1c * (eps + cr2));
-                    const float guha = cu1 + 0.5f * (cfav - cu2);
-                    const float gdha = cd1 + 0.5f * (cfav - cd2);
-                    const float glha = cl1 + 0.5f * (cfav - cl2);
-                    const float grha = cr1 + 0.5f * (cfav - cr2);
-                    float guar = fabsf(1.f - cru) < arthresh ? cfav * cru : guha;
-                    float gdar = fabsf(1.f - crd) < arthresh ? cfav * crd : gdha;
-                    float glar = fabsf(1.f - crl) < arthresh ? cfav * crl : glha;
-                    float grar = fabsf(1.f - crr) < arthresh ? cfav * crr : grha;
-                    const float d1l = d1r[cc - 1], d1rr = d1r[cc + 1], d0u = SF_ROW(r_d0, 16, r - 1)[cc], d0d = SF_ROW(r_d0, 16, r + 1)[cc];
-                    const float hwt = d1l / (d1l + d1rr);
-                    const float vwt = d0u / (d0d + d0u);
-                    const float Ginthha = intp(hwt, grha, glha);
-                    const float Gintvha = intp(vwt, gdha, guha);
-                    o_hcdalt = sgn * (Ginthha - cfav);
-                    o_vcdalt = sgn * (Gintvha - cfav);
-                    const bool clip = (cfav > clip_pt8) || (Gintvha > clip_pt8) || (Ginthha > clip_pt8);
-                    if (clip) { guar = guha; gdar = gdha; glar = glha; grar = grha; }
-                    o_vcd = clip ? o_vcdalt : sgn * (intp(vwt, gdar, guar) - cfav);
-                    o_hcd = clip ? o_hcdalt : sgn * (intp(hwt, grar, glar) - cfav);
-                    o_dgv = sse_min(sqr(guha - gdha), sqr(guar - gdar));
-                    o_dgh = sse_min(sqr(glha - grha), sqr(glar - grar));
-                }
-                SF_ROW(r_hcdalt, 4, r)[cc] = o_hcdalt; SF_ROW(r_vcdalt, 8, r)[cc] = o_vcdalt;
-                SF_ROW(r_vcdo, 4, r)[cc] = o_vcd; SF_ROW(r_hcdo, 4, r)[cc] = o_hcd;
-                SF_ROW(r_dgv, 16, r)[cc] = o_dgv; SF_ROW(r_dgh, 8, r)[cc] = o_dgh;
-                a_hcdalt[r * ts + cc] = o_hcdalt; a_vcdalt[r * ts + cc] = o_vcdalt; a_dgv[r * ts + cc] = o_dgv;
-            }
-        } else if (wave < 9) {
-            // ---- P3, hcd of row t-7 (L540-583): lanes 2,3 of a 4-lane group read original values only; lanes 0,1 read the
-            //      updated lanes 2,3 of the group to their left (the original ones in the first group)
-            const int r = t - 7, idx = tid - 384, cc = 4 + idx;
-            if (r >= 0 && r < ts && cc < ts - 4) {
-                float nh = 0.f;
-                if (r >= 4 && r < ts - 4) {
-                    const lfloat *ho = SF_ROW(r_hcdo, 4, r), *ha = SF_ROW(r_hcdalt, 4, r), *cf = SF_ROW(r_cfa, SF_CFA, r);
-                    const int k = idx & 3, g = idx >> 2;
-                    if (k >= 2) {
-                        nh = sf_hcd_pure(ho, ha, cf, filters, r, cc, clip_pt);
-                    } else {
-                        const float hm2 = g > 0 ? sf_hcd_pure(ho, ha, cf, filters, r, cc - 2, clip_pt) : ho[cc - 2];
-                        const float sgn = (fc(filters, r, cc) & 1) ? -1.f : 1.f;
-                        float hcdv = ho[cc];
-                        const float hv = var3(hm2, hcdv, ho[cc + 2]);
-                        const float a0 = ha[cc];
-                        const float hav = var3(ha[cc - 2], a0, ha[cc + 2]);
-                        hcdv = hav < hv ? a0 : hcdv;
-                        nh = bound_cd(hcdv, sgn, cf[cc], cf[cc - 1], cf[cc + 1], clip_pt);
-                    }
-                }
-                SF_ROW(r_hcdn, 8, r)[cc] = nh;
-                a_hcd[r * ts + cc] = nh;
-            }
-        } else if (wave < 12) {
-            // ---- P3, vcd of row t-9: row r reads the UPDATED row r-2; then cddiffsq of row t-10
-            const int idx = tid - 576, cc = 4 + idx;
-            if (cc < ts - 4) {
-                const int r = t - 9;
-                if (r >= 0 && r < ts) {
-                    float nv = 0.f;
-                    if (r >= 4 && r < ts - 4) {
-                        const float sgn = (fc(filters, r, cc) & 1) ? -1.f : 1.f;
-                        const float n2 = SF_ROW(r_vcdn, 16, r - 2)[cc];
-                        const float o0 = SF_ROW(r_vcdo, 4, r)[cc], o2 = SF_ROW(r_vcdo, 4, r + 2)[cc];
-                        const float am2 = SF_ROW(r_vcdalt, 8, r - 2)[cc], a0 = SF_ROW(r_vcdalt, 8, r)[cc], a2 = SF_ROW(r_vcdalt, 8, r + 2)[cc];
-                        const float cm1 = SF_ROW(r_cfa, SF_CFA, r - 1)[cc], c0 = SF_ROW(r_cfa, SF_CFA, r)[cc], cp1 = SF_ROW(r_cfa, SF_CFA, r + 1)[cc];
-                        float vcdv = o0;
-                        const float vv = var3(n2, vcdv, o2);
-                        const float vav = var3(am2, a0, a2);
-                        vcdv = vav < vv ? a0 : vcdv;
-                        nv = bound_cd(vcdv, sgn, c0, cm1, cp1, clip_pt);
-                    }
-                    SF_ROW(r_vcdn, 16, r)[cc] = nv;
-                    a_vcd[r * ts + cc] = nv;
-                }
-                const int r2 = t - 10;
-                if (r2 >= 0 && r2 < ts) {
-                    float cd = 0.f;
-                    if (r2 >= 4 && r2 < ts - 4) cd = sqr(SF_ROW(r_vcdn, 16, r2)[cc] - SF_ROW(r_hcdn, 8, r2)[cc]);
-                    SF_ROW(r_cdd, 8, r2)[cc] = cd;
-                    a_cdd[r2 * ts + cc] = cd;
-                }
-            }
-        } else if (wave < 14) {
-            // ---- P4: h/v weight at the R/B sites of row t-13 (L680-728)
-            const int r = t - 13, it = tid - 768;
-            if (r >= 6 && r < ts - 6) {
-                const int par = fc(filters, r, 2) & 1;
-                if (it < 4 * ngroups(6 + par, ts - 6, 8)) {
-                    const int cc = 6 + par + 2 * it;
-                    const lfloat *hn = SF_ROW(r_hcdn, 8, r), *d1r = SF_ROW(r_d1, 16, r), *dh = SF_ROW(r_dgh, 8, r);
-                    // columns past the row end (the last 4-lane group overruns): what the flat tile holds there is either a never
-                    // written column (0) or feeds only sites beyond the range anyone reads; 0 keeps the arithmetic finite
-                    auto col = [&](const lfloat *row, int c) -> float { return c < ts ? row[c] : 0.f; };
-                    float tv = SF_ROW(r_vcdn, 16, r)[cc];
-                    const float vu1 = SF_ROW(r_vcdn, 16, r - 1)[cc], vu2 = SF_ROW(r_vcdn, 16, r - 2)[cc], vu3 = SF_ROW(r_vcdn, 16, r - 3)[cc];
-                    const float vd1 = SF_ROW(r_vcdn, 16, r + 1)[cc], vd2 = SF_ROW(r_vcdn, 16, r + 2)[cc], vd3 = SF_ROW(r_vcdn, 16, r + 3)[cc];
-                    const float uave = tv + vu1 + vu2 + vu3;
-                    const float dave = tv + vd1 + vd2 + vd3;
-                    float Dvu = sqr(tv - uave) + sqr(vu1 - uave) + sqr(vu2 - uave) + sqr(vu3 - uave);
-                    float Dvd = sqr(tv - dave) + sqr(vd1 - dave) + sqr(vd2 - dave) + sqr(vd3 - dave);
-                    const float d1l = d1r[cc - 1], d1rr = col(d1r, cc + 1), d0u = SF_ROW(r_d0, 16, r - 1)[cc], d0d = SF_ROW(r_d0, 16, r + 1)[cc];
-                    const float hwt = d1l / (d1l + d1rr);
-                    const float vwt = d0u / (d0u + d0d);
-                    tv = hn[cc];
-                    const float hl1 = hn[cc - 1], hl2 = hn[cc - 2], hl3 = hn[cc - 3];
-                    const float hr1 = col(hn, cc + 1), hr2 = col(hn, cc + 2), hr3 = col(hn, cc + 3);
-                    const float lave = tv + (hl3 + hl2) + hl1;
-                    const float rave = tv + (hr1 + hr2) + hr3;
-                    float Dhl = sqr(tv - lave) + sqr(hl1 - lave) + sqr(hl2 - lave) + sqr(hl3 - lave);
-                    float Dhr = sqr(tv - rave) + sqr(hr1 - rave) + sqr(hr2 - rave) + sqr(hr3 - rave);
-                    const float vcdvar = epssq + intp(vwt, Dvd, Dvu);
-                    const float hcdvar = epssq + intp(hwt, Dhr, Dhl);
-                    Dvu = SF_ROW(r_dgv, 16, r - 1)[cc] + SF_ROW(r_dgv, 16, r - 2)[cc];
-                    Dvd = SF_ROW(r_dgv, 16, r + 1)[cc] + SF_ROW(r_dgv, 16, r + 2)[cc];
-                    Dhl = dh[cc - 2] + dh[cc - 1];
-                    Dhr = col(dh, cc + 1) + col(dh, cc + 2);
-                    const float vcdvar1 = epssq + SF_ROW(r_dgv, 16, r)[cc] + intp(vwt, Dvd, Dvu);
-                    const float hcdvar1 = epssq + dh[cc] + intp(hwt, Dhr, Dhl);
-                    const float varwt = hcdvar / (vcdvar + hcdvar);
-                    const float diffwt = hcdvar1 / (vcdvar1 + hcdvar1);
-                    const bool dec = ((0.5f - varwt) * (0.5f - diffwt) > 0.f) && (fabsf(0.5f - diffwt) < fabsf(0.5f - varwt));
-                    a_hvwt[(r * ts + cc) >> 1] = dec ? varwt : diffwt;
-                }
-            }
-        } else {
-            // ---- P5 nyquist test value of row t-13 (L746-803) and P6 flags + bounding box (L806-825)
-            const int r = t - 13, it = tid - 896;
-            if (r >= 0 && r < ts && it < tsh) {
-                unsigned char flag = 0;
-                if (r >= 6 && r < ts - 6) {
-                    const float go0 = 0.14659727707323927f, go1 = 0.103592713382435f, go2 = 0.0732036125103057f, go3 = 0.0365543548389495f;
-                    const float nyqthresh = 0.5f;
-                    const float gg0 = nyqthresh * 0.07384411893421103f, gg1 = nyqthresh * 0.06207511968171489f, gg2 = nyqthresh * 0.0521818194747806f;
-                    const float gg3 = nyqthresh * 0.03687419286733595f, gg4 = nyqthresh * 0.03099732204057846f, gg5 = nyqthresh * 0.018413194161458882f;
-                    const int par = fc(filters, r, 2) & 1;
-                    const int si = it - 3;                 // site index: byte (r*ts + cc) >> 1 = r*tsh + 3 + si
-                    const int cc = 6 + par + 2 * si;
-                    if (si >= 0 && cc < ts - 6) {          // the sites P6 tests; the vector-group overrun of P5 beyond them is never read
-                        const bool vec = si < 4 * ngroups(6 + par, ts - 7, 8);
-                        const lfloat *c0 = SF_ROW(r_cdd, 8, r), *cu1 = SF_ROW(r_cdd, 8, r - 1), *cu2 = SF_ROW(r_cdd, 8, r - 2);
-                        const lfloat *cd1 = SF_ROW(r_cdd, 8, r + 1), *cd2 = SF_ROW(r_cdd, 8, r + 2);
-                        const lfloat *d0 = SF_ROW(r_dhv, 16, r), *du1 = SF_ROW(r_dhv, 16, r - 1), *du2 = SF_ROW(r_dhv, 16, r - 2);
-                        const lfloat *dd1 = SF_ROW(r_dhv, 16, r + 1), *dd2 = SF_ROW(r_dhv, 16, r + 2);
-                        const float gA = go0 * c0[cc] +
-                                         go1 * (cu1[cc - 1] + cu1[cc + 1] + cd1[cc - 1] + cd1[cc + 1]) +
-                                         go2 * (cu2[cc] + c0[cc - 2] + c0[cc + 2] + cd2[cc]) +
-                                         go3 * (cu2[cc - 2] + cu2[cc + 2] + cd2[cc - 2] + cd2[cc + 2]);
-                        const float s1 = vec ? (du1[cc] + d0[cc - 1] + d0[cc + 1] + dd1[cc])
-                                             : (du1[cc] + d0[cc + 1] + d0[cc - 1] + dd1[cc]);
-                        const float gB = gg0 * d0[cc] + gg1 * s1 +
-                                         gg2 * (du1[cc - 1] + du1[cc + 1] + dd1[cc - 1] + dd1[cc + 1]) +
-                                         gg3 * (du2[cc] + d0[cc - 2] + d0[cc + 2] + dd2[cc]) +
-                                         gg4 * (du2[cc - 1] + du2[cc + 1] + du1[cc - 2] + du1[cc + 2] +
-                                                dd1[cc - 2] + dd1[cc + 2] + dd2[cc - 1] + dd2[cc + 1]) +
-                                         gg5 * (du2[cc - 2] + du2[cc + 2] + dd2[cc - 2] + dd2[cc + 2]);
-                        if (gA - gB > 0.f) {
-                            flag = 1;
-                            __hip_atomic_fetch_min(&s_red[0], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_max(&s_red[1], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            __hip_atomic_fetch_min(&s_red[2], cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_fetch_max(&s_red[3], cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
-                }
-                a_nyq[r * tsh + it] = flag;
-            }
-        }
-#ifdef SF_PROFILE
-        tbody += wall_clock64() - tb0;
-#endif
-        lds_barrier();
-    }
-#ifdef SF_PROFILE
-    if (blockIdx.x == 1500 && (tid & 63) == 0) printf("stream front tile 1500 wave %d: body %lld ticks of %lld (100 MHz)\n", wave, tbody, wall_clock64() - tloop0);
-#endif
-    __syncthreads();        // the arena rows written above become visible to the phases that follow
-    if (tid == 0) {
-        atomicMin(&bbox[0], s_red[0]); atomicMax(&bbox[1], s_red[1]);
-        atomicMin(&bbox[2], s_red[2]); atomicMax(&bbox[3], s_red[3]);
-    }
-    __syncthreads();
-}
-
-#ifndef AMAZE_STREAM_FRONT
-#define AMAZE_STREAM_FRONT 0
-#endif
 #ifndef AMAZE_MIN_WAVES
 #define AMAZE_MIN_WAVES 6   // fused kernel: 512 threads x 3 workgroups per CU (51 KB LDS plane each) = 6 waves per SIMD: <= 80 VGPRs (some spill); measured best of {256,384,512,640,768,1024} x {3..8}
 #endif
@@ -499,9 +149,7 @@ amaze_kernel(AmazeArgs a)
     const int tid = threadIdx.x + (G > 1 ? (int)(blockIdx.x % G) * AMAZE_THREADS : 0);
     float *const A = a.arena + (size_t)(blockIdx.x / G) * AMAZE_ARENA_FLOATS;
     int *const bbox = a.bbox + (size_t)(blockIdx.x / G) * 4;   // nyquist bounding box of the tile (min row, max row, min col, max col)
-    constexpr bool STREAM = AMAZE_STREAM_FRONT && FIRST == 0 && LAST == AMAZE_NPHASES - 1 && G == 1;
-    extern __shared__ float dyn_lds[];        // STREAM: the front end's ring buffers; the recurrence plane of the later phases reuses it
-    float *const s_plane = STREAM ? dyn_lds : lds_plane<!STREAM && (RUN(10) || RUN(11) || RUN(15))>();
+    float *const s_plane = lds_plane<RUN(10) || RUN(11) || RUN(15)>();
     float *const rgbgreen = A + O_rgbgreen, *const delhvsqsum = A + O_delhvsqsum;
     float *const dirwts0 = A + O_dirwts0, *const dirwts1 = A + O_dirwts1;
     float *const vcd = A + O_vcd, *const hcd = A + O_hcd, *const vcdalt = A + O_vcdalt, *const hcdalt = A + O_hcdalt;
@@ -546,19 +194,8 @@ amaze_kernel(AmazeArgs a)
         const int rrmax = bottom > height ? height - top : rr1;
         const int ccmax = right > width ? width - left : cc1;
 
-        // full interior tile -> streaming front end instead of phases 0-7
-        bool streamed = false;
-        if constexpr (STREAM) {
-            if (rr1 == ts && cc1 == ts && top >= 0 && left >= 0 && bottom <= height && right <= width) {
-                amaze_stream_front(dyn_lds, A, bbox, s_red, raw, rs, top, left, filters, clip_pt, clip_pt8, tid, NTT);
-                streamed = true;
-#ifdef AMAZE_STREAM_ONLY
-                continue;
-#endif
-            }
-        }
         // ======== phase 0: clear what has to be cleared, tile initialisation ========
-        if constexpr (RUN(0)) if (!streamed) {
+        if constexpr (RUN(0)) {
         // ---- zero the arena (fresh-calloc semantics) ----
         {
             constexpr int NREG = 17;
@@ -640,7 +277,7 @@ amaze_kernel(AmazeArgs a)
         SYNC_AFTER(0);
 
         // ---- P1: gradients (L342-351); 4-lane groups over [0, cc1) ----
-        if constexpr (RUN(1)) if (!streamed)
+        if constexpr (RUN(1))
         FOR_ITEMS(2, rr1 - 2, 4 * ngroups(0, cc1, 4)) {
             const int i = rr * ts + it;
             const float c0 = cfa[i];
@@ -653,7 +290,7 @@ amaze_kernel(AmazeArgs a)
         SYNC_AFTER(1);
 
         // ---- P2: vertical/horizontal colour differences (L380-434) ----
-        if constexpr (RUN(2)) if (!streamed)
+        if constexpr (RUN(2))
         FOR_ITEMS(4, rr1 - 4, 4 * ngroups(4, cc1 - 7, 4)) {
             const int cc = 4 + it, i = rr * ts + cc;
             const float sgn = (fc(filters, rr, cc) & 1) ? -1.f : 1.f;
@@ -697,7 +334,7 @@ amaze_kernel(AmazeArgs a)
         float *const Thi = Dgrbsq1m; // new hcd of lanes 2,3 (plane is free until P11)
         float *const Tlo = Dgrbsq1p; // new hcd of lanes 0,1
         // 3a: lanes 2,3 read only original hcd
-        if constexpr (RUN(3)) if (!streamed)
+        if constexpr (RUN(3))
         FOR_ITEMS(4, rr1 - 4, 2 * ng3) {
             const int g = it >> 1, k = 2 + (it & 1), cc = 4 + 4 * g + k, i = rr * ts + cc;
             const float sgn = (fc(filters, rr, cc) & 1) ? -1.f : 1.f;
@@ -710,7 +347,7 @@ amaze_kernel(AmazeArgs a)
         }
         SYNC_AFTER(3);
         // 3b: lanes 0,1 read the previous group's updated lanes 2,3 at i-2
-        if constexpr (RUN(4)) if (!streamed) {
+        if constexpr (RUN(4)) {
         FOR_ITEMS(4, rr1 - 4, 2 * ng3) {
             const int g = it >> 1, k = it & 1, cc = 4 + 4 * g + k, i = rr * ts + cc;
             const float sgn = (fc(filters, rr, cc) & 1) ? -1.f : 1.f;
@@ -747,7 +384,7 @@ amaze_kernel(AmazeArgs a)
         }
         SYNC_AFTER(4);
         // 3d: commit hcd, cddiffsq
-        if constexpr (RUN(5)) if (!streamed)
+        if constexpr (RUN(5))
         FOR_ITEMS(4, rr1 - 4, 4 * ng3) {
             const int g = it >> 2, k = it & 3, cc = 4 + it, i = rr * ts + cc;
             const float h = (k < 2) ? Tlo[rr * tsh + 2 * g + k] : Thi[rr * tsh + 2 * g + (k - 2)];
@@ -757,7 +394,7 @@ amaze_kernel(AmazeArgs a)
         SYNC_AFTER(5);
 
         // ---- P4: h/v weight at R/B sites (L680-728) ----
-        if constexpr (RUN(6)) if (!streamed) {
+        if constexpr (RUN(6)) {
         FOR_ITEMS(6, rr1 - 6, 4 * ngroups(6, cc1 - 6, 8)) {
             const int par = fc(filters, rr, 2) & 1;
             if (it < 4 * ngroups(6 + par, cc1 - 6, 8)) {
@@ -828,7 +465,7 @@ amaze_kernel(AmazeArgs a)
         SYNC_AFTER(6);
 
         // ---- P6: nyquist flags + bounding box (L806-825): per-workgroup box in LDS, merged into the tile's box in HBM ----
-        if constexpr (RUN(7)) if (!streamed) {
+        if constexpr (RUN(7)) {
         if (threadIdx.x == 0) { s_red[0] = 1 << 30; s_red[1] = 0; s_red[2] = ts + 1; s_red[3] = 0; }
         __syncthreads();
         FOR_ITEMS(6, rr1 - 6, ngroups(6, cc1 - 6, 2)) {
@@ -1219,19 +856,7 @@ hipError_t launch_amaze(const AmazeArgs &a, int grid, hipStream_t stream)
     // (profiles/r1/amaze_split_phase_stats.csv) rather than the fast path.
     const bool split = a.split && !a.tile_list && grid >= a.ntiles;
     if (!split) {
-#if AMAZE_STREAM_FRONT
-        constexpr size_t dyn = (size_t)SF_LDS_FLOATS * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&amaze_kernel<0, AMAZE_NPHASES - 1, 1, AMAZE_MIN_WAVES>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((amaze_kernel<0, AMAZE_NPHASES - 1, 1, AMAZE_MIN_WAVES>), dim3(grid), dim3(AMAZE_THREADS), dyn, stream, a);
-#else
         hipLaunchKernelGGL((amaze_kernel<0, AMAZE_NPHASES - 1, 1, AMAZE_MIN_WAVES>), dim3(grid), dim3(AMAZE_THREADS), 0, stream, a);
-#endif
         return hipGetLastError();
     }
     launch_phase<0, 1>(a, stream);    // clear + tile initialisation (ordered sub-steps)

@@ -419,8 +419,6 @@ hipError_t launch_detail_mask(const MaskArgs &a, hipStream_t s);
 hipError_t launch_gaussian(const GaussArgs &a, hipStream_t s);
 hipError_t launch_gaussian3(float *img, float *tmp, int W, int H, float c0, float c1, hipStream_t s);   // 0.25 <= sigma < 0.6, in place
 hipError_t launch_nlm(const NlmArgs &a, hipStream_t s);
-bool nlm_sweep_supported(const NlmArgs &a);
-hipError_t launch_nlm_sweep(const NlmArgs &a, hipStream_t s);   // nlm_sweep.hip (flush-to-zero TU)
 bool nlm_group_supported(const NlmArgs &a);
 hipError_t launch_nlm_group(const NlmArgs &a, hipStream_t s);   // nlm_sweep.hip: workgroup per tile, a search row of offsets in flight
 

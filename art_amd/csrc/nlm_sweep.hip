@@ -1,4 +1,4 @@
-// art_amd/csrc/nlm_sweep.hip -- NL-means tile kernel v2 (reference: rtengine/nlmeans.cc:138-276).
+// art_amd/csrc/nlm_sweep.hip -- NL-means tile kernel (reference: rtengine/nlmeans.cc:138-276).
 //
 // THIS TRANSLATION UNIT IS COMPILED WITH -fgpu-flush-denormals-to-zero: the reference runs the whole tile loop with
 // MXCSR flush-to-zero on (nlmeans.cc:157-160), so every fp32 result below is flushed by the hardware instead of by
@@ -6,20 +6,20 @@
 // of a flushed operation, a normal-range value, or a denormal exp-LUT entry whose products and sums are themselves
 // flushed by SSE's FTZ -- see DESIGN.md.)
 //
-// One WAVE owns one reference tile (150x150, stride 150 - 2*border) for its whole life; a workgroup is ten waves
-// sharing the 8192-entry exp LUT in LDS, and no workgroup barrier is needed after the LUT load.  For each of the
-// (2*sr+1)^2 offsets, in the reference's order:
-//   load pass  : squared differences for the next 12 anti-diagonal steps, lanes along x (coalesced 48-byte row
-//                segments), written to an LDS ring in *skewed* coordinates [step][row];
-//   sweep      : lane l owns tile rows 3l..3l+2 and walks x = d - l.  The integral image uses the reference's
-//                association (left + up) - (upleft - s) (nlmeans.cc:192-204); `up` of the lane's first row comes from
-//                the previous lane by a wave shift, everything else from registers.  S goes to an 8-column LDS ring,
-//                the four-corner box sum (L219/236) of the pixel whose lower-right corner was just completed replaces
-//                the consumed squared difference in the ring;
-//   accumulate : lanes along x again: weight from the exp LUT (vector / scalar lane forms, L213-243), SW and the
-//                weighted sum are read-modify-written in HBM/L2 with coalesced row segments.
-// Then the final estimate (L252-273).  Offsets are accumulated in order by the same wave, so per-pixel summation
-// order is the reference's.
+// One WORKGROUP per reference tile (150x150, stride 150 - 2*border); the 2*sr+1 offsets of one search row (same ty) are in flight
+// at once, one wave each.  For every chunk of 8 anti-diagonal steps:
+//   stage      : the source rows the chunk needs go to LDS ONCE (strip_a: the pixels themselves, strip_b: the rows shifted by ty
+//                with a 21-column window that covers every tx of the row and the patch-centre shift); all eleven waves take their
+//                squared differences and, later, the weighted sample from there;
+//   sweep      : lane l of a wave owns tile rows 3l..3l+2 and walks x = d - l (skewed coordinates).  The integral image uses the
+//                reference's association (left + up) - (upleft - s) (nlmeans.cc:192-204); `up` of the lane's first row comes from
+//                the previous lane by a wave shift, everything else from registers.  S goes to an 8-column LDS ring, the
+//                four-corner box sum (L219/236) of the pixel whose lower-right corner was just completed goes to the chunk ring;
+//   accumulate : ALL threads walk the chunk's pixels once: mask, SW and the weighted sum are loaded once, the eleven offsets are
+//                applied in the reference's order (tx ascending inside ty; weight from the exp LUT, vector / scalar lane forms of
+//                L213-243) and both accumulators are stored once.
+// Then the final estimate (L252-273).  Per offset that is ~3 B per pixel of global traffic.  Same arithmetic per pixel, same
+// order as the reference: bit-identical.
 #include <hip/hip_runtime.h>
 #include "devmath.h"
 #include "kernels.h"
@@ -29,13 +29,9 @@ namespace artgpu {
 namespace {
 constexpr int TS = 150;          // reference tile size
 constexpr int RPL = 3;           // tile rows per lane
-constexpr int CH = 12;           // anti-diagonal steps per chunk
 constexpr int RP = 151;          // ring pitch (floats per step)
 constexpr int SCOLS = 8;         // S ring depth in columns (needs >= 2*pr + 4)
 constexpr int SP = 153;          // S ring pitch
-constexpr int WAVES = 10;
-constexpr int LB = 8;            // load-pass iterations in flight
-constexpr int AB = 4;            // accumulate-pass iterations in flight
 
 // c ? a : b on the bit patterns: always a select, never a branch
 __device__ __forceinline__ float bsel(bool c, float a, float b)
@@ -46,179 +42,7 @@ __device__ __forceinline__ float bsel(bool c, float a, float b)
 __device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 } // namespace
 
-__global__ void __launch_bounds__(WAVES * 64) nlm_sweep_kernel(NlmArgs a)
-{
-    __shared__ float explut[8192];
-    __shared__ float cring_all[WAVES][CH * RP];
-    __shared__ float sring_all[WAVES][SCOLS * SP];
-    for (int i = threadIdx.x; i < 8192; i += WAVES * 64) explut[i] = a.explut[i];
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * WAVES + wave;
-    if (tile >= a.ntiles_x * a.ntiles_y) return;
-    float *cring = cring_all[wave], *sring = sring_all[wave];
-    const float *__restrict__ src = a.src;
-    const float *__restrict__ mask = a.mask;
-    float *__restrict__ SW = a.SW;
-    float *__restrict__ img = a.img;
 
-    const int tile_y = tile / a.ntiles_x, tile_x = tile - tile_y * a.ntiles_x;
-    const int border = a.border, WW = a.WW, HH = a.HH, W = a.W;
-    const int step = TS - 2 * border;
-    const int start_y = tile_y * step, end_y = min(start_y + TS, HH), TH = end_y - start_y;
-    const int start_x = tile_x * step, end_x = min(start_x + TS, WW), TW = end_x - start_x;
-    const int pr = a.patch_radius, sr = a.search_radius, pr2 = 2 * pr;
-    // vector / scalar lane split of the weight loop (nlmeans.cc:213,230)
-    const int xx0 = start_x + border, xvec_end = end_x - border - 3;
-    const int nvec = xvec_end > xx0 ? (xvec_end - xx0 + 3) / 4 * 4 : 0;
-    const int nsteps = TW + (TH + RPL - 1) / RPL - 1;    // last lane with rows finishes column TW-1 at this step - 1
-    const int row0 = lane * RPL;
-    const bool lane_has_rows = row0 < TH;
-    const bool has1 = row0 + 1 < TH, has2 = row0 + 2 < TH;
-
-    for (int ty = -sr; ty <= sr; ++ty) {
-        for (int tx = -sr; tx <= sr; ++tx) {
-            float left0 = 0.f, left1 = 0.f, left2 = 0.f, upleft0 = 0.f, s2_latest = 0.f;
-            for (int d0 = 0; d0 < nsteps; d0 += CH) {
-                // ---- load pass: squared differences in skewed coordinates (LB iterations of loads in flight)
-                for (int t0 = lane; t0 < TS * CH; t0 += 64 * LB) {
-                    float va[LB], vb[LB];
-#pragma unroll
-                    for (int k = 0; k < LB; ++k) {
-                        const int t = t0 + 64 * k;
-                        const int row = t / CH, s = t - row * CH;
-                        const int xx = d0 + s - row / RPL;
-                        va[k] = vb[k] = 0.f;
-                        if (t < TS * CH && row < TH && xx >= 0 && xx < TW) {
-                            const int gy = min(max(row + start_y, 0), HH - 1), gy2 = min(max(row + ty + start_y, 0), HH - 1);
-                            const int gx = min(max(xx + start_x, 0), WW - 1), gx2 = min(max(xx + tx + start_x, 0), WW - 1);
-                            va[k] = src[(size_t)gy * WW + gx];
-                            vb[k] = src[(size_t)gy2 * WW + gx2];
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < LB; ++k) {
-                        const int t = t0 + 64 * k;
-                        const int row = t / CH, s = t - row * CH;
-                        const float df = va[k] - vb[k];
-                        if (t < TS * CH) cring[s * RP + row] = df * df;
-                    }
-                }
-                wave_fence();
-                // ---- sweep
-                for (int s = 0; s < CH; ++s) {
-                    const int xx = d0 + s - lane;
-                    const float up0 = __shfl_up(s2_latest, 1);
-                    const bool act = lane_has_rows && xx >= 0 && xx < TW;
-                    if (act) {
-                        float *cr = cring + s * RP + row0;
-                        const float sc0 = cr[0], sc1 = cr[1], sc2 = cr[2];
-                        float st0, st1 = 0.f, st2 = 0.f;
-                        if (row0 == 0) st0 = (xx == 0) ? 0.f : left0 + sc0;
-                        else if (xx == 0) st0 = up0 + sc0;
-                        else st0 = (left0 + up0) - (upleft0 - sc0);
-                        if (has1) st1 = (xx == 0) ? st0 + sc1 : (left1 + st0) - (left0 - sc1);
-                        if (has2) st2 = (xx == 0) ? st1 + sc2 : (left2 + st1) - (left1 - sc2);
-                        float *sw = sring + (xx & (SCOLS - 1)) * SP + row0;
-                        sw[0] = st0; sw[1] = st1; sw[2] = st2;
-                        // box sums whose (+pr,+pr) corner is (row, xx): pixel (row - pr, xx - pr)
-                        if (xx >= pr2) {
-                            const float *sb = sring + ((xx - pr2) & (SCOLS - 1)) * SP + row0;   // column xx - 2pr
-                            if (row0 >= pr2) {
-                                cr[0] = ((st0 + sb[-pr2]) - sb[0]) - sw[-pr2];
-                            }
-                            if (has1 && row0 + 1 >= pr2) cr[1] = ((st1 + sb[1 - pr2]) - sb[1]) - sw[1 - pr2];
-                            if (has2 && row0 + 2 >= pr2) cr[2] = ((st2 + sb[2 - pr2]) - sb[2]) - sw[2 - pr2];
-                        }
-                        upleft0 = up0;
-                        left0 = st0; left1 = st1; left2 = st2;
-                        s2_latest = st2;
-                    }
-                    wave_fence();
-                }
-                // ---- accumulate pass: pixel (row - pr, d - row/3 - pr) for ring entry [s][row]; AB iterations in flight
-                for (int t0 = lane; t0 < TS * CH; t0 += 64 * AB) {
-                    float m[AB], sw_[AB], im[AB], sv[AB], dist[AB];
-                    bool ok[AB];
-                    size_t oo[AB], io_[AB];
-                    bool vecl[AB];
-#pragma unroll
-                    for (int k = 0; k < AB; ++k) {
-                        const int t = t0 + 64 * k;
-                        const int row = t / CH, s = t - row * CH;
-                        const int xx = d0 + s - row / RPL;
-                        const int sty = row - pr, stx = xx - pr;
-                        ok[k] = t < TS * CH && row < TH && xx < TW && sty >= border && sty < TH - border && stx >= border && stx < TW - border;
-                        m[k] = sw_[k] = im[k] = sv[k] = dist[k] = 0.f; oo[k] = io_[k] = 0; vecl[k] = false;
-                        if (ok[k]) {
-                            const int py = sty + start_y, px = stx + start_x;
-                            const int y = py - border, x = px - border;
-                            oo[k] = (size_t)y * W + x;
-                            io_[k] = (size_t)y * a.img_stride + x;
-                            vecl[k] = (px - xx0) < nvec;
-                            dist[k] = cring[s * RP + row];
-                            m[k] = mask[oo[k]];
-                            sw_[k] = SW[oo[k]];
-                            im[k] = img[io_[k]];
-                            sv[k] = src[(size_t)(py + ty) * WW + (px + tx)];
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < AB; ++k) {
-                        if (ok[k]) {
-                            const bool vec = vecl[k];
-                            const float dist2 = vec ? sse_max(dist[k], 0.f) : std_max(dist[k], 0.f);
-                            const float dd = dist2 * m[k];
-                            float weight;
-                            if (vec) {
-                                const float clamped = sse_max(sse_min(8190.f, dd), 0.f);
-                                const int idx = (int)clamped;
-                                const float diff = sse_max(sse_min(8191.f, dd), 0.f) - (float)idx;
-                                weight = (diff * explut[idx + 1]) + ((1.f - diff) * explut[idx]);
-                            } else {
-                                if (dd < 0.f || !(dd == dd)) weight = explut[0];
-                                else if (dd > 8190.f) weight = explut[8191];
-                                else {
-                                    const int idx = (int)dd;
-                                    const float diff = dd - (float)idx;
-                                    const float p1 = explut[idx], p2 = explut[idx + 1] - p1;
-                                    weight = p1 + (p2 * diff);
-                                }
-                            }
-                            SW[oo[k]] = sw_[k] + weight;
-                            img[io_[k]] = im[k] + (weight * sv[k]);
-                        }
-                    }
-                }
-                wave_fence();
-            }
-        }
-    }
-    // final estimate (nlmeans.cc:252-273)
-    const int ow = TW - 2 * border, oh = TH - 2 * border;
-    if (ow > 0 && oh > 0)
-        for (int t = lane; t < oh * ow; t += 64) {
-            const int ry = t / ow, rx = t - ry * ow;
-            const int y = start_y + ry, x = start_x + rx;
-            const size_t io = (size_t)y * a.img_stride + x;
-            const float f = 1e-5f + a.SW[(size_t)y * W + x];
-            a.img[io] = (a.img[io] / f) * a.factor;
-        }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// v3: one WORKGROUP per reference tile, the 2*sr+1 offsets of one search row (same ty) in flight at once, one wave each.
-//
-// v2 above spends its time in memory round trips, not in the sweep: per offset it re-reads the source twice for the squared
-// differences and read-modify-writes both accumulators (32 B per pixel per offset, ~290 GB per 45 MP frame through L2).  Here
-//   * the source rows a chunk of anti-diagonals needs are staged ONCE per chunk in LDS (strip_a: the pixels themselves,
-//     strip_b: the rows shifted by ty with a 21-column window that covers every tx of the row and the patch-centre shift);
-//     all eleven waves take their squared differences and, later, the weighted sample from there;
-//   * each wave sweeps the integral image of its own offset exactly as in v2 (same association, same ring), taking the squared
-//     differences straight from the strips (v2's separate pass that filled the ring with them is gone);
-//   * then ALL threads walk the chunk's pixels once: mask, SW and the weighted sum are loaded once, the eleven offsets are applied
-//     in the reference's order (tx ascending inside ty), and both accumulators are stored once -- 1/11 of the read-modify-writes.
-// Per offset that is ~3 B per pixel of global traffic instead of 32.  Same arithmetic per pixel, same order: bit-identical.
 namespace {
 constexpr int G_CH = 8;                 // anti-diagonal steps per chunk
 constexpr int G_NW = 11;                // waves per workgroup = offsets in flight (2 * 5 + 1)
@@ -334,7 +158,7 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
             }
         }
         if (sweeper) {
-            // ---- sweep (v2's recurrence, written without branches: every LDS read of a step is an unconditional load issued up
+            // ---- sweep (the recurrence, written without branches: every LDS read of a step is an unconditional load issued up
             //      front -- any address stays inside this kernel's LDS block -- and conditions only select values or mask stores, so a
             //      step is one LDS round trip; the row above comes from the previous lane through a DPP wave shift)
             for (int s = 0; s < G_CH; ++s) {
@@ -459,15 +283,6 @@ hipError_t launch_nlm_group(const NlmArgs &a, hipStream_t s)
         attr_set = true;
     }
     hipLaunchKernelGGL(nlm_group_kernel, dim3(a.ntiles_x * a.ntiles_y), dim3(G_NT), dyn, s, a);
-    return hipGetLastError();
-}
-
-bool nlm_sweep_supported(const NlmArgs &a) { return 2 * a.patch_radius + 4 <= SCOLS && a.border * 2 < TS; }
-
-hipError_t launch_nlm_sweep(const NlmArgs &a, hipStream_t s)
-{
-    const int ntiles = a.ntiles_x * a.ntiles_y;
-    hipLaunchKernelGGL(nlm_sweep_kernel, dim3((ntiles + WAVES - 1) / WAVES), dim3(WAVES * 64), 0, s, a);
     return hipGetLastError();
 }
 

@@ -246,99 +246,6 @@ __global__ void __launch_bounds__(256) nlm_zero_kernel(NlmArgs a)
     }
 }
 
-constexpr int NLM_TS = 150, NLM_RING = 16, NLM_THREADS = 192;
-__global__ void __launch_bounds__(NLM_THREADS) nlm_tile_kernel(NlmArgs a)
-{
-    __shared__ float ring[NLM_RING][NLM_TS + 2];
-    __shared__ float explut[8192];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < 8192; i += NLM_THREADS) explut[i] = a.explut[i];
-    const int tile_y = blockIdx.x / a.ntiles_x, tile_x = blockIdx.x - tile_y * a.ntiles_x;
-    const int border = a.border, WW = a.WW, HH = a.HH, W = a.W;
-    const int step = NLM_TS - 2 * border;
-    const int start_y = tile_y * step, end_y = min(start_y + NLM_TS, HH), TH = end_y - start_y;
-    const int start_x = tile_x * step, end_x = min(start_x + NLM_TS, WW), TW = end_x - start_x;
-    const int pr = a.patch_radius, sr = a.search_radius;
-    const int yy = tid;                         // this lane's row of the tile
-    const bool rowok = yy < TH;
-    const int gy = min(max(yy + start_y, 0), HH - 1);
-    // vector / scalar lane split of the weight loop (nlmeans.cc:213,230)
-    const int xx0 = start_x + border, xvec_end = end_x - border - 3;
-    const int nvec = xvec_end > xx0 ? (xvec_end - xx0 + 3) / 4 * 4 : 0;
-    __syncthreads();
-    for (int ty = -sr; ty <= sr; ++ty) {
-        const int gy2 = min(max(yy + ty + start_y, 0), HH - 1);
-        for (int tx = -sr; tx <= sr; ++tx) {
-            for (int d = 0; d < TW + TH - 1; ++d) {
-                const int xx = d - yy;
-                float st = 0.f;
-                if (rowok && xx >= 0 && xx < TW) {
-                    if (!(xx == 0 && yy == 0)) {
-                        const int gx = min(max(xx + start_x, 0), WW - 1), gx2 = min(max(xx + tx + start_x, 0), WW - 1);
-                        const float sc = ftz(sqr(ftz(a.src[(size_t)gy * WW + gx] - a.src[(size_t)gy2 * WW + gx2])));
-                        const float left = xx > 0 ? ring[(d - 1) & (NLM_RING - 1)][yy] : 0.f;
-                        const float up = yy > 0 ? ring[(d - 1) & (NLM_RING - 1)][yy - 1] : 0.f;
-                        const float upleft = (yy > 0 && xx > 0) ? ring[(d - 2) & (NLM_RING - 1)][yy - 1] : 0.f;
-                        // first row / column: running sums; interior: (left + up) - (upleft - score)
-                        if (yy == 0) st = ftz(left + sc);
-                        else if (xx == 0) st = ftz(up + sc);
-                        else st = ftz(ftz(left + up) - ftz(upleft - sc));
-                    }
-                    ring[d & (NLM_RING - 1)][yy] = st;
-                }
-                __syncthreads();
-                // box sums whose (+pr,+pr) corner is (yy, xx): pixel (sty, stx) = (yy - pr, xx - pr)
-                if (rowok && xx >= 0 && xx < TW) {
-                    const int sty = yy - pr, stx = xx - pr;
-                    const int py = sty + start_y, px = stx + start_x; // padded coordinates (yy_ref, xx_ref)
-                    if (py >= start_y + border && py < end_y - border && px >= start_x + border && px < end_x - border) {
-                        const float cA = st;                                                          // St[sty+pr][stx+pr]
-                        const float cB = ring[(d - 4 * pr) & (NLM_RING - 1)][yy - 2 * pr];            // St[sty-pr][stx-pr]
-                        const float cC = ring[(d - 2 * pr) & (NLM_RING - 1)][yy];                     // St[sty+pr][stx-pr]
-                        const float cD = ring[(d - 2 * pr) & (NLM_RING - 1)][yy - 2 * pr];            // St[sty-pr][stx+pr]
-                        float dist2 = ftz(ftz(ftz(cA + cB) - cC) - cD);
-                        const bool vec = (px - xx0) < nvec;
-                        dist2 = vec ? sse_max(dist2, 0.f) : std_max(dist2, 0.f);
-                        const int y = py - border, x = px - border;
-                        const float dd = ftz(dist2 * a.mask[(size_t)y * W + x]);
-                        float weight;
-                        if (vec) {
-                            const float clamped = sse_max(sse_min(8190.f, dd), 0.f);
-                            const int idx = (int)clamped;
-                            const float diff = ftz(sse_max(sse_min(8191.f, dd), 0.f) - (float)idx);
-                            weight = ftz(ftz(diff * explut[idx + 1]) + ftz(ftz(1.f - diff) * explut[idx]));
-                        } else {
-                            if (dd < 0.f || !(dd == dd)) weight = explut[0];
-                            else if (dd > 8190.f) weight = explut[8191];
-                            else {
-                                const int idx = (int)dd;
-                                const float diff = ftz(dd - (float)idx);
-                                const float p1 = explut[idx], p2 = ftz(explut[idx + 1] - p1);
-                                weight = ftz(p1 + ftz(p2 * diff));
-                            }
-                        }
-                        const size_t o = (size_t)y * W + x;
-                        a.SW[o] = ftz(a.SW[o] + weight);
-                        const float Yv = ftz(weight * a.src[(size_t)(py + ty) * WW + (px + tx)]);
-                        const size_t io = (size_t)y * a.img_stride + x;
-                        a.img[io] = ftz(a.img[io] + Yv);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    // final estimate (nlmeans.cc:252-273)
-    for (int t = tid; t < (TH - 2 * border) * (TW - 2 * border); t += NLM_THREADS) {
-        const int ry = t / (TW - 2 * border), rx = t - ry * (TW - 2 * border);
-        const int y = start_y + ry, x = start_x + rx; // = (yy_ref - border), (xx_ref - border)
-        if (TH - 2 * border <= 0 || TW - 2 * border <= 0) break;
-        const size_t io = (size_t)y * a.img_stride + x;
-        const float f = ftz(1e-5f + a.SW[(size_t)y * W + x]);
-        a.img[io] = ftz(ftz(a.img[io] / f) * a.factor);
-    }
-}
-
 static int fgrid(long long n) { long long g = (n + 255) / 256; return (int)(g < 16384 ? g : 16384); }
 hipError_t launch_detail_mask(const MaskArgs &a, hipStream_t s)
 {
@@ -387,13 +294,10 @@ hipError_t launch_nlm(const NlmArgs &a, hipStream_t s)
     const long long npad = (long long)a.WW * a.HH;
     hipLaunchKernelGGL(nlm_prepare_kernel, dim3(fgrid(npad > 8192 ? npad : 8192)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(nlm_zero_kernel, dim3(fgrid((long long)a.W * a.H)), dim3(256), 0, s, a);
-    // v2 (one wave per tile, nlm_sweep.hip) handles patch radii up to 2 (scale >= 1); the v1 workgroup-per-tile kernel is
-    // the exact general path (and ARTGPU_NLM_V1=1 forces it for A/B runs)
-    static const bool force_v1 = getenv("ARTGPU_NLM_V1") != nullptr, force_v2 = getenv("ARTGPU_NLM_V2") != nullptr;
-    if (!force_v1 && !force_v2 && nlm_group_supported(a)) return launch_nlm_group(a, s);     // v3: a search row of offsets per workgroup pass
-    if (!force_v1 && nlm_sweep_supported(a)) return launch_nlm_sweep(a, s);
-    hipLaunchKernelGGL(nlm_tile_kernel, dim3(a.ntiles_x * a.ntiles_y), dim3(NLM_THREADS), 0, s, a);
-    return hipGetLastError();
+    // one workgroup per reference tile, a search row of offsets in flight (nlm_sweep.hip); covers every radius the reference
+    // can ask for at scale >= 1 (search <= 5, patch 1..2, nlmeans.cc:62-66) -- anything else is a caller error, not a slow path
+    if (!nlm_group_supported(a)) return hipErrorInvalidValue;
+    return launch_nlm_group(a, s);
 }
 
 } // namespace artgpu
