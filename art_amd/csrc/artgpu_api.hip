@@ -53,6 +53,9 @@ struct artgpu_ctx {
     long opt_amaze_zero_mask = 0x81f0;
     int opt_amaze_zero_frame = 16;
     int opt_amaze_poison = -1;     // >= 0: byte pattern the arenas are filled with before the launch
+    int opt_rcd_path = 0;          // 0: LDS streaming kernel; 1: arena kernel (rcd.hip)
+    int opt_rcd_rows = 8;          // rows per iteration of the streaming kernel (4 or 8)
+    int *rcd_counter = nullptr;    // RCD streaming kernel: tile counter
     int curve_tail_kind = ARTGPU_CURVE_TAIL_HOST;   // artgpu_set_curve_tail
     double curve_tail_y = 1.0;
     float *lut = nullptr; // 65536-entry tone LUT on the device
@@ -261,6 +264,7 @@ int artgpu_destroy(artgpu_ctx *ctx)
     if (ctx->lut) (void)hipFree(ctx->lut);
     if (ctx->bbox) (void)hipFree(ctx->bbox);
     if (ctx->amz_lists) (void)hipFree(ctx->amz_lists);
+    if (ctx->rcd_counter) (void)hipFree(ctx->rcd_counter);
     for (int k = 0; k < artgpu_ctx::NPOOL; ++k)
         if (ctx->pool[k]) (void)hipFree(ctx->pool[k]);
     for (int k = 0; k < 3; ++k)
@@ -329,6 +333,8 @@ int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value)
     else if (n == "amaze_zero_mask") ctx->opt_amaze_zero_mask = value;
     else if (n == "amaze_zero_frame") ctx->opt_amaze_zero_frame = (int)value;
     else if (n == "amaze_poison") ctx->opt_amaze_poison = (int)value;
+    else if (n == "rcd_path") { if (value < 0 || value > 1) return fail(ctx, ARTGPU_EINVAL, "rcd_path: 0 or 1"); ctx->opt_rcd_path = (int)value; }
+    else if (n == "rcd_rows") { if (value != 4 && value != 8) return fail(ctx, ARTGPU_EINVAL, "rcd_rows: 4 or 8"); ctx->opt_rcd_rows = (int)value; }
     else return fail(ctx, ARTGPU_EINVAL, "set_option: unknown option '%s'", name);
     return ARTGPU_OK;
 }
@@ -499,16 +505,36 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
         const int tileSizeN = RCD_TS - 2 * RCD_BORDER;
         const int numTh = H / tileSizeN + ((H % tileSizeN) ? 1 : 0), numTw = W / tileSizeN + ((W % tileSizeN) ? 1 : 0);
         const int ntiles = numTh * numTw;
-        const int grid = ntiles < MAX_TILE_WORKGROUPS ? ntiles : MAX_TILE_WORKGROUPS;
-        rc = ensure(ctx, &ctx->arena, &ctx->arena_bytes, (size_t)grid * RCD_ARENA_FLOATS * sizeof(float));
-        if (rc) return rc;
-        RcdArgs a;
-        a.raw = d.raw; a.raw_stride = d.raw_stride;
-        a.red = d.r; a.green = d.g; a.blue = d.b; a.out_stride = d.out_stride;
-        a.arena = ctx->arena;
-        a.W = W; a.H = H; a.numTw = numTw; a.ntiles = ntiles;
-        a.filters = filters;
-        HIPCHK(ctx, launch_rcd(a, grid, ctx->stream));
+        if (ctx->opt_rcd_path == 0) {
+            // persistent workgroups take tiles from a counter; as many as the CUs hold at once
+            if (ctx->num_cus <= 0) {
+                hipDeviceProp_t prop;
+                HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+                ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            }
+            if (!ctx->rcd_counter) HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->rcd_counter), 64));
+            HIPCHK(ctx, hipMemsetAsync(ctx->rcd_counter, 0, sizeof(int), ctx->stream));
+            RcdStreamArgs a;
+            a.raw = d.raw; a.raw_stride = d.raw_stride;
+            a.red = d.r; a.green = d.g; a.blue = d.b; a.out_stride = d.out_stride;
+            a.W = W; a.H = H; a.numTw = numTw; a.ntiles = ntiles;
+            a.filters = filters;
+            a.vec2 = d.out_stride % 2 == 0 && (reinterpret_cast<uintptr_t>(d.r) | reinterpret_cast<uintptr_t>(d.g) | reinterpret_cast<uintptr_t>(d.b)) % 8 == 0;
+            a.counter = ctx->rcd_counter;
+            const int R = ctx->opt_rcd_rows;
+            HIPCHK(ctx, launch_rcd_stream(a, R, std::min(ntiles, ctx->num_cus * rcd_stream_workgroups_per_cu(R)), ctx->stream));
+        } else {
+            const int grid = ntiles < MAX_TILE_WORKGROUPS ? ntiles : MAX_TILE_WORKGROUPS;
+            rc = ensure(ctx, &ctx->arena, &ctx->arena_bytes, (size_t)grid * RCD_ARENA_FLOATS * sizeof(float));
+            if (rc) return rc;
+            RcdArgs a;
+            a.raw = d.raw; a.raw_stride = d.raw_stride;
+            a.red = d.r; a.green = d.g; a.blue = d.b; a.out_stride = d.out_stride;
+            a.arena = ctx->arena;
+            a.W = W; a.H = H; a.numTw = numTw; a.ntiles = ntiles;
+            a.filters = filters;
+            HIPCHK(ctx, launch_rcd(a, grid, ctx->stream));
+        }
         bord = RCD_BORDER; // rcd_demosaic.cc:342
     }
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream));

@@ -80,6 +80,21 @@ struct RcdArgs {
 __global__ void rcd_tiles_kernel(RcdArgs a);
 hipError_t launch_rcd(const RcdArgs &a, int grid, hipStream_t stream);
 
+// ---- RCD with the tile state in LDS (rcd_stream.hip) ----
+struct RcdStreamArgs {
+    const float *raw;
+    size_t raw_stride;
+    float *red, *green, *blue;
+    size_t out_stride;
+    int W, H;
+    int numTw, ntiles;
+    unsigned filters;
+    int vec2;           // out planes 8-byte aligned with an even stride: column pairs are stored as one 64-bit word
+    int *counter;       // zeroed before the launch: next tile = gridDim.x + counter++
+};
+int rcd_stream_workgroups_per_cu(int rows_per_iter);
+hipError_t launch_rcd_stream(const RcdStreamArgs &a, int rows_per_iter, int grid, hipStream_t stream);
+
 // ---- X-Trans Markesteijn demosaic (xtrans.hip) ----
 #define XTRANS_TS 114
 #ifndef XTRANS_THREADS
