@@ -53,7 +53,6 @@ struct artgpu_ctx {
     long opt_amaze_zero_mask = 0x81f0;
     int opt_amaze_zero_frame = 16;
     int opt_amaze_poison = -1;     // >= 0: byte pattern the arenas are filled with before the launch
-    int opt_rcd_path = 0;          // 0: LDS streaming kernel; 1: arena kernel (rcd.hip)
     int opt_rcd_rows = 8;          // rows per iteration of the streaming kernel (4 or 8)
     int *rcd_counter = nullptr;    // RCD streaming kernel: tile counter
     int curve_tail_kind = ARTGPU_CURVE_TAIL_HOST;   // artgpu_set_curve_tail
@@ -333,7 +332,6 @@ int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value)
     else if (n == "amaze_zero_mask") ctx->opt_amaze_zero_mask = value;
     else if (n == "amaze_zero_frame") ctx->opt_amaze_zero_frame = (int)value;
     else if (n == "amaze_poison") ctx->opt_amaze_poison = (int)value;
-    else if (n == "rcd_path") { if (value < 0 || value > 1) return fail(ctx, ARTGPU_EINVAL, "rcd_path: 0 or 1"); ctx->opt_rcd_path = (int)value; }
     else if (n == "rcd_rows") { if (value != 4 && value != 8) return fail(ctx, ARTGPU_EINVAL, "rcd_rows: 4 or 8"); ctx->opt_rcd_rows = (int)value; }
     else return fail(ctx, ARTGPU_EINVAL, "set_option: unknown option '%s'", name);
     return ARTGPU_OK;
@@ -502,10 +500,10 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
         if ((rc = vng4_dev(ctx, d.raw, d.raw_stride, d.r, d.g, d.b, d.out_stride, W, H, filters))) return rc;
         bord = 3; // vng4_demosaic_RT.cc:384
     } else {
-        const int tileSizeN = RCD_TS - 2 * RCD_BORDER;
+        const int tileSizeN = RCD_TS - 2 * RCD_BORDER;      // the reference's tile grid (rcd_demosaic.cc:82-87)
         const int numTh = H / tileSizeN + ((H % tileSizeN) ? 1 : 0), numTw = W / tileSizeN + ((W % tileSizeN) ? 1 : 0);
         const int ntiles = numTh * numTw;
-        if (ctx->opt_rcd_path == 0) {
+        {
             // persistent workgroups take tiles from a counter; as many as the CUs hold at once
             if (ctx->num_cus <= 0) {
                 hipDeviceProp_t prop;
@@ -523,17 +521,6 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
             a.counter = ctx->rcd_counter;
             const int R = ctx->opt_rcd_rows;
             HIPCHK(ctx, launch_rcd_stream(a, R, std::min(ntiles, ctx->num_cus * rcd_stream_workgroups_per_cu(R)), ctx->stream));
-        } else {
-            const int grid = ntiles < MAX_TILE_WORKGROUPS ? ntiles : MAX_TILE_WORKGROUPS;
-            rc = ensure(ctx, &ctx->arena, &ctx->arena_bytes, (size_t)grid * RCD_ARENA_FLOATS * sizeof(float));
-            if (rc) return rc;
-            RcdArgs a;
-            a.raw = d.raw; a.raw_stride = d.raw_stride;
-            a.red = d.r; a.green = d.g; a.blue = d.b; a.out_stride = d.out_stride;
-            a.arena = ctx->arena;
-            a.W = W; a.H = H; a.numTw = numTw; a.ntiles = ntiles;
-            a.filters = filters;
-            HIPCHK(ctx, launch_rcd(a, grid, ctx->stream));
         }
         bord = RCD_BORDER; // rcd_demosaic.cc:342
     }

@@ -61,26 +61,9 @@ struct AmazeStreamArgs {
 };
 hipError_t launch_amaze_stream(const AmazeStreamArgs &s, int grid, hipStream_t stream);
 
-// ---- RCD (rcd.hip) ----
-constexpr int RCD_THREADS = 256;
+// ---- RCD (rcd_stream.hip: the tile state in LDS) ----
 constexpr int RCD_TS = 194;
 constexpr int RCD_BORDER = 9;
-constexpr int RCD_ARENA_FLOATS = ((RCD_TS * RCD_TS * 13 / 2) + 3) & ~3; // cfa, rgb[3], VH_Dir + 3 half planes
-
-struct RcdArgs {
-    const float *raw;
-    size_t raw_stride;
-    float *red, *green, *blue;
-    size_t out_stride;
-    float *arena;
-    int W, H;
-    int numTw, ntiles;
-    unsigned filters;
-};
-__global__ void rcd_tiles_kernel(RcdArgs a);
-hipError_t launch_rcd(const RcdArgs &a, int grid, hipStream_t stream);
-
-// ---- RCD with the tile state in LDS (rcd_stream.hip) ----
 struct RcdStreamArgs {
     const float *raw;
     size_t raw_stride;

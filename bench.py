@@ -338,7 +338,7 @@ def main() -> None:
             "completion_records": len(records),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "xtrans_tiles_kernel" if xtrans else "amaze_stream_kernel" if method == capi.BAYER_AMAZE else "rcd_tiles_kernel",
+            "bound": "hbm", "kernel": "xtrans_tiles_kernel" if xtrans else "amaze_stream_kernel" if method == capi.BAYER_AMAZE else "rcd_stream_kernel",
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "traffic_raw_counters": traffic_raw,
             # the whole step against the same contract (MP/s x 16 B / 8 TB/s), next to the dominant kernel's fraction

@@ -34,26 +34,23 @@ def test_amaze_bit_exact(gpu_ctx, w, h, filt, gain, border):
 @pytest.fixture
 def rcd_options(gpu_ctx):
     yield gpu_ctx
-    gpu_ctx.set_option("rcd_path", 0)
     gpu_ctx.set_option("rcd_rows", 8)
 
 
-@pytest.mark.parametrize("rows", [4, 8, 0])
+@pytest.mark.parametrize("rows", [4, 8])
 @pytest.mark.parametrize("w,h,filt,noise", [(400, 300, synth.FILTERS_RGGB, 1024), (401, 331, synth.FILTERS_GRBG, 64),
                                             (64, 64, synth.FILTERS_BGGR, 1024), (64, 64, synth.FILTERS_GBRG, 1024),
                                             (640, 480, synth.FILTERS_GBRG, 0), (1233, 907, synth.FILTERS_RGGB, 4096),
                                             (195, 204, synth.FILTERS_BGGR, 512)])
 def test_rcd_bit_exact(rcd_options, w, h, filt, noise, rows):
-    """rows 4 / 8: the LDS streaming kernel (rcd_stream.hip) with that many rows per iteration, called three times in a row
-    (rings and the tile counter carry over); rows 0: the arena kernel (rcd.hip)."""
+    """the LDS streaming kernel (rcd_stream.hip) with 4 / 8 rows per iteration, called three times in a row (the rings and the tile
+    counter carry over)"""
     from art_amd import capi
     ctx = rcd_options
-    ctx.set_option("rcd_path", 0 if rows else 1)
-    if rows:
-        ctx.set_option("rcd_rows", rows)
+    ctx.set_option("rcd_rows", rows)
     raw = synth.bayer_frame(w, h, filt, seed=w * 3 + h, noise=noise)
     ref = oracle_lib.rcd(raw, filt)
-    for _ in range(3 if rows else 1):
+    for _ in range(3):
         got = ctx.demosaic_bayer_host(capi.BAYER_RCD, raw, filt, 1.0, 4)
         assert _diff(got, ref) == [0, 0, 0]
 

@@ -64,6 +64,19 @@ def test_config2_and_3_stages_45mp_bit_exact(gpu_ctx):
         assert err.max() <= DCT_ABS_BOUND and np.median(err[::7, ::5]) <= DCT_MEDIAN_BOUND
 
 
+def test_rcd_45mp_bit_exact(gpu_ctx):
+    """BASELINE configs[1] with RCD: the whole 8192x5464 frame (1504 reference tiles, partial ones at the right / bottom edge)"""
+    W, H = 8192, 5464
+    raw = synth.bayer_frame(W, H, synth.FILTERS_GRBG, seed=3)
+    d_raw = torch.from_numpy(raw).cuda()
+    d_out, out = _dev_planes(H, W)
+    gpu_ctx.demosaic_bayer(capi.BAYER_RCD, capi.device_plane(d_raw), synth.FILTERS_GRBG, 1.0, 4, out)
+    gpu_ctx.synchronize()
+    ref = O.rcd(raw, synth.FILTERS_GRBG)
+    for t, r in zip(d_out, ref):
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))
+
+
 def test_config4_stages_45mp_bit_exact_without_dct(gpu_ctx):
     """BASELINE configs[3]'s per-frame pipe at full size -- AMaZE, getImage + matrix, ImProcFunctions::denoise with guided chroma smoothing
     and NL-means, exposure, tone curve -- with the DCT detail-recovery stage switched off on both sides: everything else is bit for bit."""
