@@ -52,3 +52,57 @@ def complete_batch(dist, device, rank: int, frames_done: int, status: int, check
         v = [int(x) for x in r.cpu().tolist()]
         out.append({"rank": v[0], "frames": v[1], "status": v[2], "checksum": v[3] & 0xFFFFFFFFFFFFFFFF, "elapsed_us": v[4]})
     return out, max(o["elapsed_us"] for o in out) / 1e6
+
+
+def _records_to_dicts(rows):
+    out = []
+    for v in rows:
+        out.append({"rank": int(v[0]), "frames": int(v[1]), "status": int(v[2]), "checksum": int(v[3]) & 0xFFFFFFFFFFFFFFFF, "elapsed_us": int(v[4])})
+    return out, max(o["elapsed_us"] for o in out) / 1e6
+
+
+def complete_batch_rccl(ctx, dist, device, rank: int, world: int, frames_done: int, status: int, checksum: int, elapsed_s: float):
+    """The same completion step through the library's own entry point: `artgpu_batch_complete` all-gathers the records over an
+    RCCL communicator that this function creates with librccl's C API (the unique id travels over the already initialised
+    torch.distributed group).  Returns (records, max_elapsed_s, "rccl-capi"), or falls back to complete_batch() -- on ALL ranks, agreed
+    by a MIN-reduce -- when some rank cannot load librccl."""
+    import ctypes as C
+    import torch
+
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+        try:
+            rccl = C.CDLL(name)
+            break
+        except OSError:
+            continue
+    ok = torch.tensor([1 if rccl is not None and hasattr(ctx, "batch_complete") else 0], dtype=torch.int32, device=device)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        recs, el = complete_batch(dist if world > 1 else None, device, rank, frames_done, status, checksum, elapsed_s)
+        return recs, el, "torch.distributed"
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+        raise RuntimeError("ncclGetUniqueId failed")
+    wire = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=device)
+    if world > 1:
+        dist.broadcast(wire, src=0)
+    C.memmove(C.byref(uid), bytes(wire.cpu().tolist()), 128)
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(device)
+    if rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) != 0:
+        raise RuntimeError("ncclCommInitRank failed")
+    try:
+        cs = checksum - (1 << 64) if checksum >= (1 << 63) else checksum
+        rows = ctx.batch_complete([rank, frames_done, status, cs, int(elapsed_s * 1e6), 0, 0, 0], nranks=world, rccl_comm=comm)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+    recs, el = _records_to_dicts(rows)
+    return recs, el, "rccl-capi"

@@ -144,6 +144,7 @@ def _load():
     lib.artgpu_ordered_sum_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float)]
     lib.artgpu_saturation_vibrance.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.artgpu_set_batch_lanes.argtypes = [C.c_void_p, C.c_int]
+    lib.artgpu_batch_complete.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.artgpu_rgb2out_matrix.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(RGB), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]
     lib.artgpu_get_scanlines.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int]
     lib.artgpu_guided_filter.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(Plane), C.POINTER(Plane), C.c_int, C.c_float, C.c_int]
@@ -182,7 +183,7 @@ EXPORTS = ["artgpu_set_option", "artgpu_get_option", "artgpu_set_curve_tail", "a
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter", "artgpu_hsl_equalizer", "artgpu_log_encoding", "artgpu_rgb_to_lab", "artgpu_lab_to_rgb", "artgpu_lab_histogram", "artgpu_lab_adjustments", "artgpu_dual_demosaic_bayer"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_batch_complete", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter", "artgpu_hsl_equalizer", "artgpu_log_encoding", "artgpu_rgb_to_lab", "artgpu_lab_to_rgb", "artgpu_lab_histogram", "artgpu_lab_adjustments", "artgpu_dual_demosaic_bayer"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -398,6 +399,13 @@ class Context:
 
     def set_batch_lanes(self, lanes: int):
         self._chk(LIB.artgpu_set_batch_lanes(self._h, int(lanes)))
+
+    def batch_complete(self, record, nranks: int = 1, rccl_comm=None):
+        """All-gather of the ranks' 8-word completion records over an RCCL communicator (None: single rank)."""
+        rec = (C.c_int64 * 8)(*[int(v) for v in record])
+        out = (C.c_int64 * (8 * nranks))()
+        self._chk(LIB.artgpu_batch_complete(self._h, rccl_comm, int(nranks), rec, out))
+        return [list(out[8 * r:8 * r + 8]) for r in range(nranks)]
 
     def pipeline_run(self, raw: Plane, params: PipelineParams, out: RGB):
         self._chk(LIB.artgpu_pipeline_run(self._h, C.byref(raw), C.byref(params), C.byref(out)))

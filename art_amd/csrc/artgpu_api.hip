@@ -2,6 +2,7 @@
 // device buffers, staging for host-pointer calls, kernel launches, error reporting.
 // There is no CPU fallback here: every entry point either runs the HIP kernels or fails.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdarg>
@@ -832,7 +833,7 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_NSLOTS };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_BATCH, P_NSLOTS };
 static_assert(P_NSLOTS <= artgpu_ctx::NPOOL, "grow artgpu_ctx::pool");
 
 struct DevDecomp {
@@ -2395,6 +2396,47 @@ int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, con
     for (std::thread &t : threads) t.join();
     for (int k = 0; k < L; ++k)
         if (rcs[k]) return fail(ctx, rcs[k], "batch_run: lane %d: %s", k, k == 0 ? ctx->err.c_str() : ctx->lanes[k - 1]->err.c_str());
+    return ARTGPU_OK;
+}
+
+// The one collective of a multi-GPU batch: an all-gather of the ranks' completion records over the caller's RCCL communicator.
+// RCCL is bound at run time (dlopen), so the library has no link-time dependency on it and single-GPU users never load it.
+int artgpu_batch_complete(artgpu_ctx *ctx, void *rccl_comm, int nranks, const int64_t record[ARTGPU_BATCH_RECORD_WORDS], int64_t *all_records)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!record || !all_records || nranks < 1) return fail(ctx, ARTGPU_EINVAL, "batch_complete: bad argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // the record describes work that has finished
+    if (!rccl_comm) {
+        if (nranks != 1) return fail(ctx, ARTGPU_EINVAL, "batch_complete: %d ranks need a communicator", nranks);
+        std::memcpy(all_records, record, sizeof(int64_t) * ARTGPU_BATCH_RECORD_WORDS);
+        return ARTGPU_OK;
+    }
+    // ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t, ncclComm_t, hipStream_t)
+    typedef int (*allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+    typedef const char *(*errstr_fn)(int);
+    static allgather_fn allgather = nullptr;
+    static errstr_fn errstr = nullptr;
+    if (!allgather) {
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) return fail(ctx, ARTGPU_EUNSUPPORTED, "batch_complete: cannot load librccl (%s)", dlerror());
+        allgather = reinterpret_cast<allgather_fn>(dlsym(h, "ncclAllGather"));
+        errstr = reinterpret_cast<errstr_fn>(dlsym(h, "ncclGetErrorString"));
+        if (!allgather) return fail(ctx, ARTGPU_EUNSUPPORTED, "batch_complete: librccl has no ncclAllGather");
+    }
+    constexpr int NCCL_INT64 = 4;       // ncclDataType_t (nccl.h): ncclInt8 0, ncclUint8 1, ncclInt32 2, ncclUint32 3, ncclInt64 4
+    const size_t words = ARTGPU_BATCH_RECORD_WORDS;
+    float *buf;
+    int rc = pool_get(ctx, P_BATCH, (size_t)(nranks + 1) * words * sizeof(int64_t), &buf);
+    if (rc) return rc;
+    int64_t *d_send = reinterpret_cast<int64_t *>(buf), *d_recv = d_send + words;
+    HIPCHK(ctx, hipMemcpyAsync(d_send, record, words * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    const int nrc = allgather(d_send, d_recv, words, NCCL_INT64, rccl_comm, ctx->stream);
+    if (nrc != 0) return fail(ctx, ARTGPU_EHIP, "batch_complete: ncclAllGather failed: %s", errstr ? errstr(nrc) : "?");
+    HIPCHK(ctx, hipMemcpyAsync(all_records, d_recv, (size_t)nranks * words * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return ARTGPU_OK;
 }
 

@@ -270,8 +270,13 @@ def main() -> None:
     # completion step: all-gather of the 64-byte per-rank records (the batch's only collective),
     # elapsed = MAX over ranks
     from art_amd import batch
-    records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, args.steps, 0,
-                                            batch.checksum64([int(d_out[1][H // 2, W // 2].item())]), t1 - t0)
+    cs = batch.checksum64([int(d_out[1][H // 2, W // 2].item())])
+    if "WORLD_SIZE" in os.environ and not os.environ.get("ARTGPU_BENCH_TORCH_GATHER"):
+        # under a launcher (any N): through the C ABI, over an RCCL communicator (artgpu_batch_complete)
+        records, elapsed, gather_via = batch.complete_batch_rccl(ctx, dist, dev, rank, world, args.steps, 0, cs, t1 - t0)
+    else:
+        records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, args.steps, 0, cs, t1 - t0)
+        gather_via = "torch.distributed" if world > 1 else "single process"
 
     stage_ms = {nm: round(statistics.mean(ev[i].elapsed_time(ev[i + 1]) for ev in stage_ev), 4) for i, nm in enumerate(stage_names)}
     mp = W * H / 1e6
@@ -335,7 +340,7 @@ def main() -> None:
             "stage_ms": stage_ms,
             "frame": f"{W}x{H}", "frames_per_step": world * args.lanes, "lanes_per_gpu": args.lanes,
             "parallelism": f"frame-per-gpu x{world}" + (f", {args.lanes} frames in flight per GPU" if args.lanes > 1 else ""),
-            "completion_records": len(records),
+            "completion_records": len(records), "completion_via": gather_via,
         },
         "roofline": {
             "bound": "hbm", "kernel": "xtrans_tiles_kernel" if xtrans else "amaze_stream_kernel" if method == capi.BAYER_AMAZE else "rcd_stream_kernel",

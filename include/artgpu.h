@@ -463,6 +463,15 @@ int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, con
  * the same bits.  On return the secondary lanes have completed; lane 0 stays ordered on the context's stream as before. */
 int artgpu_set_batch_lanes(artgpu_ctx *ctx, int lanes);
 
+/* The completion step of a multi-GPU batch -- the only collective of the path (frames are independent; the reference's loop
+ * simply finishes, simpleprocess.cc:591-611): every rank contributes one 64-byte record (by convention of art_amd/batch.py: rank,
+ * frames done, status, checksum of the outputs, elapsed microseconds, 3 spare words) and receives all of them, rank-major, in
+ * `all_records` (host memory, nranks * 8 words).  `rccl_comm` is the caller's ncclComm_t (RCCL) whose ranks each hold one
+ * artgpu context on their own GPU; the all-gather runs on the context's stream after the frames queued there, and doubles as
+ * the batch barrier.  NULL with nranks == 1 copies the record.  RCCL is loaded at run time (no link-time dependency). */
+#define ARTGPU_BATCH_RECORD_WORDS 8
+int artgpu_batch_complete(artgpu_ctx *ctx, void *rccl_comm, int nranks, const int64_t record[ARTGPU_BATCH_RECORD_WORDS], int64_t *all_records);
+
 /* Bytes of device scratch the context currently holds (arena + staging). */
 size_t artgpu_scratch_bytes(const artgpu_ctx *ctx);
 

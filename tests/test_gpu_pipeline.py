@@ -154,3 +154,33 @@ def test_batch_lanes_give_the_same_bits(lanes):
             ctx.set_batch_lanes(0)
     finally:
         ctx.close()
+
+
+def test_batch_complete_over_rccl(gpu_ctx):
+    """artgpu_batch_complete: the completion all-gather of a multi-GPU batch over the caller's RCCL communicator.  One GPU here, so the
+    communicator has one rank (created through librccl's C API the way a host application would); the two-rank exchange itself is
+    RCCL's, the N > 1 bookkeeping of bench.py is covered on CPU by tests/test_multiproc.py."""
+    import ctypes as C
+    rec = [0, 3, 0, 0x1234567890ABCDEF - (1 << 64) if 0x1234567890ABCDEF >= (1 << 63) else 0x1234567890ABCDEF, 16424, 0, 0, 0]
+    assert gpu_ctx.batch_complete(rec) == [rec]                       # no communicator: single rank
+    with pytest.raises(capi.ArtGpuError):
+        gpu_ctx.batch_complete(rec, nranks=2)                         # two ranks need one
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL("/opt/rocm/lib/librccl.so.1")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        assert gpu_ctx.batch_complete(rec, nranks=1, rccl_comm=comm) == [rec]
+        rec2 = [0, 5, 0, -7, 99, 1, 2, 3]
+        assert gpu_ctx.batch_complete(rec2, nranks=1, rccl_comm=comm) == [rec2]
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
