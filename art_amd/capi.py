@@ -95,6 +95,9 @@ class ArtGpuError(RuntimeError):
     pass
 
 
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_char_p, C.c_double)
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -144,6 +147,7 @@ def _load():
     lib.artgpu_ordered_sum_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float)]
     lib.artgpu_saturation_vibrance.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.artgpu_set_batch_lanes.argtypes = [C.c_void_p, C.c_int]
+    lib.artgpu_set_progress_callback.argtypes = [C.c_void_p, PROGRESS_FN, C.c_void_p]
     lib.artgpu_batch_complete.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.artgpu_rgb2out_matrix.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(RGB), C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]
     lib.artgpu_get_scanlines.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int]
@@ -177,7 +181,7 @@ def _load():
 
 LIB = _load()
 
-EXPORTS = ["artgpu_set_option", "artgpu_get_option", "artgpu_set_curve_tail", "artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
+EXPORTS = ["artgpu_set_progress_callback", "artgpu_set_option", "artgpu_get_option", "artgpu_set_curve_tail", "artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
            "artgpu_synchronize", "artgpu_enable_timing", "artgpu_get_timings", "artgpu_scratch_bytes",
            "artgpu_demosaic_bayer", "artgpu_border_interpolate2", "artgpu_get_image",
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
@@ -396,6 +400,11 @@ class Context:
         ptr = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32).ctypes.data_as(C.POINTER(C.c_float))
         keep = [None if a is None else np.ascontiguousarray(a, dtype=np.float32) for a in (rcurve, gcurve, bcurve)]
         self._chk(LIB.artgpu_rgb_curves(self._h, C.byref(image), *[None if k is None else k.ctypes.data_as(C.POINTER(C.c_float)) for k in keep]))
+
+    def set_progress_callback(self, fn):
+        """fn(stage: str, fraction: float) or None"""
+        self._progress = PROGRESS_FN(lambda user, stage, frac: fn(stage.decode(), frac)) if fn else PROGRESS_FN()
+        self._chk(LIB.artgpu_set_progress_callback(self._h, self._progress, None))
 
     def set_batch_lanes(self, lanes: int):
         self._chk(LIB.artgpu_set_batch_lanes(self._h, int(lanes)))

@@ -54,6 +54,9 @@ struct artgpu_ctx {
     long opt_amaze_zero_mask = 0x81f0;
     int opt_amaze_zero_frame = 16;
     int opt_amaze_poison = -1;     // >= 0: byte pattern the arenas are filled with before the launch
+    int opt_roctx = 0;             // 1: roctx ranges named after the reference functions around the entry points (rocprofv3 --marker-trace)
+    artgpu_progress_fn progress_fn = nullptr;   // artgpu_set_progress_callback
+    void *progress_user = nullptr;
     int opt_rcd_rows = 8;          // rows per iteration of the streaming kernel (4 or 8)
     int *rcd_counter = nullptr;    // RCD streaming kernel: tile counter
     int curve_tail_kind = ARTGPU_CURVE_TAIL_HOST;   // artgpu_set_curve_tail
@@ -333,8 +336,17 @@ int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value)
     else if (n == "amaze_zero_mask") ctx->opt_amaze_zero_mask = value;
     else if (n == "amaze_zero_frame") ctx->opt_amaze_zero_frame = (int)value;
     else if (n == "amaze_poison") ctx->opt_amaze_poison = (int)value;
+    else if (n == "roctx") ctx->opt_roctx = value != 0;
     else if (n == "rcd_rows") { if (value != 4 && value != 8) return fail(ctx, ARTGPU_EINVAL, "rcd_rows: 4 or 8"); ctx->opt_rcd_rows = (int)value; }
     else return fail(ctx, ARTGPU_EINVAL, "set_option: unknown option '%s'", name);
+    return ARTGPU_OK;
+}
+
+int artgpu_set_progress_callback(artgpu_ctx *ctx, artgpu_progress_fn fn, void *user)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    ctx->progress_fn = fn;
+    ctx->progress_user = user;
     return ARTGPU_OK;
 }
 
@@ -362,12 +374,51 @@ size_t artgpu_scratch_bytes(const artgpu_ctx *ctx)
     return s;
 }
 
+// Host-side milestones of an entry point: the reference's ProgressListener (rtengine.h:165; amaze_demosaic_RT.cc:1567-1580 reports
+// per-tile fractions, the device path reports 0 when the stage's work starts being queued and 1 when the entry point returns) and,
+// with the "roctx" option, a roctx range named after the reference function so that profiles read like the reference's call tree.
+struct StageScope {
+    artgpu_ctx *ctx;
+    const char *name;
+    bool range;
+    typedef int (*push_fn)(const char *);
+    typedef int (*pop_fn)();
+    static push_fn &push() { static push_fn f = nullptr; return f; }
+    static pop_fn &pop() { static pop_fn f = nullptr; return f; }
+    StageScope(artgpu_ctx *c, const char *n) : ctx(c), name(n), range(false)
+    {
+        if (!ctx) return;
+        if (ctx->opt_roctx) {
+            static bool tried = false;
+            if (!tried) {
+                tried = true;
+                void *h = nullptr;
+                for (const char *lib : {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so"})
+                    if ((h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL))) break;
+                if (h) {
+                    push() = reinterpret_cast<push_fn>(dlsym(h, "roctxRangePushA"));
+                    pop() = reinterpret_cast<pop_fn>(dlsym(h, "roctxRangePop"));
+                }
+            }
+            if (push() && pop()) { push()(name); range = true; }
+        }
+        if (ctx->progress_fn) ctx->progress_fn(ctx->progress_user, name, 0.0);
+    }
+    ~StageScope()
+    {
+        if (!ctx) return;
+        if (ctx->progress_fn) ctx->progress_fn(ctx->progress_user, name, 1.0);
+        if (range) pop()();
+    }
+};
+
 struct DualReq { double *contrast; int auto_contrast; int second; };
 static int vng4_dev(artgpu_ctx *ctx, const float *raw, size_t raw_stride, float *r, float *g, float *b, size_t out_stride, int W, int H, uint32_t filters);
 static int dual_blend_dev(artgpu_ctx *ctx, const DevImage &d, int W, int H, uint32_t filters, DualReq *req);
 static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *raw, uint32_t filters,
                                double initial_gain, int border, artgpu_rgb *out, DualReq *dual)
 {
+    StageScope scope_(ctx, "RawImageSource::demosaic (Bayer)");
     if (!ctx) return ARTGPU_EINVAL;
     if (!plane_ok(raw) || !out) return fail(ctx, ARTGPU_EINVAL, "demosaic_bayer: bad raw plane or null output");
     if (method != ARTGPU_BAYER_AMAZE && method != ARTGPU_BAYER_RCD && method != ARTGPU_BAYER_VNG4) return fail(ctx, ARTGPU_EUNSUPPORTED, "demosaic_bayer: method %d is not on the device path", method);
@@ -582,6 +633,7 @@ int artgpu_border_interpolate2(artgpu_ctx *ctx, const artgpu_plane *raw, uint32_
 int artgpu_get_image(artgpu_ctx *ctx, const artgpu_rgb *planes, int sx1, int sy1, const float mul[3],
                      int do_clip, const double *mat, artgpu_rgb *image)
 {
+    StageScope scope_(ctx, "RawImageSource::getImage");
     return artgpu_get_image_skip(ctx, planes, sx1, sy1, 1, mul, do_clip, mat, image);
 }
 
@@ -631,6 +683,7 @@ int artgpu_convert_color_space(artgpu_ctx *ctx, artgpu_rgb *image, const double 
 
 int artgpu_exposure(artgpu_ctx *ctx, artgpu_rgb *image, float exp_scale, float black)
 {
+    StageScope scope_(ctx, "ImProcFunctions::expcomp");
     if (!ctx) return ARTGPU_EINVAL;
     if (!image) return fail(ctx, ARTGPU_EINVAL, "exposure: null image");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -647,6 +700,7 @@ int artgpu_exposure(artgpu_ctx *ctx, artgpu_rgb *image, float exp_scale, float b
 
 int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float *lut65536, float whitept, int filmlike_clip)
 {
+    StageScope scope_(ctx, "ImProcFunctions::toneCurve");
     if (!ctx) return ARTGPU_EINVAL;
     if (!image) return fail(ctx, ARTGPU_EINVAL, "tone_curve: null image");
     if (mode != ARTGPU_TONE_STD) return fail(ctx, ARTGPU_EUNSUPPORTED, "tone_curve: curve mode %d is not on the device path", mode);
@@ -898,6 +952,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
                        double expcomp, double scale, const artgpu_plane *ccalc, uint32_t flags,
                        float *nresi, float *highresi)
 {
+    StageScope scope_(ctx, "denoise::RGB_denoise");
     if (!ctx) return ARTGPU_EINVAL;
     if (!img || !p || !ws) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: null argument");
     if (p->color_space != 0 && p->color_space != 1) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: color_space must be 0 (RGB) or 1 (LAB)");
@@ -1166,6 +1221,7 @@ int gf_subsampling(int w, int h, int r)   // calculate_subsampling (guidedfilter
 
 int artgpu_denoise_guided_smoothing(artgpu_ctx *ctx, artgpu_rgb *img, const double ws[9], int guided_chroma_radius, double scale)
 {
+    StageScope scope_(ctx, "denoise::denoiseGuidedSmoothing");
     if (!ctx) return ARTGPU_EINVAL;
     if (!img || !ws || !(scale >= 1.0)) return fail(ctx, ARTGPU_EINVAL, "denoise_guided_smoothing: bad arguments");
     if (guided_chroma_radius == 0) return ARTGPU_OK;   // ipsmoothing.cc:877-879
@@ -1658,6 +1714,7 @@ int artgpu_detail_mask(artgpu_ctx *ctx, const artgpu_plane *src, artgpu_plane *m
 
 int artgpu_nlmeans(artgpu_ctx *ctx, artgpu_plane *img, float normcoeff, int strength, int detail_thresh, float scale)
 {
+    StageScope scope_(ctx, "denoise::NLMeans");
     if (!ctx) return ARTGPU_EINVAL;
     if (!plane_ok(img) || !(scale >= 1.f)) return fail(ctx, ARTGPU_EINVAL, "nlmeans: bad arguments");
     if (!strength) return ARTGPU_OK;                       // nlmeans.cc:52-54
@@ -1694,6 +1751,7 @@ int artgpu_nlmeans(artgpu_ctx *ctx, artgpu_plane *img, float normcoeff, int stre
 int artgpu_demosaic_xtrans(artgpu_ctx *ctx, int passes, int use_cielab, const artgpu_plane *raw, const int32_t xtrans[36],
                            const float rgb_cam[12], artgpu_rgb *out)
 {
+    StageScope scope_(ctx, "RawImageSource::xtrans_interpolate");
     if (!ctx) return ARTGPU_EINVAL;
     if (!plane_ok(raw) || !out || !xtrans || !rgb_cam) return fail(ctx, ARTGPU_EINVAL, "demosaic_xtrans: bad raw plane or null argument");
     if (passes < 1 || passes > 4) return fail(ctx, ARTGPU_EINVAL, "demosaic_xtrans: passes must be 1..4");
@@ -1792,6 +1850,7 @@ int artgpu_demosaic_xtrans(artgpu_ctx *ctx, int passes, int use_cielab, const ar
 // ---------------------------------------------------------------------------------------------
 int artgpu_tone_curve_neutral(artgpu_ctx *ctx, artgpu_rgb *image, const float *lut65536, float whitecoeff, const artgpu_neutral_state *st)
 {
+    StageScope scope_(ctx, "ImProcFunctions::toneCurve (NEUTRAL)");
     if (!ctx) return ARTGPU_EINVAL;
     if (!image || !lut65536 || !st || !(whitecoeff > 0.f)) return fail(ctx, ARTGPU_EINVAL, "tone_curve_neutral: null/invalid argument");
     DevRGB d;
@@ -2024,6 +2083,7 @@ int artgpu_denoise_chroma_map(artgpu_ctx *ctx, const artgpu_rgb *img, const doub
 int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_tool_params *p, const double ws[9], const double *iws,
                           double ecomp, double scale, const double *calclum_mat, const float *noise_c_curve, uint32_t flags)
 {
+    StageScope scope_(ctx, "ImProcFunctions::denoise");
     if (!ctx) return ARTGPU_EINVAL;
     if (!img || !p || !ws) return fail(ctx, ARTGPU_EINVAL, "improc_denoise: null argument");
     if (!img->r.on_device) {
@@ -2291,6 +2351,7 @@ int artgpu_scale_colors(artgpu_ctx *ctx, const void *src, int32_t w, int32_t h, 
 // ---------------------------------------------------------------------------------------------
 int artgpu_pipeline_run(artgpu_ctx *ctx, const artgpu_plane *raw, const artgpu_pipeline_params *p, artgpu_rgb *out)
 {
+    StageScope scope_(ctx, "ImageProcessor (stage_init .. stage_finish)");
     if (!ctx) return ARTGPU_EINVAL;
     if (!plane_ok(raw) || !p || !out) return fail(ctx, ARTGPU_EINVAL, "pipeline_run: null/bad argument");
     const int W = raw->w, H = raw->h, b = p->border;

@@ -178,6 +178,14 @@ int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float 
 #define ARTGPU_CURVE_TAIL_HOST 3
 int artgpu_set_curve_tail(artgpu_ctx *ctx, int kind, double y_last);
 
+/* rtengine::ProgressListener (rtengine/rtengine.h:165-181; the demosaicers report through it, amaze_demosaic_RT.cc:1567-1580).
+ * `fn(user, stage, fraction)` is called on the calling thread by every stage-level entry point: fraction 0.0 when the stage starts
+ * queueing its work, 1.0 when the entry point returns (device-resident outputs may still be in flight on the stream; host-resident
+ * ones are complete).  `stage` is the name of the reference function the entry point replaces.  NULL removes the callback.
+ * The same names label roctx ranges when artgpu_set_option(ctx, "roctx", 1) is set (rocprofv3 --marker-trace). */
+typedef void (*artgpu_progress_fn)(void *user, const char *stage, double fraction);
+int artgpu_set_progress_callback(artgpu_ctx *ctx, artgpu_progress_fn fn, void *user);
+
 /* rtengine::wavelet_decomposition with subsampling == 1 and the 6-tap Daub4 filters, the only
  * configuration the denoise path uses (rtengine/cplx_wavelet_dec.h:97-270; constructed at
  * rtengine/FTblockDN.cc:2296,2328,2365).  The object owns its coefficients in HBM.

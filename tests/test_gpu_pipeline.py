@@ -184,3 +184,26 @@ def test_batch_complete_over_rccl(gpu_ctx):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_progress_callback_and_roctx_ranges(gpu_ctx):
+    """artgpu_set_progress_callback (rtengine::ProgressListener): every stage-level entry point reports (name of the reference function,
+    0.0) when it starts and (name, 1.0) when it returns, nested the way the reference's call tree is; with the "roctx" option the same
+    names label roctx ranges (must not change any result)."""
+    w, h, filt = 330, 270, synth.FILTERS_RGGB
+    raw = synth.bayer_frame(w, h, filt, seed=5)
+    ref = gpu_ctx.demosaic_bayer_host(capi.BAYER_RCD, raw, filt, 1.0, 4)
+    events = []
+    gpu_ctx.set_progress_callback(lambda stage, frac: events.append((stage, frac)))
+    gpu_ctx.set_option("roctx", 1)
+    try:
+        got = gpu_ctx.demosaic_bayer_host(capi.BAYER_RCD, raw, filt, 1.0, 4)
+    finally:
+        gpu_ctx.set_progress_callback(None)
+        gpu_ctx.set_option("roctx", 0)
+    assert events == [("RawImageSource::demosaic (Bayer)", 0.0), ("RawImageSource::demosaic (Bayer)", 1.0)]
+    for a, b in zip(got, ref):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    n = len(events)
+    gpu_ctx.demosaic_bayer_host(capi.BAYER_RCD, raw, filt, 1.0, 4)
+    assert len(events) == n                                       # removed
