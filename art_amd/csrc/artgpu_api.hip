@@ -1485,7 +1485,6 @@ int artgpu_log_encoding(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_logenc_pa
     if (!ctx) return ARTGPU_EINVAL;
     if (!img || !p || !ws) return fail(ctx, ARTGPU_EINVAL, "log_encoding: null argument");
     if (!p->enabled) return ARTGPU_OK;
-    if (p->highlight_compression > 0) return fail(ctx, ARTGPU_EUNSUPPORTED, "log_encoding: highlight compression evaluates the C library's powf per pixel; not on the device path");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     LogEncArgs a = {};
     a.gray = std::pow(2.f, -(float)p->gain + std::log2(0.18f));                                   // ev2gray (L119-122)
@@ -1495,6 +1494,14 @@ int artgpu_log_encoding(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_logenc_pa
         ? logenc_find_gray((float)(std::abs(p->black_ev) / a.dynamic_range), (float)(p->target_gray / 100.f)) : 0.f;
     a.linbase = b < 0.f ? 0.f : b;
     a.satcontrol = p->satcontrol ? 1 : 0;
+    {   // highlight compression (L148-156): the constants with the host's libm like the reference, the per-pixel curve on the device
+        a.hlcompr = p->highlight_compression > 0 ? 1 : 0;
+        const float hf = float(p->highlight_compression) / 100.f;
+        a.hlcompr_factor = hf < 0.f ? 0.f : (hf > 1.f ? 1.f : hf);
+        constexpr float compr_l = 1.01f, compr_t = 0.8f;
+        a.compr_p = std::max(a.hlcompr_factor, 0.1f);
+        a.compr_s = (compr_l - compr_t) / std::pow(std::pow((1.f - compr_t) / (compr_l - compr_t), -a.compr_p) - 1.f, 1.f / a.compr_p);
+    }
     { const float bl = float(p->regularization) / 100.f; a.blend = bl < 0.f ? 0.f : (bl > 1.f ? 1.f : bl); }
     for (int k = 0; k < 3; ++k) a.ws1[k] = ws[3 + k];
     DevRGB d;

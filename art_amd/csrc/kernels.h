@@ -231,6 +231,8 @@ struct LogEncArgs {
     double ws1[3];                // working-space row 1 (Color::rgbLuminance<double>)
     float gray, shadows_range, dynamic_range, linbase, blend;
     int satcontrol;
+    int hlcompr;                  // highlightCompression > 0 (iplogenc.cc:148-170)
+    float hlcompr_factor, compr_p, compr_s;
     float *Y, *Y2;                // w*h: smoothed norm / its guide
 };
 hipError_t launch_logenc_direct(const LogEncArgs &a, hipStream_t s);

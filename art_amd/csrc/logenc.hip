@@ -28,11 +28,27 @@ __device__ __forceinline__ float le_norm(const LogEncArgs &a, float r, float g, 
     const float pn = n / std_max(d, 1e-12f);
     return std_min(hi, pn / 2.f + lum / 2.f);
 }
-// the `apply` lambda (L172-188), highlight compression off
+// The highlight-compression curve (L152-170).  The reference evaluates it with the C library's powf, which is not specified bit
+// for bit (glibc documents < 1 ULP); here powf(a, b) is the double-precision pow rounded to float -- the correctly rounded value
+// except for results within ~1e-16 relative of a rounding boundary, which is also what glibc's powf returns in all but about one
+// case in 10^5.  This is the ONE place of the tool that is tolerance-checked instead of bit-checked (tests/test_gpu_logenc.py).
+__device__ __forceinline__ float le_powf(float x, float y) { return (float)pow((double)x, (double)y); }
+__device__ __forceinline__ float le_compr(const LogEncArgs &a, float x)
+{
+    constexpr float compr_t = 0.8f;
+    if (x < compr_t) return x;
+    const float n = (x - compr_t) / a.compr_s;
+    const float d = le_powf(1.f + le_powf((x - compr_t) / a.compr_s, a.compr_p), 1.f / a.compr_p);
+    float res = compr_t + a.compr_s * n / d;
+    if (a.hlcompr_factor < 0.1f) res = intp(a.hlcompr_factor * 10.f, res, x);
+    return res;
+}
+// the `apply` lambda (L172-188)
 __device__ __forceinline__ float le_apply(const LogEncArgs &a, float noise, float log2, float x)
 {
     x = std_max(x, noise);
     x = std_max(x / a.gray, noise);
+    if (a.hlcompr) x = le_compr(a, x);
     x = std_max((xlogf_s(x) / log2 - a.shadows_range) / a.dynamic_range, noise);
     if (a.linbase > 0.f) x = (le_pow_F(a.linbase, x) - 1.f) / (a.linbase - 1.f);   // xlog2lin (sleef.h:1309-1313)
     return x;

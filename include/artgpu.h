@@ -367,8 +367,9 @@ int artgpu_dual_demosaic_bayer(artgpu_ctx *ctx, int method, int second, const ar
  * The struct holds the LogEncodingParams fields the function reads (procparams.h; defaults procparams.cc:2039-2051); `enabled == 0`
  * returns at once like the reference.  regularization > 0 smooths the posterised log-norm with rtengine::guidedFilter at radius
  * max(full_width, W, full_height, H) / 30 (full_width/height = ImProcFunctions::full_width/full_height, the uncropped image size).
- * highlight_compression > 0 evaluates std::pow per pixel (the C library's powf); that branch is not restated on the device:
- * ARTGPU_EUNSUPPORTED, the caller keeps its CPU path for it. */
+ * highlight_compression > 0 (L148-170) evaluates std::pow(float, float) twice per pixel above 0.8; the C library's powf is not
+ * specified bit for bit, the device uses double-precision pow rounded to float: identical to glibc's result except for a few
+ * values per million (at most 1.2e-6 relative; tests/test_gpu_logenc.py holds the bound).  Every other branch is bit-exact. */
 typedef struct artgpu_logenc_params {
     int32_t enabled;
     int32_t regularization;          /* 0..100 */
