@@ -287,16 +287,27 @@ def main() -> None:
     # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the figure is the mean per
     # launch of the separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command, committed under
     # profiles/ (KB units; uncorrected -- the kernel's accesses are 4 B per lane, see profiles/r1/README.md)
-    traffic, traffic_src, traffic_raw = None, None, None
-    pmc_rel = os.path.join("profiles", "r2", "amaze_v2_pmc_summary.json")
+    traffic, traffic_src, traffic_raw, issue = None, None, None, None
+    kname = "xtrans_tiles_kernel" if xtrans else "amaze_stream_kernel" if method == capi.BAYER_AMAZE else "rcd_stream_kernel"
+    pmc_rel = os.path.join("profiles", "r2", {"amaze_stream_kernel": "amaze_v2_pmc_summary.json", "rcd_stream_kernel": "rcd_stream_pmc_summary.json",
+                                              "xtrans_tiles_kernel": "xtrans_v1_pmc_summary.json"}[kname])
     pmc_path = os.path.join(ROOT, pmc_rel)
-    if method == capi.BAYER_AMAZE and not xtrans and (W, H) == (W45, H45) and os.path.exists(pmc_path):
+    full_size = (W, H) == ((11648, 8736) if xtrans else (W45, H45))
+    if full_size and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
         # FETCH_SIZE on gfx950 reports half the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM section): doubled here.
-        # (Sanity check: the raw figure, 156 MB, is less than the 179 MB CFA plane that has to be read at least once.)
+        # (Sanity check for AMaZE: the raw figure, 156 MB, is less than the 179 MB CFA plane that has to be read at least once.)
         traffic_raw = {"FETCH_SIZE_KB": pmc["FETCH_SIZE"]["mean_per_launch"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"]["mean_per_launch"]}
         traffic = int((2 * pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024)
-        traffic_src = pmc_rel + " (rocprofv3 --pmc passes of `bench.py --workload amaze`, kernel amaze_stream_kernel; FETCH_SIZE doubled)"
+        traffic_src = pmc_rel + f" (rocprofv3 --pmc passes of `bench.py --workload {args.workload}`, kernel {kname}; FETCH_SIZE doubled)"
+        # The streaming demosaicers are bound by instruction issue, not by HBM: instruction counts of the same PMC passes priced with
+        # the per-SIMD issue times measured by scripts/ubench/issue_mix.hip (vector 1.19 ns, scalar 1.3 ns when mixed, LDS 1.06 ns;
+        # the classes add up on this chip), over the 1024 SIMDs -- the time the kernel cannot go below without fewer instructions.
+        if "SQ_INSTS_VALU" in pmc and "SQ_INSTS_SALU" in pmc and "SQ_INSTS_LDS" in pmc:
+            iv, isa, il = pmc["SQ_INSTS_VALU"]["mean_per_launch"], pmc["SQ_INSTS_SALU"]["mean_per_launch"], pmc["SQ_INSTS_LDS"]["mean_per_launch"]
+            model_ms = (iv * 1.19 + isa * 1.3 + il * 1.06) / 1024 / 1e6
+            issue = {"valu": int(iv), "salu": int(isa), "lds": int(il), "ns_per_instr_per_simd": {"valu": 1.19, "salu": 1.3, "lds": 1.06},
+                     "issue_time_ms": round(model_ms, 3), "frac_of_kernel_ms": None, "source": pmc_rel + " + scripts/ubench/issue_mix.hip"}
 
     # measured device-copy bandwidth in the same run (the practical HBM ceiling next to the 8 TB/s datasheet peak):
     # a 716 MB device-to-device copy, read + write bytes over its HIP-event time
@@ -316,6 +327,8 @@ def main() -> None:
         copy_gbs = 5 * 2 * nb * 4 / 1e9 / (ce[0].elapsed_time(ce[1]) / 1e3)
         del src_t, dst_t
 
+    if issue is not None:
+        issue["frac_of_kernel_ms"] = round(issue["issue_time_ms"] / kern_ms, 3)
     result = {
         "metric": ("megapixels/sec end-to-end (X-Trans+FTblockDN+tone), 100 MP X-Trans" if xtrans else
                    "megapixels/sec end-to-end (AMaZE+FTblockDN+tone), 45 MP Bayer"),
@@ -343,7 +356,7 @@ def main() -> None:
             "completion_records": len(records), "completion_via": gather_via,
         },
         "roofline": {
-            "bound": "hbm", "kernel": "xtrans_tiles_kernel" if xtrans else "amaze_stream_kernel" if method == capi.BAYER_AMAZE else "rcd_stream_kernel",
+            "bound": "hbm", "kernel": kname,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "traffic_raw_counters": traffic_raw,
             # the whole step against the same contract (MP/s x 16 B / 8 TB/s), next to the dominant kernel's fraction
@@ -351,6 +364,7 @@ def main() -> None:
             "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": W * H * ALGO_BYTES_PER_PX,
             "device_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
             "traffic_rate_frac_of_copy": None if (copy_gbs is None or traffic is None) else round(traffic / 1e9 / (kern_ms / 1e3) / copy_gbs, 4),
+            "instruction_issue": issue,
         },
     }
 
