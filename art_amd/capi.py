@@ -127,6 +127,7 @@ def _load():
     lib.artgpu_demosaic_bayer.argtypes = [C.c_void_p, C.c_int, C.POINTER(Plane), C.c_uint32, C.c_double, C.c_int, C.POINTER(RGB)]
     lib.artgpu_border_interpolate2.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_uint32, C.c_int, C.POINTER(RGB)]
     lib.artgpu_wavelet_decompose.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_int, C.POINTER(C.c_void_p)]
+    lib.artgpu_wavelet_mad.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]
     lib.artgpu_wavelet_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.artgpu_wavelet_get_band.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
     lib.artgpu_wavelet_set_band.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -185,7 +186,7 @@ EXPORTS = ["artgpu_set_progress_callback", "artgpu_set_option", "artgpu_get_opti
            "artgpu_synchronize", "artgpu_enable_timing", "artgpu_get_timings", "artgpu_scratch_bytes",
            "artgpu_demosaic_bayer", "artgpu_border_interpolate2", "artgpu_get_image",
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
-           "artgpu_wavelet_decompose", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
+           "artgpu_wavelet_decompose", "artgpu_wavelet_mad", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
            "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_batch_complete", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter", "artgpu_hsl_equalizer", "artgpu_log_encoding", "artgpu_rgb_to_lab", "artgpu_lab_to_rgb", "artgpu_lab_histogram", "artgpu_lab_adjustments", "artgpu_dual_demosaic_bayer"]
 
@@ -479,6 +480,13 @@ class Context:
     def wavelet_set_band(self, wv, level: int, direction: int, data: np.ndarray):
         data = np.ascontiguousarray(data, dtype=np.float32)
         self._chk(LIB.artgpu_wavelet_set_band(self._h, wv, level, direction, data.ctypes.data, 0))
+
+    def wavelet_mad(self, wv) -> np.ndarray:
+        """SQR(MadRgb) of every detail band: [3 * level + dir - 1]"""
+        _, _, lv = self.wavelet_info(wv)
+        out = (C.c_float * (3 * lv))()
+        self._chk(LIB.artgpu_wavelet_mad(self._h, wv, out))
+        return np.array(out[:], dtype=np.float32)
 
     def wavelet_reconstruct(self, wv, dst: Plane, blend: float = 1.0):
         self._chk(LIB.artgpu_wavelet_reconstruct(self._h, wv, C.byref(dst), blend))

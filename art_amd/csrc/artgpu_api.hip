@@ -948,6 +948,22 @@ int detail_mask_dev(artgpu_ctx *ctx, const float *src, size_t src_stride, float 
                     float scaling, float threshold, float ceiling, float factor, float blur, float *scratch);
 }
 
+int artgpu_wavelet_mad(artgpu_ctx *ctx, const artgpu_wavelet *wv, float *mad_sqr)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (!wv || !mad_sqr) return fail(ctx, ARTGPU_EINVAL, "wavelet_mad: null argument");
+    if (wv->n > 0x7fffffff) return fail(ctx, ARTGPU_EUNSUPPORTED, "wavelet_mad: band larger than an int holds (MadRgb's datalen is an int)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int nsub = 3 * wv->nlevels;
+    float *histo_f, *mad;
+    int rc;
+    if ((rc = pool_get(ctx, P_HISTO, (size_t)nsub * (65536 + MAD_SCRATCH_INTS_PER_BAND) * 4, &histo_f)) || (rc = pool_get(ctx, P_MAD, 3 * 32 * 4, &mad))) return rc;
+    HIPCHK(ctx, launch_mad(wv->bands, wv->n, nsub, reinterpret_cast<int *>(histo_f), mad, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(mad_sqr, mad, (size_t)nsub * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
 int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_params *p, const float ws[9], const float *iws,
                        double expcomp, double scale, const artgpu_plane *ccalc, uint32_t flags,
                        float *nresi, float *highresi)
@@ -1018,7 +1034,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         (rc = pool_get(ctx, P_LBANDS, (size_t)nsub * n2 * 4, &Ld.bands)) || (rc = pool_get(ctx, P_LLOW0, n2 * 4, &Ld.low[0])) || (rc = pool_get(ctx, P_LLOW1, n2 * 4, &Ld.low[1])) ||
         (rc = pool_get(ctx, P_CBANDS, (size_t)nsub * n2 * 4, &Cd.bands)) || (rc = pool_get(ctx, P_CLOW0, n2 * 4, &Cd.low[0])) || (rc = pool_get(ctx, P_CLOW1, n2 * 4, &Cd.low[1])) ||
         (rc = pool_get(ctx, P_SF, (size_t)nsub * n2 * 4, &sf)) || (rc = pool_get(ctx, P_TMP, (size_t)nsub * n2 * 4, &tmp)) ||
-        (rc = pool_get(ctx, P_HISTO, (size_t)nsub * 65536 * 4, &histo_f)) || (rc = pool_get(ctx, P_MAD, 3 * 32 * 4, &mad)) ||
+        (rc = pool_get(ctx, P_HISTO, (size_t)nsub * (65536 + MAD_SCRATCH_INTS_PER_BAND) * 4, &histo_f)) || (rc = pool_get(ctx, P_MAD, 3 * 32 * 4, &mad)) ||
         (rc = pool_get(ctx, P_GAM, 2 * 65536 * 4, &gamlut)))
         return rc;
     int *histo = reinterpret_cast<int *>(histo_f);
@@ -1984,7 +2000,7 @@ int artgpu_denoise_compute_params(artgpu_ctx *ctx, const artgpu_rgb *planes, int
     if ((rc = lab_tabs_dev(ctx, &tabs)) || (rc = pool_get(ctx, P_A, n * 4, &a.A)) || (rc = pool_get(ctx, P_B, n * 4, &a.B)) ||
         (rc = pool_get(ctx, P_CBANDS, (size_t)nsub * n2 * 4, &Cd.bands)) || (rc = pool_get(ctx, P_CLOW0, n2 * 4, &Cd.low[0])) ||
         (rc = pool_get(ctx, P_CLOW1, n2 * 4, &Cd.low[1])) || (rc = pool_get(ctx, P_SF, (size_t)27 * n2 * 4, &a.maps)) ||
-        (rc = pool_get(ctx, P_HISTO, (size_t)nsub * 65536 * 4, &histo_f)) || (rc = pool_get(ctx, P_GAM, 2 * 65536 * 4, &gamlut)) ||
+        (rc = pool_get(ctx, P_HISTO, (size_t)nsub * (65536 + MAD_SCRATCH_INTS_PER_BAND) * 4, &histo_f)) || (rc = pool_get(ctx, P_GAM, 2 * 65536 * 4, &gamlut)) ||
         (rc = pool_get(ctx, P_DNINFO, (9 * 32 + 9 * 8) * 4, &res)))
         return rc;
     for (int k = 0; k < 3; ++k) { a.src[k] = src.p[k]; a.mul[k] = mul[k]; }

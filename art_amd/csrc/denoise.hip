@@ -229,8 +229,11 @@ constexpr int MAD_LDS_BINS = MAD_LDS_BINS_OVERRIDE;
 #ifndef MAD_GRID
 #define MAD_GRID 192
 #endif
-__global__ void __launch_bounds__(256) mad_hist_kernel(const float *bands, size_t n, int *histo /*[nsub][65536]*/)
+constexpr int MAD_SAMPLE_BINS = 4096;
+constexpr int MAD_WIN_STRIDE = MAD_SCRATCH_INTS_PER_BAND;       // ints of scratch per band behind the full histograms (kernels.h)
+__global__ void __launch_bounds__(256) mad_hist_kernel(const float *bands, size_t n, int *histo /*[nsub][65536]*/, const int *done /*[nsub] or null*/)
 {
+    if (done && done[blockIdx.y * MAD_WIN_STRIDE]) return;       // the windowed pass below already has this band's median
     // The first MAD_LDS_BINS bins live in LDS (16 KB: more LDS costs more in occupancy than it saves in global atomics); the
     // long tail goes straight to global memory.  The loop is bound by the latency of its loads, so eight are kept in flight.
     __shared__ int h[MAD_LDS_BINS];
@@ -244,7 +247,7 @@ __global__ void __launch_bounds__(256) mad_hist_kernel(const float *bands, size_
     for (size_t i0 = blockIdx.x * (size_t)256 + threadIdx.x; i0 < n; i0 += stride * U) {
         float x[U];
 #pragma unroll
-        for (int k = 0; k < U; ++k) { const size_t i = i0 + k * stride; x[k] = i < n ? data[i] : 0.f; }
+        for (int k = 0; k < U; ++k) { const size_t i = i0 + k * stride; x[k] = data[i < n ? i : n - 1]; }     // (clamped, unconditional: see mad_window_kernel)
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             if (i0 + k * stride >= n) break;
@@ -261,11 +264,144 @@ __global__ void __launch_bounds__(256) mad_hist_kernel(const float *bands, size_
         if (h[i]) atomicAdd(&gh[i], h[i]);
 }
 
+// ---- MadRgb without the full histogram.  The median walk of the reference (`while (count < half) count += histo[median++]`) only
+// needs (a) how many coefficients lie below some bin L that is itself below the median bin, and (b) the exact counts of the bins
+// from L up to the median bin.  A 1/32 sub-sample locates the median bin to within a bin or two; the exact pass then COUNTS what is
+// below L = estimate - 3 and in each of the 8 bins from L on with plain per-thread adds -- no atomic in the loop (the full histogram
+// is bound by LDS atomic throughput, ~1 lane per clock, not by its loads; a first version with a 64-bin LDS window still sent half
+// of the coefficients to an atomic, because they cluster around their median).
+// If the true median bin is not inside the window (or the estimate is >= 4096) the band's `done` flag stays 0 and the full
+// histogram above runs for it: the result is the reference's in every case.
+// scratch per band (ints): [0] done, [1] L, [2] below, [3] sampled total, [8..15] window (room to 71), [72 ..] sub-sample histogram (4096 bins + overflow)
+__global__ void __launch_bounds__(256) mad_sample_kernel(const float *bands, size_t n, int *scr)
+{
+    __shared__ int h[MAD_SAMPLE_BINS + 1];
+    const int sub = blockIdx.y;
+    const float *data = bands + (size_t)sub * n;
+    int *s = scr + (size_t)sub * MAD_WIN_STRIDE;
+    for (int i = threadIdx.x; i <= MAD_SAMPLE_BINS; i += 256) h[i] = 0;
+    __syncthreads();
+    // every 32nd chunk of 256 consecutive coefficients
+    for (size_t chunk = (size_t)blockIdx.x * 32; chunk * 256 < n; chunk += (size_t)gridDim.x * 32) {
+        const size_t i = chunk * 256 + threadIdx.x;
+        if (i < n) {
+            const int v = (int)fminf(fabsf(data[i]), 65535.f);
+            atomicAdd(&h[v < MAD_SAMPLE_BINS ? v : MAD_SAMPLE_BINS], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i <= MAD_SAMPLE_BINS; i += 256)
+        if (h[i]) atomicAdd(&s[72 + i], h[i]);
+}
+__global__ void __launch_bounds__(256) mad_pick_kernel(int *scr)
+{
+    __shared__ int part[256];
+    int *s = scr + (size_t)blockIdx.x * MAD_WIN_STRIDE;
+    const int *h = s + 72;
+    int p = 0;
+    for (int i = 0; i < MAD_SAMPLE_BINS / 256; ++i) p += h[threadIdx.x * (MAD_SAMPLE_BINS / 256) + i];
+    part[threadIdx.x] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = h[MAD_SAMPLE_BINS];
+        for (int i = 0; i < 256; ++i) total += part[i];
+        const int half = total / 2;
+        int count = 0, chunk = 0;
+        while (chunk < 256 && count + part[chunk] < half) { count += part[chunk]; ++chunk; }
+        int L = -1;
+        if (chunk < 256 && total > 0) {
+            int m = chunk * (MAD_SAMPLE_BINS / 256);
+            while (m < MAD_SAMPLE_BINS && count < half) { count += h[m]; ++m; }
+            if (count >= half) L = max(0, m - 1 - 3);
+        }
+        s[0] = 0; s[1] = L; s[2] = 0; s[3] = total;
+    }
+    if (threadIdx.x < 64) s[8 + threadIdx.x] = 0;
+}
+#ifndef MAD_WINDOW_LOADS
+#define MAD_WINDOW_LOADS 8
+#endif
+#ifndef MAD_WINDOW_GRID
+#define MAD_WINDOW_GRID MAD_GRID
+#endif
+constexpr int MAD_WIN = 8;        // bins counted exactly: [L, L + 8), L = estimate - 3 (the estimate of 350 k samples is good to a fraction of a bin)
+__global__ void __launch_bounds__(256) mad_window_kernel(const float *bands, size_t n, int *scr)
+{
+    __shared__ int red[MAD_WIN + 1];
+    const int sub = blockIdx.y;
+    int *s = scr + (size_t)sub * MAD_WIN_STRIDE;
+    const int L = s[1];
+    if (L < 0) return;
+    const float *data = bands + (size_t)sub * n;
+    if (threadIdx.x <= MAD_WIN) red[threadIdx.x] = 0;
+    __syncthreads();
+    constexpr int U = MAD_WINDOW_LOADS;
+    const size_t stride = (size_t)gridDim.x * 256;
+    // no atomics in the loop: the coefficients cluster around their median, so even a narrow window would send a fifth of the lanes
+    // to the same few LDS words; per-thread counters cost 2 instructions per bin and element instead
+    int below = 0, cnt[MAD_WIN];
+#pragma unroll
+    for (int b = 0; b < MAD_WIN; ++b) cnt[b] = 0;
+    for (size_t i0 = blockIdx.x * (size_t)256 + threadIdx.x; i0 < n; i0 += stride * U) {
+        // unconditional loads from a clamped index (a load under `if (i < n)` is not hoisted above the previous element's
+        // arithmetic: one load in flight per wave instead of U); elements past the end count in no bin
+        float x[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) { const size_t i = i0 + k * stride; x[k] = data[i < n ? i : n - 1]; }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            int w = (int)fminf(fabsf(x[k]), 65535.f) - L;           // the bin of mad_hist_kernel, relative to the window
+            w = i0 + k * stride < n ? w : MAD_WIN;
+            below += w < 0;
+#pragma unroll
+            for (int b = 0; b < MAD_WIN; ++b) cnt[b] += w == b;
+        }
+    }
+    // wave sums, one LDS atomic per wave and counter, one global atomic per workgroup and counter
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        below += __shfl_down(below, o);
+#pragma unroll
+        for (int b = 0; b < MAD_WIN; ++b) cnt[b] += __shfl_down(cnt[b], o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&red[MAD_WIN], below);
+#pragma unroll
+        for (int b = 0; b < MAD_WIN; ++b) atomicAdd(&red[b], cnt[b]);
+    }
+    __syncthreads();
+    if (threadIdx.x < MAD_WIN && red[threadIdx.x]) atomicAdd(&s[8 + threadIdx.x], red[threadIdx.x]);
+    if (threadIdx.x == MAD_WIN && red[MAD_WIN]) atomicAdd(&s[2], red[MAD_WIN]);
+}
+__global__ void __launch_bounds__(64) mad_window_finish_kernel(int *scr, int datalen, float *out)
+{
+    if (threadIdx.x) return;
+    int *s = scr + (size_t)blockIdx.x * MAD_WIN_STRIDE;
+    if (datalen <= 1) { out[blockIdx.x] = 0.f; s[0] = 1; return; }
+    const int L = s[1], half = datalen / 2;
+    int count = s[2];
+    if (L < 0 || count >= half) return;              // no estimate, or the median bin lies below the window
+    for (int b = 0; b < MAD_WIN; ++b) {
+        const int hb = s[8 + b];
+        count += hb;
+        if (count >= half) {
+            // the walk of mad_finish_kernel stopped with median = L + b + 1, count_ = count - h[median - 1]
+            const int median = L + b + 1, count_ = count - hb;
+            const float q = ((median - 1) + (half - count_) / ((float)(count - count_)));
+            const float r = (float)((double)q / 0.6745);
+            out[blockIdx.x] = r * r;
+            s[0] = 1;
+            return;
+        }
+    }
+}
+
 // one workgroup per subband: exact median walk; out[sub] = SQR(MadRgb)
-__global__ void __launch_bounds__(256) mad_finish_kernel(const int *histo, int datalen, float *out)
+__global__ void __launch_bounds__(256) mad_finish_kernel(const int *histo, int datalen, float *out, const int *done)
 {
     __shared__ int part[256];
     const int sub = blockIdx.x;
+    if (done && done[sub * MAD_WIN_STRIDE]) return;
     const int *h = histo + (size_t)sub * 65536;
     int s = 0;
     for (int i = 0; i < 256; ++i) s += h[threadIdx.x * 256 + i];
@@ -668,10 +804,17 @@ hipError_t launch_yuv2rgb(const DnPixArgs &a, hipStream_t s)
 }
 hipError_t launch_mad(const float *bands, size_t n, int nsub, int *histo, float *out, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(histo, 0, (size_t)nsub * 65536 * sizeof(int), s);
+    // histo: nsub * 65536 ints (the full histograms, only built for bands the windowed pass could not settle) followed by
+    // nsub * MAD_SCRATCH_INTS_PER_BAND ints of scratch
+    int *scr = histo + (size_t)nsub * 65536;
+    hipError_t e = hipMemsetAsync(histo, 0, ((size_t)nsub * 65536 + (size_t)nsub * MAD_SCRATCH_INTS_PER_BAND) * sizeof(int), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mad_hist_kernel, dim3(flat_grid((long long)n, MAD_GRID), nsub), dim3(256), 0, s, bands, n, histo);
-    hipLaunchKernelGGL(mad_finish_kernel, dim3(nsub), dim3(256), 0, s, (const int *)histo, (int)n, out);
+    hipLaunchKernelGGL(mad_sample_kernel, dim3(64, nsub), dim3(256), 0, s, bands, n, scr);
+    hipLaunchKernelGGL(mad_pick_kernel, dim3(nsub), dim3(256), 0, s, scr);
+    hipLaunchKernelGGL(mad_window_kernel, dim3(flat_grid((long long)n, MAD_WINDOW_GRID), nsub), dim3(256), 0, s, bands, n, scr);
+    hipLaunchKernelGGL(mad_window_finish_kernel, dim3(nsub), dim3(64), 0, s, scr, (int)n, out);
+    hipLaunchKernelGGL(mad_hist_kernel, dim3(flat_grid((long long)n, MAD_GRID), nsub), dim3(256), 0, s, bands, n, histo, (const int *)scr);
+    hipLaunchKernelGGL(mad_finish_kernel, dim3(nsub), dim3(256), 0, s, (const int *)histo, (int)n, out, (const int *)scr);
     return hipGetLastError();
 }
 hipError_t launch_shrink_sf(const ShrinkArgs &a, int nsub, bool ab, hipStream_t s)

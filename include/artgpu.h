@@ -196,6 +196,10 @@ int artgpu_set_progress_callback(artgpu_ctx *ctx, artgpu_progress_fn fn, void *u
  * Requires min(w2,h2) >= 2^maxlvl (no Haar level wider than half the plane). */
 typedef struct artgpu_wavelet artgpu_wavelet;
 int artgpu_wavelet_decompose(artgpu_ctx *ctx, const artgpu_plane *src, int maxlvl, artgpu_wavelet **out);
+/* SQR(MadRgb(band)) of every detail band (rtengine/FTblockDN.cc:569-603: the median of (int)min(|x|, 65535) found by a histogram
+ * walk, / 0.6745): mad_sqr[3 * level + dir - 1], host memory, 3 * nlevels floats.  RGB_denoise calls it on the L and ab
+ * decompositions (L2307-2320, L1000-1010); exposed so that the median search can be tested on arbitrary band contents. */
+int artgpu_wavelet_mad(artgpu_ctx *ctx, const artgpu_wavelet *wv, float *mad_sqr);
 int artgpu_wavelet_info(const artgpu_wavelet *wv, int32_t *w2, int32_t *h2, int32_t *nlevels);
 /* copy one subband out of / into the object; `host_or_device` follows `on_device` */
 int artgpu_wavelet_get_band(artgpu_ctx *ctx, const artgpu_wavelet *wv, int level, int dir, float *dst, int on_device);

@@ -64,3 +64,39 @@ def test_too_many_levels_is_rejected(gpu_ctx):
     src = np.zeros((40, 40), np.float32)
     with pytest.raises(capi.ArtGpuError):
         gpu_ctx.wavelet_decompose(capi.host_plane(src), 7)
+
+
+def test_madrgb_on_adversarial_bands(gpu_ctx):
+    """MadRgb (FTblockDN.cc:569-603) through artgpu_wavelet_mad.  The device locates the median bin with a 1/32 sub-sample, counts
+    what lies below a 64-bin window around the estimate and histograms only the window; bands where that cannot settle the median
+    fall back to the full histogram.  Every band must give the oracle's float exactly, whichever way it went: typical coefficients,
+    large ones (median bin beyond the sub-sample histogram), a distribution whose sub-sample misleads the estimate (the sampled
+    chunks -- every 32nd run of 256 -- are all zero), constants, a gap around the median, and the non-finite values of the MAD clamp."""
+    import oracle_lib as O
+    from art_amd import capi
+    w, h, lv = 1280, 960, 3
+    rng = np.random.default_rng(7)
+    wv = gpu_ctx.wavelet_decompose(capi.host_plane(rng.normal(0, 1, (h, w)).astype(np.float32)), lv)
+    w2, h2, _ = gpu_ctx.wavelet_info(wv)
+    n = w2 * h2
+    bands = []
+    bands.append(rng.laplace(0, 40, n))                                     # typical
+    bands.append(rng.normal(0, 9000, n))                                    # median bin ~6000: beyond the sub-sample's 4096 bins
+    b = rng.laplace(0, 300, n); b.reshape(-1)[:(n // 8192) * 8192].reshape(-1, 32, 256)[:, 0, :] = 0.0; bands.append(b)   # misleading sub-sample
+    bands.append(np.full(n, 17.3))                                          # one bin
+    b = np.where(rng.random(n) < 0.4999, 3.0, 2500.0); bands.append(b)      # gap: the walk ends far above the estimate's neighbourhood
+    b = rng.laplace(0, 5, n); b[::1000] = np.inf; b[1::1000] = np.nan; b[2::1000] = -1e30; bands.append(b)
+    bands.append(np.zeros(n))
+    bands.append(rng.uniform(-70000, 70000, n))                             # top bin populated
+    bands.append(rng.laplace(0, 0.3, n))                                    # nearly everything in bin 0
+    try:
+        ref = []
+        for k, b in enumerate(bands):
+            b = np.ascontiguousarray(b, dtype=np.float32)
+            gpu_ctx.wavelet_set_band(wv, k // 3, k % 3 + 1, b.reshape(h2, w2))
+            ref.append(np.float32(O.madrgb(b)) ** 2)
+        got = gpu_ctx.wavelet_mad(wv)
+    finally:
+        gpu_ctx.wavelet_free(wv)
+    assert got.shape == (9,)
+    assert np.array_equal(got.view(np.uint32), np.array(ref, np.float32).view(np.uint32)), (got, ref)
