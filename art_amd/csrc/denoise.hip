@@ -434,17 +434,32 @@ __global__ void __launch_bounds__(256) shrink_sf_L_kernel(ShrinkArgs a)
     const float levelFactor = mad_L * 5.f / (float)(level + 1);
     const float eps = 0.01f;
     const size_t nv4 = (a.n / 4) * 4;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-        const float nv = a.noisevar ? a.noisevar[i] : a.noisevar_const;
-        const float mag = sqr(c[i]);
-        float r;
-        if (i < nv4) {
-            const float madv = nv * levelFactor;
-            r = mag / (mag + madv * xexpf_v(-mag / (9.0f * madv)) + eps);
-        } else {
-            r = mag / (mag + levelFactor * nv * xexpf_s(-mag / (9 * levelFactor * nv)) + eps);
+    // four coefficients per thread and iteration, their loads issued before any arithmetic (one per iteration left the kernel at
+    // 3.8 TB/s waiting for its own loads)
+    constexpr int U = 4;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i0 = blockIdx.x * (size_t)256 + threadIdx.x; i0 < a.n; i0 += stride * U) {
+        float cv[U], nvv[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const size_t i = i0 + k * stride, ic = i < a.n ? i : a.n - 1;
+            cv[k] = c[ic];
+            nvv[k] = a.noisevar ? a.noisevar[ic] : a.noisevar_const;
         }
-        sf[i] = r;
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const size_t i = i0 + k * stride;
+            const float nv = nvv[k];
+            const float mag = sqr(cv[k]);
+            float r;
+            if (i < nv4) {
+                const float madv = nv * levelFactor;
+                r = mag / (mag + madv * xexpf_v(-mag / (9.0f * madv)) + eps);
+            } else {
+                r = mag / (mag + levelFactor * nv * xexpf_s(-mag / (9 * levelFactor * nv)) + eps);
+            }
+            if (i < a.n) sf[i] = r;
+        }
     }
 }
 
@@ -459,20 +474,34 @@ __global__ void __launch_bounds__(256) shrink_sf_AB_kernel(ShrinkArgs a)
     madab = a.useNoiseCCurve ? madab : madab * a.noisevar_ab;
     const float rmadLm9 = 1.f / (mad_L * 9.f);
     const size_t nv4 = (a.n / 4) * 4;
-    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
-        // noisevarchrom[i] = useNoiseCCurve ? maxNoiseVarab * ccalc[i] : 1 (FTblockDN.cc:2124)
-        const float nvc = a.noisevar ? a.noisevar_scale * a.noisevar[i] : 1.f;
-        const float mag_ab = sqr(c[i]);
-        float r;
-        if (i < nv4) {
-            const float mad_abv = nvc * madab;
-            const float mag_L = sqr(cL[i]) * rmadLm9;
-            r = 1.f - xexpf_v(-(mag_ab / mad_abv) - mag_L);
-        } else {
-            const float mag_L = sqr(cL[i]);
-            r = 1.f - xexpf_s(-(mag_ab / (nvc * madab)) - (mag_L / (9.f * mad_L)));
+    constexpr int U = 4;          // (see shrink_sf_L_kernel)
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i0 = blockIdx.x * (size_t)256 + threadIdx.x; i0 < a.n; i0 += stride * U) {
+        float cv[U], clv[U], nvv[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const size_t i = i0 + k * stride, ic = i < a.n ? i : a.n - 1;
+            cv[k] = c[ic];
+            clv[k] = cL[ic];
+            // noisevarchrom[i] = useNoiseCCurve ? maxNoiseVarab * ccalc[i] : 1 (FTblockDN.cc:2124)
+            nvv[k] = a.noisevar ? a.noisevar[ic] : 0.f;
         }
-        sf[i] = r;
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const size_t i = i0 + k * stride;
+            const float nvc = a.noisevar ? a.noisevar_scale * nvv[k] : 1.f;
+            const float mag_ab = sqr(cv[k]);
+            float r;
+            if (i < nv4) {
+                const float mad_abv = nvc * madab;
+                const float mag_L = sqr(clv[k]) * rmadLm9;
+                r = 1.f - xexpf_v(-(mag_ab / mad_abv) - mag_L);
+            } else {
+                const float mag_L = sqr(clv[k]);
+                r = 1.f - xexpf_s(-(mag_ab / (nvc * madab)) - (mag_L / (9.f * mad_L)));
+            }
+            if (i < a.n) sf[i] = r;
+        }
     }
 }
 
