@@ -92,10 +92,15 @@ __global__ void __launch_bounds__(256) exposure_kernel(PixArgs a)
     const int wv = (a.w / 4) * 4;
     FOR_IMAGE_XY(y, x, a.w, a.h) {
         const size_t di = (size_t)y * a.dst_stride + x;
+        // the three loads first: the planes may alias as far as the compiler knows, so load - store - load - store ... was three
+        // dependent memory round trips per pixel
+        float v[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = a.dst[c][di];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float v = a.dst[c][di] * a.exp_scale - a.black;
-            a.dst[c][di] = x < wv ? sse_max(v, 0.f) : std_max(v, 0.f);
+            const float e = v[c] * a.exp_scale - a.black;
+            a.dst[c][di] = x < wv ? sse_max(e, 0.f) : std_max(e, 0.f);
         }
     }
 }
