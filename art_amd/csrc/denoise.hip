@@ -148,16 +148,16 @@ __global__ void __launch_bounds__(1024) rgb2yuv_lds_kernel(DnPixArgs a)
     extern __shared__ float dn_lut_lds[];
     lut_lds_fill(dn_lut_lds, a.gamcurve, 1024);
     for (int y = blockIdx.x; y < a.h; y += gridDim.x)
-        for (int x0 = 0; x0 < a.w; x0 += 4096) {
-            float r[4], g[4], b[4];
+        for (int x0 = 0; x0 < a.w; x0 += LDSK_PX * 1024) {
+            float r[LDSK_PX], g[LDSK_PX], b[LDSK_PX];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < LDSK_PX; ++k) {
                 const int x = x0 + k * 1024 + (int)threadIdx.x;
                 const size_t si = (size_t)y * a.stride + (x < a.w ? x : a.w - 1);
                 r[k] = a.rgb[0][si]; g[k] = a.rgb[1][si]; b[k] = a.rgb[2][si];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < LDSK_PX; ++k) {
                 const int x = x0 + k * 1024 + (int)threadIdx.x;
                 if (x < a.w) rgb2yuv_px<true>(a, dn_lut_lds, y, x, r[k], g[k], b[k]);
             }
@@ -205,16 +205,16 @@ __global__ void __launch_bounds__(1024) yuv2rgb_lds_kernel(DnPixArgs a)
     extern __shared__ float dn_lut_lds[];
     lut_lds_fill(dn_lut_lds, a.igamcurve, 1024);
     for (int y = blockIdx.x; y < a.h; y += gridDim.x)
-        for (int x0 = 0; x0 < a.w; x0 += 4096) {
-            float l[4], av[4], bv[4];
+        for (int x0 = 0; x0 < a.w; x0 += LDSK_PX * 1024) {
+            float l[LDSK_PX], av[LDSK_PX], bv[LDSK_PX];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < LDSK_PX; ++k) {
                 const int x = x0 + k * 1024 + (int)threadIdx.x;
                 const long long t = (long long)y * a.w + (x < a.w ? x : a.w - 1);
                 l[k] = a.L[t]; av[k] = a.A[t]; bv[k] = a.B[t];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < LDSK_PX; ++k) {
                 const int x = x0 + k * 1024 + (int)threadIdx.x;
                 if (x < a.w) yuv2rgb_px<true>(a, dn_lut_lds, y, x, l[k], av[k], bv[k]);
             }

@@ -56,6 +56,12 @@ __device__ __forceinline__ int ngroups(int start, int bound, int step)
 
 } // namespace artgpu
 
+// pixels per thread and batch of the persistent 1024-thread LUT-in-LDS pixel kernels (rgb2yuv_lds, yuv2rgb_lds, tone_std_lds): with one
+// such workgroup per CU the loads of a batch are all that is in flight, so the batch is what hides the memory latency
+#ifndef LDSK_PX
+#define LDSK_PX 8
+#endif
+
 // Pixel loops without integer division: blockIdx.y strides over rows, blockIdx.x * blockDim.x + threadIdx.x over columns
 // (a flat index costs a 64-bit division per pixel, which showed up as ~1.5 TB/s on kernels that should stream at 4 TB/s).
 #define FOR_IMAGE_XY(yv, xv, W, H)                              \

@@ -131,16 +131,16 @@ __global__ void __launch_bounds__(1024) tone_std_lds_kernel(PixArgs a)
     lut_lds_fill(tone_lds, a.lut, 1024);
     const float Lmax = 65535.f * a.whitept;
     for (int y = blockIdx.x; y < a.h; y += gridDim.x)
-        for (int x0 = 0; x0 < a.w; x0 += 4096) {
-            float r[4], g[4], b[4];
+        for (int x0 = 0; x0 < a.w; x0 += LDSK_PX * 1024) {
+            float r[LDSK_PX], g[LDSK_PX], b[LDSK_PX];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < LDSK_PX; ++k) {
                 const int x = x0 + k * 1024 + (int)threadIdx.x;
                 const size_t di = (size_t)y * a.dst_stride + (x < a.w ? x : a.w - 1);
                 r[k] = a.dst[0][di]; g[k] = a.dst[1][di]; b[k] = a.dst[2][di];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < LDSK_PX; ++k) {
                 const int x = x0 + k * 1024 + (int)threadIdx.x;
                 if (x >= a.w) continue;
                 const size_t di = (size_t)y * a.dst_stride + x;
