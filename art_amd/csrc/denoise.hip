@@ -266,13 +266,17 @@ __global__ void __launch_bounds__(256) mad_hist_kernel(const float *bands, size_
 
 // ---- MadRgb without the full histogram.  The median walk of the reference (`while (count < half) count += histo[median++]`) only
 // needs (a) how many coefficients lie below some bin L that is itself below the median bin, and (b) the exact counts of the bins
-// from L up to the median bin.  A 1/32 sub-sample locates the median bin to within a bin or two; the exact pass then COUNTS what is
-// below L = estimate - 3 and in each of the 8 bins from L on with plain per-thread adds -- no atomic in the loop (the full histogram
-// is bound by LDS atomic throughput, ~1 lane per clock, not by its loads; a first version with a 64-bin LDS window still sent half
-// of the coefficients to an atomic, because they cluster around their median).
-// If the true median bin is not inside the window (or the estimate is >= 4096) the band's `done` flag stays 0 and the full
-// histogram above runs for it: the result is the reference's in every case.
-// scratch per band (ints): [0] done, [1] L, [2] below, [3] sampled total, [8..15] window (room to 71), [72 ..] sub-sample histogram (4096 bins + overflow)
+// from L up to the median bin.  A 1/32 sub-sample brackets the median bin: L and the window width Wn come from the sub-sample's
+// quantiles at half -+ 3 sqrt(N) (six standard deviations of the sampling error), 8 <= Wn <= 1024.  The exact pass then COUNTS
+// what is below L with a per-thread add, the first 8 window bins in packed per-thread byte counters, and the bins 8 .. Wn with LDS
+// atomics: a peaked distribution (most chroma bands: half of all coefficients within a few bins of the median) has a window of
+// 8 and never reaches an atomic -- the full histogram is bound by LDS atomic throughput there, ~1 lane per clock --, a broad one has
+// a wide window but then only a percent or so of the coefficients fall into it.
+// If the true median bin is not inside the window after all (or the bracket is wider than 1024 bins / beyond the sub-sample's 4096)
+// the band's `done` flag stays 0 and the full histogram above runs for it: the result is the reference's in every case.
+// scratch per band (ints): [0] done, [1] L, [2] below, [3] sampled total, [4] Wn, [8 .. 8+1024) window, then the sub-sample histogram
+constexpr int MAD_WMAX = 1024, MAD_REG_BINS = 8, MAD_SAMPLE_OFF = 8 + MAD_WMAX;
+static_assert(MAD_SAMPLE_OFF + MAD_SAMPLE_BINS + 1 <= MAD_WIN_STRIDE, "MAD_SCRATCH_INTS_PER_BAND too small");
 __global__ void __launch_bounds__(256) mad_sample_kernel(const float *bands, size_t n, int *scr)
 {
     __shared__ int h[MAD_SAMPLE_BINS + 1];
@@ -291,58 +295,73 @@ __global__ void __launch_bounds__(256) mad_sample_kernel(const float *bands, siz
     }
     __syncthreads();
     for (int i = threadIdx.x; i <= MAD_SAMPLE_BINS; i += 256)
-        if (h[i]) atomicAdd(&s[72 + i], h[i]);
+        if (h[i]) atomicAdd(&s[MAD_SAMPLE_OFF + i], h[i]);
 }
 __global__ void __launch_bounds__(256) mad_pick_kernel(int *scr)
 {
     __shared__ int part[256];
     int *s = scr + (size_t)blockIdx.x * MAD_WIN_STRIDE;
-    const int *h = s + 72;
+    const int *h = s + MAD_SAMPLE_OFF;
+    constexpr int PER = MAD_SAMPLE_BINS / 256;
     int p = 0;
-    for (int i = 0; i < MAD_SAMPLE_BINS / 256; ++i) p += h[threadIdx.x * (MAD_SAMPLE_BINS / 256) + i];
+    for (int i = 0; i < PER; ++i) p += h[threadIdx.x * PER + i];
     part[threadIdx.x] = p;
     __syncthreads();
     if (threadIdx.x == 0) {
         int total = h[MAD_SAMPLE_BINS];
         for (int i = 0; i < 256; ++i) total += part[i];
-        const int half = total / 2;
-        int count = 0, chunk = 0;
-        while (chunk < 256 && count + part[chunk] < half) { count += part[chunk]; ++chunk; }
-        int L = -1;
-        if (chunk < 256 && total > 0) {
-            int m = chunk * (MAD_SAMPLE_BINS / 256);
-            while (m < MAD_SAMPLE_BINS && count < half) { count += h[m]; ++m; }
-            if (count >= half) L = max(0, m - 1 - 3);
+        const int half = total / 2, d = 3 * (int)sqrtf((float)total) + 1;
+        // first bin whose cumulative count reaches `target` (whole 16-bin chunks first), -1 if none below the overflow bin
+        auto first_reaching = [&](int target) {
+            int count = 0, chunk = 0;
+            while (chunk < 256 && count + part[chunk] < target) { count += part[chunk]; ++chunk; }
+            if (chunk == 256) return -1;
+            int b = chunk * PER;
+            for (; b < (chunk + 1) * PER; ++b) { count += h[b]; if (count >= target) break; }
+            return b;
+        };
+        int L = -1, Wn = 0;
+        if (total > 0) {
+            const int lo = half - d <= 0 ? 0 : first_reaching(half - d), hi = first_reaching(half + d);
+            if (lo >= 0 && hi >= 0) {
+                L = lo > 0 ? lo - 1 : 0;
+                Wn = hi + 2 - L;
+                Wn = Wn < MAD_REG_BINS ? MAD_REG_BINS : Wn;
+                if (Wn > MAD_WMAX) L = -1;
+            }
         }
-        s[0] = 0; s[1] = L; s[2] = 0; s[3] = total;
+        s[0] = 0; s[1] = L; s[2] = 0; s[3] = total; s[4] = Wn;
     }
-    if (threadIdx.x < 64) s[8 + threadIdx.x] = 0;
 }
 #ifndef MAD_WINDOW_LOADS
 #define MAD_WINDOW_LOADS 8
 #endif
-#ifndef MAD_WINDOW_GRID
-#define MAD_WINDOW_GRID MAD_GRID
-#endif
-constexpr int MAD_WIN = 8;        // bins counted exactly: [L, L + 8), L = estimate - 3 (the estimate of 350 k samples is good to a fraction of a bin)
 __global__ void __launch_bounds__(256) mad_window_kernel(const float *bands, size_t n, int *scr)
 {
-    __shared__ int red[MAD_WIN + 1];
+    __shared__ int win[MAD_WMAX];
+    __shared__ int red[MAD_REG_BINS + 1];
     const int sub = blockIdx.y;
     int *s = scr + (size_t)sub * MAD_WIN_STRIDE;
-    const int L = s[1];
+    const int L = s[1], Wn = s[4];
     if (L < 0) return;
     const float *data = bands + (size_t)sub * n;
-    if (threadIdx.x <= MAD_WIN) red[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < Wn; i += 256) win[i] = 0;
+    if (threadIdx.x <= MAD_REG_BINS) red[threadIdx.x] = 0;
     __syncthreads();
     constexpr int U = MAD_WINDOW_LOADS;
+    static_assert(U * 16 < 256, "the packed byte counters are flushed every 16 iterations");
     const size_t stride = (size_t)gridDim.x * 256;
-    // no atomics in the loop: the coefficients cluster around their median, so even a narrow window would send a fifth of the lanes
-    // to the same few LDS words; per-thread counters cost 2 instructions per bin and element instead
-    int below = 0, cnt[MAD_WIN];
+    int below = 0, cnt[MAD_REG_BINS];
+    unsigned long long packed = 0;          // eight 8-bit counters: window bins 0 .. 7
 #pragma unroll
-    for (int b = 0; b < MAD_WIN; ++b) cnt[b] = 0;
-    for (size_t i0 = blockIdx.x * (size_t)256 + threadIdx.x; i0 < n; i0 += stride * U) {
+    for (int b = 0; b < MAD_REG_BINS; ++b) cnt[b] = 0;
+    auto flush = [&]() {
+#pragma unroll
+        for (int b = 0; b < MAD_REG_BINS; ++b) cnt[b] += (int)((packed >> (8 * b)) & 0xffull);
+        packed = 0;
+    };
+    int it = 0;
+    for (size_t i0 = blockIdx.x * (size_t)256 + threadIdx.x; i0 < n; i0 += stride * U, ++it) {
         // unconditional loads from a clamped index (a load under `if (i < n)` is not hoisted above the previous element's
         // arithmetic: one load in flight per wave instead of U); elements past the end count in no bin
         float x[U];
@@ -351,37 +370,41 @@ __global__ void __launch_bounds__(256) mad_window_kernel(const float *bands, siz
 #pragma unroll
         for (int k = 0; k < U; ++k) {
             int w = (int)fminf(fabsf(x[k]), 65535.f) - L;           // the bin of mad_hist_kernel, relative to the window
-            w = i0 + k * stride < n ? w : MAD_WIN;
+            w = i0 + k * stride < n ? w : 0x10000;
             below += w < 0;
-#pragma unroll
-            for (int b = 0; b < MAD_WIN; ++b) cnt[b] += w == b;
+            packed += (unsigned)w < (unsigned)MAD_REG_BINS ? 1ull << (8 * w) : 0ull;
+            if (w >= MAD_REG_BINS && w < Wn) atomicAdd(&win[w], 1);
         }
+        if ((it & 15) == 15) flush();
     }
+    flush();
     // wave sums, one LDS atomic per wave and counter, one global atomic per workgroup and counter
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         below += __shfl_down(below, o);
 #pragma unroll
-        for (int b = 0; b < MAD_WIN; ++b) cnt[b] += __shfl_down(cnt[b], o);
+        for (int b = 0; b < MAD_REG_BINS; ++b) cnt[b] += __shfl_down(cnt[b], o);
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&red[MAD_WIN], below);
+        atomicAdd(&red[MAD_REG_BINS], below);
 #pragma unroll
-        for (int b = 0; b < MAD_WIN; ++b) atomicAdd(&red[b], cnt[b]);
+        for (int b = 0; b < MAD_REG_BINS; ++b) atomicAdd(&red[b], cnt[b]);
     }
     __syncthreads();
-    if (threadIdx.x < MAD_WIN && red[threadIdx.x]) atomicAdd(&s[8 + threadIdx.x], red[threadIdx.x]);
-    if (threadIdx.x == MAD_WIN && red[MAD_WIN]) atomicAdd(&s[2], red[MAD_WIN]);
+    if (threadIdx.x < MAD_REG_BINS && red[threadIdx.x]) atomicAdd(&s[8 + threadIdx.x], red[threadIdx.x]);
+    if (threadIdx.x == MAD_REG_BINS && red[MAD_REG_BINS]) atomicAdd(&s[2], red[MAD_REG_BINS]);
+    for (int i = MAD_REG_BINS + threadIdx.x; i < Wn; i += 256)
+        if (win[i]) atomicAdd(&s[8 + i], win[i]);
 }
 __global__ void __launch_bounds__(64) mad_window_finish_kernel(int *scr, int datalen, float *out)
 {
     if (threadIdx.x) return;
     int *s = scr + (size_t)blockIdx.x * MAD_WIN_STRIDE;
     if (datalen <= 1) { out[blockIdx.x] = 0.f; s[0] = 1; return; }
-    const int L = s[1], half = datalen / 2;
+    const int L = s[1], Wn = s[4], half = datalen / 2;
     int count = s[2];
-    if (L < 0 || count >= half) return;              // no estimate, or the median bin lies below the window
-    for (int b = 0; b < MAD_WIN; ++b) {
+    if (L < 0 || count >= half) return;              // no bracket, or the median bin lies below the window
+    for (int b = 0; b < Wn; ++b) {
         const int hb = s[8 + b];
         count += hb;
         if (count >= half) {
@@ -840,7 +863,7 @@ hipError_t launch_mad(const float *bands, size_t n, int nsub, int *histo, float 
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(mad_sample_kernel, dim3(64, nsub), dim3(256), 0, s, bands, n, scr);
     hipLaunchKernelGGL(mad_pick_kernel, dim3(nsub), dim3(256), 0, s, scr);
-    hipLaunchKernelGGL(mad_window_kernel, dim3(flat_grid((long long)n, MAD_WINDOW_GRID), nsub), dim3(256), 0, s, bands, n, scr);
+    hipLaunchKernelGGL(mad_window_kernel, dim3(flat_grid((long long)n, MAD_GRID), nsub), dim3(256), 0, s, bands, n, scr);
     hipLaunchKernelGGL(mad_window_finish_kernel, dim3(nsub), dim3(64), 0, s, scr, (int)n, out);
     hipLaunchKernelGGL(mad_hist_kernel, dim3(flat_grid((long long)n, MAD_GRID), nsub), dim3(256), 0, s, bands, n, histo, (const int *)scr);
     hipLaunchKernelGGL(mad_finish_kernel, dim3(nsub), dim3(256), 0, s, (const int *)histo, (int)n, out, (const int *)scr);

@@ -349,7 +349,7 @@ hipError_t launch_gamma_lut(float *lut, float gamma, float start, float slope, f
 hipError_t launch_rgb2yuv(const DnPixArgs &a, hipStream_t s);
 hipError_t launch_yuv2rgb(const DnPixArgs &a, hipStream_t s);
 hipError_t launch_bishrink_AB(const ShrinkArgs &a, int nsub, hipStream_t s);
-constexpr int MAD_SCRATCH_INTS_PER_BAND = 72 + 4096 + 8;      // launch_mad: `histo` holds nsub * (65536 + this) ints
+constexpr int MAD_SCRATCH_INTS_PER_BAND = 8 + 1024 + 4096 + 8;      // launch_mad: `histo` holds nsub * (65536 + this) ints
 hipError_t launch_mad(const float *bands, size_t n, int nsub, int *histo, float *out, hipStream_t s);
 hipError_t launch_shrink_sf(const ShrinkArgs &a, int nsub, bool ab, hipStream_t s);
 hipError_t launch_hblur(const BlurArgs &a, int nsub, hipStream_t s);
