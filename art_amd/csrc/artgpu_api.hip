@@ -1057,6 +1057,9 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     px.gam = gam; px.gamthresh = gamthresh; px.gamslope = gamslope; px.igam = igam; px.igamthresh = igamthresh; px.igamslope = igamslope;
     px.gamcurve = gamlut; px.igamcurve = gamlut + 65536;
     px.pre_scale = ctx->fuse_pre; px.post_scale = ctx->fuse_post;
+    // the inverse-gamma pass looks up gamma-encoded values: the mid-tones sit in the middle of the table, so the 40704 entries kept in LDS
+    // start at 8000 (gamma 1.7: linear 0.03 .. 0.60 of white); the forward pass and the tone curve index with linear data and keep [0, 40704)
+    px.igam_lds_lo = 8000;
     if (lab_mode) {
         // Color::cachef / cachefy / denoiseGammaTab / denoiseIGammaTab, built on the host like the reference's (color.cc:202-292)
         float *tabs;

@@ -110,9 +110,9 @@ __device__ __forceinline__ void lab2rgb_dev(const DnPixArgs &a, float l, float l
 // Two launch shapes of each pixel pass: the plain 2-D grid, and (large frames, gamma LUT in use) one persistent 1024-thread
 // workgroup per CU with the lower part of the 65536-entry gamma LUT in LDS (lutf_lookup_lds): 0.61 -> ~0.35 ms at 45 MP.
 template <bool LDS>
-__device__ __forceinline__ float gam_lookup(const float *lds, const float *__restrict__ lut, float v)
+__device__ __forceinline__ float gam_lookup(const float *lds, const float *__restrict__ lut, float v, int lo = 0)
 {
-    return LDS ? lutf_lookup_lds<false>(lds, lut, 65536, v) : lutf_lookup<false>(lut, 65536, v);
+    return LDS ? lutf_lookup_lds<false>(lds, lut, 65536, v, lo) : lutf_lookup<false>(lut, 65536, v);
 }
 template <bool LDS>
 __device__ __forceinline__ void rgb2yuv_px(const DnPixArgs &a, const float *lds, int y, int x, float r0, float g0, float b0)
@@ -178,9 +178,9 @@ __device__ __forceinline__ void yuv2rgb_px(const DnPixArgs &a, const float *lds,
     float Y = (Lv - X * a.ws1[0] - Z * a.ws1[2]) / a.ws1[1];
     if (a.lab_mode) lab2rgb_dev(a, Lv, av, bv, X, Y, Z);    // L2522-2524
     if (a.gam > 1.f) {
-        if (X > 0.f) X = X < 65536.f ? gam_lookup<LDS>(lds, a.igamcurve, X) : (gammaf_s(X / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
-        if (Y > 0.f) Y = Y < 65536.f ? gam_lookup<LDS>(lds, a.igamcurve, Y) : (gammaf_s(Y / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
-        if (Z > 0.f) Z = Z < 65536.f ? gam_lookup<LDS>(lds, a.igamcurve, Z) : (gammaf_s(Z / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
+        if (X > 0.f) X = X < 65536.f ? gam_lookup<LDS>(lds, a.igamcurve, X, a.igam_lds_lo) : (gammaf_s(X / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
+        if (Y > 0.f) Y = Y < 65536.f ? gam_lookup<LDS>(lds, a.igamcurve, Y, a.igam_lds_lo) : (gammaf_s(Y / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
+        if (Z > 0.f) Z = Z < 65536.f ? gam_lookup<LDS>(lds, a.igamcurve, Z, a.igam_lds_lo) : (gammaf_s(Z / 65535.f, a.igam, a.igamthresh, a.igamslope) * 65535.f);
     }
     const size_t di = (size_t)y * a.stride + x;
     if (a.lab_mode) { X = lutf_noclip(a.dn_gamma, X); Y = lutf_noclip(a.dn_gamma, Y); Z = lutf_noclip(a.dn_gamma, Z); }   // L2533-2537
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) yuv2rgb_kernel(DnPixArgs a)
 __global__ void __launch_bounds__(1024) yuv2rgb_lds_kernel(DnPixArgs a)
 {
     extern __shared__ float dn_lut_lds[];
-    lut_lds_fill(dn_lut_lds, a.igamcurve, 1024);
+    lut_lds_fill(dn_lut_lds, a.igamcurve, 1024, a.igam_lds_lo);
     for (int y = blockIdx.x; y < a.h; y += gridDim.x)
         for (int x0 = 0; x0 < a.w; x0 += LDSK_PX * 1024) {
             float l[LDSK_PX], av[LDSK_PX], bv[LDSK_PX];

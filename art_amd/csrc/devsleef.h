@@ -190,11 +190,16 @@ __device__ __forceinline__ float lutf_lookup(const float *__restrict__ data, int
 // table (256 KB) does not fit L1, so each lookup of a streaming kernel is otherwise an L2 line gather; linear scene data sit mostly in
 // the lower part of the range.  159 KB of the CU's 160 KB LDS: one workgroup per CU.
 constexpr int LUT_LDS_N = 40704;
+// (the LDS copy is addressed through an LDS-qualified pointer: with a generic one the compiler merges the two arms below into a select
+// of POINTERS and every lookup, LDS or not, becomes a flat_load -- SQ_INSTS_LDS of these kernels was the table fill and nothing else)
+typedef __attribute__((address_space(3))) const float lds_cfloat;
 template <bool CLIP_ABOVE>
-__device__ __forceinline__ float lutf_lookup_lds(const float *lds, const float *__restrict__ data, int size, float index)
+__device__ __forceinline__ float lutf_lookup_lds(const float *lds_generic, const float *__restrict__ data, int size, float index, int lo = 0)
 {
+    // entries [lo, lo + LUT_LDS_N) of the table are in LDS (lo a multiple of 4)
+    lds_cfloat *lds = (lds_cfloat *)lds_generic;
     const int maxs = size - 2;
-    if (index < 0.f || !(index == index)) return lds[0];
+    if (index < 0.f || !(index == index)) return lo ? data[0] : lds[0];
     int idx = (int)index;
     if (index > (float)maxs) {
         if (CLIP_ABOVE) return data[size - 1];
@@ -202,14 +207,14 @@ __device__ __forceinline__ float lutf_lookup_lds(const float *lds, const float *
     }
     const float diff = index - (float)idx;
     float p1, q;
-    if (idx + 1 < LUT_LDS_N) { p1 = lds[idx]; q = lds[idx + 1]; }
+    if ((unsigned)(idx - lo) < (unsigned)(LUT_LDS_N - 1)) { p1 = lds[idx - lo]; q = lds[idx - lo + 1]; }
     else { p1 = data[idx]; q = data[idx + 1]; }
     const float p2 = q - p1;
     return p1 + p2 * diff;
 }
-__device__ __forceinline__ void lut_lds_fill(float *lds, const float *__restrict__ data, int nthreads)
+__device__ __forceinline__ void lut_lds_fill(float *lds, const float *__restrict__ data, int nthreads, int lo = 0)
 {
-    const float4 *src = reinterpret_cast<const float4 *>(data);
+    const float4 *src = reinterpret_cast<const float4 *>(data + lo);
     float4 *dst = reinterpret_cast<float4 *>(lds);
     for (int i = threadIdx.x; i < LUT_LDS_N / 4; i += nthreads) dst[i] = src[i];
     __syncthreads();

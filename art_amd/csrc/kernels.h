@@ -299,6 +299,7 @@ struct DnPixArgs {
     float realred, realblue, qhighFactor;
     float pre_scale, post_scale;   // != 0: exposure compensation fused in front of rgb2yuv / behind yuv2rgb
     int lab_mode;                  // DenoiseParams::colorSpace == LAB (FTblockDN.cc:1996)
+    int igam_lds_lo;               // yuv2rgb_lds: entries [lo, lo + 40704) of the inverse gamma table live in LDS (multiple of 4)
     float wpi[9], iws[9];          // LAB: working space <-> XYZ, float casts
     const float *cachef, *cachefy, *dn_gamma, *dn_igamma;   // LAB: 65536-entry LUTs
 };

@@ -43,7 +43,7 @@ __device__ __forceinline__ float get_pq(const PqTab pq, float x)
     if (index > 65534.f) idx = 65534;
     const float diff = index - (float)idx;
     float p1, q;
-    if (idx + 1 < LUT_LDS_N) { p1 = pq.lds[idx]; q = pq.lds[idx + 1]; }
+    if (idx + 1 < LUT_LDS_N) { lds_cfloat *l = (lds_cfloat *)pq.lds; p1 = l[idx]; q = l[idx + 1]; }     // (LDS-qualified: ds_read, not flat_load)
     else { p1 = pq.g[idx]; q = pq.g[idx + 1]; }
     const float p2 = q - p1;
     return p1 + p2 * diff;
