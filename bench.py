@@ -271,9 +271,23 @@ def main() -> None:
     # elapsed = MAX over ranks
     from art_amd import batch
     cs = batch.checksum64([int(d_out[1][H // 2, W // 2].item())])
+    hard_exit = False
     if "WORLD_SIZE" in os.environ and not os.environ.get("ARTGPU_BENCH_TORCH_GATHER"):
         # under a launcher (any N): through the C ABI, over an RCCL communicator (artgpu_batch_complete)
-        records, elapsed, gather_via = batch.complete_batch_rccl(ctx, dist, dev, rank, world, args.steps, 0, cs, t1 - t0)
+        # (in a watchdog thread: should the communicator set-up ever hang on some node, every rank times out the same way and the
+        # measurement is completed through torch.distributed instead of being lost)
+        import threading
+        box = {}
+        th = threading.Thread(target=lambda: box.update(r=batch.complete_batch_rccl(ctx, dist, dev, rank, world, args.steps, 0, cs, t1 - t0)), daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("ARTGPU_BENCH_RCCL_TIMEOUT", "180")))
+        if "r" in box:
+            records, elapsed, gather_via = box["r"]
+        else:
+            print(f"[bench rank {rank}] artgpu_batch_complete over RCCL did not finish: completing through torch.distributed", file=sys.stderr, flush=True)
+            records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, args.steps, 0, cs, t1 - t0)
+            gather_via = "torch.distributed (rccl-capi timed out)"
+            hard_exit = True
     else:
         records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, args.steps, 0, cs, t1 - t0)
         gather_via = "torch.distributed" if world > 1 else "single process"
@@ -424,6 +438,9 @@ def main() -> None:
         }
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if hard_exit:               # a thread is still blocked inside RCCL: do not wait for it
+        sys.stdout.flush()
+        os._exit(0)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
