@@ -220,28 +220,43 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
             float swv = asw[q], imv = aim[q];
             const float *sbp = strip_b + sty * G_SB + (s - row / RPL + sty / RPL - pr + 8 - sr);    // + w: the sample at offset w
             const float *crp = cring_all + s * RP + row;
-            for (int w = 0; w < nt; ++w) {
-                const float dist = crp[w * (G_CH * RP)];
-                const float dist2 = vec ? sse_max(dist, 0.f) : std_max(dist, 0.f);
-                const float dd = dist2 * m;
+            // weight of offset w in the reference's two lane forms (vector lanes L213-228, scalar tail L229-243), added in offset order
+            auto add_vec = [&](int w) {
+                const float dd = sse_max(crp[w * (G_CH * RP)], 0.f) * m;
+                const float clamped = sse_max(sse_min(8190.f, dd), 0.f);
+                const int idx = (int)clamped;
+                const float diff = sse_max(sse_min(8191.f, dd), 0.f) - (float)idx;
+                const float weight = (diff * explut[idx + 1]) + ((1.f - diff) * explut[idx]);
+                swv = swv + weight;
+                imv = imv + (weight * sbp[w]);
+            };
+            auto add_any = [&](int w) {
+                if (vec) { add_vec(w); return; }
+                const float dd = std_max(crp[w * (G_CH * RP)], 0.f) * m;
                 float weight;
-                if (vec) {
-                    const float clamped = sse_max(sse_min(8190.f, dd), 0.f);
-                    const int idx = (int)clamped;
-                    const float diff = sse_max(sse_min(8191.f, dd), 0.f) - (float)idx;
-                    weight = (diff * explut[idx + 1]) + ((1.f - diff) * explut[idx]);
-                } else {
-                    if (dd < 0.f || !(dd == dd)) weight = explut[0];
-                    else if (dd > 8190.f) weight = explut[8191];
-                    else {
-                        const int idx = (int)dd;
-                        const float diff = dd - (float)idx;
-                        const float p1 = explut[idx], p2 = explut[idx + 1] - p1;
-                        weight = p1 + (p2 * diff);
-                    }
+                if (dd < 0.f || !(dd == dd)) weight = explut[0];
+                else if (dd > 8190.f) weight = explut[8191];
+                else {
+                    const int idx = (int)dd;
+                    const float diff = dd - (float)idx;
+                    const float p1 = explut[idx], p2 = explut[idx + 1] - p1;
+                    weight = p1 + (p2 * diff);
                 }
                 swv = swv + weight;
                 imv = imv + (weight * sbp[w]);
+            };
+            // Nearly every wave holds vector-form pixels only (the scalar form is the last < 4 columns of a tile): that case runs
+            // without a per-offset branch, and with the full search row as straight-line code -- the exec-mask bookkeeping and the
+            // loop control of the general form were a third of this pass's instructions.
+            if (__builtin_amdgcn_ballot_w64(!vec) == 0) {
+                if (nt == G_NW) {
+#pragma unroll
+                    for (int w = 0; w < G_NW; ++w) add_vec(w);
+                } else {
+                    for (int w = 0; w < nt; ++w) add_vec(w);
+                }
+            } else {
+                for (int w = 0; w < nt; ++w) add_any(w);
             }
             SW[aoo[q]] = swv;
             img[aio[q]] = imv;
