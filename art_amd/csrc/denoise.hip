@@ -147,19 +147,19 @@ __global__ void __launch_bounds__(1024) rgb2yuv_lds_kernel(DnPixArgs a)
 {
     extern __shared__ float dn_lut_lds[];
     lut_lds_fill(dn_lut_lds, a.gamcurve, 1024);
-    for (int y = blockIdx.x; y < a.h; y += gridDim.x)
+    for (int yb = blockIdx.x; yb < a.h; yb += LDSK_ROWS * gridDim.x)
         for (int x0 = 0; x0 < a.w; x0 += LDSK_PX * 1024) {
-            float r[LDSK_PX], g[LDSK_PX], b[LDSK_PX];
+            float r[LDSK_ROWS * LDSK_PX], g[LDSK_ROWS * LDSK_PX], b[LDSK_ROWS * LDSK_PX];
 #pragma unroll
-            for (int k = 0; k < LDSK_PX; ++k) {
-                const int x = x0 + k * 1024 + (int)threadIdx.x;
+            for (int k = 0; k < LDSK_ROWS * LDSK_PX; ++k) {
+                const int x = x0 + (k % LDSK_PX) * 1024 + (int)threadIdx.x, yr = yb + (k / LDSK_PX) * (int)gridDim.x, y = yr < a.h ? yr : a.h - 1;
                 const size_t si = (size_t)y * a.stride + (x < a.w ? x : a.w - 1);
                 r[k] = a.rgb[0][si]; g[k] = a.rgb[1][si]; b[k] = a.rgb[2][si];
             }
 #pragma unroll
-            for (int k = 0; k < LDSK_PX; ++k) {
-                const int x = x0 + k * 1024 + (int)threadIdx.x;
-                if (x < a.w) rgb2yuv_px<true>(a, dn_lut_lds, y, x, r[k], g[k], b[k]);
+            for (int k = 0; k < LDSK_ROWS * LDSK_PX; ++k) {
+                const int x = x0 + (k % LDSK_PX) * 1024 + (int)threadIdx.x, yr = yb + (k / LDSK_PX) * (int)gridDim.x, y = yr < a.h ? yr : a.h - 1;
+                if (x < a.w && yr < a.h) rgb2yuv_px<true>(a, dn_lut_lds, y, x, r[k], g[k], b[k]);
             }
         }
 }
@@ -204,19 +204,19 @@ __global__ void __launch_bounds__(1024) yuv2rgb_lds_kernel(DnPixArgs a)
 {
     extern __shared__ float dn_lut_lds[];
     lut_lds_fill(dn_lut_lds, a.igamcurve, 1024, a.igam_lds_lo);
-    for (int y = blockIdx.x; y < a.h; y += gridDim.x)
+    for (int yb = blockIdx.x; yb < a.h; yb += LDSK_ROWS * gridDim.x)
         for (int x0 = 0; x0 < a.w; x0 += LDSK_PX * 1024) {
-            float l[LDSK_PX], av[LDSK_PX], bv[LDSK_PX];
+            float l[LDSK_ROWS * LDSK_PX], av[LDSK_ROWS * LDSK_PX], bv[LDSK_ROWS * LDSK_PX];
 #pragma unroll
-            for (int k = 0; k < LDSK_PX; ++k) {
-                const int x = x0 + k * 1024 + (int)threadIdx.x;
+            for (int k = 0; k < LDSK_ROWS * LDSK_PX; ++k) {
+                const int x = x0 + (k % LDSK_PX) * 1024 + (int)threadIdx.x, yr = yb + (k / LDSK_PX) * (int)gridDim.x, y = yr < a.h ? yr : a.h - 1;
                 const long long t = (long long)y * a.w + (x < a.w ? x : a.w - 1);
                 l[k] = a.L[t]; av[k] = a.A[t]; bv[k] = a.B[t];
             }
 #pragma unroll
-            for (int k = 0; k < LDSK_PX; ++k) {
-                const int x = x0 + k * 1024 + (int)threadIdx.x;
-                if (x < a.w) yuv2rgb_px<true>(a, dn_lut_lds, y, x, l[k], av[k], bv[k]);
+            for (int k = 0; k < LDSK_ROWS * LDSK_PX; ++k) {
+                const int x = x0 + (k % LDSK_PX) * 1024 + (int)threadIdx.x, yr = yb + (k / LDSK_PX) * (int)gridDim.x, y = yr < a.h ? yr : a.h - 1;
+                if (x < a.w && yr < a.h) yuv2rgb_px<true>(a, dn_lut_lds, y, x, l[k], av[k], bv[k]);
             }
         }
 }

@@ -61,6 +61,9 @@ __device__ __forceinline__ int ngroups(int start, int bound, int step)
 #ifndef LDSK_PX
 #define LDSK_PX 8
 #endif
+#ifndef LDSK_ROWS
+#define LDSK_ROWS 2      // rows per batch (the rows a workgroup owns are gridDim.x apart)
+#endif
 
 // Pixel loops without integer division: blockIdx.y strides over rows, blockIdx.x * blockDim.x + threadIdx.x over columns
 // (a flat index costs a 64-bit division per pixel, which showed up as ~1.5 TB/s on kernels that should stream at 4 TB/s).

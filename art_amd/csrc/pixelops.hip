@@ -130,19 +130,19 @@ __global__ void __launch_bounds__(1024) tone_std_lds_kernel(PixArgs a)
     extern __shared__ float tone_lds[];
     lut_lds_fill(tone_lds, a.lut, 1024);
     const float Lmax = 65535.f * a.whitept;
-    for (int y = blockIdx.x; y < a.h; y += gridDim.x)
+    for (int yb = blockIdx.x; yb < a.h; yb += LDSK_ROWS * gridDim.x)
         for (int x0 = 0; x0 < a.w; x0 += LDSK_PX * 1024) {
-            float r[LDSK_PX], g[LDSK_PX], b[LDSK_PX];
+            float r[LDSK_ROWS * LDSK_PX], g[LDSK_ROWS * LDSK_PX], b[LDSK_ROWS * LDSK_PX];
 #pragma unroll
-            for (int k = 0; k < LDSK_PX; ++k) {
-                const int x = x0 + k * 1024 + (int)threadIdx.x;
+            for (int k = 0; k < LDSK_ROWS * LDSK_PX; ++k) {
+                const int x = x0 + (k % LDSK_PX) * 1024 + (int)threadIdx.x, yr = yb + (k / LDSK_PX) * (int)gridDim.x, y = yr < a.h ? yr : a.h - 1;
                 const size_t di = (size_t)y * a.dst_stride + (x < a.w ? x : a.w - 1);
                 r[k] = a.dst[0][di]; g[k] = a.dst[1][di]; b[k] = a.dst[2][di];
             }
 #pragma unroll
-            for (int k = 0; k < LDSK_PX; ++k) {
-                const int x = x0 + k * 1024 + (int)threadIdx.x;
-                if (x >= a.w) continue;
+            for (int k = 0; k < LDSK_ROWS * LDSK_PX; ++k) {
+                const int x = x0 + (k % LDSK_PX) * 1024 + (int)threadIdx.x, yr = yb + (k / LDSK_PX) * (int)gridDim.x, y = yr < a.h ? yr : a.h - 1;
+                if (x >= a.w || yr >= a.h) continue;
                 const size_t di = (size_t)y * a.dst_stride + x;
                 float rr = r[k], gg = g[k], bb = b[k];
                 if (a.do_clip) filmlike_clip_px(rr, gg, bb, Lmax);
