@@ -55,24 +55,27 @@ def test_rcd_bit_exact(rcd_options, w, h, filt, noise, rows):
         assert _diff(got, ref) == [0, 0, 0]
 
 
-def test_device_pointers_and_strides(gpu_ctx):
-    """Device-resident planes with a padded row stride (PlanarRGBData layout, iimage.h:653-720)."""
+@pytest.mark.parametrize("method,pad,shift", [("amaze", 16, 0), ("rcd", 16, 0), ("rcd", 13, 1), ("rcd", 7, 3)])
+def test_device_pointers_and_strides(gpu_ctx, method, pad, shift):
+    """Device-resident planes with a padded row stride (PlanarRGBData layout, iimage.h:653-720).  RCD stores column pairs as one
+    64-bit word when the output rows allow it: odd strides and planes that start on an odd float take the scalar path."""
     import torch
     from art_amd import capi
     w, h, filt = 330, 270, synth.FILTERS_RGGB
     raw = synth.bayer_frame(w, h, filt, seed=11)
-    stride = (w + 15) // 16 * 16 + 16
+    stride = (w + 15) // 16 * 16 + pad
     d_raw = torch.zeros((h, stride), device="cuda:0")
     d_raw[:, :w] = torch.from_numpy(raw).cuda()
-    d_out = [torch.full((h, stride), float("nan"), device="cuda:0") for _ in range(3)]
-    out = capi.RGB(*[capi.device_plane(t[:, :w]) for t in d_out])
-    gpu_ctx.demosaic_bayer(capi.BAYER_AMAZE, capi.device_plane(d_raw[:, :w]), filt, 1.0, 4, out)
+    d_out = [torch.full((h, stride + shift), float("nan"), device="cuda:0") for _ in range(3)]
+    out = capi.RGB(*[capi.device_plane(t[:, shift:shift + w]) for t in d_out])
+    m = capi.BAYER_AMAZE if method == "amaze" else capi.BAYER_RCD
+    gpu_ctx.demosaic_bayer(m, capi.device_plane(d_raw[:, :w]), filt, 1.0, 4, out)
     gpu_ctx.synchronize()
-    ref = oracle_lib.amaze(raw, filt, 1.0, 4)
-    got = [t[:, :w].cpu().numpy() for t in d_out]
+    ref = oracle_lib.amaze(raw, filt, 1.0, 4) if method == "amaze" else oracle_lib.rcd(raw, filt)
+    got = [t[:, shift:shift + w].cpu().numpy() for t in d_out]
     assert _diff(got, ref) == [0, 0, 0]
     for t in d_out:  # padding untouched
-        assert torch.isnan(t[:, w:]).all()
+        assert torch.isnan(t[:, shift + w:]).all() and torch.isnan(t[:, :shift]).all()
 
 
 def test_deterministic(gpu_ctx):
