@@ -160,8 +160,9 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
 __global__ void __launch_bounds__(256) detail_gather_kernel(DetailArgs a)
 {
     const float DCTnorm = 1.0f / (4 * TS * TS);
-    FOR_IMAGE_XY(y, x, a.w, a.h) {            // (no 64-bit division per pixel)
-        const size_t t = (size_t)y * a.w + x;
+    const long long n = (long long)a.w * a.h;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
         // blocks with top <= y < top + 64, top = (vblk - 1) * 25: at most three per axis
         const int vb0 = max(0, y / OFF + BLKRAD - 2), vb1 = min(a.numblox_H - 1, y / OFF + BLKRAD);
         const int hb0 = max(0, x / OFF + BLKRAD - 2), hb1 = min(a.numblox_W - 1, x / OFF + BLKRAD);
@@ -195,7 +196,9 @@ hipError_t launch_detail_blocks(const DetailArgs &a, hipStream_t s)
 }
 hipError_t launch_detail_gather(const DetailArgs &a, hipStream_t s)
 {
-    hipLaunchKernelGGL(detail_gather_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
+    const long long n = (long long)a.w * a.h;
+    const long long g = (n + 255) / 256;
+    hipLaunchKernelGGL(detail_gather_kernel, dim3((int)(g < 16384 ? g : 16384)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -35,9 +35,10 @@ __device__ __forceinline__ float bilinear(const float *__restrict__ src, int W, 
 //    chan = xlin2log(max(chan,0),10)                                      (ipsmoothing.cc:353-369, guidedfilter.cc:246-253)
 __global__ void __launch_bounds__(256) gf_prepare_kernel(GuidedArgs a)
 {
+    const long long n = (long long)a.W * a.H;
     const float f1 = 1.f / 65535.f;
-    FOR_IMAGE_XY(y, x, a.W, a.H) {          // (no 64-bit division per pixel)
-        const size_t t = (size_t)y * a.W + x;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.W), x = (int)(t - (long long)y * a.W);
         const size_t si = (size_t)y * a.stride + x;
         const float r = a.rgb[0][si] * f1, g = a.rgb[1][si] * f1, b = a.rgb[2][si] * f1;
         a.in[0][t] = r; a.in[1][t] = g; a.in[2][t] = b;
@@ -99,9 +100,10 @@ __global__ void __launch_bounds__(256) gf_ab_kernel(GuidedArgs a)
 //    original luminance (ipsmoothing.cc:382-406); x 65535                      (guidedfilter.cc:225-240,258-264)
 __global__ void __launch_bounds__(256) gf_finish_kernel(GuidedArgs a)
 {
+    const long long n = (long long)a.W * a.H;
     const float col_scale = (float)a.w / (float)a.W, row_scale = (float)a.h / (float)a.H;
-    FOR_IMAGE_XY(y, x, a.W, a.H) {
-        const size_t t = (size_t)y * a.W + x;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.W), x = (int)(t - (long long)y * a.W);
         const float fx = x * col_scale, fy = y * row_scale;
         const float I = a.guide[t];
         float o[3];
@@ -140,10 +142,10 @@ __global__ void __launch_bounds__(256) gf_finish_plain_kernel(GuidedArgs a)
 }
 
 static int fgrid(long long n) { long long g = (n + 255) / 256; return (int)(g < 16384 ? g : 16384); }
-hipError_t launch_gf_prepare(const GuidedArgs &a, hipStream_t s) { hipLaunchKernelGGL(gf_prepare_kernel, image_grid(a.W, a.H), dim3(256), 0, s, a); return hipGetLastError(); }
+hipError_t launch_gf_prepare(const GuidedArgs &a, hipStream_t s) { hipLaunchKernelGGL(gf_prepare_kernel, dim3(fgrid((long long)a.W * a.H)), dim3(256), 0, s, a); return hipGetLastError(); }
 hipError_t launch_gf_subsample(const GuidedArgs &a, hipStream_t s) { hipLaunchKernelGGL(gf_subsample_kernel, dim3(fgrid((long long)a.w * a.h)), dim3(256), 0, s, a); return hipGetLastError(); }
 hipError_t launch_gf_ab(const GuidedArgs &a, hipStream_t s) { hipLaunchKernelGGL(gf_ab_kernel, dim3(fgrid((long long)a.w * a.h)), dim3(256), 0, s, a); return hipGetLastError(); }
 hipError_t launch_gf_finish_plain(const GuidedArgs &a, hipStream_t s) { hipLaunchKernelGGL(gf_finish_plain_kernel, image_grid(a.W, a.H), dim3(256), 0, s, a); return hipGetLastError(); }
-hipError_t launch_gf_finish(const GuidedArgs &a, hipStream_t s) { hipLaunchKernelGGL(gf_finish_kernel, image_grid(a.W, a.H), dim3(256), 0, s, a); return hipGetLastError(); }
+hipError_t launch_gf_finish(const GuidedArgs &a, hipStream_t s) { hipLaunchKernelGGL(gf_finish_kernel, dim3(fgrid((long long)a.W * a.H)), dim3(256), 0, s, a); return hipGetLastError(); }
 
 } // namespace artgpu

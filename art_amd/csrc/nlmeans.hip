@@ -81,10 +81,11 @@ __global__ void __launch_bounds__(256) dm_laplacian_kernel(MaskArgs a)
 // mask = scurve(LIM01(rescaleBilinear(m2 -> W x H) + 1 - factor))
 __global__ void __launch_bounds__(256) dm_up_scurve_kernel(MaskArgs a)
 {
+    const long long n = (long long)a.W * a.H;
     const float col_scale = (float)a.w4 / (float)a.W, row_scale = (float)a.h4 / (float)a.H;
     const float thr1 = 1.f - a.factor;
-    FOR_IMAGE_XY(y, x, a.W, a.H) {
-        const size_t t = (size_t)y * a.W + x;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.W), x = (int)(t - (long long)y * a.W);
         const float v = lim01(bilinear(a.m2, a.w4, a.h4, x * col_scale, y * row_scale) + thr1);
         a.mask[t] = xlin2log(pow_F(v, 2.23f), 101.f);
     }
@@ -237,8 +238,9 @@ __global__ void __launch_bounds__(256) nlm_prepare_kernel(NlmArgs a)
 }
 __global__ void __launch_bounds__(256) nlm_zero_kernel(NlmArgs a)
 {
-    FOR_IMAGE_XY(y, x, a.W, a.H) {
-        const size_t t = (size_t)y * a.W + x;
+    const long long n = (long long)a.W * a.H;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.W), x = (int)(t - (long long)y * a.W);
         a.img[(size_t)y * a.img_stride + x] = 0.f;
         a.SW[t] = 0.f;
     }
@@ -249,7 +251,7 @@ hipError_t launch_detail_mask(const MaskArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(dm_down_log_kernel, dim3(fgrid((long long)a.w4 * a.h4)), dim3(256), 0, s, a);
     hipLaunchKernelGGL(dm_laplacian_kernel, dim3(fgrid((long long)a.w4 * a.h4)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(dm_up_scurve_kernel, image_grid(a.W, a.H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(dm_up_scurve_kernel, dim3(fgrid((long long)a.W * a.H)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 // gaussianBlur with 0.25 <= sigma < 0.6 and src == dst (gauss.cc:1474-1483): separated 3-tap filter, gaussHorizontal3 (L446-465) into
@@ -291,7 +293,7 @@ hipError_t launch_nlm(const NlmArgs &a, hipStream_t s)
 {
     const long long npad = (long long)a.WW * a.HH;
     hipLaunchKernelGGL(nlm_prepare_kernel, dim3(fgrid(npad > 8192 ? npad : 8192)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(nlm_zero_kernel, image_grid(a.W, a.H), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(nlm_zero_kernel, dim3(fgrid((long long)a.W * a.H)), dim3(256), 0, s, a);
     // one workgroup per reference tile, a search row of offsets in flight (nlm_sweep.hip); covers every radius the reference
     // can ask for at scale >= 1 (search <= 5, patch 1..2, nlmeans.cc:62-66) -- anything else is a caller error, not a slow path
     if (!nlm_group_supported(a)) return hipErrorInvalidValue;
