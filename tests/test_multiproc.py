@@ -30,6 +30,41 @@ def _worker(rank, world, port, nframes, q):
     dist.destroy_process_group()
 
 
+def _worker_rccl_fallback(rank, world, port, q):
+    """complete_batch_rccl with a context that cannot do the RCCL gather on one rank only: the MIN-reduce has to send BOTH ranks to the
+    torch.distributed path (a one-sided fallback would deadlock)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Ctx:          # rank 0 "has" the entry point, rank 1 does not
+        pass
+    ctx = Ctx()
+    if rank == 0:
+        ctx.batch_complete = lambda *a, **k: (_ for _ in ()).throw(AssertionError("must not be called"))
+    recs, tmax, via = batch.complete_batch_rccl(ctx, dist, torch.device("cpu"), rank, world, 3 + rank, 0, 1000 + rank, 0.001 * (rank + 1))
+    q.put((rank, recs, tmax, via))
+    dist.destroy_process_group()
+
+
+def test_rccl_completion_falls_back_on_all_ranks_or_none():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rccl_fallback, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, recs, tmax, via in res:
+        assert via == "torch.distributed"
+        assert [r["frames"] for r in recs] == [3, 4] and [r["checksum"] for r in recs] == [1000, 1001]
+        assert abs(tmax - 0.002) < 1e-6
+
+
 def test_frames_partition_round_robin():
     for world in (1, 2, 4, 8):
         owned = [batch.frames_for_rank(8, r, world) for r in range(world)]
