@@ -153,7 +153,20 @@ __global__ void __launch_bounds__(256) wavelet_synthesis0_kernel(WaveArgs a)
     }
     __syncthreads();
     const float srcFactor = 1.f - a.blend;
-    for (int t = threadIdx.x; t < S0_TH * S0_TW; t += 256) {
+    // the destination values that take part in the blend are loaded up front: as `dst[o] = dst[o] * f + ...` in the loop every
+    // iteration's load had to wait for the previous iteration's store (same array), sixteen dependent memory round trips per thread
+    constexpr int NIT = S0_TH * S0_TW / 256;
+    float dv[NIT];
+#pragma unroll
+    for (int n = 0; n < NIT; ++n) {
+        const int t = threadIdx.x + n * 256;
+        const int rr = t / S0_TW, cc = t - rr * S0_TW;
+        const int i = min(r0 + rr, h - 1), k = min(c0 + cc, w - 1);
+        dv[n] = a.dst[(size_t)i * a.dst_stride + k];
+    }
+#pragma unroll
+    for (int n = 0; n < NIT; ++n) {
+        const int t = threadIdx.x + n * 256;
         const int rr = t / S0_TW, cc = t - rr * S0_TW;
         const int i = r0 + rr, k = c0 + cc;
         if (i >= h || k >= w) continue;
@@ -165,7 +178,7 @@ __global__ void __launch_bounds__(256) wavelet_synthesis0_kernel(WaveArgs a)
             tot += (SYN_LO[j] * tLo[lr][cc] + SYN_HI[j] * tHi[lr][cc]);
         }
         const size_t o = (size_t)i * a.dst_stride + k;
-        a.dst[o] = a.dst[o] * srcFactor + a.blend * 4.f * tot;
+        a.dst[o] = dv[n] * srcFactor + a.blend * 4.f * tot;
     }
 }
 
