@@ -14,6 +14,7 @@
 #include "cplx_wavelet_dec.h"
 #include "rescale.h"
 #include "iccmatrices.h"
+#include "linalgebra.h"
 
 extern "C" {
 
@@ -42,6 +43,30 @@ void ref_rec2020_matrices(float *xyz_rec2020_9, float *rec2020_xyz_9)
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { xyz_rec2020_9[3 * i + j] = rtengine::xyz_rec2020[i][j]; rec2020_xyz_9[3 * i + j] = rtengine::rec2020_xyz[i][j]; }
 }
 
+// linalgebra.h:141-239 (NeutralToneCurve builds its matrices with these and applies them per pixel, curves.cc:880-1038)
+void ref_mat33_dot_vec3(const float *m9, const float *v3, float *r3)
+{
+    float a[3][3];
+    for (int i = 0; i < 9; ++i) a[i / 3][i % 3] = m9[i];
+    rtengine::Vec3<float> r = rtengine::dot_product(a, v3);
+    for (int i = 0; i < 3; ++i) r3[i] = r[i];
+}
+void ref_mat33_dot_mat33(const float *a9, const float *b9, float *r9)
+{
+    float a[3][3], b[3][3];
+    for (int i = 0; i < 9; ++i) { a[i / 3][i % 3] = a9[i]; b[i / 3][i % 3] = b9[i]; }
+    rtengine::Mat33<float> r = rtengine::dot_product(a, b);
+    for (int i = 0; i < 9; ++i) r9[i] = r[i / 3][i % 3];
+}
+int ref_mat33_inverse(const float *m9, float *r9)
+{
+    float a[3][3];
+    for (int i = 0; i < 9; ++i) a[i / 3][i % 3] = m9[i];
+    rtengine::Mat33<float> r;
+    const bool ok = rtengine::inverse(a, r);
+    for (int i = 0; i < 9; ++i) r9[i] = r[i / 3][i % 3];
+    return ok ? 1 : 0;
+}
 void ref_xexpf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xexpf(x[i]); }
 void ref_xcbrtf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xcbrtf(x[i]); }
 void ref_xsincosf(const float *d, float *sn, float *cs, size_t n) { for (size_t i = 0; i < n; ++i) { float2 v = xsincosf(d[i]); sn[i] = v.x; cs[i] = v.y; } }

@@ -60,6 +60,11 @@ static inline void mat_vec(const float m[9], const float v[3], float r[3])
         r[i] = acc;
     }
 }
+/* test export: n products m[k] (9 floats) x v[k] (3 floats), pinned against linalgebra.h's dot_product (tests/test_golden_pins.py) */
+void oracle_t_mat_vec(const float *m, const float *v, float *r, size_t n)
+{
+    for (size_t k = 0; k < n; ++k) mat_vec(m + 9 * k, v + 3 * k, r + 3 * k);
+}
 static const float D50_D65[9] = {0.9555766f, -0.0230393f, 0.0631636f, -0.0282895f, 1.0099416f, 0.0210077f, 0.0122982f, -0.0204830f, 1.3299098f};
 static const float D65_D50[9] = {1.0478112f, 0.0228866f, -0.0501270f, 0.0295424f, 0.9904844f, -0.0170491f, -0.0092345f, 0.0150436f, 0.7521316f};
 

@@ -185,7 +185,24 @@ def rescale_and_matrices():
     np.savez_compressed(os.path.join(HERE, "rescale.npz"), **out)
 
 
+def linalgebra():
+    """dot_product(Mat33<float>, Vec3<float>) of linalgebra.h:226-239: what NeutralToneCurve applies per pixel (to_out, to_work, the D50 / D65
+    adaptation matrices of Jzazbz).  Random matrices and vectors incl. special values."""
+    rng = np.random.default_rng(91)
+    n = 4096
+    m = rng.normal(0, 1.5, (n, 9)).astype(np.float32)
+    v = (rng.normal(0, 1, (n, 3)) * np.exp2(rng.integers(-20, 20, (n, 1)))).astype(np.float32)
+    v[:16, 0] = 0.0
+    v[16:32, 1] = -0.0
+    m[32:48, 4] = np.float32(1e-30)
+    r = np.empty((n, 3), np.float32)
+    for k in range(n):
+        R.ref_mat33_dot_vec3(P(m[k]), P(v[k]), P(r[k]))
+    np.savez_compressed(os.path.join(HERE, "linalgebra.npz"), m=m, v=v, r=r)
+
+
 if __name__ == "__main__":
+    linalgebra()
     rescale_and_matrices()
     wavelet()
     helpers()

@@ -126,3 +126,13 @@ def test_working_space_matrices_are_the_reference_constants():
     for m, name in ((g["xyz_rec2020"], "ws"), (g["rec2020_xyz"], "iws_n")):
         txt = re.search(name + r" = np\.array\((\[\[.*?\]\])\)", src, re.S).group(1)
         assert np.array_equal(np.array(eval(txt), dtype=np.float32), m), name
+
+
+def test_mat_vec_matches_reference_linalgebra_h():
+    """the oracle's mat_vec (tonecurve.c: NEUTRAL's to_out / to_work / chromatic-adaptation products) against dot_product(Mat33, Vec3) of the
+    reference's own linalgebra.h:226-239 (compiled in place into oracle/_ref)"""
+    g = np.load(os.path.join(G, "linalgebra.npz"))
+    m, v, ref = np.ascontiguousarray(g["m"]), np.ascontiguousarray(g["v"]), g["r"]
+    out = np.empty_like(ref)
+    O.lib().oracle_t_mat_vec(P(m), P(v), P(out), C.c_size_t(len(m)))
+    assert same_bits(out, ref)
