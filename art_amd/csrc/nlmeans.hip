@@ -92,92 +92,166 @@ __global__ void __launch_bounds__(256) dm_up_scurve_kernel(MaskArgs a)
 }
 
 // ---------------------------------------------------------------- Young-van Vliet gaussian (gauss.cc:554-665,716-856)
-template <typename C>
-__device__ __forceinline__ void yvv_line(float *__restrict__ p, size_t st, float *__restrict__ tmp, size_t tst, int n, C B, C b1, C b2, C b3, const C *M)
+// A line (row or column) is one serial recurrence: forward into tmp, Triggs-Sdika boundary, backward into the image.  One lane
+// per line is the only parallelism there is, and a wave that does its own load and store per step is limited by the 64 memory
+// operations it may have outstanding (vmcnt) and by their latency, whatever the prefetch depth or the number of waves (measured:
+// 0.52 ms vertical, 0.74 ms horizontal per 45 MP plane).  So the recurrence wave of a workgroup touches LDS only: four loader
+// waves bring 64-step chunks of the group's 64 lines into an LDS ring by LDS-DMA, three chunks ahead (no registers in between,
+// each wave with its own window of outstanding operations), three storer waves write the chunk the recurrence wave has filtered
+// in place back, one LDS-only barrier per chunk.  Loaders and storers are different waves because vmcnt counts loads and stores
+// together: a wave waiting for its prefetch would wait for its younger stores as well.
+// Lines the reference filters with double coefficients (the rows / columns behind its 4- / 8-wide vector loops) form a
+// workgroup of their own in the same launch.
+namespace {
+typedef __attribute__((address_space(3))) float *gs_lf;
+constexpr int GS_CH = 64;             // steps per chunk
+constexpr int GS_PITCH = 65;          // LDS row pitch (65: the recurrence wave's column walk through horizontal chunks is conflict-free)
+constexpr int GS_AHEAD = 3;           // chunks in flight
+constexpr int GS_NB = GS_AHEAD + 2;   // ring: in flight, being filtered, being written back
+constexpr int GS_LOADERS = 4, GS_STORERS = 3, GS_NT = 64 * (1 + GS_LOADERS + GS_STORERS);
+constexpr int GS_LPER = GS_CH / GS_LOADERS, GS_SPER = (GS_CH + GS_STORERS - 1) / GS_STORERS;
+constexpr int GS_LDS_BYTES = GS_NB * GS_CH * GS_PITCH * 4;
+static_assert(GS_AHEAD * GS_LPER < 64, "vmcnt window");
+
+// workgroup barrier that orders LDS traffic only: a __syncthreads() would also drain the DMA in flight and the stores
+__device__ __forceinline__ void gs_lds_barrier()
 {
-    // forward (tmp may alias nothing; float storage as in the reference's AlignedMatrix<float>)
-    const float s0 = p[0], sl = p[(size_t)(n - 1) * st];
-    float t0 = s0 * (B + b1 + b2 + b3);
-    float t1 = sizeof(C) == 4 ? (float)(p[st] * B + t0 * b1 + s0 * (b2 + b3)) : (float)(B * p[st] + b1 * t0 + s0 * (b2 + b3));
-    float t2 = sizeof(C) == 4 ? (float)(p[2 * st] * B + t1 * b1 + t0 * b2 + s0 * b3) : (float)(B * p[2 * st] + b1 * t1 + b2 * t0 + b3 * s0);
-    tmp[0] = t0; tmp[tst] = t1; tmp[2 * tst] = t2;
-    float m3 = t0, m2 = t1, m1 = t2;
-    // the loads do not depend on the recurrence: sixteen of them are issued before the sixteen steps that consume them -- and one batch
-    // AHEAD of the stores of the current batch: vmcnt retires in order, so a wait for loads issued after stores would wait for the stores too
-    int j = 3;
-    float x[16], xn[16];
-    if (j + 16 <= n) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = p[(size_t)(j + k) * st];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// position of step s of chunk k along the line
+__device__ __forceinline__ int gs_pos(bool fwd, int n, int k, int s) { return fwd ? k * GS_CH + s : n - 1 - k * GS_CH - s; }
+
+template <bool HORIZ, typename C>
+__device__ __forceinline__ void gauss_stream_group(const GaussArgs &a, int line0, int nl, C B, C b1, C b2, C b3, const C *M, gs_lf lds)
+{
+    const int n = HORIZ ? a.W : a.H, nlines = line0 + nl;
+    const size_t W = (size_t)a.W;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nchunks = (n + GS_CH - 1) / GS_CH;
+    const bool compute = wave == 0, loader = wave >= 1 && wave <= GS_LOADERS, storer = wave > GS_LOADERS;
+    const int m = loader ? wave - 1 : wave - 1 - GS_LOADERS;
+    // chunk row j = step j of the chunk (vertical: lanes are the lines) or line j of the group (horizontal: lanes are the steps)
+    float m1 = 0.f, m2 = 0.f, m3 = 0.f, sl = 0.f;
+    if (compute) {
+        const int l = min(line0 + lane, nlines - 1);
+        sl = a.img[HORIZ ? (size_t)l * W + (n - 1) : (size_t)(n - 1) * W + l];
     }
-    for (; j + 16 <= n; j += 16) {
-        const bool more = j + 32 <= n;
+
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool fwd = pass == 0;
+        const float *__restrict__ src = fwd ? a.img : a.tmp;
+        float *__restrict__ dst = fwd ? a.tmp : a.img;
+        // chunk k -> ring slot k % GS_NB; every lane fetches (addresses clamped into the plane) so that the number of loads in flight is known
+        auto fetch = [&](int k) {
+            const gs_lf slot = lds + (k % GS_NB) * (GS_CH * GS_PITCH);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) xn[k] = p[(size_t)(more ? j + 16 + k : j + k) * st];
+            for (int q = 0; q < GS_LPER; ++q) {
+                const int j = m + GS_LOADERS * q;
+                const int line = min(line0 + (HORIZ ? j : lane), nlines - 1);
+                const int pos = min(max(gs_pos(fwd, n, k, HORIZ ? lane : j), 0), n - 1);
+                const float *g = HORIZ ? src + (size_t)line * W + pos : src + (size_t)pos * W + line;
+                __builtin_amdgcn_global_load_lds(g, slot + j * GS_PITCH, 4, 0, 0);      // to (wave-uniform LDS base) + 4 * lane
+            }
+        };
+        auto drain = [&](int k) {
+            const gs_lf slot = lds + (k % GS_NB) * (GS_CH * GS_PITCH);
+            float v[GS_SPER];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float v = sizeof(C) == 4 ? (float)(x[k] * B + m1 * b1 + m2 * b2 + m3 * b3) : (float)(B * x[k] + b1 * m1 + b2 * m2 + b3 * m3);
-            tmp[(size_t)(j + k) * tst] = v;
-            m3 = m2; m2 = m1; m1 = v;
+            for (int q = 0; q < GS_SPER; ++q) v[q] = slot[min(m + GS_STORERS * q, GS_CH - 1) * GS_PITCH + lane];
+#pragma unroll
+            for (int q = 0; q < GS_SPER; ++q) {
+                const int j = m + GS_STORERS * q;
+                const int line = line0 + (HORIZ ? j : lane), pos = gs_pos(fwd, n, k, HORIZ ? lane : j);
+                if (j < GS_CH && line < nlines && pos >= 0 && pos < n) dst[HORIZ ? (size_t)line * W + pos : (size_t)pos * W + line] = v[q];
+            }
+        };
+        if (loader) {
+#pragma unroll
+            for (int k = 0; k < GS_AHEAD; ++k) fetch(k);
+            __builtin_amdgcn_s_waitcnt(0x0f70 | (((GS_AHEAD - 1) * GS_LPER) & 15) | ((((GS_AHEAD - 1) * GS_LPER) >> 4) << 14));   // chunk 0 has landed
         }
+        gs_lds_barrier();
+        for (int i = 0; i <= nchunks; ++i) {
+            if (loader) {
+                // chunk i + 1 has landed when at most the GS_AHEAD - 2 younger chunks are outstanding; then chunk i + GS_AHEAD goes out
+                __builtin_amdgcn_s_waitcnt(0x0f70 | (((GS_AHEAD - 2) * GS_LPER) & 15) | ((((GS_AHEAD - 2) * GS_LPER) >> 4) << 14));
+                fetch(i + GS_AHEAD);
+            } else if (storer) {
+                if (i >= 1) drain(i - 1);
+            } else if (i < nchunks) {
+                // chunk i is filtered in place
+                const gs_lf in = lds + (i % GS_NB) * (GS_CH * GS_PITCH) + (HORIZ ? lane * GS_PITCH : lane);
+                constexpr int ST = HORIZ ? 1 : GS_PITCH;
+                const int cnt = min(GS_CH, n - i * GS_CH);
+                int s = 0;
+                if (i == 0) {
+                    if (fwd) {
+                        // the first three outputs (gauss.cc:573-576 and the vector forms)
+                        const float s0 = in[0];
+                        const float t0 = s0 * (B + b1 + b2 + b3);
+                        const float t1 = sizeof(C) == 4 ? (float)(in[ST] * B + t0 * b1 + s0 * (b2 + b3)) : (float)(B * in[ST] + b1 * t0 + s0 * (b2 + b3));
+                        const float t2 = sizeof(C) == 4 ? (float)(in[2 * ST] * B + t1 * b1 + t0 * b2 + s0 * b3) : (float)(B * in[2 * ST] + b1 * t1 + b2 * t0 + b3 * s0);
+                        in[0] = t0; in[ST] = t1; in[2 * ST] = t2;
+                        m3 = t0; m2 = t1; m1 = t2;
+                    } else {
+                        // Triggs-Sdika boundary (m1 = tmp[n-1], m2 = tmp[n-2], m3 = tmp[n-3]); outputs n-1, n-2, n-3
+                        const float t2Wp1 = (float)(sl + M[6] * (m1 - sl) + M[7] * (m2 - sl) + M[8] * (m3 - sl));
+                        const float t2W = (float)(sl + M[3] * (m1 - sl) + M[4] * (m2 - sl) + M[5] * (m3 - sl));
+                        const float r1 = (float)(sl + M[0] * (m1 - sl) + M[1] * (m2 - sl) + M[2] * (m3 - sl));
+                        const float r2 = (float)(B * m2 + b1 * r1 + b2 * t2W + b3 * t2Wp1);
+                        const float r3 = (float)(B * m3 + b1 * r2 + b2 * r1 + b3 * t2W);
+                        in[0] = r1; in[ST] = r2; in[2 * ST] = r3;
+                        m1 = r3; m2 = r2; m3 = r1;
+                    }
+                    s = 3;
+                }
+                // the loads do not depend on the recurrence: the next batch is read before this batch's results are stored over their inputs
+                float x[16], xn[16];
+                if (s + 16 <= cnt) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = xn[k];
-    }
-    for (; j < n; j++) {
-        const float v = sizeof(C) == 4 ? (float)(p[(size_t)j * st] * B + m1 * b1 + m2 * b2 + m3 * b3) : (float)(B * p[(size_t)j * st] + b1 * m1 + b2 * m2 + b3 * m3);
-        tmp[(size_t)j * tst] = v;
-        m3 = m2; m2 = m1; m1 = v;
-    }
-    // Triggs-Sdika boundary (m1 = tmp[n-1], m2 = tmp[n-2], m3 = tmp[n-3])
-    const float t2Wp1 = (float)(sl + M[6] * (m1 - sl) + M[7] * (m2 - sl) + M[8] * (m3 - sl));
-    const float t2W = (float)(sl + M[3] * (m1 - sl) + M[4] * (m2 - sl) + M[5] * (m3 - sl));
-    const float r1 = (float)(sl + M[0] * (m1 - sl) + M[1] * (m2 - sl) + M[2] * (m3 - sl));
-    const float r2 = (float)(B * m2 + b1 * r1 + b2 * t2W + b3 * t2Wp1);
-    const float r3 = (float)(B * m3 + b1 * r2 + b2 * r1 + b3 * t2W);
-    p[(size_t)(n - 1) * st] = r1; p[(size_t)(n - 2) * st] = r2; p[(size_t)(n - 3) * st] = r3;
-    float a1 = r3, a2 = r2, a3 = r1; // outputs at j+1, j+2, j+3
-    int jb = n - 4;
-    if (jb - 15 >= 0) {
+                    for (int k = 0; k < 16; ++k) x[k] = in[(s + k) * ST];
+                }
+                for (; s + 16 <= cnt; s += 16) {
+                    const int sn = s + 32 <= cnt ? s + 16 : s;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = tmp[(size_t)(jb - k) * tst];
-    }
-    for (; jb - 15 >= 0; jb -= 16) {
-        const bool more = jb - 31 >= 0;
+                    for (int k = 0; k < 16; ++k) xn[k] = in[(sn + k) * ST];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) xn[k] = tmp[(size_t)(more ? jb - 16 - k : jb - k) * tst];
+                    for (int k = 0; k < 16; ++k) {
+                        const float v = sizeof(C) == 4 ? (float)(x[k] * B + m1 * b1 + m2 * b2 + m3 * b3) : (float)(B * x[k] + b1 * m1 + b2 * m2 + b3 * m3);
+                        in[(s + k) * ST] = v;
+                        m3 = m2; m2 = m1; m1 = v;
+                    }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float v = sizeof(C) == 4 ? (float)(x[k] * B + a1 * b1 + a2 * b2 + a3 * b3) : (float)(B * x[k] + b1 * a1 + b2 * a2 + b3 * a3);
-            p[(size_t)(jb - k) * st] = v;
-            a3 = a2; a2 = a1; a1 = v;
+                    for (int k = 0; k < 16; ++k) x[k] = xn[k];
+                }
+                for (; s < cnt; ++s) {
+                    const float xv = in[s * ST];
+                    const float v = sizeof(C) == 4 ? (float)(xv * B + m1 * b1 + m2 * b2 + m3 * b3) : (float)(B * xv + b1 * m1 + b2 * m2 + b3 * m3);
+                    in[s * ST] = v;
+                    m3 = m2; m2 = m1; m1 = v;
+                }
+            }
+            gs_lds_barrier();
         }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) x[k] = xn[k];
-    }
-    for (; jb >= 0; jb--) {
-        const float tj = tmp[(size_t)jb * tst];
-        const float v = sizeof(C) == 4 ? (float)(tj * B + a1 * b1 + a2 * b2 + a3 * b3) : (float)(B * tj + b1 * a1 + b2 * a2 + b3 * a3);
-        p[(size_t)jb * st] = v;
-        a3 = a2; a2 = a1; a1 = v;
+        // the DMA that ran ahead of the last chunk has to land before the ring is reused; the backward pass reads what other waves of this group stored
+        __threadfence();
+        __syncthreads();
     }
 }
 
-__global__ void __launch_bounds__(64) gauss_h_kernel(GaussArgs a)
+template <bool HORIZ>
+__global__ void __launch_bounds__(GS_NT) gauss_stream_kernel(GaussArgs a, int nfloat)
 {
-    const int row = blockIdx.x * 64 + threadIdx.x;
-    if (row >= a.H) return;
-    float *p = a.img + (size_t)row * a.W, *tmp = a.tmp + (size_t)row * a.W;
-    if (row < a.H - (a.H % 4)) yvv_line<float>(p, 1, tmp, 1, a.W, a.Bf, a.bf[0], a.bf[1], a.bf[2], a.Mf);
-    else yvv_line<double>(p, 1, tmp, 1, a.W, a.B, a.b[0], a.b[1], a.b[2], a.M);
+    extern __shared__ float gs_dyn_lds[];
+    const gs_lf lds = (gs_lf)gs_dyn_lds;
+    const int nlines = HORIZ ? a.H : a.W;
+    const int line0 = blockIdx.x * 64;
+    if (line0 < nfloat) gauss_stream_group<HORIZ, float>(a, line0, min(64, nfloat - line0), a.Bf, a.bf[0], a.bf[1], a.bf[2], a.Mf, lds);
+    else gauss_stream_group<HORIZ, double>(a, nfloat, nlines - nfloat, a.B, a.b[0], a.b[1], a.b[2], a.M, lds);
 }
-__global__ void __launch_bounds__(64) gauss_v_kernel(GaussArgs a)
-{
-    const int col = blockIdx.x * 64 + threadIdx.x;
-    if (col >= a.W) return;
-    float *p = a.img + col, *tmp = a.tmp + col;
-    if (col < a.W - (a.W % 8)) yvv_line<float>(p, (size_t)a.W, tmp, (size_t)a.W, a.H, a.Bf, a.bf[0], a.bf[1], a.bf[2], a.Mf);
-    else yvv_line<double>(p, (size_t)a.W, tmp, (size_t)a.W, a.H, a.B, a.b[0], a.b[1], a.b[2], a.M);
-}
+} // namespace
 
 // sigma >= 25 (GAUSS_DOUBLE): gaussHorizontal<T> / gaussVertical<T> (gauss.cc:669-713,1148-1225): every line in double, with
 // a double forward buffer; one lane per line.
@@ -285,8 +359,18 @@ hipError_t launch_gaussian(const GaussArgs &a, hipStream_t s)
         hipLaunchKernelGGL(gauss_v64_kernel, dim3((a.W + 63) / 64), dim3(64), 0, s, a);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(gauss_h_kernel, dim3((a.H + 63) / 64), dim3(64), 0, s, a);
-    hipLaunchKernelGGL(gauss_v_kernel, dim3((a.W + 63) / 64), dim3(64), 0, s, a);
+    // gaussHorizontalSse filters H - H % 4 rows with float coefficients and the rest with double ones (gauss.cc:1163-1225);
+    // gaussVerticalSse W - W % 8 columns (gauss.cc:716-856)
+    const int fh = a.H - a.H % 4, fv = a.W - a.W % 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gauss_stream_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gauss_stream_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gauss_stream_kernel<true>, dim3((fh + 63) / 64 + (fh < a.H ? 1 : 0)), dim3(GS_NT), GS_LDS_BYTES, s, a, fh);
+    hipLaunchKernelGGL(gauss_stream_kernel<false>, dim3((fv + 63) / 64 + (fv < a.W ? 1 : 0)), dim3(GS_NT), GS_LDS_BYTES, s, a, fv);
     return hipGetLastError();
 }
 hipError_t launch_nlm(const NlmArgs &a, hipStream_t s)

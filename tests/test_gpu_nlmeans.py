@@ -18,7 +18,9 @@ def _Y(w, h, seed):
 
 
 @pytest.mark.parametrize("w,h,sigma", [(320, 240, 2.0), (323, 241, 2.0), (326, 243, 1.0), (200, 150, 0.8), (257, 129, 7.5), (323, 241, 25.0), (200, 151, 40.0),
-                                         (323, 241, 0.1), (323, 241, 0.25), (326, 243, 0.4), (200, 151, 0.59)])   # GAUSS_SKIP / the 3-tap branch
+                                         (323, 241, 0.1), (323, 241, 0.25), (326, 243, 0.4), (200, 151, 0.59),    # GAUSS_SKIP / the 3-tap branch
+                                         # line lengths around the 64-step chunks of the stream kernel, line counts around its 64-line groups
+                                         (64, 64, 2.0), (65, 67, 1.5), (128, 130, 3.0), (131, 127, 2.0), (8, 8, 1.0), (11, 9, 0.7), (1027, 515, 2.0)])
 def test_gaussian_blur(gpu_ctx, w, h, sigma):
     from art_amd import capi
     img = _Y(w, h, w)
