@@ -47,6 +47,9 @@ __device__ __forceinline__ void hex_minmax(const float *pix, const int *hex, flo
 __device__ __forceinline__ float cbrt_lut(const float *__restrict__ lut, int i) { return lut[i < 0 ? 0 : (i > 0x14000 - 1 ? 0x14000 - 1 : i)]; }
 } // namespace
 
+#ifndef XT_SR
+#define XT_SR 36               // lab rows per strip of the fused cielab + derivative phase (48 KB of LDS with the two halo rows)
+#endif
 #define FOR_T(N) for (int t = tid, _n = (N); t < _n; t += NT)
 
 #ifndef XTRANS_MIN_WAVES
@@ -54,6 +57,7 @@ __device__ __forceinline__ float cbrt_lut(const float *__restrict__ lut, int i) 
 #endif
 __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles_kernel(XtransArgs a)
 {
+    __shared__ float s_lab[3][(XT_SR + 2) * LW];
     const int tid = threadIdx.x;
     const Geo G{a};
     const int ndir = a.ndir, passes = a.passes;
@@ -249,48 +253,59 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
         }
 
         const int mrl = mrow - top, mcl = mcol - left;   // tile-local bounds (L654-655)
-        // ---- perceptual space + directional derivatives (L657-741), one direction at a time (lab is reused)
+        // ---- perceptual space + directional derivatives (L657-741), one direction at a time.  The lab planes never reach the arena: they
+        // are produced in LDS in strips of XT_SR rows (+ one row above and below, recomputed by the neighbouring strip) and consumed
+        // there by the derivative (every lab value the derivative reads is one this direction wrote).  The LAST direction's planes are
+        // stored as well: the homogeneity maps alias them (L301-308), and the 5x5 sums read map bytes no one wrote = bytes of those floats
+        const int nlab = mrl - 8;                               // lab rows [0, nlab); derivative rows i = r - 4 in [1, nlab - 1)
         for (int d = 0; d < ndir; d++) {
-            if (a.use_cielab) {
-                FOR_T((mrl - 8) * LW) {
-                    const int i = t / LW, j = t - i * LW;
-                    const float *p = RGB(d, 4 + i, 4 + j);
-                    float c0, c1, c2;
-                    if (j < ((LW - 3 + 3) / 4) * 4) {       // 4-lane groups while j < labWidth - 3
-                        const float x0 = p[0] * a.xyz_cam[0] + p[PL] * a.xyz_cam[1] + p[2 * PL] * a.xyz_cam[2];
-                        const float x1 = p[0] * a.xyz_cam[3] + p[PL] * a.xyz_cam[4] + p[2 * PL] * a.xyz_cam[5];
-                        const float x2 = p[0] * a.xyz_cam[6] + p[PL] * a.xyz_cam[7] + p[2 * PL] * a.xyz_cam[8];
-                        c0 = cbrt_lut(a.cbrt_lut, __float2int_rn(x0)); c1 = cbrt_lut(a.cbrt_lut, __float2int_rn(x1)); c2 = cbrt_lut(a.cbrt_lut, __float2int_rn(x2));
-                        LAB(0, i, j) = 116.f * c1 - 16.f;
-                    } else {
-                        float x0 = 0.5f, x1 = 0.5f, x2 = 0.5f;
+            const int dd = d & 3;
+            const int f = dd == 0 ? 1 : (dd == 1 ? LW : (dd == 2 ? LW + 1 : LW - 1));
+            for (int i0 = 1; i0 < nlab - 1; i0 += XT_SR) {
+                const int i1 = min(i0 + XT_SR, nlab - 1), lo = i0 - 1, nrows = i1 + 1 - lo;
+                if (a.use_cielab) {
+                    FOR_T(nrows * LW) {
+                        const int ii = t / LW, j = t - ii * LW, i = lo + ii;
+                        const float *p = RGB(d, 4 + i, 4 + j);
+                        float c0, c1, c2, L;
+                        if (j < ((LW - 3 + 3) / 4) * 4) {       // 4-lane groups while j < labWidth - 3
+                            const float x0 = p[0] * a.xyz_cam[0] + p[PL] * a.xyz_cam[1] + p[2 * PL] * a.xyz_cam[2];
+                            const float x1 = p[0] * a.xyz_cam[3] + p[PL] * a.xyz_cam[4] + p[2 * PL] * a.xyz_cam[5];
+                            const float x2 = p[0] * a.xyz_cam[6] + p[PL] * a.xyz_cam[7] + p[2 * PL] * a.xyz_cam[8];
+                            c0 = cbrt_lut(a.cbrt_lut, __float2int_rn(x0)); c1 = cbrt_lut(a.cbrt_lut, __float2int_rn(x1)); c2 = cbrt_lut(a.cbrt_lut, __float2int_rn(x2));
+                            L = 116.f * c1 - 16.f;
+                        } else {
+                            float x0 = 0.5f, x1 = 0.5f, x2 = 0.5f;
 #pragma unroll
-                        for (int k = 0; k < 3; k++) { x0 += a.xyz_cam[k] * p[k * PL]; x1 += a.xyz_cam[3 + k] * p[k * PL]; x2 += a.xyz_cam[6 + k] * p[k * PL]; }
-                        c0 = cbrt_lut(a.cbrt_lut, (int)x0); c1 = cbrt_lut(a.cbrt_lut, (int)x1); c2 = cbrt_lut(a.cbrt_lut, (int)x2);
-                        LAB(0, i, j) = 116 * c1 - 16;
+                            for (int k = 0; k < 3; k++) { x0 += a.xyz_cam[k] * p[k * PL]; x1 += a.xyz_cam[3 + k] * p[k * PL]; x2 += a.xyz_cam[6 + k] * p[k * PL]; }
+                            c0 = cbrt_lut(a.cbrt_lut, (int)x0); c1 = cbrt_lut(a.cbrt_lut, (int)x1); c2 = cbrt_lut(a.cbrt_lut, (int)x2);
+                            L = 116 * c1 - 16;
+                        }
+                        const float A = 500.f * (c0 - c1), Bv = 200.f * (c1 - c2);
+                        s_lab[0][t] = L;
+                        s_lab[1][t] = A;
+                        s_lab[2][t] = Bv;
+                        if (d == ndir - 1) { LAB(0, i, j) = L; LAB(1, i, j) = A; LAB(2, i, j) = Bv; }
                     }
-                    LAB(1, i, j) = 500.f * (c0 - c1);
-                    LAB(2, i, j) = 200.f * (c1 - c2);
+                } else {
+                    FOR_T(nrows * LW) {
+                        const int ii = t / LW, j = t - ii * LW, i = lo + ii;
+                        if (j >= mcl - 8) continue;
+                        const float *p = RGB(d, 4 + i, 4 + j);
+                        const float y = 0.2627f * p[0] + 0.6780f * p[PL] + 0.0593f * p[2 * PL];
+                        const float A = (p[2 * PL] - y) * 0.56433f, Bv = (p[0] - y) * 0.67815f;
+                        s_lab[0][t] = y;
+                        s_lab[1][t] = A;
+                        s_lab[2][t] = Bv;
+                        if (d == ndir - 1) { LAB(0, i, j) = y; LAB(1, i, j) = A; LAB(2, i, j) = Bv; }
+                    }
                 }
-            } else {
-                FOR_T(TS * TS) {
-                    const int r = t / TS, c = t - r * TS;
-                    if (r < 4 || c < 4 || r >= mrl - 4 || c >= mcl - 4) continue;
-                    const float *p = RGB(d, r, c);
-                    const float y = 0.2627f * p[0] + 0.6780f * p[PL] + 0.0593f * p[2 * PL];
-                    LAB(0, r - 4, c - 4) = y;
-                    LAB(1, r - 4, c - 4) = (p[2 * PL] - y) * 0.56433f;
-                    LAB(2, r - 4, c - 4) = (p[0] - y) * 0.67815f;
-                }
-            }
-            __syncthreads();
-            {
-                const int dd = d & 3;
-                const int f = dd == 0 ? 1 : (dd == 1 ? LW : (dd == 2 ? LW + 1 : LW - 1));
-                FOR_T(TS * TS) {
-                    const int r = t / TS, c = t - r * TS;
-                    if (r < 5 || c < 5 || r >= mrl - 5 || c >= mcl - 5) continue;
-                    const float *l = &LAB(0, r - 4, c - 4), *aa = &LAB(1, r - 4, c - 4), *b = &LAB(2, r - 4, c - 4);
+                __syncthreads();
+                FOR_T((i1 - i0) * TS) {
+                    const int rr = t / TS, c = t - rr * TS, i = i0 + rr;
+                    if (c < 5 || c >= mcl - 5) continue;
+                    const int o = (i - lo) * LW + (c - 4);
+                    const float *l = &s_lab[0][o], *aa = &s_lab[1][o], *b = &s_lab[2][o];
                     float v;
                     if (a.use_cielab) {
                         const float g = 2 * l[0] - l[f] - l[-f];
@@ -298,10 +313,10 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                     } else {
                         v = sqr(2 * l[0] - l[f] - l[-f]) + sqr(2 * aa[0] - aa[f] - aa[-f]) + sqr(2 * b[0] - b[f] - b[-f]);
                     }
-                    DRV(d, r - 5, c - 5) = v;
+                    DRV(d, i - 1, c - 5) = v;
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
 
         // ---- homogeneity maps (L744-811)
