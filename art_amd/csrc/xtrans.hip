@@ -51,6 +51,11 @@ __device__ __forceinline__ float cbrt_lut(const float *__restrict__ lut, int i) 
 #define XT_SR 36               // lab rows per strip of the fused cielab + derivative phase (48 KB of LDS with the two halo rows)
 #endif
 #define FOR_T(N) for (int t = tid, _n = (N); t < _n; t += NT)
+#ifdef XT_PROFILE
+#define XT_MARK(k) do { const long long _n2 = wall_clock64(); xt_acc[k] += _n2 - xt_last; xt_last = _n2; } while (0)
+#else
+#define XT_MARK(k) do { } while (0)
+#endif
 
 #ifndef XTRANS_MIN_WAVES
 #define XTRANS_MIN_WAVES 8
@@ -75,6 +80,9 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
 #define LAB(k, i, j) labbase[((k) * LW + (i)) * LW + (j)]
 #define DRV(d, i, j) drvbase[((d) * DW + (i)) * DW + (j)]
 
+#ifdef XT_PROFILE
+    long long xt_acc[16] = {0}, xt_last = wall_clock64();
+#endif
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
         const int top = 3 + tyi * (TS - 16), left = 3 + txi * (TS - 16);
@@ -82,7 +90,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
 
         // ---- clear the lab planes (greenminmax / homo live there)
         FOR_T(3 * LW * LW) labbase[t] = 0.f;
-        __syncthreads();
+        __syncthreads(); XT_MARK(0);
 
         // ---- green min/max (L320-408): one item per (row, group of the row's non-green run)
         FOR_T(TS * 40) {
@@ -120,7 +128,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                 }
             }
         }
-        __syncthreads();
+        __syncthreads(); XT_MARK(1);
 
         // ---- rgb[0..3] = CFA samples, green interpolated along the 4 directions at the non-green sites (L410-475)
         FOR_T(TS * TS) {
@@ -153,13 +161,13 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                 p[0] = base[0]; p[PL] = interp ? gdir[d] : base[1]; p[2 * PL] = base[2];
             }
         }
-        __syncthreads();
+        __syncthreads(); XT_MARK(2);
 
         for (int pass = 0; pass < passes; pass++) {
             const int B = pass ? 4 : 0;
             if (pass == 1) {
                 FOR_T(4 * TS * TS * 3) buffer[(size_t)4 * TS * TS * 3 + t] = buffer[t];
-                __syncthreads();
+                __syncthreads(); XT_MARK(3);
             }
             // recalculate green from interpolated values of closer pixels (L483-524)
             if (pass) {
@@ -170,14 +178,22 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                     const int *hex = a.allhex1[row % 3][col % 3];
                     const int flip = a.right_shift[row % 3] ? 0 : 1;
                     const float *s = gmm + ((size_t)r * TSH + (c >> 1)) * 2;
+                    // all fifteen loads first: issued one direction at a time behind that direction's store they would be three dependent round trips
+                    float v[3][5];
 #pragma unroll
                     for (int d = 3; d < 6; d++) {
-                        float *rix = RGB(B + ((d - 2) ^ flip), r, c);
-                        const float val = 0.33333333f * (rix[-2 * hex[d] + PL] + 2 * (rix[hex[d] + PL] - rix[hex[d] + f * PL]) - rix[-2 * hex[d] + f * PL]) + rix[f * PL];
-                        rix[PL] = limf(val, s[0], s[1]);
+                        const float *rix = RGB(B + ((d - 2) ^ flip), r, c);
+                        v[d - 3][0] = rix[-2 * hex[d] + PL]; v[d - 3][1] = rix[hex[d] + PL]; v[d - 3][2] = rix[hex[d] + f * PL];
+                        v[d - 3][3] = rix[-2 * hex[d] + f * PL]; v[d - 3][4] = rix[f * PL];
+                    }
+                    const float lo = s[0], hi = s[1];
+#pragma unroll
+                    for (int d = 3; d < 6; d++) {
+                        const float val = 0.33333333f * (v[d - 3][0] + 2 * (v[d - 3][1] - v[d - 3][2]) - v[d - 3][3]) + v[d - 3][4];
+                        *(RGB(B + ((d - 2) ^ flip), r, c) + PL) = limf(val, lo, hi);
                     }
                 }
-                __syncthreads();
+                __syncthreads(); XT_MARK(4);
             }
             // red and blue for solitary green pixels (L527-561)
             {
@@ -213,7 +229,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                     }
                 }
             }
-            __syncthreads();
+            __syncthreads(); XT_MARK(5);
             // red for blue pixels and vice versa (L564-606)
             FOR_T(TS * TS) {
                 const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
@@ -222,14 +238,25 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                 const int hd = 3 * (cd ^ TS ^ 1);
                 const int f = 2 - G.fcol(row, col);
                 float *rix = RGB(B, r, c);
+                // Only one of the four directions compares the two candidate axes (d <= 1 with d and cd of equal parity); the others use
+                // cd.  All 24 loads are issued before the first store (the short-circuit form is four dependent round trips).
+                const int dc = cd == 1 ? 1 : 0;
+                float g0[4], gp[4], gm[4], Fp[4], Fm[4];
 #pragma unroll
-                for (int d = 0; d < 4; d++, rix += 3 * PL) {
-                    const int i = d > 1 || ((d ^ cd) & 1) ||
-                                  ((fabsf(rix[PL] - rix[cd + PL]) + fabsf(rix[PL] - rix[-cd + PL])) < 2.f * (fabsf(rix[PL] - rix[hd + PL]) + fabsf(rix[PL] - rix[-hd + PL]))) ? cd : hd;
-                    rix[f * PL] = rix[PL] + 0.5f * (rix[i + f * PL] + rix[-i + f * PL] - rix[i + PL] - rix[-i + PL]);
+                for (int d = 0; d < 4; d++) {
+                    const float *q = rix + d * 3 * PL;
+                    g0[d] = q[PL]; gp[d] = q[cd + PL]; gm[d] = q[-cd + PL]; Fp[d] = q[cd + f * PL]; Fm[d] = q[-cd + f * PL];
+                }
+                const float *q = rix + dc * 3 * PL;
+                const float ghp = q[hd + PL], ghm = q[-hd + PL], Fhp = q[hd + f * PL], Fhm = q[-hd + f * PL];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const bool use_cd = d != dc || ((fabsf(g0[d] - gp[d]) + fabsf(g0[d] - gm[d])) < 2.f * (fabsf(g0[d] - ghp) + fabsf(g0[d] - ghm)));
+                    const float a1 = use_cd ? Fp[d] : Fhp, a2 = use_cd ? Fm[d] : Fhm, a3 = use_cd ? gp[d] : ghp, a4 = use_cd ? gm[d] : ghm;
+                    rix[d * 3 * PL + f * PL] = g0[d] + 0.5f * (a1 + a2 - a3 - a4);
                 }
             }
-            __syncthreads();
+            __syncthreads(); XT_MARK(6);
             // red and blue for 2x2 blocks of green (L609-650)
             FOR_T(TS * TS) {
                 const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
@@ -237,19 +264,31 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                 if ((row - sgrow) % 3 == 0 || (col - sgcol) % 3 == 0) continue;
                 const int *hex = a.allhex1[row % 3][col % 3];
                 float *rix = RGB(B, r, c);
-                for (int d = 0; d < ndir; d += 2, rix += 3 * PL) {
-                    if (hex[d] + hex[d + 1]) {
-                        const float g = 3 * rix[PL] - 2 * rix[hex[d] + PL] - rix[hex[d + 1] + PL];
-                        rix[0] = (g + 2 * rix[hex[d]] + rix[hex[d + 1]]) * 0.33333333f;
-                        rix[2 * PL] = (g + 2 * rix[hex[d] + 2 * PL] + rix[hex[d + 1] + 2 * PL]) * 0.33333333f;
+                // the four buffers' 28 loads first (d steps by two over the hexagon table while rix steps by one buffer, L609-650)
+                float gc[4], gh0[4], gh1[4], r0[4], r1[4], b0[4], b1[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float *q = rix + k * 3 * PL;
+                    const int h0 = hex[2 * k], h1 = hex[2 * k + 1];
+                    gc[k] = q[PL]; gh0[k] = q[h0 + PL]; gh1[k] = q[h1 + PL];
+                    r0[k] = q[h0]; r1[k] = q[h1]; b0[k] = q[h0 + 2 * PL]; b1[k] = q[h1 + 2 * PL];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (2 * k >= ndir) break;
+                    float *q = rix + k * 3 * PL;
+                    if (hex[2 * k] + hex[2 * k + 1]) {
+                        const float g = 3 * gc[k] - 2 * gh0[k] - gh1[k];
+                        q[0] = (g + 2 * r0[k] + r1[k]) * 0.33333333f;
+                        q[2 * PL] = (g + 2 * b0[k] + b1[k]) * 0.33333333f;
                     } else {
-                        const float g = 2 * rix[PL] - rix[hex[d] + PL] - rix[hex[d + 1] + PL];
-                        rix[0] = (g + rix[hex[d]] + rix[hex[d + 1]]) * 0.5f;
-                        rix[2 * PL] = (g + rix[hex[d] + 2 * PL] + rix[hex[d + 1] + 2 * PL]) * 0.5f;
+                        const float g = 2 * gc[k] - gh0[k] - gh1[k];
+                        q[0] = (g + r0[k] + r1[k]) * 0.5f;
+                        q[2 * PL] = (g + b0[k] + b1[k]) * 0.5f;
                     }
                 }
             }
-            __syncthreads();
+            __syncthreads(); XT_MARK(7);
         }
 
         const int mrl = mrow - top, mcl = mcol - left;   // tile-local bounds (L654-655)
@@ -300,7 +339,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                         if (d == ndir - 1) { LAB(0, i, j) = y; LAB(1, i, j) = A; LAB(2, i, j) = Bv; }
                     }
                 }
-                __syncthreads();
+                __syncthreads(); XT_MARK(8);
                 FOR_T((i1 - i0) * TS) {
                     const int rr = t / TS, c = t - rr * TS, i = i0 + rr;
                     if (c < 5 || c >= mcl - 5) continue;
@@ -315,7 +354,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                     }
                     DRV(d, i - 1, c - 5) = v;
                 }
-                __syncthreads();
+                __syncthreads(); XT_MARK(9);
             }
         }
 
@@ -335,7 +374,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                 homo[((size_t)d * TS + r) * TS + c] = (unsigned char)cnt;
             }
         }
-        __syncthreads();
+        __syncthreads(); XT_MARK(10);
 
         int mr2 = mrl, mc2 = mcl;
         if (height - top < TS + 4) mr2 = height - top + 2;
@@ -357,7 +396,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             const int ncov = endcol > startcol ? ((endcol - startcol + 15) / 16) * 16 : 0;
             homosum[((size_t)d * TS + r) * TS + c] = (c < startcol + ncov) ? (unsigned char)(sum > 255 ? 255 : sum) : (unsigned char)sum;
         }
-        __syncthreads();
+        __syncthreads(); XT_MARK(11);
         // ---- per-pixel maximum (L870-906)
         FOR_T(TS * TS) {
             const int r = t / TS, c = t - r * TS;
@@ -370,7 +409,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             maxval -= maxval >> 3;
             homosummax[(size_t)r * TS + c] = maxval;
         }
-        __syncthreads();
+        __syncthreads(); XT_MARK(12);
         // ---- average the most homogeneous directions (L910-949)
         FOR_T(TS * TS) {
             const int r = t / TS, c = t - r * TS;
@@ -400,8 +439,15 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             a.green[o] = std_max(0.f, avg[1] / avg[3]);
             a.blue[o] = std_max(0.f, avg[2] / avg[3]);
         }
-        __syncthreads();
+        __syncthreads(); XT_MARK(13);
     }
+#ifdef XT_PROFILE
+    if (blockIdx.x == 7 && tid == 0) {
+        printf("XTPROF");
+        for (int k = 0; k < 14; ++k) printf(" %lld", xt_acc[k]);
+        printf("\n");
+    }
+#endif
 }
 
 // xtransborder_interpolate (L122-173): one lane per frame pixel inside the border strips
