@@ -47,9 +47,12 @@ __device__ __forceinline__ void hex_minmax(const float *pix, const int *hex, flo
 __device__ __forceinline__ float cbrt_lut(const float *__restrict__ lut, int i) { return lut[i < 0 ? 0 : (i > 0x14000 - 1 ? 0x14000 - 1 : i)]; }
 } // namespace
 
-#ifndef XT_SR
-#define XT_SR 36               // lab rows per strip of the fused cielab + derivative phase (48 KB of LDS with the two halo rows)
-#endif
+// LDS scratch of a workgroup: two workgroups share a CU's 160 KB.  It holds, one after the other, strips of the lab planes (XT_SR rows +
+// two halo rows), strips of the eight derivative planes (XT_DR rows + two) and XT_HP homogeneity maps.
+constexpr int XT_LDS_FLOATS = 19968;                            // 78 KB
+constexpr int XT_SR = XT_LDS_FLOATS / (3 * (TS - 8)) - 2;       // 60 lab rows per strip
+constexpr int XT_DR = XT_LDS_FLOATS / (8 * (TS - 10)) - 2;      // 22 derivative rows per strip
+constexpr int XT_HP = XT_LDS_FLOATS * 4 / (TS * TS);            // 6 maps
 #define FOR_T(N) for (int t = tid, _n = (N); t < _n; t += NT)
 #ifdef XT_PROFILE
 #define XT_MARK(k) do { const long long _n2 = wall_clock64(); xt_acc[k] += _n2 - xt_last; xt_last = _n2; } while (0)
@@ -62,7 +65,8 @@ __device__ __forceinline__ float cbrt_lut(const float *__restrict__ lut, int i) 
 #endif
 __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles_kernel(XtransArgs a)
 {
-    __shared__ float s_lab[3][(XT_SR + 2) * LW];
+    extern __shared__ float xt_lds[];
+    float *const s_lab[3] = {xt_lds, xt_lds + (XT_SR + 2) * LW, xt_lds + 2 * (XT_SR + 2) * LW};
     const int tid = threadIdx.x;
     const Geo G{a};
     const int ndir = a.ndir, passes = a.passes;
@@ -358,45 +362,69 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             }
         }
 
-        // ---- homogeneity maps (L744-811)
-        FOR_T(TS * TS) {
-            const int r = t / TS, c = t - r * TS;
-            if (r < 6 || c < 6 || r >= mrl - 6 || c >= mcl - 6) continue;
-            float tr = DRV(0, r - 5, c - 5) < DRV(1, r - 5, c - 5) ? DRV(0, r - 5, c - 5) : DRV(1, r - 5, c - 5);
-            for (int d = 2; d < ndir; d++) tr = (DRV(d, r - 5, c - 5) < tr ? DRV(d, r - 5, c - 5) : tr);
-            tr *= 8;
-            for (int d = 0; d < ndir; d++) {
-                int cnt = 0;
-#pragma unroll
-                for (int v = -1; v <= 1; v++)
-#pragma unroll
-                    for (int h = -1; h <= 1; h++) cnt += (DRV(d, r + v - 5, c + h - 5) <= tr ? 1 : 0);
-                homo[((size_t)d * TS + r) * TS + c] = (unsigned char)cnt;
+        // ---- homogeneity maps (L744-811): the derivative rows of all directions are staged in LDS strip by strip (every value is read
+        // 9 x for the counts and once for the threshold)
+        for (int ra = 6; ra < mrl - 6; ra += XT_DR) {
+            const int rb = min(ra + XT_DR, mrl - 6), nrows = rb - ra + 2;       // derivative rows ra - 6 .. rb - 5
+            FOR_T(ndir * nrows * DW) {
+                const int d = t / (nrows * DW), q = t - d * nrows * DW, ii = q / DW, j = q - ii * DW;
+                xt_lds[(d * (XT_DR + 2) + ii) * DW + j] = DRV(d, ra - 6 + ii, j);
             }
+            __syncthreads();
+            FOR_T((rb - ra) * TS) {
+                const int rr = t / TS, c = t - rr * TS, r = ra + rr;
+                if (c < 6 || c >= mcl - 6) continue;
+#define SDRV(d, v, h) xt_lds[((d) * (XT_DR + 2) + rr + 1 + (v)) * DW + c - 5 + (h)]
+                float tr = SDRV(0, 0, 0) < SDRV(1, 0, 0) ? SDRV(0, 0, 0) : SDRV(1, 0, 0);
+                for (int d = 2; d < ndir; d++) tr = (SDRV(d, 0, 0) < tr ? SDRV(d, 0, 0) : tr);
+                tr *= 8;
+                for (int d = 0; d < ndir; d++) {
+                    int cnt = 0;
+#pragma unroll
+                    for (int v = -1; v <= 1; v++)
+#pragma unroll
+                        for (int h = -1; h <= 1; h++) cnt += (SDRV(d, v, h) <= tr ? 1 : 0);
+                    homo[((size_t)d * TS + r) * TS + c] = (unsigned char)cnt;
+                }
+#undef SDRV
+            }
+            __syncthreads();
         }
-        __syncthreads(); XT_MARK(10);
+        XT_MARK(10);
 
         int mr2 = mrl, mc2 = mcl;
         if (height - top < TS + 4) mr2 = height - top + 2;
         if (width - left < TS + 4) mc2 = width - left + 2;
         const int startrow = min(top, 8), startcol = min(left, 8);
         // ---- 5x5 sums of the homogeneity maps (L823-866)
-        FOR_T(ndir * TS * TS) {
-            const int d = t / (TS * TS), q = t - d * TS * TS, r = q / TS, c = q - r * TS;
-            if (r < startrow || c < startcol || r >= mr2 - 8 || c >= mc2 - 8) continue;
-            int sum = 0;
+        // XT_HP maps at a time are staged in LDS with dword loads (25 byte loads per sum from the arena were 12 % of the kernel)
+        for (int d0 = 0; d0 < ndir; d0 += XT_HP) {
+            const int nd = min(XT_HP, ndir - d0);
+            unsigned char *const s_b = reinterpret_cast<unsigned char *>(xt_lds);
+            {
+                const unsigned *src = reinterpret_cast<const unsigned *>(homo + (size_t)d0 * TS * TS);      // TS * TS is a multiple of 4
+                unsigned *dstw = reinterpret_cast<unsigned *>(s_b);
+                FOR_T(nd * (TS * TS / 4)) dstw[t] = src[t];
+            }
+            __syncthreads();
+            FOR_T(nd * TS * TS) {
+                const int dl = t / (TS * TS), q = t - dl * TS * TS, r = q / TS, c = q - r * TS;
+                if (r < startrow || c < startcol || r >= mr2 - 8 || c >= mc2 - 8) continue;
+                int sum = 0;
 #pragma unroll
-            for (int v = -2; v <= 2; v++)
+                for (int v = -2; v <= 2; v++)
 #pragma unroll
-                for (int h = -2; h <= 2; h++) sum += homo[((size_t)d * TS + r + v) * TS + c + h];
-            // the reference's 16-wide loop adds with unsigned saturation (_mm_adds_epu8, L835-843); its running-sum tail,
-            // which only the last row reaches, truncates to uint8 (L846-864).  Sums above 255 arise where never-written
-            // homogeneity bytes (= lab bytes) are read at the right / bottom edge.
-            const int endcol = r < mr2 - 9 ? mc2 - 8 : mc2 - 23;
-            const int ncov = endcol > startcol ? ((endcol - startcol + 15) / 16) * 16 : 0;
-            homosum[((size_t)d * TS + r) * TS + c] = (c < startcol + ncov) ? (unsigned char)(sum > 255 ? 255 : sum) : (unsigned char)sum;
+                    for (int h = -2; h <= 2; h++) sum += s_b[(dl * TS + r + v) * TS + c + h];
+                // the reference's 16-wide loop adds with unsigned saturation (_mm_adds_epu8, L835-843); its running-sum tail,
+                // which only the last row reaches, truncates to uint8 (L846-864).  Sums above 255 arise where never-written
+                // homogeneity bytes (= lab bytes) are read at the right / bottom edge.
+                const int endcol = r < mr2 - 9 ? mc2 - 8 : mc2 - 23;
+                const int ncov = endcol > startcol ? ((endcol - startcol + 15) / 16) * 16 : 0;
+                homosum[((size_t)(d0 + dl) * TS + r) * TS + c] = (c < startcol + ncov) ? (unsigned char)(sum > 255 ? 255 : sum) : (unsigned char)sum;
+            }
+            __syncthreads();
         }
-        __syncthreads(); XT_MARK(11);
+        XT_MARK(11);
         // ---- per-pixel maximum (L870-906)
         FOR_T(TS * TS) {
             const int r = t / TS, c = t - r * TS;
@@ -484,7 +512,13 @@ __global__ void __launch_bounds__(256) xtrans_border_kernel(XtransArgs a)
 
 hipError_t launch_xtrans(const XtransArgs &a, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL(xtrans_tiles_kernel, dim3(grid), dim3(XTRANS_THREADS), 0, s, a);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&xtrans_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS_FLOATS * 4);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(xtrans_tiles_kernel, dim3(grid), dim3(XTRANS_THREADS), XT_LDS_FLOATS * 4, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const long long n = (long long)a.W * a.H;
