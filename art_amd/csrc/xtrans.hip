@@ -307,28 +307,54 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             for (int i0 = 1; i0 < nlab - 1; i0 += XT_SR) {
                 const int i1 = min(i0 + XT_SR, nlab - 1), lo = i0 - 1, nrows = i1 + 1 - lo;
                 if (a.use_cielab) {
-                    FOR_T(nrows * LW) {
-                        const int ii = t / LW, j = t - ii * LW, i = lo + ii;
-                        const float *p = RGB(d, 4 + i, 4 + j);
-                        float c0, c1, c2, L;
-                        if (j < ((LW - 3 + 3) / 4) * 4) {       // 4-lane groups while j < labWidth - 3
-                            const float x0 = p[0] * a.xyz_cam[0] + p[PL] * a.xyz_cam[1] + p[2 * PL] * a.xyz_cam[2];
-                            const float x1 = p[0] * a.xyz_cam[3] + p[PL] * a.xyz_cam[4] + p[2 * PL] * a.xyz_cam[5];
-                            const float x2 = p[0] * a.xyz_cam[6] + p[PL] * a.xyz_cam[7] + p[2 * PL] * a.xyz_cam[8];
-                            c0 = cbrt_lut(a.cbrt_lut, __float2int_rn(x0)); c1 = cbrt_lut(a.cbrt_lut, __float2int_rn(x1)); c2 = cbrt_lut(a.cbrt_lut, __float2int_rn(x2));
-                            L = 116.f * c1 - 16.f;
-                        } else {
-                            float x0 = 0.5f, x1 = 0.5f, x2 = 0.5f;
+                    // four pixels per thread and iteration: their twelve colour loads, then their twelve table look-ups, are in flight together
+                    // (one pixel at a time is a chain of two memory round trips per iteration)
+                    constexpr int U = 4;
+                    const int n = nrows * LW;
+                    for (int t0 = tid; t0 < n; t0 += U * NT) {
+                        float pv[U][3];
+                        int jj[U], ti[U];
 #pragma unroll
-                            for (int k = 0; k < 3; k++) { x0 += a.xyz_cam[k] * p[k * PL]; x1 += a.xyz_cam[3 + k] * p[k * PL]; x2 += a.xyz_cam[6 + k] * p[k * PL]; }
-                            c0 = cbrt_lut(a.cbrt_lut, (int)x0); c1 = cbrt_lut(a.cbrt_lut, (int)x1); c2 = cbrt_lut(a.cbrt_lut, (int)x2);
-                            L = 116 * c1 - 16;
+                        for (int u = 0; u < U; u++) {
+                            const int t = min(t0 + u * NT, n - 1);
+                            const int ii = t / LW, j = t - ii * LW;
+                            const float *p = RGB(d, 4 + lo + ii, 4 + j);
+                            ti[u] = t; jj[u] = j;
+                            pv[u][0] = p[0]; pv[u][1] = p[PL]; pv[u][2] = p[2 * PL];
                         }
-                        const float A = 500.f * (c0 - c1), Bv = 200.f * (c1 - c2);
-                        s_lab[0][t] = L;
-                        s_lab[1][t] = A;
-                        s_lab[2][t] = Bv;
-                        if (d == ndir - 1) { LAB(0, i, j) = L; LAB(1, i, j) = A; LAB(2, i, j) = Bv; }
+                        int ix[U][3];
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            const float *p = pv[u];
+                            // 4-lane groups while j < labWidth - 3 ...
+                            const float x0 = p[0] * a.xyz_cam[0] + p[1] * a.xyz_cam[1] + p[2] * a.xyz_cam[2];
+                            const float x1 = p[0] * a.xyz_cam[3] + p[1] * a.xyz_cam[4] + p[2] * a.xyz_cam[5];
+                            const float x2 = p[0] * a.xyz_cam[6] + p[1] * a.xyz_cam[7] + p[2] * a.xyz_cam[8];
+                            // ... the scalar tail rounds by adding 0.5 and truncating
+                            float y0 = 0.5f, y1 = 0.5f, y2 = 0.5f;
+#pragma unroll
+                            for (int k = 0; k < 3; k++) { y0 += a.xyz_cam[k] * p[k]; y1 += a.xyz_cam[3 + k] * p[k]; y2 += a.xyz_cam[6 + k] * p[k]; }
+                            const bool vec = jj[u] < ((LW - 3 + 3) / 4) * 4;
+                            ix[u][0] = vec ? __float2int_rn(x0) : (int)y0;
+                            ix[u][1] = vec ? __float2int_rn(x1) : (int)y1;
+                            ix[u][2] = vec ? __float2int_rn(x2) : (int)y2;
+                        }
+                        float cv[U][3];
+#pragma unroll
+                        for (int u = 0; u < U; u++)
+#pragma unroll
+                            for (int k = 0; k < 3; k++) cv[u][k] = cbrt_lut(a.cbrt_lut, ix[u][k]);
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            if (t0 + u * NT >= n) break;
+                            const int t = ti[u];
+                            const float L = jj[u] < ((LW - 3 + 3) / 4) * 4 ? 116.f * cv[u][1] - 16.f : 116 * cv[u][1] - 16;
+                            const float A = 500.f * (cv[u][0] - cv[u][1]), Bv = 200.f * (cv[u][1] - cv[u][2]);
+                            s_lab[0][t] = L;
+                            s_lab[1][t] = A;
+                            s_lab[2][t] = Bv;
+                            if (d == ndir - 1) { const int ii = t / LW, j = t - ii * LW, i = lo + ii; LAB(0, i, j) = L; LAB(1, i, j) = A; LAB(2, i, j) = Bv; }
+                        }
                     }
                 } else {
                     FOR_T(nrows * LW) {
