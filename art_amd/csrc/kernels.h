@@ -81,7 +81,7 @@ hipError_t launch_rcd_stream(const RcdStreamArgs &a, int rows_per_iter, int grid
 // ---- X-Trans Markesteijn demosaic (xtrans.hip) ----
 #define XTRANS_TS 114
 #ifndef XTRANS_THREADS
-#define XTRANS_THREADS 1024   // measured: {256,512,1024} x min-waves {4,6,8}: 1024 x 8 is the fastest (65.8 vs 69.0 ms at 100 MP)
+#define XTRANS_THREADS 1024   // round 1, one load in flight per pixel: {256,512,1024} x min-waves {4,6,8}: 1024 x 8 the fastest; round 2, loads batched: 1024 x 4 (xtrans.hip)
 #endif
 struct XtransArgs {
     const float *raw; size_t raw_stride;

@@ -49,7 +49,10 @@ __device__ __forceinline__ float cbrt_lut(const float *__restrict__ lut, int i) 
 
 // LDS scratch of a workgroup: two workgroups share a CU's 160 KB.  It holds, one after the other, strips of the lab planes (XT_SR rows +
 // two halo rows), strips of the eight derivative planes (XT_DR rows + two) and XT_HP homogeneity maps.
-constexpr int XT_LDS_FLOATS = 19968;                            // 78 KB
+#ifndef XT_LDS_F
+#define XT_LDS_F 19968
+#endif
+constexpr int XT_LDS_FLOATS = XT_LDS_F;                         // 78 KB
 constexpr int XT_SR = XT_LDS_FLOATS / (3 * (TS - 8)) - 2;       // 60 lab rows per strip
 constexpr int XT_DR = XT_LDS_FLOATS / (8 * (TS - 10)) - 2;      // 22 derivative rows per strip
 constexpr int XT_HP = XT_LDS_FLOATS * 4 / (TS * TS);            // 6 maps
@@ -61,7 +64,7 @@ constexpr int XT_HP = XT_LDS_FLOATS * 4 / (TS * TS);            // 6 maps
 #endif
 
 #ifndef XTRANS_MIN_WAVES
-#define XTRANS_MIN_WAVES 8
+#define XTRANS_MIN_WAVES 4     // 128 VGPRs, one 1024-thread workgroup per CU: with the loads of a pixel batched the phases want registers, not waves (46.1 -> 38.8 ms)
 #endif
 __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles_kernel(XtransArgs a)
 {
