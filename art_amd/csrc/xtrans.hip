@@ -209,30 +209,44 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                     const int i3 = t / 40, j3 = t - i3 * 40;
                     const int row = row0 + 3 * i3, col = col0 + 3 * j3;
                     if (row >= mrow - 2 || col >= mcol - 2) continue;
-                    int h = G.fcol(row, col0 + 1) ^ ((j3 & 1) ? 2 : 0);
+                    const int h0 = G.fcol(row, col0 + 1) ^ ((j3 & 1) ? 2 : 0);
                     float *rix = RGB(B, row - top, col - left);
-                    float color[3][6];
-                    float diff[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    int i = 1;
+                    // Six candidate pairs over four buffers (d = 0, 1 -> buffers 0, 1; d = 2, 3 -> buffer 2; d = 4, 5 -> buffer 3), along the row
+                    // for even d and the column for odd d, the nearer neighbours holding colour h and the farther ones colour h ^ 2.  None of
+                    // the 52 values is written by this phase: all loads first (behind each buffer's stores they were six round trips).
+                    float gc[4], L[6][2][4];
+#pragma unroll
+                    for (int bq = 0; bq < 4; bq++) gc[bq] = rix[bq * 3 * PL + PL];
 #pragma unroll
                     for (int d = 0; d < 6; d++) {
+                        const float *q = rix + (d < 2 ? d : (d < 4 ? 2 : 3)) * 3 * PL;
+                        const int i = (d & 1) ? TS : 1, hd = h0 ^ ((d & 1) ? 2 : 0);
 #pragma unroll
                         for (int k = 0; k < 2; k++) {
-                            const int o = (i << k);
-                            const float g = rix[PL] + rix[PL] - rix[o + PL] - rix[-o + PL];
-                            color[h][d] = g + rix[o + h * PL] + rix[-o + h * PL];
-                            if (d > 1) diff[d] += sqr(rix[o + PL] - rix[-o + PL] - rix[o + h * PL] + rix[-o + h * PL]) + sqr(g);
-                            h ^= 2;
+                            const int o = i << k, hk = hd ^ (k ? 2 : 0);
+                            L[d][k][0] = q[o + PL]; L[d][k][1] = q[-o + PL]; L[d][k][2] = q[o + hk * PL]; L[d][k][3] = q[-o + hk * PL];
                         }
+                    }
+                    float c0[6], c2[6], diff[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int d = 0; d < 6; d++) {
+                        const int bq = d < 2 ? d : (d < 4 ? 2 : 3);
+                        const int hd = h0 ^ ((d & 1) ? 2 : 0);
+                        float ck[2];
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            const float g = gc[bq] + gc[bq] - L[d][k][0] - L[d][k][1];
+                            ck[k] = g + L[d][k][2] + L[d][k][3];
+                            if (d > 1) diff[d] += sqr(L[d][k][0] - L[d][k][1] - L[d][k][2] + L[d][k][3]) + sqr(g);
+                        }
+                        c0[d] = hd == 0 ? ck[0] : ck[1];
+                        c2[d] = hd == 0 ? ck[1] : ck[0];
                         if (d > 2 && (d & 1))
-                            if (diff[d - 1] < diff[d]) { color[0][d] = color[0][d - 1]; color[2][d] = color[2][d - 1]; }
+                            if (diff[d - 1] < diff[d]) { c0[d] = c0[d - 1]; c2[d] = c2[d - 1]; }
                         if ((d & 1) || d < 2) {
-                            rix[0] = 0.5f * color[0][d];
-                            rix[2 * PL] = 0.5f * color[2][d];
-                            rix += 3 * PL;
+                            rix[bq * 3 * PL] = 0.5f * c0[d];
+                            rix[bq * 3 * PL + 2 * PL] = 0.5f * c2[d];
                         }
-                        i ^= TS ^ 1;
-                        h ^= 2;
                     }
                 }
             }
@@ -484,13 +498,21 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             }
             float avg[4] = {0.f, 0.f, 0.f, 0.f};
             const unsigned char maxval = homosummax[(size_t)r * TS + c];
+            // the chosen directions' colours: every load is issued (a direction that is not chosen re-reads direction 0's address and adds
+            // +0, which changes no bit of a sum that starts at +0) instead of one guarded round trip per direction
+            float pv[8][3];
 #pragma unroll
-            for (int d = 0; d < 8; d++)
-                if (d < ndir && hm[d] >= maxval) {
-                    const float *p = RGB(d, r, c);
-                    avg[0] += p[0]; avg[1] += p[PL]; avg[2] += p[2 * PL];
-                    avg[3]++;
-                }
+            for (int d = 0; d < 8; d++) {
+                const bool on = d < ndir && hm[d] >= maxval;
+                const float *p = RGB(on ? d : 0, r, c);
+                pv[d][0] = p[0]; pv[d][1] = p[PL]; pv[d][2] = p[2 * PL];
+            }
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                const bool on = d < ndir && hm[d] >= maxval;
+                avg[0] += on ? pv[d][0] : 0.f; avg[1] += on ? pv[d][1] : 0.f; avg[2] += on ? pv[d][2] : 0.f;
+                avg[3] += on ? 1.f : 0.f;
+            }
             const size_t o = (size_t)(r + top) * a.out_stride + c + left;
             a.red[o] = std_max(0.f, avg[0] / avg[3]);
             a.green[o] = std_max(0.f, avg[1] / avg[3]);
