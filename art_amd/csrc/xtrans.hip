@@ -31,6 +31,16 @@ struct Geo {
     __device__ int isgreen(int row, int col) const { return a.xtrans[(row % 3) * 6 + col % 3] & 1; }
 };
 
+typedef __attribute__((address_space(3))) float *xt_lf;
+typedef float xt_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) xt_f4 *xt_lf4;
+// workgroup barrier that orders LDS traffic only: a __syncthreads() would also wait for the stores to the arena
+__device__ __forceinline__ void xt_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 __device__ __forceinline__ float limf(float v, float lo, float hi) { return std_max(lo, std_min(v, hi)); }
 
 __device__ __forceinline__ void hex_minmax(const float *pix, const int *hex, float &mn, float &mx)
@@ -47,15 +57,11 @@ __device__ __forceinline__ void hex_minmax(const float *pix, const int *hex, flo
 __device__ __forceinline__ float cbrt_lut(const float *__restrict__ lut, int i) { return lut[i < 0 ? 0 : (i > 0x14000 - 1 ? 0x14000 - 1 : i)]; }
 } // namespace
 
-// LDS scratch of a workgroup: two workgroups share a CU's 160 KB.  It holds, one after the other, strips of the lab planes (XT_SR rows +
-// two halo rows), strips of the eight derivative planes (XT_DR rows + two) and XT_HP homogeneity maps.
-#ifndef XT_LDS_F
-#define XT_LDS_F 19968
-#endif
-constexpr int XT_LDS_FLOATS = XT_LDS_F;                         // 78 KB
-constexpr int XT_SR = XT_LDS_FLOATS / (3 * (TS - 8)) - 2;       // 60 lab rows per strip
-constexpr int XT_DR = XT_LDS_FLOATS / (8 * (TS - 10)) - 2;      // 22 derivative rows per strip
-constexpr int XT_HP = XT_LDS_FLOATS * 4 / (TS * TS);            // 6 maps
+// LDS of a workgroup (it has the CU to itself): the three planes of one direction buffer, 156 KB; the homogeneity phases reuse it for strips of the
+// eight derivative planes (XT_DR rows + two halo rows) and for the homogeneity maps (XT_HP at a time).
+constexpr int XT_LDS_FLOATS = 3 * TS * TS;
+constexpr int XT_DR = XT_LDS_FLOATS / (8 * (TS - 10)) - 2;      // 44 derivative rows per strip
+constexpr int XT_HP = XT_LDS_FLOATS * 4 / (TS * TS);            // 12 maps
 #define FOR_T(N) for (int t = tid, _n = (N); t < _n; t += NT)
 #ifdef XT_PROFILE
 #define XT_MARK(k) do { const long long _n2 = wall_clock64(); xt_acc[k] += _n2 - xt_last; xt_last = _n2; } while (0)
@@ -69,7 +75,6 @@ constexpr int XT_HP = XT_LDS_FLOATS * 4 / (TS * TS);            // 6 maps
 __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles_kernel(XtransArgs a)
 {
     extern __shared__ float xt_lds[];
-    float *const s_lab[3] = {xt_lds, xt_lds + (XT_SR + 2) * LW, xt_lds + 2 * (XT_SR + 2) * LW};
     const int tid = threadIdx.x;
     const Geo G{a};
     const int ndir = a.ndir, passes = a.passes;
@@ -137,273 +142,236 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
         }
         __syncthreads(); XT_MARK(1);
 
-        // ---- rgb[0..3] = CFA samples, green interpolated along the 4 directions at the non-green sites (L410-475)
-        FOR_T(TS * TS) {
-            const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
-            float base[3] = {0.f, 0.f, 0.f};
-            float gdir[4];
-            bool interp = false;
-            if (row < mrow && col < mcol) {
-                const int f = G.fcol(row, col);
-                const float *pix = a.raw + (size_t)row * rs + col;
-                base[f] = pix[0];
-                if (!(f & 1)) {
-                    interp = true;
-                    const int *hex = a.allhex0[row % 3][col % 3];
-                    float color[4];
-                    color[0] = 0.6796875f * (pix[hex[1]] + pix[hex[0]]) - 0.1796875f * (pix[2 * hex[1]] + pix[2 * hex[0]]);
-                    color[1] = 0.87109375f * pix[hex[3]] + pix[hex[2]] * 0.12890625f + 0.359375f * (pix[0] - pix[-hex[2]]);
-#pragma unroll
-                    for (int k = 0; k < 2; k++)
-                        color[2 + k] = 0.640625f * pix[hex[4 + k]] + 0.359375f * pix[-2 * hex[4 + k]] + 0.12890625f * (2.f * pix[0] - pix[3 * hex[4 + k]] - pix[-3 * hex[4 + k]]);
-                    const float *s = gmm + ((size_t)r * TSH + (c >> 1)) * 2;
-                    const int flip = a.right_shift[row % 3] ? 0 : 1;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) gdir[k ^ flip] = limf(color[k], s[0], s[1]);
-                }
-            }
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                float *p = RGB(d, r, c);
-                p[0] = base[0]; p[PL] = interp ? gdir[d] : base[1]; p[2 * PL] = base[2];
-            }
-        }
-        __syncthreads(); XT_MARK(2);
+        // ---- The interpolation passes, the perceptual space and the derivative (L410-741), ONE DIRECTION BUFFER AT A TIME IN LDS.
+        // Within a pass every phase reads and writes one buffer only, and buffer k + 4 is buffer k after pass 0 (the memcpy of L479-481),
+        // so buffer k's three planes (3 x 114 x 114 floats = 156 KB: the workgroup has the CU to itself) are filled from the CFA, taken
+        // through pass 0, stored as rgb[k], taken through the remaining passes and stored as rgb[k + 4]; cielab then overwrites the planes
+        // in place and the derivative reads it there.  rgb[k] comes back once for its own cielab + derivative.  Offsets keep the arena's
+        // meaning: plane stride PL, row stride TS.
+        const int mrl = mrow - top, mcl = mcol - left;   // tile-local bounds (L654-655)
+        const int nlab = mrl - 8;                        // lab rows [0, nlab)
+        const xt_lf L = (xt_lf)xt_lds;
+        const int row0s = (top - sgrow + 4) / 3 * 3 + sgrow, col0s = (left - sgcol + 4) / 3 * 3 + sgcol;
 
-        for (int pass = 0; pass < passes; pass++) {
-            const int B = pass ? 4 : 0;
-            if (pass == 1) {
-                FOR_T(4 * TS * TS * 3) buffer[(size_t)4 * TS * TS * 3 + t] = buffer[t];
-                __syncthreads(); XT_MARK(3);
-            }
-            // recalculate green from interpolated values of closer pixels (L483-524)
-            if (pass) {
-                FOR_T(TS * TS) {
-                    const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
-                    if (r < 2 || c < 2 || row >= mrow - 2 || col >= mcol - 2 || G.isgreen(row, col)) continue;
-                    const int f = G.fcol(row, col);
-                    const int *hex = a.allhex1[row % 3][col % 3];
-                    const int flip = a.right_shift[row % 3] ? 0 : 1;
-                    const float *s = gmm + ((size_t)r * TSH + (c >> 1)) * 2;
-                    // all fifteen loads first: issued one direction at a time behind that direction's store they would be three dependent round trips
-                    float v[3][5];
+        // cielab (L41-116) in place over rows 4 .. 4 + nlab, columns 4 .. 4 + LW of the buffer in LDS + the derivative along direction d (L657-741)
+        auto lab_and_derivative = [&](int d) {
+            if (a.use_cielab) {
+                // four pixels per thread and iteration: their twelve table look-ups are in flight together
+                constexpr int U = 4;
+                const int n = nlab * LW;
+                for (int t0 = tid; t0 < n; t0 += U * NT) {
+                    int pp[U], jj[U], ix[U][3];
 #pragma unroll
-                    for (int d = 3; d < 6; d++) {
-                        const float *rix = RGB(B + ((d - 2) ^ flip), r, c);
-                        v[d - 3][0] = rix[-2 * hex[d] + PL]; v[d - 3][1] = rix[hex[d] + PL]; v[d - 3][2] = rix[hex[d] + f * PL];
-                        v[d - 3][3] = rix[-2 * hex[d] + f * PL]; v[d - 3][4] = rix[f * PL];
+                    for (int u = 0; u < U; u++) {
+                        const int t = min(t0 + u * NT, n - 1);
+                        const int i = t / LW, j = t - i * LW;
+                        const int p = (4 + i) * TS + 4 + j;
+                        pp[u] = p; jj[u] = j;
+                        const float p0 = L[p], p1 = L[PL + p], p2 = L[2 * PL + p];
+                        // 4-lane groups while j < labWidth - 3 ...
+                        const float x0 = p0 * a.xyz_cam[0] + p1 * a.xyz_cam[1] + p2 * a.xyz_cam[2];
+                        const float x1 = p0 * a.xyz_cam[3] + p1 * a.xyz_cam[4] + p2 * a.xyz_cam[5];
+                        const float x2 = p0 * a.xyz_cam[6] + p1 * a.xyz_cam[7] + p2 * a.xyz_cam[8];
+                        // ... the scalar tail rounds by adding 0.5 and truncating
+                        float y0 = 0.5f, y1 = 0.5f, y2 = 0.5f;
+                        y0 += a.xyz_cam[0] * p0; y1 += a.xyz_cam[3] * p0; y2 += a.xyz_cam[6] * p0;
+                        y0 += a.xyz_cam[1] * p1; y1 += a.xyz_cam[4] * p1; y2 += a.xyz_cam[7] * p1;
+                        y0 += a.xyz_cam[2] * p2; y1 += a.xyz_cam[5] * p2; y2 += a.xyz_cam[8] * p2;
+                        const bool vec = j < ((LW - 3 + 3) / 4) * 4;
+                        ix[u][0] = vec ? __float2int_rn(x0) : (int)y0;
+                        ix[u][1] = vec ? __float2int_rn(x1) : (int)y1;
+                        ix[u][2] = vec ? __float2int_rn(x2) : (int)y2;
                     }
-                    const float lo = s[0], hi = s[1];
+                    float cv[U][3];
 #pragma unroll
-                    for (int d = 3; d < 6; d++) {
-                        const float val = 0.33333333f * (v[d - 3][0] + 2 * (v[d - 3][1] - v[d - 3][2]) - v[d - 3][3]) + v[d - 3][4];
-                        *(RGB(B + ((d - 2) ^ flip), r, c) + PL) = limf(val, lo, hi);
+                    for (int u = 0; u < U; u++)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) cv[u][k] = cbrt_lut(a.cbrt_lut, ix[u][k]);
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        if (t0 + u * NT >= n) break;
+                        const float Lv = 116.f * cv[u][1] - 16.f;
+                        const float A = 500.f * (cv[u][0] - cv[u][1]), Bv = 200.f * (cv[u][1] - cv[u][2]);
+                        L[pp[u]] = Lv; L[PL + pp[u]] = A; L[2 * PL + pp[u]] = Bv;
+                        // the last direction's planes are stored as well: the homogeneity maps alias them (L301-308), and the 5x5 sums
+                        // read map bytes no one wrote = bytes of those floats
+                        if (d == ndir - 1) { const int i = pp[u] / TS - 4; LAB(0, i, jj[u]) = Lv; LAB(1, i, jj[u]) = A; LAB(2, i, jj[u]) = Bv; }
                     }
                 }
-                __syncthreads(); XT_MARK(4);
+            } else {
+                FOR_T(nlab * LW) {
+                    const int i = t / LW, j = t - i * LW;
+                    if (j >= mcl - 8) continue;
+                    const int p = (4 + i) * TS + 4 + j;
+                    const float p0 = L[p], p1 = L[PL + p], p2 = L[2 * PL + p];
+                    const float y = 0.2627f * p0 + 0.6780f * p1 + 0.0593f * p2;
+                    const float A = (p2 - y) * 0.56433f, Bv = (p0 - y) * 0.67815f;
+                    L[p] = y; L[PL + p] = A; L[2 * PL + p] = Bv;
+                    if (d == ndir - 1) { LAB(0, i, j) = y; LAB(1, i, j) = A; LAB(2, i, j) = Bv; }
+                }
             }
-            // red and blue for solitary green pixels (L527-561)
-            {
-                const int row0 = (top - sgrow + 4) / 3 * 3 + sgrow, col0 = (left - sgcol + 4) / 3 * 3 + sgcol;
+            xt_lds_barrier();
+            const int dd = d & 3;
+            const int f = dd == 0 ? 1 : (dd == 1 ? TS : (dd == 2 ? TS + 1 : TS - 1));
+            FOR_T((mrl - 10) * TS) {
+                const int rr = t / TS, c = t - rr * TS, r = 5 + rr;
+                if (c < 5 || c >= mcl - 5) continue;
+                const xt_lf l = L + r * TS + c, aa = l + PL, b = l + 2 * PL;
+                float v;
+                if (a.use_cielab) {
+                    const float g = 2 * l[0] - l[f] - l[-f];
+                    v = sqr(g) + sqr((2 * aa[0] - aa[f] - aa[-f] + g * 2.1551724f)) + sqr((2 * b[0] - b[f] - b[-f] - g * 0.86206896f));
+                } else {
+                    v = sqr(2 * l[0] - l[f] - l[-f]) + sqr(2 * aa[0] - aa[f] - aa[-f]) + sqr(2 * b[0] - b[f] - b[-f]);
+                }
+                DRV(d, r - 5, c - 5) = v;
+            }
+            xt_lds_barrier();
+        };
+        // the buffer in LDS -> rgb[d] of the arena
+        auto store_buffer = [&](int d) {
+            xt_f4 *dst = reinterpret_cast<xt_f4 *>(buffer + (size_t)d * 3 * PL);
+            FOR_T(3 * PL / 4) dst[t] = ((xt_lf4)L)[t];
+        };
+
+        for (int k = 0; k < 4; k++) {
+            // ---- CFA samples, green interpolated along direction k at the non-green sites (L410-475)
+            FOR_T(TS * TS) {
+                const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
+                float base[3] = {0.f, 0.f, 0.f};
+                float g = 0.f;
+                bool interp = false;
+                if (row < mrow && col < mcol) {
+                    const int f = G.fcol(row, col);
+                    const float *pix = a.raw + (size_t)row * rs + col;
+                    base[f] = pix[0];
+                    if (!(f & 1)) {
+                        interp = true;
+                        const int *hex = a.allhex0[row % 3][col % 3];
+                        const int flip = a.right_shift[row % 3] ? 0 : 1;
+                        const int j = k ^ flip;                         // gdir[j ^ flip] = color[j]: buffer k holds colour k ^ flip
+                        float color;
+                        if (j == 0) color = 0.6796875f * (pix[hex[1]] + pix[hex[0]]) - 0.1796875f * (pix[2 * hex[1]] + pix[2 * hex[0]]);
+                        else if (j == 1) color = 0.87109375f * pix[hex[3]] + pix[hex[2]] * 0.12890625f + 0.359375f * (pix[0] - pix[-hex[2]]);
+                        else {
+                            const int h = hex[2 + j];
+                            color = 0.640625f * pix[h] + 0.359375f * pix[-2 * h] + 0.12890625f * (2.f * pix[0] - pix[3 * h] - pix[-3 * h]);
+                        }
+                        const float *s = gmm + ((size_t)r * TSH + (c >> 1)) * 2;
+                        g = limf(color, s[0], s[1]);
+                    }
+                }
+                L[t] = base[0]; L[PL + t] = interp ? g : base[1]; L[2 * PL + t] = base[2];
+            }
+            xt_lds_barrier();
+
+            for (int pass = 0; pass < passes; pass++) {
+                // recalculate green from interpolated values of closer pixels (L483-524): buffer k is the target of hexagon entry
+                // (k ^ flip) + 2, of none where k == flip
+                if (pass) {
+                    FOR_T(TS * TS) {
+                        const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
+                        if (r < 2 || c < 2 || row >= mrow - 2 || col >= mcol - 2 || G.isgreen(row, col)) continue;
+                        const int flip = a.right_shift[row % 3] ? 0 : 1;
+                        const int e = k ^ flip;
+                        if (e == 0) continue;
+                        const int f = G.fcol(row, col);
+                        const int hx = a.allhex1[row % 3][col % 3][e + 2];
+                        const float *s = gmm + ((size_t)r * TSH + (c >> 1)) * 2;
+                        const xt_lf rix = L + t;
+                        const float val = 0.33333333f * (rix[-2 * hx + PL] + 2 * (rix[hx + PL] - rix[hx + f * PL]) - rix[-2 * hx + f * PL]) + rix[f * PL];
+                        rix[PL] = limf(val, s[0], s[1]);
+                    }
+                    xt_lds_barrier();
+                }
+                // red and blue for solitary green pixels (L527-561): buffers 0 and 1 take the row / column pair as it is, buffers 2
+                // and 3 the better of the two
                 FOR_T(40 * 40) {
                     const int i3 = t / 40, j3 = t - i3 * 40;
-                    const int row = row0 + 3 * i3, col = col0 + 3 * j3;
+                    const int row = row0s + 3 * i3, col = col0s + 3 * j3;
                     if (row >= mrow - 2 || col >= mcol - 2) continue;
-                    const int h0 = G.fcol(row, col0 + 1) ^ ((j3 & 1) ? 2 : 0);
-                    float *rix = RGB(B, row - top, col - left);
-                    // Six candidate pairs over four buffers (d = 0, 1 -> buffers 0, 1; d = 2, 3 -> buffer 2; d = 4, 5 -> buffer 3), along the row
-                    // for even d and the column for odd d, the nearer neighbours holding colour h and the farther ones colour h ^ 2.  None of
-                    // the 52 values is written by this phase: all loads first (behind each buffer's stores they were six round trips).
-                    float gc[4], L[6][2][4];
+                    const int h0 = G.fcol(row, col0s + 1) ^ ((j3 & 1) ? 2 : 0);
+                    const xt_lf rix = L + (row - top) * TS + (col - left);
+                    const float gc = rix[PL];
+                    float c0 = 0.f, c2 = 0.f, pc0 = 0.f, pc2 = 0.f, pdiff = 0.f;
 #pragma unroll
-                    for (int bq = 0; bq < 4; bq++) gc[bq] = rix[bq * 3 * PL + PL];
-#pragma unroll
-                    for (int d = 0; d < 6; d++) {
-                        const float *q = rix + (d < 2 ? d : (d < 4 ? 2 : 3)) * 3 * PL;
+                    for (int q = 0; q < 2; q++) {
+                        if (k < 2 && q) break;
+                        const int d = k < 2 ? k : 2 * (k - 1) + q;                 // 0 | 1 | 2, 3 | 4, 5
                         const int i = (d & 1) ? TS : 1, hd = h0 ^ ((d & 1) ? 2 : 0);
+                        float ck[2], diff = 0.f;
 #pragma unroll
-                        for (int k = 0; k < 2; k++) {
-                            const int o = i << k, hk = hd ^ (k ? 2 : 0);
-                            L[d][k][0] = q[o + PL]; L[d][k][1] = q[-o + PL]; L[d][k][2] = q[o + hk * PL]; L[d][k][3] = q[-o + hk * PL];
+                        for (int kk = 0; kk < 2; kk++) {
+                            const int o = i << kk, hk = hd ^ (kk ? 2 : 0);
+                            const float gp = rix[o + PL], gm = rix[-o + PL], hp = rix[o + hk * PL], hm = rix[-o + hk * PL];
+                            const float g = gc + gc - gp - gm;
+                            ck[kk] = g + hp + hm;
+                            diff += sqr(gp - gm - hp + hm) + sqr(g);
+                        }
+                        c0 = hd == 0 ? ck[0] : ck[1];
+                        c2 = hd == 0 ? ck[1] : ck[0];
+                        if (q && pdiff < diff) { c0 = pc0; c2 = pc2; }
+                        pc0 = c0; pc2 = c2; pdiff = diff;
+                    }
+                    rix[0] = 0.5f * c0;
+                    rix[2 * PL] = 0.5f * c2;
+                }
+                xt_lds_barrier();
+                // red for blue pixels and vice versa (L564-606): only buffer dc ever compares the two candidate axes
+                FOR_T(TS * TS) {
+                    const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
+                    if (r < 3 || c < 3 || row >= mrow - 3 || col >= mcol - 3 || G.isgreen(row, col)) continue;
+                    const int cd = ((row - sgrow) % 3) ? TS : 1;
+                    const int hd = 3 * (cd ^ TS ^ 1);
+                    const int f = 2 - G.fcol(row, col);
+                    const xt_lf rix = L + t;
+                    const int dc = cd == 1 ? 1 : 0;
+                    const float g0 = rix[PL];
+                    int i = cd;
+                    if (k == dc && !((fabsf(g0 - rix[cd + PL]) + fabsf(g0 - rix[-cd + PL])) < 2.f * (fabsf(g0 - rix[hd + PL]) + fabsf(g0 - rix[-hd + PL])))) i = hd;
+                    rix[f * PL] = g0 + 0.5f * (rix[i + f * PL] + rix[-i + f * PL] - rix[i + PL] - rix[-i + PL]);
+                }
+                xt_lds_barrier();
+                // red and blue for 2x2 blocks of green (L609-650): the reference steps d by two over the hexagon table while it steps by
+                // one buffer, so with four directions only buffers 0 and 1 are filled
+                if (2 * k < ndir) {
+                    FOR_T(TS * TS) {
+                        const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
+                        if (r < 2 || c < 2 || row >= mrow - 2 || col >= mcol - 2) continue;
+                        if ((row - sgrow) % 3 == 0 || (col - sgcol) % 3 == 0) continue;
+                        const int *hex = a.allhex1[row % 3][col % 3];
+                        const int h0 = hex[2 * k], h1 = hex[2 * k + 1];
+                        const xt_lf rix = L + t;
+                        if (h0 + h1) {
+                            const float g = 3 * rix[PL] - 2 * rix[h0 + PL] - rix[h1 + PL];
+                            const float vr = (g + 2 * rix[h0] + rix[h1]) * 0.33333333f;
+                            const float vb = (g + 2 * rix[h0 + 2 * PL] + rix[h1 + 2 * PL]) * 0.33333333f;
+                            rix[0] = vr; rix[2 * PL] = vb;
+                        } else {
+                            const float g = 2 * rix[PL] - rix[h0 + PL] - rix[h1 + PL];
+                            const float vr = (g + rix[h0] + rix[h1]) * 0.5f;
+                            const float vb = (g + rix[h0 + 2 * PL] + rix[h1 + 2 * PL]) * 0.5f;
+                            rix[0] = vr; rix[2 * PL] = vb;
                         }
                     }
-                    float c0[6], c2[6], diff[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int d = 0; d < 6; d++) {
-                        const int bq = d < 2 ? d : (d < 4 ? 2 : 3);
-                        const int hd = h0 ^ ((d & 1) ? 2 : 0);
-                        float ck[2];
-#pragma unroll
-                        for (int k = 0; k < 2; k++) {
-                            const float g = gc[bq] + gc[bq] - L[d][k][0] - L[d][k][1];
-                            ck[k] = g + L[d][k][2] + L[d][k][3];
-                            if (d > 1) diff[d] += sqr(L[d][k][0] - L[d][k][1] - L[d][k][2] + L[d][k][3]) + sqr(g);
-                        }
-                        c0[d] = hd == 0 ? ck[0] : ck[1];
-                        c2[d] = hd == 0 ? ck[1] : ck[0];
-                        if (d > 2 && (d & 1))
-                            if (diff[d - 1] < diff[d]) { c0[d] = c0[d - 1]; c2[d] = c2[d - 1]; }
-                        if ((d & 1) || d < 2) {
-                            rix[bq * 3 * PL] = 0.5f * c0[d];
-                            rix[bq * 3 * PL + 2 * PL] = 0.5f * c2[d];
-                        }
-                    }
+                    xt_lds_barrier();
                 }
+                if (pass == 0) { store_buffer(k); xt_lds_barrier(); }
+                else if (pass == passes - 1) { store_buffer(k + 4); xt_lds_barrier(); }
             }
-            __syncthreads(); XT_MARK(5);
-            // red for blue pixels and vice versa (L564-606)
-            FOR_T(TS * TS) {
-                const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
-                if (r < 3 || c < 3 || row >= mrow - 3 || col >= mcol - 3 || G.isgreen(row, col)) continue;
-                const int cd = ((row - sgrow) % 3) ? TS : 1;
-                const int hd = 3 * (cd ^ TS ^ 1);
-                const int f = 2 - G.fcol(row, col);
-                float *rix = RGB(B, r, c);
-                // Only one of the four directions compares the two candidate axes (d <= 1 with d and cd of equal parity); the others use
-                // cd.  All 24 loads are issued before the first store (the short-circuit form is four dependent round trips).
-                const int dc = cd == 1 ? 1 : 0;
-                float g0[4], gp[4], gm[4], Fp[4], Fm[4];
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    const float *q = rix + d * 3 * PL;
-                    g0[d] = q[PL]; gp[d] = q[cd + PL]; gm[d] = q[-cd + PL]; Fp[d] = q[cd + f * PL]; Fm[d] = q[-cd + f * PL];
-                }
-                const float *q = rix + dc * 3 * PL;
-                const float ghp = q[hd + PL], ghm = q[-hd + PL], Fhp = q[hd + f * PL], Fhm = q[-hd + f * PL];
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    const bool use_cd = d != dc || ((fabsf(g0[d] - gp[d]) + fabsf(g0[d] - gm[d])) < 2.f * (fabsf(g0[d] - ghp) + fabsf(g0[d] - ghm)));
-                    const float a1 = use_cd ? Fp[d] : Fhp, a2 = use_cd ? Fm[d] : Fhm, a3 = use_cd ? gp[d] : ghp, a4 = use_cd ? gm[d] : ghm;
-                    rix[d * 3 * PL + f * PL] = g0[d] + 0.5f * (a1 + a2 - a3 - a4);
-                }
+            XT_MARK(2 + k);
+            lab_and_derivative(passes > 1 ? k + 4 : k);
+            if (passes > 1) {
+                // rgb[k] once more, for its own cielab + derivative (written above by this workgroup: a full barrier)
+                __syncthreads();
+                const xt_f4 *src = reinterpret_cast<const xt_f4 *>(buffer + (size_t)k * 3 * PL);
+                FOR_T(3 * PL / 4) ((xt_lf4)L)[t] = src[t];
+                xt_lds_barrier();
+                lab_and_derivative(k);
             }
-            __syncthreads(); XT_MARK(6);
-            // red and blue for 2x2 blocks of green (L609-650)
-            FOR_T(TS * TS) {
-                const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
-                if (r < 2 || c < 2 || row >= mrow - 2 || col >= mcol - 2) continue;
-                if ((row - sgrow) % 3 == 0 || (col - sgcol) % 3 == 0) continue;
-                const int *hex = a.allhex1[row % 3][col % 3];
-                float *rix = RGB(B, r, c);
-                // the four buffers' 28 loads first (d steps by two over the hexagon table while rix steps by one buffer, L609-650)
-                float gc[4], gh0[4], gh1[4], r0[4], r1[4], b0[4], b1[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const float *q = rix + k * 3 * PL;
-                    const int h0 = hex[2 * k], h1 = hex[2 * k + 1];
-                    gc[k] = q[PL]; gh0[k] = q[h0 + PL]; gh1[k] = q[h1 + PL];
-                    r0[k] = q[h0]; r1[k] = q[h1]; b0[k] = q[h0 + 2 * PL]; b1[k] = q[h1 + 2 * PL];
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (2 * k >= ndir) break;
-                    float *q = rix + k * 3 * PL;
-                    if (hex[2 * k] + hex[2 * k + 1]) {
-                        const float g = 3 * gc[k] - 2 * gh0[k] - gh1[k];
-                        q[0] = (g + 2 * r0[k] + r1[k]) * 0.33333333f;
-                        q[2 * PL] = (g + 2 * b0[k] + b1[k]) * 0.33333333f;
-                    } else {
-                        const float g = 2 * gc[k] - gh0[k] - gh1[k];
-                        q[0] = (g + r0[k] + r1[k]) * 0.5f;
-                        q[2 * PL] = (g + b0[k] + b1[k]) * 0.5f;
-                    }
-                }
-            }
-            __syncthreads(); XT_MARK(7);
+            XT_MARK(6 + k);
         }
-
-        const int mrl = mrow - top, mcl = mcol - left;   // tile-local bounds (L654-655)
-        // ---- perceptual space + directional derivatives (L657-741), one direction at a time.  The lab planes never reach the arena: they
-        // are produced in LDS in strips of XT_SR rows (+ one row above and below, recomputed by the neighbouring strip) and consumed
-        // there by the derivative (every lab value the derivative reads is one this direction wrote).  The LAST direction's planes are
-        // stored as well: the homogeneity maps alias them (L301-308), and the 5x5 sums read map bytes no one wrote = bytes of those floats
-        const int nlab = mrl - 8;                               // lab rows [0, nlab); derivative rows i = r - 4 in [1, nlab - 1)
-        for (int d = 0; d < ndir; d++) {
-            const int dd = d & 3;
-            const int f = dd == 0 ? 1 : (dd == 1 ? LW : (dd == 2 ? LW + 1 : LW - 1));
-            for (int i0 = 1; i0 < nlab - 1; i0 += XT_SR) {
-                const int i1 = min(i0 + XT_SR, nlab - 1), lo = i0 - 1, nrows = i1 + 1 - lo;
-                if (a.use_cielab) {
-                    // four pixels per thread and iteration: their twelve colour loads, then their twelve table look-ups, are in flight together
-                    // (one pixel at a time is a chain of two memory round trips per iteration)
-                    constexpr int U = 4;
-                    const int n = nrows * LW;
-                    for (int t0 = tid; t0 < n; t0 += U * NT) {
-                        float pv[U][3];
-                        int jj[U], ti[U];
-#pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            const int t = min(t0 + u * NT, n - 1);
-                            const int ii = t / LW, j = t - ii * LW;
-                            const float *p = RGB(d, 4 + lo + ii, 4 + j);
-                            ti[u] = t; jj[u] = j;
-                            pv[u][0] = p[0]; pv[u][1] = p[PL]; pv[u][2] = p[2 * PL];
-                        }
-                        int ix[U][3];
-#pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            const float *p = pv[u];
-                            // 4-lane groups while j < labWidth - 3 ...
-                            const float x0 = p[0] * a.xyz_cam[0] + p[1] * a.xyz_cam[1] + p[2] * a.xyz_cam[2];
-                            const float x1 = p[0] * a.xyz_cam[3] + p[1] * a.xyz_cam[4] + p[2] * a.xyz_cam[5];
-                            const float x2 = p[0] * a.xyz_cam[6] + p[1] * a.xyz_cam[7] + p[2] * a.xyz_cam[8];
-                            // ... the scalar tail rounds by adding 0.5 and truncating
-                            float y0 = 0.5f, y1 = 0.5f, y2 = 0.5f;
-#pragma unroll
-                            for (int k = 0; k < 3; k++) { y0 += a.xyz_cam[k] * p[k]; y1 += a.xyz_cam[3 + k] * p[k]; y2 += a.xyz_cam[6 + k] * p[k]; }
-                            const bool vec = jj[u] < ((LW - 3 + 3) / 4) * 4;
-                            ix[u][0] = vec ? __float2int_rn(x0) : (int)y0;
-                            ix[u][1] = vec ? __float2int_rn(x1) : (int)y1;
-                            ix[u][2] = vec ? __float2int_rn(x2) : (int)y2;
-                        }
-                        float cv[U][3];
-#pragma unroll
-                        for (int u = 0; u < U; u++)
-#pragma unroll
-                            for (int k = 0; k < 3; k++) cv[u][k] = cbrt_lut(a.cbrt_lut, ix[u][k]);
-#pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            if (t0 + u * NT >= n) break;
-                            const int t = ti[u];
-                            const float L = jj[u] < ((LW - 3 + 3) / 4) * 4 ? 116.f * cv[u][1] - 16.f : 116 * cv[u][1] - 16;
-                            const float A = 500.f * (cv[u][0] - cv[u][1]), Bv = 200.f * (cv[u][1] - cv[u][2]);
-                            s_lab[0][t] = L;
-                            s_lab[1][t] = A;
-                            s_lab[2][t] = Bv;
-                            if (d == ndir - 1) { const int ii = t / LW, j = t - ii * LW, i = lo + ii; LAB(0, i, j) = L; LAB(1, i, j) = A; LAB(2, i, j) = Bv; }
-                        }
-                    }
-                } else {
-                    FOR_T(nrows * LW) {
-                        const int ii = t / LW, j = t - ii * LW, i = lo + ii;
-                        if (j >= mcl - 8) continue;
-                        const float *p = RGB(d, 4 + i, 4 + j);
-                        const float y = 0.2627f * p[0] + 0.6780f * p[PL] + 0.0593f * p[2 * PL];
-                        const float A = (p[2 * PL] - y) * 0.56433f, Bv = (p[0] - y) * 0.67815f;
-                        s_lab[0][t] = y;
-                        s_lab[1][t] = A;
-                        s_lab[2][t] = Bv;
-                        if (d == ndir - 1) { LAB(0, i, j) = y; LAB(1, i, j) = A; LAB(2, i, j) = Bv; }
-                    }
-                }
-                __syncthreads(); XT_MARK(8);
-                FOR_T((i1 - i0) * TS) {
-                    const int rr = t / TS, c = t - rr * TS, i = i0 + rr;
-                    if (c < 5 || c >= mcl - 5) continue;
-                    const int o = (i - lo) * LW + (c - 4);
-                    const float *l = &s_lab[0][o], *aa = &s_lab[1][o], *b = &s_lab[2][o];
-                    float v;
-                    if (a.use_cielab) {
-                        const float g = 2 * l[0] - l[f] - l[-f];
-                        v = sqr(g) + sqr((2 * aa[0] - aa[f] - aa[-f] + g * 2.1551724f)) + sqr((2 * b[0] - b[f] - b[-f] - g * 0.86206896f));
-                    } else {
-                        v = sqr(2 * l[0] - l[f] - l[-f]) + sqr(2 * aa[0] - aa[f] - aa[-f]) + sqr(2 * b[0] - b[f] - b[-f]);
-                    }
-                    DRV(d, i - 1, c - 5) = v;
-                }
-                __syncthreads(); XT_MARK(9);
-            }
-        }
+        __syncthreads();
 
         // ---- homogeneity maps (L744-811): the derivative rows of all directions are staged in LDS strip by strip (every value is read
         // 9 x for the counts and once for the threshold)
