@@ -25,10 +25,13 @@ constexpr int PL = TS * TS;    // one colour plane of a direction buffer (the rg
                                // [dir][channel][row][col] -- every value is written before it is read, so only the
                                // lab/drv/homo regions need the reference's exact byte layout)
 
+// the small tables of the kernel arguments, copied to LDS: indexed per lane from the argument segment each look-up is a memory round trip
+struct XtTables { int xtrans[36], allhex0[3][3][8], allhex1[3][3][8], right_shift[3]; };
+typedef const __attribute__((address_space(3))) XtTables *xt_tab;
 struct Geo {
-    const XtransArgs &a;
-    __device__ int fcol(int row, int col) const { return a.xtrans[(row % 6) * 6 + col % 6]; }
-    __device__ int isgreen(int row, int col) const { return a.xtrans[(row % 3) * 6 + col % 3] & 1; }
+    xt_tab a;
+    __device__ int fcol(int row, int col) const { return a->xtrans[(row % 6) * 6 + col % 6]; }
+    __device__ int isgreen(int row, int col) const { return a->xtrans[(row % 3) * 6 + col % 3] & 1; }
 };
 
 typedef __attribute__((address_space(3))) float *xt_lf;
@@ -43,7 +46,8 @@ __device__ __forceinline__ void xt_lds_barrier()
 }
 __device__ __forceinline__ float limf(float v, float lo, float hi) { return std_max(lo, std_min(v, hi)); }
 
-__device__ __forceinline__ void hex_minmax(const float *pix, const int *hex, float &mn, float &mx)
+template <typename H>
+__device__ __forceinline__ void hex_minmax(const float *pix, H hex, float &mn, float &mx)
 {
     float minval = FLT_MAX, maxval = 0.f;
 #pragma unroll
@@ -76,7 +80,13 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
 {
     extern __shared__ float xt_lds[];
     const int tid = threadIdx.x;
-    const Geo G{a};
+    __shared__ XtTables s_tab;
+    if (tid < 36) s_tab.xtrans[tid] = a.xtrans[tid];
+    if (tid < 72) { (&s_tab.allhex0[0][0][0])[tid] = (&a.allhex0[0][0][0])[tid]; (&s_tab.allhex1[0][0][0])[tid] = (&a.allhex1[0][0][0])[tid]; }
+    if (tid < 3) s_tab.right_shift[tid] = a.right_shift[tid];
+    __syncthreads();
+    const xt_tab T = (xt_tab)&s_tab;
+    const Geo G{T};
     const int ndir = a.ndir, passes = a.passes;
     float *const buffer = a.arena + (size_t)blockIdx.x * a.arena_floats;
     float *const labbase = buffer + (size_t)TS * TS * (ndir * 3);
@@ -113,23 +123,23 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                 if (!G.isgreen(row, leftstart)) break;
             const float *rawrow = a.raw + (size_t)row * rs;
             float mn, mx;
-            if (a.right_shift[row % 3]) {
+            if (T->right_shift[row % 3]) {
                 const int col = leftstart + 3 * g;
                 if (col < mcol) {
-                    hex_minmax(rawrow + col, a.allhex0[row % 3][col % 3], mn, mx);
+                    hex_minmax(rawrow + col, T->allhex0[row % 3][col % 3], mn, mx);
                     float *s = gmm + ((size_t)r * TSH + ((col - left) >> 1)) * 2;
                     s[0] = mn; s[1] = mx;
                 }
             } else {
                 const int single = (G.fcol(row, leftstart + 1) & 1);    // coloffset == 2: the run starts with a lone pixel
                 if (single && g == 0) {
-                    hex_minmax(rawrow + leftstart, a.allhex0[row % 3][leftstart % 3], mn, mx);
+                    hex_minmax(rawrow + leftstart, T->allhex0[row % 3][leftstart % 3], mn, mx);
                     float *s = gmm + ((size_t)r * TSH + ((leftstart - left) >> 1)) * 2;
                     s[0] = mn; s[1] = mx;
                 } else {
                     const int col = leftstart + (single ? 2 : 0) + 3 * (g - single);
                     if (col < mcol) {
-                        hex_minmax(rawrow + col, a.allhex0[row % 3][col % 3], mn, mx);   // the pair shares the first pixel's hexagon
+                        hex_minmax(rawrow + col, T->allhex0[row % 3][col % 3], mn, mx);   // the pair shares the first pixel's hexagon
                         float *s = gmm + ((size_t)r * TSH + ((col - left) >> 1)) * 2;
                         s[0] = mn; s[1] = mx;
                         if (col < mcol - 1) {
@@ -247,8 +257,8 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                     base[f] = pix[0];
                     if (!(f & 1)) {
                         interp = true;
-                        const int *hex = a.allhex0[row % 3][col % 3];
-                        const int flip = a.right_shift[row % 3] ? 0 : 1;
+                        const auto hex = T->allhex0[row % 3][col % 3];
+                        const int flip = T->right_shift[row % 3] ? 0 : 1;
                         const int j = k ^ flip;                         // gdir[j ^ flip] = color[j]: buffer k holds colour k ^ flip
                         float color;
                         if (j == 0) color = 0.6796875f * (pix[hex[1]] + pix[hex[0]]) - 0.1796875f * (pix[2 * hex[1]] + pix[2 * hex[0]]);
@@ -272,11 +282,11 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                     FOR_T(TS * TS) {
                         const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
                         if (r < 2 || c < 2 || row >= mrow - 2 || col >= mcol - 2 || G.isgreen(row, col)) continue;
-                        const int flip = a.right_shift[row % 3] ? 0 : 1;
+                        const int flip = T->right_shift[row % 3] ? 0 : 1;
                         const int e = k ^ flip;
                         if (e == 0) continue;
                         const int f = G.fcol(row, col);
-                        const int hx = a.allhex1[row % 3][col % 3][e + 2];
+                        const int hx = T->allhex1[row % 3][col % 3][e + 2];
                         const float *s = gmm + ((size_t)r * TSH + (c >> 1)) * 2;
                         const xt_lf rix = L + t;
                         const float val = 0.33333333f * (rix[-2 * hx + PL] + 2 * (rix[hx + PL] - rix[hx + f * PL]) - rix[-2 * hx + f * PL]) + rix[f * PL];
@@ -339,7 +349,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                         const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
                         if (r < 2 || c < 2 || row >= mrow - 2 || col >= mcol - 2) continue;
                         if ((row - sgrow) % 3 == 0 || (col - sgcol) % 3 == 0) continue;
-                        const int *hex = a.allhex1[row % 3][col % 3];
+                        const auto hex = T->allhex1[row % 3][col % 3];
                         const int h0 = hex[2 * k], h1 = hex[2 * k + 1];
                         const xt_lf rix = L + t;
                         if (h0 + h1) {
