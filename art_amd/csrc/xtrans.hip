@@ -37,6 +37,7 @@ struct Geo {
 typedef __attribute__((address_space(3))) float *xt_lf;
 typedef float xt_f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) xt_f4 *xt_lf4;
+typedef __attribute__((address_space(3))) unsigned char *xt_lb;
 // workgroup barrier that orders LDS traffic only: a __syncthreads() would also wait for the stores to the arena
 __device__ __forceinline__ void xt_lds_barrier()
 {
@@ -61,11 +62,10 @@ __device__ __forceinline__ void hex_minmax(const float *pix, H hex, float &mn, f
 __device__ __forceinline__ float cbrt_lut(const float *__restrict__ lut, int i) { return lut[i < 0 ? 0 : (i > 0x14000 - 1 ? 0x14000 - 1 : i)]; }
 } // namespace
 
-// LDS of a workgroup (it has the CU to itself): the three planes of one direction buffer, 156 KB; the homogeneity phases reuse it for strips of the
-// eight derivative planes (XT_DR rows + two halo rows) and for the homogeneity maps (XT_HP at a time).
+// LDS of a workgroup (it has the CU to itself): the three planes of one direction buffer, 156 KB; the homogeneity phases reuse it for the eight
+// homogeneity maps (bytes, 104 KB) and strips of the eight derivative planes (XT_DR rows + two halo rows).
 constexpr int XT_LDS_FLOATS = 3 * TS * TS;
-constexpr int XT_DR = XT_LDS_FLOATS / (8 * (TS - 10)) - 2;      // 44 derivative rows per strip
-constexpr int XT_HP = XT_LDS_FLOATS * 4 / (TS * TS);            // 12 maps
+constexpr int XT_DR = (XT_LDS_FLOATS - 8 * TS * TS / 4) / (8 * (TS - 10)) - 2;      // 13 derivative rows per strip beside the eight byte maps
 #define FOR_T(N) for (int t = tid, _n = (N); t < _n; t += NT)
 #ifdef XT_PROFILE
 #define XT_MARK(k) do { const long long _n2 = wall_clock64(); xt_acc[k] += _n2 - xt_last; xt_last = _n2; } while (0)
@@ -93,8 +93,6 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
     float *const drvbase = buffer + (size_t)TS * TS * (ndir * 3 + 3);
     unsigned char *const homo = reinterpret_cast<unsigned char *>(labbase);       // [ndir][TS][TS]
     float *const gmm = labbase;                                                   // [TS][TSH][2]
-    unsigned char *const homosum = reinterpret_cast<unsigned char *>(drvbase);    // [ndir][TS][TS]
-    unsigned char *const homosummax = homo + (size_t)(ndir - 1) * TS * TS;        // [TS][TS]
     const int width = a.W, height = a.H;
     const size_t rs = a.raw_stride;
     const int sgrow = a.sgrow, sgcol = a.sgcol;
@@ -383,19 +381,29 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
         }
         __syncthreads();
 
-        // ---- homogeneity maps (L744-811): the derivative rows of all directions are staged in LDS strip by strip (every value is read
-        // 9 x for the counts and once for the threshold)
+        // ---- homogeneity maps (L744-811), their 5x5 sums (L823-866), the per-pixel maximum (L870-906) and the average of the most
+        // homogeneous directions (L910-949).  The byte maps live in LDS: first a copy of what the arena holds where the reference keeps
+        // them (the bytes of the last direction's lab planes / greenminmax / the cleared rest: the 5x5 sums at the frame's edges read map
+        // bytes no one wrote), then the counts on top of it; the sums, the maximum and the average are one pass per pixel over that.
+        // The derivative rows of all directions are staged beside the maps strip by strip (every value is read 9 x for the counts and
+        // once for the threshold).
+        const xt_lb s_b = (xt_lb)xt_lds;                                  // [ndir][TS][TS]
+        const xt_lf sdrv = L + 8 * TS * TS / 4;                           // [ndir][XT_DR + 2][DW]
+        {
+            const unsigned *src = reinterpret_cast<const unsigned *>(homo);                 // TS * TS is a multiple of 4
+            FOR_T(ndir * (TS * TS / 4)) ((__attribute__((address_space(3))) unsigned *)xt_lds)[t] = src[t];
+        }
         for (int ra = 6; ra < mrl - 6; ra += XT_DR) {
             const int rb = min(ra + XT_DR, mrl - 6), nrows = rb - ra + 2;       // derivative rows ra - 6 .. rb - 5
             FOR_T(ndir * nrows * DW) {
                 const int d = t / (nrows * DW), q = t - d * nrows * DW, ii = q / DW, j = q - ii * DW;
-                xt_lds[(d * (XT_DR + 2) + ii) * DW + j] = DRV(d, ra - 6 + ii, j);
+                sdrv[(d * (XT_DR + 2) + ii) * DW + j] = DRV(d, ra - 6 + ii, j);
             }
-            __syncthreads();
+            xt_lds_barrier();
             FOR_T((rb - ra) * TS) {
                 const int rr = t / TS, c = t - rr * TS, r = ra + rr;
                 if (c < 6 || c >= mcl - 6) continue;
-#define SDRV(d, v, h) xt_lds[((d) * (XT_DR + 2) + rr + 1 + (v)) * DW + c - 5 + (h)]
+#define SDRV(d, v, h) sdrv[((d) * (XT_DR + 2) + rr + 1 + (v)) * DW + c - 5 + (h)]
                 float tr = SDRV(0, 0, 0) < SDRV(1, 0, 0) ? SDRV(0, 0, 0) : SDRV(1, 0, 0);
                 for (int d = 2; d < ndir; d++) tr = (SDRV(d, 0, 0) < tr ? SDRV(d, 0, 0) : tr);
                 tr *= 8;
@@ -405,11 +413,11 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                     for (int v = -1; v <= 1; v++)
 #pragma unroll
                         for (int h = -1; h <= 1; h++) cnt += (SDRV(d, v, h) <= tr ? 1 : 0);
-                    homo[((size_t)d * TS + r) * TS + c] = (unsigned char)cnt;
+                    s_b[(d * TS + r) * TS + c] = (unsigned char)cnt;
                 }
 #undef SDRV
             }
-            __syncthreads();
+            xt_lds_barrier();
         }
         XT_MARK(10);
 
@@ -417,65 +425,39 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
         if (height - top < TS + 4) mr2 = height - top + 2;
         if (width - left < TS + 4) mc2 = width - left + 2;
         const int startrow = min(top, 8), startcol = min(left, 8);
-        // ---- 5x5 sums of the homogeneity maps (L823-866)
-        // XT_HP maps at a time are staged in LDS with dword loads (25 byte loads per sum from the arena were 12 % of the kernel)
-        for (int d0 = 0; d0 < ndir; d0 += XT_HP) {
-            const int nd = min(XT_HP, ndir - d0);
-            unsigned char *const s_b = reinterpret_cast<unsigned char *>(xt_lds);
-            {
-                const unsigned *src = reinterpret_cast<const unsigned *>(homo + (size_t)d0 * TS * TS);      // TS * TS is a multiple of 4
-                unsigned *dstw = reinterpret_cast<unsigned *>(s_b);
-                FOR_T(nd * (TS * TS / 4)) dstw[t] = src[t];
-            }
-            __syncthreads();
-            FOR_T(nd * TS * TS) {
-                const int dl = t / (TS * TS), q = t - dl * TS * TS, r = q / TS, c = q - r * TS;
-                if (r < startrow || c < startcol || r >= mr2 - 8 || c >= mc2 - 8) continue;
+        FOR_T(TS * TS) {
+            const int r = t / TS, c = t - r * TS;
+            if (r < startrow || c < startcol || r >= mr2 - 8 || c >= mc2 - 8) continue;
+            // the reference's 16-wide loop adds with unsigned saturation (_mm_adds_epu8, L835-843); its running-sum tail,
+            // which only the last row reaches, truncates to uint8 (L846-864).  Sums above 255 arise where never-written
+            // homogeneity bytes (= lab bytes) are read at the right / bottom edge.
+            const int endcol = r < mr2 - 9 ? mc2 - 8 : mc2 - 23;
+            const int ncov = endcol > startcol ? ((endcol - startcol + 15) / 16) * 16 : 0;
+            const bool saturate = c < startcol + ncov;
+            unsigned char hm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                if (d >= ndir) break;
                 int sum = 0;
 #pragma unroll
                 for (int v = -2; v <= 2; v++)
 #pragma unroll
-                    for (int h = -2; h <= 2; h++) sum += s_b[(dl * TS + r + v) * TS + c + h];
-                // the reference's 16-wide loop adds with unsigned saturation (_mm_adds_epu8, L835-843); its running-sum tail,
-                // which only the last row reaches, truncates to uint8 (L846-864).  Sums above 255 arise where never-written
-                // homogeneity bytes (= lab bytes) are read at the right / bottom edge.
-                const int endcol = r < mr2 - 9 ? mc2 - 8 : mc2 - 23;
-                const int ncov = endcol > startcol ? ((endcol - startcol + 15) / 16) * 16 : 0;
-                homosum[((size_t)(d0 + dl) * TS + r) * TS + c] = (c < startcol + ncov) ? (unsigned char)(sum > 255 ? 255 : sum) : (unsigned char)sum;
+                    for (int h = -2; h <= 2; h++) sum += s_b[(d * TS + r + v) * TS + c + h];
+                hm[d] = saturate ? (unsigned char)(sum > 255 ? 255 : sum) : (unsigned char)sum;
             }
-            __syncthreads();
-        }
-        XT_MARK(11);
-        // ---- per-pixel maximum (L870-906)
-        FOR_T(TS * TS) {
-            const int r = t / TS, c = t - r * TS;
-            if (r < startrow || c < startcol || r >= mr2 - 8 || c >= mc2 - 8) continue;
-            unsigned char maxval = homosum[(size_t)r * TS + c];
-            for (int d = 1; d < ndir; d++) {
-                const unsigned char v = homosum[((size_t)d * TS + r) * TS + c];
-                maxval = maxval < v ? v : maxval;
-            }
-            maxval -= maxval >> 3;
-            homosummax[(size_t)r * TS + c] = maxval;
-        }
-        __syncthreads(); XT_MARK(12);
-        // ---- average the most homogeneous directions (L910-949)
-        FOR_T(TS * TS) {
-            const int r = t / TS, c = t - r * TS;
-            if (r < startrow || c < startcol || r >= mr2 - 8 || c >= mc2 - 8) continue;
-            unsigned char hm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            unsigned char maxval = hm[0];
 #pragma unroll
-            for (int d = 0; d < 4; d++) hm[d] = homosum[((size_t)d * TS + r) * TS + c];
+            for (int d = 1; d < 8; d++)
+                if (d < ndir) maxval = maxval < hm[d] ? hm[d] : maxval;
+            maxval -= maxval >> 3;
             if (ndir > 4) {
 #pragma unroll
                 for (int d = 4; d < 8; d++) {
-                    hm[d] = homosum[((size_t)d * TS + r) * TS + c];
                     if (hm[d - 4] < hm[d]) hm[d - 4] = 0;
                     else if (hm[d - 4] > hm[d]) hm[d] = 0;
                 }
             }
             float avg[4] = {0.f, 0.f, 0.f, 0.f};
-            const unsigned char maxval = homosummax[(size_t)r * TS + c];
             // the chosen directions' colours: every load is issued (a direction that is not chosen re-reads direction 0's address and adds
             // +0, which changes no bit of a sum that starts at +0) instead of one guarded round trip per direction
             float pv[8][3];
