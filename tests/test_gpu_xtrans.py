@@ -26,6 +26,17 @@ def test_xtrans_bit_exact(gpu_ctx, passes, lab, size):
         assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
 
 
+@pytest.mark.parametrize("passes,lab", [(1, False), (2, True)])
+def test_xtrans_more_tiles_than_workgroups(gpu_ctx, passes, lab):
+    """25 x 24 tiles for 512 workgroups: some walk two tiles, with the LDS buffer and the arena as the first tile left them"""
+    w, h = 2400, 2350
+    raw = synth.xtrans_frame(w, h, seed=11, noise=900)
+    got = run(gpu_ctx, raw, passes, lab)
+    ref = O.xtrans_demosaic(raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, passes, lab)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+
+
 def test_xtrans_shifted_pattern_and_device_planes(gpu_ctx):
     """a sensor whose pattern phase differs (rolled colour map), device-resident planes with a padded row stride"""
     import torch
