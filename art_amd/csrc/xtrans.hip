@@ -26,7 +26,7 @@ constexpr int PL = TS * TS;    // one colour plane of a direction buffer (the rg
                                // lab/drv/homo regions need the reference's exact byte layout)
 
 // the small tables of the kernel arguments, copied to LDS: indexed per lane from the argument segment each look-up is a memory round trip
-struct XtTables { int xtrans[36], allhex0[3][3][8], allhex1[3][3][8], right_shift[3]; };
+struct XtTables { int xtrans[36], allhex0[3][3][8], allhex1[3][3][8], right_shift[3], cls[2][2][9], ncls[2]; };
 typedef const __attribute__((address_space(3))) XtTables *xt_tab;
 struct Geo {
     xt_tab a;
@@ -84,7 +84,25 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
     if (tid < 36) s_tab.xtrans[tid] = a.xtrans[tid];
     if (tid < 72) { (&s_tab.allhex0[0][0][0])[tid] = (&a.allhex0[0][0][0])[tid]; (&s_tab.allhex1[0][0][0])[tid] = (&a.allhex1[0][0][0])[tid]; }
     if (tid < 3) s_tab.right_shift[tid] = a.right_shift[tid];
+    // Dense site lists for the phases that work on one site class only (4 of 9 pixels each: with a lane per pixel more than half of
+    // every wave sat out).  The green layout has period 3 (`isgreen`), so a class is a list of (row, column) residues per 3 x 3 cell
+    // and the tile is 38 x 38 cells.  cls[0]: the non-green sites, cls[1]: the greens off the solitary green's row and column (2x2 blocks).
+    if (tid == 0) {
+        int n0 = 0, n1 = 0;
+        for (int rr = 0; rr < 3; rr++)
+            for (int cc = 0; cc < 3; cc++) {
+                if (!(a.xtrans[rr * 6 + cc] & 1)) { s_tab.cls[0][0][n0] = rr; s_tab.cls[0][1][n0] = cc; n0++; }
+                if ((rr - a.sgrow % 3 + 3) % 3 != 0 && (cc - a.sgcol % 3 + 3) % 3 != 0) { s_tab.cls[1][0][n1] = rr; s_tab.cls[1][1][n1] = cc; n1++; }
+            }
+        s_tab.ncls[0] = n0; s_tab.ncls[1] = n1;
+    }
     __syncthreads();
+    constexpr int NCELL = TS / 3;
+    static_assert(NCELL * 3 == TS, "the tile is a whole number of 3 x 3 cells");
+    // site `t` of class `cls` in a tile whose origin is (top, left): tile-local row and column
+#define XT_SITE(KC, t, top, left, r, c)                                                               \
+    const int _sn = T->ncls[KC], _cell = (t) / _sn, _k = (t) - _cell * _sn, _bi = _cell / NCELL;      \
+    const int r = 3 * _bi + (T->cls[KC][0][_k] - (top) % 3 + 3) % 3, c = 3 * (_cell - _bi * NCELL) + (T->cls[KC][1][_k] - (left) % 3 + 3) % 3
     const xt_tab T = (xt_tab)&s_tab;
     const Geo G{T};
     const int ndir = a.ndir, passes = a.passes;
@@ -277,16 +295,17 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                 // recalculate green from interpolated values of closer pixels (L483-524): buffer k is the target of hexagon entry
                 // (k ^ flip) + 2, of none where k == flip
                 if (pass) {
-                    FOR_T(TS * TS) {
-                        const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
-                        if (r < 2 || c < 2 || row >= mrow - 2 || col >= mcol - 2 || G.isgreen(row, col)) continue;
+                    FOR_T(NCELL * NCELL * T->ncls[0]) {
+                        XT_SITE(0, t, top, left, r, c);
+                        const int row = top + r, col = left + c;
+                        if (r < 2 || c < 2 || row >= mrow - 2 || col >= mcol - 2) continue;
                         const int flip = T->right_shift[row % 3] ? 0 : 1;
                         const int e = k ^ flip;
                         if (e == 0) continue;
                         const int f = G.fcol(row, col);
                         const int hx = T->allhex1[row % 3][col % 3][e + 2];
                         const float *s = gmm + ((size_t)r * TSH + (c >> 1)) * 2;
-                        const xt_lf rix = L + t;
+                        const xt_lf rix = L + r * TS + c;
                         const float val = 0.33333333f * (rix[-2 * hx + PL] + 2 * (rix[hx + PL] - rix[hx + f * PL]) - rix[-2 * hx + f * PL]) + rix[f * PL];
                         rix[PL] = limf(val, s[0], s[1]);
                     }
@@ -326,13 +345,14 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                 }
                 xt_lds_barrier();
                 // red for blue pixels and vice versa (L564-606): only buffer dc ever compares the two candidate axes
-                FOR_T(TS * TS) {
-                    const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
-                    if (r < 3 || c < 3 || row >= mrow - 3 || col >= mcol - 3 || G.isgreen(row, col)) continue;
+                FOR_T(NCELL * NCELL * T->ncls[0]) {
+                    XT_SITE(0, t, top, left, r, c);
+                    const int row = top + r, col = left + c;
+                    if (r < 3 || c < 3 || row >= mrow - 3 || col >= mcol - 3) continue;
                     const int cd = ((row - sgrow) % 3) ? TS : 1;
                     const int hd = 3 * (cd ^ TS ^ 1);
                     const int f = 2 - G.fcol(row, col);
-                    const xt_lf rix = L + t;
+                    const xt_lf rix = L + r * TS + c;
                     const int dc = cd == 1 ? 1 : 0;
                     const float g0 = rix[PL];
                     int i = cd;
@@ -343,13 +363,13 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                 // red and blue for 2x2 blocks of green (L609-650): the reference steps d by two over the hexagon table while it steps by
                 // one buffer, so with four directions only buffers 0 and 1 are filled
                 if (2 * k < ndir) {
-                    FOR_T(TS * TS) {
-                        const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
+                    FOR_T(NCELL * NCELL * T->ncls[1]) {
+                        XT_SITE(1, t, top, left, r, c);
+                        const int row = top + r, col = left + c;
                         if (r < 2 || c < 2 || row >= mrow - 2 || col >= mcol - 2) continue;
-                        if ((row - sgrow) % 3 == 0 || (col - sgcol) % 3 == 0) continue;
                         const auto hex = T->allhex1[row % 3][col % 3];
                         const int h0 = hex[2 * k], h1 = hex[2 * k + 1];
-                        const xt_lf rix = L + t;
+                        const xt_lf rix = L + r * TS + c;
                         if (h0 + h1) {
                             const float g = 3 * rix[PL] - 2 * rix[h0 + PL] - rix[h1 + PL];
                             const float vr = (g + 2 * rix[h0] + rix[h1]) * 0.33333333f;
