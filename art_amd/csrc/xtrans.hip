@@ -101,7 +101,10 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
     static_assert(NCELL * 3 == TS, "the tile is a whole number of 3 x 3 cells");
     // site `t` of class `cls` in a tile whose origin is (top, left): tile-local row and column
 #define XT_SITE(KC, t, top, left, r, c)                                                               \
-    const int _sn = T->ncls[KC], _cell = (t) / _sn, _k = (t) - _cell * _sn, _bi = _cell / NCELL;      \
+    const int _sn = T->ncls[KC];                                                                       \
+    int _cell;                                                                                         \
+    if (_sn == 4) _cell = (t) >> 2; else _cell = (t) / _sn;   /* uniform: four sites per cell for every real sensor */ \
+    const int _k = (t) - _cell * _sn, _bi = _cell / NCELL;                                             \
     const int r = 3 * _bi + (T->cls[KC][0][_k] - (top) % 3 + 3) % 3, c = 3 * (_cell - _bi * NCELL) + (T->cls[KC][1][_k] - (left) % 3 + 3) % 3
     const xt_tab T = (xt_tab)&s_tab;
     const Geo G{T};
@@ -413,12 +416,33 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             const unsigned *src = reinterpret_cast<const unsigned *>(homo);                 // TS * TS is a multiple of 4
             FOR_T(ndir * (TS * TS / 4)) ((__attribute__((address_space(3))) unsigned *)xt_lds)[t] = src[t];
         }
+        // (a strip's values are fetched into registers while the strip before it is counted)
+        constexpr int XT_SPT = (8 * (XT_DR + 2) * DW + NT - 1) / NT;       // strip values per thread
+        float pre[XT_SPT];
+        auto fetch_strip = [&](int ra) {
+            const int rb = min(ra + XT_DR, mrl - 6), nrows = rb - ra + 2, n = ndir * nrows * DW;
+#pragma unroll
+            for (int u = 0; u < XT_SPT; u++) {
+                const int t = min(tid + u * NT, n - 1);
+                const int d = t / (nrows * DW), q = t - d * nrows * DW, ii = q / DW, j = q - ii * DW;
+                pre[u] = DRV(d, ra - 6 + ii, j);
+            }
+        };
+        if (6 < mrl - 6) fetch_strip(6);
         for (int ra = 6; ra < mrl - 6; ra += XT_DR) {
             const int rb = min(ra + XT_DR, mrl - 6), nrows = rb - ra + 2;       // derivative rows ra - 6 .. rb - 5
-            FOR_T(ndir * nrows * DW) {
-                const int d = t / (nrows * DW), q = t - d * nrows * DW, ii = q / DW, j = q - ii * DW;
-                sdrv[(d * (XT_DR + 2) + ii) * DW + j] = DRV(d, ra - 6 + ii, j);
+            {
+                const int n = ndir * nrows * DW;
+#pragma unroll
+                for (int u = 0; u < XT_SPT; u++) {
+                    const int t = tid + u * NT;
+                    if (t < n) {
+                        const int d = t / (nrows * DW), q = t - d * nrows * DW, ii = q / DW, j = q - ii * DW;
+                        sdrv[(d * (XT_DR + 2) + ii) * DW + j] = pre[u];
+                    }
+                }
             }
+            if (ra + XT_DR < mrl - 6) fetch_strip(ra + XT_DR);
             xt_lds_barrier();
             FOR_T((rb - ra) * TS) {
                 const int rr = t / TS, c = t - rr * TS, r = ra + rr;
