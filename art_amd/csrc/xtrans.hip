@@ -1,15 +1,22 @@
-// art_amd/csrc/xtrans.hip -- X-Trans (Markesteijn) demosaic for gfx950, v1 "arena" kernel.
+// art_amd/csrc/xtrans.hip -- X-Trans (Markesteijn) demosaic for gfx950.
 //
 // Replaces RawImageSource::xtrans_interpolate(passes, useCieLab) (reference: rtengine/xtrans_demosaic.cc:181-969),
 // cielab (L41-116, x86-64 path) and xtransborder_interpolate (L122-173).  One workgroup per REFERENCE tile (114x114,
 // origin (3,3), stride 98 -- the tile grid decides where each direction buffer is defined, so it is part of the
-// result).  The per-workgroup HBM arena keeps the reference's layout and aliasing (L301-308):
-//     rgb[ndir] (planar here: [dir][channel][114][114], coalesced; interleaved [..][3] in the reference) | lab[3][106][106] | drv[ndir][104][104]
-//     greenminmax + uint8 homogeneity maps alias lab, 5x5 sums alias drv, the per-pixel maximum aliases homo[ndir-1].
-// rgb[0] and the lab planes are cleared per tile (a reference thread's first tile); everything else is written before
-// it is read.  Every step of the algorithm reads only values produced by EARLIER steps (the in-place green
-// recalculation of pass >= 1 reads green and interpolated R/B at green sites only), so each step is a parallel loop
-// over the tile and steps are separated by workgroup barriers.
+// result), and the workgroup has its CU to itself (1024 threads, 157 KB of LDS):
+//   * ONE direction buffer (3 planes x 114 x 114 floats) is in LDS at a time.  Within a pass every phase reads and writes
+//     one buffer only and buffer k + 4 starts as buffer k after pass 0, so buffer k is filled from the CFA, taken through
+//     pass 0, stored as rgb[k], taken through the other passes, stored as rgb[k + 4], converted to the perceptual space
+//     in place and differentiated there; rgb[k] comes back once for its own conversion + derivative.
+//   * the per-workgroup HBM arena holds what has to outlive that: rgb[ndir] (planar: [dir][channel][114][114]) |
+//     lab[3][106][106] | drv[ndir][104][104] in the reference's layout (L301-308).  greenminmax lives where the reference
+//     keeps it (in the lab region); of the lab planes only the last direction's are stored, because the uint8
+//     homogeneity maps alias them and the 5x5 sums read map bytes no one wrote.
+//   * the homogeneity maps are bytes in LDS (a copy of those arena bytes with the counts on top); their 5x5 sums, the
+//     per-pixel maximum and the average of the chosen directions are one pass per pixel over them.
+// Every step reads only values produced by EARLIER steps (the in-place green recalculation of pass >= 1 reads green
+// and interpolated R/B at green sites only), so each step is a parallel loop over the tile's sites and steps are
+// separated by workgroup barriers (LDS-only ones inside the buffer loop).
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include "devmath.h"

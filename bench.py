@@ -304,7 +304,7 @@ def main() -> None:
     traffic, traffic_src, traffic_raw, issue = None, None, None, None
     kname = "xtrans_tiles_kernel" if xtrans else "amaze_stream_kernel" if method == capi.BAYER_AMAZE else "rcd_stream_kernel"
     pmc_rel = os.path.join("profiles", "r2", {"amaze_stream_kernel": "amaze_v2_pmc_summary.json", "rcd_stream_kernel": "rcd_stream_pmc_summary.json",
-                                              "xtrans_tiles_kernel": "xtrans_v1b_pmc_summary.json"}[kname])
+                                              "xtrans_tiles_kernel": "xtrans_v2_pmc_summary.json"}[kname])
     pmc_path = os.path.join(ROOT, pmc_rel)
     full_size = (W, H) == ((11648, 8736) if xtrans else (W45, H45))
     if full_size and os.path.exists(pmc_path):
