@@ -26,6 +26,16 @@ def test_xtrans_bit_exact(gpu_ctx, passes, lab, size):
         assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
 
 
+@pytest.mark.parametrize("w,h,passes,lab", [(64, 64, 3, True), (70, 66, 1, False), (115, 117, 3, True), (131, 120, 4, True), (122, 230, 3, False)])
+def test_xtrans_small_frames(gpu_ctx, w, h, passes, lab):
+    """one or two tiles per direction, the second one a sliver: every bound of the LDS phases at its smallest"""
+    raw = synth.xtrans_frame(w, h, seed=w + h, noise=1200)
+    got = run(gpu_ctx, raw, passes, lab)
+    ref = O.xtrans_demosaic(raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, passes, lab)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+
+
 @pytest.mark.parametrize("passes,lab", [(1, False), (2, True)])
 def test_xtrans_more_tiles_than_workgroups(gpu_ctx, passes, lab):
     """25 x 24 tiles for 512 workgroups: some walk two tiles, with the LDS buffer and the arena as the first tile left them"""
