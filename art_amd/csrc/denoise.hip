@@ -581,27 +581,53 @@ __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
     float reclen = 0.f;
     for (int c0 = 0; c0 < W; c0 += HB_COLS) {
         // window columns [c0 - rad - 1, c0 + HB_COLS + rad): coalesced row segments -> LDS,
-        // 8 rows (16 independent loads) in flight per lane before the LDS stores
+        // 8 rows (16 independent loads) in flight per lane before the LDS stores.  After the first chunk the 2 * rad + 1 columns the
+        // next window shares with this one are moved inside LDS and only the HB_COLS new columns are read (the re-read was a third of
+        // this kernel's traffic).
         const int wc0 = c0 - rad - 1, wn = HB_COLS + 2 * rad + 1;
-        const int colA = wc0 + lane, colB = wc0 + lane + 64, colC = wc0 + lane + 128;
-        const bool okA = colA >= 0 && colA < W, okB = (lane + 64 < wn) && colB >= 0 && colB < W;
-        const bool okC = HB_MAXR > 31 && (lane + 128 < wn) && colC >= 0 && colC < W;
-        for (int k0 = 0; k0 < HB_ROWS; k0 += 8) {
-            float va[8], vb[8], vc[8];
+        if (c0 == 0) {
+            const int colA = wc0 + lane, colB = wc0 + lane + 64, colC = wc0 + lane + 128;
+            const bool okA = colA >= 0 && colA < W, okB = (lane + 64 < wn) && colB >= 0 && colB < W;
+            const bool okC = HB_MAXR > 31 && (lane + 128 < wn) && colC >= 0 && colC < W;
+            for (int k0 = 0; k0 < HB_ROWS; k0 += 8) {
+                float va[8], vb[8], vc[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k = k0 + i;
-                const size_t ro = (size_t)(r0 + k) * W;
-                va[i] = (okA && k < nrows) ? src[ro + colA] : 0.f;
-                vb[i] = (okB && k < nrows) ? src[ro + colB] : 0.f;
-                if constexpr (HB_MAXR > 31) vc[i] = (okC && k < nrows) ? src[ro + colC] : 0.f;
+                for (int i = 0; i < 8; ++i) {
+                    const int k = k0 + i;
+                    const size_t ro = (size_t)(r0 + k) * W;
+                    va[i] = (okA && k < nrows) ? src[ro + colA] : 0.f;
+                    vb[i] = (okB && k < nrows) ? src[ro + colB] : 0.f;
+                    if constexpr (HB_MAXR > 31) vc[i] = (okC && k < nrows) ? src[ro + colC] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    sT[k0 + i][lane] = va[i];
+                    if (lane + 64 < wn) sT[k0 + i][lane + 64] = vb[i];
+                    if constexpr (HB_MAXR > 31) { if (lane + 128 < wn) sT[k0 + i][lane + 128] = vc[i]; }
+                }
+            }
+        } else {
+            // the new columns first (their loads fly while the overlap moves)
+            const int colN = c0 + rad + lane;                       // window index 2 * rad + 1 + lane
+            const bool okN = colN < W;
+            float vn[HB_ROWS];
+#pragma unroll
+            for (int k = 0; k < HB_ROWS; ++k) vn[k] = (okN && k < nrows) ? src[(size_t)(r0 + k) * W + colN] : 0.f;
+            const int nov = 2 * rad + 1;                            // <= 2 * HB_MAXR + 1 columns per row
+            constexpr int NMV = (HB_ROWS * (2 * HB_MAXR + 1) + 63) / 64;
+            float mv[NMV];
+#pragma unroll
+            for (int q = 0; q < NMV; ++q) {
+                const int e = lane + 64 * q, k = e / nov, x = e - k * nov;
+                mv[q] = k < HB_ROWS ? sT[k][x + HB_COLS] : 0.f;
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                sT[k0 + i][lane] = va[i];
-                if (lane + 64 < wn) sT[k0 + i][lane + 64] = vb[i];
-                if constexpr (HB_MAXR > 31) { if (lane + 128 < wn) sT[k0 + i][lane + 128] = vc[i]; }
+            for (int q = 0; q < NMV; ++q) {
+                const int e = lane + 64 * q, k = e / nov, x = e - k * nov;
+                if (k < HB_ROWS) sT[k][x] = mv[q];
             }
+#pragma unroll
+            for (int k = 0; k < HB_ROWS; ++k) sT[k][nov + lane] = vn[k];
         }
         __syncthreads();
         const int cend = min(HB_COLS, W - c0);
