@@ -63,6 +63,8 @@ struct artgpu_ctx {
     double curve_tail_y = 1.0;
     float *lut = nullptr; // 65536-entry tone LUT on the device
     size_t lut_bytes = 0;
+    std::vector<float> lut_host;           // what ctx->lut holds (a curve that comes back unchanged is not uploaded again)
+    std::vector<float> ncurve_host;        // likewise the 501-entry chroma noise curve behind the cachef table
     // timing
     bool timing = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -698,6 +700,20 @@ int artgpu_exposure(artgpu_ctx *ctx, artgpu_rgb *image, float exp_scale, float b
     return unbind_rgb(ctx, image, &d);
 }
 
+// the 65536-entry curve of a tone-curve call -> ctx->lut.  The same curve frame after frame (a batch) is uploaded once: a copy from
+// pageable host memory stalls the stream and the enqueueing thread for ~60 us each time.
+static int upload_curve(artgpu_ctx *ctx, const float *lut65536)
+{
+    int rc = ensure(ctx, &ctx->lut, &ctx->lut_bytes, 65536 * sizeof(float));
+    if (rc) return rc;
+    if (ctx->lut_host.size() == 65536 && std::memcmp(ctx->lut_host.data(), lut65536, 65536 * sizeof(float)) == 0) return ARTGPU_OK;
+    ctx->lut_host.assign(lut65536, lut65536 + 65536);
+    // from the context's own copy: the caller's array may change as soon as this call returns
+    HIPCHK(ctx, hipMemcpyAsync(ctx->lut, ctx->lut_host.data(), 65536 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
 int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float *lut65536, float whitept, int filmlike_clip)
 {
     StageScope scope_(ctx, "ImProcFunctions::toneCurve");
@@ -717,9 +733,7 @@ int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float 
     a.do_clip = filmlike_clip ? 1 : 0; a.whitept = whitept;
     a.tail_kind = ctx->curve_tail_kind == ARTGPU_CURVE_TAIL_HOST ? 0 : ctx->curve_tail_kind; a.tail_y = ctx->curve_tail_y;
     if (lut65536) {
-        rc = ensure(ctx, &ctx->lut, &ctx->lut_bytes, 65536 * sizeof(float));
-        if (rc) return rc;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->lut, lut65536, 65536 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = upload_curve(ctx, lut65536))) return rc;
         a.lut = ctx->lut;
     }
     HIPCHK(ctx, launch_tone_std(a, ctx->stream));
@@ -887,7 +901,7 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_BATCH, P_NSLOTS };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_BATCH, P_DCTTAB, P_NSLOTS };
 static_assert(P_NSLOTS <= artgpu_ctx::NPOOL, "grow artgpu_ctx::pool");
 
 struct DevDecomp {
@@ -1180,9 +1194,12 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
             da.detail_lo = compute_detail(0.f);
             { const int br = int(3 / scale); da.blur_rad = br > 1 ? br : 1; }
             float *dtab;
-            if ((rc = pool_get(ctx, P_DTAB, 4 * 4096 * 4, &dtab))) return rc;
+            // the tables are constants: built and uploaded once per context (a slot of their own: the upload needs a stream
+            // synchronisation, i.e. a bubble in the middle of every frame)
+            const bool fresh_dtab = ctx->pool[P_DCTTAB] == nullptr;
+            if ((rc = pool_get(ctx, P_DCTTAB, 4 * 4096 * 4, &dtab))) return rc;
             if ((rc = pool_get(ctx, P_BLOCKS, (size_t)da.numblox_W * da.numblox_H * 4096 * 4, &da.blocks))) return rc;
-            {
+            if (fresh_dtab) {
                 std::vector<float> host(4 * 4096);
                 float *tm_in = host.data(), *tm_out = tm_in + 4096, *ct = tm_out + 4096, *ctt = ct + 4096;
                 const float epsilon = 0.001f / (64 * 64);
@@ -1894,9 +1911,7 @@ int artgpu_tone_curve_neutral(artgpu_ctx *ctx, artgpu_rgb *image, const float *l
         HIPCHK(ctx, hipMemcpyAsync(pq, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     }
-    rc = ensure(ctx, &ctx->lut, &ctx->lut_bytes, 65536 * sizeof(float));
-    if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->lut, lut65536, 65536 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = upload_curve(ctx, lut65536))) return rc;
     NeutralArgs a = {};
     for (int k = 0; k < 3; ++k) a.img[k] = d.p[k];
     a.stride = d.stride; a.w = d.w; a.h = d.h;
@@ -1935,8 +1950,13 @@ static int chroma_map_dev(artgpu_ctx *ctx, float *const planes[3], size_t stride
         HIPCHK(ctx, hipMemcpyAsync(tab, host.data(), 65536 * 4, hipMemcpyHostToDevice, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host vector goes out of scope
     }
-    HIPCHK(ctx, hipMemcpyAsync(tab + 65536, curve, 501 * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));       // caller's curve may be a temporary
+    // the same curve frame after frame is uploaded once: the copy needs a stream synchronisation (the caller's curve may be a
+    // temporary), i.e. a bubble in the middle of every frame
+    if (fresh || ctx->ncurve_host.size() != 501 || std::memcmp(ctx->ncurve_host.data(), curve, 501 * 4) != 0) {
+        ctx->ncurve_host.assign(curve, curve + 501);
+        HIPCHK(ctx, hipMemcpyAsync(tab + 65536, ctx->ncurve_host.data(), 501 * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ChromaMapArgs a = {};
     for (int k = 0; k < 3; ++k) a.src[k] = planes[k];
     a.stride = stride; a.wid = wid; a.hei = hei;
