@@ -278,12 +278,7 @@ st_p7(lds, a, 2 * T - 14 - a.gbase, lane);
 hipError_t launch_amaze_stream(const AmazeStreamArgs &s, int grid, hipStream_t stream)
 {
     constexpr size_t dyn = (size_t)amz::LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&amaze_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = dyn_lds_once(reinterpret_cast<const void *>(&amaze_stream_kernel), (int)dyn); e != hipSuccess) return e;
     hipLaunchKernelGGL(amaze_stream_kernel, dim3(grid), dim3(amz::NTHREADS), dyn, stream, s);
     return hipGetLastError();
 }

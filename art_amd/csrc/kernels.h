@@ -5,6 +5,25 @@
 #include <vector>
 #include <stddef.h>
 #include <stdint.h>
+#include <mutex>
+#include <set>
+#include <utility>
+
+// Kernels that need more than 64 KB of dynamic LDS raise the limit once per (kernel, device): the attribute belongs to the device's copy
+// of the function, and a host application may hold contexts on several devices and threads.
+inline hipError_t dyn_lds_once(const void *fn, int bytes)
+{
+    static std::mutex m;
+    static std::set<std::pair<const void *, int>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(m);
+    if (done.count({fn, dev})) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.insert({fn, dev});
+    return e;
+}
 
 namespace artgpu {
 

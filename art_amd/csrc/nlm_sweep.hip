@@ -291,12 +291,7 @@ hipError_t launch_nlm_group(const NlmArgs &a, hipStream_t s)
 {
     constexpr size_t dyn = (size_t)G_LDS_FLOATS * sizeof(float);
     static_assert(dyn <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&nlm_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = dyn_lds_once(reinterpret_cast<const void *>(&nlm_group_kernel), (int)dyn); e != hipSuccess) return e;
     hipLaunchKernelGGL(nlm_group_kernel, dim3(a.ntiles_x * a.ntiles_y), dim3(G_NT), dyn, s, a);
     return hipGetLastError();
 }

@@ -362,13 +362,8 @@ hipError_t launch_gaussian(const GaussArgs &a, hipStream_t s)
     // gaussHorizontalSse filters H - H % 4 rows with float coefficients and the rest with double ones (gauss.cc:1163-1225);
     // gaussVerticalSse W - W % 8 columns (gauss.cc:716-856)
     const int fh = a.H - a.H % 4, fv = a.W - a.W % 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gauss_stream_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gauss_stream_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GS_LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = dyn_lds_once(reinterpret_cast<const void *>(&gauss_stream_kernel<true>), GS_LDS_BYTES); e != hipSuccess) return e;
+    if (hipError_t e = dyn_lds_once(reinterpret_cast<const void *>(&gauss_stream_kernel<false>), GS_LDS_BYTES); e != hipSuccess) return e;
     hipLaunchKernelGGL(gauss_stream_kernel<true>, dim3((fh + 63) / 64 + (fh < a.H ? 1 : 0)), dim3(GS_NT), GS_LDS_BYTES, s, a, fh);
     hipLaunchKernelGGL(gauss_stream_kernel<false>, dim3((fv + 63) / 64 + (fv < a.W ? 1 : 0)), dim3(GS_NT), GS_LDS_BYTES, s, a, fv);
     return hipGetLastError();

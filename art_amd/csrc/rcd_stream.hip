@@ -71,12 +71,7 @@ template <int R>
 hipError_t launch_r(const RcdStreamArgs &a, int grid, hipStream_t stream)
 {
     constexpr size_t dyn = (size_t)rcs::Cfg<R>::LDS_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&rcd_stream_kernel<R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = dyn_lds_once(reinterpret_cast<const void *>(&rcd_stream_kernel<R>), (int)dyn); e != hipSuccess) return e;
     hipLaunchKernelGGL(rcd_stream_kernel<R>, dim3(grid), dim3(rcs::Cfg<R>::NT), dyn, stream, a);
     return hipGetLastError();
 }

@@ -574,12 +574,7 @@ __global__ void __launch_bounds__(256) xtrans_border_kernel(XtransArgs a)
 
 hipError_t launch_xtrans(const XtransArgs &a, int grid, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&xtrans_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, XT_LDS_FLOATS * 4);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = dyn_lds_once(reinterpret_cast<const void *>(&xtrans_tiles_kernel), XT_LDS_FLOATS * 4); e != hipSuccess) return e;
     hipLaunchKernelGGL(xtrans_tiles_kernel, dim3(grid), dim3(XTRANS_THREADS), XT_LDS_FLOATS * 4, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
