@@ -120,6 +120,8 @@ __device__ __forceinline__ void gs_lds_barrier()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+// s_waitcnt immediate of gfx9 that waits for vmcnt <= n only (vmcnt is bits [3:0] and [15:14]; expcnt [6:4] and lgkmcnt [11:8] left at their maxima)
+constexpr int gs_vmcnt(int n) { return 0x0f70 | (n & 15) | ((n >> 4) << 14); }
 // position of step s of chunk k along the line
 __device__ __forceinline__ int gs_pos(bool fwd, int n, int k, int s) { return fwd ? k * GS_CH + s : n - 1 - k * GS_CH - s; }
 
@@ -170,13 +172,13 @@ __device__ __forceinline__ void gauss_stream_group(const GaussArgs &a, int line0
         if (loader) {
 #pragma unroll
             for (int k = 0; k < GS_AHEAD; ++k) fetch(k);
-            __builtin_amdgcn_s_waitcnt(0x0f70 | (((GS_AHEAD - 1) * GS_LPER) & 15) | ((((GS_AHEAD - 1) * GS_LPER) >> 4) << 14));   // chunk 0 has landed
+            __builtin_amdgcn_s_waitcnt(gs_vmcnt((GS_AHEAD - 1) * GS_LPER));   // chunk 0 has landed
         }
         gs_lds_barrier();
         for (int i = 0; i <= nchunks; ++i) {
             if (loader) {
                 // chunk i + 1 has landed when at most the GS_AHEAD - 2 younger chunks are outstanding; then chunk i + GS_AHEAD goes out
-                __builtin_amdgcn_s_waitcnt(0x0f70 | (((GS_AHEAD - 2) * GS_LPER) & 15) | ((((GS_AHEAD - 2) * GS_LPER) >> 4) << 14));
+                __builtin_amdgcn_s_waitcnt(gs_vmcnt((GS_AHEAD - 2) * GS_LPER));
                 fetch(i + GS_AHEAD);
             } else if (storer) {
                 if (i >= 1) drain(i - 1);
