@@ -271,33 +271,50 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
         };
 
         for (int k = 0; k < 4; k++) {
-            // ---- CFA samples, green interpolated along direction k at the non-green sites (L410-475)
-            FOR_T(TS * TS) {
-                const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
-                float base[3] = {0.f, 0.f, 0.f};
-                float g = 0.f;
-                bool interp = false;
-                if (row < mrow && col < mcol) {
-                    const int f = G.fcol(row, col);
-                    const float *pix = a.raw + (size_t)row * rs + col;
-                    base[f] = pix[0];
-                    if (!(f & 1)) {
-                        interp = true;
-                        const auto hex = T->allhex0[row % 3][col % 3];
-                        const int flip = T->right_shift[row % 3] ? 0 : 1;
-                        const int j = k ^ flip;                         // gdir[j ^ flip] = color[j]: buffer k holds colour k ^ flip
-                        float color;
-                        if (j == 0) color = 0.6796875f * (pix[hex[1]] + pix[hex[0]]) - 0.1796875f * (pix[2 * hex[1]] + pix[2 * hex[0]]);
-                        else if (j == 1) color = 0.87109375f * pix[hex[3]] + pix[hex[2]] * 0.12890625f + 0.359375f * (pix[0] - pix[-hex[2]]);
-                        else {
-                            const int h = hex[2 + j];
-                            color = 0.640625f * pix[h] + 0.359375f * pix[-2 * h] + 0.12890625f * (2.f * pix[0] - pix[3 * h] - pix[-3 * h]);
-                        }
-                        const float *s = gmm + ((size_t)r * TSH + (c >> 1)) * 2;
-                        g = limf(color, s[0], s[1]);
+            // ---- CFA samples, green interpolated along direction k at the non-green sites (L410-475).  Four pixels per thread and
+            // iteration with their loads first (the sample, four neighbours along the hexagon entry buffer k takes, greenminmax): one pixel
+            // at a time is a chain of global round trips per iteration.  Buffer k holds colour j = k ^ flip (gdir[j ^ flip] = color[j]):
+            //   j = 0: 0.68 (p[h1] + p[h0]) - 0.18 (p[2 h1] + p[2 h0]);  j = 1: 0.87 p[h3] + 0.13 p[h2] + 0.36 (p[0] - p[-h2]);
+            //   j >= 2, h = hex[2 + j]: 0.64 p[h] + 0.36 p[-2 h] + 0.13 (2 p[0] - p[3 h] - p[-3 h])
+            for (int t0 = tid; t0 < TS * TS; t0 += 4 * NT) {
+                float cen[4], nb[4][4], lo[4], hi[4];
+                int fq[4], jq[4];
+                bool inq[4], itq[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = min(t0 + u * NT, TS * TS - 1);
+                    const int r = t / TS, c = t - r * TS, row = top + r, col = left + c;
+                    const bool in = row < mrow && col < mcol;
+                    const int rowc = in ? row : top, colc = in ? col : left;       // a pixel outside the frame reads the tile's first one (unused)
+                    const int f = G.fcol(rowc, colc);
+                    const bool it = in && !(f & 1);
+                    const auto hex = T->allhex0[rowc % 3][colc % 3];
+                    const int flip = T->right_shift[rowc % 3] ? 0 : 1;
+                    const int j = k ^ flip;
+                    int o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+                    if (it) {
+                        if (j == 0) { o0 = hex[1]; o1 = hex[0]; o2 = 2 * hex[1]; o3 = 2 * hex[0]; }
+                        else if (j == 1) { o0 = hex[3]; o1 = hex[2]; o2 = -hex[2]; }
+                        else { const int h = hex[2 + j]; o0 = h; o1 = -2 * h; o2 = 3 * h; o3 = -3 * h; }
                     }
+                    const float *pix = a.raw + (size_t)rowc * rs + colc;
+                    cen[u] = pix[0]; nb[u][0] = pix[o0]; nb[u][1] = pix[o1]; nb[u][2] = pix[o2]; nb[u][3] = pix[o3];
+                    const float *sm = gmm + ((size_t)r * TSH + (c >> 1)) * 2;
+                    lo[u] = sm[0]; hi[u] = sm[1];
+                    fq[u] = f; jq[u] = j; inq[u] = in; itq[u] = it;
                 }
-                L[t] = base[0]; L[PL + t] = interp ? g : base[1]; L[2 * PL + t] = base[2];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int t = t0 + u * NT;
+                    if (t >= TS * TS) break;
+                    float base[3] = {0.f, 0.f, 0.f};
+                    if (inq[u]) base[fq[u]] = cen[u];
+                    float color;
+                    if (jq[u] == 0) color = 0.6796875f * (nb[u][0] + nb[u][1]) - 0.1796875f * (nb[u][2] + nb[u][3]);
+                    else if (jq[u] == 1) color = 0.87109375f * nb[u][0] + nb[u][1] * 0.12890625f + 0.359375f * (cen[u] - nb[u][2]);
+                    else color = 0.640625f * nb[u][0] + 0.359375f * nb[u][1] + 0.12890625f * (2.f * cen[u] - nb[u][2] - nb[u][3]);
+                    L[t] = base[0]; L[PL + t] = itq[u] ? limf(color, lo[u], hi[u]) : base[1]; L[2 * PL + t] = base[2];
+                }
             }
             xt_lds_barrier();
 
