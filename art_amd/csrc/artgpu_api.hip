@@ -23,6 +23,11 @@ struct artgpu_ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;      // second stream (serial statistics of the AUTOMATIC chroma estimation run beside the decompositions)
     hipEvent_t aux_ev[2] = {nullptr, nullptr};
+    // RGB_denoise: the a and b chroma chains run beside the L chain on streams of their own (they share nothing but the untouched L bands)
+    hipStream_t dn_stream[2] = {nullptr, nullptr};
+    hipEvent_t dn_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int opt_lut_lds = 1;           // 0: never the LUT-in-LDS shapes of the pixel passes (tests compare the two)
+    int opt_dn_streams = 1;        // 0: the whole chain on the context's stream, one kernel after the other
     std::string err;
     // per-workgroup work arenas (demosaic)
     float *arena = nullptr;
@@ -32,7 +37,7 @@ struct artgpu_ctx {
     float *stage[NSTAGE] = {};
     size_t stage_bytes[NSTAGE] = {};
     // grow-only scratch pool for the denoise path (planes, decompositions, shrink buffers)
-    static constexpr int NPOOL = 32;
+    static constexpr int NPOOL = 48;
     float *pool[NPOOL] = {};
     size_t pool_bytes[NPOOL] = {};
     // artgpu_batch_run lanes: sibling contexts (own stream, arena, pools) that take every lanes-th frame on their own host thread
@@ -65,6 +70,7 @@ struct artgpu_ctx {
     size_t lut_bytes = 0;
     std::vector<float> lut_host;           // what ctx->lut holds (a curve that comes back unchanged is not uploaded again)
     std::vector<float> ncurve_host;        // likewise the 501-entry chroma noise curve behind the cachef table
+    std::vector<float> rgbcurve_host[3];   // likewise the three rgbCurves tables (P_PIPE_R)
     // timing
     bool timing = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -101,6 +107,21 @@ int ensure(artgpu_ctx *ctx, float **buf, size_t *cur, size_t need)
         return fail(ctx, ARTGPU_ENOMEM, "hipMalloc(%zu bytes) failed: %s", need, hipGetErrorString(e));
     }
     *cur = need;
+    return ARTGPU_OK;
+}
+
+// A caller's look-up table -> device memory, one lifetime rule for all of them (artgpu.h "Host look-up tables"): the array is free when
+// the entry point returns.  A copy from pageable memory has been staged by then; a pinned / registered array is read by the DMA engine
+// when the stream gets there, so the stream is drained for those.
+int h2d_table(artgpu_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, src) == hipSuccess) {
+        if (at.type == hipMemoryTypeHost) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        (void)hipGetLastError();      // an ordinary malloc'ed array is "invalid value" to the query: pageable
+    }
     return ARTGPU_OK;
 }
 
@@ -280,6 +301,10 @@ int artgpu_destroy(artgpu_ctx *ctx)
     for (int k = 0; k < 2; ++k)
         if (ctx->aux_ev[k]) (void)hipEventDestroy(ctx->aux_ev[k]);
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+    for (int k = 0; k < 6; ++k)
+        if (ctx->dn_ev[k]) (void)hipEventDestroy(ctx->dn_ev[k]);
+    for (int k = 0; k < 2; ++k)
+        if (ctx->dn_stream[k]) { (void)hipStreamSynchronize(ctx->dn_stream[k]); (void)hipStreamDestroy(ctx->dn_stream[k]); }
     delete ctx;
     return ARTGPU_OK;
 }
@@ -339,6 +364,8 @@ int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value)
     else if (n == "amaze_zero_frame") ctx->opt_amaze_zero_frame = (int)value;
     else if (n == "amaze_poison") ctx->opt_amaze_poison = (int)value;
     else if (n == "roctx") ctx->opt_roctx = value != 0;
+    else if (n == "dn_streams") ctx->opt_dn_streams = value != 0;
+    else if (n == "lut_lds") ctx->opt_lut_lds = value != 0;
     else if (n == "rcd_rows") { if (value != 4 && value != 8) return fail(ctx, ARTGPU_EINVAL, "rcd_rows: 4 or 8"); ctx->opt_rcd_rows = (int)value; }
     else return fail(ctx, ARTGPU_EINVAL, "set_option: unknown option '%s'", name);
     return ARTGPU_OK;
@@ -709,8 +736,12 @@ static int upload_curve(artgpu_ctx *ctx, const float *lut65536)
     if (ctx->lut_host.size() == 65536 && std::memcmp(ctx->lut_host.data(), lut65536, 65536 * sizeof(float)) == 0) return ARTGPU_OK;
     ctx->lut_host.assign(lut65536, lut65536 + 65536);
     // from the context's own copy: the caller's array may change as soon as this call returns
-    HIPCHK(ctx, hipMemcpyAsync(ctx->lut, ctx->lut_host.data(), 65536 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    hipError_t e = hipMemcpyAsync(ctx->lut, ctx->lut_host.data(), 65536 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        ctx->lut_host.clear();      // the cache only describes ctx->lut after a copy that succeeded
+        return fail(ctx, ARTGPU_EHIP, "tone curve upload failed: %s", hipGetErrorString(e));
+    }
     return ARTGPU_OK;
 }
 
@@ -736,6 +767,7 @@ int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float 
         if ((rc = upload_curve(ctx, lut65536))) return rc;
         a.lut = ctx->lut;
     }
+    a.no_lds_lut = !ctx->opt_lut_lds;
     HIPCHK(ctx, launch_tone_std(a, ctx->stream));
     return unbind_rgb(ctx, image, &d);
 }
@@ -901,7 +933,7 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_BATCH, P_DCTTAB, P_NSLOTS };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_BATCH, P_DCTTAB, P_CBANDS2, P_CLOW0_2, P_CLOW1_2, P_SF_A, P_TMP_A, P_SF_B, P_TMP_B, P_HISTO_A, P_HISTO_B, P_NSLOTS };
 static_assert(P_NSLOTS <= artgpu_ctx::NPOOL, "grow artgpu_ctx::pool");
 
 struct DevDecomp {
@@ -911,38 +943,40 @@ struct DevDecomp {
     float *band(int l, int dir) const { return bands + ((size_t)l * 3 + (dir - 1)) * n; }
 };
 
-int decompose_dev(artgpu_ctx *ctx, DevDecomp &d, const float *src)
+int decompose_dev(artgpu_ctx *ctx, DevDecomp &d, const float *src, hipStream_t st = nullptr)
 {
+    if (!st) st = ctx->stream;
     WaveArgs a = {};
     a.w = d.w; a.h = d.h; a.w2 = d.w2; a.h2 = d.h2;
     for (int l = 0; l < d.nlevels; ++l) {
         a.b1 = d.band(l, 1); a.b2 = d.band(l, 2); a.b3 = d.band(l, 3);
         if (l == 0) {
             a.src = src; a.src_stride = d.w; a.lo = d.low[0]; d.cur = 0;
-            HIPCHK(ctx, launch_wavelet_analysis0(a, ctx->stream));
+            HIPCHK(ctx, launch_wavelet_analysis0(a, st));
         } else {
             a.src = d.low[d.cur]; a.lo = d.low[d.cur ^ 1]; a.skip = wavelet_skip(l);
-            HIPCHK(ctx, launch_wavelet_haar_analysis(a, ctx->stream));
+            HIPCHK(ctx, launch_wavelet_haar_analysis(a, st));
             d.cur ^= 1;
         }
     }
     return ARTGPU_OK;
 }
 
-int reconstruct_dev(artgpu_ctx *ctx, DevDecomp &d, float *dst)
+int reconstruct_dev(artgpu_ctx *ctx, DevDecomp &d, float *dst, hipStream_t st = nullptr)
 {
+    if (!st) st = ctx->stream;
     WaveArgs a = {};
     a.w = d.w; a.h = d.h; a.w2 = d.w2; a.h2 = d.h2; a.blend = 1.f;
     for (int l = d.nlevels - 1; l > 0; --l) {
         a.src = d.low[d.cur]; a.lo = d.low[d.cur ^ 1];
         a.b1 = d.band(l, 1); a.b2 = d.band(l, 2); a.b3 = d.band(l, 3); a.skip = wavelet_skip(l);
-        HIPCHK(ctx, launch_wavelet_haar_synthesis(a, ctx->stream));
+        HIPCHK(ctx, launch_wavelet_haar_synthesis(a, st));
         d.cur ^= 1;
     }
     a.src = d.low[d.cur];
     a.b1 = d.band(0, 1); a.b2 = d.band(0, 2); a.b3 = d.band(0, 3);
     a.dst = dst; a.dst_stride = d.w;
-    HIPCHK(ctx, launch_wavelet_synthesis0(a, ctx->stream));
+    HIPCHK(ctx, launch_wavelet_synthesis0(a, st));
     return ARTGPU_OK;
 }
 
@@ -1040,19 +1074,25 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     const int nsub = 3 * levwav;
     bool autoch = p->chrominance_method == 1;
 
-    // ---- device buffers
-    float *L, *A, *B, *sf, *tmp, *gamlut, *mad, *histo_f, *ccalc_dev = nullptr;
-    DevDecomp Ld = {}, Cd = {};
-    Ld.w = Cd.w = w; Ld.h = Cd.h = h; Ld.w2 = Cd.w2 = w2; Ld.h2 = Cd.h2 = h2; Ld.n = Cd.n = n2; Ld.nlevels = Cd.nlevels = levwav;
+    // ---- device buffers.  The three channels have their own shrink scratch and the two chroma channels their own decomposition, so that
+    // the a and b chains can run beside the L chain (below); nothing is allocated in steady state.
+    float *L, *A, *B, *gamlut, *mad, *ccalc_dev = nullptr;
+    float *sfc[3], *tmpc[3], *histo_fc[3];          // 0: L, 1: a, 2: b
+    DevDecomp Ld = {}, Cdd[2] = {};
+    Ld.w = w; Ld.h = h; Ld.w2 = w2; Ld.h2 = h2; Ld.n = n2; Ld.nlevels = levwav;
+    Cdd[0] = Cdd[1] = Ld;
+    const size_t histo_bytes = (size_t)nsub * (65536 + MAD_SCRATCH_INTS_PER_BAND) * 4;
     if ((rc = pool_get(ctx, P_L, n * 4, &L)) || (rc = pool_get(ctx, P_A, n * 4, &A)) || (rc = pool_get(ctx, P_B, n * 4, &B)) ||
         (rc = pool_get(ctx, P_LBANDS, (size_t)nsub * n2 * 4, &Ld.bands)) || (rc = pool_get(ctx, P_LLOW0, n2 * 4, &Ld.low[0])) || (rc = pool_get(ctx, P_LLOW1, n2 * 4, &Ld.low[1])) ||
-        (rc = pool_get(ctx, P_CBANDS, (size_t)nsub * n2 * 4, &Cd.bands)) || (rc = pool_get(ctx, P_CLOW0, n2 * 4, &Cd.low[0])) || (rc = pool_get(ctx, P_CLOW1, n2 * 4, &Cd.low[1])) ||
-        (rc = pool_get(ctx, P_SF, (size_t)nsub * n2 * 4, &sf)) || (rc = pool_get(ctx, P_TMP, (size_t)nsub * n2 * 4, &tmp)) ||
-        (rc = pool_get(ctx, P_HISTO, (size_t)nsub * (65536 + MAD_SCRATCH_INTS_PER_BAND) * 4, &histo_f)) || (rc = pool_get(ctx, P_MAD, 3 * 32 * 4, &mad)) ||
-        (rc = pool_get(ctx, P_GAM, 2 * 65536 * 4, &gamlut)))
+        (rc = pool_get(ctx, P_CBANDS, (size_t)nsub * n2 * 4, &Cdd[0].bands)) || (rc = pool_get(ctx, P_CLOW0, n2 * 4, &Cdd[0].low[0])) || (rc = pool_get(ctx, P_CLOW1, n2 * 4, &Cdd[0].low[1])) ||
+        (rc = pool_get(ctx, P_CBANDS2, (size_t)nsub * n2 * 4, &Cdd[1].bands)) || (rc = pool_get(ctx, P_CLOW0_2, n2 * 4, &Cdd[1].low[0])) || (rc = pool_get(ctx, P_CLOW1_2, n2 * 4, &Cdd[1].low[1])) ||
+        (rc = pool_get(ctx, P_SF, (size_t)nsub * n2 * 4, &sfc[0])) || (rc = pool_get(ctx, P_TMP, (size_t)nsub * n2 * 4, &tmpc[0])) ||
+        (rc = pool_get(ctx, P_SF_A, (size_t)nsub * n2 * 4, &sfc[1])) || (rc = pool_get(ctx, P_TMP_A, (size_t)nsub * n2 * 4, &tmpc[1])) ||
+        (rc = pool_get(ctx, P_SF_B, (size_t)nsub * n2 * 4, &sfc[2])) || (rc = pool_get(ctx, P_TMP_B, (size_t)nsub * n2 * 4, &tmpc[2])) ||
+        (rc = pool_get(ctx, P_HISTO, histo_bytes, &histo_fc[0])) || (rc = pool_get(ctx, P_HISTO_A, histo_bytes, &histo_fc[1])) || (rc = pool_get(ctx, P_HISTO_B, histo_bytes, &histo_fc[2])) ||
+        (rc = pool_get(ctx, P_MAD, 3 * 32 * 4, &mad)) || (rc = pool_get(ctx, P_GAM, 2 * 65536 * 4, &gamlut)))
         return rc;
-    int *histo = reinterpret_cast<int *>(histo_f);
-    float *madL = mad, *madab = mad + 32;
+    float *madL = mad;
     if (useNoiseCCurve) {
         if (!plane_ok(ccalc) || ccalc->w != w2 || ccalc->h != h2) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: ccalc must be %dx%d", w2, h2);
         if ((rc = pool_get(ctx, P_CCALC, n2 * 4, &ccalc_dev))) return rc;
@@ -1060,9 +1100,21 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
                                      ccalc->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     }
 
+    // ---- streams.  The reference runs a, then b, then L (L2328-2438).  The chains only meet in the untouched L coefficients and their MADs
+    // (read by the chroma shrink factors) and in yuv2rgb, so their order is free.  With "dn_streams" the DCT detail recovery of L -- bound by
+    // instruction issue, it leaves HBM idle -- runs on a side stream beside the box blurs and reconstructions of a and b, which are bound by
+    // HBM: L goes first for that, after the chroma shrink factors have read its coefficients.  Same kernels on the same data: the same bits.
+    // (Running all three chains side by side was measured too: 9.7 ms against 9.2 -- three HBM-bound chains only get in each other's way.)
+    const bool fork = ctx->opt_dn_streams != 0 && do_detail && denoiseLuminance;
+    if (fork && !ctx->dn_stream[0]) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->dn_stream[0], hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->dn_ev[k], hipEventDisableTiming));
+    }
+    hipStream_t sL = ctx->stream;
+
     // ---- gamma LUTs (built on the device with the SSE-form sleef, color.cc:1128-1161)
-    HIPCHK(ctx, launch_gamma_lut(gamlut, gam, gamthresh, gamslope, 65535.f, 65535.f, ctx->stream));
-    HIPCHK(ctx, launch_gamma_lut(gamlut + 65536, igam, igamthresh, igamslope, 65535.f, 65535.f, ctx->stream));
+    HIPCHK(ctx, launch_gamma_lut(gamlut, gam, gamthresh, gamslope, 65535.f, 65535.f, sL));
+    HIPCHK(ctx, launch_gamma_lut(gamlut + 65536, igam, igamthresh, igamslope, 65535.f, 65535.f, sL));
 
     DnPixArgs px = {};
     for (int k = 0; k < 3; ++k) { px.rgb[k] = d.p[k]; px.ws1[k] = ws[3 + k]; }
@@ -1070,7 +1122,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     px.gain = gain; px.newGain = 1.f / gain;
     px.gam = gam; px.gamthresh = gamthresh; px.gamslope = gamslope; px.igam = igam; px.igamthresh = igamthresh; px.igamslope = igamslope;
     px.gamcurve = gamlut; px.igamcurve = gamlut + 65536;
-    px.pre_scale = ctx->fuse_pre; px.post_scale = ctx->fuse_post;
+    px.pre_scale = ctx->fuse_pre; px.post_scale = ctx->fuse_post; px.no_lds_lut = !ctx->opt_lut_lds;
     // the inverse-gamma pass looks up gamma-encoded values: the mid-tones sit in the middle of the table, so the 40704 entries kept in LDS
     // start at 8000 (gamma 1.7: linear 0.03 .. 0.60 of white); the forward pass and the tone curve index with linear data and keep [0, 40704)
     px.igam_lds_lo = 8000;
@@ -1083,68 +1135,87 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
             std::vector<float> host(4 * 65536);
             build_cachef(host.data()); build_cachefy(host.data() + 65536);
             build_denoise_gamma_tabs(host.data() + 2 * 65536, host.data() + 3 * 65536);
-            HIPCHK(ctx, hipMemcpyAsync(tabs, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            hipError_t e = hipMemcpyAsync(tabs, host.data(), host.size() * 4, hipMemcpyHostToDevice, sL);
+            if (e == hipSuccess) e = hipStreamSynchronize(sL);
+            if (e != hipSuccess) {     // the slot doubles as the "tables are there" flag: give it back, or the next call would skip the upload
+                (void)hipFree(ctx->pool[P_LABTABS]); ctx->pool[P_LABTABS] = nullptr; ctx->pool_bytes[P_LABTABS] = 0;
+                return fail(ctx, ARTGPU_EHIP, "rgb_denoise: upload of the Lab tables failed: %s", hipGetErrorString(e));
+            }
         }
         px.lab_mode = 1;
         px.cachef = tabs; px.cachefy = tabs + 65536; px.dn_gamma = tabs + 2 * 65536; px.dn_igamma = tabs + 3 * 65536;
         for (int k = 0; k < 9; ++k) { px.wpi[k] = ws[k]; px.iws[k] = iws[k]; }
     }
     px.realred = realred; px.realblue = realblue; px.qhighFactor = aggressive ? 1.f / static_cast<float>(0.9) : 1.0f;   // L1672
-    HIPCHK(ctx, launch_rgb2yuv(px, ctx->stream));
+    HIPCHK(ctx, launch_rgb2yuv(px, sL));
 
     // ---- L decomposition and its MADs (L2296-2320)
-    if ((rc = decompose_dev(ctx, Ld, L))) return rc;
-    HIPCHK(ctx, launch_mad(Ld.bands, n2, nsub, histo, madL, ctx->stream));
+    if ((rc = decompose_dev(ctx, Ld, L, sL))) return rc;
+    HIPCHK(ctx, launch_mad(Ld.bands, n2, nsub, reinterpret_cast<int *>(histo_fc[0]), madL, sL));
 
-    BlurArgs bl = {};
-    bl.n = n2; bl.w = w2; bl.h = h2;
-    for (int l = 0; l < levwav; ++l) { const int r = int((l + 2) / scale); bl.rad[l] = r > 1 ? r : 1; }
+    BlurArgs bl0 = {};
+    bl0.n = n2; bl0.w = w2; bl0.h = h2;
+    for (int l = 0; l < levwav; ++l) { const int r = int((l + 2) / scale); bl0.rad[l] = r > 1 ? r : 1; }
 
-    // ---- a then b: decompose, shrink against L, reconstruct (L2328-2402)
-    float chresidtemp = 0.f, chmaxresidtemp = 0.f;
-    for (int ch = 0; ch < 2; ++ch) {
-        float *plane = ch == 0 ? A : B;
+    // ---- a and b (L2328-2402), first half: decompose, MADs, shrink factors against the untouched L coefficients
+    float noisevar_abc[2];
+    auto chroma_front = [&](int ch) -> int {
+        DevDecomp &Cd = Cdd[ch];
+        float *sf = sfc[1 + ch], *tmp = tmpc[1 + ch], *madab = mad + 32 * (1 + ch);
+        int *histo = reinterpret_cast<int *>(histo_fc[1 + ch]);
         float noisevar_ab = ch == 0 ? noisevarab_r : noisevarab_b;
         if (autoch && noisevar_ab <= 0.001f) noisevar_ab = 0.02f;
-        if ((rc = decompose_dev(ctx, Cd, plane))) return rc;
+        noisevar_abc[ch] = noisevar_ab;
+        int rc2;
+        if ((rc2 = decompose_dev(ctx, Cd, ch == 0 ? A : B, sL))) return rc2;
         if (aggressive && noisevar_ab > 0.001f) {
             // WaveletDenoiseAll_BiShrinkAB (L976-1108): MAD of all untouched bands, ShrinkAllAB on the top level (same MAD),
             // point-wise shrink of the levels below
-            HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, madab, ctx->stream));
+            HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, madab, sL));
             ShrinkArgs sa = {};
             sa.n = n2; sa.noisevar = ccalc_dev; sa.noisevar_scale = maxNoiseVarab; sa.noisevar_ab = noisevar_ab; sa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
             const size_t top = (size_t)(nsub - 3) * n2;
             sa.coef = Cd.bands + top; sa.coefL = Ld.bands + top; sa.sfave = sf; sa.madL = madL + (nsub - 3); sa.madab = madab + (nsub - 3);
-            HIPCHK(ctx, launch_shrink_sf(sa, 3, true, ctx->stream));
-            BlurArgs bt = bl;
+            HIPCHK(ctx, launch_shrink_sf(sa, 3, true, sL));
+            BlurArgs bt = bl0;
             bt.level0 = levwav - 1;
             bt.src = sf; bt.dst = tmp;
-            HIPCHK(ctx, launch_hblur(bt, 3, ctx->stream));
+            HIPCHK(ctx, launch_hblur(bt, 3, sL));
             bt.src = tmp; bt.sfave = sf; bt.coef = Cd.bands + top;
-            HIPCHK(ctx, launch_vblur_combine(bt, 3, ctx->stream));
+            HIPCHK(ctx, launch_vblur_combine(bt, 3, sL));
             if (nsub > 3) {
                 sa.coef = Cd.bands; sa.coefL = Ld.bands; sa.madL = madL; sa.madab = madab;
-                HIPCHK(ctx, launch_bishrink_AB(sa, nsub - 3, ctx->stream));
+                HIPCHK(ctx, launch_bishrink_AB(sa, nsub - 3, sL));
             }
         }
         if (noisevar_ab > 0.001f) {
-            HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, madab, ctx->stream));
+            HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, madab, sL));
             ShrinkArgs sa = {};
             sa.coef = Cd.bands; sa.coefL = Ld.bands; sa.sfave = sf; sa.n = n2; sa.madL = madL; sa.madab = madab;
             sa.noisevar = ccalc_dev; sa.noisevar_scale = maxNoiseVarab; sa.noisevar_ab = noisevar_ab; sa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
-            HIPCHK(ctx, launch_shrink_sf(sa, nsub, true, ctx->stream));
+            HIPCHK(ctx, launch_shrink_sf(sa, nsub, true, sL));
+        }
+        return ARTGPU_OK;
+    };
+    // second half: box blur of the shrink factors, coefficient update, residuals, reconstruction
+    float chresidtemp = 0.f, chmaxresidtemp = 0.f;
+    auto chroma_back = [&](int ch) -> int {
+        DevDecomp &Cd = Cdd[ch];
+        float *sf = sfc[1 + ch], *tmp = tmpc[1 + ch], *madab = mad + 32 * (1 + ch);
+        int *histo = reinterpret_cast<int *>(histo_fc[1 + ch]);
+        if (noisevar_abc[ch] > 0.001f) {
+            BlurArgs bl = bl0;
             bl.src = sf; bl.dst = tmp;
-            HIPCHK(ctx, launch_hblur(bl, nsub, ctx->stream));
+            HIPCHK(ctx, launch_hblur(bl, nsub, sL));
             bl.src = tmp; bl.sfave = sf; bl.coef = Cd.bands;
-            HIPCHK(ctx, launch_vblur_combine(bl, nsub, ctx->stream));
+            HIPCHK(ctx, launch_vblur_combine(bl, nsub, sL));
         }
         if (nresi || highresi) {
             // Noise_residualAB (FTblockDN.cc:605-635, kall == 0): SQR(MadRgb) of the shrunk chroma bands, summed in level/dir order
             float host[32];
-            HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, madab, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(host, madab, (size_t)nsub * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, madab, sL));
+            HIPCHK(ctx, hipMemcpyAsync(host, madab, (size_t)nsub * sizeof(float), hipMemcpyDeviceToHost, sL));
+            HIPCHK(ctx, hipStreamSynchronize(sL));
             float resid = 0.f, maxresid = 0.f;
             for (int k = 0; k < nsub; ++k) {
                 resid += host[k];
@@ -1158,31 +1229,36 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
                 if (nresi) *nresi = chresid;
             }
         }
-        if ((rc = reconstruct_dev(ctx, Cd, plane))) return rc;
-    }
+        return reconstruct_dev(ctx, Cd, ch == 0 ? A : B, sL);
+    };
 
-    // ---- L: shrink the first min(levels,5) levels, reconstruct (L2405-2438)
-    if (denoiseLuminance) {
+    // ---- L: shrink the first min(levels,5) levels, reconstruct (L2405-2438); detail recovery on stream `sd`
+    float *Lout = L;
+    auto luma = [&](hipStream_t sd) -> int {
+        if (!denoiseLuminance) return ARTGPU_OK;
+        int rc2;
         const int nsubL = 3 * (levwav < 5 ? levwav : 5);
+        float *sf = sfc[0], *tmp = tmpc[0];
+        BlurArgs bl = bl0;
         ShrinkArgs sa = {};
         sa.coef = Ld.bands; sa.sfave = sf; sa.n = n2; sa.madL = madL; sa.noisevar = nullptr; sa.noisevar_const = noisevarL;
         // QUALITY_HIGH runs WaveletDenoiseAll_BiShrinkL first (L842-973); its per-band body is ShrinkAllL's (top level included),
         // and madL is not recomputed in between (L2408-2421): the standard pass simply runs twice
         for (int rep = aggressive ? 0 : 1; rep < 2; ++rep) {
-            HIPCHK(ctx, launch_shrink_sf(sa, nsubL, false, ctx->stream));
+            HIPCHK(ctx, launch_shrink_sf(sa, nsubL, false, sL));
             bl.src = sf; bl.dst = tmp;
-            HIPCHK(ctx, launch_hblur(bl, nsubL, ctx->stream));
+            HIPCHK(ctx, launch_hblur(bl, nsubL, sL));
             bl.src = tmp; bl.sfave = sf; bl.coef = Ld.bands;
-            HIPCHK(ctx, launch_vblur_combine(bl, nsubL, ctx->stream));
+            HIPCHK(ctx, launch_vblur_combine(bl, nsubL, sL));
         }
-        float *Lin = nullptr;
         if (do_detail) {
-            // copy labdn->L to Lin before it gets modified by reconstruction (L2423-2432)
-            if ((rc = pool_get(ctx, P_LIN, n * 4, &Lin))) return rc;
-            HIPCHK(ctx, hipMemcpyAsync(Lin, L, n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            // labdn->L is kept as Lin before the reconstruction modifies it (L2423-2432): here the reconstruction writes a second plane
+            // instead of the first being copied
+            if ((rc2 = pool_get(ctx, P_LIN, n * 4, &Lout))) return rc2;
         }
-        if ((rc = reconstruct_dev(ctx, Ld, L))) return rc;
+        if ((rc2 = reconstruct_dev(ctx, Ld, Lout, sL))) return rc2;
         if (do_detail) {
+            float *Lin = L;
             // ---- detail_recovery (L1479-1635): host-side tables exactly as the reference builds them
             DetailArgs da = {};
             da.w = w; da.h = h;
@@ -1197,8 +1273,8 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
             // the tables are constants: built and uploaded once per context (a slot of their own: the upload needs a stream
             // synchronisation, i.e. a bubble in the middle of every frame)
             const bool fresh_dtab = ctx->pool[P_DCTTAB] == nullptr;
-            if ((rc = pool_get(ctx, P_DCTTAB, 4 * 4096 * 4, &dtab))) return rc;
-            if ((rc = pool_get(ctx, P_BLOCKS, (size_t)da.numblox_W * da.numblox_H * 4096 * 4, &da.blocks))) return rc;
+            if ((rc2 = pool_get(ctx, P_DCTTAB, 4 * 4096 * 4, &dtab))) return rc2;
+            if ((rc2 = pool_get(ctx, P_BLOCKS, (size_t)da.numblox_W * da.numblox_H * 4096 * 4, &da.blocks))) return rc2;
             if (fresh_dtab) {
                 std::vector<float> host(4 * 4096);
                 float *tm_in = host.data(), *tm_out = tm_in + 4096, *ct = tm_out + 4096, *ctt = ct + 4096;
@@ -1217,23 +1293,46 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
                         ctt[j * 64 + i] = ct[i * 64 + j];
                     }
                 }
-                HIPCHK(ctx, hipMemcpyAsync(dtab, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // host vector goes out of scope
+                hipError_t e = hipMemcpyAsync(dtab, host.data(), host.size() * 4, hipMemcpyHostToDevice, sL);
+                if (e == hipSuccess) e = hipStreamSynchronize(sL); // host vector goes out of scope
+                if (e != hipSuccess) {     // (see P_LABTABS above)
+                    (void)hipFree(ctx->pool[P_DCTTAB]); ctx->pool[P_DCTTAB] = nullptr; ctx->pool_bytes[P_DCTTAB] = 0;
+                    return fail(ctx, ARTGPU_EHIP, "rgb_denoise: upload of the DCT tables failed: %s", hipGetErrorString(e));
+                }
             }
             da.tm_in = dtab; da.tm_out = dtab + 4096; da.costab = dtab + 2 * 4096; da.costab_t = dtab + 3 * 4096;
-            da.L = L; da.Lin = Lin;
+            da.L = Lout; da.Lin = Lin;
             if (p->luminance_detail_threshold > 0) {
                 // detail_mask(LL, mask, 65535, 25, 10000, amount, GAUSS, 25 / scale) on the denoised L (FTblockDN.cc:1502-1507)
                 float *dmask;
-                if ((rc = pool_get(ctx, P_DMASK, n * 4, &dmask))) return rc;
+                if ((rc2 = pool_get(ctx, P_DMASK, n * 4, &dmask))) return rc2;
                 const float amount = std::max(0.f, std::min(float(p->luminance_detail_threshold) / 100.f, 1.f));
-                if ((rc = detail_mask_dev(ctx, L, (size_t)w, dmask, w, h, 65535.f, 25.f, 10000.f, amount, (float)(25.f / scale), tmp))) return rc;
+                if ((rc2 = detail_mask_dev(ctx, Lout, (size_t)w, dmask, w, h, 65535.f, 25.f, 10000.f, amount, (float)(25.f / scale), tmp))) return rc2;
                 da.mask = dmask; da.params_Ldetail = params_Ldetail;
             }
-            HIPCHK(ctx, launch_detail_blocks(da, ctx->stream));
-            HIPCHK(ctx, launch_detail_gather(da, ctx->stream));
+            if (sd != sL) {
+                HIPCHK(ctx, hipEventRecord(ctx->dn_ev[0], sL));
+                HIPCHK(ctx, hipStreamWaitEvent(sd, ctx->dn_ev[0], 0));
+            }
+            HIPCHK(ctx, launch_detail_blocks(da, sd));
+            HIPCHK(ctx, launch_detail_gather(da, sd));
+            if (sd != sL) HIPCHK(ctx, hipEventRecord(ctx->dn_ev[1], sd));
         }
+        return ARTGPU_OK;
+    };
+
+    if (!fork) {
+        // the reference's order
+        for (int ch = 0; ch < 2; ++ch)
+            if ((rc = chroma_front(ch)) || (rc = chroma_back(ch))) return rc;
+        if ((rc = luma(sL))) return rc;
+    } else {
+        if ((rc = chroma_front(0)) || (rc = chroma_front(1))) return rc;      // the last readers of the untouched L coefficients
+        if ((rc = luma(ctx->dn_stream[0]))) return rc;
+        if ((rc = chroma_back(0)) || (rc = chroma_back(1))) return rc;
+        HIPCHK(ctx, hipStreamWaitEvent(sL, ctx->dn_ev[1], 0));                // join: the context's stream is behind all the work of the call
     }
+    px.L = Lout;
 
     // ---- back to RGB (L2502-2550)
     HIPCHK(ctx, launch_yuv2rgb(px, ctx->stream));
@@ -1502,9 +1601,7 @@ int artgpu_lab_adjustments(artgpu_ctx *ctx, artgpu_rgb *img, const float *lcurve
     float *luts;
     constexpr size_t NL = 32772;       // lcurve padded to a multiple of four floats
     if ((rc = pool_get(ctx, P_PIPE_R, (NL + 2 * 65536) * 4, &luts))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(luts, lcurve, 32770 * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(luts + NL, acurve, 65536 * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(luts + NL + 65536, bcurve, 65536 * 4, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = h2d_table(ctx, luts, lcurve, 32770 * 4)) || (rc = h2d_table(ctx, luts + NL, acurve, 65536 * 4)) || (rc = h2d_table(ctx, luts + NL + 65536, bcurve, 65536 * 4))) return rc;
     LabArgs a = {};
     for (int k = 0; k < 3; ++k) a.img[k] = d.p[k];
     a.stride = d.stride; a.w = d.w; a.h = d.h;
@@ -1920,6 +2017,7 @@ int artgpu_tone_curve_neutral(artgpu_ctx *ctx, artgpu_rgb *image, const float *l
     a.whitecoeff = whitecoeff;
     a.tail_kind = ctx->curve_tail_kind == ARTGPU_CURVE_TAIL_HOST ? 0 : ctx->curve_tail_kind; a.tail_y = ctx->curve_tail_y;
     if (fresh) HIPCHK(ctx, launch_neutral_hues(a, ctx->stream));
+    a.no_lds_lut = !ctx->opt_lut_lds;
     HIPCHK(ctx, launch_tone_neutral(a, ctx->stream));
     return unbind_rgb(ctx, image, &d);
 }
@@ -1947,15 +2045,24 @@ static int chroma_map_dev(artgpu_ctx *ctx, float *const planes[3], size_t stride
     if (fresh) {
         std::vector<float> host(65536);
         build_cachef(host.data());
-        HIPCHK(ctx, hipMemcpyAsync(tab, host.data(), 65536 * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // host vector goes out of scope
+        ctx->ncurve_host.clear();
+        hipError_t e = hipMemcpyAsync(tab, host.data(), 65536 * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // host vector goes out of scope
+        if (e != hipSuccess) {      // the slot is the "table uploaded" flag: give it back
+            (void)hipFree(ctx->pool[P_CACHEF]); ctx->pool[P_CACHEF] = nullptr; ctx->pool_bytes[P_CACHEF] = 0;
+            return fail(ctx, ARTGPU_EHIP, "chroma map: upload of the cachef table failed: %s", hipGetErrorString(e));
+        }
     }
     // the same curve frame after frame is uploaded once: the copy needs a stream synchronisation (the caller's curve may be a
     // temporary), i.e. a bubble in the middle of every frame
     if (fresh || ctx->ncurve_host.size() != 501 || std::memcmp(ctx->ncurve_host.data(), curve, 501 * 4) != 0) {
         ctx->ncurve_host.assign(curve, curve + 501);
-        HIPCHK(ctx, hipMemcpyAsync(tab + 65536, ctx->ncurve_host.data(), 501 * 4, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        hipError_t e = hipMemcpyAsync(tab + 65536, ctx->ncurve_host.data(), 501 * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->ncurve_host.clear();
+            return fail(ctx, ARTGPU_EHIP, "chroma map: upload of the noise curve failed: %s", hipGetErrorString(e));
+        }
     }
     ChromaMapArgs a = {};
     for (int k = 0; k < 3; ++k) a.src[k] = planes[k];
@@ -2252,7 +2359,7 @@ int artgpu_rgb2out_matrix(artgpu_ctx *ctx, const artgpu_rgb *src, artgpu_rgb *ds
     a.unsupported = reinterpret_cast<int *>(tab + 65536);
     HIPCHK(ctx, hipMemsetAsync(a.unsupported, 0, 4, ctx->stream));
     if (lut) {
-        HIPCHK(ctx, hipMemcpyAsync(tab, lut, (size_t)lutsz * 4, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = h2d_table(ctx, tab, lut, (size_t)lutsz * 4))) return rc;
         a.lut = tab; a.lutsz = lutsz;
     }
     HIPCHK(ctx, launch_rgb2out_matrix(a, ctx->stream));
@@ -2328,7 +2435,15 @@ int artgpu_rgb_curves(artgpu_ctx *ctx, artgpu_rgb *image, const float *rcurve, c
     for (int k = 0; k < 3; ++k) {
         a.dst[k] = d.p[k];
         if (host[k]) {
-            HIPCHK(ctx, hipMemcpyAsync(tabs + (size_t)k * 65536, host[k], 65536 * 4, hipMemcpyHostToDevice, ctx->stream));
+            // one rule for every look-up table that crosses the boundary (artgpu.h "Host look-up tables"): the call keeps its own copy and
+            // the caller's array is free when the call returns; the same table call after call is uploaded once
+            std::vector<float> &own = ctx->rgbcurve_host[k];
+            if (own.size() != 65536 || std::memcmp(own.data(), host[k], 65536 * 4) != 0) {
+                own.assign(host[k], host[k] + 65536);
+                hipError_t e = hipMemcpyAsync(tabs + (size_t)k * 65536, own.data(), 65536 * 4, hipMemcpyHostToDevice, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) { own.clear(); return fail(ctx, ARTGPU_EHIP, "rgb_curves: curve upload failed: %s", hipGetErrorString(e)); }
+            }
             a.lut[k] = tabs + (size_t)k * 65536;
         }
     }
@@ -2489,6 +2604,15 @@ int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, con
         if (hipStreamCreateWithFlags(&peer->stream, hipStreamNonBlocking) != hipSuccess) { (void)artgpu_destroy(peer); return fail(ctx, ARTGPU_EHIP, "batch_run: stream"); }
         peer->owns_stream = true;
         ctx->lanes.push_back(peer);
+    }
+    // the lanes are this context as far as the caller can tell: its options, curve tail and progress listener apply to every frame,
+    // whichever lane runs it (copied on every call -- they may change between calls)
+    for (artgpu_ctx *peer : ctx->lanes) {
+        peer->curve_tail_kind = ctx->curve_tail_kind; peer->curve_tail_y = ctx->curve_tail_y;
+        peer->opt_amaze_path = ctx->opt_amaze_path; peer->opt_amaze_split = ctx->opt_amaze_split;
+        peer->opt_amaze_zero_mask = ctx->opt_amaze_zero_mask; peer->opt_amaze_zero_frame = ctx->opt_amaze_zero_frame; peer->opt_amaze_poison = ctx->opt_amaze_poison;
+        peer->opt_rcd_rows = ctx->opt_rcd_rows; peer->opt_roctx = ctx->opt_roctx; peer->opt_lut_lds = ctx->opt_lut_lds; peer->opt_dn_streams = ctx->opt_dn_streams;
+        peer->progress_fn = ctx->progress_fn; peer->progress_user = ctx->progress_user;
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // inputs the caller produced on this context's stream
     std::vector<int> rcs(L, ARTGPU_OK);

@@ -848,7 +848,7 @@ hipError_t launch_gamma_lut(float *lut, float gamma, float start, float slope, f
 // the LDS-table shape: large frames with the gamma LUTs in use (their pool memory is 16-byte aligned)
 static bool dn_lds_shape(const DnPixArgs &a, const float *lut, int *cus)
 {
-    if (a.lab_mode || !(a.gam > 1.f) || (long long)a.w * a.h < (1 << 22) || (reinterpret_cast<uintptr_t>(lut) & 15) || getenv("ARTGPU_DN_NOLDS")) return false;
+    if (a.lab_mode || !(a.gam > 1.f) || (long long)a.w * a.h < (1 << 22) || (reinterpret_cast<uintptr_t>(lut) & 15) || a.no_lds_lut) return false;
     int dev = 0;
     *cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -148,6 +148,7 @@ struct PixArgs {
     float whitept;
     int tail_kind;         // curves::setLutVal above 65535 (artgpu_set_curve_tail): 0 LUT clip, 1 constant, 2 identity
     double tail_y;
+    int no_lds_lut;        // artgpu_set_option "lut_lds" 0: the plain one-lane-per-pixel kernels (table lookups served by L2) on every frame size
 };
 hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s);
 hipError_t launch_exposure(const PixArgs &a, hipStream_t s);
@@ -281,6 +282,7 @@ struct NeutralArgs {
     float whitecoeff;
     int tail_kind;               // as in PixArgs
     double tail_y;
+    int no_lds_lut;              // as in PixArgs
 };
 hipError_t launch_neutral_hues(const NeutralArgs &a, hipStream_t s);
 hipError_t launch_tone_neutral(const NeutralArgs &a, hipStream_t s);
@@ -321,6 +323,7 @@ struct DnPixArgs {
     int igam_lds_lo;               // yuv2rgb_lds: entries [lo, lo + 40704) of the inverse gamma table live in LDS (multiple of 4)
     float wpi[9], iws[9];          // LAB: working space <-> XYZ, float casts
     const float *cachef, *cachefy, *dn_gamma, *dn_igamma;   // LAB: 65536-entry LUTs
+    int no_lds_lut;                // artgpu_set_option "lut_lds" 0
 };
 // chroma noise-curve map (ipdenoise.cc:1113-1131 + FTblockDN.cc:1716-1777)
 struct ChromaMapArgs {

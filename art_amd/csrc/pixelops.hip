@@ -395,7 +395,7 @@ hipError_t launch_yuv_mode(const PixArgs &a, hipStream_t s)
 hipError_t launch_tone_std(const PixArgs &a, hipStream_t s)
 {
     // large frames with a curve: the LDS-resident variant (the curve pointer is 16-byte aligned: pool or hipMalloc memory)
-    if (a.lut && (long long)a.w * a.h >= (1 << 22) && (reinterpret_cast<uintptr_t>(a.lut) & 15) == 0 && !getenv("ARTGPU_TONE_NOLDS")) {
+    if (a.lut && (long long)a.w * a.h >= (1 << 22) && (reinterpret_cast<uintptr_t>(a.lut) & 15) == 0 && !a.no_lds_lut) {
         const size_t lds = (size_t)LUT_LDS_N * sizeof(float);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tone_std_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -250,7 +250,7 @@ hipError_t launch_neutral_hues(const NeutralArgs &a, hipStream_t s)
 }
 hipError_t launch_tone_neutral(const NeutralArgs &a, hipStream_t s)
 {
-    if ((long long)a.w * a.h >= (1 << 22) && (reinterpret_cast<uintptr_t>(a.pq) & 15) == 0 && !getenv("ARTGPU_TONE_NOLDS")) {
+    if ((long long)a.w * a.h >= (1 << 22) && (reinterpret_cast<uintptr_t>(a.pq) & 15) == 0 && !a.no_lds_lut) {
         const size_t lds = (size_t)LUT_LDS_N * sizeof(float);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tone_neutral_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

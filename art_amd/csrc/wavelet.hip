@@ -155,14 +155,19 @@ __global__ void __launch_bounds__(256) wavelet_synthesis0_kernel(WaveArgs a)
     const float srcFactor = 1.f - a.blend;
     // the destination values that take part in the blend are loaded up front: as `dst[o] = dst[o] * f + ...` in the loop every
     // iteration's load had to wait for the previous iteration's store (same array), sixteen dependent memory round trips per thread
+    // With blend == 1 (every reconstruct() of RGB_denoise) the old value only contributes `old * 0`: nothing for a finite old value (the sum
+    // below is never -0, so the sign of that zero cannot show), and a non-finite pixel has already sent the reference's MadRgb histogram index
+    // out of range (FTblockDN.cc:587).  The load is skipped then -- a quarter of this kernel's traffic -- and the destination may be a plane
+    // that was never written (the L channel is reconstructed into a second plane so that the first one stays as `Lin`).
     constexpr int NIT = S0_TH * S0_TW / 256;
     float dv[NIT];
+    const bool use_old = a.blend != 1.f;
 #pragma unroll
     for (int n = 0; n < NIT; ++n) {
         const int t = threadIdx.x + n * 256;
         const int rr = t / S0_TW, cc = t - rr * S0_TW;
         const int i = min(r0 + rr, h - 1), k = min(c0 + cc, w - 1);
-        dv[n] = a.dst[(size_t)i * a.dst_stride + k];
+        dv[n] = use_old ? a.dst[(size_t)i * a.dst_stride + k] : 0.f;
     }
 #pragma unroll
     for (int n = 0; n < NIT; ++n) {

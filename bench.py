@@ -92,6 +92,8 @@ def main() -> None:
                     help="run the rank / sharding / completion code path without a GPU: gloo instead of RCCL, every device call replaced by a "
                          "no-op (tests/test_multiproc.py drives `bench.py --gpus 2 --dry` on the CPU); the printed line carries \"dry\": true "
                          "and is not a measurement")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="artgpu_set_option on every context of the run (A/B switches, e.g. dn_streams=0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     args = ap.parse_args()
@@ -141,7 +143,13 @@ def main() -> None:
     d_raw = torch.from_numpy(raw).to(dev)
     d_out = [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(3)]
     stream = torch.cuda.current_stream(dev)
-    ctx = capi.Context(local_rank, stream.cuda_stream)
+    def apply_opts(c):
+        for o in args.opt:
+            name, _, val = o.partition("=")
+            c.set_option(name, int(val, 0))
+        return c
+
+    ctx = apply_opts(capi.Context(local_rank, stream.cuda_stream))
     out = capi.RGB(*[capi.device_plane(t) for t in d_out])
     p_raw = capi.device_plane(d_raw)
     method = capi.BAYER_RCD if args.workload == "rcd" else capi.BAYER_AMAZE
@@ -182,7 +190,7 @@ def main() -> None:
         for k in range(1, args.lanes):
             st = torch.cuda.Stream(dev)
             lr = synth.xtrans_frame(W, H, seed=rank + 1000 * k) if xtrans else synth.bayer_frame(W, H, filt, seed=rank + 1000 * k)
-            ln = {"ctx": capi.Context(local_rank, st.cuda_stream), "stream": st, "raw": torch.from_numpy(lr).to(dev),
+            ln = {"ctx": apply_opts(capi.Context(local_rank, st.cuda_stream)), "stream": st, "raw": torch.from_numpy(lr).to(dev),
                   "out": [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(3)],
                   "img": [torch.empty((ih, iw), dtype=torch.float32, device=dev) for _ in range(3)]}
             ln["p_raw"] = capi.device_plane(ln["raw"]); ln["p_out"] = capi.RGB(*[capi.device_plane(t) for t in ln["out"]])

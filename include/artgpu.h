@@ -156,11 +156,11 @@ int artgpu_exposure(artgpu_ctx *ctx, artgpu_rgb *image, float exp_scale, float b
 int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float *lut65536,
                       float whitept, int filmlike_clip);
 
-/* Host look-up tables.  Every entry point that takes a LUT (artgpu_tone_curve, artgpu_tone_curve_neutral, artgpu_rgb_curves,
- * artgpu_rgb2out_matrix, artgpu_lab_adjustments, ...) copies it to the device with an asynchronous copy on the context's stream.
- * With pageable host memory that copy has left the caller's buffer when the call returns; a LUT in PINNED host memory
- * (hipHostMalloc / hipHostRegister) is read later, when the stream gets there: keep it unchanged until artgpu_synchronize() or the
- * next call that downloads a result to the host.  (Calls on host-resident images synchronise before they return.) */
+/* Host look-up tables.  One lifetime rule for every entry point that takes a LUT (artgpu_tone_curve, artgpu_tone_curve_neutral,
+ * artgpu_rgb_curves, artgpu_rgb2out_matrix, artgpu_lab_adjustments, ...): the caller's array is free again when the call returns.
+ * The tone and rgb curves are kept in a context-owned copy (the same curve call after call is uploaded once); the others are
+ * copied on the context's stream, which is drained before the call returns if the array is pinned host memory (hipHostMalloc /
+ * hipHostRegister: the DMA engine reads it when the stream gets there; a pageable array has been staged by then). */
 
 /* curves::setLutVal (rtengine/curves.h:224-231): a value above 65535 does not go through the LUT but through the Curve object,
  * curve->getVal(val / 65535.f) * 65535.f.  The LUT is all that crosses this boundary, so the adapter states what its Curve returns

@@ -259,7 +259,7 @@ def test_improc_denoise_preview_scale_bit_exact(gpu_ctx):
 
 def test_large_frame_lds_gamma_tables_same_bits_as_plain_kernels(gpu_ctx, monkeypatch):
     """frames of >= 4 Mpx run RGB->YUV / YUV->RGB with the lower 40704 gamma-table entries in LDS: wide-range data (both sides of the
-    split, above the table, zeros and negatives) must give the bits of the plain kernels (ARTGPU_DN_NOLDS) and of the oracle"""
+    split, above the table, zeros and negatives) must give the bits of the plain kernels (option "lut_lds" 0) and of the oracle"""
     w, h = 2308, 1822
     rng = np.random.default_rng(12)
     base = rng.uniform(0, 1, (h, w)).astype(np.float32) ** 3 * 9000.0           # gain 2^5 * 2^0.3 later: spans 0 .. ~350000
@@ -270,9 +270,12 @@ def test_large_frame_lds_gamma_tables_same_bits_as_plain_kernels(gpu_ctx, monkey
     tp = capi.DenoiseToolParams(capi.DenoiseParams(30.0, 50.0, 0, 12.0, 0.0, 0.0, 1.7, 0, 0, 0), 0, 3, 0, 80)
     got = [p.copy() for p in img]
     gpu_ctx.improc_denoise(capi.host_rgb(got), tp, O.REC2020_WS_D, ecomp=0.3, flags=capi.DN_SKIP_DETAIL_RECOVERY)
-    monkeypatch.setenv("ARTGPU_DN_NOLDS", "1")
+    gpu_ctx.set_option("lut_lds", 0)
     plain = [p.copy() for p in img]
-    gpu_ctx.improc_denoise(capi.host_rgb(plain), tp, O.REC2020_WS_D, ecomp=0.3, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    try:
+        gpu_ctx.improc_denoise(capi.host_rgb(plain), tp, O.REC2020_WS_D, ecomp=0.3, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    finally:
+        gpu_ctx.set_option("lut_lds", 1)
     ref = O.improc_denoise(img, dict(luminance=30.0, chrominance=12.0), smoothing=False, ecomp=0.3, detail_recovery=False)
     for g, p, r in zip(got, plain, ref):
         assert np.array_equal(g.view(np.uint32), p.view(np.uint32))

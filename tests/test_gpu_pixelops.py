@@ -220,7 +220,7 @@ def test_rgb2out_fast_path_and_scanlines_bit_exact(gpu_ctx):
 @pytest.mark.parametrize("w,h,clip", [(2304, 1900, True), (4099, 1031, False)])
 def test_tone_std_large_frame_lds_curve_bit_exact(gpu_ctx, monkeypatch, w, h, clip):
     """frames of >= 4 Mpx take the kernel that keeps the lower 40704 curve entries in LDS: values on both sides of that split, at the
-    curve's ends, negative, above 65535 and NaN; same bits as the oracle and as the plain kernel (ARTGPU_TONE_NOLDS)"""
+    curve's ends, negative, above 65535 and NaN; same bits as the oracle and as the plain kernel (option "lut_lds" 0)"""
     from art_amd import capi
     import oracle_lib as O
     rng = np.random.default_rng(w)
@@ -232,9 +232,12 @@ def test_tone_std_large_frame_lds_curve_bit_exact(gpu_ctx, monkeypatch, w, h, cl
     ref = O.tone_std(img, lut, 1.0, clip)
     got = [p.copy() for p in img]
     gpu_ctx.tone_curve(capi.host_rgb(got), lut, 1.0, clip)
-    monkeypatch.setenv("ARTGPU_TONE_NOLDS", "1")
+    gpu_ctx.set_option("lut_lds", 0)
     plain = [p.copy() for p in img]
-    gpu_ctx.tone_curve(capi.host_rgb(plain), lut, 1.0, clip)
+    try:
+        gpu_ctx.tone_curve(capi.host_rgb(plain), lut, 1.0, clip)
+    finally:
+        gpu_ctx.set_option("lut_lds", 1)
     for g, p, r in zip(got, plain, ref):
         assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
         assert np.array_equal(p.view(np.uint32), r.view(np.uint32))

@@ -64,9 +64,12 @@ def test_neutral_large_frame_lds_pq_table_bit_exact(gpu_ctx, monkeypatch):
     ref, oor = O.tone_neutral(img, lut, 1.0, want_oor=True)
     got = [p.copy() for p in img]
     gpu_ctx.tone_curve_neutral(capi.host_rgb(got), lut, 1.0, O.REC2020_WS_D, O.REC2020_IWS_D)
-    monkeypatch.setenv("ARTGPU_TONE_NOLDS", "1")
+    gpu_ctx.set_option("lut_lds", 0)
     plain = [p.copy() for p in img]
-    gpu_ctx.tone_curve_neutral(capi.host_rgb(plain), lut, 1.0, O.REC2020_WS_D, O.REC2020_IWS_D)
+    try:
+        gpu_ctx.tone_curve_neutral(capi.host_rgb(plain), lut, 1.0, O.REC2020_WS_D, O.REC2020_IWS_D)
+    finally:
+        gpu_ctx.set_option("lut_lds", 1)
     for g, p, r in zip(got, plain, ref):
         assert np.array_equal(g.view(np.uint32), p.view(np.uint32))
         assert np.array_equal(g[~oor].view(np.uint32), r[~oor].view(np.uint32))
