@@ -23,11 +23,11 @@ struct artgpu_ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;      // second stream (serial statistics of the AUTOMATIC chroma estimation run beside the decompositions)
     hipEvent_t aux_ev[2] = {nullptr, nullptr};
-    // RGB_denoise: the a and b chroma chains run beside the L chain on streams of their own (they share nothing but the untouched L bands)
-    hipStream_t dn_stream[2] = {nullptr, nullptr};
-    hipEvent_t dn_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // RGB_denoise: the DCT detail recovery of L runs on a side stream beside the chroma blurs / reconstructions
+    hipStream_t dn_stream[1] = {nullptr};
+    hipEvent_t dn_ev[2] = {nullptr, nullptr};
     int opt_lut_lds = 1;           // 0: never the LUT-in-LDS shapes of the pixel passes (tests compare the two)
-    int opt_dn_streams = 1;        // 0: the whole chain on the context's stream, one kernel after the other
+    int opt_dn_streams = 1;        // 0: the whole chain on the context's stream, one kernel after the other, in the reference's order
     std::string err;
     // per-workgroup work arenas (demosaic)
     float *arena = nullptr;
@@ -301,10 +301,9 @@ int artgpu_destroy(artgpu_ctx *ctx)
     for (int k = 0; k < 2; ++k)
         if (ctx->aux_ev[k]) (void)hipEventDestroy(ctx->aux_ev[k]);
     if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
-    for (int k = 0; k < 6; ++k)
-        if (ctx->dn_ev[k]) (void)hipEventDestroy(ctx->dn_ev[k]);
     for (int k = 0; k < 2; ++k)
-        if (ctx->dn_stream[k]) { (void)hipStreamSynchronize(ctx->dn_stream[k]); (void)hipStreamDestroy(ctx->dn_stream[k]); }
+        if (ctx->dn_ev[k]) (void)hipEventDestroy(ctx->dn_ev[k]);
+    if (ctx->dn_stream[0]) { (void)hipStreamSynchronize(ctx->dn_stream[0]); (void)hipStreamDestroy(ctx->dn_stream[0]); }
     delete ctx;
     return ARTGPU_OK;
 }
