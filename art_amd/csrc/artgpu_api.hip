@@ -932,7 +932,7 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_BATCH, P_DCTTAB, P_CBANDS2, P_CLOW0_2, P_CLOW1_2, P_SF_A, P_TMP_A, P_SF_B, P_TMP_B, P_HISTO_A, P_HISTO_B, P_NSLOTS };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_BATCH, P_DCTTAB, P_CBANDS2, P_CLOW0_2, P_CLOW1_2, P_SF_A, P_SF_B, P_HISTO_A, P_HISTO_B, P_NSLOTS };
 static_assert(P_NSLOTS <= artgpu_ctx::NPOOL, "grow artgpu_ctx::pool");
 
 struct DevDecomp {
@@ -1073,24 +1073,40 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     const int nsub = 3 * levwav;
     bool autoch = p->chrominance_method == 1;
 
-    // ---- device buffers.  The three channels have their own shrink scratch and the two chroma channels their own decomposition, so that
-    // the a and b chains can run beside the L chain (below); nothing is allocated in steady state.
-    float *L, *A, *B, *gamlut, *mad, *ccalc_dev = nullptr;
+    // ---- streams.  The reference runs a, then b, then L (L2328-2438).  The chains only meet in the untouched L coefficients and their MADs
+    // (read by the chroma shrink factors) and in yuv2rgb, so their order is free.  With "dn_streams" the DCT detail recovery of L -- bound by
+    // instruction issue, it leaves HBM idle -- runs on a side stream beside the box blurs and reconstructions of a and b, which are bound by
+    // HBM: L goes first for that, after the chroma shrink factors have read its coefficients.  Same kernels on the same data: the same bits.
+    // (Running all three chains side by side was measured too: 9.7 ms against 9.2 -- three HBM-bound chains only get in each other's way.)
+    const bool fork = ctx->opt_dn_streams != 0 && do_detail && denoiseLuminance;
+
+    // ---- device buffers; nothing is allocated in steady state.  Scratch planes are shared wherever the order of the kernels allows it:
+    // one `tmp` (horizontally blurred factors) serves all three channels -- its producer and its consumer are neighbours on the context's
+    // stream --; in the reference's order one `sf` plane set and one chroma decomposition do too, with the side stream a and b keep theirs
+    // across the L chain.
+    float *L, *A, *B, *gamlut, *mad, *ccalc_dev = nullptr, *tmp1;
     float *sfc[3], *tmpc[3], *histo_fc[3];          // 0: L, 1: a, 2: b
     DevDecomp Ld = {}, Cdd[2] = {};
     Ld.w = w; Ld.h = h; Ld.w2 = w2; Ld.h2 = h2; Ld.n = n2; Ld.nlevels = levwav;
     Cdd[0] = Cdd[1] = Ld;
-    const size_t histo_bytes = (size_t)nsub * (65536 + MAD_SCRATCH_INTS_PER_BAND) * 4;
+    const size_t histo_bytes = (size_t)nsub * (65536 + MAD_SCRATCH_INTS_PER_BAND) * 4, band_bytes = (size_t)nsub * n2 * 4;
     if ((rc = pool_get(ctx, P_L, n * 4, &L)) || (rc = pool_get(ctx, P_A, n * 4, &A)) || (rc = pool_get(ctx, P_B, n * 4, &B)) ||
-        (rc = pool_get(ctx, P_LBANDS, (size_t)nsub * n2 * 4, &Ld.bands)) || (rc = pool_get(ctx, P_LLOW0, n2 * 4, &Ld.low[0])) || (rc = pool_get(ctx, P_LLOW1, n2 * 4, &Ld.low[1])) ||
-        (rc = pool_get(ctx, P_CBANDS, (size_t)nsub * n2 * 4, &Cdd[0].bands)) || (rc = pool_get(ctx, P_CLOW0, n2 * 4, &Cdd[0].low[0])) || (rc = pool_get(ctx, P_CLOW1, n2 * 4, &Cdd[0].low[1])) ||
-        (rc = pool_get(ctx, P_CBANDS2, (size_t)nsub * n2 * 4, &Cdd[1].bands)) || (rc = pool_get(ctx, P_CLOW0_2, n2 * 4, &Cdd[1].low[0])) || (rc = pool_get(ctx, P_CLOW1_2, n2 * 4, &Cdd[1].low[1])) ||
-        (rc = pool_get(ctx, P_SF, (size_t)nsub * n2 * 4, &sfc[0])) || (rc = pool_get(ctx, P_TMP, (size_t)nsub * n2 * 4, &tmpc[0])) ||
-        (rc = pool_get(ctx, P_SF_A, (size_t)nsub * n2 * 4, &sfc[1])) || (rc = pool_get(ctx, P_TMP_A, (size_t)nsub * n2 * 4, &tmpc[1])) ||
-        (rc = pool_get(ctx, P_SF_B, (size_t)nsub * n2 * 4, &sfc[2])) || (rc = pool_get(ctx, P_TMP_B, (size_t)nsub * n2 * 4, &tmpc[2])) ||
-        (rc = pool_get(ctx, P_HISTO, histo_bytes, &histo_fc[0])) || (rc = pool_get(ctx, P_HISTO_A, histo_bytes, &histo_fc[1])) || (rc = pool_get(ctx, P_HISTO_B, histo_bytes, &histo_fc[2])) ||
+        (rc = pool_get(ctx, P_LBANDS, band_bytes, &Ld.bands)) || (rc = pool_get(ctx, P_LLOW0, n2 * 4, &Ld.low[0])) || (rc = pool_get(ctx, P_LLOW1, n2 * 4, &Ld.low[1])) ||
+        (rc = pool_get(ctx, P_CBANDS, band_bytes, &Cdd[0].bands)) || (rc = pool_get(ctx, P_CLOW0, n2 * 4, &Cdd[0].low[0])) || (rc = pool_get(ctx, P_CLOW1, n2 * 4, &Cdd[0].low[1])) ||
+        (rc = pool_get(ctx, P_SF, band_bytes, &sfc[0])) || (rc = pool_get(ctx, P_TMP, band_bytes, &tmp1)) || (rc = pool_get(ctx, P_HISTO, histo_bytes, &histo_fc[0])) ||
         (rc = pool_get(ctx, P_MAD, 3 * 32 * 4, &mad)) || (rc = pool_get(ctx, P_GAM, 2 * 65536 * 4, &gamlut)))
         return rc;
+    tmpc[0] = tmpc[1] = tmpc[2] = tmp1;
+    if (fork) {
+        if ((rc = pool_get(ctx, P_CBANDS2, band_bytes, &Cdd[1].bands)) || (rc = pool_get(ctx, P_CLOW0_2, n2 * 4, &Cdd[1].low[0])) || (rc = pool_get(ctx, P_CLOW1_2, n2 * 4, &Cdd[1].low[1])) ||
+            (rc = pool_get(ctx, P_SF_A, band_bytes, &sfc[1])) || (rc = pool_get(ctx, P_SF_B, band_bytes, &sfc[2])) ||
+            (rc = pool_get(ctx, P_HISTO_A, histo_bytes, &histo_fc[1])) || (rc = pool_get(ctx, P_HISTO_B, histo_bytes, &histo_fc[2])))
+            return rc;
+    } else {
+        sfc[1] = sfc[2] = sfc[0];
+        histo_fc[1] = histo_fc[2] = histo_fc[0];
+        Cdd[1] = Cdd[0];
+    }
     float *madL = mad;
     if (useNoiseCCurve) {
         if (!plane_ok(ccalc) || ccalc->w != w2 || ccalc->h != h2) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: ccalc must be %dx%d", w2, h2);
@@ -1099,12 +1115,6 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
                                      ccalc->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     }
 
-    // ---- streams.  The reference runs a, then b, then L (L2328-2438).  The chains only meet in the untouched L coefficients and their MADs
-    // (read by the chroma shrink factors) and in yuv2rgb, so their order is free.  With "dn_streams" the DCT detail recovery of L -- bound by
-    // instruction issue, it leaves HBM idle -- runs on a side stream beside the box blurs and reconstructions of a and b, which are bound by
-    // HBM: L goes first for that, after the chroma shrink factors have read its coefficients.  Same kernels on the same data: the same bits.
-    // (Running all three chains side by side was measured too: 9.7 ms against 9.2 -- three HBM-bound chains only get in each other's way.)
-    const bool fork = ctx->opt_dn_streams != 0 && do_detail && denoiseLuminance;
     if (fork && !ctx->dn_stream[0]) {
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->dn_stream[0], hipStreamNonBlocking));
         for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->dn_ev[k], hipEventDisableTiming));
