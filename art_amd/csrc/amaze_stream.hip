@@ -103,14 +103,16 @@ amaze_stream_kernel(AmazeStreamArgs s)
     frame.W = s.W; frame.H = s.H; frame.filters = s.filters; frame.clip_pt = s.clip_pt; frame.clip_pt8 = s.clip_pt8; frame.g00 = s.g00; frame.ey = s.ey;
     frame.top = 0; frame.left = 0; frame.rr1 = 0; frame.gbase = 0;
 
-    // this workgroup's tile sequence: tiles blockIdx.x, blockIdx.x + gridDim.x, ... and then whatever the redo queue holds
-    int nk = ((int)blockIdx.x < s.ntiles) ? (s.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    // this workgroup's tile sequence: tile blockIdx.x, then whatever the shared tile counter hands out (the workgroups do not start
+    // together when the arena kernel's tiles occupy some CUs at first, and a fixed share per workgroup made the last starter the
+    // kernel's length), then whatever the redo queue holds
+    int nk = ((int)blockIdx.x < s.ntiles) ? 1 : 0;
     const int nk_static = nk;
     amz_li dyn = (amz_li)(lds + DYN_OFF);          // the redo entry tid 0 pulled for sequence position dyn[0]
     auto tile_ref = [&](int k) -> TileRef {
         TileRef t;
         if (k < nk_static) {
-            const int tile = s.tiles[blockIdx.x + k * gridDim.x];
+            const int tile = s.tiles[blockIdx.x];
             const int ty = tile / s.ntx, tx = tile - ty * s.ntx;
             const int top = -16 + ty * (TS - 32);
             tile_ref_set(t, k, tile, top, -16 + tx * (TS - 32), min(top + TS, s.H + 16) - top);
@@ -119,7 +121,7 @@ amaze_stream_kernel(AmazeStreamArgs s)
             const int ty = tile / s.ntx, tx = tile - ty * s.ntx;
             const int top = -16 + ty * (TS - 32);
             tile_ref_set(t, k, tile, top, -16 + tx * (TS - 32), min(top + TS, s.H + 16) - top);
-            t.redo = 1; t.r0 = dyn[2]; t.r1 = dyn[3]; t.c0 = dyn[4]; t.c1 = dyn[5];
+            if (dyn[6]) { t.redo = 1; t.r0 = dyn[2]; t.r1 = dyn[3]; t.c0 = dyn[4]; t.c1 = dyn[5]; }
         } else {
             tile_ref_none(t, k);
         }
@@ -127,9 +129,19 @@ amaze_stream_kernel(AmazeStreamArgs s)
     };
     // tid 0: take one entry of the redo queue for sequence position k (none: dyn[1] = -1)
     int *const cnt = reinterpret_cast<int *>(s.queue_words + s.ntiles);    // eight bookkeeping counters behind the queue (artgpu_get_option)
+    bool tiles_left = true;
     auto pull = [&](int k) {
         int tile = -1;
         unsigned long long w = 0;
+        if (tiles_left) {
+            // tiles gridDim.x .. ntiles - 1 of the list are handed out in order (queue_hdr[2], cleared per launch)
+            const int i = (int)gridDim.x + atomicAdd(&s.queue_hdr[2], 1);
+            if (i < s.ntiles) {
+                dyn[0] = k; dyn[1] = s.tiles[i]; dyn[6] = 0;
+                return;
+            }
+            tiles_left = false;
+        }
         // every read of the queue is a read-modify-write (+0): the per-XCD L2s are not coherent with each other, and a plain or sc1
         // load can return what an earlier launch left in this XCD's L2 -- a consumer that trusted a stale "reserved" count took a
         // slot that was never published in this launch, and the real entry published there later was lost
@@ -154,7 +166,7 @@ amaze_stream_kernel(AmazeStreamArgs s)
             }
         }
         atomicAdd(&cnt[tile >= 0 ? 0 : 1], 1);
-        dyn[0] = k; dyn[1] = tile;
+        dyn[0] = k; dyn[1] = tile; dyn[6] = 1;
         dyn[2] = (int)((w >> 24) & 0xff); dyn[3] = (int)((w >> 32) & 0xff); dyn[4] = (int)((w >> 40) & 0xff); dyn[5] = (int)((w >> 48) & 0xff);
     };
     if (nk == 0) return;       // (more workgroups than tiles)

@@ -62,6 +62,9 @@ struct artgpu_ctx {
     int opt_roctx = 0;             // 1: roctx ranges named after the reference functions around the entry points (rocprofv3 --marker-trace)
     artgpu_progress_fn progress_fn = nullptr;   // artgpu_set_progress_callback
     void *progress_user = nullptr;
+    int opt_amaze_overlap = 1;     // 0: the arena kernel's static tiles behind the stream kernel instead of beside it
+    hipStream_t amz_side = nullptr;
+    hipEvent_t amz_ev[2] = {nullptr, nullptr};
     int opt_rcd_rows = 8;          // rows per iteration of the streaming kernel (4 or 8)
     int *rcd_counter = nullptr;    // RCD streaming kernel: tile counter
     int curve_tail_kind = ARTGPU_CURVE_TAIL_HOST;   // artgpu_set_curve_tail
@@ -304,6 +307,9 @@ int artgpu_destroy(artgpu_ctx *ctx)
     for (int k = 0; k < 2; ++k)
         if (ctx->dn_ev[k]) (void)hipEventDestroy(ctx->dn_ev[k]);
     if (ctx->dn_stream[0]) { (void)hipStreamSynchronize(ctx->dn_stream[0]); (void)hipStreamDestroy(ctx->dn_stream[0]); }
+    for (int k = 0; k < 2; ++k)
+        if (ctx->amz_ev[k]) (void)hipEventDestroy(ctx->amz_ev[k]);
+    if (ctx->amz_side) { (void)hipStreamSynchronize(ctx->amz_side); (void)hipStreamDestroy(ctx->amz_side); }
     delete ctx;
     return ARTGPU_OK;
 }
@@ -359,6 +365,7 @@ int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value)
     const std::string n(name);
     if (n == "amaze_path") { if (value < 0 || value > 1) return fail(ctx, ARTGPU_EINVAL, "amaze_path: 0 or 1"); ctx->opt_amaze_path = (int)value; }
     else if (n == "amaze_split") ctx->opt_amaze_split = value != 0;
+    else if (n == "amaze_overlap") ctx->opt_amaze_overlap = value != 0;
     else if (n == "amaze_zero_mask") ctx->opt_amaze_zero_mask = value;
     else if (n == "amaze_zero_frame") ctx->opt_amaze_zero_frame = (int)value;
     else if (n == "amaze_poison") ctx->opt_amaze_poison = (int)value;
@@ -507,10 +514,61 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
         const size_t nfixed = (((size_t)ctx->amz_nstream + (1 + ctx->amz_narena) + (1 + ctx->amz_narena + ctx->amz_nstream) + 3) / 4) * 4;
         int *const d_queue = d_stream + nfixed;                                          // header (4 ints), then the 64-bit entries
         unsigned long long *const d_qwords = reinterpret_cast<unsigned long long *>(d_queue + 4);
-        HIPCHK(ctx, hipMemcpyAsync(d_work, d_templ, (size_t)(1 + ctx->amz_narena) * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(d_queue, 0, (4 + 2 * (size_t)ctx->amz_nstream + 8) * sizeof(int), ctx->stream));   // + the 8 counters behind it
         const float clip_pt = (float)(1.0 / initial_gain);   // amaze_demosaic_RT.cc:53-54
         const float clip_pt8 = (float)(0.8 / initial_gain);
+        // The arena kernel runs twice.  EARLY, beside the stream kernel on a stream of its own: the tiles the stream cannot take (for a
+        // frame width that is not 32 + a multiple of 128 that is a whole column of narrow tiles: 43 of 2860 at 8256 x 5504) -- they are
+        // one workgroup each and a chain of twenty HBM round trips, 0.45 ms that used to follow the stream kernel; now they hold a few CUs
+        // back for that long while the stream workgroups on the other CUs take tiles from the shared counter.  LATE, behind both: whatever
+        // the stream handed back (tiles whose Nyquist sites did not fit its assumption and found no taker in the redo queue), normally nothing.
+        const bool split = mode == 1 && ctx->opt_amaze_split;
+        const bool early = ctx->amz_nstream > 0 && ctx->amz_narena > 0 && ctx->opt_amaze_overlap;
+        const int nlist_max = ctx->amz_narena + ctx->amz_nstream;
+        const int cap = split ? MAX_TILE_WORKGROUPS : 768;
+        const int grid = std::max(1, std::min(nlist_max, cap));
+        rc = ensure(ctx, &ctx->arena, &ctx->arena_bytes, (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float));
+        if (rc) return rc;
+        if ((rc = ensure(ctx, &ctx->bbox, &ctx->bbox_bytes, (size_t)grid * 4 * sizeof(int)))) return rc;
+        AmazeArgs a;
+        a.raw = d.raw; a.raw_stride = d.raw_stride;
+        a.red = d.r; a.green = d.g; a.blue = d.b; a.out_stride = d.out_stride;
+        a.arena = ctx->arena;
+        a.W = W; a.H = H; a.ntx = ntx; a.ntiles = ntiles;
+        a.filters = filters;
+        a.clip_pt = clip_pt;
+        a.clip_pt8 = clip_pt8;
+        a.bbox = reinterpret_cast<int *>(ctx->bbox);
+        // Arena regions that have read-before-write positions on full tiles and therefore must be cleared per tile: vcd, hcd,
+        // vcdalt, hcdalt, cddiffsq, nyquist (bits 4-8, 15): on a full tile every other position is written before it is read, for
+        // every CFA phase, because the phase loops cover fixed index ranges (derivation: DESIGN.md section 10).
+        // tests/test_gpu_demosaic.py re-checks it with poisoned arenas (artgpu_set_option "amaze_poison").  Partial tiles clear everything.
+        a.zero_mask = (unsigned)ctx->opt_amaze_zero_mask;
+        // ... and of the five full-size planes among them only positions within a few pixels of the tile edge (plus the gap behind each
+        // plane): a frame of 4 already passes the poison test, 16 (the discarded tile border) is used.  0: whole planes.
+        a.zero_frame = ctx->opt_amaze_zero_frame;
+        a.split = split ? 1 : 0;
+        a.queue_words = d_qwords;
+        a.queue_counters = reinterpret_cast<int *>(d_qwords + ctx->amz_nstream);
+        if (ctx->opt_amaze_poison >= 0)   // test hook: fill the arenas with a byte pattern first
+            HIPCHK(ctx, hipMemsetAsync(ctx->arena, ctx->opt_amaze_poison, (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float), ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_queue, 0, (4 + 2 * (size_t)ctx->amz_nstream + 8) * sizeof(int), ctx->stream));   // + the 8 counters behind it
+        if (early) {
+            // the working list starts empty (the stream appends to it), the static tiles are taken from the template
+            HIPCHK(ctx, hipMemsetAsync(d_work, 0, sizeof(int), ctx->stream));
+            if (!ctx->amz_side) {
+                HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->amz_side, hipStreamNonBlocking));
+                for (int k = 0; k < 2; ++k) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->amz_ev[k], hipEventDisableTiming));
+            }
+            // the STREAM kernel goes to the side stream, behind an event: the arena kernel is then the one the hardware starts first (the
+            // other way round the persistent stream workgroups took every CU and the arena tiles waited for them to finish)
+            HIPCHK(ctx, hipEventRecord(ctx->amz_ev[0], ctx->stream));          // the CFA plane, the cleared queue
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->amz_side, ctx->amz_ev[0], 0));
+            a.tile_list = d_templ + 1; a.tile_count = d_templ;
+            a.queue_hdr = nullptr;
+            HIPCHK(ctx, launch_amaze(a, std::min(ctx->amz_narena, cap), ctx->stream));
+        } else {
+            HIPCHK(ctx, hipMemcpyAsync(d_work, d_templ, (size_t)(1 + ctx->amz_narena) * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+        }
         if (ctx->amz_nstream > 0) {
             AmazeStreamArgs sa;
             sa.raw = d.raw; sa.raw_stride = d.raw_stride;
@@ -524,45 +582,20 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
             sa.tiles = d_stream; sa.ntiles = ctx->amz_nstream;
             sa.fallback = d_work;
             sa.queue_hdr = d_queue; sa.queue_words = d_qwords;
-            // persistent workgroups, one per CU (the kernel needs almost all of a CU's LDS): each streams its share of the tiles
-            // back to back
+            // persistent workgroups, one per CU (the kernel needs almost all of a CU's LDS): each streams tiles back to back
             if (ctx->num_cus <= 0) {
                 hipDeviceProp_t prop;
                 HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
                 ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
             }
-            HIPCHK(ctx, launch_amaze_stream(sa, std::min(ctx->amz_nstream, ctx->num_cus), ctx->stream));
+            HIPCHK(ctx, launch_amaze_stream(sa, std::min(ctx->amz_nstream, ctx->num_cus), early ? ctx->amz_side : ctx->stream));
         }
-        // arena kernel over the listed tiles (the static ones plus whatever the stream handed back; the count is read on the device)
-        const int nlist_max = ctx->amz_narena + ctx->amz_nstream;
-        const bool split = mode == 1 && ctx->opt_amaze_split;
-        const int cap = split ? MAX_TILE_WORKGROUPS : 768;
-        const int grid = std::max(1, std::min(nlist_max, cap));
-        rc = ensure(ctx, &ctx->arena, &ctx->arena_bytes, (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float));
-        if (rc) return rc;
-        AmazeArgs a;
-        a.raw = d.raw; a.raw_stride = d.raw_stride;
-        a.red = d.r; a.green = d.g; a.blue = d.b; a.out_stride = d.out_stride;
-        a.arena = ctx->arena;
-        a.W = W; a.H = H; a.ntx = ntx; a.ntiles = ntiles;
-        a.filters = filters;
-        a.clip_pt = clip_pt;
-        a.clip_pt8 = clip_pt8;
-        {
-            float *bb;
-            if ((rc = ensure(ctx, &ctx->bbox, &ctx->bbox_bytes, (size_t)grid * 4 * sizeof(int)))) return rc;
-            bb = ctx->bbox;
-            a.bbox = reinterpret_cast<int *>(bb);
+        if (early) {
+            HIPCHK(ctx, hipEventRecord(ctx->amz_ev[1], ctx->amz_side));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->amz_ev[1], 0));    // the streamed tiles are written, the hand-back list is final
         }
-        // Arena regions that have read-before-write positions on full tiles and therefore must be cleared per tile: vcd, hcd,
-        // vcdalt, hcdalt, cddiffsq, nyquist (bits 4-8, 15): on a full tile every other position is written before it is read, for
-        // every CFA phase, because the phase loops cover fixed index ranges (derivation: DESIGN.md section 10).
-        // tests/test_gpu_demosaic.py re-checks it with poisoned arenas (artgpu_set_option "amaze_poison").  Partial tiles clear everything.
-        a.zero_mask = (unsigned)ctx->opt_amaze_zero_mask;
-        // ... and of the five full-size planes among them only positions within a few pixels of the tile edge (plus the gap behind each
-        // plane): a frame of 4 already passes the poison test, 16 (the discarded tile border) is used.  0: whole planes.
-        a.zero_frame = ctx->opt_amaze_zero_frame;
-        a.split = split ? 1 : 0;
+        // arena kernel over the listed tiles (the static ones unless they went early, plus whatever the stream handed back; the count is
+        // read on the device)
         if (split) {               // one arena per tile, tiles 0..ntiles-1 (the empty ones write nothing)
             a.tile_list = nullptr; a.tile_count = nullptr;
             if (grid < ntiles) return fail(ctx, ARTGPU_EUNSUPPORTED, "amaze_split needs one arena per tile (%d tiles)", ntiles);
@@ -570,10 +603,6 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
             a.tile_list = d_work + 1; a.tile_count = d_work;
         }
         a.queue_hdr = (!split && ctx->amz_nstream > 0) ? d_queue : nullptr;
-        a.queue_words = d_qwords;
-        a.queue_counters = reinterpret_cast<int *>(d_qwords + ctx->amz_nstream);
-        if (ctx->opt_amaze_poison >= 0)   // test hook: fill the arenas with a byte pattern first
-            HIPCHK(ctx, hipMemsetAsync(ctx->arena, ctx->opt_amaze_poison, (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float), ctx->stream));
         HIPCHK(ctx, launch_amaze(a, split ? ntiles : grid, ctx->stream));
         bord = border < 4 ? 3 : 0; // amaze_demosaic_RT.cc:1587-1589
     } else if (method == ARTGPU_BAYER_VNG4) {
@@ -2618,7 +2647,7 @@ int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, con
     // whichever lane runs it (copied on every call -- they may change between calls)
     for (artgpu_ctx *peer : ctx->lanes) {
         peer->curve_tail_kind = ctx->curve_tail_kind; peer->curve_tail_y = ctx->curve_tail_y;
-        peer->opt_amaze_path = ctx->opt_amaze_path; peer->opt_amaze_split = ctx->opt_amaze_split;
+        peer->opt_amaze_path = ctx->opt_amaze_path; peer->opt_amaze_split = ctx->opt_amaze_split; peer->opt_amaze_overlap = ctx->opt_amaze_overlap;
         peer->opt_amaze_zero_mask = ctx->opt_amaze_zero_mask; peer->opt_amaze_zero_frame = ctx->opt_amaze_zero_frame; peer->opt_amaze_poison = ctx->opt_amaze_poison;
         peer->opt_rcd_rows = ctx->opt_rcd_rows; peer->opt_roctx = ctx->opt_roctx; peer->opt_lut_lds = ctx->opt_lut_lds; peer->opt_dn_streams = ctx->opt_dn_streams;
         peer->progress_fn = ctx->progress_fn; peer->progress_user = ctx->progress_user;
