@@ -61,13 +61,34 @@ def _records_to_dicts(rows):
     return out, max(o["elapsed_us"] for o in out) / 1e6
 
 
-def complete_batch_rccl(ctx, dist, device, rank: int, world: int, frames_done: int, status: int, checksum: int, elapsed_s: float):
-    """The same completion step through the library's own entry point: `artgpu_batch_complete` all-gathers the records over an
-    RCCL communicator that this function creates with librccl's C API (the unique id travels over the already initialised
-    torch.distributed group).  Returns (records, max_elapsed_s, "rccl-capi"), or falls back to complete_batch() -- on ALL ranks, agreed
-    by a MIN-reduce -- when some rank cannot load librccl."""
+class RcclComm:
+    """An RCCL communicator created through librccl's C API (what a non-Python host would do); `comm` is the ncclComm_t."""
+
+    def __init__(self, lib, comm):
+        self.lib, self.comm = lib, comm
+
+    def close(self):
+        import ctypes as C
+        if self.comm is not None:
+            self.lib.ncclCommDestroy.argtypes = [C.c_void_p]
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+def open_rccl(ctx, dist, device, rank: int, world: int):
+    """Create the communicator `artgpu_batch_complete` gathers over -- BEFORE the timed region: communicator set-up takes seconds and is
+    not part of the batch.  The unique id travels over the already initialised torch.distributed group.  Every step that can fail on one
+    rank only (loading librccl, ncclGetUniqueId on rank 0, ncclCommInitRank) is followed by a MIN-reduce of "did it work here", so that
+    either ALL ranks get a communicator or ALL of them get None and complete through torch.distributed: a rank that raised or fell back
+    on its own would leave the others hanging in the next collective."""
     import ctypes as C
     import torch
+
+    def agree(flag: bool) -> bool:
+        ok = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return int(ok.item()) == 1
 
     rccl = None
     for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
@@ -76,19 +97,16 @@ def complete_batch_rccl(ctx, dist, device, rank: int, world: int, frames_done: i
             break
         except OSError:
             continue
-    ok = torch.tensor([1 if rccl is not None and hasattr(ctx, "batch_complete") else 0], dtype=torch.int32, device=device)
-    if world > 1:
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if int(ok.item()) == 0:
-        recs, el = complete_batch(dist if world > 1 else None, device, rank, frames_done, status, checksum, elapsed_s)
-        return recs, el, "torch.distributed"
+    if not agree(rccl is not None and hasattr(ctx, "batch_complete")):
+        return None
 
     class UniqueId(C.Structure):
         _fields_ = [("internal", C.c_char * 128)]
 
     uid = UniqueId()
-    if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
-        raise RuntimeError("ncclGetUniqueId failed")
+    got_id = rank != 0 or rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    if not agree(got_id):
+        return None
     wire = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=device)
     if world > 1:
         dist.broadcast(wire, src=0)
@@ -96,13 +114,22 @@ def complete_batch_rccl(ctx, dist, device, rank: int, world: int, frames_done: i
     comm = C.c_void_p()
     rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
     torch.cuda.set_device(device)
-    if rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) != 0:
-        raise RuntimeError("ncclCommInitRank failed")
-    try:
-        cs = checksum - (1 << 64) if checksum >= (1 << 63) else checksum
-        rows = ctx.batch_complete([rank, frames_done, status, cs, int(elapsed_s * 1e6), 0, 0, 0], nranks=world, rccl_comm=comm)
-    finally:
-        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
-        rccl.ncclCommDestroy(comm)
+    inited = rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+    handle = RcclComm(rccl, comm if inited else None)
+    if not agree(inited):
+        handle.close()
+        return None
+    return handle
+
+
+def complete_batch_rccl(ctx, handle, dist, device, rank: int, world: int, frames_done: int, status: int, checksum: int, elapsed_s: float):
+    """The completion step through the library's own entry point: `artgpu_batch_complete` all-gathers the records over the communicator
+    of open_rccl().  handle None (no communicator, on every rank by construction): complete_batch() over torch.distributed.
+    Returns (records, max_elapsed_s, "rccl-capi" | "torch.distributed")."""
+    if handle is None:
+        recs, el = complete_batch(dist if world > 1 else None, device, rank, frames_done, status, checksum, elapsed_s)
+        return recs, el, "torch.distributed"
+    cs = checksum - (1 << 64) if checksum >= (1 << 63) else checksum
+    rows = ctx.batch_complete([rank, frames_done, status, cs, int(elapsed_s * 1e6), 0, 0, 0], nranks=world, rccl_comm=handle.comm)
     recs, el = _records_to_dicts(rows)
     return recs, el, "rccl-capi"

@@ -88,3 +88,18 @@ XTRANS_RGB_CAM = np.array([[1.60, -0.45, -0.15, 0.0],
 
 def xtrans_frame(width: int, height: int, seed: int = 0, noise: int = 1024, clip_patch: bool = True) -> np.ndarray:
     return bayer_frame(width, height, 0, seed, noise, clip_patch, True, xtrans=XTRANS_FUJI)
+
+
+def nyquist_patches_frame(width: int, height: int, filters: int = FILTERS_RGGB, step=(97, 89), size: int = 12, amp: int = 6000,
+                          noise: int = 0, seed: int = 5) -> np.ndarray:
+    """A smooth scene with small patches of 1-px stripes scattered over it, at positions that drift against AMaZE's 128-pixel tile grid:
+    most tiles get a sparse set of Nyquist flags, i.e. a bounding box (amaze_demosaic_RT.cc:806-876) smaller than the tile -- the case in
+    which the streaming kernel has to give a tile a second attempt (about a quarter of the tiles of a 13 MP frame)."""
+    raw = bayer_frame(width, height, filters, seed=seed, noise=noise, clip_patch=False, nyquist_patch=False).astype(np.int64)
+    yy, xx = np.mgrid[0:height, 0:width]
+    py, px = yy % step[1], xx % step[0]
+    oy = (7 * (yy // step[1]) + 3 * (xx // step[0])) % (step[1] - size)
+    ox = (5 * (xx // step[0]) + 11 * (yy // step[1])) % (step[0] - size)
+    inside = (py >= oy) & (py < oy + size) & (px >= ox) & (px < ox + size)
+    raw = raw + np.where(inside, np.where((xx & 1) == 1, amp, -amp), 0)
+    return np.clip(raw, 0, 65535).astype(np.float32)

@@ -62,8 +62,9 @@ def dry_main(args, rank, world, dist, torch, synth) -> None:
         print(json.dumps({"metric": "megapixels/sec end-to-end (AMaZE+FTblockDN+tone), 45 MP Bayer", "dry": True,
                           "value": round(world * args.lanes * args.steps * W * H / 1e6 / max(elapsed, 1e-9), 2), "unit": "MP/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak", "data": "synthetic",
-                          "config": {"workload": "dry run (no device work)", "frames_per_step": world * args.lanes,
+                          "config": {"workload": "dry run (no device work)", "workload_flag": args.workload, "frames_per_step": world * args.lanes,
                                      "parallelism": f"frame-per-gpu x{world}", "completion_records": len(records),
+                                     "completion_via": "torch.distributed (gloo, dry run)" if world > 1 else "single process",
                                      "records": records}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -94,6 +95,9 @@ def main() -> None:
                          "and is not a measurement")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="artgpu_set_option on every context of the run (A/B switches, e.g. dn_streams=0)")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0,
+                    help="after the timed K steps: back-to-back steps for at least this long (the batch queue of simpleprocess.cc:591-611 runs "
+                         "for minutes, the contract region for a fraction of a second at boost clocks); reported as `sustained`.  0: off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     args = ap.parse_args()
@@ -246,6 +250,12 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # The completion gather's RCCL communicator (artgpu_batch_complete, the C-ABI form of the batch's one collective) is opened here,
+    # before the warm-up: its set-up takes seconds and belongs to the job's start, not to the timed steps or to what follows them.
+    from art_amd import batch
+    use_rccl_capi = "WORLD_SIZE" in os.environ and not os.environ.get("ARTGPU_BENCH_TORCH_GATHER")
+    rccl_handle = batch.open_rccl(ctx, dist, dev, rank, world) if use_rccl_capi else None
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -277,20 +287,21 @@ def main() -> None:
         kernel_ms = [ev[0].elapsed_time(ev[1]) for ev in stage_ev]
     # completion step: all-gather of the 64-byte per-rank records (the batch's only collective),
     # elapsed = MAX over ranks
-    from art_amd import batch
     cs = batch.checksum64([int(d_out[1][H // 2, W // 2].item())])
     hard_exit = False
-    if "WORLD_SIZE" in os.environ and not os.environ.get("ARTGPU_BENCH_TORCH_GATHER"):
-        # under a launcher (any N): through the C ABI, over an RCCL communicator (artgpu_batch_complete)
-        # (in a watchdog thread: should the communicator set-up ever hang on some node, every rank times out the same way and the
-        # measurement is completed through torch.distributed instead of being lost)
+    if use_rccl_capi:
+        # under a launcher (any N): through the C ABI, over the RCCL communicator opened before the timed region (artgpu_batch_complete)
+        # (in a watchdog thread: should the gather ever hang on some node, every rank times out the same way and the measurement is
+        # completed through torch.distributed instead of being lost)
         import threading
         box = {}
-        th = threading.Thread(target=lambda: box.update(r=batch.complete_batch_rccl(ctx, dist, dev, rank, world, args.steps, 0, cs, t1 - t0)), daemon=True)
+        th = threading.Thread(target=lambda: box.update(r=batch.complete_batch_rccl(ctx, rccl_handle, dist, dev, rank, world, args.steps, 0, cs, t1 - t0)), daemon=True)
         th.start()
         th.join(timeout=float(os.environ.get("ARTGPU_BENCH_RCCL_TIMEOUT", "180")))
         if "r" in box:
             records, elapsed, gather_via = box["r"]
+            if rccl_handle is not None:
+                rccl_handle.close()
         else:
             print(f"[bench rank {rank}] artgpu_batch_complete over RCCL did not finish: completing through torch.distributed", file=sys.stderr, flush=True)
             records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, args.steps, 0, cs, t1 - t0)
@@ -311,9 +322,10 @@ def main() -> None:
     # profiles/ (KB units; uncorrected -- the kernel's accesses are 4 B per lane, see profiles/r1/README.md)
     traffic, traffic_src, traffic_raw, issue = None, None, None, None
     kname = "xtrans_tiles_kernel" if xtrans else "amaze_stream_kernel" if method == capi.BAYER_AMAZE else "rcd_stream_kernel"
-    pmc_rel = os.path.join("profiles", "r2", {"amaze_stream_kernel": "amaze_v2_pmc_summary.json", "rcd_stream_kernel": "rcd_stream_pmc_summary.json",
-                                              "xtrans_tiles_kernel": "xtrans_v2_pmc_summary.json"}[kname])
+    pmc_rel = os.path.join("profiles", "r3", {"amaze_stream_kernel": "amaze_stream_pmc_summary.json", "rcd_stream_kernel": "rcd_stream_pmc_summary.json",
+                                              "xtrans_tiles_kernel": "xtrans_tiles_pmc_summary.json"}[kname])
     pmc_path = os.path.join(ROOT, pmc_rel)
+    traffic_stale = None
     full_size = (W, H) == ((11648, 8736) if xtrans else (W45, H45))
     if full_size and os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path))
@@ -322,6 +334,9 @@ def main() -> None:
         traffic_raw = {"FETCH_SIZE_KB": pmc["FETCH_SIZE"]["mean_per_launch"], "WRITE_SIZE_KB": pmc["WRITE_SIZE"]["mean_per_launch"]}
         traffic = int((2 * pmc["FETCH_SIZE"]["mean_per_launch"] + pmc["WRITE_SIZE"]["mean_per_launch"]) * 1024)
         traffic_src = pmc_rel + f" (rocprofv3 --pmc passes of `bench.py --workload {args.workload}`, kernel {kname}; FETCH_SIZE doubled)"
+        # the counters describe the kernel as it was when they were taken: the summary carries the digest of its sources
+        from art_amd import srchash
+        traffic_stale = pmc.get("_source_sha256") != srchash.kernel_source_sha256(kname)
         # The streaming demosaicers are bound by instruction issue, not by HBM: instruction counts of the same PMC passes priced with
         # the per-SIMD issue times measured by scripts/ubench/issue_mix.hip (vector 1.19 ns, scalar 1.3 ns when mixed, LDS 1.06 ns;
         # the classes add up on this chip), over the 1024 SIMDs -- the time the kernel cannot go below without fewer instructions.
@@ -380,7 +395,7 @@ def main() -> None:
         "roofline": {
             "bound": "hbm", "kernel": kname,
             "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "traffic_raw_counters": traffic_raw,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "traffic_raw_counters": traffic_raw,
             # the whole step against the same contract (MP/s x 16 B / 8 TB/s), next to the dominant kernel's fraction
             "end_to_end_frac": round(value * 1e6 * ALGO_BYTES_PER_PX / 1e9 / HBM_PEAK_GBS / max(world, 1), 5),
             "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": W * H * ALGO_BYTES_PER_PX,
@@ -389,6 +404,25 @@ def main() -> None:
             "instruction_issue": issue,
         },
     }
+
+    # the same step back to back for several seconds (no per-step barrier: the host runs ahead of the device, as a batch would)
+    if args.sustained_seconds > 0:
+        barrier()
+        s0 = time.perf_counter()
+        ns = 0
+        chunk = max(args.steps, 10)
+        while True:
+            for _ in range(chunk):
+                step()
+            torch.cuda.synchronize(dev)
+            ns += chunk
+            if time.perf_counter() - s0 >= args.sustained_seconds:
+                break
+        s_el = time.perf_counter() - s0
+        s_ms = 1e3 * s_el / ns
+        result["sustained"] = {"seconds": round(s_el, 2), "steps": ns, "ms_per_step": round(s_ms, 4),
+                               "value": round(args.lanes * mp / (s_ms / 1e3), 2), "unit": "MP/s per GPU",
+                               "ratio_to_timed_steps": round(s_ms / (1e3 * elapsed / args.steps), 4)}
 
     # ART's default tone-curve mode is NEUTRAL (curves.cc:854-1038), the headline line uses STD: report the NEUTRAL step beside it
     if pipeline and world == 1 and args.tone == "std" and args.lanes == 1:
@@ -432,16 +466,32 @@ def main() -> None:
                 return oracle_lib.tone_neutral(im, lut, 1.0) if args.tone == "neutral" else oracle_lib.tone_std(im, lut, 1.0, True)
         else:
             fn = (lambda: oracle_lib.amaze(raw, filt, 1.0, 4)) if method == capi.BAYER_AMAZE else (lambda: oracle_lib.rcd(raw, filt))
-        fn()  # warm-up (page faults)
-        ts = []
-        for _ in range(args.cpu_repeats):
-            c0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - c0)
+        # Two timings of the same sample.  "checker": the oracle exactly as the tests use it (double-accumulated direct DCT, one core
+        # per wavelet band).  The headline `cpu_baseline` is its TIMING variant (oracle_fast, never used as a checker): the 64-point DCTs
+        # as an fp32 O(n log n) recursion -- the reference calls FFTW there, FTblockDN.cc:1604-1614 --, all cores on one band at a time
+        # in the shrink passes, sliced MadRgb histograms: closer to what the reference's own OpenMP code does on this host.
+        import ctypes
+        fast_flag = ctypes.c_int.in_dll(oracle_lib.lib(), "oracle_fast")
+
+        def timed(fast, reps):
+            fast_flag.value = fast
+            try:
+                fn()  # warm-up (page faults)
+                ts = []
+                for _ in range(reps):
+                    c0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - c0)
+            finally:
+                fast_flag.value = 0
+            return statistics.median(ts)
+        t_fast = timed(1, args.cpu_repeats)
+        t_chk = timed(0, 1)
+        sample = f"{cw}x{ch} region of the frame through the same stages of the CPU oracle (oracle/*.c, OpenMP), median of {args.cpu_repeats}"
         result["cpu_baseline"] = {
-            "value": round(cw * ch / 1e6 / statistics.median(ts), 2), "unit": "MP/s", "cores": ncores, "kind": "port",
-            "sample": f"{args.cpu_repeats} x {cw}x{ch} region of the frame through the same stages of the CPU oracle (oracle/*.c, OpenMP), median",
-            "note": "a port written for checking, not for speed: its detail-recovery DCT is the direct O(n^2) double-precision form (the "
-                    "reference calls FFTW) and the histogram medians are serial, so it is several times slower than the reference itself "
-                    "(SURVEY probe: the reference's AMaZE alone runs 38.9 MP/s on 8 vCPU).  The GPU/CPU ratio is not a quality measure; "
+            "value": round(cw * ch / 1e6 / t_fast, 2), "unit": "MP/s", "cores": ncores, "kind": "port", "variant": "port-fast (timing only)",
+            "sample": sample,
+            "checker": {"value": round(cw * ch / 1e6 / t_chk, 2), "unit": "MP/s", "cores": ncores, "kind": "port", "variant": "the tests' checker", "sample": sample.replace(f"median of {args.cpu_repeats}", "one run")},
+            "note": "a CPU restatement of the reference's algorithm, not the reference (it cannot be built here: glibmm, lcms2, fftw3 are absent); "
+                    "SURVEY probe for scale: the reference's AMaZE alone runs 38.9 MP/s on 8 vCPU.  The GPU/CPU ratio is not a quality measure; "
                     "roofline.frac and roofline.end_to_end_frac are.",
         }
     if rank == 0:

@@ -19,10 +19,26 @@
 #include "oracle_common.h"
 #include <stdlib.h>
 
+extern int oracle_fast;       /* detail.c: timing variant (one band at a time on all cores, sliced histograms) */
+
 float oracle_madrgb(const float *data, int datalen)
 {
     if (datalen <= 1) return 0;
     int *histo = (int *)calloc(65536, sizeof(int));
+    if (oracle_fast) {
+        /* timing variant: partial histograms of sixteen slices (integer counts: the same histogram) */
+        enum { NS = 16 };
+        int *part = (int *)calloc((size_t)NS * 65536, sizeof(int));
+#pragma omp parallel for num_threads(NS) schedule(static, 1)
+        for (int s = 0; s < NS; ++s) {
+            int *h = part + (size_t)s * 65536;
+            const long long i0 = (long long)datalen * s / NS, i1 = (long long)datalen * (s + 1) / NS;
+            for (long long i = i0; i < i1; ++i) h[(int)fminf(fabsf(data[i]), 65535.f)]++;
+        }
+        for (int s = 0; s < NS; ++s)
+            for (int b = 0; b < 65536; ++b) histo[b] += part[(size_t)s * 65536 + b];
+        free(part);
+    } else
     for (int i = 0; i < datalen; ++i) {
         /* FTblockDN.cc:587: histo[min(65535, abs(static_cast<int>(x)))]; for |x| >= 2^31, Inf and NaN that conversion is undefined
            (x86 gives INT_MIN and an out-of-range index): clamped in float first, which is the same bin for every x an int can hold */
@@ -373,7 +389,7 @@ int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, cons
         float *plane = ch == 0 ? laba : labb;
         oracle_wavelet *d = oracle_wavelet_decompose(plane, w, h, levwav);
         if (p->aggressive) oracle_bishrink_AB(Ldecomp, d, noisevarchrom, ch == 0 ? noisevarab_r : noisevarab_b, useNoiseCCurve, p->autoch, madL, scale);
-#pragma omp parallel for collapse(2) schedule(dynamic)
+#pragma omp parallel for collapse(2) schedule(dynamic) if(!oracle_fast)
         for (int lvl = 0; lvl < levwav; ++lvl)
             for (int dir = 1; dir < 4; ++dir)
                 oracle_shrink_all_AB(Ldecomp, d, lvl, dir, noisevarchrom, ch == 0 ? noisevarab_r : noisevarab_b, useNoiseCCurve, p->autoch, madL[lvl], scale);
@@ -401,7 +417,7 @@ int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, cons
         /* QUALITY_HIGH: WaveletDenoiseAll_BiShrinkL first (L842-973) -- its per-band body is ShrinkAllL's, top level included --
          * then the standard pass; madL is not recomputed in between (L2408-2421) */
         for (int rep = p->aggressive ? 0 : 1; rep < 2; ++rep) {
-#pragma omp parallel for collapse(2) schedule(dynamic)
+#pragma omp parallel for collapse(2) schedule(dynamic) if(!oracle_fast)
             for (int lvl = 0; lvl < maxlvl; ++lvl)
                 for (int dir = 1; dir < 4; ++dir) oracle_shrink_all_L(Ldecomp, lvl, dir, noisevarlum, madL[lvl], scale);
         }

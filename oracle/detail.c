@@ -50,6 +50,63 @@ float oracle_detail_factor(float d)
    implementation gives -- the yardstick tests/test_gpu_denoise.py measures the device's fp32 fast DCT against */
 int oracle_detail_dct_f32 = 0;
 
+/* TIMING variant, never the checker (bench.py's cpu_baseline sets oracle_fast = 1): what a CPU implementation written for speed does
+   where the checker is written for exactness -- the 64-point DCTs as Lee's O(n log n) recursion in fp32 (the reference calls FFTW's
+   r2r plans, FTblockDN.cc:1604-1614), and the per-band loops of the shrink passes handing all cores to one band at a time instead of
+   one core per band (the checker has at most 15 bands to spread over the host's cores).  Results then differ from the checker's by
+   fp32 rounding of the DCT; nothing compares them. */
+int oracle_fast = 0;
+
+static const float LEE_TW[6][32] = {
+    {0.707106781f},
+    {0.5411961f, 1.30656296f},
+    {0.509795579f, 0.601344887f, 0.899976223f, 2.56291545f},
+    {0.502419286f, 0.522498615f, 0.566944035f, 0.646821783f, 0.788154623f, 1.06067769f, 1.7224471f, 5.10114862f},
+    {0.500602998f, 0.50547096f, 0.51544731f, 0.531042591f, 0.553103896f, 0.582934968f, 0.622504123f, 0.674808341f, 0.744536271f, 0.839349645f, 0.972568238f, 1.16943993f, 1.48416462f, 2.05778101f, 3.40760842f, 10.1900081f},
+    {0.500150636f, 0.501358452f, 0.503788726f, 0.507471172f, 0.512451479f, 0.518792713f, 0.526577315f, 0.535909817f, 0.546920438f, 0.559769813f, 0.574655184f, 0.591818536f, 0.611557348f, 0.634238937f, 0.660319808f, 0.690372128f, 0.725120522f, 0.765494165f, 0.812702091f, 0.868344715f, 0.934583597f, 1.01440826f, 1.11207162f, 1.23383274f, 1.38929396f, 1.59397228f, 1.87467598f, 2.28205007f, 2.92462843f, 4.08461108f, 6.79675071f, 20.3738782f}};
+
+/* x <- F, F[k] = sum_n x[n] cos(pi (2n+1) k / (2N)); lg = log2(N) */
+static void lee_fwd(float *x, int N, int lg)
+{
+    if (N == 1) return;
+    float a[32], b[32];
+    const float *tw = LEE_TW[lg - 1];
+    const int h = N / 2;
+    for (int n = 0; n < h; ++n) { a[n] = x[n] + x[N - 1 - n]; b[n] = (x[n] - x[N - 1 - n]) * tw[n]; }
+    lee_fwd(a, h, lg - 1);
+    lee_fwd(b, h, lg - 1);
+    for (int k = 0; k < h; ++k) { x[2 * k] = a[k]; x[2 * k + 1] = k + 1 < h ? b[k] + b[k + 1] : b[k]; }
+}
+/* z <- y, y[n] = sum_k z[k] cos(pi (2n+1) k / (2N)) */
+static void lee_inv(float *z, int N, int lg)
+{
+    if (N == 1) return;
+    float a[32], b[32];
+    const float *tw = LEE_TW[lg - 1];
+    const int h = N / 2;
+    for (int k = 0; k < h; ++k) { a[k] = z[2 * k]; b[k] = k > 0 ? z[2 * k + 1] + z[2 * k - 1] : z[1]; }
+    lee_inv(a, h, lg - 1);
+    lee_inv(b, h, lg - 1);
+    for (int n = 0; n < h; ++n) { const float t = b[n] * tw[n]; z[n] = a[n] + t; z[N - 1 - n] = a[n] - t; }
+}
+/* REDFT10 = 2 lee_fwd; REDFT01(X) = lee_inv(X[0], 2 X[1], 2 X[2], ...) -- rows, then columns */
+static void dct2d_fast(float *blk, int inverse)
+{
+    float line[DTS];
+    for (int pass = 0; pass < 2; ++pass)
+        for (int r = 0; r < DTS; ++r) {
+            for (int j = 0; j < DTS; ++j) line[j] = pass == 0 ? blk[r * DTS + j] : blk[j * DTS + r];
+            if (!inverse) {
+                lee_fwd(line, DTS, 6);
+                for (int j = 0; j < DTS; ++j) line[j] *= 2.f;
+            } else {
+                for (int j = 1; j < DTS; ++j) line[j] *= 2.f;
+                lee_inv(line, DTS, 6);
+            }
+            for (int j = 0; j < DTS; ++j) { if (pass == 0) blk[r * DTS + j] = line[j]; else blk[j * DTS + r] = line[j]; }
+        }
+}
+
 static void dct2d_f32(float *blk, const double *costab, int inverse)
 {
     float tmp[DTS * DTS];
@@ -74,6 +131,7 @@ static void dct2d_f32(float *blk, const double *costab, int inverse)
 
 static void dct2d(float *blk, const double *costab, int inverse)
 {
+    if (oracle_fast) { dct2d_fast(blk, inverse); return; }
     if (oracle_detail_dct_f32) { dct2d_f32(blk, costab, inverse); return; }
     /* costab[k*64+j] = cos(pi*(j+0.5)*k/64).  Rows then columns; float storage between passes. */
     float tmp[DTS * DTS];
@@ -204,11 +262,14 @@ void oracle_detail_recovery_ex(int width, int height, float *L, const float *Lin
             for (int k = 0; k < DTS * DTS; ++k) blk[k] = blk[k] * (1.0f - oracle_xexpf_v(-sqrf(nbrwt[k]) / factor[k]));
             dct2d(blk, costab, 1);
         }
+    /* every pixel takes its contributions in the reference's order (vblk ascending, then hblk ascending); rows are independent */
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int y = 0; y < height; ++y)
     for (int vblk = 0; vblk < numblox_H; ++vblk) {
         const int top = (vblk - DBLKRAD) * DOFF;
-        for (int i = 0; i < DTS; ++i) {
-            const int y = top + i;
-            if (y < 0 || y >= height) continue;
+        {
+            const int i = y - top;
+            if (i < 0 || i >= DTS) continue;
             for (int hblk = 0; hblk < numblox_W; ++hblk) {
                 const int left = (hblk - DBLKRAD) * DOFF;
                 const float *blk = blocks + ((size_t)vblk * numblox_W + hblk) * DTS * DTS;

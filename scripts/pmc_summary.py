@@ -14,5 +14,12 @@ for d in sys.argv[3:]:
                 continue
             per[row["Counter_Name"]][(f, row.get("Dispatch_Id", ""))] += float(row["Counter_Value"])
 res = {c: {"launches": len(v), "mean_per_launch": sum(v.values()) / len(v)} for c, v in sorted(per.items())}
+# the digest of the kernel's sources as they are now (bench.py compares it with the sources of the day it runs: `traffic_stale`)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from art_amd import srchash
+for k in srchash.KERNEL_SOURCES:
+    if k in kern or kern in k:
+        res["_kernel"] = k
+        res["_source_sha256"] = srchash.kernel_source_sha256(k)
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res))

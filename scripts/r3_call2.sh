@@ -4,6 +4,6 @@ python -m pytest tests/test_gpu_denoise.py tests/test_gpu_pipeline.py tests/test
 tail -3 gpurun_out/r3c2/pytest.log
 for i in 1 2 3; do
 for s in 0 1; do
-python bench.py --no-cpu-baseline --steps 10 --warmup 3 --opt dn_streams=$s 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('dn_streams=$s', d['ms_per_step'], d['config']['stage_ms'])"
+python bench.py --no-cpu-baseline --sustained-seconds 0 --steps 10 --warmup 3 --opt dn_streams=$s 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('dn_streams=$s', d['ms_per_step'], d['config']['stage_ms'])"
 done
 done

@@ -161,3 +161,22 @@ def test_amaze_phase_per_kernel_path_is_identical(gpu_ctx, amaze_options):
     gpu_ctx.demosaic_bayer(capi.BAYER_AMAZE, capi.host_plane(raw), filt, 1.0, 4, capi.host_rgb(out))
     for o, r in zip(out, ref):
         assert np.array_equal(o.view(np.uint32), r.view(np.uint32))
+
+
+@pytest.mark.parametrize("noise", [0, 64])
+def test_amaze_redo_queue_under_load(gpu_ctx, noise):
+    """Hundreds of second attempts in one frame, several tiles per workgroup, ten calls in a row: a 13 MP scene of scattered Nyquist
+    patches (synth.nyquist_patches_frame) gives most tiles a partial Nyquist box, so about a quarter of them go through the redo queue
+    -- published by one workgroup, streamed again by whichever runs out of tiles first, usually on another XCD -- while the tiles
+    themselves are handed out by the shared counter.  Every call has to give the oracle's bits, and the counters have to show that the
+    path was really taken (0: entries pulled, 2: entries published, 3: handed to the arena kernel instead)."""
+    from art_amd import capi
+    w, h, filt = 4224, 3168, synth.FILTERS_RGGB
+    raw = synth.nyquist_patches_frame(w, h, filt, noise=noise)
+    ref = oracle_lib.amaze(raw, filt, 1.0, 4)
+    for call in range(10):
+        got = gpu_ctx.demosaic_bayer_host(capi.BAYER_AMAZE, raw, filt, 1.0, 4)
+        assert _diff(got, ref) == [0, 0, 0], f"call {call}"
+        pulled, published, to_arena = (gpu_ctx.get_option(f"amaze_counter{k}") for k in (0, 2, 3))
+        assert published >= 100, published
+        assert pulled + to_arena >= published           # every published entry was taken by a stream workgroup or by the arena kernel

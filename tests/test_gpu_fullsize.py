@@ -106,7 +106,7 @@ def test_config4_stages_45mp_bit_exact_without_dct(gpu_ctx):
         assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))
 
 
-def test_config5_xtrans_100mp_bit_exact(gpu_ctx):
+def test_config5_xtrans_and_ftblockdn_100mp_bit_exact(gpu_ctx):
     W, H = 11648, 8736
     raw = synth.xtrans_frame(W, H, seed=0)
     d_raw = torch.from_numpy(raw).cuda()
@@ -115,6 +115,28 @@ def test_config5_xtrans_100mp_bit_exact(gpu_ctx):
     gpu_ctx.synchronize()
     ref = O.xtrans_demosaic(raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, 3, True)
     for t, r in zip(d_out, ref):
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))
+    # ... and the rest of BASELINE configs[4] on top, at full size: getImage + matrix (border 7), ImProcFunctions::denoise (FTblockDN
+    # wavelet shrinkage luma + chroma; the tolerance-checked DCT stage off on both sides), exposure, tone curve -- bit for bit
+    iw, ih = W - 14, H - 14
+    d_img, img = _dev_planes(ih, iw)
+    gpu_ctx.get_image(out, 7, 7, MUL, True, MAT, img)
+    curve, _ = capi.noise_curve_lut()
+    tp = capi.DenoiseToolParams(capi.DenoiseParams(40.0, 50.0, 0, 15.0, 0.0, 0.0, 1.7, 0, 0, 0), 0, 3, 0, 80)
+    gpu_ctx.improc_denoise(img, tp, O.REC2020_WS_D, ecomp=0.3, calclum_mat=MAT, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    gpu_ctx.exposure(img, float(np.float32(2.0 ** 0.3)), 0.0)
+    x = np.arange(65536, dtype=np.float64) / 65535.0
+    lut = ((1.0 - np.cos(np.pi * x ** 0.7)) / 2.0 * 65535.0).astype(np.float32)
+    gpu_ctx.tone_curve(img, lut, 1.0, True)
+    gpu_ctx.synchronize()
+    del d_out
+    o = O.get_image(ref, 7, 7, iw, ih, MUL, True)
+    del ref
+    o = O.convert_color_space(o, MAT)
+    o = O.improc_denoise(o, calclum_mat=MAT, noise_c_curve=curve, smoothing=False, ecomp=0.3, detail_recovery=False)
+    o = O.exposure(o, float(np.float32(2.0 ** 0.3)), 0.0)
+    o = O.tone_std(o, lut, 1.0, True)
+    for t, r in zip(d_img, o):
         assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))
 
 

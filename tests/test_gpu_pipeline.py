@@ -156,6 +156,43 @@ def test_batch_lanes_give_the_same_bits(lanes):
         ctx.close()
 
 
+def test_batch_lanes_inherit_the_context_settings():
+    """The lanes are the context as far as the caller can tell: a curve tail above 65535 (artgpu_set_curve_tail) and the options apply to
+    every frame whichever lane runs it -- with white_point > 1 and bright frames the output of a lane that missed the setting would differ
+    (or the call would fail: the default tail kind refuses white_point > 1)."""
+    w, h = 392, 296
+    lut = _lut()
+    p = _params(lut, 0)
+    p.white_point = 1.6
+    raws = [np.minimum(synth.bayer_frame(w, h, synth.FILTERS_RGGB, seed=s, noise=1500) * np.float32(1.7), np.float32(65535.0)) for s in (21, 22, 23, 24, 25, 26, 27)]
+    ctx = capi.Context(0)
+    try:
+        ctx.set_curve_tail(1, 0.93)
+        ctx.set_option("lut_lds", 0)
+        ref = [[np.zeros((h - 8, w - 8), np.float32) for _ in range(3)] for _ in raws]
+        ctx.batch_run([capi.host_plane(r) for r in raws], p, [capi.host_rgb(o) for o in ref])
+        ctx.set_batch_lanes(3)
+        outs = [[np.zeros((h - 8, w - 8), np.float32) for _ in range(3)] for _ in raws]
+        ctx.batch_run([capi.host_plane(r) for r in raws], p, [capi.host_rgb(o) for o in outs])
+        for o, r in zip(outs, ref):
+            for a, b in zip(o, r):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and a.max() > 0
+        # the setting changes between calls: the lanes follow
+        ctx.set_curve_tail(2, 1.0)
+        ctx.set_batch_lanes(1)
+        ref2 = [[np.zeros((h - 8, w - 8), np.float32) for _ in range(3)] for _ in raws]
+        ctx.batch_run([capi.host_plane(r) for r in raws], p, [capi.host_rgb(o) for o in ref2])
+        ctx.set_batch_lanes(3)
+        outs2 = [[np.zeros((h - 8, w - 8), np.float32) for _ in range(3)] for _ in raws]
+        ctx.batch_run([capi.host_plane(r) for r in raws], p, [capi.host_rgb(o) for o in outs2])
+        for o, r in zip(outs2, ref2):
+            for a, b in zip(o, r):
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert any((a != b).any() for o, r in zip(ref, ref2) for a, b in zip(o, r))        # the tail does show in these frames
+    finally:
+        ctx.close()
+
+
 def test_batch_complete_over_rccl(gpu_ctx):
     """artgpu_batch_complete: the completion all-gather of a multi-GPU batch over the caller's RCCL communicator.  One GPU here, so the
     communicator has one rank (created through librccl's C API the way a host application would); the two-rank exchange itself is

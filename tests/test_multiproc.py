@@ -31,8 +31,8 @@ def _worker(rank, world, port, nframes, q):
 
 
 def _worker_rccl_fallback(rank, world, port, q):
-    """complete_batch_rccl with a context that cannot do the RCCL gather on one rank only: the MIN-reduce has to send BOTH ranks to the
-    torch.distributed path (a one-sided fallback would deadlock)."""
+    """open_rccl with a context that cannot do the RCCL gather on one rank only: the MIN-reduce has to leave BOTH ranks without a
+    communicator, i.e. on the torch.distributed path (a one-sided fallback would deadlock)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -42,7 +42,9 @@ def _worker_rccl_fallback(rank, world, port, q):
     ctx = Ctx()
     if rank == 0:
         ctx.batch_complete = lambda *a, **k: (_ for _ in ()).throw(AssertionError("must not be called"))
-    recs, tmax, via = batch.complete_batch_rccl(ctx, dist, torch.device("cpu"), rank, world, 3 + rank, 0, 1000 + rank, 0.001 * (rank + 1))
+    handle = batch.open_rccl(ctx, dist, torch.device("cpu"), rank, world)
+    assert handle is None
+    recs, tmax, via = batch.complete_batch_rccl(ctx, handle, dist, torch.device("cpu"), rank, world, 3 + rank, 0, 1000 + rank, 0.001 * (rank + 1))
     q.put((rank, recs, tmax, via))
     dist.destroy_process_group()
 
@@ -114,6 +116,30 @@ def test_bench_py_two_rank_path_dry():
     d = json.loads(lines[0])
     assert d["dry"] is True and d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert d["config"]["completion_records"] == 2 and d["config"]["frames_per_step"] == 2
+    assert d["config"]["completion_via"] == "torch.distributed (gloo, dry run)"
     recs = d["config"]["records"]
     assert [x["rank"] for x in recs] == [0, 1] and all(x["frames"] == 3 and x["status"] == 0 for x in recs)
     assert recs[0]["checksum"] != recs[1]["checksum"]        # rank r works on frame r of the batch (different seeds)
+
+
+@pytest.mark.parametrize("gpus,workload", [(8, "c3"), (2, "c4")])
+def test_bench_py_rank_path_dry_world8_and_config4(gpus, workload):
+    """BASELINE configs[3] is eight ranks of the c4 per-frame pipe: the launcherless start, the sharding and the completion gather of
+    `bench.py --gpus 8` (and of `--workload c4`) on the CPU -- gloo instead of RCCL, no device work."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--dry", "--workload", workload, "--steps", "2", "--warmup", "1",
+                        "--width", "256", "--height", "192"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry"] is True and d["n_gpus"] == gpus and d["scaling"] == "weak"
+    c = d["config"]
+    assert c["completion_records"] == gpus and c["frames_per_step"] == gpus and c["completion_via"] == "torch.distributed (gloo, dry run)"
+    assert c["workload_flag"] == workload
+    assert [x["rank"] for x in c["records"]] == list(range(gpus)) and all(x["frames"] == 2 and x["status"] == 0 for x in c["records"])
+    assert len({x["checksum"] for x in c["records"]}) == gpus          # rank r works on frame r of the batch
