@@ -19,7 +19,16 @@
 #include "oracle_common.h"
 #include <stdlib.h>
 
-extern int oracle_fast;       /* detail.c: timing variant (one band at a time on all cores, sliced histograms) */
+extern int oracle_fast;       /* detail.c: timing variant */
+#include <omp.h>
+/* timing variant: the band loops stay one task per band (at most 15), and each task's inner loops get their own team -- cores / 15
+   threads -- instead of running on the task's single thread (nested regions are inactive in the checker: max-active-levels 1) */
+static void fast_inner_team(void)
+{
+    if (!oracle_fast) return;
+    int t = omp_get_num_procs() / 15;
+    omp_set_num_threads(t < 1 ? 1 : (t > 16 ? 16 : t));
+}
 
 float oracle_madrgb(const float *data, int datalen)
 {
@@ -141,6 +150,7 @@ static int blur_radius(int level, double scale)
 
 void oracle_shrink_all_L(oracle_wavelet *L, int level, int dir, const float *noisevarlum, const float *madL3, double scale)
 {
+    fast_inner_team();
     const float eps = 0.01f;
     const int N = L->w2 * L->h2, nv4 = (N / 4) * 4;
     float *c = L->band[level][dir];
@@ -173,6 +183,7 @@ void oracle_shrink_all_L(oracle_wavelet *L, int level, int dir, const float *noi
 void oracle_shrink_all_AB(const oracle_wavelet *L, oracle_wavelet *ab, int level, int dir, const float *noisevarchrom,
                           float noisevar_ab, int useNoiseCCurve, int autoch, const float *madL3, double scale)
 {
+    fast_inner_team();
     const float eps = 0.01f;
     if (autoch && noisevar_ab <= 0.001f) noisevar_ab = 0.02f;
     const int N = ab->w2 * ab->h2, nv4 = (N / 4) * 4;
@@ -299,6 +310,7 @@ int oracle_rgb_denoise(float *const img[3], size_t stride, int w, int h, const o
 int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, const oracle_denoise_params *p,
                           const float wpi[9], const float *noisevarchrom_in, float *Lin_out, float *Lden_out, int detail_recovery, float *resid_out)
 {
+    omp_set_max_active_levels(oracle_fast ? 2 : 1);      /* (timing variant: see fast_inner_team) */
     const double scale = p->scale > 0 ? p->scale : 1.0;
     const float noiseluma = (float)p->luminance;
     /* the luminance noise curve is never set in ART (ipdenoise.cc:1108 leaves noiseLCurve empty) */
@@ -389,7 +401,7 @@ int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, cons
         float *plane = ch == 0 ? laba : labb;
         oracle_wavelet *d = oracle_wavelet_decompose(plane, w, h, levwav);
         if (p->aggressive) oracle_bishrink_AB(Ldecomp, d, noisevarchrom, ch == 0 ? noisevarab_r : noisevarab_b, useNoiseCCurve, p->autoch, madL, scale);
-#pragma omp parallel for collapse(2) schedule(dynamic) if(!oracle_fast)
+#pragma omp parallel for collapse(2) schedule(dynamic)
         for (int lvl = 0; lvl < levwav; ++lvl)
             for (int dir = 1; dir < 4; ++dir)
                 oracle_shrink_all_AB(Ldecomp, d, lvl, dir, noisevarchrom, ch == 0 ? noisevarab_r : noisevarab_b, useNoiseCCurve, p->autoch, madL[lvl], scale);
@@ -417,7 +429,7 @@ int oracle_rgb_denoise_ex(float *const img[3], size_t stride, int w, int h, cons
         /* QUALITY_HIGH: WaveletDenoiseAll_BiShrinkL first (L842-973) -- its per-band body is ShrinkAllL's, top level included --
          * then the standard pass; madL is not recomputed in between (L2408-2421) */
         for (int rep = p->aggressive ? 0 : 1; rep < 2; ++rep) {
-#pragma omp parallel for collapse(2) schedule(dynamic) if(!oracle_fast)
+#pragma omp parallel for collapse(2) schedule(dynamic)
             for (int lvl = 0; lvl < maxlvl; ++lvl)
                 for (int dir = 1; dir < 4; ++dir) oracle_shrink_all_L(Ldecomp, lvl, dir, noisevarlum, madL[lvl], scale);
         }
