@@ -120,6 +120,7 @@ def _load():
     lib.artgpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_long]
     lib.artgpu_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_long)]
     lib.artgpu_set_curve_tail.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    lib.artgpu_set_curve_tail_parametric.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     lib.artgpu_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.artgpu_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
     lib.artgpu_scratch_bytes.argtypes = [C.c_void_p]
@@ -182,7 +183,7 @@ def _load():
 
 LIB = _load()
 
-EXPORTS = ["artgpu_set_progress_callback", "artgpu_set_option", "artgpu_get_option", "artgpu_set_curve_tail", "artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
+EXPORTS = ["artgpu_set_progress_callback", "artgpu_set_option", "artgpu_get_option", "artgpu_set_curve_tail", "artgpu_set_curve_tail_parametric", "artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
            "artgpu_synchronize", "artgpu_enable_timing", "artgpu_get_timings", "artgpu_scratch_bytes",
            "artgpu_demosaic_bayer", "artgpu_border_interpolate2", "artgpu_get_image",
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
@@ -238,6 +239,11 @@ class Context:
     def set_curve_tail(self, kind: int, y_last: float = 1.0):
         """0 LUT clip (no Curve object), 1 constant y_last, 2 identity, 3 host (default): curves::setLutVal above 65535"""
         self._chk(LIB.artgpu_set_curve_tail(self._h, int(kind), float(y_last)))
+
+    def set_curve_tail_parametric(self, p):
+        """DiagonalCurve's DCT_Parametric parameter vector (8 or 9 doubles, p[0] = the kind): getVal above 1.0 on the device"""
+        arr = (C.c_double * len(p))(*[float(v) for v in p])
+        self._chk(LIB.artgpu_set_curve_tail_parametric(self._h, arr, len(p)))
 
     def enable_timing(self, on: bool = True):
         self._chk(LIB.artgpu_enable_timing(self._h, int(on)))

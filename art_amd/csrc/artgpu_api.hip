@@ -69,6 +69,7 @@ struct artgpu_ctx {
     int *rcd_counter = nullptr;    // RCD streaming kernel: tile counter
     int curve_tail_kind = ARTGPU_CURVE_TAIL_HOST;   // artgpu_set_curve_tail
     double curve_tail_y = 1.0;
+    ParamCurve curve_tail_pc = {};
     float *lut = nullptr; // 65536-entry tone LUT on the device
     size_t lut_bytes = 0;
     std::vector<float> lut_host;           // what ctx->lut holds (a curve that comes back unchanged is not uploaded again)
@@ -334,9 +335,21 @@ int artgpu_synchronize(artgpu_ctx *ctx)
 int artgpu_set_curve_tail(artgpu_ctx *ctx, int kind, double y_last)
 {
     if (!ctx) return ARTGPU_EINVAL;
-    if (kind < ARTGPU_CURVE_TAIL_LUT || kind > ARTGPU_CURVE_TAIL_HOST) return fail(ctx, ARTGPU_EINVAL, "set_curve_tail: kind %d", kind);
+    if (kind < ARTGPU_CURVE_TAIL_LUT || kind > ARTGPU_CURVE_TAIL_HOST) return fail(ctx, ARTGPU_EINVAL, "set_curve_tail: kind %d (a parametric curve: artgpu_set_curve_tail_parametric)", kind);
     ctx->curve_tail_kind = kind;
     ctx->curve_tail_y = y_last;
+    return ARTGPU_OK;
+}
+
+int artgpu_set_curve_tail_parametric(artgpu_ctx *ctx, const double *p, int np)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    // DiagonalCurve's constructor (diagonalcurves.cc:106-131): eight or nine parameters behind the kind; a curve whose four slider values
+    // are all zero is the identity there (and `identity` curves never reach setLutVal with a Curve object: ARTGPU_CURVE_TAIL_LUT)
+    if (!p || (np != 8 && np != 9)) return fail(ctx, ARTGPU_EINVAL, "set_curve_tail_parametric: 8 or 9 parameters (p[0] = DCT_Parametric)");
+    if (p[4] == 0.0 && p[5] == 0.0 && p[6] == 0.0 && p[7] == 0.0) return fail(ctx, ARTGPU_EINVAL, "set_curve_tail_parametric: an identity curve has no Curve object (ARTGPU_CURVE_TAIL_LUT)");
+    pc_init(ctx->curve_tail_pc, p, np);
+    ctx->curve_tail_kind = ARTGPU_CURVE_TAIL_PARAMETRIC;
     return ARTGPU_OK;
 }
 
@@ -790,7 +803,7 @@ int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float 
     for (int k = 0; k < 3; ++k) a.dst[k] = d.p[k];
     a.dst_stride = d.stride; a.w = d.w; a.h = d.h;
     a.do_clip = filmlike_clip ? 1 : 0; a.whitept = whitept;
-    a.tail_kind = ctx->curve_tail_kind == ARTGPU_CURVE_TAIL_HOST ? 0 : ctx->curve_tail_kind; a.tail_y = ctx->curve_tail_y;
+    a.tail_kind = ctx->curve_tail_kind == ARTGPU_CURVE_TAIL_HOST ? 0 : ctx->curve_tail_kind; a.tail_y = ctx->curve_tail_y; a.tail_pc = ctx->curve_tail_pc;
     if (lut65536) {
         if ((rc = upload_curve(ctx, lut65536))) return rc;
         a.lut = ctx->lut;
@@ -2053,7 +2066,7 @@ int artgpu_tone_curve_neutral(artgpu_ctx *ctx, artgpu_rgb *image, const float *l
     a.lut = ctx->lut; a.pq = pq; a.pq_inv = pq + 65536; a.hues = pq + 2 * 65536;
     for (int k = 0; k < 9; ++k) { a.ws[k] = (float)st->ws[k]; a.iws[k] = (float)st->iws[k]; a.to_out[k] = st->to_out[k]; a.to_work[k] = st->to_work[k]; }
     a.whitecoeff = whitecoeff;
-    a.tail_kind = ctx->curve_tail_kind == ARTGPU_CURVE_TAIL_HOST ? 0 : ctx->curve_tail_kind; a.tail_y = ctx->curve_tail_y;
+    a.tail_kind = ctx->curve_tail_kind == ARTGPU_CURVE_TAIL_HOST ? 0 : ctx->curve_tail_kind; a.tail_y = ctx->curve_tail_y; a.tail_pc = ctx->curve_tail_pc;
     if (fresh) HIPCHK(ctx, launch_neutral_hues(a, ctx->stream));
     a.no_lds_lut = !ctx->opt_lut_lds;
     HIPCHK(ctx, launch_tone_neutral(a, ctx->stream));
@@ -2646,7 +2659,7 @@ int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, con
     // the lanes are this context as far as the caller can tell: its options, curve tail and progress listener apply to every frame,
     // whichever lane runs it (copied on every call -- they may change between calls)
     for (artgpu_ctx *peer : ctx->lanes) {
-        peer->curve_tail_kind = ctx->curve_tail_kind; peer->curve_tail_y = ctx->curve_tail_y;
+        peer->curve_tail_kind = ctx->curve_tail_kind; peer->curve_tail_y = ctx->curve_tail_y; peer->curve_tail_pc = ctx->curve_tail_pc;
         peer->opt_amaze_path = ctx->opt_amaze_path; peer->opt_amaze_split = ctx->opt_amaze_split; peer->opt_amaze_overlap = ctx->opt_amaze_overlap;
         peer->opt_amaze_zero_mask = ctx->opt_amaze_zero_mask; peer->opt_amaze_zero_frame = ctx->opt_amaze_zero_frame; peer->opt_amaze_poison = ctx->opt_amaze_poison;
         peer->opt_rcd_rows = ctx->opt_rcd_rows; peer->opt_roctx = ctx->opt_roctx; peer->opt_lut_lds = ctx->opt_lut_lds; peer->opt_dn_streams = ctx->opt_dn_streams;

@@ -11,6 +11,7 @@
 //   fc              : RawImage::FC (rtengine/rawimage.h:186-189)
 #pragma once
 #include <hip/hip_runtime.h>
+#include "paramcurve.h"
 #include <stdint.h>
 
 namespace artgpu {
@@ -43,10 +44,12 @@ __device__ __forceinline__ float xdivf(float d, int n)
     return __int_as_float(i);
 }
 // curves::setLutVal above the LUT (curves.h:228-230): curve->getVal(val / 65535.f) * 65535.f with getVal = the last point's y
-// (kind 1: DCT_Linear / DCT_Spline / DCT_CatmullRom) or t (kind 2: DCT_Empty, DCT_NURBS beyond its hash), diagonalcurves.cc:443-561
-__device__ __forceinline__ float curve_tail(int kind, double y_last, float val)
+// (kind 1: DCT_Linear / DCT_Spline / DCT_CatmullRom), t (kind 2: DCT_Empty, DCT_NURBS beyond its hash) or the analytic form of a
+// DCT_Parametric curve (kind 4, paramcurve.h), diagonalcurves.cc:443-561
+__device__ __forceinline__ float curve_tail(int kind, double y_last, const ParamCurve &pc, float val)
 {
     const double t = (double)(val / 65535.f);
+    if (kind == 4) return (float)(pc_getval(pc, t) * (double)65535.f);
     return (float)((kind == 1 ? y_last : t) * (double)65535.f);
 }
 __device__ __forceinline__ int ngroups(int start, int bound, int step)

@@ -2,6 +2,7 @@
 // .hip kernels and the C-ABI host code (artgpu_api.hip).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "paramcurve.h"
 #include <vector>
 #include <stddef.h>
 #include <stdint.h>
@@ -146,8 +147,9 @@ struct PixArgs {
     float exp_scale, black;
     const float *lut;      // tone: 65536-entry LUT on the device (nullable)
     float whitept;
-    int tail_kind;         // curves::setLutVal above 65535 (artgpu_set_curve_tail): 0 LUT clip, 1 constant, 2 identity
+    int tail_kind;         // curves::setLutVal above 65535 (artgpu_set_curve_tail): 0 LUT clip, 1 constant, 2 identity, 4 parametric
     double tail_y;
+    ParamCurve tail_pc;    // kind 4 (artgpu_set_curve_tail_parametric)
     int no_lds_lut;        // artgpu_set_option "lut_lds" 0: the plain one-lane-per-pixel kernels (table lookups served by L2) on every frame size
 };
 hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s);
@@ -282,6 +284,7 @@ struct NeutralArgs {
     float whitecoeff;
     int tail_kind;               // as in PixArgs
     double tail_y;
+    ParamCurve tail_pc;
     int no_lds_lut;              // as in PixArgs
 };
 hipError_t launch_neutral_hues(const NeutralArgs &a, hipStream_t s);

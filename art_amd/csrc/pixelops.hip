@@ -113,9 +113,9 @@ __global__ void __launch_bounds__(256) tone_std_kernel(PixArgs a)
         float r = a.dst[0][di], g = a.dst[1][di], b = a.dst[2][di];
         if (a.do_clip) filmlike_clip_px(r, g, b, Lmax);
         if (a.lut) {
-            r = (a.tail_kind && r > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, r) : lutf(a.lut, 65536, std_max(r, 0.f));
-            g = (a.tail_kind && g > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, g) : lutf(a.lut, 65536, std_max(g, 0.f));
-            b = (a.tail_kind && b > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, b) : lutf(a.lut, 65536, std_max(b, 0.f));
+            r = (a.tail_kind && r > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, r) : lutf(a.lut, 65536, std_max(r, 0.f));
+            g = (a.tail_kind && g > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, g) : lutf(a.lut, 65536, std_max(g, 0.f));
+            b = (a.tail_kind && b > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, b) : lutf(a.lut, 65536, std_max(b, 0.f));
         }
         a.dst[0][di] = r; a.dst[1][di] = g; a.dst[2][di] = b;
     }
@@ -146,9 +146,9 @@ __global__ void __launch_bounds__(1024) tone_std_lds_kernel(PixArgs a)
                 const size_t di = (size_t)y * a.dst_stride + x;
                 float rr = r[k], gg = g[k], bb = b[k];
                 if (a.do_clip) filmlike_clip_px(rr, gg, bb, Lmax);
-                rr = (a.tail_kind && rr > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, rr) : lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(rr, 0.f));
-                gg = (a.tail_kind && gg > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, gg) : lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(gg, 0.f));
-                bb = (a.tail_kind && bb > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, bb) : lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(bb, 0.f));
+                rr = (a.tail_kind && rr > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, rr) : lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(rr, 0.f));
+                gg = (a.tail_kind && gg > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, gg) : lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(gg, 0.f));
+                bb = (a.tail_kind && bb > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, bb) : lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(bb, 0.f));
                 a.dst[0][di] = rr; a.dst[1][di] = gg; a.dst[2][di] = bb;
             }
         }

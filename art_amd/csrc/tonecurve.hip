@@ -190,7 +190,7 @@ __device__ __forceinline__ void neutral_px(const NeutralArgs &a, const NeutralCo
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             float nt = rgb[j] * 65535.f;
-            nt = (a.tail_kind && nt > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, nt) : lutf_lookup<true>(a.lut, 65536, std_max(nt, 0.f));   // setLutVal
+            nt = (a.tail_kind && nt > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, nt) : lutf_lookup<true>(a.lut, 65536, std_max(nt, 0.f));   // setLutVal
             rgb[j] = nt / 65535.f;
         }
         rgb2jzczhz(pq, rgb[0], rgb[1], rgb[2], jch[0], jch[1], jch[2], a.ws);

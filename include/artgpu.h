@@ -169,14 +169,23 @@ int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float 
  *   ARTGPU_CURVE_TAIL_LUT       no Curve object (ToneCurve::curve == nullptr): the LUT's last entry
  *   ARTGPU_CURVE_TAIL_CONSTANT  DCT_Linear / DCT_Spline / DCT_CatmullRom: the last point's y (`y_last`, L476-477, L514-515)
  *   ARTGPU_CURVE_TAIL_IDENTITY  DCT_Empty, DCT_NURBS beyond its hash table: t itself (L529-535, L557-560)
- *   ARTGPU_CURVE_TAIL_HOST      (default) anything else, e.g. DCT_Parametric: not evaluated on the device -- artgpu_tone_curve then
- *                               returns ARTGPU_EUNSUPPORTED for whitept > 1; values above 65535 that reach the curve because
- *                               filmlike_clip is off take the LUT's last entry (set the tail if the image can hold such values). */
+ *   ARTGPU_CURVE_TAIL_PARAMETRIC  DCT_Parametric: the analytic form (L448-470), evaluated per pixel on the device; set with
+ *                               artgpu_set_curve_tail_parametric, which takes the curve's parameter vector
+ *   ARTGPU_CURVE_TAIL_HOST      (default) the adapter has not said: artgpu_tone_curve then returns ARTGPU_EUNSUPPORTED for
+ *                               whitept > 1; values above 65535 that reach the curve because filmlike_clip is off take the LUT's
+ *                               last entry (set the tail if the image can hold such values). */
 #define ARTGPU_CURVE_TAIL_LUT 0
 #define ARTGPU_CURVE_TAIL_CONSTANT 1
 #define ARTGPU_CURVE_TAIL_IDENTITY 2
 #define ARTGPU_CURVE_TAIL_HOST 3
+#define ARTGPU_CURVE_TAIL_PARAMETRIC 4
 int artgpu_set_curve_tail(artgpu_ctx *ctx, int kind, double y_last);
+/* DiagonalCurve(p) with p[0] == DCT_Parametric (rtengine/diagonalcurves.cc:106-131): `p` is the curve's parameter vector as the
+ * reference's constructor receives it -- p[0] the kind, p[1..3] the three zone boundaries, p[4..7] highlights / lights / darks /
+ * shadows (-100 .. 100), optionally p[8] -- and `np` its length (8 or 9).  The derived constants (mc, mfc, msc, mhc) are computed here
+ * with the reference's double-precision sleef forms; getVal above 1.0 then runs on the device.  ARTGPU_EINVAL for an all-zero
+ * slider set: that curve is the identity in the reference and has no Curve object (ARTGPU_CURVE_TAIL_LUT). */
+int artgpu_set_curve_tail_parametric(artgpu_ctx *ctx, const double *p, int np);
 
 /* rtengine::ProgressListener (rtengine/rtengine.h:165-181; the demosaicers report through it, amaze_demosaic_RT.cc:1567-1580).
  * `fn(user, stage, fraction)` is called on the calling thread by every stage-level entry point: fraction 0.0 when the stage starts

@@ -111,13 +111,77 @@ float oracle_lutf(const float *data, int size, float index)
 /* curves::setLutVal (curves.h:224-231): val <= 65535 or no Curve object -> lut[max(val, 0)]; above, curve->getVal(val / 65535.f) *
    65535.f.  What getVal returns above 1.0 depends on the curve kind (diagonalcurves.cc:443-561): the last point's y for DCT_Linear /
    DCT_Spline / DCT_CatmullRom (L476-477, L514-515), t itself for DCT_Empty and DCT_NURBS beyond its hash table (L529-535, L557-560);
-   DCT_Parametric continues analytically (not restated).  oracle_curve_tail_kind: 0 no Curve object, 1 constant, 2 identity. */
+   DCT_Parametric continues analytically (kind 4, below).  oracle_curve_tail_kind: 0 no Curve object, 1 constant, 2 identity, 4 parametric. */
 int oracle_curve_tail_kind = 0;
 double oracle_curve_tail_y = 1.0;
+
+/* DCT_Parametric (kind 4): the elementary curves of curves.h:92-156, DiagonalCurve's constructor (diagonalcurves.cc:106-131) and
+   getVal (L448-470), in double with the reference's sleef xlog / xexp (oracle/sleef.c; pinned by tests/golden/sleef_d.npz) */
+double oracle_xlog(double d);
+double oracle_xexp(double d);
+static double pc_basel(double x, double m1, double m2)
+{
+    if (x == 0.0) return 0.0;
+    double k = sqrt((m1 - 1.0) * (m1 - m2) * 0.5) / (1.0 - m2);
+    double l = (m1 - m2) / (1.0 - m2) + k;
+    double lx = oracle_xlog(x);
+    return m2 * x + (1.0 - m2) * (2.0 - oracle_xexp(k * lx)) * oracle_xexp(l * lx);
+}
+static double pc_baseu(double x, double m1, double m2) { return 1.0 - pc_basel(1.0 - x, m1, m2); }
+static double pc_cupper(double x, double m, double hr)
+{
+    if (hr > 1.0) return pc_baseu(x, m, 2.0 * (hr - 1.0) / m);
+    double x1 = (1.0 - hr) / m;
+    double x2 = x1 + hr;
+    if (x >= x2) return 1.0;
+    if (x < x1) return x * m;
+    return 1.0 - hr + hr * pc_baseu((x - x1) / hr, m, 0);
+}
+static double pc_clower(double x, double m, double sr) { return 1.0 - pc_cupper(1.0 - x, m, sr); }
+static double pc_p00(double x, double prot) { return pc_clower(x, 2.0, prot); }
+static double pc_p11(double x, double prot) { return pc_cupper(x, 2.0, prot); }
+static double pc_p01(double x, double prot) { return x <= 0.5 ? pc_clower(x * 2, 2.0, prot) * 0.5 : 0.5 + pc_cupper((x - 0.5) * 2, 2.0, prot) * 0.5; }
+static double pc_p10(double x, double prot) { return x <= 0.5 ? pc_cupper(x * 2, 2.0, prot) * 0.5 : 0.5 + pc_clower((x - 0.5) * 2, 2.0, prot) * 0.5; }
+static double pc_pfull(double x, double prot, double sh, double hl)
+{
+    return (1 - sh) * (1 - hl) * pc_p00(x, prot) + sh * hl * pc_p11(x, prot) + (1 - sh) * hl * pc_p01(x, prot) + sh * (1 - hl) * pc_p10(x, prot);
+}
+static double pcx[9], pc_mc, pc_mfc, pc_msc, pc_mhc;
+void oracle_set_parametric_curve(const double *p, int np)
+{
+    pcx[0] = p[0];
+    for (int i = 1; i < 4; i++) { double v = p[i] > 0.001 ? p[i] : 0.001; pcx[i] = v < 0.99 ? v : 0.99; }
+    for (int i = 4; i < 8; i++) pcx[i] = (p[i] + 100.0) / 200.0;
+    pcx[8] = np < 9 ? 1.0 : p[8] / 100.0;
+    pc_mc = -oracle_xlog(2.0) / oracle_xlog(pcx[2]);
+    double mbase = pc_pfull(0.5, pcx[8], pcx[6], pcx[5]);
+    pc_mfc = mbase <= 1e-14 ? 0.0 : oracle_xexp(oracle_xlog(mbase) / pc_mc);
+    pc_msc = -oracle_xlog(2.0) / oracle_xlog(pcx[1] / pcx[2]);
+    pc_mhc = -oracle_xlog(2.0) / oracle_xlog((pcx[3] - pcx[2]) / (1 - pcx[2]));
+    oracle_curve_tail_kind = 4;
+}
+double oracle_parametric_getval(double t)
+{
+    if (t <= 1e-14) return 0.0;
+    double tv = oracle_xexp(pc_mc * oracle_xlog(t));
+    double base = pc_pfull(tv, pcx[8], pcx[6], pcx[5]);
+    double stretched = base <= 1e-14 ? 0.0 : oracle_xexp(oracle_xlog(base) / pc_mc);
+    if (t < pcx[2]) {
+        double stv = oracle_xexp(pc_msc * oracle_xlog(stretched / pc_mfc));
+        double sbase = pc_pfull(stv, pcx[8], pcx[7], 0.5);
+        return pc_mfc * (sbase <= 1e-14 ? 0.0 : oracle_xexp(oracle_xlog(sbase) / pc_msc));
+    }
+    double htv = oracle_xexp(pc_mhc * oracle_xlog((stretched - pc_mfc) / (1 - pc_mfc)));
+    double hbase = pc_pfull(htv, pcx[8], 0.5, pcx[4]);
+    return pc_mfc + (1 - pc_mfc) * (hbase <= 1e-14 ? 0.0 : oracle_xexp(oracle_xlog(hbase) / pc_mhc));
+}
+void oracle_t_parametric_getval(const double *t, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = oracle_parametric_getval(t[i]); }
+
 float oracle_set_lut_val(const float *lut65536, float val)
 {
     if (val <= 65535.f || oracle_curve_tail_kind == 0) return oracle_lutf(lut65536, 65536, std_maxf(val, 0.f));
     const double t = (double)(val / 65535.f);
+    if (oracle_curve_tail_kind == 4) return (float)(oracle_parametric_getval(t) * (double)65535.f);
     return (float)((oracle_curve_tail_kind == 1 ? oracle_curve_tail_y : t) * (double)65535.f);
 }
 

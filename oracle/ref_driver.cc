@@ -67,6 +67,8 @@ int ref_mat33_inverse(const float *m9, float *r9)
     for (int i = 0; i < 9; ++i) r9[i] = r[i / 3][i % 3];
     return ok ? 1 : 0;
 }
+void ref_xlog(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xlog(x[i]); }
+void ref_xexp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xexp(x[i]); }
 void ref_xexpf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xexpf(x[i]); }
 void ref_xcbrtf(const float *x, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = xcbrtf(x[i]); }
 void ref_xsincosf(const float *d, float *sn, float *cs, size_t n) { for (size_t i = 0; i < n; ++i) { float2 v = xsincosf(d[i]); sn[i] = v.x; cs[i] = v.y; } }

@@ -224,3 +224,73 @@ MAP1(oracle_t_xlogf_vn, oracle_xlogf_v_nocheck)
 void oracle_t_pow_F(const float *a, const float *b, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = oracle_pow_F(a[i], b[i]); }
 void oracle_t_xlin2log(const float *x, float base, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = oracle_xlin2log(x[i], base); }
 void oracle_t_xlog2lin(const float *x, float base, float *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = oracle_xlog2lin(x[i], base); }
+
+
+/* ---- double-precision xlog / xexp (rtengine/sleef.h:26-28,58-92,519-571), used by the elementary curves of curves.h:92-156 ---- */
+static int64_t d_bits(double d) { int64_t i; memcpy(&i, &d, 8); return i; }
+static double d_from_bits(int64_t i) { double d; memcpy(&d, &i, 8); return d; }
+static double d_mla(double x, double y, double z) { return x * y + z; }
+static double d_ldexpk(double x, int q)
+{
+    int m = q >> 31;
+    m = (((m + q) >> 9) - m) << 7;
+    q = q - (m << 2);
+    double u = d_from_bits(((int64_t)(m + 0x3ff)) << 52);
+    double u2 = u * u;
+    u2 = u2 * u2;
+    x = x * u2;
+    u = d_from_bits(((int64_t)(q + 0x3ff)) << 52);
+    return x * u;
+}
+static int d_ilogbp1(double d)
+{
+    int m = d < 4.9090934652977266E-91;
+    d = m ? 2.037035976334486E90 * d : d;
+    int q = (int)((d_bits(d) >> 52) & 0x7ff);
+    q = m ? q - (300 + 0x03fe) : q - 0x03fe;
+    return q;
+}
+double oracle_xlog(double d)
+{
+    int e = d_ilogbp1(d * 0.7071);
+    double m = d_ldexpk(d, -e);
+    double x = (m - 1) / (m + 1);
+    double x2 = x * x;
+    double t = 0.148197055177935105296783;
+    t = d_mla(t, x2, 0.153108178020442575739679);
+    t = d_mla(t, x2, 0.181837339521549679055568);
+    t = d_mla(t, x2, 0.22222194152736701733275);
+    t = d_mla(t, x2, 0.285714288030134544449368);
+    t = d_mla(t, x2, 0.399999999989941956712869);
+    t = d_mla(t, x2, 0.666666666666685503450651);
+    t = d_mla(t, x2, 2);
+    x = x * t + 0.693147180559945286226764 * e;
+    if (d == INFINITY) x = INFINITY;
+    if (d < 0) x = NAN;
+    if (d == 0) x = -INFINITY;
+    return x;
+}
+double oracle_xexp(double d)
+{
+    double r = d * 1.442695040888963407359924681001892137426645954152985934135449406931;
+    int q = (int)(r < 0 ? (int)(r - 0.5) : (int)(r + 0.5));
+    double s = d_mla(q, -.69314718055966295651160180568695068359375, d);
+    s = d_mla(q, -.28235290563031577122588448175013436025525412068e-12, s);
+    double u = 2.08860621107283687536341e-09;
+    u = d_mla(u, s, 2.51112930892876518610661e-08);
+    u = d_mla(u, s, 2.75573911234900471893338e-07);
+    u = d_mla(u, s, 2.75572362911928827629423e-06);
+    u = d_mla(u, s, 2.4801587159235472998791e-05);
+    u = d_mla(u, s, 0.000198412698960509205564975);
+    u = d_mla(u, s, 0.00138888888889774492207962);
+    u = d_mla(u, s, 0.00833333333331652721664984);
+    u = d_mla(u, s, 0.0416666666666665047591422);
+    u = d_mla(u, s, 0.166666666666666851703837);
+    u = d_mla(u, s, 0.5);
+    u = s * s * u + s + 1;
+    u = d_ldexpk(u, q);
+    if (d == -INFINITY) u = 0;
+    return u;
+}
+void oracle_t_xlog(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = oracle_xlog(x[i]); }
+void oracle_t_xexp(const double *x, double *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = oracle_xexp(x[i]); }

@@ -201,7 +201,24 @@ def linalgebra():
     np.savez_compressed(os.path.join(HERE, "linalgebra.npz"), m=m, v=v, r=r)
 
 
+def sleef_double():
+    """xlog / xexp in double (sleef.h:519-571) as DiagonalCurve's parametric form uses them (curves.h:92-156, diagonalcurves.cc:106-131,
+    448-470): arguments around the curve's working range, the wide range, and the special cases"""
+    rng = np.random.default_rng(13)
+    n = 8192
+    dp = C.POINTER(C.c_double)
+    xl = np.concatenate([rng.uniform(1e-3, 4.0, n // 2), np.exp(rng.uniform(-700, 700, n // 4)), rng.uniform(-1.0, 1e-300, n // 4)])
+    xl[:10] = [1.0, 2.0, 0.5, 0.0, -0.0, np.inf, -1.0, np.nan, 4.9e-324, 1.7e308]
+    xe = np.concatenate([rng.uniform(-5.0, 5.0, n // 2), rng.uniform(-745.0, 709.0, n // 4), rng.uniform(-1e-8, 1e-8, n // 4)])
+    xe[:8] = [0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 709.5]
+    yl, ye = np.empty(n), np.empty(n)
+    R.ref_xlog(xl.ctypes.data_as(dp), yl.ctypes.data_as(dp), C.c_size_t(n))
+    R.ref_xexp(xe.ctypes.data_as(dp), ye.ctypes.data_as(dp), C.c_size_t(n))
+    np.savez_compressed(os.path.join(HERE, "sleef_d.npz"), xl=xl, log=yl, xe=xe, exp=ye)
+
+
 if __name__ == "__main__":
+    sleef_double()
     linalgebra()
     rescale_and_matrices()
     wavelet()

@@ -103,6 +103,12 @@ def exposure(img, exp_scale, black):
     return img
 
 
+def set_parametric_curve(p):
+    """DiagonalCurve(DCT_Parametric) behind setLutVal: values above 65535 take getVal's analytic form (oracle kind 4)"""
+    arr = (C.c_double * len(p))(*[float(v) for v in p])
+    lib().oracle_set_parametric_curve(arr, len(p))
+
+
 def set_curve_tail(kind=0, y_last=1.0):
     """What the tone curve's Curve object returns above 1.0 (curves::setLutVal): 0 no Curve object (LUT clip), 1 constant y_last, 2 identity."""
     C.c_int.in_dll(lib(), "oracle_curve_tail_kind").value = int(kind)

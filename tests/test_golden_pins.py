@@ -136,3 +136,77 @@ def test_mat_vec_matches_reference_linalgebra_h():
     out = np.empty_like(ref)
     O.lib().oracle_t_mat_vec(P(m), P(v), P(out), C.c_size_t(len(m)))
     assert same_bits(out, ref)
+
+
+def test_double_xlog_xexp_match_reference_sleef_h():
+    """the double-precision forms behind DiagonalCurve's parametric branch (oracle/sleef.c oracle_xlog / oracle_xexp)"""
+    g = np.load(os.path.join(G, "sleef_d.npz"))
+    L = O.lib()
+    dp = C.POINTER(C.c_double)
+    for src, want, fn in ((g["xl"], g["log"], L.oracle_t_xlog), (g["xe"], g["exp"], L.oracle_t_xexp)):
+        x = np.ascontiguousarray(src)
+        y = np.empty_like(x)
+        fn(x.ctypes.data_as(dp), y.ctypes.data_as(dp), C.c_size_t(len(x)))
+        nan = np.isnan(y) & np.isnan(want)
+        assert bool(np.all((y.view(np.uint64) == want.view(np.uint64)) | nan))
+
+
+def test_parametric_curve_is_continuous_with_its_lut_and_monotonic_above_one():
+    """oracle_parametric_getval (diagonalcurves.cc:448-470, unpinned: curves.h needs glibmm): a float64 model of the same formulas
+    with libm's log / exp agrees to rounding level, getVal(1) is 1, and the tail keeps rising above 1"""
+    import math
+    p = [2.0, 0.25, 0.5, 0.75, 30.0, 20.0, -15.0, -25.0, 0.0]
+    O.set_parametric_curve(p)
+    try:
+        L = O.lib()
+        dp = C.POINTER(C.c_double)
+        t = np.concatenate([np.linspace(1e-6, 1.0, 500), np.linspace(1.0, 2.5, 300)])
+        y = np.empty_like(t)
+        L.oracle_t_parametric_getval(t.ctypes.data_as(dp), y.ctypes.data_as(dp), C.c_size_t(len(t)))
+
+        def basel(x, m1, m2):
+            if x == 0.0:
+                return 0.0
+            k = math.sqrt((m1 - 1.0) * (m1 - m2) * 0.5) / (1.0 - m2)
+            l = (m1 - m2) / (1.0 - m2) + k
+            lx = math.log(x) if x > 0 else float("nan")
+            return m2 * x + (1.0 - m2) * (2.0 - math.exp(k * lx)) * math.exp(l * lx)
+
+        def cupper(x, m, hr):
+            if hr > 1.0:
+                return 1.0 - basel(1.0 - x, m, 2.0 * (hr - 1.0) / m)
+            x1 = (1.0 - hr) / m
+            if x >= x1 + hr:
+                return 1.0
+            if x < x1:
+                return x * m
+            return 1.0 - hr + hr * (1.0 - basel(1.0 - (x - x1) / hr, m, 0))
+
+        def clower(x, m, sr):
+            return 1.0 - cupper(1.0 - x, m, sr)
+
+        def pfull(x, prot, sh, hl):
+            p01 = clower(x * 2, 2.0, prot) * 0.5 if x <= 0.5 else 0.5 + cupper((x - 0.5) * 2, 2.0, prot) * 0.5
+            p10 = cupper(x * 2, 2.0, prot) * 0.5 if x <= 0.5 else 0.5 + clower((x - 0.5) * 2, 2.0, prot) * 0.5
+            return (1 - sh) * (1 - hl) * clower(x, 2.0, prot) + sh * hl * cupper(x, 2.0, prot) + (1 - sh) * hl * p01 + sh * (1 - hl) * p10
+
+        x = [p[0]] + [min(max(v, 0.001), 0.99) for v in p[1:4]] + [(v + 100.0) / 200.0 for v in p[4:8]] + [p[8] / 100.0]
+        mc = -math.log(2.0) / math.log(x[2])
+        mfc = math.exp(math.log(pfull(0.5, x[8], x[6], x[5])) / mc)
+        msc = -math.log(2.0) / math.log(x[1] / x[2])
+        mhc = -math.log(2.0) / math.log((x[3] - x[2]) / (1 - x[2]))
+
+        def getval(tt):
+            base = pfull(math.exp(mc * math.log(tt)), x[8], x[6], x[5])
+            st = math.exp(math.log(base) / mc)
+            if tt < x[2]:
+                sb = pfull(math.exp(msc * math.log(st / mfc)), x[8], x[7], 0.5)
+                return mfc * math.exp(math.log(sb) / msc)
+            hb = pfull(math.exp(mhc * math.log((st - mfc) / (1 - mfc))), x[8], 0.5, x[4])
+            return mfc + (1 - mfc) * math.exp(math.log(hb) / mhc)
+        model = np.array([getval(float(v)) for v in t[:500]])
+        assert np.allclose(y[:500], model, rtol=1e-9, atol=1e-12)
+        assert abs(y[499] - 1.0) < 1e-9
+        assert np.all(np.isfinite(y[500:]))
+    finally:
+        O.set_curve_tail(0)

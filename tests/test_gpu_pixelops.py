@@ -87,6 +87,40 @@ def test_tone_std_above_the_lut(gpu_ctx, kind, y_last, w, h):
         assert (np.array(ref) > 65535.0).any() == (kind == 2)        # only the identity tail leaves values above the LUT range
 
 
+PARAMETRIC = [2.0, 0.25, 0.5, 0.75, 30.0, 20.0, -15.0, -25.0, 0.0]        # DCT_Parametric, zone boundaries, highlights / lights / darks / shadows
+
+
+@pytest.mark.parametrize("w,h", [(333, 201), (2304, 1800)])          # plain kernel / the kernel with the curve in LDS
+def test_tone_std_above_the_lut_parametric_curve(gpu_ctx, w, h):
+    """A DCT_Parametric tone curve with whitePoint > 1: values above 65535 take DiagonalCurve::getVal's analytic form
+    (diagonalcurves.cc:448-470, double-precision sleef) on the device, bit for bit with the oracle's restatement."""
+    from art_amd import capi
+    import oracle_lib as O
+    rng = np.random.default_rng(w)
+    img = [rng.uniform(-500, 160000, (h, w)).astype(np.float32) for _ in range(3)]
+    img[0][0, :6] = [65535.0, 65535.004, 65536.0, 98302.5, 98303.0, 3e6]
+    x = np.arange(65536, dtype=np.float64) / 65535.0
+    lut = ((1.0 - np.cos(np.pi * x ** 0.7)) / 2.0 * 65535.0).astype(np.float32)
+    for clip in (True, False):
+        O.set_parametric_curve(PARAMETRIC)
+        try:
+            ref = O.tone_std(img, lut, 2.0, clip)
+        finally:
+            O.set_curve_tail(0)
+        base = O.tone_std(img, lut, 2.0, clip)
+        got = [p.copy() for p in img]
+        gpu_ctx.set_curve_tail_parametric(PARAMETRIC)
+        try:
+            gpu_ctx.tone_curve(capi.host_rgb(got), lut, 2.0, clip)
+        finally:
+            gpu_ctx.set_curve_tail(3)
+        assert _same(got, ref) == [0, 0, 0]
+        assert any((b != r).any() for b, r in zip(base, ref))          # the tail was reached
+    with pytest.raises(capi.ArtGpuError):
+        gpu_ctx.set_curve_tail_parametric([2.0, 0.25, 0.5, 0.75, 0.0, 0.0, 0.0, 0.0])        # the identity: no Curve object
+    gpu_ctx.set_curve_tail(3)
+
+
 def test_tone_unsupported(gpu_ctx):
     from art_amd import capi
     img = _img(64, 64, 3)

@@ -98,3 +98,27 @@ def test_neutral_tone_curve_above_the_lut(gpu_ctx, kind, y_last):
     for g, r in zip(got, ref):
         assert np.array_equal(g[~oor].view(np.uint32), r[~oor].view(np.uint32))
         assert np.allclose(g[oor], r[oor], rtol=2e-4, atol=0.5)
+
+
+def test_neutral_tone_curve_above_the_lut_parametric_curve(gpu_ctx):
+    """the same through NeutralToneCurve::BatchApply (curves.cc:1003) with a DCT_Parametric curve"""
+    w, h = 389, 150
+    img = frame(w, h, 34, 65535.0 * 1.4)
+    lut = (s_curve() * np.float32(0.9)).astype(np.float32)
+    par = [2.0, 0.25, 0.5, 0.75, 30.0, 20.0, -15.0, -25.0, 0.0]
+    O.set_parametric_curve(par)
+    try:
+        ref, oor = O.tone_neutral(img, lut, 1.5, want_oor=True)
+    finally:
+        O.set_curve_tail(0)
+    base = O.tone_neutral(img, lut, 1.5)
+    got = [p.copy() for p in img]
+    gpu_ctx.set_curve_tail_parametric(par)
+    try:
+        gpu_ctx.tone_curve_neutral(capi.host_rgb(got), lut, 1.5, O.REC2020_WS_D, O.REC2020_IWS_D)
+    finally:
+        gpu_ctx.set_curve_tail(3)
+    assert any((b != r).any() for b, r in zip(base, ref))
+    for g, r in zip(got, ref):
+        assert np.array_equal(g[~oor].view(np.uint32), r[~oor].view(np.uint32))
+        assert np.allclose(g[oor], r[oor], rtol=2e-4, atol=0.5)
