@@ -538,7 +538,8 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
         const bool early = ctx->amz_nstream > 0 && ctx->amz_narena > 0 && ctx->opt_amaze_overlap;
         const int nlist_max = ctx->amz_narena + ctx->amz_nstream;
         const int cap = split ? MAX_TILE_WORKGROUPS : 768;
-        const int grid = std::max(1, std::min(nlist_max, cap));
+        // (the per-phase profiling path runs one arena per tile of the grid, the tiles that write nothing included)
+        const int grid = split ? std::min(ntiles, cap) : std::max(1, std::min(nlist_max, cap));
         rc = ensure(ctx, &ctx->arena, &ctx->arena_bytes, (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float));
         if (rc) return rc;
         if ((rc = ensure(ctx, &ctx->bbox, &ctx->bbox_bytes, (size_t)grid * 4 * sizeof(int)))) return rc;
