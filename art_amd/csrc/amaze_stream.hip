@@ -121,7 +121,7 @@ amaze_stream_kernel(AmazeStreamArgs s)
             const int ty = tile / s.ntx, tx = tile - ty * s.ntx;
             const int top = -16 + ty * (TS - 32);
             tile_ref_set(t, k, tile, top, -16 + tx * (TS - 32), min(top + TS, s.H + 16) - top);
-            if (dyn[6]) { t.redo = 1; t.r0 = dyn[2]; t.r1 = dyn[3]; t.c0 = dyn[4]; t.c1 = dyn[5]; }
+            if (dyn[6]) { t.tile |= TILE_REDO; t.box = ny_pack(dyn[2], dyn[3], dyn[4], dyn[5]); }
         } else {
             tile_ref_none(t, k);
         }
@@ -218,11 +218,11 @@ amaze_stream_kernel(AmazeStreamArgs s)
                 int box[4];
 #ifdef AMZ_DEBUG
                 { amz_li red = (amz_li)(lds + RED_OFF) + 8 * par; const bool v_ = tile_valid(lds, par, q.back.rr1, box);
-                  if ((!v_ || q.back.redo) && ndbg < 3) { dbg[ndbg][0] = q.back.tile; dbg[ndbg][1] = q.back.redo; dbg[ndbg][2] = (int)v_; dbg[ndbg][3] = box[2]; dbg[ndbg][4] = box[3]; dbg[ndbg][5] = red[6]; dbg[ndbg][6] = red[7]; dbg[ndbg][7] = T; ++ndbg; } }
+                  if ((!v_ || tile_redo(q.back)) && ndbg < 3) { dbg[ndbg][0] = tile_index(q.back); dbg[ndbg][1] = tile_redo(q.back); dbg[ndbg][2] = (int)v_; dbg[ndbg][3] = box[2]; dbg[ndbg][4] = box[3]; dbg[ndbg][5] = red[6]; dbg[ndbg][6] = red[7]; dbg[ndbg][7] = T; ++ndbg; } }
 #endif
-                if (!tile_valid(lds, par, q.back.rr1, box) && !q.back.redo) {
+                if (!tile_valid(lds, par, q.back.rr1, box) && !tile_redo(q.back)) {
                     // stream it again with the true box: publish a queue entry; if the slot was abandoned, the arena kernel takes the tile
-                    const unsigned long long w = (unsigned long long)q.back.tile | ((unsigned long long)box[0] << 24) | ((unsigned long long)box[1] << 32) |
+                    const unsigned long long w = (unsigned long long)tile_index(q.back) | ((unsigned long long)box[0] << 24) | ((unsigned long long)box[1] << 32) |
                                                  ((unsigned long long)box[2] << 40) | ((unsigned long long)box[3] << 48) | (1ull << 63);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -231,7 +231,7 @@ amaze_stream_kernel(AmazeStreamArgs s)
                     atomicAdd(&cnt[2], 1);
                     if (!__hip_atomic_compare_exchange_strong(&s.queue_words[slot], &zero, w, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                         const int fs = atomicAdd(&s.fallback[0], 1);
-                        s.fallback[1 + fs] = q.back.tile;
+                        s.fallback[1 + fs] = tile_index(q.back);
                         atomicAdd(&cnt[3], 1);
                     }
                 }
@@ -261,7 +261,7 @@ amaze_stream_kernel(AmazeStreamArgs s)
         } else if (role.b == B_P7_P10) {
             {
                 const TileArgs a = stage_tile(frame, q, 2 * T - 14);
-st_p7(lds, a, 2 * T - 14 - a.gbase, lane);
+                st_p7(lds, a, 2 * T - 14 - a.gbase, lane);
                 st_p7(lds, a, 2 * T - 14 - a.gbase, 64 + lane);
                 st_p7(lds, a, 2 * T - 14 - a.gbase, 128 + lane);
             }

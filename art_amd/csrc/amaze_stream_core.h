@@ -197,13 +197,20 @@ struct TileArgs {
     int top, left;      // tile origin in the frame (may be negative: mirrored border, L205-334)
     int rr1;            // rows of the tile (160, less at the bottom edge of the frame; 0: no tile)
     int gbase;          // 160 * (position of the tile in the workgroup's sequence): ring rows are gbase + tile row
-    int ny_r0, ny_r1, ny_c0, ny_c1;   // the Nyquist box P7 / P8 / P10 work in (L827-876): [8, rr1-8) x [8, 152) on the first attempt
+    int ny_box;         // the Nyquist box P7 / P8 / P10 work in (L827-876), [8, rr1-8) x [8, 152) on the first attempt, one byte per bound
+                        // (r0 | r1 << 8 | c0 << 16 | c1 << 24: every value the kernel keeps per tile in flight is a scalar register it does not have)
     int W, H;
     unsigned filters;
     float clip_pt, clip_pt8;
     int g00;            // 1 if (0,0) is a green site
     int ey;             // row parity of the red sites (L1381: ey, ex)
 };
+
+AMZ_DEV int ny_pack(int r0, int r1, int c0, int c1) { return r0 | (r1 << 8) | (c0 << 16) | (c1 << 24); }
+AMZ_DEV int ny_r0(const TileArgs &a) { return a.ny_box & 255; }
+AMZ_DEV int ny_r1(const TileArgs &a) { return (a.ny_box >> 8) & 255; }
+AMZ_DEV int ny_c0(const TileArgs &a) { return (a.ny_box >> 16) & 255; }
+AMZ_DEV int ny_c1(const TileArgs &a) { return (int)((unsigned)a.ny_box >> 24); }
 
 // parity helpers: site (r,c) is green iff ((r + c) & 1) ^ g00; the R/B sites of row r are the columns cc = par(r) mod 2
 AMZ_DEV int row_par(const TileArgs &a, int r) { return (r & 1) ^ a.g00; }
@@ -371,17 +378,47 @@ AMZ_DEV float p3_hcd_pure(amz_lf ho, amz_lf ha, amz_lf cf, const TileArgs &a, in
 }
 // P3 (L540-583): variance choice + highlight bounding of row r.  hcd: lanes 0,1 of a 4-lane group read the UPDATED lanes 2,3 of
 // the group to their left (recomputed here: they only depend on original values); vcd: row r reads the updated row r-2.
-AMZ_DEV void st_p3(amz_lf lds, const TileArgs &a, int r, int c)
+#ifdef AMZ_EMUL
+#define AMZ_P3_COL(c) (c)
+#else
+// On the device the hcd value a lane 0 / 1 of a 4-lane group needs from the group to its left is the one lane - 2 of the same wave has
+// just computed: it comes over by a wave shuffle instead of being evaluated a second time (with the two halves of a group in two divergent
+// branches the wave paid for p3_hcd_pure twice).  For that a wave's 64 columns start two columns early -- 64 part - 2 --, so that the
+// source lane is always in the same wave; the three parts still cover columns 0 .. 159.  (The emulation, which runs one thread at a time,
+// keeps the recomputation: same values.)
+#define AMZ_P3_COL(c) ((c) - 2)
+#endif
+AMZ_DEV void st_p3(amz_lf lds, const TileArgs &a, int r, int c_in)
 {
+    const int c = AMZ_P3_COL(c_in);
+#ifdef AMZ_EMUL
     if (r < 4 || r >= a.rr1 - 4 || c >= TS) return;
+#else
+    if (r < 4 || r >= a.rr1 - 4) return;          // (uniform over the wave: every lane reaches the shuffle)
+#endif
     float nh = 0.f;
-    if (c >= 4 && c < TS - 4) {
-        amz_lf ho = ROWR(HCO, r), ha = ROWR(HCA, r), cf = ROWR(CFA, r);
-        const int idx = c - 4, k = idx & 3, g = idx >> 2;
+    const bool dom = c >= 4 && c < TS - 4;
+    amz_lf ho = ROWR(HCO, r), ha = ROWR(HCA, r), cf = ROWR(CFA, r);
+    const int idx = c - 4, k = idx & 3, g = idx >> 2;
+#ifndef AMZ_EMUL
+    float pure = 0.f;
+    if (dom) pure = p3_hcd_pure(ho, ha, cf, a, r, c);
+    const float left2 = __shfl_up(pure, 2);          // lane - 2 = column c - 2 (lanes 0, 1 of a wave are lanes 2, 3 of their group: not used)
+    if (c < 0 || c >= TS) return;
+#endif
+    if (dom) {
         if (k >= 2) {
+#ifdef AMZ_EMUL
             nh = p3_hcd_pure(ho, ha, cf, a, r, c);
+#else
+            nh = pure;
+#endif
         } else {
+#ifdef AMZ_EMUL
             const float hm2 = g > 0 ? p3_hcd_pure(ho, ha, cf, a, r, c - 2) : ho[c - 2];
+#else
+            const float hm2 = g > 0 ? left2 : ho[c - 2];
+#endif
             const float sgn = is_green(a, r, c) ? -1.f : 1.f;
             float hcdv = ho[c];
             const float hv = var3(hm2, hcdv, ho[c + 2]);
@@ -532,7 +569,7 @@ AMZ_DEV void st_p7(amz_lf lds, const TileArgs &a, int r, int item)
     const int sl = item >= TSH, rr = r + sl, b = item - (sl ? TSH : 0);
     if (rr < 2 || rr >= a.rr1 - 2) return;
     amz_lb out = (amz_lb)SROWW(NYQ2, r, 0, sl);
-    if (rr < a.ny_r0 || rr >= a.ny_r1) {
+    if (rr < ny_r0(a) || rr >= ny_r1(a)) {
         // outside [nystartrow, nyendrow): the memset value (L879); rows 156..159 lie behind the memset (L879): they still hold the bytes of cddiffsq(19, 80..159), and P8's window at rows
         // 150, 151 tests them
         out[b] = rr >= TS - 4 ? ((amz_lb)(lds + NQA_OFF))[(rr - (TS - 4)) * TSH + b] : 0;   // (only tiles of 159 / 160 rows get there)
@@ -556,7 +593,7 @@ AMZ_DEV bool nyq_site(amz_lf lds, const TileArgs &a, int r, int c, int *prr)
     if (c >= TS) return false;
     const int sl = site_sel(a, r, c), rr = r + sl;
     *prr = rr;
-    if (rr < a.ny_r0 || rr >= a.ny_r1 || c < a.ny_c0 + row_par(a, rr) || c >= a.ny_c1) return false;     // L914-915, L980-981
+    if (rr < ny_r0(a) || rr >= ny_r1(a) || c < ny_c0(a) + row_par(a, rr) || c >= ny_c1(a)) return false;     // L914-915, L980-981
     return ((amz_lb)SROWR(NYQ2, r, 0, sl))[c >> 1] != 0;
 }
 
@@ -794,7 +831,7 @@ AMZ_DEV int st_p1014_classify(amz_lf lds, const TileArgs &a, int r, int c, int *
     if (c < 8 + par || c >= TS - 8) return 0;
     const bool in14 = p14_in_range(a, rr, c);
     if (in14 && fabsf(0.5f - SROWR(PMWT, r, 0, sl)[idx]) >= fabsf(0.5f - SROWR(HVWT, r, 0, sl)[idx])) return 2;
-    if (rr >= a.ny_r0 && rr < a.ny_r1 && c >= a.ny_c0 + par && c < a.ny_c1 && ((amz_lb)SROWR(NYQ2, r, 0, sl))[idx]) return 1;
+    if (rr >= ny_r0(a) && rr < ny_r1(a) && c >= ny_c0(a) + par && c < ny_c1(a) && ((amz_lb)SROWR(NYQ2, r, 0, sl))[idx]) return 1;
     p15_store(lds, a, r, sl, c, in14, SROWR(DG0, r, 0, sl)[idx], SROWR(RGBG, r, 0, sl)[idx]);
     return 0;
 }
@@ -993,13 +1030,16 @@ AMZ_DEV void seq_begin(amz_lf lds, int tid)
 // the early stages already work on tile k + 1 (no pipeline fill / drain per tile: 80 steps per tile instead of 99).  At most
 // two tiles are in flight (the deepest offset is 38 rows); the loader prefetches one step ahead and needs the next one too.
 // ---------------------------------------------------------------------------------------------------------------------
-struct TileRef { int top, left, rr1, gbase, tile, redo, r0, r1, c0, c1; };   // tile: index in the frame; redo: second attempt, the box is the true one
+struct TileRef { int top, left, rr1, gbase, tile, box; };   // tile: index in the frame, bit 30 = second attempt (the box is then the true one); box: ny_pack
+constexpr int TILE_REDO = 1 << 30;
+AMZ_DEV int tile_index(const TileRef &t) { return t.tile < 0 ? t.tile : (t.tile & (TILE_REDO - 1)); }
+AMZ_DEV bool tile_redo(const TileRef &t) { return t.tile >= 0 && (t.tile & TILE_REDO) != 0; }
 struct TileSeq { TileRef back, front, next; };
 AMZ_DEV TileArgs with_tile(const TileArgs &frame, const TileRef &t)
 {
     TileArgs a = frame;
     a.top = t.top; a.left = t.left; a.rr1 = t.rr1; a.gbase = t.gbase;
-    a.ny_r0 = t.r0; a.ny_r1 = t.r1; a.ny_c0 = t.c0; a.ny_c1 = t.c1;
+    a.ny_box = t.box;
     return a;
 }
 // the tile a stage at global row G works on
@@ -1076,13 +1116,16 @@ AMZ_DEV WaveRole wave_role(int wave)
 {
     //                      SIMD class 0                 1                          2                          3
     // a: 0,4,8,12 / 1,5,9,13 / 2,6,10,14 = P2, P5+L, P12, P4 (part 0 / 1 / 2);   3,7,11 = classification parts 0..2, 15 = P8
-    // b: class 0: w0 P1P11.2, w4 P3r0.0, w8 P16OUT.0, w12 P13+P14 | class 1: w1 P3r0.1, w5 P3r0.2, w9 P3r1.0, w13 P7+P10
-    //    class 2: w2 P16OUT.1, w6 P16OUT.2, w10 P3r1.1, w14 P9     | class 3: w3 P1P11.0, w7 P1P11.1, w11 P3r1.2, w15 P8
+    // b: class 0: w0 P16OUT.2, w4 P3r0.0, w8 P1P11.0, w12 P13+P14 | class 1: w1 P3r0.1, w5 P3r0.2, w9 P3r1.0, w13 P7+P10
+    //    class 2: w2 P16OUT.1, w6 P1P11.2, w10 P3r1.1, w14 P9     | class 3: w3 P16OUT.0, w7 P1P11.1, w11 P3r1.2, w15 P8
+    // (round 3: chosen with the per-wave timestamps of -DAMZ_PROFILE instead of static instruction counts -- the table of round 2 with
+    // P16OUT.0 / P1P11.0 and P16OUT.2 / P1P11.2 exchanged between the SIMD classes: 4.60 -> 4.35 ms per 45 MP frame.  Five other exchanges,
+    // and P7 moved from the P10 wave to the P9 wave, were slower.)
     const int cls = wave & 3, row = wave >> 2;
     WaveRole r;
     if (cls == 3) { r.a = row == 3 ? A_P8 : A_LIGHT; r.apart = row; }
     else { r.a = row == 0 ? A_P2 : (row == 1 ? A_P5L : (row == 2 ? A_P12 : A_P4)); r.apart = cls; }
-    const int btab[16] = {B_P1P11, B_P3R0, B_P16OUT, B_P1P11, B_P3R0, B_P3R0, B_P16OUT, B_P1P11, B_P16OUT, B_P3R1, B_P3R1, B_P3R1, B_P13_P14, B_P7_P10, B_P9, B_P8};
+    const int btab[16] = {B_P16OUT, B_P3R0, B_P16OUT, B_P16OUT, B_P3R0, B_P3R0, B_P1P11, B_P1P11, B_P1P11, B_P3R1, B_P3R1, B_P3R1, B_P13_P14, B_P7_P10, B_P9, B_P8};
     const int bpar[16] = {2, 1, 1, 0, 0, 2, 2, 1, 0, 0, 1, 2, 0, 0, 0, 0};
     r.b = btab[wave]; r.bpart = bpar[wave];
     return r;
@@ -1155,8 +1198,8 @@ AMZ_DEV bool tile_done(const TileSeq &q, int T) { return 2 * T - LAST_OFF - 2 ==
 AMZ_DEV bool tile_drain(const TileSeq &q, int T) { return 2 * T - LAST_OFF == q.front.gbase && q.front.gbase > 0 && q.back.rr1 > 0; }
 AMZ_DEV void tile_ref_set(TileRef &t, int k, int tile, int top, int left, int rr1)
 {
-    t.gbase = TS * k; t.tile = tile; t.top = top; t.left = left; t.rr1 = rr1; t.redo = 0;
-    t.r0 = 8; t.r1 = rr1 - 8; t.c0 = 8; t.c1 = TS - 8;
+    t.gbase = TS * k; t.tile = tile; t.top = top; t.left = left; t.rr1 = rr1;
+    t.box = ny_pack(8, rr1 > 8 ? rr1 - 8 : 0, 8, TS - 8);
 }
 AMZ_DEV void tile_ref_none(TileRef &t, int k) { tile_ref_set(t, k, -1, 0, 0, 0); }
 constexpr int STEPS_PER_TILE = TS / 2;

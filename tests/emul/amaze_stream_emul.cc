@@ -82,7 +82,7 @@ int amaze_stream_emul_seq(const float *raw, long rs, int W, int H, unsigned filt
     TileArgs frame;
     frame.raw = raw; frame.rs = rs; frame.red = red; frame.green = green; frame.blue = blue; frame.os = os;
     frame.top = 0; frame.left = 0; frame.rr1 = 0; frame.gbase = 0;
-    frame.ny_r0 = frame.ny_r1 = frame.ny_c0 = frame.ny_c1 = 0;
+    frame.ny_box = 0;
     frame.W = W; frame.H = H; frame.filters = filters; frame.clip_pt = clip_pt; frame.clip_pt8 = clip_pt8;
     frame.g00 = (int)(fc(filters, 0, 0) & 1);
     if (fc(filters, 0, 0) == 1) frame.ey = fc(filters, 0, 1) == 0 ? 0 : 1;
@@ -113,7 +113,7 @@ int amaze_stream_emul_seq(const float *raw, long rs, int W, int H, unsigned filt
         TileRef t;
         if (k < ntiles && tops[k] > -1000) {           // (top <= -1000: an empty position, as when the redo queue had nothing to offer)
             tile_ref_set(t, k, k, tops[k], lefts[k], (tops[k] + TS < H + 16 ? tops[k] + TS : H + 16) - tops[k]);
-            if (redo && redo[k]) { t.redo = 1; t.r0 = redo_box[4 * k]; t.r1 = redo_box[4 * k + 1]; t.c0 = redo_box[4 * k + 2]; t.c1 = redo_box[4 * k + 3]; }
+            if (redo && redo[k]) { t.tile |= amz::TILE_REDO; t.box = amz::ny_pack(redo_box[4 * k], redo_box[4 * k + 1], redo_box[4 * k + 2], redo_box[4 * k + 3]); }
         } else {
             tile_ref_none(t, k);
         }
