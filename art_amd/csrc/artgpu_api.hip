@@ -2019,10 +2019,16 @@ int artgpu_demosaic_xtrans(artgpu_ctx *ctx, int passes, int use_cielab, const ar
     a.ntx = (W - 22 + (XTRANS_TS - 16) - 1) / (XTRANS_TS - 16);
     const int nty = (H - 22 + (XTRANS_TS - 16) - 1) / (XTRANS_TS - 16);
     a.ntiles = a.ntx * nty;
-    // one 1024-thread workgroup is resident per CU; two rounds of them walk the tiles (the arena is 0.9 GB instead of 14 GB for 8192 workgroups,
-    // and the same speed: measured 128 ... 8192)
-    constexpr int XTRANS_MAX_WG = 512;
-    const int grid = a.ntiles < XTRANS_MAX_WG ? a.ntiles : XTRANS_MAX_WG;
+    // one 1024-thread workgroup is resident per CU: one persistent workgroup per CU, tiles from a shared counter (the arena is 0.45 GB)
+    if (ctx->num_cus <= 0) {
+        hipDeviceProp_t prop;
+        HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = a.ntiles < ctx->num_cus ? a.ntiles : ctx->num_cus;
+    if (!ctx->rcd_counter) HIPCHK(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->rcd_counter), 64));
+    a.counter = ctx->rcd_counter + 4;           // (the RCD kernel's counter is word 0 of the same 64 bytes)
+    HIPCHK(ctx, hipMemsetAsync(a.counter, 0, sizeof(int), ctx->stream));
     a.arena_floats = (size_t)XTRANS_TS * XTRANS_TS * (a.ndir * 4 + 3) + 128;
     rc = ensure(ctx, &ctx->arena, &ctx->arena_bytes, (size_t)grid * a.arena_floats * sizeof(float));
     if (rc) return rc;

@@ -115,6 +115,7 @@ struct XtransArgs {
     int allhex1[3][3][8];                    // offsets in a tile plane (h + v*TS)
     float xyz_cam[9];
     int border;                              // xtrans_border_kernel only
+    int *counter;                            // tile counter (device int, cleared before the launch); null: tiles blockIdx.x + k * gridDim.x
 };
 hipError_t launch_xtrans(const XtransArgs &a, int grid, hipStream_t s);
 

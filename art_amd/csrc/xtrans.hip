@@ -131,7 +131,12 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
 #ifdef XT_PROFILE
     long long xt_acc[16] = {0}, xt_last = wall_clock64();
 #endif
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    // tiles from a shared counter (cleared per launch): the first one is the workgroup's index, the others are handed out in order --
+    // thread 0 asks for the next one while this one is being worked on (a fixed share per workgroup left the last ones idle for a tile's
+    // length at the end, and edge tiles are cheaper than full ones)
+    __shared__ int s_next;
+    for (int tile = blockIdx.x; tile < a.ntiles;) {
+        if (tid == 0) s_next = a.counter ? (int)gridDim.x + atomicAdd(a.counter, 1) : tile + (int)gridDim.x;
         const int tyi = tile / a.ntx, txi = tile - tyi * a.ntx;
         const int top = 3 + tyi * (TS - 16), left = 3 + txi * (TS - 16);
         int mrow = min(top + TS, height - 3), mcol = min(left + TS, width - 3);
@@ -547,6 +552,8 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             a.blue[o] = std_max(0.f, avg[2] / avg[3]);
         }
         __syncthreads(); XT_MARK(13);
+        tile = s_next;
+        __syncthreads();
     }
 #ifdef XT_PROFILE
     if (blockIdx.x == 7 && tid == 0) {
