@@ -254,7 +254,20 @@ def main() -> None:
     # before the warm-up: its set-up takes seconds and belongs to the job's start, not to the timed steps or to what follows them.
     from art_amd import batch
     use_rccl_capi = "WORLD_SIZE" in os.environ and not os.environ.get("ARTGPU_BENCH_TORCH_GATHER")
-    rccl_handle = batch.open_rccl(ctx, dist, dev, rank, world) if use_rccl_capi else None
+    rccl_handle, rccl_stuck = None, False
+    if use_rccl_capi:
+        # (in a watchdog thread: communicator set-up is a rendezvous of all ranks -- should it hang on some node, every rank times out the
+        # same way, the completion step goes through torch.distributed and the process leaves with os._exit past the stuck thread)
+        import threading
+        obox = {}
+        oth = threading.Thread(target=lambda: obox.update(h=batch.open_rccl(ctx, dist, dev, rank, world)), daemon=True)
+        oth.start()
+        oth.join(timeout=float(os.environ.get("ARTGPU_BENCH_RCCL_TIMEOUT", "180")))
+        if "h" in obox:
+            rccl_handle = obox["h"]
+        else:
+            print(f"[bench rank {rank}] the RCCL communicator for artgpu_batch_complete did not come up: completing through torch.distributed", file=sys.stderr, flush=True)
+            use_rccl_capi, rccl_stuck = False, True
 
     for _ in range(args.warmup):
         step()
@@ -309,7 +322,8 @@ def main() -> None:
             hard_exit = True
     else:
         records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, args.steps, 0, cs, t1 - t0)
-        gather_via = "torch.distributed" if world > 1 else "single process"
+        gather_via = ("torch.distributed" if world > 1 else "single process") + (" (rccl-capi set-up timed out)" if rccl_stuck else "")
+        hard_exit = rccl_stuck
 
     stage_ms = {nm: round(statistics.mean(ev[i].elapsed_time(ev[i + 1]) for ev in stage_ev), 4) for i, nm in enumerate(stage_names)}
     mp = W * H / 1e6
