@@ -46,10 +46,14 @@ __device__ __forceinline__ float xdivf(float d, int n)
 // curves::setLutVal above the LUT (curves.h:228-230): curve->getVal(val / 65535.f) * 65535.f with getVal = the last point's y
 // (kind 1: DCT_Linear / DCT_Spline / DCT_CatmullRom), t (kind 2: DCT_Empty, DCT_NURBS beyond its hash) or the analytic form of a
 // DCT_Parametric curve (kind 4, paramcurve.h), diagonalcurves.cc:443-561
+// PC: the kernel was instantiated for a parametric tail.  The pixel kernels exist twice: the double-precision chain of the parametric form
+// costs them a third of their scalar registers (and scratch in one case) when it is merely PRESENT, so the instantiation every other
+// curve kind uses does not contain it.
+template <bool PC>
 __device__ __forceinline__ float curve_tail(int kind, double y_last, const ParamCurve &pc, float val)
 {
     const double t = (double)(val / 65535.f);
-    if (kind == 4) return (float)(pc_getval(pc, t) * (double)65535.f);
+    if constexpr (PC) { if (kind == 4) return (float)(pc_getval(pc, t) * (double)65535.f); }
     return (float)((kind == 1 ? y_last : t) * (double)65535.f);
 }
 __device__ __forceinline__ int ngroups(int start, int bound, int step)

@@ -105,6 +105,7 @@ __global__ void __launch_bounds__(256) exposure_kernel(PixArgs a)
     }
 }
 
+template <bool PC>
 __global__ void __launch_bounds__(256) tone_std_kernel(PixArgs a)
 {
     const float Lmax = 65535.f * a.whitept;
@@ -113,9 +114,9 @@ __global__ void __launch_bounds__(256) tone_std_kernel(PixArgs a)
         float r = a.dst[0][di], g = a.dst[1][di], b = a.dst[2][di];
         if (a.do_clip) filmlike_clip_px(r, g, b, Lmax);
         if (a.lut) {
-            r = (a.tail_kind && r > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, r) : lutf(a.lut, 65536, std_max(r, 0.f));
-            g = (a.tail_kind && g > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, g) : lutf(a.lut, 65536, std_max(g, 0.f));
-            b = (a.tail_kind && b > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, b) : lutf(a.lut, 65536, std_max(b, 0.f));
+            r = (a.tail_kind && r > 65535.f) ? curve_tail<PC>(a.tail_kind, a.tail_y, a.tail_pc, r) : lutf(a.lut, 65536, std_max(r, 0.f));
+            g = (a.tail_kind && g > 65535.f) ? curve_tail<PC>(a.tail_kind, a.tail_y, a.tail_pc, g) : lutf(a.lut, 65536, std_max(g, 0.f));
+            b = (a.tail_kind && b > 65535.f) ? curve_tail<PC>(a.tail_kind, a.tail_y, a.tail_pc, b) : lutf(a.lut, 65536, std_max(b, 0.f));
         }
         a.dst[0][di] = r; a.dst[1][di] = g; a.dst[2][di] = b;
     }
@@ -125,6 +126,7 @@ __global__ void __launch_bounds__(256) tone_std_kernel(PixArgs a)
 // (256 KB) does not fit L1, so every lookup of the kernel above is an L2 line gather (6 per pixel, ~1.5 TB/s effective); linear
 // scene data sit mostly in the lower part of the range, and those lookups become LDS reads.  Entries above come from L2 as before.
 // One persistent workgroup of 1024 threads per CU, rows strided over the workgroups.
+template <bool PC>
 __global__ void __launch_bounds__(1024) tone_std_lds_kernel(PixArgs a)
 {
     extern __shared__ float tone_lds[];
@@ -146,9 +148,9 @@ __global__ void __launch_bounds__(1024) tone_std_lds_kernel(PixArgs a)
                 const size_t di = (size_t)y * a.dst_stride + x;
                 float rr = r[k], gg = g[k], bb = b[k];
                 if (a.do_clip) filmlike_clip_px(rr, gg, bb, Lmax);
-                rr = (a.tail_kind && rr > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, rr) : lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(rr, 0.f));
-                gg = (a.tail_kind && gg > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, gg) : lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(gg, 0.f));
-                bb = (a.tail_kind && bb > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, bb) : lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(bb, 0.f));
+                rr = (a.tail_kind && rr > 65535.f) ? curve_tail<PC>(a.tail_kind, a.tail_y, a.tail_pc, rr) : lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(rr, 0.f));
+                gg = (a.tail_kind && gg > 65535.f) ? curve_tail<PC>(a.tail_kind, a.tail_y, a.tail_pc, gg) : lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(gg, 0.f));
+                bb = (a.tail_kind && bb > 65535.f) ? curve_tail<PC>(a.tail_kind, a.tail_y, a.tail_pc, bb) : lutf_lookup_lds<true>(tone_lds, a.lut, 65536, std_max(bb, 0.f));
                 a.dst[0][di] = rr; a.dst[1][di] = gg; a.dst[2][di] = bb;
             }
         }
@@ -397,14 +399,17 @@ hipError_t launch_tone_std(const PixArgs &a, hipStream_t s)
     // large frames with a curve: the LDS-resident variant (the curve pointer is 16-byte aligned: pool or hipMalloc memory)
     if (a.lut && (long long)a.w * a.h >= (1 << 22) && (reinterpret_cast<uintptr_t>(a.lut) & 15) == 0 && !a.no_lds_lut) {
         const size_t lds = (size_t)LUT_LDS_N * sizeof(float);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tone_std_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const bool pc = a.tail_kind == 4;
+        hipError_t e = hipFuncSetAttribute(pc ? reinterpret_cast<const void *>(tone_std_lds_kernel<true>) : reinterpret_cast<const void *>(tone_std_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        hipLaunchKernelGGL(tone_std_lds_kernel, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
+        if (pc) hipLaunchKernelGGL(tone_std_lds_kernel<true>, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
+        else hipLaunchKernelGGL(tone_std_lds_kernel<false>, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(tone_std_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
+    if (a.tail_kind == 4) hipLaunchKernelGGL(tone_std_kernel<true>, image_grid(a.w, a.h), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(tone_std_kernel<false>, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

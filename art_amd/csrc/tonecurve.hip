@@ -149,6 +149,7 @@ __device__ __forceinline__ NeutralConsts neutral_consts(const NeutralArgs &a)
     for (int i = 0; i < 3; ++i) k.sc[i] = (1.f - th[i]) / sqrtf(dl[i] - 1.f);
     return k;
 }
+template <bool PC>
 __device__ __forceinline__ void neutral_px(const NeutralArgs &a, const NeutralConsts &k, const PqTab pq, size_t o, float r0, float g0, float b0)
 {
     const float whitept = k.whitept, rhue = k.rhue, bhue = k.bhue, yhue = k.yhue, yrange = k.yrange, rrange = k.rrange, brange = k.brange;
@@ -190,7 +191,7 @@ __device__ __forceinline__ void neutral_px(const NeutralArgs &a, const NeutralCo
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             float nt = rgb[j] * 65535.f;
-            nt = (a.tail_kind && nt > 65535.f) ? curve_tail(a.tail_kind, a.tail_y, a.tail_pc, nt) : lutf_lookup<true>(a.lut, 65536, std_max(nt, 0.f));   // setLutVal
+            nt = (a.tail_kind && nt > 65535.f) ? curve_tail<PC>(a.tail_kind, a.tail_y, a.tail_pc, nt) : lutf_lookup<true>(a.lut, 65536, std_max(nt, 0.f));   // setLutVal
             rgb[j] = nt / 65535.f;
         }
         rgb2jzczhz(pq, rgb[0], rgb[1], rgb[2], jch[0], jch[1], jch[2], a.ws);
@@ -211,15 +212,17 @@ __device__ __forceinline__ void neutral_px(const NeutralArgs &a, const NeutralCo
         a.img[2][o] = std_max(0.f, std_min(rgb[2] * 65535.f, whitept));
     }
 }
+template <bool PC>
 __global__ void __launch_bounds__(256) tone_neutral_kernel(NeutralArgs a)
 {
     const NeutralConsts k = neutral_consts(a);
     FOR_IMAGE_XY(y, x, a.w, a.h) {
         const size_t o = (size_t)y * a.stride + x;
-        neutral_px(a, k, PqTab{a.pq, nullptr}, o, a.img[0][o], a.img[1][o], a.img[2][o]);
+        neutral_px<PC>(a, k, PqTab{a.pq, nullptr}, o, a.img[0][o], a.img[1][o], a.img[2][o]);
     }
 }
 // large frames: one persistent 1024-thread workgroup per CU, the lower 40 704 entries of the forward PQ table in LDS
+template <bool PC>
 __global__ void __launch_bounds__(1024) tone_neutral_lds_kernel(NeutralArgs a)
 {
     extern __shared__ float pq_lds[];
@@ -238,7 +241,7 @@ __global__ void __launch_bounds__(1024) tone_neutral_lds_kernel(NeutralArgs a)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int x = x0 + q * 1024 + (int)threadIdx.x;
-                if (x < a.w) neutral_px(a, k, pq, (size_t)y * a.stride + x, r[q], g[q], b[q]);
+                if (x < a.w) neutral_px<PC>(a, k, pq, (size_t)y * a.stride + x, r[q], g[q], b[q]);
             }
         }
 }
@@ -252,14 +255,17 @@ hipError_t launch_tone_neutral(const NeutralArgs &a, hipStream_t s)
 {
     if ((long long)a.w * a.h >= (1 << 22) && (reinterpret_cast<uintptr_t>(a.pq) & 15) == 0 && !a.no_lds_lut) {
         const size_t lds = (size_t)LUT_LDS_N * sizeof(float);
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(tone_neutral_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const bool pc = a.tail_kind == 4;
+        hipError_t e = hipFuncSetAttribute(pc ? reinterpret_cast<const void *>(tone_neutral_lds_kernel<true>) : reinterpret_cast<const void *>(tone_neutral_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        hipLaunchKernelGGL(tone_neutral_lds_kernel, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
+        if (pc) hipLaunchKernelGGL(tone_neutral_lds_kernel<true>, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
+        else hipLaunchKernelGGL(tone_neutral_lds_kernel<false>, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(tone_neutral_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
+    if (a.tail_kind == 4) hipLaunchKernelGGL(tone_neutral_kernel<true>, image_grid(a.w, a.h), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(tone_neutral_kernel<false>, image_grid(a.w, a.h), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
