@@ -12,15 +12,21 @@
 //                with a 21-column window that covers every tx of the row and the patch-centre shift); all eleven waves take their
 //                squared differences and, later, the weighted sample from there;
 //   sweep      : lane l of a wave owns tile rows 3l..3l+2 and walks x = d - l (skewed coordinates).  The integral image uses the
-//                reference's association (left + up) - (upleft - s) (nlmeans.cc:192-204); `up` of the lane's first row comes from
-//                the previous lane by a wave shift, everything else from registers.  S goes to an 8-column LDS ring, the
-//                four-corner box sum (L219/236) of the pixel whose lower-right corner was just completed goes to the chunk ring;
+//                reference's association (left + up) - (upleft - s) (nlmeans.cc:192-204).  S never leaves the registers: a lane keeps
+//                the last eight steps of its three rows (and of the row above, which it receives anyway) in a ring whose index is
+//                the step number -- static once the eight steps of a chunk are unrolled -- and everything a step needs from the
+//                rows above (the row above itself and the two upper corners of the three box sums) is some entry of the PREVIOUS
+//                lane's ring, one DPP wave shift away: lane l-1 is one column ahead, so "column x of its rows" is its previous
+//                step and "column x - 2pr" the one 2pr before that.  A step is straight-line code without an LDS round trip on
+//                its dependent chain; the four-corner box sum (L219/236) of the pixel whose lower-right corner was just completed
+//                goes to the chunk ring in LDS;
 //   accumulate : ALL threads walk the chunk's pixels once: mask, SW and the weighted sum are loaded once, the eleven offsets are
 //                applied in the reference's order (tx ascending inside ty; weight from the exp LUT, vector / scalar lane forms of
 //                L213-243) and both accumulators are stored once.
 // Then the final estimate (L252-273).  Per offset that is ~3 B per pixel of global traffic.  Same arithmetic per pixel, same
 // order as the reference: bit-identical.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "devmath.h"
 #include "kernels.h"
 
@@ -29,9 +35,8 @@ namespace artgpu {
 namespace {
 constexpr int TS = 150;          // reference tile size
 constexpr int RPL = 3;           // tile rows per lane
-constexpr int RP = 151;          // ring pitch (floats per step)
-constexpr int SCOLS = 8;         // S ring depth in columns (needs >= 2*pr + 4)
-constexpr int SP = 153;          // S ring pitch
+constexpr int RP = 156;          // chunk ring pitch (floats per step): >= 152 (a lane's three rows are stored whether they exist or not), and
+                                 // = 4 mod 8 so that the accumulate pass (32 lanes = 4 rows x 8 steps per LDS cycle) touches 32 banks
 
 // c ? a : b on the bit patterns: always a select, never a branch
 __device__ __forceinline__ float bsel(bool c, float a, float b)
@@ -39,7 +44,19 @@ __device__ __forceinline__ float bsel(bool c, float a, float b)
     const int m = -(int)c;
     return __int_as_float((__float_as_int(a) & m) | (__float_as_int(b) & ~m));
 }
-__device__ __forceinline__ void wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+// the previous lane's value (0 for lane 0): one DPP operand, no LDS
+__device__ __forceinline__ float lane_above(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+}
+// _mm_max_ps(x, 0) for an x that is the result of an arithmetic instruction (never a signalling NaN): NaN -> 0, like the compare-and-select
+// form, in one instruction (the compiler's fmaxf would canonicalise the LDS operand first)
+__device__ __forceinline__ float max0(float x)
+{
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 } // namespace
 
 
@@ -49,20 +66,22 @@ constexpr int G_NW = 11;                // waves per workgroup = offsets in flig
 constexpr int G_NT = G_NW * 64;
 constexpr int G_SB = 21;                // strip_b columns: x from (d0 - row/RPL - 8)
 constexpr int G_SA = G_CH + 1;          // strip_a row pitch (odd: the sweep reads three rows per lane)
-constexpr int G_LDS_FLOATS = 8192 + G_NW * G_CH * RP + G_NW * SCOLS * SP + TS * G_SB + (TS + 42) * G_SA;
+constexpr int G_NLUT = 8192;            // exp table entries; in LDS as 8192 pairs (e[i], e[i+1]): one 8-byte read per weight
+constexpr int G_LDS_FLOATS = 2 * G_NLUT + G_NW * G_CH * RP + TS * G_SB + (TS + 42) * G_SA;
+static_assert(G_CH == 8, "the register ring of the sweep is indexed by the step inside a chunk");
 } // namespace
 
+template <int PR>
 __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
 {
     extern __shared__ float g_lds[];
-    float *const explut = g_lds;
-    float *const cring_all = explut + 8192;
-    float *const sring_all = cring_all + G_NW * G_CH * RP;
-    float *const strip_b = sring_all + G_NW * SCOLS * SP;
+    float2 *const exppair = reinterpret_cast<float2 *>(g_lds);
+    float *const cring_all = g_lds + 2 * G_NLUT;
+    float *const strip_b = cring_all + G_NW * G_CH * RP;
     float *const strip_a = strip_b + TS * G_SB;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < 8192; i += G_NT) explut[i] = a.explut[i];
-    float *const cring = cring_all + wave * (G_CH * RP), *const sring = sring_all + wave * (SCOLS * SP);
+    for (int i = tid; i < G_NLUT; i += G_NT) exppair[i] = make_float2(a.explut[i], a.explut[min(i + 1, G_NLUT - 1)]);
+    float *const cring = cring_all + wave * (G_CH * RP);
     const float *__restrict__ src = a.src;
     const float *__restrict__ mask = a.mask;
     float *__restrict__ SW = a.SW;
@@ -74,13 +93,13 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
     const int step = TS - 2 * border;
     const int start_y = tile_y * step, end_y = min(start_y + TS, HH), TH = end_y - start_y;
     const int start_x = tile_x * step, end_x = min(start_x + TS, WW), TW = end_x - start_x;
-    const int pr = a.patch_radius, sr = a.search_radius, pr2 = 2 * pr, nt = 2 * sr + 1;
+    constexpr int pr = PR, pr2 = 2 * PR;
+    const int sr = a.search_radius, nt = 2 * sr + 1;
     const int xx0 = start_x + border, xvec_end = end_x - border - 3;
     const int nvec = xvec_end > xx0 ? (xvec_end - xx0 + 3) / 4 * 4 : 0;
     const int nsteps = TW + (TH + RPL - 1) / RPL - 1;
     const int row0 = lane * RPL;
     const bool lane_has_rows = row0 < TH;
-    const bool has1 = row0 + 1 < TH, has2 = row0 + 2 < TH;
     const bool sweeper = wave < nt;
     const int tx = wave - sr;
 
@@ -123,10 +142,16 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
 #define TICK(k) do { } while (0)
 #endif
     fetch_strips(0);
-    float left0 = 0.f, left1 = 0.f, left2 = 0.f, upleft0 = 0.f, s2_latest = 0.f;
+    // the sweep's ring: S of the lane's three rows and of the row above at the last eight steps, indexed by step & 7
+    float h0[G_CH], h1[G_CH], h2[G_CH], hu[G_CH];
+#pragma unroll
+    for (int j = 0; j < G_CH; ++j) h0[j] = h1[j] = h2[j] = hu[j] = 0.f;
     for (int it = 0; it < niter; ++it) {
         const int d0 = (it % nchunks) * G_CH;
-        if (d0 == 0) { left0 = left1 = left2 = upleft0 = s2_latest = 0.f; }     // a new search row: new integral images
+        if (d0 == 0) {                                                           // a new search row: new integral images
+#pragma unroll
+            for (int j = 0; j < G_CH; ++j) h0[j] = h1[j] = h2[j] = hu[j] = 0.f;
+        }
         __syncthreads();            // the previous iteration's accumulate pass is done with the strips and the rings
         TICK(0);
 #pragma unroll
@@ -157,53 +182,51 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
                 am[q] = mask[aoo[q]]; asw[q] = SW[aoo[q]]; aim[q] = img[aio[q]];
             }
         }
-        if (sweeper) {
-            // ---- sweep (the recurrence, written without branches: every LDS read of a step is an unconditional load issued up
-            //      front -- any address stays inside this kernel's LDS block -- and conditions only select values or mask stores, so a
-            //      step is one LDS round trip; the row above comes from the previous lane through a DPP wave shift)
-            for (int s = 0; s < G_CH; ++s) {
-                const int xx = d0 + s - lane;
-                const float up0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s2_latest), 0x138 /* wave_shr:1 */, 0xf, 0xf, false));
-                const bool act = lane_has_rows && xx >= 0 && xx < TW;
-                float *cr = cring + s * RP + row0;
-                float *sw = sring + (xx & (SCOLS - 1)) * SP + row0;
-                const float *sb = sring + ((xx - pr2) & (SCOLS - 1)) * SP + row0;
-                // squared differences of this wave's offset straight from the staged source rows (strip_a: the pixel, strip_b: the
-                // pixel at the offset); positions outside the tile are only ever computed by lanes whose results are discarded
-                const float *pa0 = strip_a + row0 * G_SA + s, *pb0 = strip_b + row0 * G_SB + s + tx + 8;
-                const float df0 = pa0[0] - pb0[0], df1 = pa0[G_SA] - pb0[G_SB], df2 = pa0[2 * G_SA] - pb0[2 * G_SB];
-                const float sc0 = df0 * df0, sc1 = df1 * df1, sc2 = df2 * df2;
-                // corners of the three box sums: column xx - 2pr at rows -2pr.. and 0.., and this column at the rows above
-                float ca[3], cb[3], cc[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { ca[k] = sb[k - pr2]; cb[k] = sb[k]; cc[k] = sw[k - pr2]; }
-                // The reference's first-column forms (up + s, above + s) are what the general form gives when everything to the left is
-                // +0: (0 + u) - (0 - s) = u + s with the same single rounding.  The state of a lane that has not started (xx < 0) is
-                // kept at 0 below, so only S(0,0) = 0 needs its own case.  Arms are chosen with bit masks (no branches).
-                const float st0 = bsel(row0 == 0, bsel(xx == 0, 0.f, left0 + sc0), (left0 + up0) - (upleft0 - sc0));
-                const float st1 = bsel(has1, (left1 + st0) - (left0 - sc1), 0.f);
-                const float st2 = bsel(has2, (left2 + st1) - (left1 - sc2), 0.f);
-                if (pr2 == 2) cc[2] = st0;            // index 0 of this column is this step's own result (2pr >= 4: all rows above)
-                const float r0 = ((st0 + ca[0]) - cb[0]) - cc[0];
-                const float r1 = ((st1 + ca[1]) - cb[1]) - cc[1];
-                const float r2 = ((st2 + ca[2]) - cb[2]) - cc[2];
-                if (act) {
-                    sw[0] = st0; sw[1] = st1; sw[2] = st2;
-                    if (xx >= pr2) {
-                        if (row0 >= pr2) cr[0] = r0;
-                        if (has1 && row0 + 1 >= pr2) cr[1] = r1;
-                        if (has2 && row0 + 2 >= pr2) cr[2] = r2;
-                    }
+        if (sweeper && lane_has_rows) {
+            // ---- sweep.  Step t = d0 + s puts lane l on column t - l.  A lane that has not started (t < l) is switched off, so its ring
+            //      still holds the zeros of the reset: that is the "everything to the left is +0" its first column needs -- the
+            //      reference's first-column forms (up + s, above + s) are what the general form gives then: (0 + u) - (0 - s) = u + s
+            //      with the same single rounding, and likewise the first row with lane 0's wave shift delivering 0.  Only S(0,0) = 0
+            //      is a case of its own.  A lane past its last column keeps computing: what it stores is never read (the accumulate
+            //      pass reads box sums of columns < TW only), and nothing here can trap.  From step 49 on every lane with rows has
+            //      started: those chunks run without the per-step test.
+            const float *const pa = strip_a + row0 * G_SA, *const pb = strip_b + row0 * G_SB + tx + 8;
+            float *const cr = cring + row0;
+            auto step = [&](auto sc_, auto starting_) {
+                constexpr int s = decltype(sc_)::value;
+                constexpr bool starting = decltype(starting_)::value;
+                constexpr int p = (s + 7) & 7, q = (s + 8 - pr2) & 7, qq = (s + 7 - pr2) & 7;
+                if (starting && lane > d0 + s) return;
+                const float up0 = lane_above(h2[p]);
+                const float df0 = pa[s] - pb[s], df1 = pa[G_SA + s] - pb[G_SB + s], df2 = pa[2 * G_SA + s] - pb[2 * G_SB + s];
+                float sc0 = df0 * df0;
+                const float sc1 = df1 * df1, sc2 = df2 * df2;
+                if (starting && s == 0 && d0 == 0) sc0 = 0.f;        // step 0: lane 0 alone, at S(0,0)
+                const float st0 = (h0[p] + up0) - (hu[p] - sc0);
+                const float st1 = (h1[p] + st0) - (h0[p] - sc1);
+                const float st2 = (h2[p] + st1) - (h1[p] - sc2);
+                // corners of the three box sums: rows k - 2pr at this column (cc) and at column - 2pr (ca), the lane's own rows at column - 2pr (cb)
+                float ca0, ca1, ca2, cc0, cc1, cc2;
+                if (pr2 == 4) {         // rows -4 (two lanes up: the previous lane's "row above"), -3, -2 (the previous lane's rows 0, 1)
+                    cc0 = lane_above(hu[p]); cc1 = lane_above(h0[p]); cc2 = lane_above(h1[p]);
+                    ca0 = lane_above(hu[qq]); ca1 = lane_above(h0[qq]); ca2 = lane_above(h1[qq]);
+                } else {                // rows -2, -1 (the previous lane's rows 1, 2) and the lane's own row 0
+                    cc0 = lane_above(h1[p]); cc1 = up0; cc2 = st0;
+                    ca0 = lane_above(h1[qq]); ca1 = lane_above(h2[qq]); ca2 = h0[q];
                 }
-                // state: zero until the lane starts; what a lane holds after its last column is never read
-                const int started = -(int)(xx >= 0);
-                upleft0 = __int_as_float(__float_as_int(up0) & started);
-                left0 = __int_as_float(__float_as_int(st0) & started);
-                left1 = __int_as_float(__float_as_int(st1) & started);
-                left2 = __int_as_float(__float_as_int(st2) & started);
-                s2_latest = left2;
-                wave_fence();
-            }
+                cr[s * RP] = ((st0 + ca0) - h0[q]) - cc0;
+                cr[s * RP + 1] = ((st1 + ca1) - h1[q]) - cc1;
+                cr[s * RP + 2] = ((st2 + ca2) - h2[q]) - cc2;
+                h0[s] = st0; h1[s] = st1; h2[s] = st2; hu[s] = up0;
+            };
+            auto chunk = [&](auto starting_) {
+                step(std::integral_constant<int, 0>{}, starting_); step(std::integral_constant<int, 1>{}, starting_);
+                step(std::integral_constant<int, 2>{}, starting_); step(std::integral_constant<int, 3>{}, starting_);
+                step(std::integral_constant<int, 4>{}, starting_); step(std::integral_constant<int, 5>{}, starting_);
+                step(std::integral_constant<int, 6>{}, starting_); step(std::integral_constant<int, 7>{}, starting_);
+            };
+            if (d0 < 56) chunk(std::true_type{});
+            else chunk(std::false_type{});
         }
         TICK(4);
         __syncthreads();
@@ -222,11 +245,13 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
             const float *crp = cring_all + s * RP + row;
             // weight of offset w in the reference's two lane forms (vector lanes L213-228, scalar tail L229-243), added in offset order
             auto add_vec = [&](int w) {
-                const float dd = sse_max(crp[w * (G_CH * RP)], 0.f) * m;
-                const float clamped = sse_max(sse_min(8190.f, dd), 0.f);
-                const int idx = (int)clamped;
-                const float diff = sse_max(sse_min(8191.f, dd), 0.f) - (float)idx;
-                const float weight = (diff * explut[idx + 1]) + ((1.f - diff) * explut[idx]);
+                // _mm_max_ps(_mm_min_ps(c, x), 0) is the median of (x, 0, c) for every x: a NaN gives 0 both ways (v_med3_f32 returns the
+                // minimum of the three when one is a NaN), -0 and +0 give the same weight below
+                const float dd = max0(crp[w * (G_CH * RP)]) * m;
+                const int idx = (int)__builtin_amdgcn_fmed3f(dd, 0.f, 8190.f);
+                const float diff = __builtin_amdgcn_fmed3f(dd, 0.f, 8191.f) - (float)idx;
+                const float2 e = exppair[idx];
+                const float weight = (diff * e.y) + ((1.f - diff) * e.x);
                 swv = swv + weight;
                 imv = imv + (weight * sbp[w]);
             };
@@ -234,12 +259,13 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
                 if (vec) { add_vec(w); return; }
                 const float dd = std_max(crp[w * (G_CH * RP)], 0.f) * m;
                 float weight;
-                if (dd < 0.f || !(dd == dd)) weight = explut[0];
-                else if (dd > 8190.f) weight = explut[8191];
+                if (dd < 0.f || !(dd == dd)) weight = exppair[0].x;
+                else if (dd > 8190.f) weight = exppair[8190].y;
                 else {
                     const int idx = (int)dd;
                     const float diff = dd - (float)idx;
-                    const float p1 = explut[idx], p2 = explut[idx + 1] - p1;
+                    const float2 e = exppair[idx];
+                    const float p1 = e.x, p2 = e.y - p1;
                     weight = p1 + (p2 * diff);
                 }
                 swv = swv + weight;
@@ -284,15 +310,17 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
 
 bool nlm_group_supported(const NlmArgs &a)
 {
-    return 2 * a.patch_radius + 4 <= SCOLS && a.border * 2 < TS && a.search_radius <= 5 && a.patch_radius <= 2 && a.patch_radius >= 1;
+    return a.border * 2 < TS && a.search_radius <= 5 && a.patch_radius <= 2 && a.patch_radius >= 1;
 }
 
 hipError_t launch_nlm_group(const NlmArgs &a, hipStream_t s)
 {
     constexpr size_t dyn = (size_t)G_LDS_FLOATS * sizeof(float);
     static_assert(dyn <= 160 * 1024, "LDS budget");
-    if (hipError_t e = dyn_lds_once(reinterpret_cast<const void *>(&nlm_group_kernel), (int)dyn); e != hipSuccess) return e;
-    hipLaunchKernelGGL(nlm_group_kernel, dim3(a.ntiles_x * a.ntiles_y), dim3(G_NT), dyn, s, a);
+    const void *const k = a.patch_radius == 2 ? reinterpret_cast<const void *>(&nlm_group_kernel<2>) : reinterpret_cast<const void *>(&nlm_group_kernel<1>);
+    if (hipError_t e = dyn_lds_once(k, (int)dyn); e != hipSuccess) return e;
+    if (a.patch_radius == 2) hipLaunchKernelGGL(nlm_group_kernel<2>, dim3(a.ntiles_x * a.ntiles_y), dim3(G_NT), dyn, s, a);
+    else hipLaunchKernelGGL(nlm_group_kernel<1>, dim3(a.ntiles_x * a.ntiles_y), dim3(G_NT), dyn, s, a);
     return hipGetLastError();
 }
 

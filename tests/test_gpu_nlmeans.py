@@ -82,3 +82,23 @@ def test_full_denoise_tool_config4_stages(gpu_ctx, detail):
             err = np.abs(g.astype(np.float64) - r.astype(np.float64))
             # on a 0..65535 scale: the NL-means weights amplify the DCT round-off at isolated pixels
             assert err.max() <= 64.0 and np.percentile(err, 99.9) <= 32.0 and np.median(err) <= 0.25, (err.max(), np.percentile(err, 99.9), np.median(err))
+
+
+@pytest.mark.parametrize("poison", ["huge", "nan"])
+def test_nlmeans_non_finite_and_huge_samples(gpu_ctx, poison):
+    """The weight index is clamped with _mm_min_ps / _mm_max_ps in the reference (nlmeans.cc:213-228): a NaN distance gives index 0, an
+    infinite one the last entry.  Samples of 1e30 overflow the squared differences to +inf (and inf - inf to NaN further along the integral
+    image); NaN samples reach the distances directly.  Same bits wherever the result is a number, NaN in the same places."""
+    from art_amd import capi
+    img = _Y(300, 300, 77)
+    if poison == "huge":
+        img[40, 50] = 1e30; img[200, 13] = -1e30; img[299, 299] = 3e38
+    else:
+        img[40, 50] = np.nan; img[151, 151] = np.inf
+    got = img.copy()
+    gpu_ctx.nlmeans(capi.host_plane(got), 50, 80, 1.0)
+    ref = O.nlmeans(img, 50, 80, 1.0)
+    gn, rn = np.isnan(got), np.isnan(ref)
+    assert (gn == rn).all()
+    assert int((got.view(np.uint32)[~gn] != ref.view(np.uint32)[~rn]).sum()) == 0
+    assert (~gn).sum() > 0
