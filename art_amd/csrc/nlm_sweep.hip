@@ -33,6 +33,7 @@
 namespace artgpu {
 
 namespace {
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int TS = 150;          // reference tile size
 constexpr int RPL = 3;           // tile rows per lane
 constexpr int RP = 156;          // chunk ring pitch (floats per step): >= 152 (a lane's three rows are stored whether they exist or not), and
@@ -75,12 +76,12 @@ template <int PR>
 __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
 {
     extern __shared__ float g_lds[];
-    float2 *const exppair = reinterpret_cast<float2 *>(g_lds);
+    f32x2 *const exppair = reinterpret_cast<f32x2 *>(g_lds);
     float *const cring_all = g_lds + 2 * G_NLUT;
     float *const strip_b = cring_all + G_NW * G_CH * RP;
     float *const strip_a = strip_b + TS * G_SB;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < G_NLUT; i += G_NT) exppair[i] = make_float2(a.explut[i], a.explut[min(i + 1, G_NLUT - 1)]);
+    for (int i = tid; i < G_NLUT; i += G_NT) exppair[i] = f32x2{a.explut[i], a.explut[min(i + 1, G_NLUT - 1)]};
     float *const cring = cring_all + wave * (G_CH * RP);
     const float *__restrict__ src = a.src;
     const float *__restrict__ mask = a.mask;
@@ -245,13 +246,17 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
             const float *crp = cring_all + s * RP + row;
             // weight of offset w in the reference's two lane forms (vector lanes L213-228, scalar tail L229-243), added in offset order
             auto add_vec = [&](int w) {
-                // _mm_max_ps(_mm_min_ps(c, x), 0) is the median of (x, 0, c) for every x: a NaN gives 0 both ways (v_med3_f32 returns the
-                // minimum of the three when one is a NaN), -0 and +0 give the same weight below
+                // The reference clamps twice (L213-228): index = (int)max(min(8190, dd), 0), fraction = max(min(8191, dd), 0) - index.  One clamp
+                // to [0, 8191] gives the same weight: below 8191 the integer part and the fraction (x - floor x, exact) are the reference's;
+                // at 8191 it reads pair 8191 = (e[8191], e[8191]) with fraction 0 where the reference reads pair 8190 with fraction 1 --
+                // 0 * e + 1 * e[8191] either way.  _mm_max_ps(_mm_min_ps(c, x), 0) is the median of (x, 0, c) for every x: a NaN gives 0
+                // both ways (v_med3_f32 returns the minimum of the three when one is a NaN); -0 and +0 give the same weight.
                 const float dd = max0(crp[w * (G_CH * RP)]) * m;
-                const int idx = (int)__builtin_amdgcn_fmed3f(dd, 0.f, 8190.f);
-                const float diff = __builtin_amdgcn_fmed3f(dd, 0.f, 8191.f) - (float)idx;
-                const float2 e = exppair[idx];
-                const float weight = (diff * e.y) + ((1.f - diff) * e.x);
+                const float t = __builtin_amdgcn_fmed3f(dd, 0.f, 8191.f);
+                const int idx = (int)t;
+                const float diff = __builtin_amdgcn_fractf(t);
+                const f32x2 pr = exppair[idx] * f32x2{1.f - diff, diff};       // v_pk_mul_f32
+                const float weight = pr.y + pr.x;
                 swv = swv + weight;
                 imv = imv + (weight * sbp[w]);
             };
@@ -264,7 +269,7 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
                 else {
                     const int idx = (int)dd;
                     const float diff = dd - (float)idx;
-                    const float2 e = exppair[idx];
+                    const f32x2 e = exppair[idx];
                     const float p1 = e.x, p2 = e.y - p1;
                     weight = p1 + (p2 * diff);
                 }
