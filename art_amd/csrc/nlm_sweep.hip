@@ -109,8 +109,40 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
     constexpr int NPB = (TS * G_SB + G_NT - 1) / G_NT, NPA = (TS * G_CH + G_NT - 1) / G_NT;
     const int nchunks = (nsteps + G_CH - 1) / G_CH, niter = nt * nchunks;
     float pb[NPB], pa[NPA];
+    // A tile whose strips (the 21-column window of every search row, the skew of the anti-diagonals) lie inside the padded image -- nine
+    // tiles in ten -- fetches them without clamps: a per-thread element offset that never changes, added by the load itself to a
+    // uniform base that moves with (ty, d0).  strip_a's zero fill outside the tile is not needed: lanes left of the tile are switched
+    // off in the sweep and what lanes right of it compute is never read.
+    constexpr int SKEW = (TS - 1) / RPL;
+    const bool interior = TH == TS && TW == TS && start_y >= sr && start_y + TS - 1 + sr <= HH - 1 && start_x >= 8 + SKEW &&
+                          start_x + (nchunks - 1) * G_CH - 8 + G_SB - 1 <= WW - 1;
+    unsigned pbo[NPB], pao[NPA];
+#pragma unroll
+    for (int q = 0; q < NPB; ++q) {
+        const int e = min(tid + q * G_NT, TS * G_SB - 1);
+        const int row = e / G_SB, k = e - row * G_SB;
+        pbo[q] = (unsigned)(row * WW + k + SKEW - row / RPL) * 4u;
+    }
+#pragma unroll
+    for (int q = 0; q < NPA; ++q) {
+        const int e = min(tid + q * G_NT, TS * G_CH - 1);
+        const int row = e / G_CH, st = e - row * G_CH;
+        pao[q] = (unsigned)(row * WW + st + SKEW - row / RPL) * 4u;
+    }
+    // a uniform base plus a 32-bit byte offset per lane: the addressing form the load / store instructions have (no 64-bit vector arithmetic)
+    auto at = [](float *base, unsigned byte_off) { return reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off); };
+    auto atc = [](const float *base, unsigned byte_off) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off); };
     auto fetch_strips = [&](int it) {
         const int ty = it / nchunks - sr, d0 = (it % nchunks) * G_CH;
+        if (interior) {
+            const float *const ub = src + ((size_t)(ty + start_y) * WW + (d0 - 8 + start_x - SKEW));
+            const float *const ua = src + ((size_t)start_y * WW + (d0 + start_x - SKEW));
+#pragma unroll
+            for (int q = 0; q < NPB; ++q) pb[q] = *atc(ub, pbo[q]);
+#pragma unroll
+            for (int q = 0; q < NPA; ++q) pa[q] = *atc(ua, pao[q]);
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NPB; ++q) {
             const int e = tid + q * G_NT;
@@ -126,8 +158,8 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
 #pragma unroll
         for (int q = 0; q < NPA; ++q) {
             const int e = tid + q * G_NT;
-            const int row = e / G_CH, s = e - row * G_CH;
-            const int xx = d0 + s - row / RPL;
+            const int row = e / G_CH, st = e - row * G_CH;
+            const int xx = d0 + st - row / RPL;
             float v = 0.f;
             if (e < TS * G_CH && row < TH && xx >= 0 && xx < TW) {
                 const int gy = min(max(row + start_y, 0), HH - 1), gx = min(max(xx + start_x, 0), WW - 1);
@@ -142,6 +174,23 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
 #else
 #define TICK(k) do { } while (0)
 #endif
+    // per-thread constants of the accumulate pass: thread t of slot q holds pixel (row, step) = (t / 8, t % 8) of the chunk, i.e. tile
+    // column d0 + step - row / 3; everything but d0 is fixed for the whole tile
+    bool arow[NPA];
+    int axc[NPA];
+    unsigned aoc[NPA], aic[NPA];
+#pragma unroll
+    for (int q = 0; q < NPA; ++q) {
+        const int t = tid + q * G_NT;
+        const int row = t / G_CH, st = t - row * G_CH;
+        const int sty = row - pr;
+        arow[q] = t < TS * G_CH && sty >= border && sty < TH - border;
+        axc[q] = st - row / RPL - pr - border;                   // stx - border = d0 + this
+        // byte offsets of the pixel at d0 = 0, modulo 2^32: together with 4 * d0 they are in range whenever the pixel is valid
+        const int y = max(sty + start_y - border, 0), x0 = axc[q] + start_x;
+        aoc[q] = ((unsigned)y * (unsigned)W + (unsigned)x0) * 4u;
+        aic[q] = ((unsigned)y * (unsigned)a.img_stride + (unsigned)x0) * 4u;
+    }
     fetch_strips(0);
     // the sweep's ring: S of the lane's three rows and of the row above at the last eight steps, indexed by step & 7
     float h0[G_CH], h1[G_CH], h2[G_CH], hu[G_CH];
@@ -167,21 +216,13 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
         if (it + 1 < niter) fetch_strips(it + 1);
         bool aok[NPA];
         float am[NPA], asw[NPA], aim[NPA];
-        size_t aoo[NPA], aio[NPA];
+        unsigned aoo[NPA], aio[NPA];
 #pragma unroll
         for (int q = 0; q < NPA; ++q) {
-            const int t = tid + q * G_NT;
-            const int row = t / G_CH, s = t - row * G_CH;
-            const int xx = d0 + s - row / RPL;
-            const int sty = row - pr, stx = xx - pr;
-            aok[q] = t < TS * G_CH && row < TH && xx < TW && sty >= border && sty < TH - border && stx >= border && stx < TW - border;
-            am[q] = asw[q] = aim[q] = 0.f; aoo[q] = aio[q] = 0;
-            if (aok[q]) {
-                const int y = sty + start_y - border, x = stx + start_x - border;
-                aoo[q] = (size_t)y * W + x;
-                aio[q] = (size_t)y * a.img_stride + x;
-                am[q] = mask[aoo[q]]; asw[q] = SW[aoo[q]]; aim[q] = img[aio[q]];
-            }
+            aok[q] = arow[q] && (unsigned)(d0 + axc[q]) < (unsigned)(TW - 2 * border);
+            aoo[q] = aoc[q] + 4u * (unsigned)d0; aio[q] = aic[q] + 4u * (unsigned)d0;
+            am[q] = asw[q] = aim[q] = 0.f;
+            if (aok[q]) { am[q] = *atc(mask, aoo[q]); asw[q] = *at(SW, aoo[q]); aim[q] = *at(img, aio[q]); }
         }
         if (sweeper && lane_has_rows) {
             // ---- sweep.  Step t = d0 + s puts lane l on column t - l.  A lane that has not started (t < l) is switched off, so its ring
@@ -237,9 +278,8 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
             if (!aok[q]) continue;
             const int t = tid + q * G_NT;
             const int row = t / G_CH, s = t - row * G_CH;
-            const int xx = d0 + s - row / RPL;
-            const int sty = row - pr, px = xx - pr + start_x;
-            const bool vec = (px - xx0) < nvec;
+            const int sty = row - pr;
+            const bool vec = d0 + axc[q] < nvec;        // column - (start_x + border), nlmeans.cc:207-212
             const float m = am[q];
             float swv = asw[q], imv = aim[q];
             const float *sbp = strip_b + sty * G_SB + (s - row / RPL + sty / RPL - pr + 8 - sr);    // + w: the sample at offset w
@@ -289,8 +329,8 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
             } else {
                 for (int w = 0; w < nt; ++w) add_any(w);
             }
-            SW[aoo[q]] = swv;
-            img[aio[q]] = imv;
+            *at(SW, aoo[q]) = swv;
+            *at(img, aio[q]) = imv;
         }
         TICK(5);
     }
