@@ -50,6 +50,17 @@ __device__ __forceinline__ float lane_above(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
 }
+// x - (the previous lane's v) for three pairs, the wave shift folded into the subtraction as its DPP operand (the compiler folds the shift
+// into additions only and leaves a v_mov_b32_dpp in front of a subtraction).  Inline assembly is outside the compiler's hazard
+// bookkeeping: a VALU result needs two wait states before a DPP instruction may read it, hence the s_nop.
+__device__ __forceinline__ void sub_lane_above3(float &r0, float &r1, float &r2, float x0, float x1, float x2, float v0, float v1, float v2)
+{
+    asm("s_nop 1\n\t"
+        "v_subrev_f32_dpp %0, %6, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_subrev_f32_dpp %1, %7, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_subrev_f32_dpp %2, %8, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(x0), "v"(x1), "v"(x2), "v"(v0), "v"(v1), "v"(v2));
+}
 // _mm_max_ps(x, 0) for an x that is the result of an arithmetic instruction (never a signalling NaN): NaN -> 0, like the compare-and-select
 // form, in one instruction (the compiler's fmaxf would canonicalise the LDS operand first)
 __device__ __forceinline__ float max0(float x)
@@ -234,13 +245,20 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
             //      started: those chunks run without the per-step test.
             const float *const pa = strip_a + row0 * G_SA, *const pb = strip_b + row0 * G_SB + tx + 8;
             float *const cr = cring + row0;
+            float na0 = pa[0], na1 = pa[G_SA], na2 = pa[2 * G_SA], nb0 = pb[0], nb1 = pb[G_SB], nb2 = pb[2 * G_SB];
             auto step = [&](auto sc_, auto starting_) {
                 constexpr int s = decltype(sc_)::value;
                 constexpr bool starting = decltype(starting_)::value;
                 constexpr int p = (s + 7) & 7, q = (s + 8 - pr2) & 7, qq = (s + 7 - pr2) & 7;
+                // the strips' samples one step ahead, so that a step's LDS latency is not at the head of its dependent chain
+                const float a0 = na0, a1 = na1, a2 = na2, b0 = nb0, b1 = nb1, b2 = nb2;
+                if (s + 1 < G_CH) {
+                    na0 = pa[s + 1]; na1 = pa[G_SA + s + 1]; na2 = pa[2 * G_SA + s + 1];
+                    nb0 = pb[s + 1]; nb1 = pb[G_SB + s + 1]; nb2 = pb[2 * G_SB + s + 1];
+                }
                 if (starting && lane > d0 + s) return;
                 const float up0 = lane_above(h2[p]);
-                const float df0 = pa[s] - pb[s], df1 = pa[G_SA + s] - pb[G_SB + s], df2 = pa[2 * G_SA + s] - pb[2 * G_SB + s];
+                const float df0 = a0 - b0, df1 = a1 - b1, df2 = a2 - b2;
                 float sc0 = df0 * df0;
                 const float sc1 = df1 * df1, sc2 = df2 * df2;
                 if (starting && s == 0 && d0 == 0) sc0 = 0.f;        // step 0: lane 0 alone, at S(0,0)
@@ -248,17 +266,17 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
                 const float st1 = (h1[p] + st0) - (h0[p] - sc1);
                 const float st2 = (h2[p] + st1) - (h1[p] - sc2);
                 // corners of the three box sums: rows k - 2pr at this column (cc) and at column - 2pr (ca), the lane's own rows at column - 2pr (cb)
-                float ca0, ca1, ca2, cc0, cc1, cc2;
+                float r0, r1, r2;
                 if (pr2 == 4) {         // rows -4 (two lanes up: the previous lane's "row above"), -3, -2 (the previous lane's rows 0, 1)
-                    cc0 = lane_above(hu[p]); cc1 = lane_above(h0[p]); cc2 = lane_above(h1[p]);
-                    ca0 = lane_above(hu[qq]); ca1 = lane_above(h0[qq]); ca2 = lane_above(h1[qq]);
+                    const float ca0 = lane_above(hu[qq]), ca1 = lane_above(h0[qq]), ca2 = lane_above(h1[qq]);
+                    sub_lane_above3(r0, r1, r2, (st0 + ca0) - h0[q], (st1 + ca1) - h1[q], (st2 + ca2) - h2[q], hu[p], h0[p], h1[p]);
                 } else {                // rows -2, -1 (the previous lane's rows 1, 2) and the lane's own row 0
-                    cc0 = lane_above(h1[p]); cc1 = up0; cc2 = st0;
-                    ca0 = lane_above(h1[qq]); ca1 = lane_above(h2[qq]); ca2 = h0[q];
+                    const float ca0 = lane_above(h1[qq]), ca1 = lane_above(h2[qq]), ca2 = h0[q];
+                    r0 = ((st0 + ca0) - h0[q]) - lane_above(h1[p]);
+                    r1 = ((st1 + ca1) - h1[q]) - up0;
+                    r2 = ((st2 + ca2) - h2[q]) - st0;
                 }
-                cr[s * RP] = ((st0 + ca0) - h0[q]) - cc0;
-                cr[s * RP + 1] = ((st1 + ca1) - h1[q]) - cc1;
-                cr[s * RP + 2] = ((st2 + ca2) - h2[q]) - cc2;
+                cr[s * RP] = r0; cr[s * RP + 1] = r1; cr[s * RP + 2] = r2;
                 h0[s] = st0; h1[s] = st1; h2[s] = st2; hu[s] = up0;
             };
             auto chunk = [&](auto starting_) {
