@@ -188,18 +188,22 @@ def main() -> None:
     # --lanes: additional frames in flight, each with its own context / stream / buffers / frame of the batch
     import threading
     extra = []
+
+    def make_lane(k):
+        st = torch.cuda.Stream(dev)
+        lr = synth.xtrans_frame(W, H, seed=rank + 1000 * k) if xtrans else synth.bayer_frame(W, H, filt, seed=rank + 1000 * k)
+        ln = {"ctx": apply_opts(capi.Context(local_rank, st.cuda_stream)), "stream": st, "raw": torch.from_numpy(lr).to(dev),
+              "out": [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(3)],
+              "img": [torch.empty((ih, iw), dtype=torch.float32, device=dev) for _ in range(3)]}
+        ln["p_raw"] = capi.device_plane(ln["raw"]); ln["p_out"] = capi.RGB(*[capi.device_plane(t) for t in ln["out"]])
+        ln["p_img"] = capi.RGB(*[capi.device_plane(t) for t in ln["img"]])
+        return ln
+
     if args.lanes > 1:
         if not pipeline:
             raise SystemExit("--lanes needs a pipeline workload (c3/c4/c5)")
         for k in range(1, args.lanes):
-            st = torch.cuda.Stream(dev)
-            lr = synth.xtrans_frame(W, H, seed=rank + 1000 * k) if xtrans else synth.bayer_frame(W, H, filt, seed=rank + 1000 * k)
-            ln = {"ctx": apply_opts(capi.Context(local_rank, st.cuda_stream)), "stream": st, "raw": torch.from_numpy(lr).to(dev),
-                  "out": [torch.empty((H, W), dtype=torch.float32, device=dev) for _ in range(3)],
-                  "img": [torch.empty((ih, iw), dtype=torch.float32, device=dev) for _ in range(3)]}
-            ln["p_raw"] = capi.device_plane(ln["raw"]); ln["p_out"] = capi.RGB(*[capi.device_plane(t) for t in ln["out"]])
-            ln["p_img"] = capi.RGB(*[capi.device_plane(t) for t in ln["img"]])
-            extra.append(ln)
+            extra.append(make_lane(k))
 
     def lane_frame(ln):
         c = ln["ctx"]
@@ -455,6 +459,27 @@ def main() -> None:
         barrier()
         n_ms = 1e3 * (time.perf_counter() - n0) / nn
         result["neutral_tone"] = {"ms_per_step": round(n_ms, 4), "value": round(mp / (n_ms / 1e3), 2), "unit": "MP/s", "steps": nn}
+
+    # what `--lanes 2` gives (a second frame in flight on its own context / stream / host thread), beside the one-frame-per-step line
+    if pipeline and world == 1 and args.lanes == 1 and args.sustained_seconds > 0:
+        ln2 = make_lane(1)
+
+        def step2():
+            t_ = threading.Thread(target=lane_frame, args=(ln2,))
+            t_.start()
+            step0()
+            t_.join()
+        step2()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        n2 = max(1, min(args.steps, 10))
+        for _ in range(n2):
+            step2()
+        torch.cuda.synchronize(dev)
+        ms2 = 1e3 * (time.perf_counter() - t0) / n2
+        result["two_frames_in_flight"] = {"ms_per_step": round(ms2, 4), "frames_per_step": 2, "value": round(2 * mp / (ms2 / 1e3), 2), "unit": "MP/s",
+                                          "steps": n2, "flag": "--lanes 2"}
+        del ln2
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_lib
