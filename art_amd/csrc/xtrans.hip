@@ -115,6 +115,25 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
     const int r = 3 * _bi + (T->cls[KC][0][_k] - (top) % 3 + 3) % 3, c = 3 * (_cell - _bi * NCELL) + (T->cls[KC][1][_k] - (left) % 3 + 3) % 3
     const xt_tab T = (xt_tab)&s_tab;
     const Geo G{T};
+    // With four sites of a class per cell (every real sensor) the class member a thread works on never changes -- site t = tid + i * NT is member
+    // tid & 3 of cell (tid >> 2) + 256 i -- so everything XT_SITE and the phases derive from (row % 3, col % 3) is a per-thread constant and the
+    // cell advances by (6 rows, 28 columns) of cells per iteration: no division, no table look-up per site.  FOR_SITES4 walks the cells;
+    // SiteK holds what depends on the tile origin.
+    struct SiteK { int dr, dc; unsigned fpack; };      // tile-local residues of the thread's class member; fcol for (cell row, cell column) parities, 2 bits each
+    auto site_setup = [&](int KC, int top_, int left_) {
+        SiteK q;
+        const int rr = T->cls[KC][0][tid & 3], cc = T->cls[KC][1][tid & 3];     // row % 3, col % 3 of the member
+        q.dr = (rr - top_ % 3 + 3) % 3; q.dc = (cc - left_ % 3 + 3) % 3;
+        const int mpar = ((top_ + q.dr - rr) / 3) & 1, npar = ((left_ + q.dc - cc) / 3) & 1;      // row = rr + 3 (cell row + m0): row % 6 = rr + 3 (parity)
+        q.fpack = 0;
+#pragma unroll
+        for (int ab = 0; ab < 4; ++ab)
+            q.fpack |= (unsigned)T->xtrans[(rr + 3 * (((ab >> 1) + mpar) & 1)) * 6 + cc + 3 * (((ab & 1) + npar) & 1)] << (2 * ab);
+        return q;
+    };
+#define FOR_SITES4(Q, r, c, f)                                                                                              \
+    for (int _bi = (tid >> 2) / NCELL, _cj = (tid >> 2) - _bi * NCELL; _bi < NCELL; _bi += 6 + (_cj >= NCELL - 28), _cj += _cj >= NCELL - 28 ? 28 - NCELL : 28) \
+        for (int r = 3 * _bi + (Q).dr, c = 3 * _cj + (Q).dc, f = (int)(((Q).fpack >> (2 * (((_bi & 1) << 1) | (_cj & 1)))) & 3u), _once = 1; _once; _once = 0)
     const int ndir = a.ndir, passes = a.passes;
     float *const buffer = a.arena + (size_t)blockIdx.x * a.arena_floats;
     float *const labbase = buffer + (size_t)TS * TS * (ndir * 3);
@@ -193,6 +212,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
         const int nlab = mrl - 8;                        // lab rows [0, nlab)
         const xt_lf L = (xt_lf)xt_lds;
         const int row0s = (top - sgrow + 4) / 3 * 3 + sgrow, col0s = (left - sgcol + 4) / 3 * 3 + sgcol;
+        const bool fast4 = T->ncls[0] == 4 && T->ncls[1] == 4;
 
         // cielab (L41-116) in place over rows 4 .. 4 + nlab, columns 4 .. 4 + LW of the buffer in LDS + the derivative along direction d (L657-741)
         auto lab_and_derivative = [&](int d) {
@@ -324,9 +344,25 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             xt_lds_barrier();
 
             for (int pass = 0; pass < passes; pass++) {
+                // (set up per pass: held across the whole tile the site constants push the final phases into scratch)
+                const SiteK q0 = site_setup(0, top, left), q1 = site_setup(1, top, left);
                 // recalculate green from interpolated values of closer pixels (L483-524): buffer k is the target of hexagon entry
                 // (k ^ flip) + 2, of none where k == flip
                 if (pass) {
+                    if (fast4) {
+                        const int rr0 = T->cls[0][0][tid & 3], cc0 = T->cls[0][1][tid & 3];
+                        const int flip = T->right_shift[rr0] ? 0 : 1, e = k ^ flip;
+                        const int hx = T->allhex1[rr0][cc0][e + 2];
+                        if (e != 0) {
+                            FOR_SITES4(q0, r, c, f) {
+                                if (r < 2 || c < 2 || r >= mrl - 2 || c >= mcl - 2) continue;
+                                const float *s = gmm + ((size_t)r * TSH + (c >> 1)) * 2;
+                                const xt_lf rix = L + r * TS + c;
+                                const float val = 0.33333333f * (rix[-2 * hx + PL] + 2 * (rix[hx + PL] - rix[hx + f * PL]) - rix[-2 * hx + f * PL]) + rix[f * PL];
+                                rix[PL] = limf(val, s[0], s[1]);
+                            }
+                        }
+                    } else {
                     FOR_T(NCELL * NCELL * T->ncls[0]) {
                         XT_SITE(0, t, top, left, r, c);
                         const int row = top + r, col = left + c;
@@ -340,6 +376,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                         const xt_lf rix = L + r * TS + c;
                         const float val = 0.33333333f * (rix[-2 * hx + PL] + 2 * (rix[hx + PL] - rix[hx + f * PL]) - rix[-2 * hx + f * PL]) + rix[f * PL];
                         rix[PL] = limf(val, s[0], s[1]);
+                    }
                     }
                     xt_lds_barrier();
                 }
@@ -377,6 +414,20 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                 }
                 xt_lds_barrier();
                 // red for blue pixels and vice versa (L564-606): only buffer dc ever compares the two candidate axes
+                if (fast4) {
+                    const int cd = ((T->cls[0][0][tid & 3] - sgrow % 3 + 3) % 3) ? TS : 1;         // (row - sgrow) % 3 != 0
+                    const int hd = 3 * (cd ^ TS ^ 1);
+                    const bool both = k == (cd == 1 ? 1 : 0);
+                    FOR_SITES4(q0, r, c, fc) {
+                        if (r < 3 || c < 3 || r >= mrl - 3 || c >= mcl - 3) continue;
+                        const int f = 2 - fc;
+                        const xt_lf rix = L + r * TS + c;
+                        const float g0 = rix[PL];
+                        int i = cd;
+                        if (both && !((fabsf(g0 - rix[cd + PL]) + fabsf(g0 - rix[-cd + PL])) < 2.f * (fabsf(g0 - rix[hd + PL]) + fabsf(g0 - rix[-hd + PL])))) i = hd;
+                        rix[f * PL] = g0 + 0.5f * (rix[i + f * PL] + rix[-i + f * PL] - rix[i + PL] - rix[-i + PL]);
+                    }
+                } else {
                 FOR_T(NCELL * NCELL * T->ncls[0]) {
                     XT_SITE(0, t, top, left, r, c);
                     const int row = top + r, col = left + c;
@@ -391,10 +442,29 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                     if (k == dc && !((fabsf(g0 - rix[cd + PL]) + fabsf(g0 - rix[-cd + PL])) < 2.f * (fabsf(g0 - rix[hd + PL]) + fabsf(g0 - rix[-hd + PL])))) i = hd;
                     rix[f * PL] = g0 + 0.5f * (rix[i + f * PL] + rix[-i + f * PL] - rix[i + PL] - rix[-i + PL]);
                 }
+                }
                 xt_lds_barrier();
                 // red and blue for 2x2 blocks of green (L609-650): the reference steps d by two over the hexagon table while it steps by
                 // one buffer, so with four directions only buffers 0 and 1 are filled
                 if (2 * k < ndir) {
+                    if (fast4) {
+                        const int rr1 = T->cls[1][0][tid & 3], cc1 = T->cls[1][1][tid & 3];
+                        const int h0 = T->allhex1[rr1][cc1][2 * k], h1 = T->allhex1[rr1][cc1][2 * k + 1];
+                        const bool third = (h0 + h1) != 0;
+                        FOR_SITES4(q1, r, c, fu) {
+                            (void)fu;
+                            if (r < 2 || c < 2 || r >= mrl - 2 || c >= mcl - 2) continue;
+                            const xt_lf rix = L + r * TS + c;
+                            const float gc = rix[PL], g0 = rix[h0 + PL], g1 = rix[h1 + PL], r0 = rix[h0], r1 = rix[h1], b0 = rix[h0 + 2 * PL], b1 = rix[h1 + 2 * PL];
+                            if (third) {
+                                const float g = 3 * gc - 2 * g0 - g1;
+                                rix[0] = (g + 2 * r0 + r1) * 0.33333333f; rix[2 * PL] = (g + 2 * b0 + b1) * 0.33333333f;
+                            } else {
+                                const float g = 2 * gc - g0 - g1;
+                                rix[0] = (g + r0 + r1) * 0.5f; rix[2 * PL] = (g + b0 + b1) * 0.5f;
+                            }
+                        }
+                    } else {
                     FOR_T(NCELL * NCELL * T->ncls[1]) {
                         XT_SITE(1, t, top, left, r, c);
                         const int row = top + r, col = left + c;
@@ -413,6 +483,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                             const float vb = (g + rix[h0 + 2 * PL] + rix[h1 + 2 * PL]) * 0.5f;
                             rix[0] = vr; rix[2 * PL] = vb;
                         }
+                    }
                     }
                     xt_lds_barrier();
                 }
