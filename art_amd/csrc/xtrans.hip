@@ -74,6 +74,8 @@ __device__ __forceinline__ float cbrt_lut(const float *__restrict__ lut, int i) 
 constexpr int XT_LDS_FLOATS = 3 * TS * TS;
 constexpr int XT_DR = (XT_LDS_FLOATS - 8 * TS * TS / 4) / (8 * (TS - 10)) - 2;      // 13 derivative rows per strip beside the eight byte maps
 #define FOR_T(N) for (int t = tid, _n = (N); t < _n; t += NT)
+// the same walk with t / P and t % P kept up to date by additions (a division by a constant is a quarter-rate multiply-high plus a multiply back)
+#define FOR_T_RC(N, P, r, c) for (int t = tid, _n = (N), r = tid / (P), c = tid - (tid / (P)) * (P); t < _n; t += NT, r += NT / (P) + (c >= (P) - NT % (P)), c += c >= (P) - NT % (P) ? NT % (P) - (P) : NT % (P))
 #ifdef XT_PROFILE
 #define XT_MARK(k) do { const long long _n2 = wall_clock64(); xt_acc[k] += _n2 - xt_last; xt_last = _n2; } while (0)
 #else
@@ -220,28 +222,31 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                 // four pixels per thread and iteration: their twelve table look-ups are in flight together
                 constexpr int U = 4;
                 const int n = nlab * LW;
+                int wi = tid / LW, wj = tid - wi * LW;              // (row, column) of the walk's next pixel: + NT = + (9 rows, 70 columns)
                 for (int t0 = tid; t0 < n; t0 += U * NT) {
-                    int pp[U], jj[U], ix[U][3];
+                    int pp[U], jj[U], ii[U], ix[U][3];
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        const int t = min(t0 + u * NT, n - 1);
-                        const int i = t / LW, j = t - i * LW;
+                        const bool inside = t0 + u * NT < n;
+                        const int i = inside ? wi : nlab - 1, j = inside ? wj : LW - 1;
+                        wi += NT / LW + (wj >= LW - NT % LW); wj += wj >= LW - NT % LW ? NT % LW - LW : NT % LW;
                         const int p = (4 + i) * TS + 4 + j;
-                        pp[u] = p; jj[u] = j;
+                        pp[u] = p; jj[u] = j; ii[u] = i;
                         const float p0 = L[p], p1 = L[PL + p], p2 = L[2 * PL + p];
                         // 4-lane groups while j < labWidth - 3 ...
                         const float x0 = p0 * a.xyz_cam[0] + p1 * a.xyz_cam[1] + p2 * a.xyz_cam[2];
                         const float x1 = p0 * a.xyz_cam[3] + p1 * a.xyz_cam[4] + p2 * a.xyz_cam[5];
                         const float x2 = p0 * a.xyz_cam[6] + p1 * a.xyz_cam[7] + p2 * a.xyz_cam[8];
-                        // ... the scalar tail rounds by adding 0.5 and truncating
-                        float y0 = 0.5f, y1 = 0.5f, y2 = 0.5f;
-                        y0 += a.xyz_cam[0] * p0; y1 += a.xyz_cam[3] * p0; y2 += a.xyz_cam[6] * p0;
-                        y0 += a.xyz_cam[1] * p1; y1 += a.xyz_cam[4] * p1; y2 += a.xyz_cam[7] * p1;
-                        y0 += a.xyz_cam[2] * p2; y1 += a.xyz_cam[5] * p2; y2 += a.xyz_cam[8] * p2;
+                        ix[u][0] = __float2int_rn(x0); ix[u][1] = __float2int_rn(x1); ix[u][2] = __float2int_rn(x2);
+                        // ... the scalar tail (the row's last two columns) rounds by adding 0.5 and truncating: only the waves that hold such a pixel
                         const bool vec = j < ((LW - 3 + 3) / 4) * 4;
-                        ix[u][0] = vec ? __float2int_rn(x0) : (int)y0;
-                        ix[u][1] = vec ? __float2int_rn(x1) : (int)y1;
-                        ix[u][2] = vec ? __float2int_rn(x2) : (int)y2;
+                        if (__builtin_amdgcn_ballot_w64(!vec) != 0) {
+                            float y0 = 0.5f, y1 = 0.5f, y2 = 0.5f;
+                            y0 += a.xyz_cam[0] * p0; y1 += a.xyz_cam[3] * p0; y2 += a.xyz_cam[6] * p0;
+                            y0 += a.xyz_cam[1] * p1; y1 += a.xyz_cam[4] * p1; y2 += a.xyz_cam[7] * p1;
+                            y0 += a.xyz_cam[2] * p2; y1 += a.xyz_cam[5] * p2; y2 += a.xyz_cam[8] * p2;
+                            if (!vec) { ix[u][0] = (int)y0; ix[u][1] = (int)y1; ix[u][2] = (int)y2; }
+                        }
                     }
                     float cv[U][3];
 #pragma unroll
@@ -256,12 +261,11 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
                         L[pp[u]] = Lv; L[PL + pp[u]] = A; L[2 * PL + pp[u]] = Bv;
                         // the last direction's planes are stored as well: the homogeneity maps alias them (L301-308), and the 5x5 sums
                         // read map bytes no one wrote = bytes of those floats
-                        if (d == ndir - 1) { const int i = pp[u] / TS - 4; LAB(0, i, jj[u]) = Lv; LAB(1, i, jj[u]) = A; LAB(2, i, jj[u]) = Bv; }
+                        if (d == ndir - 1) { const int i = ii[u]; LAB(0, i, jj[u]) = Lv; LAB(1, i, jj[u]) = A; LAB(2, i, jj[u]) = Bv; }
                     }
                 }
             } else {
-                FOR_T(nlab * LW) {
-                    const int i = t / LW, j = t - i * LW;
+                FOR_T_RC(nlab * LW, LW, i, j) {
                     if (j >= mcl - 8) continue;
                     const int p = (4 + i) * TS + 4 + j;
                     const float p0 = L[p], p1 = L[PL + p], p2 = L[2 * PL + p];
@@ -274,8 +278,8 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             xt_lds_barrier();
             const int dd = d & 3;
             const int f = dd == 0 ? 1 : (dd == 1 ? TS : (dd == 2 ? TS + 1 : TS - 1));
-            FOR_T((mrl - 10) * TS) {
-                const int rr = t / TS, c = t - rr * TS, r = 5 + rr;
+            FOR_T_RC((mrl - 10) * TS, TS, rr, c) {
+                const int r = 5 + rr;
                 if (c < 5 || c >= mcl - 5) continue;
                 const xt_lf l = L + r * TS + c, aa = l + PL, b = l + 2 * PL;
                 float v;
@@ -569,8 +573,7 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
         if (height - top < TS + 4) mr2 = height - top + 2;
         if (width - left < TS + 4) mc2 = width - left + 2;
         const int startrow = min(top, 8), startcol = min(left, 8);
-        FOR_T(TS * TS) {
-            const int r = t / TS, c = t - r * TS;
+        FOR_T_RC(TS * TS, TS, r, c) {
             if (r < startrow || c < startcol || r >= mr2 - 8 || c >= mc2 - 8) continue;
             // the reference's 16-wide loop adds with unsigned saturation (_mm_adds_epu8, L835-843); its running-sum tail,
             // which only the last row reaches, truncates to uint8 (L846-864).  Sums above 255 arise where never-written
