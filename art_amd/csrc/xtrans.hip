@@ -582,15 +582,29 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             const int ncov = endcol > startcol ? ((endcol - startcol + 15) / 16) * 16 : 0;
             const bool saturate = c < startcol + ncov;
             unsigned char hm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            // The 5 x 5 byte sums, a row of five as the two aligned words that hold it: the first four bytes through v_alignbyte + v_sad_u8,
+            // the fifth extracted from the upper word (200 single-byte LDS reads per pixel were what this phase took its time for).  A direction's
+            // map is a whole number of words, so the alignment of a row is the same in all eight; it alternates with the row (TS = 2 mod 4).
+            unsigned rowbase[5], rowsh[5];
+#pragma unroll
+            for (int v = 0; v < 5; v++) {
+                const unsigned A = (unsigned)((r + v - 2) * TS + c - 2);
+                rowbase[v] = A >> 2; rowsh[v] = A & 3u;
+            }
+            static_assert((TS * TS) % 4 == 0, "a homogeneity map is a whole number of words");
+            const __attribute__((address_space(3))) unsigned *const s_w = (const __attribute__((address_space(3))) unsigned *)xt_lds;
 #pragma unroll
             for (int d = 0; d < 8; d++) {
                 if (d >= ndir) break;
-                int sum = 0;
+                unsigned sum = 0;
 #pragma unroll
-                for (int v = -2; v <= 2; v++)
-#pragma unroll
-                    for (int h = -2; h <= 2; h++) sum += s_b[(d * TS + r + v) * TS + c + h];
-                hm[d] = saturate ? (unsigned char)(sum > 255 ? 255 : sum) : (unsigned char)sum;
+                for (int v = 0; v < 5; v++) {
+                    const __attribute__((address_space(3))) unsigned *const w = s_w + d * (TS * TS / 4) + rowbase[v];
+                    const unsigned lo = w[0], hi = w[1];
+                    sum = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, rowsh[v]), 0u, sum);
+                    sum += (hi >> (8u * rowsh[v])) & 0xffu;
+                }
+                hm[d] = saturate ? (unsigned char)(sum > 255u ? 255u : sum) : (unsigned char)sum;
             }
             unsigned char maxval = hm[0];
 #pragma unroll
