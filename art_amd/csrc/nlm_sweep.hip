@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
         aoc[q] = ((unsigned)y * (unsigned)W + (unsigned)x0) * 4u;
         aic[q] = ((unsigned)y * (unsigned)a.img_stride + (unsigned)x0) * 4u;
     }
+    const unsigned ncol = (unsigned)max(TW - 2 * border, 0);       // a sliver tile at the right edge (narrower than two borders) writes nothing
     fetch_strips(0);
     // the sweep's ring: S of the lane's three rows and of the row above at the last eight steps, indexed by step & 7
     float h0[G_CH], h1[G_CH], h2[G_CH], hu[G_CH];
@@ -230,7 +231,7 @@ __global__ void __launch_bounds__(G_NT) nlm_group_kernel(NlmArgs a)
         unsigned aoo[NPA], aio[NPA];
 #pragma unroll
         for (int q = 0; q < NPA; ++q) {
-            aok[q] = arow[q] && (unsigned)(d0 + axc[q]) < (unsigned)(TW - 2 * border);
+            aok[q] = arow[q] && (unsigned)(d0 + axc[q]) < ncol;
             aoo[q] = aoc[q] + 4u * (unsigned)d0; aio[q] = aic[q] + 4u * (unsigned)d0;
             am[q] = asw[q] = aim[q] = 0.f;
             if (aok[q]) { am[q] = *atc(mask, aoo[q]); asw[q] = *at(SW, aoo[q]); aim[q] = *at(img, aio[q]); }

@@ -303,11 +303,15 @@ __global__ void __launch_bounds__(256) nlm_prepare_kernel(NlmArgs a)
 {
     const long long npad = (long long)a.WW * a.HH, n = (long long)a.W * a.H;
     const float lutfactor = 100.f / 8191.f;
-    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < npad; t += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(t / a.WW), x = (int)(t - (long long)y * a.WW);
-        const int yy = y <= a.border ? 0 : y >= a.H ? a.H - 1 : y - a.border;
-        const int xx = x <= a.border ? 0 : x >= a.W ? a.W - 1 : x - a.border;
-        a.src[t] = a.img[(size_t)yy * a.img_stride + xx] / a.factor;
+    // (the walk covers the 8192 table entries as well: a padded frame of fewer pixels -- below about 76 x 76 -- used to leave the table's tail unwritten)
+    const long long nwalk = npad > 8192 ? npad : 8192;
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < nwalk; t += (long long)gridDim.x * blockDim.x) {
+        if (t < npad) {
+            const int y = (int)(t / a.WW), x = (int)(t - (long long)y * a.WW);
+            const int yy = y <= a.border ? 0 : y >= a.H ? a.H - 1 : y - a.border;
+            const int xx = x <= a.border ? 0 : x >= a.W ? a.W - 1 : x - a.border;
+            a.src[t] = a.img[(size_t)yy * a.img_stride + xx] / a.factor;
+        }
         if (t < n) a.mask[t] = (1.f / (a.mask[t] * a.h2)) / lutfactor;
         if (t < 8192) a.explut[t] = xexpf_s(-((float)t * lutfactor));
     }

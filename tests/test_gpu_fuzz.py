@@ -102,3 +102,17 @@ def test_fuzz_config4_chain(gpu_ctx, it, w, h, method, filt):
     o = O.exposure(o, float(np.float32(2.0 ** 0.3)), 0.0)
     o = O.tone_std(o, lut, 1.0, True)
     assert _same(img, o), f"{w}x{h} {method} filters={filt:#x}"
+
+
+def test_fuzz_nlmeans_sizes_on_one_context(gpu_ctx):
+    """A fixed-seed slice of scripts/fuzz_nlm.py plus the cases it found, all on ONE context in this order: a frame with a sliver tile at the
+    right edge (padded width 274 = 2 x 136 + 2: the third tile column is narrower than two borders and writes nothing), then frames whose
+    padded area is below the 8192 entries of the exp table (the table's tail used to keep whatever an earlier call had left at that place
+    in the pool)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import fuzz_nlm
+    fixed = [(260, 406, 20, 50, 1.0, 870025460), (269, 413, 50, 0, 1.0, 479761753), (72, 44, 100, 50, 1.0, 279563955), (34, 48, 50, 0, 1.0, 232415261),
+             (40, 100, 50, 0, 1.0, 5), (100, 40, 50, 0, 1.0, 5), (60, 60, 50, 50, 1.0, 5), (399, 32, 50, 0, 1.0, 805697932)]
+    for c in fixed + list(fuzz_nlm.cases(7, 10)):
+        assert fuzz_nlm.run(gpu_ctx, *c) == 0, c
