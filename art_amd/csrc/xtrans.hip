@@ -523,29 +523,32 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
         // (a strip's values are fetched into registers while the strip before it is counted)
         constexpr int XT_SPT = (8 * (XT_DR + 2) * DW + NT - 1) / NT;       // strip values per thread
         float pre[XT_SPT];
-        auto fetch_strip = [&](int ra) {
-            const int rb = min(ra + XT_DR, mrl - 6), nrows = rb - ra + 2, n = ndir * nrows * DW;
+        // element t of a strip = (direction, strip row, column) = (t / (nrows DW), ..): the walk t = tid + u NT keeps the three by additions --
+        // nrows is only known at run time, and a division by a run-time value is two dozen instructions, 26 of them per thread and strip
+        auto strip_walk = [&](int nrows, auto &&body) {
+            int d = 0, ii = tid / DW, j = tid - ii * DW;
+            while (ii >= nrows) { ii -= nrows; ++d; }
 #pragma unroll
             for (int u = 0; u < XT_SPT; u++) {
-                const int t = min(tid + u * NT, n - 1);
-                const int d = t / (nrows * DW), q = t - d * nrows * DW, ii = q / DW, j = q - ii * DW;
-                pre[u] = DRV(d, ra - 6 + ii, j);
+                body(u, d, ii, j);
+                const bool wrap = j >= DW - NT % DW;
+                j += wrap ? NT % DW - DW : NT % DW; ii += NT / DW + wrap;
+                while (ii >= nrows) { ii -= nrows; ++d; }
             }
+        };
+        auto fetch_strip = [&](int ra) {
+            const int rb = min(ra + XT_DR, mrl - 6), nrows = rb - ra + 2;
+            strip_walk(nrows, [&](int u, int d, int ii, int j) {
+                const bool in = d < ndir;          // (past the strip: any address of the plane)
+                pre[u] = DRV(in ? d : 0, ra - 6 + (in ? ii : 0), in ? j : 0);
+            });
         };
         if (6 < mrl - 6) fetch_strip(6);
         for (int ra = 6; ra < mrl - 6; ra += XT_DR) {
             const int rb = min(ra + XT_DR, mrl - 6), nrows = rb - ra + 2;       // derivative rows ra - 6 .. rb - 5
-            {
-                const int n = ndir * nrows * DW;
-#pragma unroll
-                for (int u = 0; u < XT_SPT; u++) {
-                    const int t = tid + u * NT;
-                    if (t < n) {
-                        const int d = t / (nrows * DW), q = t - d * nrows * DW, ii = q / DW, j = q - ii * DW;
-                        sdrv[(d * (XT_DR + 2) + ii) * DW + j] = pre[u];
-                    }
-                }
-            }
+            strip_walk(nrows, [&](int u, int d, int ii, int j) {
+                if (d < ndir) sdrv[(d * (XT_DR + 2) + ii) * DW + j] = pre[u];
+            });
             if (ra + XT_DR < mrl - 6) fetch_strip(ra + XT_DR);
             xt_lds_barrier();
             FOR_T((rb - ra) * TS) {
