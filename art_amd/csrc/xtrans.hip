@@ -520,35 +520,27 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             const unsigned *src = reinterpret_cast<const unsigned *>(homo);                 // TS * TS is a multiple of 4
             FOR_T(ndir * (TS * TS / 4)) ((__attribute__((address_space(3))) unsigned *)xt_lds)[t] = src[t];
         }
-        // (a strip's values are fetched into registers while the strip before it is counted)
-        constexpr int XT_SPT = (8 * (XT_DR + 2) * DW + NT - 1) / NT;       // strip values per thread
-        float pre[XT_SPT];
-        // element t of a strip = (direction, strip row, column) = (t / (nrows DW), ..): the walk t = tid + u NT keeps the three by additions --
-        // nrows is only known at run time, and a division by a run-time value is two dozen instructions, 26 of them per thread and strip
-        auto strip_walk = [&](int nrows, auto &&body) {
-            int d = 0, ii = tid / DW, j = tid - ii * DW;
-            while (ii >= nrows) { ii -= nrows; ++d; }
-#pragma unroll
-            for (int u = 0; u < XT_SPT; u++) {
-                body(u, d, ii, j);
-                const bool wrap = j >= DW - NT % DW;
-                j += wrap ? NT % DW - DW : NT % DW; ii += NT / DW + wrap;
-                while (ii >= nrows) { ii -= nrows; ++d; }
-            }
-        };
+        // (a strip's values are fetched into registers while the strip before it is counted).  Thread = (direction, column): tid >> 7 and
+        // tid & 127 -- 104 of 128 lanes hold a column --, the strip's rows are a loop with constant strides: no index arithmetic per element
+        // (element = tid + u NT needed (direction, row, column) from divisions by the strip's run-time row count).
+        static_assert(DW <= 128 && NT >= 8 * 128, "one thread per (direction, derivative column)");
+        const int sd = tid >> 7, sj = tid & 127;
+        const bool sact = sd < ndir && sj < DW;
+        float pre[XT_DR + 2];
         auto fetch_strip = [&](int ra) {
             const int rb = min(ra + XT_DR, mrl - 6), nrows = rb - ra + 2;
-            strip_walk(nrows, [&](int u, int d, int ii, int j) {
-                const bool in = d < ndir;          // (past the strip: any address of the plane)
-                pre[u] = DRV(in ? d : 0, ra - 6 + (in ? ii : 0), in ? j : 0);
-            });
+            const float *col = &DRV(sact ? sd : 0, ra - 6, sact ? sj : 0);
+#pragma unroll
+            for (int ii = 0; ii < XT_DR + 2; ii++) pre[ii] = col[min(ii, nrows - 1) * DW];
         };
         if (6 < mrl - 6) fetch_strip(6);
         for (int ra = 6; ra < mrl - 6; ra += XT_DR) {
             const int rb = min(ra + XT_DR, mrl - 6), nrows = rb - ra + 2;       // derivative rows ra - 6 .. rb - 5
-            strip_walk(nrows, [&](int u, int d, int ii, int j) {
-                if (d < ndir) sdrv[(d * (XT_DR + 2) + ii) * DW + j] = pre[u];
-            });
+            if (sact) {
+#pragma unroll
+                for (int ii = 0; ii < XT_DR + 2; ii++)
+                    if (ii < nrows) sdrv[(sd * (XT_DR + 2) + ii) * DW + sj] = pre[ii];
+            }
             if (ra + XT_DR < mrl - 6) fetch_strip(ra + XT_DR);
             xt_lds_barrier();
             FOR_T((rb - ra) * TS) {
