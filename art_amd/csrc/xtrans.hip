@@ -19,6 +19,7 @@
 // separated by workgroup barriers (LDS-only ones inside the buffer loop).
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <type_traits>
 #include "devmath.h"
 #include "kernels.h"
 
@@ -543,23 +544,48 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             }
             if (ra + XT_DR < mrl - 6) fetch_strip(ra + XT_DR);
             xt_lds_barrier();
-            FOR_T((rb - ra) * TS) {
-                const int rr = t / TS, c = t - rr * TS, r = ra + rr;
-                if (c < 6 || c >= mcl - 6) continue;
-#define SDRV(d, v, h) sdrv[((d) * (XT_DR + 2) + rr + 1 + (v)) * DW + c - 5 + (h)]
-                float tr = SDRV(0, 0, 0) < SDRV(1, 0, 0) ? SDRV(0, 0, 0) : SDRV(1, 0, 0);
-                for (int d = 2; d < ndir; d++) tr = (SDRV(d, 0, 0) < tr ? SDRV(d, 0, 0) : tr);
-                tr *= 8;
-                for (int d = 0; d < ndir; d++) {
-                    int cnt = 0;
+            // Two horizontally adjacent pixels per thread: their 3 x 3 windows share two of three columns (12 LDS reads per direction for
+            // the pair instead of 18), and with the direction loop unrolled (ndir is 4 or 8) the reads of all directions are issued
+            // together instead of one LDS round trip per direction.
+            constexpr int NPAIR = (TS - 12 + 1) / 2;                  // columns 6 .. TS - 7 in pairs
+            auto count_pairs = [&](auto nd_) {
+                constexpr int ND = decltype(nd_)::value;
+                FOR_T((rb - ra) * NPAIR) {
+                    const int rr = t / NPAIR, pc = t - rr * NPAIR, r = ra + rr, c = 6 + 2 * pc;
+                    if (c >= mcl - 6) continue;
+                    const bool two = c + 1 < mcl - 6;
+                    const xt_lf base = sdrv + (rr + 1) * DW + c - 5;                 // derivative (row, column) of the pair's first pixel
+                    float cen[ND][2];
 #pragma unroll
-                    for (int v = -1; v <= 1; v++)
+                    for (int d = 0; d < ND; d++) { cen[d][0] = base[d * (XT_DR + 2) * DW]; cen[d][1] = base[d * (XT_DR + 2) * DW + 1]; }
+                    float tr0 = cen[0][0] < cen[1][0] ? cen[0][0] : cen[1][0], tr1 = cen[0][1] < cen[1][1] ? cen[0][1] : cen[1][1];
 #pragma unroll
-                        for (int h = -1; h <= 1; h++) cnt += (SDRV(d, v, h) <= tr ? 1 : 0);
-                    s_b[(d * TS + r) * TS + c] = (unsigned char)cnt;
+                    for (int d = 2; d < ND; d++) { tr0 = (cen[d][0] < tr0 ? cen[d][0] : tr0); tr1 = (cen[d][1] < tr1 ? cen[d][1] : tr1); }
+                    tr0 *= 8; tr1 *= 8;
+#pragma unroll
+                    for (int d0 = 0; d0 < ND; d0 += 4) {          // four directions' windows (48 values) in flight at a time
+                        float x[4][3][4];
+#pragma unroll
+                        for (int d = 0; d < 4; d++)
+#pragma unroll
+                            for (int v = 0; v < 3; v++)
+#pragma unroll
+                                for (int h = 0; h < 4; h++) x[d][v][h] = base[((d0 + d) * (XT_DR + 2) + v - 1) * DW + h - 1];
+#pragma unroll
+                        for (int d = 0; d < 4; d++) {
+                            int cnt0 = 0, cnt1 = 0;
+#pragma unroll
+                            for (int v = 0; v < 3; v++)
+#pragma unroll
+                                for (int h = 0; h < 3; h++) { cnt0 += (x[d][v][h] <= tr0 ? 1 : 0); cnt1 += (x[d][v][h + 1] <= tr1 ? 1 : 0); }
+                            s_b[((d0 + d) * TS + r) * TS + c] = (unsigned char)cnt0;
+                            if (two) s_b[((d0 + d) * TS + r) * TS + c + 1] = (unsigned char)cnt1;
+                        }
+                    }
                 }
-#undef SDRV
-            }
+            };
+            if (ndir == 8) count_pairs(std::integral_constant<int, 8>{});
+            else count_pairs(std::integral_constant<int, 4>{});
             xt_lds_barrier();
         }
         XT_MARK(10);
