@@ -134,8 +134,10 @@ __global__ void __launch_bounds__(XTRANS_THREADS, XTRANS_MIN_WAVES) xtrans_tiles
             q.fpack |= (unsigned)T->xtrans[(rr + 3 * (((ab >> 1) + mpar) & 1)) * 6 + cc + 3 * (((ab & 1) + npar) & 1)] << (2 * ab);
         return q;
     };
+    constexpr int SITE_DR = (NT / 4) / NCELL, SITE_DC = (NT / 4) % NCELL;      // the walk's step in cells: NT / 4 cells = (6 rows, 28 columns)
+    static_assert(NT % 4 == 0 && SITE_DC > 0, "four sites per cell; the cell step is not a whole number of cell rows");
 #define FOR_SITES4(Q, r, c, f)                                                                                              \
-    for (int _bi = (tid >> 2) / NCELL, _cj = (tid >> 2) - _bi * NCELL; _bi < NCELL; _bi += 6 + (_cj >= NCELL - 28), _cj += _cj >= NCELL - 28 ? 28 - NCELL : 28) \
+    for (int _bi = (tid >> 2) / NCELL, _cj = (tid >> 2) - _bi * NCELL; _bi < NCELL; _bi += SITE_DR + (_cj >= NCELL - SITE_DC), _cj += _cj >= NCELL - SITE_DC ? SITE_DC - NCELL : SITE_DC) \
         for (int r = 3 * _bi + (Q).dr, c = 3 * _cj + (Q).dc, f = (int)(((Q).fpack >> (2 * (((_bi & 1) << 1) | (_cj & 1)))) & 3u), _once = 1; _once; _once = 0)
     const int ndir = a.ndir, passes = a.passes;
     float *const buffer = a.arena + (size_t)blockIdx.x * a.arena_floats;
