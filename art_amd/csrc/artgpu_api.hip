@@ -1911,6 +1911,8 @@ int artgpu_nlmeans(artgpu_ctx *ctx, artgpu_plane *img, float normcoeff, int stre
     if (!plane_ok(img) || !(scale >= 1.f)) return fail(ctx, ARTGPU_EINVAL, "nlmeans: bad arguments");
     if (!strength) return ARTGPU_OK;                       // nlmeans.cc:52-54
     if (img->w < 32 || img->h < 32) return fail(ctx, ARTGPU_EUNSUPPORTED, "nlmeans: image smaller than 32x32");
+    // (the tile kernel addresses a plane through 32-bit byte offsets)
+    if ((unsigned long long)(img->w + 14) * (unsigned long long)(img->h + 14) >= (1ull << 30)) return fail(ctx, ARTGPU_EUNSUPPORTED, "nlmeans: image of %dx%d exceeds 2^30 pixels", img->w, img->h);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int W = img->w, H = img->h;
     NlmArgs a = {};
