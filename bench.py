@@ -205,7 +205,16 @@ def main() -> None:
         for k in range(1, args.lanes):
             extra.append(make_lane(k))
 
+    lane_errors = []
+
     def lane_frame(ln):
+        # (runs on its own host thread: an exception there must stop the bench, not vanish with the thread)
+        try:
+            lane_frame_body(ln)
+        except BaseException as e:      # noqa: BLE001
+            lane_errors.append(e)
+
+    def lane_frame_body(ln):
         c = ln["ctx"]
         if xtrans:
             c.demosaic_xtrans(3, True, ln["p_raw"], synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, ln["p_out"])
@@ -224,6 +233,8 @@ def main() -> None:
             step0()
             for t_ in th:
                 t_.join()
+            if lane_errors:
+                raise lane_errors[0]
         else:
             step0()
 
@@ -469,6 +480,8 @@ def main() -> None:
             t_.start()
             step0()
             t_.join()
+            if lane_errors:
+                raise lane_errors[0]
         step2()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
