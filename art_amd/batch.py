@@ -75,19 +75,24 @@ class RcclComm:
             self.comm = None
 
 
-def open_rccl(ctx, dist, device, rank: int, world: int):
+def open_rccl(ctx, dist, device, rank: int, world: int, group=None):
     """Create the communicator `artgpu_batch_complete` gathers over -- BEFORE the timed region: communicator set-up takes seconds and is
     not part of the batch.  The unique id travels over the already initialised torch.distributed group.  Every step that can fail on one
     rank only (loading librccl, ncclGetUniqueId on rank 0, ncclCommInitRank) is followed by a MIN-reduce of "did it work here", so that
     either ALL ranks get a communicator or ALL of them get None and complete through torch.distributed: a rank that raised or fell back
-    on its own would leave the others hanging in the next collective."""
+    on its own would leave the others hanging in the next collective.
+
+    `group`: the process group the set-up's own collectives (the agreements, the broadcast of the id) run on.  A caller that runs this
+    under a watchdog passes a group of its own (dist.new_group(), created beforehand by every rank): should the set-up hang and the caller
+    give up on it, a rank may still be parked inside one of these collectives -- on a dedicated group that cannot pair up with the
+    collectives the caller goes on to issue on the default group."""
     import ctypes as C
     import torch
 
     def agree(flag: bool) -> bool:
         ok = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
         if world > 1:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         return int(ok.item()) == 1
 
     rccl = None
@@ -109,7 +114,7 @@ def open_rccl(ctx, dist, device, rank: int, world: int):
         return None
     wire = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=device)
     if world > 1:
-        dist.broadcast(wire, src=0)
+        dist.broadcast(wire, src=0, group=group)
     C.memmove(C.byref(uid), bytes(wire.cpu().tolist()), 128)
     comm = C.c_void_p()
     rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]

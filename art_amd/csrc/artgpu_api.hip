@@ -74,7 +74,11 @@ struct artgpu_ctx {
     size_t lut_bytes = 0;
     std::vector<float> lut_host;           // what ctx->lut holds (a curve that comes back unchanged is not uploaded again)
     std::vector<float> ncurve_host;        // likewise the 501-entry chroma noise curve behind the cachef table
-    std::vector<float> rgbcurve_host[3];   // likewise the three rgbCurves tables (P_PIPE_R)
+    char *tab_ring = nullptr;              // pinned staging ring of h2d_table (caller look-up tables)
+    size_t tab_ring_bytes = 0, tab_ring_off = 0;
+    bool tab_ring_busy = false;
+    hipEvent_t tab_ev = nullptr;
+    std::vector<float> rgbcurve_host[3];   // likewise the three rgbCurves tables (P_RGBCURVES: a slot nothing else writes)
     // timing
     bool timing = false;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -101,6 +105,16 @@ int fail(artgpu_ctx *ctx, int code, const char *fmt, ...)
             return fail(ctx, ARTGPU_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
+// A call that puts work on a side stream has to leave with the context's stream behind that work on EVERY path: an error return in between
+// would otherwise leave the side stream running on pool buffers the next call hands out again.  Armed when the fork happens, disarmed by the
+// regular join (an event wait, no host blocking); on any other exit the destructor drains the side stream.
+struct SideStreamJoin {
+    hipStream_t side = nullptr;
+    void arm(hipStream_t s) { side = s; }
+    void disarm() { side = nullptr; }
+    ~SideStreamJoin() { if (side) (void)hipStreamSynchronize(side); }
+};
+
 int ensure(artgpu_ctx *ctx, float **buf, size_t *cur, size_t need)
 {
     if (*cur >= need) return ARTGPU_OK;
@@ -115,17 +129,37 @@ int ensure(artgpu_ctx *ctx, float **buf, size_t *cur, size_t need)
 }
 
 // A caller's look-up table -> device memory, one lifetime rule for all of them (artgpu.h "Host look-up tables"): the array is free when
-// the entry point returns.  A copy from pageable memory has been staged by then; a pinned / registered array is read by the DMA engine
-// when the stream gets there, so the stream is drained for those.
+// the entry point returns, whatever kind of memory it is (pageable, pinned, registered, managed).  The table is copied into a pinned ring the
+// context owns and travels from there on the context's stream, so the call neither depends on how HIP treats the caller's memory type nor
+// drains the stream; the host only waits (for the ring's last copy) when the ring wraps, every dozen calls.
 int h2d_table(artgpu_ctx *ctx, void *dst, const void *src, size_t bytes)
 {
-    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, src) == hipSuccess) {
-        if (at.type == hipMemoryTypeHost) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    } else {
-        (void)hipGetLastError();      // an ordinary malloc'ed array is "invalid value" to the query: pageable
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (need > ctx->tab_ring_bytes) {
+        if (ctx->tab_ring) {
+            if (ctx->tab_ring_busy) HIPCHK(ctx, hipEventSynchronize(ctx->tab_ev));
+            HIPCHK(ctx, hipHostFree(ctx->tab_ring));
+            ctx->tab_ring = nullptr; ctx->tab_ring_bytes = 0; ctx->tab_ring_busy = false;
+        }
+        const size_t cap = need * 2 > ((size_t)8 << 20) ? need * 2 : ((size_t)8 << 20);
+        if (hipHostMalloc(reinterpret_cast<void **>(&ctx->tab_ring), cap, hipHostMallocDefault) != hipSuccess) {
+            ctx->tab_ring = nullptr;
+            return fail(ctx, ARTGPU_ENOMEM, "pinned staging ring for look-up tables (%zu bytes)", cap);
+        }
+        ctx->tab_ring_bytes = cap; ctx->tab_ring_off = 0;
+        if (!ctx->tab_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->tab_ev, hipEventDisableTiming));
     }
+    if (ctx->tab_ring_off + need > ctx->tab_ring_bytes) {        // wrap: what was staged before has to have left the ring
+        if (ctx->tab_ring_busy) HIPCHK(ctx, hipEventSynchronize(ctx->tab_ev));
+        ctx->tab_ring_busy = false;
+        ctx->tab_ring_off = 0;
+    }
+    char *slot = ctx->tab_ring + ctx->tab_ring_off;
+    std::memcpy(slot, src, bytes);
+    HIPCHK(ctx, hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->tab_ev, ctx->stream));
+    ctx->tab_ring_busy = true;
+    ctx->tab_ring_off += need;
     return ARTGPU_OK;
 }
 
@@ -292,6 +326,8 @@ int artgpu_destroy(artgpu_ctx *ctx)
     for (int k = 0; k < artgpu_ctx::NSTAGE; ++k)
         if (ctx->stage[k]) (void)hipFree(ctx->stage[k]);
     if (ctx->lut) (void)hipFree(ctx->lut);
+    if (ctx->tab_ring) (void)hipHostFree(ctx->tab_ring);
+    if (ctx->tab_ev) (void)hipEventDestroy(ctx->tab_ev);
     if (ctx->bbox) (void)hipFree(ctx->bbox);
     if (ctx->amz_lists) (void)hipFree(ctx->amz_lists);
     if (ctx->rcd_counter) (void)hipFree(ctx->rcd_counter);
@@ -566,6 +602,7 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
         if (ctx->opt_amaze_poison >= 0)   // test hook: fill the arenas with a byte pattern first
             HIPCHK(ctx, hipMemsetAsync(ctx->arena, ctx->opt_amaze_poison, (size_t)grid * AMAZE_ARENA_FLOATS * sizeof(float), ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(d_queue, 0, (4 + 2 * (size_t)ctx->amz_nstream + 8) * sizeof(int), ctx->stream));   // + the 8 counters behind it
+        SideStreamJoin amz_join;
         if (early) {
             // the working list starts empty (the stream appends to it), the static tiles are taken from the template
             HIPCHK(ctx, hipMemsetAsync(d_work, 0, sizeof(int), ctx->stream));
@@ -577,6 +614,7 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
             // other way round the persistent stream workgroups took every CU and the arena tiles waited for them to finish)
             HIPCHK(ctx, hipEventRecord(ctx->amz_ev[0], ctx->stream));          // the CFA plane, the cleared queue
             HIPCHK(ctx, hipStreamWaitEvent(ctx->amz_side, ctx->amz_ev[0], 0));
+            amz_join.arm(ctx->amz_side);
             a.tile_list = d_templ + 1; a.tile_count = d_templ;
             a.queue_hdr = nullptr;
             HIPCHK(ctx, launch_amaze(a, std::min(ctx->amz_narena, cap), ctx->stream));
@@ -607,6 +645,7 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
         if (early) {
             HIPCHK(ctx, hipEventRecord(ctx->amz_ev[1], ctx->amz_side));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->amz_ev[1], 0));    // the streamed tiles are written, the hand-back list is final
+            amz_join.disarm();
         }
         // arena kernel over the listed tiles (the static ones unless they went early, plus whatever the stream handed back; the count is
         // read on the device)
@@ -975,7 +1014,7 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_BATCH, P_DCTTAB, P_CBANDS2, P_CLOW0_2, P_CLOW1_2, P_SF_A, P_SF_B, P_HISTO_A, P_HISTO_B, P_NSLOTS };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_BATCH, P_DCTTAB, P_CBANDS2, P_CLOW0_2, P_CLOW1_2, P_SF_A, P_SF_B, P_HISTO_A, P_HISTO_B, P_RGBCURVES, P_NSLOTS };
 static_assert(P_NSLOTS <= artgpu_ctx::NPOOL, "grow artgpu_ctx::pool");
 
 struct DevDecomp {
@@ -1380,9 +1419,12 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         if ((rc = luma(sL))) return rc;
     } else {
         if ((rc = chroma_front(0)) || (rc = chroma_front(1))) return rc;      // the last readers of the untouched L coefficients
+        SideStreamJoin dn_join;
+        dn_join.arm(ctx->dn_stream[0]);                                       // any return below leaves with the side stream drained
         if ((rc = luma(ctx->dn_stream[0]))) return rc;
         if ((rc = chroma_back(0)) || (rc = chroma_back(1))) return rc;
         HIPCHK(ctx, hipStreamWaitEvent(sL, ctx->dn_ev[1], 0));                // join: the context's stream is behind all the work of the call
+        dn_join.disarm();
     }
     px.L = Lout;
 
@@ -2488,8 +2530,12 @@ int artgpu_rgb_curves(artgpu_ctx *ctx, artgpu_rgb *image, const float *rcurve, c
     DevRGB d;
     int rc = bind_rgb(ctx, image, 4, true, &d, "rgb_curves");
     if (rc) return rc;
+    // The tables live in a pool slot of their own: the host-side cache below describes what the slot holds, so nothing else may write it
+    // (P_PIPE_R, where they used to be, is also labAdjustments' curves, rgb2out's TRC table and the pipeline's red plane).
     float *tabs;
-    if ((rc = pool_get(ctx, P_PIPE_R, 3 * 65536 * 4, &tabs))) return rc;
+    if (ctx->pool_bytes[P_RGBCURVES] < (size_t)3 * 65536 * 4)
+        for (int k = 0; k < 3; ++k) ctx->rgbcurve_host[k].clear();           // a fresh allocation holds nothing
+    if ((rc = pool_get(ctx, P_RGBCURVES, 3 * 65536 * 4, &tabs))) return rc;
     const float *host[3] = {rcurve, gcurve, bcurve};
     MixArgs a = {};
     for (int k = 0; k < 3; ++k) {

@@ -6,7 +6,7 @@ import hashlib
 import os
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-_COMMON = ["kernels.h", "devmath.h", "devsleef.h"]
+_COMMON = ["kernels.h", "devmath.h", "devsleef.h", "paramcurve.h"]      # paramcurve.h: ParamCurve is embedded by value in kernels.h' argument structs
 KERNEL_SOURCES = {
     "amaze_stream_kernel": ["amaze_stream.hip", "amaze_stream_core.h"],
     "rcd_stream_kernel": ["rcd_stream.hip", "rcd_stream_core.h"],

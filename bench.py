@@ -273,9 +273,13 @@ def main() -> None:
     if use_rccl_capi:
         # (in a watchdog thread: communicator set-up is a rendezvous of all ranks -- should it hang on some node, every rank times out the
         # same way, the completion step goes through torch.distributed and the process leaves with os._exit past the stuck thread)
+        # The set-up's own collectives (agreements, the id's broadcast) run on a process group of their own, created here by every rank: a
+        # rank that is still parked in one of them when the watchdog gives up must not pair up with the barriers and the completion gather
+        # that follow on the default group.
         import threading
         obox = {}
-        oth = threading.Thread(target=lambda: obox.update(h=batch.open_rccl(ctx, dist, dev, rank, world)), daemon=True)
+        setup_group = dist.new_group() if world > 1 else None
+        oth = threading.Thread(target=lambda: obox.update(h=batch.open_rccl(ctx, dist, dev, rank, world, group=setup_group)), daemon=True)
         oth.start()
         oth.join(timeout=float(os.environ.get("ARTGPU_BENCH_RCCL_TIMEOUT", "180")))
         if "h" in obox:

@@ -176,6 +176,61 @@ def test_channel_mixer_and_rgb_curves_bit_exact(gpu_ctx):
     assert np.array_equal(got[1], img[1]) and not np.array_equal(got[0], img[0])
 
 
+def test_rgb_curves_cache_survives_other_users_of_the_context(gpu_ctx):
+    """The three rgbCurves tables are uploaded once and remembered on the host side (a curve that comes back unchanged is not sent
+    again).  The per-image order of rtengine_gpu.h is labAdjustments, then rgbCurves, on ONE context, and rgb2out / the pipeline share the
+    context too: none of them may disturb what the remembered tables describe (they once shared a pool slot with all three)."""
+    from art_amd import capi
+    import oracle_lib as O
+    rng = np.random.default_rng(31)
+    w, h = 257, 95
+    img = [rng.uniform(-500.0, 70000.0, (h, w)).astype(np.float32) for _ in range(3)]
+    x = np.arange(65536, dtype=np.float64) / 65535.0
+    lr = (65535.0 * x ** 0.7).astype(np.float32)
+    lg = (65535.0 * x ** 1.2).astype(np.float32)
+    lb = (65535.0 * (1.0 - (1.0 - x) ** 1.4)).astype(np.float32)
+    ref = O.rgb_curves(img, (lr, lg, lb))
+
+    def run_and_check():
+        got = [p.copy() for p in img]
+        gpu_ctx.rgb_curves(capi.host_rgb(got), lr, lg, lb)
+        for g, r in zip(got, ref):
+            assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+
+    run_and_check()
+    # labAdjustments' three curves (the slot the tables used to live in)
+    lab = O.image_rgb_to_lab([np.abs(p) for p in img])
+    lc = np.arange(32770, dtype=np.float32) * np.float32(0.9)
+    ac = (65535.0 * np.clip(x + 0.05 * np.sin(2 * np.pi * x), 0, 1)).astype(np.float32)
+    gpu_ctx.lab_adjustments(capi.host_rgb([p.copy() for p in lab]), lc, ac, ac, 1.1)
+    run_and_check()
+    # rgb2out's TRC table
+    m = np.array([[1.66, -0.59, -0.07], [-0.12, 1.13, -0.01], [-0.02, -0.10, 1.12]], np.float32)
+    t = np.arange(1024, dtype=np.float64) / 1023.0
+    trc = np.where(t <= 0.0031308, 12.92 * t, 1.055 * t ** (1 / 2.4) - 0.055).astype(np.float32)
+    dim = [(np.abs(p) * 0.4).astype(np.float32) for p in img]
+    out = [np.zeros((h, w), np.float32) for _ in range(3)]
+    gpu_ctx.rgb2out_matrix(capi.host_rgb(dim), capi.host_rgb(out), m, False, trc)
+    run_and_check()
+    # the pipeline's planes (it regrows the slot: free + allocate)
+    from art_amd import synth
+    W, H = 640, 480
+    raw = synth.bayer_frame(W, H, synth.FILTERS_RGGB, seed=5, noise=512)
+    pp = capi.PipelineParams()
+    pp.sensor = 0; pp.bayer_method = capi.BAYER_RCD; pp.filters = synth.FILTERS_RGGB; pp.initial_gain = 1.0; pp.border = 4
+    pp.mul[:] = (2.0, 1.0, 1.5); pp.do_clip = 1; pp.scale = 1.0
+    outp = [np.zeros((H - 8, W - 8), np.float32) for _ in range(3)]
+    gpu_ctx.pipeline_run(capi.host_plane(raw), pp, capi.host_rgb(outp))
+    assert float(outp[1].max()) > 0
+    run_and_check()
+    # a changed curve IS uploaded
+    lr2 = (65535.0 * x ** 0.5).astype(np.float32)
+    got = [p.copy() for p in img]
+    gpu_ctx.rgb_curves(capi.host_rgb(got), lr2, lg, lb)
+    for g, r in zip(got, O.rgb_curves(img, (lr2, lg, lb))):
+        assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+
+
 @pytest.mark.parametrize("skip,crop", [(2, (4, 4, 393, 289)), (3, (4, 4, 392, 288)), (4, (120, 60, 281, 233))])
 def test_get_image_skip_bit_exact(gpu_ctx, skip, crop):
     """getImage with PreviewProps::skip > 1 (rawimagesource.cc:940-975): box sums in row-major order, window clamped at the edge."""
