@@ -202,7 +202,8 @@ def test_rgb_curves_cache_survives_other_users_of_the_context(gpu_ctx):
     lab = O.image_rgb_to_lab([np.abs(p) for p in img])
     lc = np.arange(32770, dtype=np.float32) * np.float32(0.9)
     ac = (65535.0 * np.clip(x + 0.05 * np.sin(2 * np.pi * x), 0, 1)).astype(np.float32)
-    gpu_ctx.lab_adjustments(capi.host_rgb([p.copy() for p in lab]), lc, ac, ac, 1.1)
+    lab_io = [p.copy() for p in lab]                    # host_rgb borrows the arrays: they have to outlive the call
+    gpu_ctx.lab_adjustments(capi.host_rgb(lab_io), lc, ac, ac, 1.1)
     run_and_check()
     # rgb2out's TRC table
     m = np.array([[1.66, -0.59, -0.07], [-0.12, 1.13, -0.01], [-0.02, -0.10, 1.12]], np.float32)
