@@ -28,6 +28,8 @@ struct artgpu_ctx {
     hipEvent_t dn_ev[2] = {nullptr, nullptr};
     int opt_lut_lds = 1;           // 0: never the LUT-in-LDS shapes of the pixel passes (tests compare the two)
     int opt_dn_streams = 1;        // 0: the whole chain on the context's stream, one kernel after the other, in the reference's order
+    int opt_dn_fused = 1;          // ShrinkAllL / ShrinkAllAB -- 0: three kernels per channel (factors, row sums, column sums + update); 2: one kernel per
+                                   // channel; 1: one kernel, and one launch for all three channels where nothing has to happen between them
     std::string err;
     // per-workgroup work arenas (demosaic)
     float *arena = nullptr;
@@ -420,6 +422,7 @@ int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value)
     else if (n == "amaze_poison") ctx->opt_amaze_poison = (int)value;
     else if (n == "roctx") ctx->opt_roctx = value != 0;
     else if (n == "dn_streams") ctx->opt_dn_streams = value != 0;
+    else if (n == "dn_fused") ctx->opt_dn_fused = (int)value;
     else if (n == "lut_lds") ctx->opt_lut_lds = value != 0;
     else if (n == "rcd_rows") { if (value != 4 && value != 8) return fail(ctx, ARTGPU_EINVAL, "rcd_rows: 4 or 8"); ctx->opt_rcd_rows = (int)value; }
     else return fail(ctx, ARTGPU_EINVAL, "set_option: unknown option '%s'", name);
@@ -1014,7 +1017,7 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_BATCH, P_DCTTAB, P_CBANDS2, P_CLOW0_2, P_CLOW1_2, P_SF_A, P_SF_B, P_HISTO_A, P_HISTO_B, P_RGBCURVES, P_NSLOTS };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_BATCH, P_DCTTAB, P_CBANDS2, P_CLOW0_2, P_CLOW1_2, P_SF_A, P_SF_B, P_HISTO_A, P_HISTO_B, P_RGBCURVES, P_FUSED, P_LBANDS2, P_NSLOTS };
 static_assert(P_NSLOTS <= artgpu_ctx::NPOOL, "grow artgpu_ctx::pool");
 
 struct DevDecomp {
@@ -1166,24 +1169,46 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     // one `tmp` (horizontally blurred factors) serves all three channels -- its producer and its consumer are neighbours on the context's
     // stream --; in the reference's order one `sf` plane set and one chroma decomposition do too, with the side stream a and b keep theirs
     // across the L chain.
-    float *L, *A, *B, *gamlut, *mad, *ccalc_dev = nullptr, *tmp1;
-    float *sfc[3], *tmpc[3], *histo_fc[3];          // 0: L, 1: a, 2: b
+    float *L, *A, *B, *gamlut, *mad, *ccalc_dev = nullptr, *tmp1 = nullptr;
+    float *sfc[3] = {nullptr, nullptr, nullptr}, *tmpc[3], *histo_fc[3];          // 0: L, 1: a, 2: b
     DevDecomp Ld = {}, Cdd[2] = {};
     Ld.w = w; Ld.h = h; Ld.w2 = w2; Ld.h2 = h2; Ld.n = n2; Ld.nlevels = levwav;
     Cdd[0] = Cdd[1] = Ld;
+    BlurArgs bl0 = {};
+    bl0.n = n2; bl0.w = w2; bl0.h = h2;
+    int maxrad = 1;
+    for (int l = 0; l < levwav; ++l) { const int r = int((l + 2) / scale); bl0.rad[l] = r > 1 ? r : 1; maxrad = bl0.rad[l] > maxrad ? bl0.rad[l] : maxrad; }
+    // ShrinkAllL / ShrinkAllAB as one kernel per channel (shrinkblur.hip: factors, both running sums and the coefficient update in one pass
+    // over the coefficients) instead of three with the factor and the row-blurred planes in between: no `sf` / `tmp` planes at all
+    const bool fused = ctx->opt_dn_fused != 0 && shrink_blur_supported(w2, h2, bl0.rad, 0, nsub);
+    // ... and for all three channels in ONE launch where nothing has to happen between them (no residuals to read back, no BiShrink
+    // passes, every level of L shrunk, both chroma channels denoised): the strips of a band can only follow each other a few blocks apart, so
+    // it takes the bands of all channels to keep every CU busy, and one launch instead of three has one ragged end instead of three
+    const bool merged = fused && ctx->opt_dn_fused != 2 && !aggressive && !nresi && !highresi && denoiseLuminance && levwav <= 5 &&
+                        (autoch || (noisevarab_r > 0.001f && noisevarab_b > 0.001f));
+    const bool two_chroma = fork || merged;        // a and b keep their own decomposition (otherwise b reuses a's)
+    float *fused_scratch = nullptr, *Lbands2 = nullptr;
     const size_t histo_bytes = (size_t)nsub * (65536 + MAD_SCRATCH_INTS_PER_BAND) * 4, band_bytes = (size_t)nsub * n2 * 4;
     if ((rc = pool_get(ctx, P_L, n * 4, &L)) || (rc = pool_get(ctx, P_A, n * 4, &A)) || (rc = pool_get(ctx, P_B, n * 4, &B)) ||
         (rc = pool_get(ctx, P_LBANDS, band_bytes, &Ld.bands)) || (rc = pool_get(ctx, P_LLOW0, n2 * 4, &Ld.low[0])) || (rc = pool_get(ctx, P_LLOW1, n2 * 4, &Ld.low[1])) ||
-        (rc = pool_get(ctx, P_CBANDS, band_bytes, &Cdd[0].bands)) || (rc = pool_get(ctx, P_CLOW0, n2 * 4, &Cdd[0].low[0])) || (rc = pool_get(ctx, P_CLOW1, n2 * 4, &Cdd[0].low[1])) ||
-        (rc = pool_get(ctx, P_SF, band_bytes, &sfc[0])) || (rc = pool_get(ctx, P_TMP, band_bytes, &tmp1)) || (rc = pool_get(ctx, P_HISTO, histo_bytes, &histo_fc[0])) ||
+        (rc = pool_get(ctx, P_CBANDS, (merged ? 2 : 1) * band_bytes, &Cdd[0].bands)) || (rc = pool_get(ctx, P_CLOW0, n2 * 4, &Cdd[0].low[0])) || (rc = pool_get(ctx, P_CLOW1, n2 * 4, &Cdd[0].low[1])) ||
+        (rc = pool_get(ctx, P_HISTO, histo_bytes, &histo_fc[0])) ||
         (rc = pool_get(ctx, P_MAD, 3 * 32 * 4, &mad)) || (rc = pool_get(ctx, P_GAM, 2 * 65536 * 4, &gamlut)))
         return rc;
+    if (fused) {
+        if ((rc = pool_get(ctx, P_FUSED, shrink_blur_scratch_floats(w2, h2, merged ? 3 * nsub : nsub, maxrad) * 4, &fused_scratch))) return rc;
+        // the chroma factors need the L coefficients as the decomposition left them: whenever they are evaluated beside or after the L pass
+        // (one launch for all channels; the side stream's order) the L pass writes a second band set instead of updating the first
+        if ((fork || merged) && (rc = pool_get(ctx, P_LBANDS2, band_bytes, &Lbands2))) return rc;
+    } else if ((rc = pool_get(ctx, P_SF, band_bytes, &sfc[0])) || (rc = pool_get(ctx, P_TMP, band_bytes, &tmp1))) return rc;
     tmpc[0] = tmpc[1] = tmpc[2] = tmp1;
-    if (fork) {
-        if ((rc = pool_get(ctx, P_CBANDS2, band_bytes, &Cdd[1].bands)) || (rc = pool_get(ctx, P_CLOW0_2, n2 * 4, &Cdd[1].low[0])) || (rc = pool_get(ctx, P_CLOW1_2, n2 * 4, &Cdd[1].low[1])) ||
-            (rc = pool_get(ctx, P_SF_A, band_bytes, &sfc[1])) || (rc = pool_get(ctx, P_SF_B, band_bytes, &sfc[2])) ||
+    if (two_chroma) {
+        if (merged) Cdd[1].bands = Cdd[0].bands + (size_t)nsub * n2;       // (one launch walks both channels' bands: back to back)
+        else if ((rc = pool_get(ctx, P_CBANDS2, band_bytes, &Cdd[1].bands))) return rc;
+        if ((rc = pool_get(ctx, P_CLOW0_2, n2 * 4, &Cdd[1].low[0])) || (rc = pool_get(ctx, P_CLOW1_2, n2 * 4, &Cdd[1].low[1])) ||
             (rc = pool_get(ctx, P_HISTO_A, histo_bytes, &histo_fc[1])) || (rc = pool_get(ctx, P_HISTO_B, histo_bytes, &histo_fc[2])))
             return rc;
+        if (!fused && ((rc = pool_get(ctx, P_SF_A, band_bytes, &sfc[1])) || (rc = pool_get(ctx, P_SF_B, band_bytes, &sfc[2])))) return rc;
     } else {
         sfc[1] = sfc[2] = sfc[0];
         histo_fc[1] = histo_fc[2] = histo_fc[0];
@@ -1244,9 +1269,21 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     if ((rc = decompose_dev(ctx, Ld, L, sL))) return rc;
     HIPCHK(ctx, launch_mad(Ld.bands, n2, nsub, reinterpret_cast<int *>(histo_fc[0]), madL, sL));
 
-    BlurArgs bl0 = {};
-    bl0.n = n2; bl0.w = w2; bl0.h = h2;
-    for (int l = 0; l < levwav; ++l) { const int r = int((l + 2) / scale); bl0.rad[l] = r > 1 ? r : 1; }
+    // one fused ShrinkAll pass over `nb` bands starting at level `lev0` (pointers already offset to the first band)
+    auto fused_pass = [&](bool ab, const float *cin, float *cout, const float *cL, const float *mL, const float *mab, int lev0, int nb,
+                          float nv_const, float noisevar_ab) -> int {
+        FusedShrinkArgs fa = {};
+        if (ab) { fa.coefC = cout; fa.nL = 0; fa.nsub_ch = nb; }           // (chroma bands are updated in place: cin == cout)
+        else { fa.coef = cin; fa.coef_out = cout; fa.nL = nb; }
+        fa.coefL = cL; fa.n = n2; fa.w = w2; fa.h = h2;
+        fa.madL = mL; fa.madab = mab;
+        fa.noisevar = ccalc_dev; fa.noisevar_const = nv_const; fa.noisevar_scale = maxNoiseVarab; fa.noisevar_ab[0] = fa.noisevar_ab[1] = noisevar_ab;
+        fa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
+        for (int l = 0; l < 10; ++l) fa.rad[l] = bl0.rad[l];
+        fa.level0 = lev0; fa.nsub = nb;
+        HIPCHK(ctx, launch_shrink_blur(fa, fused_scratch, sL));
+        return ARTGPU_OK;
+    };
 
     // ---- a and b (L2328-2402), first half: decompose, MADs, shrink factors against the untouched L coefficients
     float noisevar_abc[2];
@@ -1267,13 +1304,17 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
             sa.n = n2; sa.noisevar = ccalc_dev; sa.noisevar_scale = maxNoiseVarab; sa.noisevar_ab = noisevar_ab; sa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
             const size_t top = (size_t)(nsub - 3) * n2;
             sa.coef = Cd.bands + top; sa.coefL = Ld.bands + top; sa.sfave = sf; sa.madL = madL + (nsub - 3); sa.madab = madab + (nsub - 3);
-            HIPCHK(ctx, launch_shrink_sf(sa, 3, true, sL));
-            BlurArgs bt = bl0;
-            bt.level0 = levwav - 1;
-            bt.src = sf; bt.dst = tmp;
-            HIPCHK(ctx, launch_hblur(bt, 3, sL));
-            bt.src = tmp; bt.sfave = sf; bt.coef = Cd.bands + top;
-            HIPCHK(ctx, launch_vblur_combine(bt, 3, sL));
+            if (fused) {
+                if ((rc2 = fused_pass(true, Cd.bands + top, Cd.bands + top, Ld.bands + top, madL + (nsub - 3), madab + (nsub - 3), levwav - 1, 3, 0.f, noisevar_ab))) return rc2;
+            } else {
+                HIPCHK(ctx, launch_shrink_sf(sa, 3, true, sL));
+                BlurArgs bt = bl0;
+                bt.level0 = levwav - 1;
+                bt.src = sf; bt.dst = tmp;
+                HIPCHK(ctx, launch_hblur(bt, 3, sL));
+                bt.src = tmp; bt.sfave = sf; bt.coef = Cd.bands + top;
+                HIPCHK(ctx, launch_vblur_combine(bt, 3, sL));
+            }
             if (nsub > 3) {
                 sa.coef = Cd.bands; sa.coefL = Ld.bands; sa.madL = madL; sa.madab = madab;
                 HIPCHK(ctx, launch_bishrink_AB(sa, nsub - 3, sL));
@@ -1281,10 +1322,12 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         }
         if (noisevar_ab > 0.001f) {
             HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, madab, sL));
-            ShrinkArgs sa = {};
-            sa.coef = Cd.bands; sa.coefL = Ld.bands; sa.sfave = sf; sa.n = n2; sa.madL = madL; sa.madab = madab;
-            sa.noisevar = ccalc_dev; sa.noisevar_scale = maxNoiseVarab; sa.noisevar_ab = noisevar_ab; sa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
-            HIPCHK(ctx, launch_shrink_sf(sa, nsub, true, sL));
+            if (!fused) {
+                ShrinkArgs sa = {};
+                sa.coef = Cd.bands; sa.coefL = Ld.bands; sa.sfave = sf; sa.n = n2; sa.madL = madL; sa.madab = madab;
+                sa.noisevar = ccalc_dev; sa.noisevar_scale = maxNoiseVarab; sa.noisevar_ab = noisevar_ab; sa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
+                HIPCHK(ctx, launch_shrink_sf(sa, nsub, true, sL));
+            }
         }
         return ARTGPU_OK;
     };
@@ -1294,12 +1337,19 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         DevDecomp &Cd = Cdd[ch];
         float *sf = sfc[1 + ch], *tmp = tmpc[1 + ch], *madab = mad + 32 * (1 + ch);
         int *histo = reinterpret_cast<int *>(histo_fc[1 + ch]);
-        if (noisevar_abc[ch] > 0.001f) {
-            BlurArgs bl = bl0;
-            bl.src = sf; bl.dst = tmp;
-            HIPCHK(ctx, launch_hblur(bl, nsub, sL));
-            bl.src = tmp; bl.sfave = sf; bl.coef = Cd.bands;
-            HIPCHK(ctx, launch_vblur_combine(bl, nsub, sL));
+        if (noisevar_abc[ch] > 0.001f && !merged) {
+            if (fused) {
+                // (the factors read the L coefficients as the decomposition left them: in the reference's order L comes last, with the side
+                // stream the L pass has written a second band set)
+                int rc2 = fused_pass(true, Cd.bands, Cd.bands, Ld.bands, madL, madab, 0, nsub, 0.f, noisevar_abc[ch]);
+                if (rc2) return rc2;
+            } else {
+                BlurArgs bl = bl0;
+                bl.src = sf; bl.dst = tmp;
+                HIPCHK(ctx, launch_hblur(bl, nsub, sL));
+                bl.src = tmp; bl.sfave = sf; bl.coef = Cd.bands;
+                HIPCHK(ctx, launch_vblur_combine(bl, nsub, sL));
+            }
         }
         if (nresi || highresi) {
             // Noise_residualAB (FTblockDN.cc:605-635, kall == 0): SQR(MadRgb) of the shrunk chroma bands, summed in level/dir order
@@ -1335,19 +1385,31 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         sa.coef = Ld.bands; sa.sfave = sf; sa.n = n2; sa.madL = madL; sa.noisevar = nullptr; sa.noisevar_const = noisevarL;
         // QUALITY_HIGH runs WaveletDenoiseAll_BiShrinkL first (L842-973); its per-band body is ShrinkAllL's (top level included),
         // and madL is not recomputed in between (L2408-2421): the standard pass simply runs twice
-        for (int rep = aggressive ? 0 : 1; rep < 2; ++rep) {
-            HIPCHK(ctx, launch_shrink_sf(sa, nsubL, false, sL));
-            bl.src = sf; bl.dst = tmp;
-            HIPCHK(ctx, launch_hblur(bl, nsubL, sL));
-            bl.src = tmp; bl.sfave = sf; bl.coef = Ld.bands;
-            HIPCHK(ctx, launch_vblur_combine(bl, nsubL, sL));
+        DevDecomp Lrec = Ld;                   // what the reconstruction reads
+        if (merged) Lrec.bands = Lbands2;
+        for (int rep = aggressive ? 0 : 1; rep < 2 && !merged; ++rep) {
+            if (fused) {
+                // the first pass reads the decomposition; with a second band set it writes there, and a second pass (QUALITY_HIGH) works on that
+                float *dstb = Lbands2 ? Lbands2 : Ld.bands;
+                if ((rc2 = fused_pass(false, Lrec.bands, dstb, nullptr, madL, nullptr, 0, nsubL, noisevarL, 0.f))) return rc2;
+                Lrec.bands = dstb;
+            } else {
+                HIPCHK(ctx, launch_shrink_sf(sa, nsubL, false, sL));
+                bl.src = sf; bl.dst = tmp;
+                HIPCHK(ctx, launch_hblur(bl, nsubL, sL));
+                bl.src = tmp; bl.sfave = sf; bl.coef = Ld.bands;
+                HIPCHK(ctx, launch_vblur_combine(bl, nsubL, sL));
+            }
         }
+        if (Lrec.bands != Ld.bands && nsubL < nsub)          // levels beyond the fifth are reconstructed as they are
+            HIPCHK(ctx, hipMemcpyAsync(Lrec.bands + (size_t)nsubL * n2, Ld.bands + (size_t)nsubL * n2, (size_t)(nsub - nsubL) * n2 * 4, hipMemcpyDeviceToDevice, sL));
         if (do_detail) {
             // labdn->L is kept as Lin before the reconstruction modifies it (L2423-2432): here the reconstruction writes a second plane
             // instead of the first being copied
             if ((rc2 = pool_get(ctx, P_LIN, n * 4, &Lout))) return rc2;
         }
-        if ((rc2 = reconstruct_dev(ctx, Ld, Lout, sL))) return rc2;
+        Lrec.cur = Ld.cur;
+        if ((rc2 = reconstruct_dev(ctx, Lrec, Lout, sL))) return rc2;
         if (do_detail) {
             float *Lin = L;
             // ---- detail_recovery (L1479-1635): host-side tables exactly as the reference builds them
@@ -1398,7 +1460,9 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
                 float *dmask;
                 if ((rc2 = pool_get(ctx, P_DMASK, n * 4, &dmask))) return rc2;
                 const float amount = std::max(0.f, std::min(float(p->luminance_detail_threshold) / 100.f, 1.f));
-                if ((rc2 = detail_mask_dev(ctx, Lout, (size_t)w, dmask, w, h, 65535.f, 25.f, 10000.f, amount, (float)(25.f / scale), tmp))) return rc2;
+                float *dm_scratch = tmp;
+                if (!dm_scratch && (rc2 = pool_get(ctx, P_TMP, ((size_t)w * h + 2 * (size_t)(w / 4) * (h / 4)) * 4, &dm_scratch))) return rc2;   // (fused: no `tmp` plane set)
+                if ((rc2 = detail_mask_dev(ctx, Lout, (size_t)w, dmask, w, h, 65535.f, 25.f, 10000.f, amount, (float)(25.f / scale), dm_scratch))) return rc2;
                 da.mask = dmask; da.params_Ldetail = params_Ldetail;
             }
             if (sd != sL) {
@@ -1412,7 +1476,31 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         return ARTGPU_OK;
     };
 
-    if (!fork) {
+    auto merged_pass = [&]() -> int {
+        FusedShrinkArgs fa = {};
+        fa.coef = Ld.bands; fa.coef_out = Lbands2; fa.coefC = Cdd[0].bands; fa.coefL = Ld.bands; fa.n = n2; fa.w = w2; fa.h = h2;
+        fa.madL = madL; fa.madab = mad + 32; fa.mad_ch_stride = 32;
+        fa.noisevar = ccalc_dev; fa.noisevar_const = noisevarL; fa.noisevar_scale = maxNoiseVarab;
+        fa.noisevar_ab[0] = noisevar_abc[0]; fa.noisevar_ab[1] = noisevar_abc[1];
+        fa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
+        for (int l = 0; l < 10; ++l) fa.rad[l] = bl0.rad[l];
+        fa.level0 = 0; fa.nsub = 3 * nsub; fa.nL = nsub; fa.nsub_ch = nsub;
+        HIPCHK(ctx, launch_shrink_blur(fa, fused_scratch, sL));
+        return ARTGPU_OK;
+    };
+    if (merged) {
+        // decompositions and MADs of a and b, the three channels' ShrinkAll passes as one launch, then the reconstructions -- L first, so that
+        // its DCT detail recovery (side stream) runs beside those of a and b
+        if ((rc = chroma_front(0)) || (rc = chroma_front(1)) || (rc = merged_pass())) return rc;
+        SideStreamJoin dn_join;
+        if (fork) dn_join.arm(ctx->dn_stream[0]);
+        if ((rc = luma(fork ? ctx->dn_stream[0] : sL))) return rc;
+        if ((rc = chroma_back(0)) || (rc = chroma_back(1))) return rc;
+        if (fork) {
+            HIPCHK(ctx, hipStreamWaitEvent(sL, ctx->dn_ev[1], 0));
+            dn_join.disarm();
+        }
+    } else if (!fork) {
         // the reference's order
         for (int ch = 0; ch < 2; ++ch)
             if ((rc = chroma_front(ch)) || (rc = chroma_back(ch))) return rc;
@@ -2717,7 +2805,7 @@ int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, con
         peer->curve_tail_kind = ctx->curve_tail_kind; peer->curve_tail_y = ctx->curve_tail_y; peer->curve_tail_pc = ctx->curve_tail_pc;
         peer->opt_amaze_path = ctx->opt_amaze_path; peer->opt_amaze_split = ctx->opt_amaze_split; peer->opt_amaze_overlap = ctx->opt_amaze_overlap;
         peer->opt_amaze_zero_mask = ctx->opt_amaze_zero_mask; peer->opt_amaze_zero_frame = ctx->opt_amaze_zero_frame; peer->opt_amaze_poison = ctx->opt_amaze_poison;
-        peer->opt_rcd_rows = ctx->opt_rcd_rows; peer->opt_roctx = ctx->opt_roctx; peer->opt_lut_lds = ctx->opt_lut_lds; peer->opt_dn_streams = ctx->opt_dn_streams;
+        peer->opt_rcd_rows = ctx->opt_rcd_rows; peer->opt_roctx = ctx->opt_roctx; peer->opt_lut_lds = ctx->opt_lut_lds; peer->opt_dn_streams = ctx->opt_dn_streams; peer->opt_dn_fused = ctx->opt_dn_fused;
         peer->progress_fn = ctx->progress_fn; peer->progress_user = ctx->progress_user;
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // inputs the caller produced on this context's stream

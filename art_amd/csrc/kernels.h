@@ -381,6 +381,41 @@ hipError_t launch_mad(const float *bands, size_t n, int nsub, int *histo, float 
 hipError_t launch_shrink_sf(const ShrinkArgs &a, int nsub, bool ab, hipStream_t s);
 hipError_t launch_hblur(const BlurArgs &a, int nsub, hipStream_t s);
 hipError_t launch_vblur_combine(const BlurArgs &a, int nsub, hipStream_t s);
+// ShrinkAllL / ShrinkAllAB in one pass over the coefficients (shrinkblur.hip): shrink factor, both box-blur directions and the coefficient
+// update; `coef_out` may be `coef` (in place) or a second band set
+struct FusedShrinkArgs {
+    // a launch holds nL bands of L (ShrinkAllL) followed by nsub - nL chroma bands (ShrinkAllAB), channel after channel
+    const float *coef;      // L bands to shrink: [nL][n]
+    float *coef_out;        // where their updated coefficients go (may be `coef`; has to be another band set when chroma bands are in the launch:
+                            // their factors read the L coefficients as the decomposition left them)
+    float *coefC;           // chroma bands, updated in place: [nsub - nL][n]
+    const float *coefL;     // the L decomposition's bands as the chroma factors see them
+    size_t n;
+    int w, h;
+    const float *madL;      // [bands per channel] SQR(MadRgb) of the L bands
+    const float *madab;     // SQR(MadRgb) of the chroma bands: channel c's at madab + c * mad_ch_stride
+    const float *noisevar;  // chroma: per-coefficient noise variance map (n floats) or nullptr
+    float noisevar_const;   // L: noisevarL
+    float noisevar_scale;   // chroma: maxNoiseVarab
+    float noisevar_ab[2];   // chroma, per channel (chroma curve off)
+    int useNoiseCCurve;
+    int rad[10];            // blur radius per level
+    int level0;             // level of the first band of a channel
+    int nsub;               // bands in the launch
+    int nL;                 // of which L bands
+    int nsub_ch;            // chroma bands per channel (0: all of them one channel)
+    int mad_ch_stride;
+    // filled in by launch_shrink_blur
+    int nstrips;
+    float *hand;            // hand-over slots between the strips of a band
+    int wpad;               // columns of a slot row (whole blocks)
+    int *progress;          // [nsub][nstrips] blocks a strip has handed down
+    int *ticket;
+    long long *prof;        // -DFS_PROFILE: cycle counters (step time, busy time per role and per wave, time spent waiting for the strip above)
+};
+bool shrink_blur_supported(int w, int h, const int *rad, int level0, int nsub);
+size_t shrink_blur_scratch_floats(int w, int h, int nsub, int maxr);
+hipError_t launch_shrink_blur(FusedShrinkArgs a, float *scratch, hipStream_t s);
 
 // ---- DCT detail recovery (detail.hip) ----
 struct DetailArgs {

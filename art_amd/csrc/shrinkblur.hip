@@ -1,0 +1,469 @@
+// art_amd/csrc/shrinkblur.hip -- ShrinkAllL / ShrinkAllAB in ONE pass over the coefficients (FTblockDN.cc:638-839).
+//
+// The reference does, per band: sfave = shrink factor of every coefficient (L664-690 / L760-790), boxblur(sfave, sfaved, radius) --
+// boxblur.h:558-742: a running sum along every row into a temporary, then a running sum down every column --, and
+// coef *= (sfaved^2 + sfave^2) / (sfaved + sfave + eps) (L698-714 / L803-836).  The running sums are fp32 accumulations whose value
+// depends on their order, so a row has to be walked from column 0 and a column from row 0: the three-kernel form (shrink_sf_*,
+// hblur_kernel, vblur_combine_kernel in denoise.hip) stores sfave and the row-blurred plane and reads them back -- 32 to 36 bytes per
+// coefficient in three dependent passes, 4.3 of the 8.5 ms the FTblockDN chain took on a 45 MP frame.
+//
+// Here a workgroup owns a STRIP of 64 rows of one band and walks it left to right in blocks of 64 columns.  Per block: all threads
+// evaluate the shrink factors of the block's coefficients into LDS; one wave (lane = row) advances the 64 row sums across the block;
+// one wave (lane = column) advances the block's 64 column sums down the strip; all threads update the coefficients.  What a column sum
+// needs from above the strip -- its accumulator and the 2 * rad + 1 row-blurred values it is about to drop -- is handed down by the strip
+// above through a small buffer in global memory: strips of a band form a wavefront, strip s working on block j while strip s - 1 is at
+// block j + 1 or further.  Workgroups take (strip, band) from a ticket counter, strip-major, so a workgroup only ever waits for one
+// that started before it (no assumption about the order in which the hardware dispatches blockIdx).  The lags: the row sum of column c
+// needs the factor of column c + rad, the column sum of row r the row-blurred value of row r + rad, so block j produces columns
+// [64 j - rad, 64 j + 64 - rad) and a strip that holds rows [R0, R0 + 64) produces rows [R0 - rad, R0 + 64 - rad): it evaluates the
+// factors of the rad rows above itself a second time (they only enter the coefficient update), the last strip runs to the bottom.
+// Every coefficient is read once (plus rad / 64 of them twice) and written once: 8 - 12 bytes instead of 32 - 36, same operations in
+// the same order on every row and every column: same bits (tests/test_gpu_denoise.py compares the two forms and both with the oracle).
+#include "kernels.h"
+#include "devmath.h"
+#include "devsleef.h"
+#include <type_traits>
+
+namespace artgpu {
+
+namespace {
+
+constexpr int FS_R = 64, FS_C = 64, FS_T = 1024, FS_NE = FS_T / 64 - 2;   // 16 waves: one for the row sums, one for the column sums, 14 elementwise
+constexpr int FS_SWIN = 256, FS_SWS = FS_SWIN + 1;                          // factor window: 256 columns (circular), odd row stride
+
+// Barrier for data that travels through LDS only: __syncthreads() would also wait for this wave's global loads -- the coefficients of the
+// next block, fetched a step ahead precisely so that nobody waits for them
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// band constants of the shrink factor (shrink_sf_L_kernel / shrink_sf_AB_kernel)
+struct SfConst { float mad_L, levelFactor, madab, rmadLm9, nv_const, nv_scale; int has_nv; };
+
+// TAIL: the block holds coefficients of the band's last n % 4 (the reference's scalar loop tail, other operation order); everywhere else the
+// vector form is the only one, and the factors of a thread's rows are independent straight-line chains the scheduler can interleave
+template <bool AB, bool TAIL>
+__device__ __forceinline__ float shrink_factor(const SfConst &k, float c, float cl, float nvv, bool vecform)
+{
+    const float eps = 0.01f;
+    if constexpr (!AB) {
+        const float nv = k.has_nv ? nvv : k.nv_const;
+        const float mag = sqr(c);
+        if (!TAIL || vecform) {
+            const float madv = nv * k.levelFactor;
+            return mag / (mag + madv * xexpf_v(-mag / (9.0f * madv)) + eps);
+        }
+        return mag / (mag + k.levelFactor * nv * xexpf_s(-mag / (9 * k.levelFactor * nv)) + eps);
+    } else {
+        const float nvc = k.has_nv ? k.nv_scale * nvv : 1.f;
+        const float mag_ab = sqr(c);
+        if (!TAIL || vecform) {
+            const float mad_abv = nvc * k.madab;
+            const float mag_L = sqr(cl) * k.rmadLm9;
+            return 1.f - xexpf_v(-(mag_ab / mad_abv) - mag_L);
+        }
+        const float mag_L = sqr(cl);
+        return 1.f - xexpf_s(-(mag_ab / (nvc * k.madab)) - (mag_L / (9.f * k.mad_L)));
+    }
+}
+
+// One workgroup per CU, the roles of a step run side by side (a step = one LDS-only barrier):
+//   step T:  elementwise waves   coefficient update of block T - 3, then the shrink factors of block T (coefficients fetched at step T - 1)
+//            row-sum wave        block T - 1
+//            column-sum wave     block T - 2 (+ the hand-over: what the strip above left for block T - 1 is sent for, block T - 2's rows
+//                                go to the strip below, block T - 3 -- whose stores have left by now -- is published)
+// A block's factors live in a circular window of 256 columns; its row-blurred values in one of three buffers (written by the row sums,
+// turned into column sums in place, read by the update).
+template <int MAXR>
+__global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
+{
+    constexpr int SROWS = FS_R + MAXR;             // window rows: up to rad rows above the strip + the strip
+    constexpr int HROWS = FS_R + 2 * MAXR + 1;     // 2 rad + 1 rows handed down + the strip
+    constexpr int HS = FS_C + 1;
+    constexpr int NQ = (SROWS + FS_NE - 1) / FS_NE;   // window rows per elementwise wave
+    constexpr int NOVMAX = 2 * MAXR + 1;
+    extern __shared__ float fs_lds[];
+    float *const S = fs_lds;                       // [SROWS][FS_SWS]: factor of window row wr (image row R0 - rad + wr), image column c at c & 255
+    float *const HB0 = S + SROWS * FS_SWS;         // 3 x [HROWS][HS]
+    __shared__ int s_ticket;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform, and known to be)
+    const int ew = wv - 2;                         // elementwise wave index
+    if (wv < 2) __builtin_amdgcn_s_setprio(3);     // the two serial roles go first on their SIMDs
+#ifdef FS_PROFILE
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define FS_T0 const long long t0_ = __builtin_readcyclecounter();
+#define FS_T1(k) pt[k] += __builtin_readcyclecounter() - t0_;
+#else
+#define FS_T0
+#define FS_T1(k)
+#endif
+    const int W = a.w, H = a.h;
+    const int n = (int)a.n;                        // (shrink_blur_supported: a band fits 31 bits)
+    const int nv4 = (n / 4) * 4;
+    const float eps = 0.01f;
+    // persistent workgroups: a workgroup that has finished its strip takes the next ticket (strip-major: strip s of every band before
+    // strip s + 1 of any), so the strips it may have to wait for belong to tickets taken before its own, i.e. to running workgroups
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_ticket = atomicAdd(a.ticket, 1);
+    __syncthreads();
+    const int ticket = s_ticket;
+    if (ticket >= a.nsub * a.nstrips) break;
+    // a launch holds nL bands of L (ShrinkAllL) followed by the bands of the chroma channels (ShrinkAllAB), channel after channel
+    const int strip = ticket / a.nsub, sub = ticket - strip * a.nsub;
+    const bool AB = sub >= a.nL;
+    const int sc = sub - a.nL;                                          // chroma: band of the launch's chroma part,
+    const int ch = AB ? sc / a.nsub_ch : 0, subc = AB ? sc - ch * a.nsub_ch : sub;   // its channel, and the band of the channel
+    const int rad = a.rad[a.level0 + subc / 3];
+    const float *coef = AB ? a.coefC + (size_t)sc * a.n : a.coef + (size_t)sub * a.n;
+    float *out = AB ? a.coefC + (size_t)sc * a.n : a.coef_out + (size_t)sub * a.n;
+    const float *coefL = a.coefL + (size_t)subc * a.n;
+    SfConst kc;
+    kc.mad_L = a.madL[subc];
+    kc.levelFactor = kc.mad_L * 5.f / (float)(subc / 3 + 1);
+    kc.madab = 0.f; kc.rmadLm9 = 0.f;
+    kc.nv_const = a.noisevar_const; kc.nv_scale = a.noisevar_scale; kc.has_nv = AB && a.noisevar != nullptr;
+    if (AB) {
+        const float m = a.madab[ch * a.mad_ch_stride + subc];
+        kc.madab = a.useNoiseCCurve ? m : m * a.noisevar_ab[ch];
+        kc.rmadLm9 = 1.f / (kc.mad_L * 9.f);
+    }
+    const int R0 = strip * FS_R, Rb = min(R0 + FS_R, H);
+    const bool first = strip == 0, last = Rb == H;
+    const int rs0 = max(0, R0 - rad);              // first image row with a factor in the window
+    const int ro0 = rs0, ro1 = last ? H : Rb - rad;    // rows this strip writes
+    const int nov = 2 * rad + 1;
+    const int NB = (W + rad + FS_C - 1) / FS_C;
+    const size_t slot = (size_t)(2 * MAXR + 2) * a.wpad;
+    float *const hand_hb = a.hand + (size_t)(sub * a.nstrips + strip) * slot;      // what the strip above left for this one, block-major:
+    float *const hand_nx = hand_hb + slot;                                         // [block][2 MAXR + 2 rows][64 columns]
+    int *const prog = a.progress + sub * a.nstrips;
+
+    // ---- elementwise waves: registers that travel a step ahead (clamped addresses: every load is unconditional)
+    float pc[NQ], pl[NQ], pn[NQ], cu[NQ];
+    auto fetch = [&](int J) {                      // coefficients of block J for its factors
+        const int col = min(J * FS_C + lane, W - 1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int r = min(max(R0 - rad + ew + FS_NE * q, 0), Rb - 1);
+            const int i = r * W + col;
+            pc[q] = coef[i];
+            pl[q] = AB ? coefL[i] : 0.f;
+            pn[q] = kc.has_nv ? a.noisevar[i] : 0.f;
+        }
+    };
+    auto fetch_upd = [&](int J) {                  // coefficients of block J's (lagged) columns for their update
+        const int col = min(max(J * FS_C - rad + lane, 0), W - 1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int r = min(max(R0 - rad + ew + FS_NE * q, 0), H - 1);
+            cu[q] = coef[r * W + col];
+        }
+    };
+    if (ew >= 0) fetch(0);
+
+    // ---- column-sum wave: what the strip above hands down for a block, fetched a step ahead
+    float hpre[NOVMAX], tvpre = 0.f;
+    int seen = 0, flagpre = 0;                     // flagpre: the strip above's counter, read a step ahead as well (a poll is a memory round trip
+                                                   // even when the counter has long moved on; only a counter that is still short is polled for)
+    auto prefetch_hand = [&](int J) {
+        seen = max(seen, flagpre);
+        if (seen < J + 1) {
+            FS_T0
+            int v;
+            while ((v = __hip_atomic_load(prog + strip - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < J + 1) __builtin_amdgcn_s_sleep(2);
+            seen = v;
+            FS_T1(6)
+#ifdef FS_PROFILE
+            pt[7] += 1;
+#endif
+        }
+        const float *hp = hand_hb + (size_t)J * (2 * MAXR + 2) * FS_C + lane;
+#pragma unroll
+        for (int k = 0; k < NOVMAX; ++k) hpre[k] = k < nov ? ld_agent(hp + k * FS_C) : 0.f;
+        tvpre = ld_agent(hp + (2 * MAXR + 1) * FS_C);
+        flagpre = __hip_atomic_load(prog + strip - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (wv == 1 && !first) prefetch_hand(0);
+
+    // ---- row-sum wave (lane = row of the strip)
+    float tempval = 0.f, reclen = 0.f;
+    int hlen = rad + 1;
+
+    for (int T = 0; T < NB + 3; ++T) {
+#ifdef FS_PROFILE
+        const long long ts_ = __builtin_readcyclecounter();
+#endif
+        if (ew >= 0) {
+            FS_T0
+            // ---- coefficient update of block J = T - 3 (FTblockDN.cc:698-714, 803-836), rows [ro0, ro1)
+            if (T >= 3) {
+                const int J = T - 3;
+                const float *HBj = HB0 + (J % 3) * (HROWS * HS);
+                const int col = J * FS_C - rad + lane;
+                const bool tailblk = last && J * FS_C - rad + FS_C > W - 4;
+                if (col >= 0 && col < W) {
+                    if (!tailblk) {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const int wr = ew + FS_NE * q, r = R0 - rad + wr;
+                            if (r >= ro0 && r < ro1) {
+                                const float sfd = HBj[wr * HS + lane];
+                                const float sf = S[wr * FS_SWS + (col & (FS_SWIN - 1))];
+                                const float num = sqr(sfd) + sqr(sf), den = sfd + sf + eps;
+                                out[r * W + col] = cu[q] * num / den;
+                            }
+                        }
+                    } else {
+#pragma unroll 1
+                        for (int q = 0; q < NQ; ++q) {
+                            const int wr = ew + FS_NE * q, r = R0 - rad + wr;
+                            if (r >= ro0 && r < ro1) {
+                                const float sfd = HBj[wr * HS + lane];
+                                const float sf = S[wr * FS_SWS + (col & (FS_SWIN - 1))], c = cu[q];
+                                const int i = r * W + col;
+                                const float num = sqr(sfd) + sqr(sf), den = sfd + sf + eps;
+                                if (i < nv4) out[i] = c * num / den; else out[i] = c * (num / den);
+                            }
+                        }
+                    }
+                }
+            }
+            if (T >= 2 && T - 2 < NB) fetch_upd(T - 2);
+            // ---- shrink factors of block T (after the update in program order: the window slots they overwrite hold columns the update
+            //      of block T - 3 has just read -- in the same rows, i.e. in this wave)
+            if (T < NB) {
+                const int col = T * FS_C + lane;
+                const bool tailblk = last && T * FS_C + FS_C > W - 4;
+                auto factors = [&](auto abtag) {                     // (one instantiation per kind of band: no per-row branch on the kind)
+                    constexpr bool ABc = decltype(abtag)::value;
+                    if (!tailblk) {
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const int wr = ew + FS_NE * q, r = R0 - rad + wr;
+                            if (r >= 0 && r < Rb) {                      // (uniform: whole rows)
+                                const float sf = shrink_factor<ABc, false>(kc, pc[q], pl[q], pn[q], true);
+                                if (col < W) S[wr * FS_SWS + (col & (FS_SWIN - 1))] = sf;
+                            }
+                        }
+                    } else {
+#pragma unroll 1
+                        for (int q = 0; q < NQ; ++q) {
+                            const int wr = ew + FS_NE * q, r = R0 - rad + wr;
+                            if (r >= 0 && r < Rb && col < W)
+                                S[wr * FS_SWS + (col & (FS_SWIN - 1))] = shrink_factor<ABc, true>(kc, pc[q], pl[q], pn[q], r * W + col < nv4);
+                        }
+                    }
+                };
+                if (AB) factors(std::true_type{}); else factors(std::false_type{});
+                if (T + 1 < NB) fetch(T + 1);
+            }
+            FS_T1(3)
+        } else if (wv == 0) {
+            // ---- row sums of block J = T - 1 over columns [X0 - rad, X0 + 64 - rad) (boxblur.h:565-600, hblur_kernel)
+            if (T >= 1 && T <= NB && R0 + lane < Rb) {
+                FS_T0
+                const int J = T - 1, X0 = J * FS_C;
+                const float *srow = S + (rad + lane) * FS_SWS;
+                auto s = [&](int k) -> float { return srow[(X0 + k) & (FS_SWIN - 1)]; };     // factor at column X0 + k
+                float *hb = HB0 + (J % 3) * (HROWS * HS) + (nov + lane) * HS;
+                int jj = 0;
+                if (J == 0) jj = rad;                                  // columns < 0 do not exist
+                while (jj < FS_C) {
+                    const int col = X0 - rad + jj;
+                    if (col >= W) break;
+                    if (col > rad && col + 8 <= W - rad && jj + 8 <= FS_C) {
+                        float hi[8], lo[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { hi[k] = s(jj + k); lo[k] = s(jj + k - nov); }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { tempval = tempval + (hi[k] - lo[k]) * reclen; hb[jj + k] = tempval; }
+                        jj += 8;
+                        continue;
+                    }
+                    if (col == 0) {
+                        tempval = s(jj - rad);
+                        for (int q = 1; q <= rad; q++) tempval += s(jj - rad + q);
+                        tempval = tempval / hlen;
+                    } else if (col <= rad) {
+                        tempval = (tempval * hlen + s(jj)) / (hlen + 1);
+                        hlen++;
+                        if (col == rad) reclen = 1.f / hlen;
+                    } else if (col < W - rad) {
+                        tempval = tempval + (s(jj) - s(jj - nov)) * reclen;
+                    } else {
+                        tempval = (tempval * hlen - s(jj - nov)) / (hlen - 1);
+                        hlen--;
+                    }
+                    hb[jj] = tempval;
+                    ++jj;
+                }
+                FS_T1(1)
+            }
+        } else {
+            // ---- column sums of block J = T - 2 and the hand-over.  Everything that crosses to another workgroup goes through THIS wave:
+            //      its write-through (sc1) stores are the only stores it has in flight, so waiting for them a step later costs nothing and
+            //      neither holds up the coefficient traffic of the other waves nor needs a release fence (which would write back the XCD's
+            //      whole dirty L2, full of this kernel's coefficient stores); the strip below reads with sc1 loads and needs no acquire.
+            FS_T0
+            float tv_in = 0.f;
+            const int J = T - 2;
+            float *HBj = HB0 + ((J + 3) % 3) * (HROWS * HS);
+            const bool work = J >= 0 && J < NB;
+            if (work && !first) {
+#pragma unroll
+                for (int k = 0; k < NOVMAX; ++k)
+                    if (k < nov) HBj[k * HS + lane] = hpre[k];
+                tv_in = tvpre;
+            }
+            if (!last && T >= 3) {                                     // block T - 3 has left: the strip below may have it
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(prog + strip, T - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (!first && T >= 1 && T - 1 < NB) prefetch_hand(T - 1);
+            if (work) {
+                const int X0 = J * FS_C;
+                if (!last) {                                           // the strip's last 2 rad + 1 row-blurred rows
+                    float *hp = hand_nx + (size_t)J * (2 * MAXR + 2) * FS_C + lane;
+#pragma unroll
+                    for (int k = 0; k < NOVMAX; ++k)
+                        if (k < nov) st_agent(hp + k * FS_C, HBj[(FS_R + k) * HS + lane]);
+                }
+                // column sums over rows [ro0, ro1) (boxblur.h:602-742, vblur_combine_kernel); the value of row r replaces the row-blurred
+                // value of row r - rad - 1, which that step was the last to need
+                const int col = X0 - rad + lane;
+                float tv = tv_in;
+                if (col >= 0 && col < W) {
+                    const bool vec = col < (W / 4) * 4;
+                    const bool allvec = X0 - rad + FS_C <= (W / 4) * 4;
+                    float lenf = first ? (float)(rad + 1) : (float)nov;
+                    int leni = first ? rad + 1 : nov;
+                    const float rlen = 1.f / (float)nov;
+                    const float *hbc = HBj + (nov - R0) * HS + lane;       // hbc[r * HS] = row-blurred value of row r
+                    float *vout = HBj + (rad - R0) * HS + lane;            // vout[r * HS] <- column sum of row r
+                    int r = ro0;
+                    while (r < ro1) {
+                        if (allvec && r > rad && r + 8 <= H - rad && r + 8 <= ro1) {       // (no lane of the block takes the scalar form)
+                            float hi[8], lo[8];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) { hi[k] = hbc[(r + k + rad) * HS]; lo[k] = hbc[(r + k - rad - 1) * HS]; }
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) { tv = tv + (hi[k] - lo[k]) * rlen; vout[(r + k) * HS] = tv; }
+                            r += 8;
+                            continue;
+                        }
+                        if (r == 0) {
+                            if (vec) {
+                                tv = hbc[0];
+                                for (int i = 1; i <= rad; i++) tv = tv + hbc[i * HS];
+                                tv = tv / lenf;
+                            } else {
+                                tv = hbc[0] / leni;
+                                for (int i = 1; i <= rad; i++) tv += hbc[i * HS] / leni;
+                            }
+                        } else if (r <= rad) {
+                            if (vec) {
+                                const float lenp1 = lenf + 1.f;
+                                tv = (tv * lenf + hbc[(r + rad) * HS]) / lenp1;
+                                lenf = lenp1;
+                            } else {
+                                tv = (tv * leni + hbc[(r + rad) * HS]) / (leni + 1);
+                                leni++;
+                            }
+                        } else if (r < H - rad) {
+                            const float d = hbc[(r + rad) * HS] - hbc[(r - rad - 1) * HS];
+                            tv = vec ? tv + d * rlen : tv + d / leni;
+                        } else {
+                            if (vec) {
+                                const float lenm1 = lenf - 1.f;
+                                tv = (tv * lenf - hbc[(r - rad - 1) * HS]) / lenm1;
+                                lenf = lenm1;
+                            } else {
+                                tv = (tv * leni - hbc[(r - rad - 1) * HS]) / (leni - 1);
+                                leni--;
+                            }
+                        }
+                        vout[r * HS] = tv;
+                        ++r;
+                    }
+                }
+                // (every lane stores: the strip below reads all 64 slots of the block)
+                if (!last) st_agent(hand_nx + (size_t)J * (2 * MAXR + 2) * FS_C + (2 * MAXR + 1) * FS_C + lane, tv);
+            }
+            FS_T1(2)
+        }
+        lds_barrier();
+#ifdef FS_PROFILE
+        pt[0] += __builtin_readcyclecounter() - ts_;
+#endif
+    }
+  }
+#ifdef FS_PROFILE
+    if (a.prof) {
+        unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.prof);
+        if (tid == 0) { atomicAdd(pp + 0, (unsigned long long)pt[0]); atomicAdd(pp + 1, (unsigned long long)pt[1]); }
+        if (tid == 64) { atomicAdd(pp + 2, (unsigned long long)pt[2]); atomicAdd(pp + 6, (unsigned long long)pt[6]); atomicAdd(pp + 7, (unsigned long long)pt[7]); }
+        if (tid == 128) atomicAdd(pp + 3, (unsigned long long)pt[3]);
+        if (lane == 0) atomicAdd(pp + 8 + wv, (unsigned long long)(pt[1] + pt[2] + pt[3]));      // busy time per wave
+    }
+#endif
+}
+
+template <int MAXR>
+hipError_t launch_one(const FusedShrinkArgs &a, hipStream_t s)
+{
+    constexpr int SROWS = FS_R + MAXR, HROWS = FS_R + 2 * MAXR + 1, HS = FS_C + 1;
+    constexpr int lds = (SROWS * FS_SWS + 3 * HROWS * HS) * (int)sizeof(float);
+    static_assert(lds <= 160 * 1024 - 64, "LDS");
+    hipError_t e = dyn_lds_once(reinterpret_cast<const void *>(shrink_blur_kernel<MAXR>), lds);
+    if (e != hipSuccess) return e;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int total = a.nsub * a.nstrips;
+    hipLaunchKernelGGL((shrink_blur_kernel<MAXR>), dim3(total < cus ? total : cus), dim3(FS_T), lds, s, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+bool shrink_blur_supported(int w, int h, const int *rad, int level0, int nsub)
+{
+    if (w < 64 || h < 64 || nsub < 1 || (long long)w * h >= (1LL << 31)) return false;
+    for (int sub = 0; sub < nsub; ++sub) {
+        const int r = rad[level0 + sub / 3];
+        if (r < 1 || r > 15) return false;
+    }
+    return true;
+}
+static int fs_strips(int h) { return (h + FS_R - 1) / FS_R; }
+static int fs_wpad(int w) { return ((w + 15 + FS_C - 1) / FS_C) * FS_C; }      // NB blocks of 64 columns (rad <= 15)
+size_t shrink_blur_scratch_floats(int w, int h, int nsub, int maxr)
+{
+    const int rows = 2 * (maxr > 7 ? 15 : 7) + 2;
+    // (nsub * nstrips + 1) hand-over slots of `rows` x wpad floats, then the progress counters and the ticket (ints)
+    return (size_t)(nsub * fs_strips(h) + 1) * rows * fs_wpad(w) + (size_t)nsub * fs_strips(h) + 64;
+}
+
+hipError_t launch_shrink_blur(FusedShrinkArgs a, float *scratch, hipStream_t s)
+{
+    int maxr = 0;
+    if (a.nsub_ch <= 0) a.nsub_ch = a.nsub - a.nL > 0 ? a.nsub - a.nL : 1;
+    const int nper = a.nL > a.nsub_ch ? a.nL : a.nsub_ch;
+    for (int sub = 0; sub < nper; ++sub) { const int r = a.rad[a.level0 + sub / 3]; maxr = r > maxr ? r : maxr; }
+    const int rows = 2 * (maxr > 7 ? 15 : 7) + 2;
+    a.nstrips = fs_strips(a.h);
+    a.wpad = fs_wpad(a.w);
+    a.hand = scratch;
+    a.progress = reinterpret_cast<int *>(scratch + (size_t)(a.nsub * a.nstrips + 1) * rows * a.wpad);
+    a.ticket = a.progress + a.nsub * a.nstrips;
+    hipError_t e = hipMemsetAsync(a.progress, 0, ((size_t)a.nsub * a.nstrips + 1) * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    return maxr > 7 ? launch_one<15>(a, s) : launch_one<7>(a, s);
+}
+
+} // namespace artgpu

@@ -280,3 +280,61 @@ def test_large_frame_lds_gamma_tables_same_bits_as_plain_kernels(gpu_ctx, monkey
     for g, p, r in zip(got, plain, ref):
         assert np.array_equal(g.view(np.uint32), p.view(np.uint32))
         assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h,kw", [
+    (640, 480, {}),                                         # band 320 x 240: 4 strips, 5 + 1 column blocks
+    (517, 389, {}),                                         # band 259 x 195: W % 4 != 0 (scalar-form columns), ragged last strip and block
+    (258, 130, {}),                                         # band 129 x 65: one row in the last strip, one column in the last block
+    (256, 256, {}),                                         # band 128 x 128: strips and blocks end exactly at the edge
+    (130, 900, {}),                                         # band 65 x 450: tall and narrow (8 strips, a column block of one)
+    (1400, 134, {}),                                        # band 700 x 67: wide and flat
+    (642, 482, dict(chrominance=90.0)),                     # six levels: radii up to 7
+    (512, 384, dict(aggressive=1)),                         # the L pass twice, BiShrink's top level on its own
+    (700, 500, dict(aggressive=1, chrominance=95.0)),       # radii above 7: the wide-window instantiation
+])
+def test_fused_shrink_pass_same_bits_as_three_kernels(gpu_ctx, w, h, kw):
+    """ShrinkAllL / ShrinkAllAB as one kernel (shrinkblur.hip: strips of 64 rows handing their column sums down) against the three-kernel
+    form (option "dn_fused" 0), with and without the side stream (which moves the L pass to a second band set), and against the oracle"""
+    img = _rgb(w, h, w + 3 * h)
+    outs = {}
+    try:
+        for fused in (1, 2, 0):                    # one launch for the three channels / one per channel / the three-kernel form
+            for streams in (1, 0):
+                gpu_ctx.set_option("dn_fused", fused)
+                gpu_ctx.set_option("dn_streams", streams)
+                got = [p.copy() for p in img]
+                gpu_ctx.rgb_denoise(capi.host_rgb(got), _params(**kw), O.REC2020_WS, flags=capi.DN_SKIP_DETAIL_RECOVERY if streams == 0 else 0)
+                outs[(fused, streams)] = got
+    finally:
+        gpu_ctx.set_option("dn_fused", 1)
+        gpu_ctx.set_option("dn_streams", 1)
+    for f in (1, 2):
+        assert _same(outs[(f, 0)], outs[(0, 0)]) == [0, 0, 0]
+        assert _same(outs[(f, 1)], outs[(0, 1)]) == [0, 0, 0]      # (with the DCT stage on: the same kernels on the same L plane)
+    okw = dict(luminance=40.0, chrominance=kw.get("chrominance", 15.0))
+    if not kw.get("aggressive"):
+        ref = O.rgb_denoise(img, O.default_denoise_params(**okw))
+        assert _same(outs[(1, 0)], ref) == [0, 0, 0]
+
+
+def test_fused_shrink_pass_repeats_on_one_context(gpu_ctx):
+    """the strips of a band wait for each other through counters in global memory: ten calls in a row, different sizes in between"""
+    img = _rgb(1000, 760, 5)
+    first = None
+    for k in range(10):
+        got = [p.copy() for p in img]
+        gpu_ctx.rgb_denoise(capi.host_rgb(got), _params(), O.REC2020_WS, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+        if first is None:
+            first = got
+        assert _same(got, first) == [0, 0, 0]
+        if k % 3 == 1:
+            small = _rgb(300 + 16 * k, 200, k)
+            gpu_ctx.rgb_denoise(capi.host_rgb(small), _params(), O.REC2020_WS, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    gpu_ctx.set_option("dn_fused", 0)
+    try:
+        got = [p.copy() for p in img]
+        gpu_ctx.rgb_denoise(capi.host_rgb(got), _params(), O.REC2020_WS, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    finally:
+        gpu_ctx.set_option("dn_fused", 1)
+    assert _same(got, first) == [0, 0, 0]
