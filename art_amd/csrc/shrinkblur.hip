@@ -28,7 +28,7 @@ namespace artgpu {
 
 namespace {
 
-constexpr int FS_R = 64, FS_C = 64, FS_T = 1024, FS_NE = FS_T / 64 - 2;   // 16 waves: one for the row sums, one for the column sums, 14 elementwise
+constexpr int FS_R = 64, FS_C = 64, FS_T = 1024, FS_NE = FS_T / 64 - 3;   // 16 waves: row sums, column sums, hand-over, 13 elementwise
 constexpr int FS_SWIN = 256, FS_SWS = FS_SWIN + 1;                          // factor window: 256 columns (circular), odd row stride
 
 // Barrier for data that travels through LDS only: __syncthreads() would also wait for this wave's global loads -- the coefficients of the
@@ -84,16 +84,19 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
 {
     constexpr int SROWS = FS_R + MAXR;             // window rows: up to rad rows above the strip + the strip
     constexpr int HROWS = FS_R + 2 * MAXR + 1;     // 2 rad + 1 rows handed down + the strip
+    constexpr int HBUF = (HROWS + 2) * (FS_C + 1);  // + the column sums entering the strip (row HROWS) and leaving it (row HROWS + 1)
     constexpr int HS = FS_C + 1;
     constexpr int NQ = (SROWS + FS_NE - 1) / FS_NE;   // window rows per elementwise wave
+    constexpr int NQB = FS_R / FS_NE;                 // passes whose window rows (< 64) every strip but the first and the last holds and writes
     constexpr int NOVMAX = 2 * MAXR + 1;
     extern __shared__ float fs_lds[];
     float *const S = fs_lds;                       // [SROWS][FS_SWS]: factor of window row wr (image row R0 - rad + wr), image column c at c & 255
     float *const HB0 = S + SROWS * FS_SWS;         // 3 x [HROWS][HS]
     __shared__ int s_ticket;
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // (wave-uniform, and known to be)
-    const int ew = wv - 2;                         // elementwise wave index
-    if (wv < 2) __builtin_amdgcn_s_setprio(3);     // the two serial roles go first on their SIMDs
+    const int ew = wv - 3;                         // elementwise wave index
+    const int rbase = ew, rstride = FS_NE;         // window rows rbase + rstride q
+    if (wv < 3) __builtin_amdgcn_s_setprio(3);     // the serial roles go first on their SIMDs
 #ifdef FS_PROFILE
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define FS_T0 const long long t0_ = __builtin_readcyclecounter();
@@ -135,6 +138,7 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
     }
     const int R0 = strip * FS_R, Rb = min(R0 + FS_R, H);
     const bool first = strip == 0, last = Rb == H;
+    const bool inner = !first && !last;            // window rows [0, 64 + rad) are image rows, rows [0, 64) of them are written
     const int rs0 = max(0, R0 - rad);              // first image row with a factor in the window
     const int ro0 = rs0, ro1 = last ? H : Rb - rad;    // rows this strip writes
     const int nov = 2 * rad + 1;
@@ -150,7 +154,7 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
         const int col = min(J * FS_C + lane, W - 1);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int r = min(max(R0 - rad + ew + FS_NE * q, 0), Rb - 1);
+            const int r = min(max(R0 - rad + rbase + rstride * q, 0), Rb - 1);
             const int i = r * W + col;
             pc[q] = coef[i];
             pl[q] = AB ? coefL[i] : 0.f;
@@ -161,7 +165,7 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
         const int col = min(max(J * FS_C - rad + lane, 0), W - 1);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int r = min(max(R0 - rad + ew + FS_NE * q, 0), H - 1);
+            const int r = min(max(R0 - rad + rbase + rstride * q, 0), H - 1);
             cu[q] = coef[r * W + col];
         }
     };
@@ -189,13 +193,13 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
         tvpre = ld_agent(hp + (2 * MAXR + 1) * FS_C);
         flagpre = __hip_atomic_load(prog + strip - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
-    if (wv == 1 && !first) prefetch_hand(0);
+    if (wv == 2 && !first) prefetch_hand(0);
 
     // ---- row-sum wave (lane = row of the strip)
     float tempval = 0.f, reclen = 0.f;
     int hlen = rad + 1;
 
-    for (int T = 0; T < NB + 3; ++T) {
+    for (int T = 0; T < NB + 4; ++T) {
 #ifdef FS_PROFILE
         const long long ts_ = __builtin_readcyclecounter();
 #endif
@@ -204,25 +208,35 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
             // ---- coefficient update of block J = T - 3 (FTblockDN.cc:698-714, 803-836), rows [ro0, ro1)
             if (T >= 3) {
                 const int J = T - 3;
-                const float *HBj = HB0 + (J % 3) * (HROWS * HS);
+                const float *HBj = HB0 + (J % 3) * HBUF;
                 const int col = J * FS_C - rad + lane;
                 const bool tailblk = last && J * FS_C - rad + FS_C > W - 4;
                 if (col >= 0 && col < W) {
                     if (!tailblk) {
+                        // rows of an inner strip's first NQF passes are all there: straight-line code the scheduler can interleave (behind a
+                        // row test every row is a dependent chain of its own, one after the other)
+                        auto upd = [&](int q) {
+                            const int wr = rbase + rstride * q;
+                            const float sfd = HBj[wr * HS + lane];
+                            const float sf = S[wr * FS_SWS + (col & (FS_SWIN - 1))];
+                            const float num = sqr(sfd) + sqr(sf), den = sfd + sf + eps;
+                            out[(R0 - rad + wr) * W + col] = cu[q] * num / den;
+                        };
+                        if (inner) {
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            const int wr = ew + FS_NE * q, r = R0 - rad + wr;
-                            if (r >= ro0 && r < ro1) {
-                                const float sfd = HBj[wr * HS + lane];
-                                const float sf = S[wr * FS_SWS + (col & (FS_SWIN - 1))];
-                                const float num = sqr(sfd) + sqr(sf), den = sfd + sf + eps;
-                                out[r * W + col] = cu[q] * num / den;
+                            for (int q = 0; q < NQB; ++q) upd(q);
+                        }
+                        {
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) {
+                                const int r = R0 - rad + rbase + rstride * q;
+                                if ((!inner || q >= NQB) && r >= ro0 && r < ro1) upd(q);
                             }
                         }
                     } else {
 #pragma unroll 1
                         for (int q = 0; q < NQ; ++q) {
-                            const int wr = ew + FS_NE * q, r = R0 - rad + wr;
+                            const int wr = rbase + rstride * q, r = R0 - rad + wr;
                             if (r >= ro0 && r < ro1) {
                                 const float sfd = HBj[wr * HS + lane];
                                 const float sf = S[wr * FS_SWS + (col & (FS_SWIN - 1))], c = cu[q];
@@ -243,18 +257,25 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
                 auto factors = [&](auto abtag) {                     // (one instantiation per kind of band: no per-row branch on the kind)
                     constexpr bool ABc = decltype(abtag)::value;
                     if (!tailblk) {
+                        auto fac = [&](int q) {
+                            const float sf = shrink_factor<ABc, false>(kc, pc[q], pl[q], pn[q], true);
+                            if (col < W) S[(rbase + rstride * q) * FS_SWS + (col & (FS_SWIN - 1))] = sf;
+                        };
+                        if (inner) {
 #pragma unroll
-                        for (int q = 0; q < NQ; ++q) {
-                            const int wr = ew + FS_NE * q, r = R0 - rad + wr;
-                            if (r >= 0 && r < Rb) {                      // (uniform: whole rows)
-                                const float sf = shrink_factor<ABc, false>(kc, pc[q], pl[q], pn[q], true);
-                                if (col < W) S[wr * FS_SWS + (col & (FS_SWIN - 1))] = sf;
+                            for (int q = 0; q < NQB; ++q) fac(q);
+                        }
+                        {
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) {
+                                const int r = R0 - rad + rbase + rstride * q;
+                                if ((!inner || q >= NQB) && r >= 0 && r < Rb) fac(q);     // (uniform: whole rows)
                             }
                         }
                     } else {
 #pragma unroll 1
                         for (int q = 0; q < NQ; ++q) {
-                            const int wr = ew + FS_NE * q, r = R0 - rad + wr;
+                            const int wr = rbase + rstride * q, r = R0 - rad + wr;
                             if (r >= 0 && r < Rb && col < W)
                                 S[wr * FS_SWS + (col & (FS_SWIN - 1))] = shrink_factor<ABc, true>(kc, pc[q], pl[q], pn[q], r * W + col < nv4);
                         }
@@ -271,7 +292,7 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
                 const int J = T - 1, X0 = J * FS_C;
                 const float *srow = S + (rad + lane) * FS_SWS;
                 auto s = [&](int k) -> float { return srow[(X0 + k) & (FS_SWIN - 1)]; };     // factor at column X0 + k
-                float *hb = HB0 + (J % 3) * (HROWS * HS) + (nov + lane) * HS;
+                float *hb = HB0 + (J % 3) * HBUF + (nov + lane) * HS;
                 int jj = 0;
                 if (J == 0) jj = rad;                                  // columns < 0 do not exist
                 while (jj < FS_C) {
@@ -305,39 +326,16 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
                 }
                 FS_T1(1)
             }
-        } else {
-            // ---- column sums of block J = T - 2 and the hand-over.  Everything that crosses to another workgroup goes through THIS wave:
-            //      its write-through (sc1) stores are the only stores it has in flight, so waiting for them a step later costs nothing and
-            //      neither holds up the coefficient traffic of the other waves nor needs a release fence (which would write back the XCD's
-            //      whole dirty L2, full of this kernel's coefficient stores); the strip below reads with sc1 loads and needs no acquire.
-            FS_T0
-            float tv_in = 0.f;
+        } else if (wv == 1) {
+            // ---- column sums of block J = T - 2 over rows [ro0, ro1) (boxblur.h:602-742, vblur_combine_kernel); the value of row r replaces
+            //      the row-blurred value of row r - rad - 1, which that step was the last to need
             const int J = T - 2;
-            float *HBj = HB0 + ((J + 3) % 3) * (HROWS * HS);
-            const bool work = J >= 0 && J < NB;
-            if (work && !first) {
-#pragma unroll
-                for (int k = 0; k < NOVMAX; ++k)
-                    if (k < nov) HBj[k * HS + lane] = hpre[k];
-                tv_in = tvpre;
-            }
-            if (!last && T >= 3) {                                     // block T - 3 has left: the strip below may have it
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(prog + strip, T - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (!first && T >= 1 && T - 1 < NB) prefetch_hand(T - 1);
-            if (work) {
+            if (J >= 0 && J < NB) {
+                FS_T0
+                float *HBj = HB0 + (J % 3) * HBUF;
                 const int X0 = J * FS_C;
-                if (!last) {                                           // the strip's last 2 rad + 1 row-blurred rows
-                    float *hp = hand_nx + (size_t)J * (2 * MAXR + 2) * FS_C + lane;
-#pragma unroll
-                    for (int k = 0; k < NOVMAX; ++k)
-                        if (k < nov) st_agent(hp + k * FS_C, HBj[(FS_R + k) * HS + lane]);
-                }
-                // column sums over rows [ro0, ro1) (boxblur.h:602-742, vblur_combine_kernel); the value of row r replaces the row-blurred
-                // value of row r - rad - 1, which that step was the last to need
                 const int col = X0 - rad + lane;
-                float tv = tv_in;
+                float tv = first ? 0.f : HBj[HROWS * HS + lane];
                 if (col >= 0 && col < W) {
                     const bool vec = col < (W / 4) * 4;
                     const bool allvec = X0 - rad + FS_C <= (W / 4) * 4;
@@ -392,10 +390,42 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
                         ++r;
                     }
                 }
-                // (every lane stores: the strip below reads all 64 slots of the block)
-                if (!last) st_agent(hand_nx + (size_t)J * (2 * MAXR + 2) * FS_C + (2 * MAXR + 1) * FS_C + lane, tv);
+                HBj[(HROWS + 1) * HS + lane] = tv;                        // leaves the strip through the hand-over wave
+                FS_T1(2)
             }
-            FS_T1(2)
+        } else {
+            // ---- the hand-over.  Everything that crosses to another workgroup goes through THIS wave: its write-through (sc1) stores are
+            //      the only stores it has in flight, so waiting for them a step later costs nothing and neither holds up the coefficient
+            //      traffic of the other waves nor needs a release fence (which would write back the XCD's whole dirty L2, full of this
+            //      kernel's coefficient stores); the strip below reads with sc1 loads and needs no acquire.
+            //      step T: what the strip above left for block T - 1 (sent for a step ago) goes to that block's buffer, where the row sums
+            //      of the block are being written; block T - 4 -- its stores have left -- is published; block T is sent for; block T - 2's
+            //      last row-blurred rows and block T - 3's column sums go to the strip below.
+            FS_T0
+            if (!first && T >= 1 && T - 1 < NB) {
+                float *HBj = HB0 + ((T - 1) % 3) * HBUF;
+#pragma unroll
+                for (int k = 0; k < NOVMAX; ++k)
+                    if (k < nov) HBj[k * HS + lane] = hpre[k];
+                HBj[HROWS * HS + lane] = tvpre;
+            }
+            if (!last && T >= 4) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(prog + strip, T - 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (!first && T < NB) prefetch_hand(T);
+            if (!last) {
+                if (T >= 2 && T - 2 < NB) {
+                    const float *HBj = HB0 + ((T - 2) % 3) * HBUF;
+                    float *hp = hand_nx + (size_t)(T - 2) * (2 * MAXR + 2) * FS_C + lane;
+#pragma unroll
+                    for (int k = 0; k < NOVMAX; ++k)
+                        if (k < nov) st_agent(hp + k * FS_C, HBj[(FS_R + k) * HS + lane]);
+                }
+                if (T >= 3 && T - 3 < NB)      // (every lane stores: the strip below reads all 64 slots of the block)
+                    st_agent(hand_nx + (size_t)(T - 3) * (2 * MAXR + 2) * FS_C + (2 * MAXR + 1) * FS_C + lane, HB0[((T - 3) % 3) * HBUF + (HROWS + 1) * HS + lane]);
+            }
+            FS_T1(4)
         }
         lds_barrier();
 #ifdef FS_PROFILE
@@ -407,9 +437,9 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
     if (a.prof) {
         unsigned long long *pp = reinterpret_cast<unsigned long long *>(a.prof);
         if (tid == 0) { atomicAdd(pp + 0, (unsigned long long)pt[0]); atomicAdd(pp + 1, (unsigned long long)pt[1]); }
-        if (tid == 64) { atomicAdd(pp + 2, (unsigned long long)pt[2]); atomicAdd(pp + 6, (unsigned long long)pt[6]); atomicAdd(pp + 7, (unsigned long long)pt[7]); }
-        if (tid == 128) atomicAdd(pp + 3, (unsigned long long)pt[3]);
-        if (lane == 0) atomicAdd(pp + 8 + wv, (unsigned long long)(pt[1] + pt[2] + pt[3]));      // busy time per wave
+        if (tid == 64) atomicAdd(pp + 2, (unsigned long long)pt[2]);
+        if (tid == 128) { atomicAdd(pp + 4, (unsigned long long)pt[4]); atomicAdd(pp + 6, (unsigned long long)pt[6]); atomicAdd(pp + 7, (unsigned long long)pt[7]); }
+        if (lane == 0) atomicAdd(pp + 8 + wv, (unsigned long long)(pt[1] + pt[2] + pt[3] + pt[4]));      // busy time per wave
     }
 #endif
 }
@@ -418,7 +448,7 @@ template <int MAXR>
 hipError_t launch_one(const FusedShrinkArgs &a, hipStream_t s)
 {
     constexpr int SROWS = FS_R + MAXR, HROWS = FS_R + 2 * MAXR + 1, HS = FS_C + 1;
-    constexpr int lds = (SROWS * FS_SWS + 3 * HROWS * HS) * (int)sizeof(float);
+    constexpr int lds = (SROWS * FS_SWS + 3 * (HROWS + 2) * HS) * (int)sizeof(float);
     static_assert(lds <= 160 * 1024 - 64, "LDS");
     hipError_t e = dyn_lds_once(reinterpret_cast<const void *>(shrink_blur_kernel<MAXR>), lds);
     if (e != hipSuccess) return e;

@@ -42,9 +42,9 @@ int main(int argc, char **argv)
         long long p[32]; CK(hipMemcpy(p, prof, 256, hipMemcpyDeviceToHost));
         printf("%s %dx%d x%d: %.3f ms  (%.2f TB/s)", ab == 0 ? "L" : ab == 1 ? "AB" : "L+a+b", W, H, NSUB, ms, n * (NL * 8.0 + NC * 16.0) / ms / 1e9);
         if (p[0] > 0) {
-            printf("  busy %% of the step: rows %.0f cols %.0f (waiting for the strip above %.0f, %lld polls) | elementwise waves:", 100.0 * p[1] / p[0],
-                   100.0 * (p[2] - p[6]) / p[0], 100.0 * p[6] / p[0], p[7]);
-            for (int w = 2; w < 16; ++w) printf(" %.0f", 100.0 * p[8 + w] / p[0]);
+            printf("  busy %% of the step: rows %.0f cols %.0f hand-over %.0f (+ waiting for the strip above %.0f, %lld polls) | elementwise waves:", 100.0 * p[1] / p[0],
+                   100.0 * p[2] / p[0], 100.0 * (p[4] - p[6]) / p[0], 100.0 * p[6] / p[0], p[7]);
+            for (int w = 3; w < 16; ++w) printf(" %.0f", 100.0 * p[8 + w] / p[0]);
         }
         printf("\n");
     }
