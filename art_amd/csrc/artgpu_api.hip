@@ -1186,6 +1186,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     // it takes the bands of all channels to keep every CU busy, and one launch instead of three has one ragged end instead of three
     const bool merged = fused && ctx->opt_dn_fused != 2 && !aggressive && !nresi && !highresi && denoiseLuminance && levwav <= 5 &&
                         (autoch || (noisevarab_r > 0.001f && noisevarab_b > 0.001f));
+    const bool merged_mad = merged && ctx->opt_dn_fused != 3;      // (3: test switch, MadRgb per channel)
     const bool two_chroma = fork || merged;        // a and b keep their own decomposition (otherwise b reuses a's)
     float *fused_scratch = nullptr, *Lbands2 = nullptr;
     const size_t histo_bytes = (size_t)nsub * (65536 + MAD_SCRATCH_INTS_PER_BAND) * 4, band_bytes = (size_t)nsub * n2 * 4;
@@ -1206,7 +1207,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         if (merged) Cdd[1].bands = Cdd[0].bands + (size_t)nsub * n2;       // (one launch walks both channels' bands: back to back)
         else if ((rc = pool_get(ctx, P_CBANDS2, band_bytes, &Cdd[1].bands))) return rc;
         if ((rc = pool_get(ctx, P_CLOW0_2, n2 * 4, &Cdd[1].low[0])) || (rc = pool_get(ctx, P_CLOW1_2, n2 * 4, &Cdd[1].low[1])) ||
-            (rc = pool_get(ctx, P_HISTO_A, histo_bytes, &histo_fc[1])) || (rc = pool_get(ctx, P_HISTO_B, histo_bytes, &histo_fc[2])))
+            (rc = pool_get(ctx, P_HISTO_A, (merged ? 2 : 1) * histo_bytes, &histo_fc[1])) || (rc = pool_get(ctx, P_HISTO_B, histo_bytes, &histo_fc[2])))
             return rc;
         if (!fused && ((rc = pool_get(ctx, P_SF_A, band_bytes, &sfc[1])) || (rc = pool_get(ctx, P_SF_B, band_bytes, &sfc[2])))) return rc;
     } else {
@@ -1320,8 +1321,8 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
                 HIPCHK(ctx, launch_bishrink_AB(sa, nsub - 3, sL));
             }
         }
-        if (noisevar_ab > 0.001f) {
-            HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, madab, sL));
+        if (noisevar_ab > 0.001f && !merged_mad) {
+            HIPCHK(ctx, launch_mad(Cd.bands, n2, nsub, histo, ch == 1 && merged ? mad + 32 + nsub : madab, sL));
             if (!fused) {
                 ShrinkArgs sa = {};
                 sa.coef = Cd.bands; sa.coefL = Ld.bands; sa.sfave = sf; sa.n = n2; sa.madL = madL; sa.madab = madab;
@@ -1479,7 +1480,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     auto merged_pass = [&]() -> int {
         FusedShrinkArgs fa = {};
         fa.coef = Ld.bands; fa.coef_out = Lbands2; fa.coefC = Cdd[0].bands; fa.coefL = Ld.bands; fa.n = n2; fa.w = w2; fa.h = h2;
-        fa.madL = madL; fa.madab = mad + 32; fa.mad_ch_stride = 32;
+        fa.madL = madL; fa.madab = mad + 32; fa.mad_ch_stride = nsub;
         fa.noisevar = ccalc_dev; fa.noisevar_const = noisevarL; fa.noisevar_scale = maxNoiseVarab;
         fa.noisevar_ab[0] = noisevar_abc[0]; fa.noisevar_ab[1] = noisevar_abc[1];
         fa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
@@ -1491,7 +1492,10 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     if (merged) {
         // decompositions and MADs of a and b, the three channels' ShrinkAll passes as one launch, then the reconstructions -- L first, so that
         // its DCT detail recovery (side stream) runs beside those of a and b
-        if ((rc = chroma_front(0)) || (rc = chroma_front(1)) || (rc = merged_pass())) return rc;
+        if ((rc = chroma_front(0)) || (rc = chroma_front(1))) return rc;
+        // MadRgb of both chroma channels' bands as one launch set (the bands are back to back; the medians land at mad + 32 + band)
+        if (merged_mad) HIPCHK(ctx, launch_mad(Cdd[0].bands, n2, 2 * nsub, reinterpret_cast<int *>(histo_fc[1]), mad + 32, sL));
+        if ((rc = merged_pass())) return rc;
         SideStreamJoin dn_join;
         if (fork) dn_join.arm(ctx->dn_stream[0]);
         if ((rc = luma(fork ? ctx->dn_stream[0] : sL))) return rc;

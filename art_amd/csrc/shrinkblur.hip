@@ -179,8 +179,13 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
         seen = max(seen, flagpre);
         if (seen < J + 1) {
             FS_T0
-            int v;
-            while ((v = __hip_atomic_load(prog + strip - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < J + 1) __builtin_amdgcn_s_sleep(2);
+            int v, spins = 0;
+            while ((v = __hip_atomic_load(prog + strip - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < J + 1) {
+                __builtin_amdgcn_s_sleep(2);
+                // the strip above belongs to a ticket taken before this one, i.e. to a running workgroup: the wait is bounded by that strip's
+                // progress.  Should that ever not hold (seconds without the counter moving), fail loudly instead of hanging the device.
+                if (++spins > (1 << 23)) __builtin_trap();
+            }
             seen = v;
             FS_T1(6)
 #ifdef FS_PROFILE
