@@ -12,6 +12,7 @@ KERNEL_SOURCES = {
     "rcd_stream_kernel": ["rcd_stream.hip", "rcd_stream_core.h"],
     "xtrans_tiles_kernel": ["xtrans.hip"],
     "nlm_group_kernel": ["nlm_sweep.hip"],
+    "shrink_blur_kernel": ["shrinkblur.hip"],
 }
 
 

@@ -355,7 +355,7 @@ def main() -> None:
     # profiles/ (KB units; uncorrected -- the kernel's accesses are 4 B per lane, see profiles/r1/README.md)
     traffic, traffic_src, traffic_raw, issue = None, None, None, None
     kname = "xtrans_tiles_kernel" if xtrans else "amaze_stream_kernel" if method == capi.BAYER_AMAZE else "rcd_stream_kernel"
-    pmc_rel = os.path.join("profiles", "r3", {"amaze_stream_kernel": "amaze_stream_pmc_summary.json", "rcd_stream_kernel": "rcd_stream_pmc_summary.json",
+    pmc_rel = os.path.join("profiles", "r4", {"amaze_stream_kernel": "amaze_stream_pmc_summary.json", "rcd_stream_kernel": "rcd_stream_pmc_summary.json",
                                               "xtrans_tiles_kernel": "xtrans_tiles_pmc_summary.json"}[kname])
     pmc_path = os.path.join(ROOT, pmc_rel)
     traffic_stale = None

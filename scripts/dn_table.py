@@ -6,7 +6,7 @@ pmc = json.load(open(sys.argv[2]))
 frames = float(sys.argv[3])
 rows = []
 for r in stats:
-    k = re.sub(r"\(.*", "", r["Name"]).replace("artgpu::", "").replace("void ", "").replace("(anonymous namespace)::", "")
+    k = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", "")).replace("artgpu::", "").replace("void ", "").replace("(anonymous namespace)::", "")
     if k.startswith("at::") or "elementwise" in k:
         continue
     calls, tot = int(r["Calls"]), float(r["TotalDurationNs"])

@@ -7,7 +7,7 @@ per = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))       # kerne
 for d in sys.argv[2:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            k = re.sub(r"\(.*", "", row.get("Kernel_Name", "")).replace("artgpu::", "").replace("void ", "")
+            k = re.sub(r"\(.*", "", row.get("Kernel_Name", "").replace("(anonymous namespace)::", "")).replace("artgpu::", "").replace("void ", "")
             per[k][row["Counter_Name"]][(f, row.get("Dispatch_Id", ""))] += float(row["Counter_Value"])
 res = {k: {c: {"launches": len(v), "mean_per_launch": sum(v.values()) / len(v)} for c, v in cs.items()} for k, cs in per.items()}
 json.dump(res, open(out, "w"), indent=1)
