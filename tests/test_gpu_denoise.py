@@ -338,3 +338,50 @@ def test_fused_shrink_pass_repeats_on_one_context(gpu_ctx):
     finally:
         gpu_ctx.set_option("dn_fused", 1)
     assert _same(got, first) == [0, 0, 0]
+
+
+def test_fused_shrink_pass_under_uneven_load():
+    """The strips of a band hand their column sums to each other through global memory while the workgroups that hold them come and go:
+    three contexts on three host threads run RGB_denoise on frames of different sizes at the same time, ten rounds each, and every result
+    has to be the bits of the same call on an idle device (a stale or torn hand-over shows as a difference in some strip)."""
+    import threading
+    sizes = [(2600, 1900), (1800, 2500), (3100, 1300)]
+    imgs = [_rgb(w, h, 7 + k, noise=1500 + 700 * k) for k, (w, h) in enumerate(sizes)]
+    alone = []
+    ctxs = [capi.Context(0) for _ in sizes]
+    try:
+        for ctx, img in zip(ctxs, imgs):
+            got = [p.copy() for p in img]
+            ctx.rgb_denoise(capi.host_rgb(got), _params(), O.REC2020_WS, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+            alone.append(got)
+        bad, errs = [], []
+
+        def worker(k):
+            try:
+                for it in range(10):
+                    got = [p.copy() for p in imgs[k]]
+                    ctxs[k].rgb_denoise(capi.host_rgb(got), _params(), O.REC2020_WS, flags=0 if it % 2 else capi.DN_SKIP_DETAIL_RECOVERY)
+                    if it % 2 == 0 and _same(got, alone[k]) != [0, 0, 0]:
+                        bad.append((k, it, _same(got, alone[k])))
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(len(sizes))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        assert not bad, bad
+    finally:
+        for c in ctxs:
+            c.close()
+    # and the idle-device result is the three-kernel form's
+    ctx = capi.Context(0)
+    try:
+        ctx.set_option("dn_fused", 0)
+        got = [p.copy() for p in imgs[0]]
+        ctx.rgb_denoise(capi.host_rgb(got), _params(), O.REC2020_WS, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+        assert _same(got, alone[0]) == [0, 0, 0]
+    finally:
+        ctx.close()
