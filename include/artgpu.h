@@ -494,7 +494,9 @@ int artgpu_set_batch_lanes(artgpu_ctx *ctx, int lanes);
 #define ARTGPU_BATCH_RECORD_WORDS 8
 int artgpu_batch_complete(artgpu_ctx *ctx, void *rccl_comm, int nranks, const int64_t record[ARTGPU_BATCH_RECORD_WORDS], int64_t *all_records);
 
-/* Bytes of device scratch the context currently holds (arena + staging). */
+/* Bytes of device scratch the context currently holds (arena + staging + the denoise pool: for a 45 MP frame through
+ * artgpu_improc_denoise about 5.5 GB -- two L band sets, the chroma band sets of both channels, the DCT block buffer, the hand-over slots of
+ * the fused shrink pass -- per context and per batch lane; grown on demand, kept between frames). */
 size_t artgpu_scratch_bytes(const artgpu_ctx *ctx);
 
 #ifdef __cplusplus
