@@ -65,6 +65,11 @@ class DenoiseToolParams(C.Structure):
                 ("nl_strength", C.c_int32), ("nl_detail", C.c_int32)]
 
 
+class DenoiseFusion(C.Structure):
+    _fields_ = [("demosaiced", C.POINTER(RGB)), ("sx1", C.c_int32), ("sy1", C.c_int32), ("mul", C.c_float * 3), ("do_clip", C.c_int32),
+                ("cam_to_work", C.POINTER(C.c_double)), ("exposure_enabled", C.c_int32), ("exp_scale", C.c_float), ("black", C.c_float)]
+
+
 PipelineParams._fields_ = [
     ("sensor", C.c_int32), ("bayer_method", C.c_int32), ("filters", C.c_uint32), ("initial_gain", C.c_double),
     ("xtrans_passes", C.c_int32), ("xtrans", C.c_int32 * 36), ("rgb_cam", C.c_float * 12), ("border", C.c_int32),
@@ -142,6 +147,8 @@ def _load():
     lib.artgpu_nlmeans.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_float, C.c_int, C.c_int, C.c_float]
     lib.artgpu_improc_denoise.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseToolParams), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
                                           C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_uint32]
+    lib.artgpu_improc_denoise_fused.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(DenoiseFusion), C.POINTER(DenoiseToolParams), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_uint32]
     lib.artgpu_scale_colors.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_uint32,
                                         C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(Plane), C.POINTER(C.c_float)]
     lib.artgpu_denoise_compute_params.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_double),
@@ -189,7 +196,7 @@ EXPORTS = ["artgpu_set_progress_callback", "artgpu_set_option", "artgpu_get_opti
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_mad", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_batch_complete", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter", "artgpu_hsl_equalizer", "artgpu_log_encoding", "artgpu_rgb_to_lab", "artgpu_lab_to_rgb", "artgpu_lab_histogram", "artgpu_lab_adjustments", "artgpu_dual_demosaic_bayer"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_improc_denoise_fused", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_batch_complete", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter", "artgpu_hsl_equalizer", "artgpu_log_encoding", "artgpu_rgb_to_lab", "artgpu_lab_to_rgb", "artgpu_lab_histogram", "artgpu_lab_adjustments", "artgpu_dual_demosaic_bayer"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
@@ -465,6 +472,36 @@ class Context:
             cv = cva.ctypes.data_as(C.POINTER(C.c_float))
         iwsd = None if iws is None else (C.c_double * 9)(*[float(v) for v in np.asarray(iws, dtype=np.float64).reshape(9)])
         self._chk(LIB.artgpu_improc_denoise(self._h, C.byref(image), C.byref(params), wsd, iwsd, ecomp, scale, m, cv, flags))
+
+    def improc_denoise_fused(self, image: RGB, params: DenoiseToolParams, ws, demosaiced: RGB = None, sx1: int = 0, sy1: int = 0, mul=(1.0, 1.0, 1.0),
+                             do_clip: bool = True, cam_to_work=None, exposure=None, ecomp: float = 0.0, scale: float = 1.0, calclum_mat=None,
+                             noise_c_curve=None, flags: int = 0, iws=None):
+        """artgpu_improc_denoise_fused: getImage + convertColorSpace in front (demosaiced != None) and ImProcFunctions::exposure behind
+        (exposure = (exp_scale, black)) inside the tool's own pixel passes"""
+        fu = DenoiseFusion()
+        keep = []
+        if demosaiced is not None:
+            keep.append(demosaiced)
+            fu.demosaiced = C.pointer(demosaiced)
+            fu.sx1, fu.sy1 = int(sx1), int(sy1)
+            fu.mul[:] = [float(v) for v in mul]
+            fu.do_clip = 1 if do_clip else 0
+            if cam_to_work is not None:
+                cm = (C.c_double * 9)(*[float(v) for v in np.asarray(cam_to_work, dtype=np.float64).reshape(9)])
+                keep.append(cm)
+                fu.cam_to_work = C.cast(cm, C.POINTER(C.c_double))
+        if exposure is not None:
+            fu.exposure_enabled = 1
+            fu.exp_scale, fu.black = float(exposure[0]), float(exposure[1])
+        wsd = (C.c_double * 9)(*[float(v) for v in np.asarray(ws, dtype=np.float64).reshape(9)])
+        m = None if calclum_mat is None else (C.c_double * 9)(*[float(v) for v in np.asarray(calclum_mat, dtype=np.float64).reshape(9)])
+        cv = None
+        if noise_c_curve is not None:
+            cva = np.ascontiguousarray(noise_c_curve, dtype=np.float32)
+            assert cva.shape == (501,)
+            cv = cva.ctypes.data_as(C.POINTER(C.c_float))
+        iwsd = None if iws is None else (C.c_double * 9)(*[float(v) for v in np.asarray(iws, dtype=np.float64).reshape(9)])
+        self._chk(LIB.artgpu_improc_denoise_fused(self._h, C.byref(image), C.byref(fu), C.byref(params), wsd, iwsd, C.c_double(ecomp), C.c_double(scale), m, cv, flags))
 
     # ---- wavelet_decomposition ----
     def wavelet_decompose(self, src: Plane, maxlvl: int):

@@ -47,6 +47,9 @@ struct artgpu_ctx {
     int batch_lanes = 1;
     bool owns_stream = false;
     float fuse_pre = 0.f, fuse_post = 0.f;   // improc_denoise -> rgb_denoise: exposure compensation fused into rgb2yuv / yuv2rgb
+    GetImageFuse fuse_gi = {};               // improc_denoise_fused -> chroma map, rgb2yuv: getImage + matrix read from the demosaiced planes
+    float fuse_exp_scale = 0.f, fuse_exp_black = 0.f;   // improc_denoise_fused -> yuv2rgb: ImProcFunctions::exposure behind the last pass
+    int fuse_exp_on = 0;
     float *bbox = nullptr; // AMaZE: per-tile nyquist bounding boxes
     size_t bbox_bytes = 0;
     // AMaZE v2: tile lists on the device (ints).  [stream tiles | arena-tile template: count, tiles | working copy: count, tiles + room
@@ -1240,6 +1243,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     px.gam = gam; px.gamthresh = gamthresh; px.gamslope = gamslope; px.igam = igam; px.igamthresh = igamthresh; px.igamslope = igamslope;
     px.gamcurve = gamlut; px.igamcurve = gamlut + 65536;
     px.pre_scale = ctx->fuse_pre; px.post_scale = ctx->fuse_post; px.no_lds_lut = !ctx->opt_lut_lds;
+    px.gi = ctx->fuse_gi; px.exp_on = ctx->fuse_exp_on; px.exp_scale = ctx->fuse_exp_scale; px.exp_black = ctx->fuse_exp_black;
     // the inverse-gamma pass looks up gamma-encoded values: the mid-tones sit in the middle of the table, so the 40704 entries kept in LDS
     // start at 8000 (gamma 1.7: linear 0.03 .. 0.60 of white); the forward pass and the tone curve index with linear data and keep [0, 40704)
     px.igam_lds_lo = 8000;
@@ -2259,6 +2263,7 @@ static int chroma_map_dev(artgpu_ctx *ctx, float *const planes[3], size_t stride
         }
     }
     ChromaMapArgs a = {};
+    a.gi = ctx->fuse_gi;
     for (int k = 0; k < 3; ++k) a.src[k] = planes[k];
     a.stride = stride; a.wid = wid; a.hei = hei;
     a.has_mat = mat ? 1 : 0;
@@ -2433,9 +2438,57 @@ int artgpu_denoise_chroma_map(artgpu_ctx *ctx, const artgpu_rgb *img, const doub
 int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_tool_params *p, const double ws[9], const double *iws,
                           double ecomp, double scale, const double *calclum_mat, const float *noise_c_curve, uint32_t flags)
 {
+    return artgpu_improc_denoise_fused(ctx, img, nullptr, p, ws, iws, ecomp, scale, calclum_mat, noise_c_curve, flags);
+}
+
+int artgpu_improc_denoise_fused(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_fusion *fu, const artgpu_denoise_tool_params *p,
+                                const double ws[9], const double *iws, double ecomp, double scale, const double *calclum_mat,
+                                const float *noise_c_curve, uint32_t flags)
+{
     StageScope scope_(ctx, "ImProcFunctions::denoise");
     if (!ctx) return ARTGPU_EINVAL;
     if (!img || !p || !ws) return fail(ctx, ARTGPU_EINVAL, "improc_denoise: null argument");
+    // what of the neighbouring stages can really live inside the tool's pixel passes: the wavelet denoise has to run (its first pass reads the
+    // image, its last one writes it), on device planes; the exposure only when nothing stands between RGB_denoise and it
+    bool use_curve0 = false;
+    if (noise_c_curve) {
+        float sum = 0.f;
+        for (int i = 0; i < 501; ++i) sum += noise_c_curve[i];
+        use_curve0 = sum > 5.f;                                        // (as below: NoiseCurve::getSum, FTblockDN.cc:1672)
+    }
+    const bool dn_runs0 = !(p->dn.luminance == 0 && p->dn.chrominance == 0 && !use_curve0);
+    const bool dev_planes = img->r.on_device && (!fu || !fu->demosaiced || (fu->demosaiced->r.on_device && fu->demosaiced->g.on_device && fu->demosaiced->b.on_device));
+    bool fuse_gi = fu && fu->demosaiced && dn_runs0 && dev_planes;
+    const bool fuse_exp = fu && fu->exposure_enabled && dn_runs0 && dev_planes && !p->smoothing_enabled;
+    if (fu && fu->demosaiced) {
+        const artgpu_rgb *dm = fu->demosaiced;
+        if (!plane_ok(&dm->r) || !plane_ok(&dm->g) || !plane_ok(&dm->b) || dm->g.row_stride_bytes != dm->r.row_stride_bytes || dm->b.row_stride_bytes != dm->r.row_stride_bytes ||
+            fu->sx1 < 0 || fu->sy1 < 0 || fu->sx1 + img->r.w > dm->r.w || fu->sy1 + img->r.h > dm->r.h)
+            return fail(ctx, ARTGPU_EINVAL, "improc_denoise_fused: crop %dx%d+%d+%d outside the demosaiced planes", img->r.w, img->r.h, fu->sx1, fu->sy1);
+        if (!fuse_gi) {     // the separate call it stands for
+            int rc0 = artgpu_get_image(ctx, dm, fu->sx1, fu->sy1, fu->mul, fu->do_clip, fu->cam_to_work, img);
+            if (rc0) return rc0;
+        }
+    }
+    if (fu && (fu->demosaiced || fu->exposure_enabled)) {
+        // one level down with what is left to fuse; the exposure that could not be fused follows as its own call
+        struct Restore { artgpu_ctx *c; ~Restore() { c->fuse_gi.on = 0; c->fuse_exp_on = 0; } } restore{ctx};
+        if (fuse_gi) {
+            GetImageFuse &g = ctx->fuse_gi;
+            g.on = 1;
+            g.src[0] = fu->demosaiced->r.p; g.src[1] = fu->demosaiced->g.p; g.src[2] = fu->demosaiced->b.p;
+            g.stride = (size_t)(fu->demosaiced->r.row_stride_bytes / 4);
+            g.sx1 = fu->sx1; g.sy1 = fu->sy1;
+            for (int k = 0; k < 3; ++k) g.mul[k] = fu->mul[k];
+            g.do_clip = fu->do_clip ? 1 : 0; g.has_mat = fu->cam_to_work ? 1 : 0;
+            for (int k = 0; k < 9; ++k) g.mat[k] = fu->cam_to_work ? fu->cam_to_work[k] : 0.0;
+        }
+        if (fuse_exp) { ctx->fuse_exp_on = 1; ctx->fuse_exp_scale = fu->exp_scale; ctx->fuse_exp_black = fu->black; }
+        int rc0 = artgpu_improc_denoise_fused(ctx, img, nullptr, p, ws, iws, ecomp, scale, calclum_mat, noise_c_curve, flags);
+        if (rc0) return rc0;
+        if (fu->exposure_enabled && !fuse_exp) return artgpu_exposure(ctx, img, fu->exp_scale, fu->black);
+        return ARTGPU_OK;
+    }
     if (!img->r.on_device) {
         // host planes: stage once, run the whole tool on the staged copy, copy back
         DevRGB d;
@@ -2746,18 +2799,27 @@ int artgpu_pipeline_run(artgpu_ctx *ctx, const artgpu_plane *raw, const artgpu_p
                                                 p->chrominance_auto_factor != 0.0 ? p->chrominance_auto_factor : 1.0, &store, &dnp.dn)))
             return rc;
     }
-    if ((rc = artgpu_get_image(ctx, &dem, b, b, p->mul, p->do_clip, p->has_cam_to_work ? p->cam_to_work : nullptr, &img))) return rc;
     if (p->denoise_enabled) {
+        // getImage + convertColorSpace in front of the tool and the STAGE_1 exposure behind it live in the tool's own pixel passes where
+        // its parameters allow (artgpu_improc_denoise_fused: otherwise they run as the separate calls)
         static const double curve_points[9] = {1 /*FCT_MinMaxCPoints*/, 0.05, 0.50, 0.35, 0.35, 0.35, 0.05, 0.35, 0.35};   // ipdenoise.cc:1139-1149
         float curve[501];
         (void)noise_curve_lut(curve_points, 9, curve);
         const double ecomp = p->exposure_enabled ? p->expcomp : 0.0;       // ipdenoise.cc:1155
-        if ((rc = artgpu_improc_denoise(ctx, &img, &dnp, p->ws, p->iws, ecomp, p->scale > 0 ? p->scale : 1.0,
-                                        p->has_cam_to_work ? p->cam_to_work : nullptr, curve, 0u)))
+        artgpu_denoise_fusion fu = {};
+        fu.demosaiced = &dem; fu.sx1 = b; fu.sy1 = b;
+        for (int k = 0; k < 3; ++k) fu.mul[k] = p->mul[k];
+        fu.do_clip = p->do_clip; fu.cam_to_work = p->has_cam_to_work ? p->cam_to_work : nullptr;
+        fu.exposure_enabled = p->exposure_enabled ? 1 : 0;
+        fu.exp_scale = (float)std::pow(2.0, p->expcomp); fu.black = (float)(p->black * 2000.0);
+        if ((rc = artgpu_improc_denoise_fused(ctx, &img, &fu, &dnp, p->ws, p->iws, ecomp, p->scale > 0 ? p->scale : 1.0,
+                                              p->has_cam_to_work ? p->cam_to_work : nullptr, curve, 0u)))
             return rc;
+    } else {
+        if ((rc = artgpu_get_image(ctx, &dem, b, b, p->mul, p->do_clip, p->has_cam_to_work ? p->cam_to_work : nullptr, &img))) return rc;
+        if (p->exposure_enabled)
+            if ((rc = artgpu_exposure(ctx, &img, (float)std::pow(2.0, p->expcomp), (float)(p->black * 2000.0)))) return rc;
     }
-    if (p->exposure_enabled)
-        if ((rc = artgpu_exposure(ctx, &img, (float)std::pow(2.0, p->expcomp), (float)(p->black * 2000.0)))) return rc;
     if (p->tone_enabled) {
         if (p->tone_mode == ARTGPU_TONE_NEUTRAL) {
             artgpu_neutral_state st;

@@ -109,6 +109,23 @@ __device__ __forceinline__ void lab2rgb_dev(const DnPixArgs &a, float l, float l
 // ---------------------------------------------------------------- RGB -> gamma -> YUV (FTblockDN.cc:2084-2128)
 // Two launch shapes of each pixel pass: the plain 2-D grid, and (large frames, gamma LUT in use) one persistent 1024-thread
 // workgroup per CU with the lower part of the 65536-entry gamma LUT in LDS (lutf_lookup_lds): 0.61 -> ~0.35 ms at 45 MP.
+// getImage + convertColorSpace of one pixel whose three raw plane values have been loaded (get_image_convert_kernel, pixelops.hip:55-88)
+__device__ __forceinline__ void gi_convert(const GetImageFuse &g, float &r, float &gg, float &b)
+{
+    float r1 = 0.f, g1 = 0.f, b1 = 0.f;
+    r1 += r; g1 += gg; b1 += b;
+    r1 *= g.mul[0]; g1 *= g.mul[1]; b1 *= g.mul[2];
+    if (g.do_clip) {
+        r1 = std_max(0.f, std_min(r1, 65535.f)); g1 = std_max(0.f, std_min(g1, 65535.f)); b1 = std_max(0.f, std_min(b1, 65535.f));
+    }
+    if (g.has_mat) {
+        const double dr = r1, dg = g1, db = b1;
+        r1 = (float)(g.mat[0] * dr + g.mat[1] * dg + g.mat[2] * db);
+        g1 = (float)(g.mat[3] * dr + g.mat[4] * dg + g.mat[5] * db);
+        b1 = (float)(g.mat[6] * dr + g.mat[7] * dg + g.mat[8] * db);
+    }
+    r = r1; gg = g1; b = b1;
+}
 template <bool LDS>
 __device__ __forceinline__ float gam_lookup(const float *lds, const float *__restrict__ lut, float v, int lo = 0)
 {
@@ -118,6 +135,7 @@ template <bool LDS>
 __device__ __forceinline__ void rgb2yuv_px(const DnPixArgs &a, const float *lds, int y, int x, float r0, float g0, float b0)
 {
     const long long t = (long long)y * a.w + x;
+    if (a.gi.on) gi_convert(a.gi, r0, g0, b0);
     if (a.pre_scale != 0.f) {   // fused ImProcFunctions::expcomp(+ecomp) (ipexposure.cc:56-70): 4-lane groups then scalar tail
         if (x < (a.w / 4) * 4) { r0 = sse_max(r0 * a.pre_scale - 0.f, 0.f); g0 = sse_max(g0 * a.pre_scale - 0.f, 0.f); b0 = sse_max(b0 * a.pre_scale - 0.f, 0.f); }
         else { r0 = std_max(r0 * a.pre_scale - 0.f, 0.f); g0 = std_max(g0 * a.pre_scale - 0.f, 0.f); b0 = std_max(b0 * a.pre_scale - 0.f, 0.f); }
@@ -139,8 +157,13 @@ __device__ __forceinline__ void rgb2yuv_px(const DnPixArgs &a, const float *lds,
 __global__ void __launch_bounds__(256) rgb2yuv_kernel(DnPixArgs a)
 {
     FOR_IMAGE_XY(y, x, a.w, a.h) {
-        const size_t si = (size_t)y * a.stride + x;
-        rgb2yuv_px<false>(a, nullptr, y, x, a.rgb[0][si], a.rgb[1][si], a.rgb[2][si]);
+        if (a.gi.on) {
+            const size_t si = (size_t)(a.gi.sy1 + y) * a.gi.stride + a.gi.sx1 + x;
+            rgb2yuv_px<false>(a, nullptr, y, x, a.gi.src[0][si], a.gi.src[1][si], a.gi.src[2][si]);
+        } else {
+            const size_t si = (size_t)y * a.stride + x;
+            rgb2yuv_px<false>(a, nullptr, y, x, a.rgb[0][si], a.rgb[1][si], a.rgb[2][si]);
+        }
     }
 }
 __global__ void __launch_bounds__(1024) rgb2yuv_lds_kernel(DnPixArgs a)
@@ -153,8 +176,10 @@ __global__ void __launch_bounds__(1024) rgb2yuv_lds_kernel(DnPixArgs a)
 #pragma unroll
             for (int k = 0; k < LDSK_ROWS * LDSK_PX; ++k) {
                 const int x = x0 + (k % LDSK_PX) * 1024 + (int)threadIdx.x, yr = yb + (k / LDSK_PX) * (int)gridDim.x, y = yr < a.h ? yr : a.h - 1;
-                const size_t si = (size_t)y * a.stride + (x < a.w ? x : a.w - 1);
-                r[k] = a.rgb[0][si]; g[k] = a.rgb[1][si]; b[k] = a.rgb[2][si];
+                const int xc = x < a.w ? x : a.w - 1;
+                const size_t si = a.gi.on ? (size_t)(a.gi.sy1 + y) * a.gi.stride + a.gi.sx1 + xc : (size_t)y * a.stride + xc;
+                const float *const p0 = a.gi.on ? a.gi.src[0] : a.rgb[0], *const p1 = a.gi.on ? a.gi.src[1] : a.rgb[1], *const p2 = a.gi.on ? a.gi.src[2] : a.rgb[2];
+                r[k] = p0[si]; g[k] = p1[si]; b[k] = p2[si];
             }
 #pragma unroll
             for (int k = 0; k < LDSK_ROWS * LDSK_PX; ++k) {
@@ -188,6 +213,11 @@ __device__ __forceinline__ void yuv2rgb_px(const DnPixArgs &a, const float *lds,
     if (a.post_scale != 0.f) {  // fused ImProcFunctions::expcomp(-ecomp)
         if (x < (a.w / 4) * 4) { ro = sse_max(ro * a.post_scale - 0.f, 0.f); go = sse_max(go * a.post_scale - 0.f, 0.f); bo = sse_max(bo * a.post_scale - 0.f, 0.f); }
         else { ro = std_max(ro * a.post_scale - 0.f, 0.f); go = std_max(go * a.post_scale - 0.f, 0.f); bo = std_max(bo * a.post_scale - 0.f, 0.f); }
+    }
+    if (a.exp_on) {             // fused ImProcFunctions::exposure (ipexposure.cc:28-79, exposure_kernel): v * exp_scale - black, floored at 0
+        const float er = ro * a.exp_scale - a.exp_black, eg = go * a.exp_scale - a.exp_black, eb = bo * a.exp_scale - a.exp_black;
+        if (x < (a.w / 4) * 4) { ro = sse_max(er, 0.f); go = sse_max(eg, 0.f); bo = sse_max(eb, 0.f); }
+        else { ro = std_max(er, 0.f); go = std_max(eg, 0.f); bo = std_max(eb, 0.f); }
     }
     a.rgb[0][di] = ro;
     a.rgb[1][di] = go;
@@ -948,8 +978,15 @@ __global__ void __launch_bounds__(256) chroma_map_kernel(ChromaMapArgs a)
     const float cn100 = t0 * t0;
     FOR_IMAGE_XY(ii, jj, a.wid, a.hei) {
         const long long t = (long long)ii * a.wid + jj;
-        const size_t o = (size_t)(2 * ii) * a.stride + 2 * jj;
-        float RL = a.src[0][o], GL = a.src[1][o], BL = a.src[2][o];
+        float RL, GL, BL;
+        if (a.gi.on) {
+            const size_t o = (size_t)(a.gi.sy1 + 2 * ii) * a.gi.stride + a.gi.sx1 + 2 * jj;
+            RL = a.gi.src[0][o]; GL = a.gi.src[1][o]; BL = a.gi.src[2][o];
+            gi_convert(a.gi, RL, GL, BL);
+        } else {
+            const size_t o = (size_t)(2 * ii) * a.stride + 2 * jj;
+            RL = a.src[0][o]; GL = a.src[1][o]; BL = a.src[2][o];
+        }
         if (a.has_mat) {
             const double dr = RL, dg = GL, db = BL;
             RL = (float)(a.mat[0] * dr + a.mat[1] * dg + a.mat[2] * db);

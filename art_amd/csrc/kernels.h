@@ -312,7 +312,22 @@ hipError_t launch_wavelet_haar_synthesis(const WaveArgs &a, hipStream_t s);
 hipError_t launch_wavelet_synthesis0(const WaveArgs &a, hipStream_t s);
 
 // ---- wavelet denoise (denoise.hip) ----
+// RawImageSource::getImage (skip 1) + the matrix branch of convertColorSpace, read by the first pixel passes of ImProcFunctions::denoise
+// straight from the demosaiced planes (artgpu_improc_denoise_fused): pixel (y, x) of the image = planes at (sy1 + y, sx1 + x), * mul, CLIP,
+// camera -> working matrix with double accumulation -- the arithmetic of get_image_convert_kernel (pixelops.hip)
+struct GetImageFuse {
+    int on;
+    const float *src[3];
+    size_t stride;
+    int sx1, sy1;
+    float mul[3];
+    int do_clip, has_mat;
+    double mat[9];
+};
 struct DnPixArgs {
+    GetImageFuse gi;               // rgb2yuv: where the image comes from when it has not been materialised
+    float exp_scale, exp_black;    // yuv2rgb: ImProcFunctions::exposure (process STAGE_1) behind the last pass, exp_on != 0
+    int exp_on;
     float *rgb[3];          // Imagefloat planes (in for rgb2yuv, out for yuv2rgb)
     size_t stride;
     float *L, *A, *B;       // LabImage planes, contiguous w*h
@@ -331,6 +346,7 @@ struct DnPixArgs {
 };
 // chroma noise-curve map (ipdenoise.cc:1113-1131 + FTblockDN.cc:1716-1777)
 struct ChromaMapArgs {
+    GetImageFuse gi;                      // (see DnPixArgs)
     const float *src[3]; size_t stride;   // full-resolution image
     int wid, hei;                         // (w+1)/2 x (h+1)/2
     int has_mat; double mat[9];           // convertColorSpace matrix applied to the subsampled copy

@@ -82,6 +82,9 @@ def main() -> None:
                          "denoise + exposure + tone curve (BASELINE configs[2], the configuration the metric is quoted on); "
                          "c4: c3 + guided chroma smoothing + NL-means (the per-frame pipe of BASELINE configs[3]); "
                          "c5: X-Trans 3-pass (Markesteijn, CIELab) + the c3 stages on a 100 MP 11648x8736 frame (BASELINE configs[4])")
+    ap.add_argument("--separate-stages", action="store_true",
+                    help="one library call per stage of the reference's order (getImage, denoise, exposure) instead of the fused tool "
+                         "artgpu_improc_denoise_fused; same result, the image written and read again between the stages")
     ap.add_argument("--lanes", type=int, default=1,
                     help="frames in flight per GPU (each on its own context, stream and host thread; a step is then `lanes` frames). "
                          "Default 1 = BASELINE's one frame per GPU; 3 gives +11 %% throughput at 45 MP (independent frames fill each "
@@ -175,7 +178,11 @@ def main() -> None:
         x = np.arange(65536, dtype=np.float64) / 65535.0
         lut = ((1.0 - np.cos(np.pi * x ** 0.7)) / 2.0 * 65535.0).astype(np.float32)   # fixed S-curve (an input of the stage)
         exp_scale = float(np.float32(2.0 ** expcomp))
-        stage_names = ["demosaic", "get_image+matrix", "denoise", "exposure", "tone_curve"]
+        # default: getImage + the camera matrix in front of ImProcFunctions::denoise and the STAGE_1 exposure behind it run inside the tool's
+        # own first / last pixel pass (artgpu_improc_denoise_fused: the same operations per pixel, the image not written and read again
+        # between the stages); --separate-stages: one call per stage of the reference's order
+        fused_tool = not args.separate_stages
+        stage_names = ["demosaic", "get_image+matrix+denoise+exposure", "tone_curve"] if fused_tool else ["demosaic", "get_image+matrix", "denoise", "exposure", "tone_curve"]
     else:
         stage_names = ["demosaic"]
     stage_ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(stage_names) + 1)] for _ in range(args.steps)]
@@ -220,9 +227,13 @@ def main() -> None:
             c.demosaic_xtrans(3, True, ln["p_raw"], synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, ln["p_out"])
         else:
             c.demosaic_bayer(method, ln["p_raw"], filt, 1.0, border, ln["p_out"])
-        c.get_image(ln["p_out"], border, border, mul, True, mat, ln["p_img"])
-        c.improc_denoise(ln["p_img"], dn, ws, ecomp=expcomp, calclum_mat=mat, noise_c_curve=ccurve)
-        c.exposure(ln["p_img"], exp_scale, 0.0)
+        if fused_tool:
+            c.improc_denoise_fused(ln["p_img"], dn, ws, demosaiced=ln["p_out"], sx1=border, sy1=border, mul=mul, do_clip=True, cam_to_work=mat,
+                                   exposure=(exp_scale, 0.0), ecomp=expcomp, calclum_mat=mat, noise_c_curve=ccurve)
+        else:
+            c.get_image(ln["p_out"], border, border, mul, True, mat, ln["p_img"])
+            c.improc_denoise(ln["p_img"], dn, ws, ecomp=expcomp, calclum_mat=mat, noise_c_curve=ccurve)
+            c.exposure(ln["p_img"], exp_scale, 0.0)
         c.tone_curve(ln["p_img"], lut, 1.0, True)
 
     def step():
@@ -246,19 +257,24 @@ def main() -> None:
             ctx.demosaic_bayer(method, p_raw, filt, 1.0, border, out)
         mark(1)
         if pipeline:
-            ctx.get_image(out, border, border, mul, True, mat, img)
-            mark(2)
             # ImProcFunctions::denoise: ccalc map, expcomp(+), RGB_denoise (shrinkage + DCT detail recovery),
             # [guided smoothing, NL-means], expcomp(-)
-            ctx.improc_denoise(img, dn, ws, ecomp=expcomp, calclum_mat=mat, noise_c_curve=ccurve)
-            mark(3)
-            ctx.exposure(img, exp_scale, 0.0)
-            mark(4)
+            if fused_tool:
+                ctx.improc_denoise_fused(img, dn, ws, demosaiced=out, sx1=border, sy1=border, mul=mul, do_clip=True, cam_to_work=mat,
+                                         exposure=(exp_scale, 0.0), ecomp=expcomp, calclum_mat=mat, noise_c_curve=ccurve)
+                mark(2)
+            else:
+                ctx.get_image(out, border, border, mul, True, mat, img)
+                mark(2)
+                ctx.improc_denoise(img, dn, ws, ecomp=expcomp, calclum_mat=mat, noise_c_curve=ccurve)
+                mark(3)
+                ctx.exposure(img, exp_scale, 0.0)
+                mark(4)
             if args.tone == "neutral":
                 ctx.tone_curve_neutral(img, lut, 1.0, ws, iws_n)
             else:
                 ctx.tone_curve(img, lut, 1.0, True)
-            mark(5)
+            mark(len(stage_names))
 
     def barrier():
         if world > 1:
@@ -421,6 +437,8 @@ def main() -> None:
                          + ("(BASELINE configs[4])" if xtrans else "(per-frame pipe of BASELINE configs[3])" if smoothing else "(BASELINE configs[2])"))
                         if pipeline else f"{args.workload.upper()} demosaic only, {W}x{H} Bayer RGGB fp32 (BASELINE configs[1])",
             "stage_ms": stage_ms,
+            "stage_calls": ("fused tool: artgpu_improc_denoise_fused (getImage + matrix in front of ImProcFunctions::denoise, exposure behind it, inside its pixel passes)"
+                            if pipeline and fused_tool else "one call per stage"),
             "frame": f"{W}x{H}", "frames_per_step": world * args.lanes, "lanes_per_gpu": args.lanes,
             "parallelism": f"frame-per-gpu x{world}" + (f", {args.lanes} frames in flight per GPU" if args.lanes > 1 else ""),
             "completion_records": len(records), "completion_via": gather_via,
@@ -461,9 +479,13 @@ def main() -> None:
     if pipeline and world == 1 and args.tone == "std" and args.lanes == 1:
         def step_neutral():
             ctx.demosaic_xtrans(3, True, p_raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, out) if xtrans else ctx.demosaic_bayer(method, p_raw, filt, 1.0, border, out)
-            ctx.get_image(out, border, border, mul, True, mat, img)
-            ctx.improc_denoise(img, dn, ws, ecomp=expcomp, calclum_mat=mat, noise_c_curve=ccurve)
-            ctx.exposure(img, exp_scale, 0.0)
+            if fused_tool:
+                ctx.improc_denoise_fused(img, dn, ws, demosaiced=out, sx1=border, sy1=border, mul=mul, do_clip=True, cam_to_work=mat,
+                                         exposure=(exp_scale, 0.0), ecomp=expcomp, calclum_mat=mat, noise_c_curve=ccurve)
+            else:
+                ctx.get_image(out, border, border, mul, True, mat, img)
+                ctx.improc_denoise(img, dn, ws, ecomp=expcomp, calclum_mat=mat, noise_c_curve=ccurve)
+                ctx.exposure(img, exp_scale, 0.0)
             ctx.tone_curve_neutral(img, lut, 1.0, ws, iws_n)
         step_neutral()
         barrier()

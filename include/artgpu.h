@@ -312,6 +312,27 @@ typedef struct {
 int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_tool_params *params, const double ws[9], const double *iws /* LAB mode only */,
                           double ecomp, double scale, const double *calclum_mat, const float *noise_c_curve, uint32_t flags);
 
+/* The same tool with its neighbours in the processing order fused into its first and last pixel passes (simpleprocess.cc:259 getImage,
+ * :311 convertColorSpace, :315 denoise, :389 process STAGE_1 -> ImProcFunctions::exposure, ipexposure.cc:28-79): per pixel the operations
+ * and their order are those of the separate calls -- the image is simply not written and read again between them.
+ *   demosaiced != NULL: `img` is an output only; its pixels are RawImageSource::getImage(demosaiced, sx1, sy1, skip 1, mul, do_clip) followed
+ *                       by convertColorSpace(cam_to_work; NULL = none), evaluated where the denoise reads them (artgpu_get_image's arguments);
+ *   exposure_enabled:   ImProcFunctions::exposure(exp_scale, black) (artgpu_exposure's arguments) is applied to the tool's result.
+ * A part that cannot be fused for the given parameters (nothing to denoise, the guided smoothing / NL-means stages between the wavelet
+ * denoise and the exposure, host planes) runs as the separate call it stands for: same result either way.  fusion == NULL: artgpu_improc_denoise. */
+typedef struct {
+    const artgpu_rgb *demosaiced;
+    int32_t sx1, sy1;
+    float mul[3];
+    int32_t do_clip;
+    const double *cam_to_work;     /* 9 doubles or NULL */
+    int32_t exposure_enabled;
+    float exp_scale, black;
+} artgpu_denoise_fusion;
+int artgpu_improc_denoise_fused(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_fusion *fusion, const artgpu_denoise_tool_params *params,
+                                const double ws[9], const double *iws, double ecomp, double scale, const double *calclum_mat,
+                                const float *noise_c_curve, uint32_t flags);
+
 /* The step immediately before the path: RawImageSource::copyOriginalPixels without dark frame / flat
  * field (rawimagesource.cc:2325-2428: rawData = (float)src->data) followed by RawImageSource::scaleColors (L2677-2859):
  *   val = max(0, raw - cblacksom[c4]) * scale_mul[c4],  chmax[c] = max over the frame   (c4 = 3 for the second Bayer green).

@@ -385,3 +385,48 @@ def test_fused_shrink_pass_under_uneven_load():
         assert _same(got, alone[0]) == [0, 0, 0]
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("w,h,smoothing,nl,ecomp,lum", [
+    (645, 483, 0, 0, 0.3, 40.0),       # W % 4 != 0: the exposure's scalar-form columns; both neighbours fused
+    (640, 480, 0, 0, 0.0, 40.0),       # no exposure compensation inside the tool: the STAGE_1 exposure is the only scaling of the last pass
+    (520, 392, 1, 50, 0.3, 40.0),      # guided smoothing + NL-means stand between RGB_denoise and the exposure: that one runs as its own call
+    (300, 260, 0, 0, 0.3, 0.0),        # luminance 0 (chroma only)
+])
+def test_improc_denoise_fused_equals_the_separate_calls(gpu_ctx, w, h, smoothing, nl, ecomp, lum):
+    """artgpu_improc_denoise_fused: getImage + convertColorSpace read by the tool's first passes straight from the demosaiced planes,
+    ImProcFunctions::exposure applied by its last pass -- against get_image, improc_denoise, exposure called one after the other (and
+    those against the oracle elsewhere in this file)"""
+    import torch
+    raw = synth.bayer_frame(w + 8, h + 8, synth.FILTERS_RGGB, seed=w, noise=2048)
+    dem = O.amaze(raw, synth.FILTERS_RGGB, 1.0, 4)
+    mul = (2.1374, 1.0, 1.5918)
+    mat = np.array([[0.6325, 0.2312, 0.0921], [0.2198, 0.7712, 0.0090], [0.0166, 0.0713, 0.7514]])
+    curve, _ = capi.noise_curve_lut()
+    tp = capi.DenoiseToolParams(capi.DenoiseParams(lum, 50.0, 0, 15.0, 0.0, 0.0, 1.7, 0, 0, 0), smoothing, 3, nl, 80)
+    exp_scale = float(np.float32(2.0 ** 0.3))
+    d_dem = [torch.from_numpy(p).cuda() for p in dem]
+    p_dem = capi.RGB(*[capi.device_plane(t) for t in d_dem])
+    outs = []
+    for fused in (True, False):
+        d_img = [torch.full((h, w), float("nan"), dtype=torch.float32, device="cuda") for _ in range(3)]
+        img = capi.RGB(*[capi.device_plane(t) for t in d_img])
+        if fused:
+            gpu_ctx.improc_denoise_fused(img, tp, O.REC2020_WS_D, demosaiced=p_dem, sx1=4, sy1=4, mul=mul, do_clip=True, cam_to_work=mat,
+                                         exposure=(exp_scale, 12.5), ecomp=ecomp, calclum_mat=mat, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+        else:
+            gpu_ctx.get_image(p_dem, 4, 4, mul, True, mat, img)
+            gpu_ctx.improc_denoise(img, tp, O.REC2020_WS_D, ecomp=ecomp, calclum_mat=mat, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+            gpu_ctx.exposure(img, exp_scale, 12.5)
+        torch.cuda.synchronize()
+        outs.append([t.cpu().numpy() for t in d_img])
+    assert _same(outs[0], outs[1]) == [0, 0, 0]
+    assert all(np.isfinite(p).all() for p in outs[0])
+    # nothing to denoise at all: both neighbours run as the calls they stand for
+    tp0 = capi.DenoiseToolParams(capi.DenoiseParams(0.0, 50.0, 0, 0.0, 0.0, 0.0, 1.7, 0, 0, 0), 0, 3, 0, 80)
+    d_img = [torch.full((h, w), float("nan"), dtype=torch.float32, device="cuda") for _ in range(3)]
+    img = capi.RGB(*[capi.device_plane(t) for t in d_img])
+    gpu_ctx.improc_denoise_fused(img, tp0, O.REC2020_WS_D, demosaiced=p_dem, sx1=4, sy1=4, mul=mul, do_clip=True, cam_to_work=mat, exposure=(exp_scale, 0.0))
+    ref = O.exposure(O.convert_color_space(O.get_image(dem, 4, 4, w, h, mul, True), mat), exp_scale, 0.0)
+    torch.cuda.synchronize()
+    assert _same([t.cpu().numpy() for t in d_img], ref) == [0, 0, 0]
