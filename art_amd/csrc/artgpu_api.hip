@@ -1194,9 +1194,9 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     float *fused_scratch = nullptr, *Lbands2 = nullptr;
     const size_t histo_bytes = (size_t)nsub * (65536 + MAD_SCRATCH_INTS_PER_BAND) * 4, band_bytes = (size_t)nsub * n2 * 4;
     if ((rc = pool_get(ctx, P_L, n * 4, &L)) || (rc = pool_get(ctx, P_A, n * 4, &A)) || (rc = pool_get(ctx, P_B, n * 4, &B)) ||
-        (rc = pool_get(ctx, P_LBANDS, band_bytes, &Ld.bands)) || (rc = pool_get(ctx, P_LLOW0, n2 * 4, &Ld.low[0])) || (rc = pool_get(ctx, P_LLOW1, n2 * 4, &Ld.low[1])) ||
-        (rc = pool_get(ctx, P_CBANDS, (merged ? 2 : 1) * band_bytes, &Cdd[0].bands)) || (rc = pool_get(ctx, P_CLOW0, n2 * 4, &Cdd[0].low[0])) || (rc = pool_get(ctx, P_CLOW1, n2 * 4, &Cdd[0].low[1])) ||
-        (rc = pool_get(ctx, P_HISTO, histo_bytes, &histo_fc[0])) ||
+        (rc = pool_get(ctx, P_LBANDS, (merged_mad ? 3 : 1) * band_bytes, &Ld.bands)) || (rc = pool_get(ctx, P_LLOW0, n2 * 4, &Ld.low[0])) || (rc = pool_get(ctx, P_LLOW1, n2 * 4, &Ld.low[1])) ||
+        (rc = merged_mad ? ARTGPU_OK : pool_get(ctx, P_CBANDS, (merged ? 2 : 1) * band_bytes, &Cdd[0].bands)) || (rc = pool_get(ctx, P_CLOW0, n2 * 4, &Cdd[0].low[0])) || (rc = pool_get(ctx, P_CLOW1, n2 * 4, &Cdd[0].low[1])) ||
+        (rc = pool_get(ctx, P_HISTO, (merged_mad ? 3 : 1) * histo_bytes, &histo_fc[0])) ||
         (rc = pool_get(ctx, P_MAD, 3 * 32 * 4, &mad)) || (rc = pool_get(ctx, P_GAM, 2 * 65536 * 4, &gamlut)))
         return rc;
     if (fused) {
@@ -1207,6 +1207,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     } else if ((rc = pool_get(ctx, P_SF, band_bytes, &sfc[0])) || (rc = pool_get(ctx, P_TMP, band_bytes, &tmp1))) return rc;
     tmpc[0] = tmpc[1] = tmpc[2] = tmp1;
     if (two_chroma) {
+        if (merged_mad) Cdd[0].bands = Ld.bands + (size_t)nsub * n2;       // (one MadRgb launch set walks the bands of all three channels)
         if (merged) Cdd[1].bands = Cdd[0].bands + (size_t)nsub * n2;       // (one launch walks both channels' bands: back to back)
         else if ((rc = pool_get(ctx, P_CBANDS2, band_bytes, &Cdd[1].bands))) return rc;
         if ((rc = pool_get(ctx, P_CLOW0_2, n2 * 4, &Cdd[1].low[0])) || (rc = pool_get(ctx, P_CLOW1_2, n2 * 4, &Cdd[1].low[1])) ||
@@ -1272,7 +1273,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
 
     // ---- L decomposition and its MADs (L2296-2320)
     if ((rc = decompose_dev(ctx, Ld, L, sL))) return rc;
-    HIPCHK(ctx, launch_mad(Ld.bands, n2, nsub, reinterpret_cast<int *>(histo_fc[0]), madL, sL));
+    if (!merged_mad) HIPCHK(ctx, launch_mad(Ld.bands, n2, nsub, reinterpret_cast<int *>(histo_fc[0]), madL, sL));
 
     // one fused ShrinkAll pass over `nb` bands starting at level `lev0` (pointers already offset to the first band)
     auto fused_pass = [&](bool ab, const float *cin, float *cout, const float *cL, const float *mL, const float *mab, int lev0, int nb,
@@ -1484,7 +1485,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     auto merged_pass = [&]() -> int {
         FusedShrinkArgs fa = {};
         fa.coef = Ld.bands; fa.coef_out = Lbands2; fa.coefC = Cdd[0].bands; fa.coefL = Ld.bands; fa.n = n2; fa.w = w2; fa.h = h2;
-        fa.madL = madL; fa.madab = mad + 32; fa.mad_ch_stride = nsub;
+        fa.madL = madL; fa.madab = merged_mad ? mad + nsub : mad + 32; fa.mad_ch_stride = nsub;
         fa.noisevar = ccalc_dev; fa.noisevar_const = noisevarL; fa.noisevar_scale = maxNoiseVarab;
         fa.noisevar_ab[0] = noisevar_abc[0]; fa.noisevar_ab[1] = noisevar_abc[1];
         fa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
@@ -1497,8 +1498,8 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         // decompositions and MADs of a and b, the three channels' ShrinkAll passes as one launch, then the reconstructions -- L first, so that
         // its DCT detail recovery (side stream) runs beside those of a and b
         if ((rc = chroma_front(0)) || (rc = chroma_front(1))) return rc;
-        // MadRgb of both chroma channels' bands as one launch set (the bands are back to back; the medians land at mad + 32 + band)
-        if (merged_mad) HIPCHK(ctx, launch_mad(Cdd[0].bands, n2, 2 * nsub, reinterpret_cast<int *>(histo_fc[1]), mad + 32, sL));
+        // MadRgb of all three channels' bands as one launch set (the bands are back to back: L, a, b; the medians land at mad + band)
+        if (merged_mad) HIPCHK(ctx, launch_mad(Ld.bands, n2, 3 * nsub, reinterpret_cast<int *>(histo_fc[0]), mad, sL));
         if ((rc = merged_pass())) return rc;
         SideStreamJoin dn_join;
         if (fork) dn_join.arm(ctx->dn_stream[0]);
