@@ -25,7 +25,13 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 
 constexpr int A0_TW = 64, A0_TH = 16;          // output tile of the level-0 analysis
 constexpr int A0_LW = 2 * A0_TW + 6;           // tmp columns kept in LDS
-constexpr int S0_TW = 128, S0_TH = 32;         // output tile of the level-0 synthesis
+#ifndef S0_TW_
+#define S0_TW_ 128
+#endif
+#ifndef S0_TH_
+#define S0_TH_ 32
+#endif
+constexpr int S0_TW = S0_TW_, S0_TH = S0_TH_;   // output tile of the level-0 synthesis
 constexpr int S0_LH = S0_TH / 2 + 4;           // horizontally synthesised rows kept in LDS
 } // namespace
 
@@ -131,25 +137,46 @@ __global__ void __launch_bounds__(256) wavelet_synthesis0_kernel(WaveArgs a)
     // the odd one takes taps 0,2,4 and the even one taps 1,3,5), so one item computes the pair from one set of loads.
     // The tile starts at an even column: pair p covers tile columns 2p-1 and 2p, p = 0..S0_TW/2.
     constexpr int NP = S0_TW / 2 + 1;
-    for (int t = threadIdx.x; t < S0_LH * NP; t += 256) {
-        const int rr = t / NP, p = t - rr * NP;
-        const int cc1 = 2 * p - 1, cc2 = 2 * p;                  // tile columns of the odd / even output
-        const int i1 = c0 + cc1;                                 // odd (c0 is even)
-        if (i1 >= w) continue;
-        const int k = clampi(srow0 + rr, 0, h2 - 1);
-        const int i_src = (i1 + shift) / 2;                      // = (i1 + 1 + shift) / 2
-        float lo1 = 0.f, hi1 = 0.f, lo2 = 0.f, hi2 = 0.f;
+    // All loads of a thread's items are issued before any arithmetic, from clamped (always valid) addresses: with the items as a loop whose
+    // body starts with a validity test the loads of item n + 1 waited for item n's LDS stores -- five to six dependent memory round trips
+    // per tile and thread (the kernel ran at 2.2 TB/s of its bytes).
+    constexpr int NI = (S0_LH * NP + 255) / 256, NH = (NI + 1) / 2;
 #pragma unroll
-        for (int l = 0; l < 3; ++l) {
-            const size_t arg = (size_t)k * w2 + clampi(i_src - l, 0, w2 - 1);
-            const float s = a.src[arg], d1 = a.b1[arg], d2 = a.b2[arg], d3 = a.b3[arg];
-            lo1 += (SYN_LO[2 * l] * s + SYN_HI[2 * l] * d1);
-            hi1 += (SYN_LO[2 * l] * d2 + SYN_HI[2 * l] * d3);
-            lo2 += (SYN_LO[2 * l + 1] * s + SYN_HI[2 * l + 1] * d1);
-            hi2 += (SYN_LO[2 * l + 1] * d2 + SYN_HI[2 * l + 1] * d3);
+    for (int half = 0; half < 2; ++half) {
+        float vs[NH][3], v1[NH][3], v2[NH][3], v3[NH][3];
+#pragma unroll
+        for (int n = 0; n < NH; ++n) {
+            const int t = min((int)threadIdx.x + (half * NH + n) * 256, S0_LH * NP - 1);
+            const int rr = t / NP, p = t - rr * NP;
+            const int i1 = min(c0 + 2 * p - 1, w - 1);
+            const int k = clampi(srow0 + rr, 0, h2 - 1);
+            const int i_src = (i1 + shift) / 2;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const size_t arg = (size_t)k * w2 + clampi(i_src - l, 0, w2 - 1);
+                vs[n][l] = a.src[arg]; v1[n][l] = a.b1[arg]; v2[n][l] = a.b2[arg]; v3[n][l] = a.b3[arg];
+            }
         }
-        if (cc1 >= 0) { tLo[rr][cc1] = lo1; tHi[rr][cc1] = hi1; }
-        if (cc2 < S0_TW && i1 + 1 < w) { tLo[rr][cc2] = lo2; tHi[rr][cc2] = hi2; }
+#pragma unroll
+        for (int n = 0; n < NH; ++n) {
+            const int t = (int)threadIdx.x + (half * NH + n) * 256;
+            if (half * NH + n >= NI || t >= S0_LH * NP) continue;
+            const int rr = t / NP, p = t - rr * NP;
+            const int cc1 = 2 * p - 1, cc2 = 2 * p;                  // tile columns of the odd / even output
+            const int i1 = c0 + cc1;                                 // odd (c0 is even)
+            if (i1 >= w) continue;
+            float lo1 = 0.f, hi1 = 0.f, lo2 = 0.f, hi2 = 0.f;
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+                const float s = vs[n][l], d1 = v1[n][l], d2 = v2[n][l], d3 = v3[n][l];
+                lo1 += (SYN_LO[2 * l] * s + SYN_HI[2 * l] * d1);
+                hi1 += (SYN_LO[2 * l] * d2 + SYN_HI[2 * l] * d3);
+                lo2 += (SYN_LO[2 * l + 1] * s + SYN_HI[2 * l + 1] * d1);
+                hi2 += (SYN_LO[2 * l + 1] * d2 + SYN_HI[2 * l + 1] * d3);
+            }
+            if (cc1 >= 0) { tLo[rr][cc1] = lo1; tHi[rr][cc1] = hi1; }
+            if (cc2 < S0_TW && i1 + 1 < w) { tLo[rr][cc2] = lo2; tHi[rr][cc2] = hi2; }
+        }
     }
     __syncthreads();
     const float srcFactor = 1.f - a.blend;
@@ -160,6 +187,14 @@ __global__ void __launch_bounds__(256) wavelet_synthesis0_kernel(WaveArgs a)
     // out of range (FTblockDN.cc:587).  The load is skipped then -- a quarter of this kernel's traffic -- and the destination may be a plane
     // that was never written (the L channel is reconstructed into a second plane so that the first one stays as `Lin`).
     constexpr int NIT = S0_TH * S0_TW / 256;
+    // The taps of output row i are filter entries begin, begin + 2, begin + 4 with begin = (i + shift) % 2.  A thread's rows all have one
+    // parity (r0 and the 256 / S0_TW row step are even), so its three tap pairs are chosen once -- indexed per output they were six loads
+    // from the constant table per output (a per-lane index is a vector load), half of this kernel's memory instructions.
+    static_assert((256 / S0_TW) % 2 == 0 && S0_TH % 2 == 0, "row parity per thread");
+    const bool odd_tap = ((r0 + (int)threadIdx.x / S0_TW + shift) & 1) != 0;
+    float flo[3], fhi[3];
+#pragma unroll
+    for (int l = 0; l < 3; ++l) { flo[l] = odd_tap ? SYN_LO[2 * l + 1] : SYN_LO[2 * l]; fhi[l] = odd_tap ? SYN_HI[2 * l + 1] : SYN_HI[2 * l]; }
     float dv[NIT];
     const bool use_old = a.blend != 1.f;
 #pragma unroll
@@ -175,12 +210,13 @@ __global__ void __launch_bounds__(256) wavelet_synthesis0_kernel(WaveArgs a)
         const int rr = t / S0_TW, cc = t - rr * S0_TW;
         const int i = r0 + rr, k = c0 + cc;
         if (i >= h || k >= w) continue;
-        const int i_src = (i + shift) / 2, begin = (i + shift) % 2;
+        const int i_src = (i + shift) / 2;
         float tot = 0.f;
-        for (int j = begin, l = 0; j < 6; j += 2, l += 1) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) {
             // LDS row rr holds source row clamp(srow0 + rr); the clamped row R sits at R - srow0 (0..18)
             const int lr = clampi(i_src - l, 0, h2 - 1) - srow0;
-            tot += (SYN_LO[j] * tLo[lr][cc] + SYN_HI[j] * tHi[lr][cc]);
+            tot += (flo[l] * tLo[lr][cc] + fhi[l] * tHi[lr][cc]);
         }
         const size_t o = (size_t)i * a.dst_stride + k;
         a.dst[o] = dv[n] * srcFactor + a.blend * 4.f * tot;
