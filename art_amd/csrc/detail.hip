@@ -157,8 +157,13 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
 
 // Sum the overlapping blocks per pixel in the reference's serial order and add the detail to L:
 //   Ldetail += tilemask_out * block * DCTnorm ; totwt += tilemask_in * tilemask_out ; L += Ldetail / totwt
-__global__ void __launch_bounds__(256) detail_gather_kernel(DetailArgs a)
+__global__ void __launch_bounds__(1024) detail_gather_kernel(DetailArgs a)
 {
+    // the two 64 x 64 tile masks in LDS: every term of a pixel's sum looks both up at the pixel's position inside the block -- as global
+    // loads they were two of the three memory instructions per term (18 of 27 per pixel)
+    __shared__ float s_in[TS * TS], s_out[TS * TS];
+    for (int k = threadIdx.x; k < TS * TS; k += 1024) { s_in[k] = a.tm_in[k]; s_out[k] = a.tm_out[k]; }
+    __syncthreads();
     const float DCTnorm = 1.0f / (4 * TS * TS);
     const long long n = (long long)a.w * a.h;
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
@@ -173,9 +178,9 @@ __global__ void __launch_bounds__(256) detail_gather_kernel(DetailArgs a)
             for (int hblk = hb0; hblk <= hb1; ++hblk) {
                 const int j = x - (hblk - BLKRAD) * OFF;
                 if (j < 0 || j >= TS) continue;
-                const float tmo = a.tm_out[i * TS + j];
+                const float tmo = s_out[i * TS + j];
                 Ldetail += tmo * a.blocks[((size_t)vblk * a.numblox_W + hblk) * TS * TS + i * TS + j] * DCTnorm;
-                totwt += a.tm_in[i * TS + j] * tmo;
+                totwt += s_in[i * TS + j] * tmo;
             }
         }
         a.L[t] += Ldetail / totwt;
@@ -197,8 +202,11 @@ hipError_t launch_detail_blocks(const DetailArgs &a, hipStream_t s)
 hipError_t launch_detail_gather(const DetailArgs &a, hipStream_t s)
 {
     const long long n = (long long)a.w * a.h;
-    const long long g = (n + 255) / 256;
-    hipLaunchKernelGGL(detail_gather_kernel, dim3((int)(g < 16384 ? g : 16384)), dim3(256), 0, s, a);
+    const long long g = (n + 1023) / 1024;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const long long cap = 2LL * cus;           // persistent: 32 KB of mask tables per 1024-thread workgroup, two per CU
+    hipLaunchKernelGGL(detail_gather_kernel, dim3((int)(g < cap ? g : cap)), dim3(1024), 0, s, a);
     return hipGetLastError();
 }
 
