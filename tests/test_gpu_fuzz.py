@@ -116,3 +116,29 @@ def test_fuzz_nlmeans_sizes_on_one_context(gpu_ctx):
              (40, 100, 50, 0, 1.0, 5), (100, 40, 50, 0, 1.0, 5), (60, 60, 50, 50, 1.0, 5), (399, 32, 50, 0, 1.0, 805697932)]
     for c in fixed + list(fuzz_nlm.cases(7, 10)):
         assert fuzz_nlm.run(gpu_ctx, *c) == 0, c
+
+
+def _denoise_cases(n, seed):
+    """scripts/fuzz_denoise.py's generator: sizes on both sides of what the fused shrink pass takes (bands of 64 x 64 and more), every strength
+    incl. 0, preview scale 2 (smaller blur radii), QUALITY_HIGH (per-channel launches, radii above 7)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for it in range(n):
+        w = int(rng.choice([rng.integers(64, 200), rng.integers(200, 700), rng.integers(700, 1100)]))
+        h = int(rng.choice([rng.integers(64, 200), rng.integers(200, 600)]))
+        out.append((it, w, h, int(rng.choice([64, 2048, 6000])), float(rng.choice([0.0, 5.0, 40.0, 100.0])), float(rng.choice([0.0, 15.0, 60.0, 100.0])),
+                    float(rng.choice([0.0, -40.0, 35.0])), float(rng.choice([0.0, 50.0, -25.0])), float(rng.choice([1.0, 1.7, 3.0])),
+                    int(rng.integers(0, 2)), float(rng.choice([1.0, 1.0, 2.0]))))
+    return out
+
+
+@pytest.mark.parametrize("it,w,h,noise,lum,chrom,rg,by,gamma,aggressive,scale", _denoise_cases(16, 20260928))
+def test_fuzz_rgb_denoise(gpu_ctx, it, w, h, noise, lum, chrom, rg, by, gamma, aggressive, scale):
+    raw = synth.bayer_frame(w // 2 * 2, h // 2 * 2, synth.FILTERS_RGGB, seed=900 + it, noise=noise)
+    img = [np.ascontiguousarray(p[:h, :w]) for p in O.amaze(raw, synth.FILTERS_RGGB, 1.0, 4)]
+    got = [p.copy() for p in img]
+    p = capi.DenoiseParams(lum, 50.0, 0, chrom, rg, by, gamma, aggressive, 0, 0)
+    gpu_ctx.rgb_denoise(capi.host_rgb(got), p, O.REC2020_WS, scale=scale, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    ref = O.rgb_denoise(img, O.default_denoise_params(luminance=lum, chrominance=chrom, chrominanceRedGreen=rg, chrominanceBlueYellow=by,
+                                                      gamma=gamma, aggressive=aggressive, scale=scale))
+    assert _same(got, ref), f"{w}x{h} lum {lum} chrom {chrom} aggressive {aggressive} scale {scale}"
