@@ -4,6 +4,6 @@ R=$1; W=$2; shift; shift
 for i in $(seq $R); do
   for v in "$@"; do
     if [ $v = default ]; then unset ARTGPU_LIB; else export ARTGPU_LIB=$PWD/$v; fi
-    timeout 120 python bench.py --workload $W --no-cpu-baseline --sustained-seconds 0 --steps 10 --warmup 3 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('[$v]', d['ms_per_step'], d['config']['stage_ms'].get('denoise'))"
+    timeout 120 python bench.py --workload $W --no-cpu-baseline --sustained-seconds 0 --steps 10 --warmup 3 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('[$v]', d['ms_per_step'], list(d['config']['stage_ms'].values()))"
   done
 done
