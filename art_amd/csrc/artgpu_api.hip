@@ -50,6 +50,8 @@ struct artgpu_ctx {
     GetImageFuse fuse_gi = {};               // improc_denoise_fused -> chroma map, rgb2yuv: getImage + matrix read from the demosaiced planes
     float fuse_exp_scale = 0.f, fuse_exp_black = 0.f;   // improc_denoise_fused -> yuv2rgb: ImProcFunctions::exposure behind the last pass
     int fuse_exp_on = 0;
+    int tail_exp_on = 0;                      // improc_denoise_fused: the exposure rides on the tool's LAST pixel pass when that is not yuv2rgb
+    float tail_exp_scale = 0.f, tail_exp_black = 0.f;
     float *bbox = nullptr; // AMaZE: per-tile nyquist bounding boxes
     size_t bbox_bytes = 0;
     // AMaZE v2: tile lists on the device (ints).  [stream tiles | arena-tile template: count, tiles | working copy: count, tiles + room
@@ -2461,6 +2463,9 @@ int artgpu_improc_denoise_fused(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_d
     const bool dev_planes = img->r.on_device && (!fu || !fu->demosaiced || (fu->demosaiced->r.on_device && fu->demosaiced->g.on_device && fu->demosaiced->b.on_device));
     bool fuse_gi = fu && fu->demosaiced && dn_runs0 && dev_planes;
     const bool fuse_exp = fu && fu->exposure_enabled && dn_runs0 && dev_planes && !p->smoothing_enabled;
+    // with guided smoothing / NL-means behind the wavelet denoise the tool's last pixel pass is setMode(RGB) or its own expcomp(-ecomp):
+    // the exposure rides on that one
+    const bool tail_exp = fu && fu->exposure_enabled && dn_runs0 && dev_planes && p->smoothing_enabled && (p->nl_strength || ecomp > 0);
     if (fu && fu->demosaiced) {
         const artgpu_rgb *dm = fu->demosaiced;
         if (!plane_ok(&dm->r) || !plane_ok(&dm->g) || !plane_ok(&dm->b) || dm->g.row_stride_bytes != dm->r.row_stride_bytes || dm->b.row_stride_bytes != dm->r.row_stride_bytes ||
@@ -2473,7 +2478,7 @@ int artgpu_improc_denoise_fused(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_d
     }
     if (fu && (fu->demosaiced || fu->exposure_enabled)) {
         // one level down with what is left to fuse; the exposure that could not be fused follows as its own call
-        struct Restore { artgpu_ctx *c; ~Restore() { c->fuse_gi.on = 0; c->fuse_exp_on = 0; } } restore{ctx};
+        struct Restore { artgpu_ctx *c; ~Restore() { c->fuse_gi.on = 0; c->fuse_exp_on = 0; c->tail_exp_on = 0; } } restore{ctx};
         if (fuse_gi) {
             GetImageFuse &g = ctx->fuse_gi;
             g.on = 1;
@@ -2485,9 +2490,10 @@ int artgpu_improc_denoise_fused(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_d
             for (int k = 0; k < 9; ++k) g.mat[k] = fu->cam_to_work ? fu->cam_to_work[k] : 0.0;
         }
         if (fuse_exp) { ctx->fuse_exp_on = 1; ctx->fuse_exp_scale = fu->exp_scale; ctx->fuse_exp_black = fu->black; }
+        if (tail_exp) { ctx->tail_exp_on = 1; ctx->tail_exp_scale = fu->exp_scale; ctx->tail_exp_black = fu->black; }
         int rc0 = artgpu_improc_denoise_fused(ctx, img, nullptr, p, ws, iws, ecomp, scale, calclum_mat, noise_c_curve, flags);
         if (rc0) return rc0;
-        if (fu->exposure_enabled && !fuse_exp) return artgpu_exposure(ctx, img, fu->exp_scale, fu->black);
+        if (fu->exposure_enabled && !fuse_exp && !tail_exp) return artgpu_exposure(ctx, img, fu->exp_scale, fu->black);
         return ARTGPU_OK;
     }
     if (!img->r.on_device) {
@@ -2547,6 +2553,13 @@ int artgpu_improc_denoise_fused(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_d
     rc = artgpu_rgb_denoise(ctx, img, &p->dn, wsf, iws ? iwsf : nullptr, 0.0, scale, ccalc_p, flags, nullptr, nullptr);
     ctx->fuse_pre = ctx->fuse_post = 0.f;
     if (rc) return rc;
+    // the exposure steps behind the tool's last stage -- its own expcomp(-ecomp) (L1181-1184) where yuv2rgb could not take it, and the STAGE_1
+    // exposure of artgpu_improc_denoise_fused -- ride on the last pixel pass there is: setMode(RGB) behind NL-means, or one exposure pass
+    int chain_n = 0;
+    float chain_scale[2], chain_black[2];
+    if (ecomp > 0 && !fuse_post) { chain_scale[chain_n] = (float)std::pow(2.0, -ecomp); chain_black[chain_n] = 0.f; ++chain_n; }
+    if (ctx->tail_exp_on) { chain_scale[chain_n] = ctx->tail_exp_scale; chain_black[chain_n] = ctx->tail_exp_black; ++chain_n; }
+    bool chained = false;
     if (p->smoothing_enabled) {
         if ((rc = artgpu_denoise_guided_smoothing(ctx, img, ws, p->guided_chroma_radius, scale))) return rc;
         if (p->nl_strength) {
@@ -2558,10 +2571,22 @@ int artgpu_improc_denoise_fused(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_d
             HIPCHK(ctx, launch_yuv_mode(a, ctx->stream));
             if ((rc = artgpu_nlmeans(ctx, &img->g, 65535.f, p->nl_strength, p->nl_detail, (float)scale))) return rc;
             a.do_clip = 1;
+            a.chain_n = chain_n;
+            for (int k = 0; k < chain_n; ++k) { a.chain_scale[k] = chain_scale[k]; a.chain_black[k] = chain_black[k]; }
             HIPCHK(ctx, launch_yuv_mode(a, ctx->stream));
+            chained = true;
         }
     }
-    if (ecomp > 0 && !fuse_post) { if ((rc = artgpu_exposure(ctx, img, (float)std::pow(2.0, -ecomp), 0.f))) return rc; }         // L1181-1184
+    if (chain_n && !chained) {
+        PixArgs a = {};
+        float *pl[3] = {img->r.p, img->g.p, img->b.p};
+        for (int k = 0; k < 3; ++k) a.dst[k] = pl[k];
+        a.dst_stride = (size_t)(img->r.row_stride_bytes / 4); a.w = img->r.w; a.h = img->r.h;
+        a.exp_scale = chain_scale[0]; a.black = chain_black[0];
+        a.chain_n = chain_n - 1;
+        if (chain_n > 1) { a.chain_scale[0] = chain_scale[1]; a.chain_black[0] = chain_black[1]; }
+        HIPCHK(ctx, launch_exposure(a, ctx->stream));
+    }
     return ARTGPU_OK;
 }
 

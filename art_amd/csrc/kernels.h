@@ -146,6 +146,8 @@ struct PixArgs {
     int has_mat;
     double mat[9];         // raw->working matrix, row-major
     float exp_scale, black;
+    int chain_n;           // exposure / setMode(RGB): this many further ImProcFunctions::exposure steps on the value before it is stored
+    float chain_scale[2], chain_black[2];
     const float *lut;      // tone: 65536-entry LUT on the device (nullable)
     float whitept;
     int tail_kind;         // curves::setLutVal above 65535 (artgpu_set_curve_tail): 0 LUT clip, 1 constant, 2 identity, 4 parametric

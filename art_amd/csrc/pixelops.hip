@@ -100,7 +100,12 @@ __global__ void __launch_bounds__(256) exposure_kernel(PixArgs a)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float e = v[c] * a.exp_scale - a.black;
-            a.dst[c][di] = x < wv ? sse_max(e, 0.f) : std_max(e, 0.f);
+            float o = x < wv ? sse_max(e, 0.f) : std_max(e, 0.f);
+            for (int k = 0; k < a.chain_n; ++k) {          // exposure steps that follow directly (ipdenoise.cc:1181-1184, then process STAGE_1)
+                const float e2 = o * a.chain_scale[k] - a.chain_black[k];
+                o = x < wv ? sse_max(e2, 0.f) : std_max(e2, 0.f);
+            }
+            a.dst[c][di] = o;
         }
     }
 }
@@ -170,7 +175,16 @@ __global__ void __launch_bounds__(256) yuv_mode_kernel(PixArgs a)
             const float Y = a.dst[1][di], u = a.dst[2][di], v = a.dst[0][di];
             const float b = Y - u, r = v + Y;
             const float g = (Y - r * a.mul[0] - b * a.mul[2]) / a.mul[1];
-            a.dst[0][di] = r; a.dst[1][di] = g; a.dst[2][di] = b;
+            float o[3] = {r, g, b};
+            if (a.chain_n) {                                // the exposure steps that follow setMode(RGB) directly (exposure_kernel's forms)
+                const bool vl = x < (a.w / 4) * 4;
+                for (int k = 0; k < a.chain_n; ++k)
+                    for (int c = 0; c < 3; ++c) {
+                        const float e = o[c] * a.chain_scale[k] - a.chain_black[k];
+                        o[c] = vl ? sse_max(e, 0.f) : std_max(e, 0.f);
+                    }
+            }
+            a.dst[0][di] = o[0]; a.dst[1][di] = o[1]; a.dst[2][di] = o[2];
         }
     }
 }

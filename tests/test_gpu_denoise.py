@@ -390,7 +390,9 @@ def test_fused_shrink_pass_under_uneven_load():
 @pytest.mark.parametrize("w,h,smoothing,nl,ecomp,lum", [
     (645, 483, 0, 0, 0.3, 40.0),       # W % 4 != 0: the exposure's scalar-form columns; both neighbours fused
     (640, 480, 0, 0, 0.0, 40.0),       # no exposure compensation inside the tool: the STAGE_1 exposure is the only scaling of the last pass
-    (520, 392, 1, 50, 0.3, 40.0),      # guided smoothing + NL-means stand between RGB_denoise and the exposure: that one runs as its own call
+    (520, 392, 1, 50, 0.3, 40.0),      # guided smoothing + NL-means stand between RGB_denoise and the exposure: expcomp(-) and the exposure ride on setMode(RGB)
+    (523, 390, 1, 0, 0.3, 40.0),       # guided smoothing only: expcomp(-) and the exposure as one pass
+    (520, 392, 1, 50, 0.0, 40.0),      # no exposure compensation: the exposure alone rides on setMode(RGB)
     (300, 260, 0, 0, 0.3, 0.0),        # luminance 0 (chroma only)
 ])
 def test_improc_denoise_fused_equals_the_separate_calls(gpu_ctx, w, h, smoothing, nl, ecomp, lum):
