@@ -424,6 +424,14 @@ def test_improc_denoise_fused_equals_the_separate_calls(gpu_ctx, w, h, smoothing
         outs.append([t.cpu().numpy() for t in d_img])
     assert _same(outs[0], outs[1]) == [0, 0, 0]
     assert all(np.isfinite(p).all() for p in outs[0])
+    # host planes: nothing can be fused (the tool stages them itself), the neighbours run as separate calls -- same result
+    h_img = [np.full((h, w), np.nan, np.float32) for _ in range(3)]
+    gpu_ctx.improc_denoise_fused(capi.host_rgb(h_img), tp, O.REC2020_WS_D, demosaiced=capi.host_rgb(dem), sx1=4, sy1=4, mul=mul, do_clip=True, cam_to_work=mat,
+                                 exposure=(exp_scale, 12.5), ecomp=ecomp, calclum_mat=mat, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+    assert _same(h_img, outs[1]) == [0, 0, 0]
+    # a crop that leaves the demosaiced planes is an error, not a clamp
+    with pytest.raises(capi.ArtGpuError):
+        gpu_ctx.improc_denoise_fused(img, tp, O.REC2020_WS_D, demosaiced=p_dem, sx1=9, sy1=4, mul=mul)
     # nothing to denoise at all: both neighbours run as the calls they stand for
     tp0 = capi.DenoiseToolParams(capi.DenoiseParams(0.0, 50.0, 0, 0.0, 0.0, 0.0, 1.7, 0, 0, 0), 0, 3, 0, 80)
     d_img = [torch.full((h, w), float("nan"), dtype=torch.float32, device="cuda") for _ in range(3)]
