@@ -26,6 +26,7 @@ struct artgpu_ctx {
     // RGB_denoise: the DCT detail recovery of L runs on a side stream beside the chroma blurs / reconstructions
     hipStream_t dn_stream[1] = {nullptr};
     hipEvent_t dn_ev[2] = {nullptr, nullptr};
+    const float *gam_tab = nullptr; float gam_key[6] = {};   // RGB_denoise's gamma / inverse-gamma tables in pool[P_GAM]: what they were built from
     int opt_lut_lds = 1;           // 0: never the LUT-in-LDS shapes of the pixel passes (tests compare the two)
     int opt_dn_streams = 1;        // 0: the whole chain on the context's stream, one kernel after the other, in the reference's order
     int opt_dn_fused = 1;          // ShrinkAllL / ShrinkAllAB -- 0: three kernels per channel (factors, row sums, column sums + update); 2: one kernel per
@@ -1224,9 +1225,13 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     float *madL = mad;
     if (useNoiseCCurve) {
         if (!plane_ok(ccalc) || ccalc->w != w2 || ccalc->h != h2) return fail(ctx, ARTGPU_EINVAL, "rgb_denoise: ccalc must be %dx%d", w2, h2);
-        if ((rc = pool_get(ctx, P_CCALC, n2 * 4, &ccalc_dev))) return rc;
-        HIPCHK(ctx, hipMemcpy2DAsync(ccalc_dev, (size_t)w2 * 4, ccalc->p, (size_t)ccalc->row_stride_bytes, (size_t)w2 * 4, h2,
-                                     ccalc->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        if (ccalc->on_device && (size_t)ccalc->row_stride_bytes == (size_t)w2 * 4) {
+            ccalc_dev = ccalc->p;              // dense and on the device already (the map artgpu_improc_denoise has just computed): read in place
+        } else {
+            if ((rc = pool_get(ctx, P_CCALC, n2 * 4, &ccalc_dev))) return rc;
+            HIPCHK(ctx, hipMemcpy2DAsync(ccalc_dev, (size_t)w2 * 4, ccalc->p, (size_t)ccalc->row_stride_bytes, (size_t)w2 * 4, h2,
+                                         ccalc->on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        }
     }
 
     if (fork && !ctx->dn_stream[0]) {
@@ -1236,8 +1241,17 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     hipStream_t sL = ctx->stream;
 
     // ---- gamma LUTs (built on the device with the SSE-form sleef, color.cc:1128-1161)
-    HIPCHK(ctx, launch_gamma_lut(gamlut, gam, gamthresh, gamslope, 65535.f, 65535.f, sL));
-    HIPCHK(ctx, launch_gamma_lut(gamlut + 65536, igam, igamthresh, igamslope, 65535.f, 65535.f, sL));
+    //      -- once per set of parameters: the pair built by the previous call on this context is still there when they have not changed
+    {
+        const float key[6] = {gam, gamthresh, gamslope, igam, igamthresh, igamslope};
+        if (ctx->gam_tab != gamlut || std::memcmp(ctx->gam_key, key, sizeof key) != 0) {
+            ctx->gam_tab = nullptr;
+            HIPCHK(ctx, launch_gamma_lut(gamlut, gam, gamthresh, gamslope, 65535.f, 65535.f, sL));
+            HIPCHK(ctx, launch_gamma_lut(gamlut + 65536, igam, igamthresh, igamslope, 65535.f, 65535.f, sL));
+            std::memcpy(ctx->gam_key, key, sizeof key);
+            ctx->gam_tab = gamlut;
+        }
+    }
 
     DnPixArgs px = {};
     for (int k = 0; k < 3; ++k) { px.rgb[k] = d.p[k]; px.ws1[k] = ws[3 + k]; }
@@ -2350,6 +2364,7 @@ int artgpu_denoise_compute_params(artgpu_ctx *ctx, const artgpu_rgb *planes, int
     a.gamslope = (float)(std::exp(std::log(static_cast<double>(a.gamthresh)) / a.gam) / a.gamthresh);
     { const double expcomp = std::log(5.f) / std::log(2.f); a.gain = std::pow(2.0f, float(expcomp)); }     // L936, L291
     a.stats = res + 9 * 32;
+    ctx->gam_tab = nullptr;                    // (the slot RGB_denoise keeps its gamma pair in)
     HIPCHK(ctx, launch_gamma_lut(gamlut, a.gam, a.gamthresh, a.gamslope, 65535.f, 32768.f, ctx->stream));
 
     // maps of all nine crops, then their serial statistics on the second stream while this one decomposes

@@ -11,7 +11,7 @@ for f in glob.glob('/tmp/pmc_*/**/*counter_collection.csv', recursive=True):
     per=collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
         k=r['Kernel_Name']
-        if not any(x in k for x in ('rgb2yuv','yuv2rgb','tone_std','chroma_map','mad_window','synthesis0','analysis0','detail_gather','haar_syn')): continue
+        if not any(x in k for x in ('rgb2yuv','yuv2rgb','tone_std','tone_neutral','chroma_map','mad_window','synthesis0','analysis0','detail_gather','haar_syn')): continue
         per[(k.split('(')[0][-40:], r['Counter_Name'], r['Dispatch_Id'])]+=float(r['Counter_Value'])
     for (k,c,d),v in per.items(): acc[k][c].append(v)
 for k,cs in acc.items():

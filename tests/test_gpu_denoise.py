@@ -340,6 +340,31 @@ def test_fused_shrink_pass_repeats_on_one_context(gpu_ctx):
     assert _same(got, first) == [0, 0, 0]
 
 
+def test_gamma_tables_are_rebuilt_when_they_have_to_be(gpu_ctx):
+    """RGB_denoise keeps its gamma / inverse-gamma tables on the context between calls with the same gamma: another gamma, and the
+    AUTOMATIC estimation (which builds its own table in the same slot), have to invalidate them -- every result equals a fresh context's"""
+    img = _rgb(520, 390, 11)
+    MATX = np.array([[0.6325, 0.2312, 0.0921], [0.2198, 0.7712, 0.0090], [0.0166, 0.0713, 0.7514]])
+
+    def run(ctx, gamma):
+        got = [p.copy() for p in img]
+        ctx.rgb_denoise(capi.host_rgb(got), _params(gamma=gamma), O.REC2020_WS, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+        return got
+
+    ref = {}
+    for g in (1.7, 2.4):
+        fresh = capi.Context(0)
+        ref[g] = run(fresh, g)
+        fresh.close()
+    assert _same(ref[1.7], ref[2.4]) != [0, 0, 0]
+    for g in (1.7, 1.7, 2.4, 1.7):
+        assert _same(run(gpu_ctx, g), ref[g]) == [0, 0, 0]
+    auto = capi.DenoiseParams(40.0, 50.0, 0, 15.0, 0.0, 0.0, 1.7, 0, 0, 1)
+    planes = [p.copy() for p in img]
+    gpu_ctx.denoise_compute_params(capi.host_rgb(planes), 0, (1.0, 1.0, 1.0), False, MATX, O.REC2020_WS_D, auto)
+    assert _same(run(gpu_ctx, 1.7), ref[1.7]) == [0, 0, 0]
+
+
 def test_fused_shrink_pass_under_uneven_load():
     """The strips of a band hand their column sums to each other through global memory while the workgroups that hold them come and go:
     three contexts on three host threads run RGB_denoise on frames of different sizes at the same time, ten rounds each, and every result
