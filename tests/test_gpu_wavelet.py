@@ -14,7 +14,7 @@ def same_bits(a, b):
     return bool(np.all(a.view(np.uint32) == b.view(np.uint32)))
 
 
-@pytest.mark.parametrize("w,h,lv", [(129, 97, 5), (258, 196, 6), (321, 255, 5), (1030, 771, 7), (640, 480, 5)])
+@pytest.mark.parametrize("w,h,lv", [(129, 97, 5), (258, 196, 6), (321, 255, 5), (1030, 771, 7), (640, 480, 5), (100, 90, 4), (2050, 300, 3), (1153, 641, 2)])
 def test_decompose_modify_reconstruct(gpu_ctx, w, h, lv):
     import sys
     sys.path.insert(0, G)
