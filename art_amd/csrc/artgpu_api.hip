@@ -364,7 +364,19 @@ const char *artgpu_last_error(const artgpu_ctx *ctx) { return ctx ? ctx->err.c_s
 int artgpu_set_stream(artgpu_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return ARTGPU_EINVAL;
-    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    hipStream_t next = static_cast<hipStream_t>(hip_stream);
+    if (next == ctx->stream) return ARTGPU_OK;
+    // The context's scratch planes and the tables it keeps between calls (curves, gamma / Lab / DCT tables) were last written on the
+    // stream it is leaving: the new stream's work is ordered behind that.  (A previous stream that no longer exists cannot be waited
+    // for -- its work is done by definition -- so a failure here is not an error.)
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+        if (hipEventRecord(ev, ctx->stream) == hipSuccess) (void)hipStreamWaitEvent(next, ev, 0);
+        (void)hipEventDestroy(ev);
+    }
+    (void)hipGetLastError();
+    ctx->stream = next;
     return ARTGPU_OK;
 }
 

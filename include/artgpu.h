@@ -72,7 +72,8 @@ int artgpu_destroy(artgpu_ctx *ctx);
 const char *artgpu_last_error(const artgpu_ctx *ctx);
 const char *artgpu_version(void);
 
-/* Launch all work of this context on `hip_stream` (a hipStream_t; NULL = default stream). */
+/* Launch all work of this context on `hip_stream` (a hipStream_t; NULL = default stream).  Work the context has queued on its previous
+ * stream is ordered before whatever it queues on the new one (its scratch memory and cached tables are shared between the two). */
 int artgpu_set_stream(artgpu_ctx *ctx, void *hip_stream);
 int artgpu_synchronize(artgpu_ctx *ctx);
 /* Test / profiling switches of the context (they never change what a call computes, only which of two bit-identical device

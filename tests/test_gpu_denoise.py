@@ -365,6 +365,38 @@ def test_gamma_tables_are_rebuilt_when_they_have_to_be(gpu_ctx):
     assert _same(run(gpu_ctx, 1.7), ref[1.7]) == [0, 0, 0]
 
 
+def test_context_moves_to_another_stream_between_calls():
+    """artgpu_set_stream: the scratch planes and the tables a context keeps between calls belong to whichever stream wrote them last, so
+    work on the new stream is ordered behind the work left on the old one -- calls alternating between two streams without any host
+    synchronisation in between give the bits of the same calls on one stream"""
+    import torch
+    dev = torch.device("cuda:0")
+    img = _rgb(1400, 1000, 21)
+    ref_ctx = capi.Context(0)
+    ref = []
+    for g in (1.7, 2.2, 1.7):
+        got = [p.copy() for p in img]
+        ref_ctx.rgb_denoise(capi.host_rgb(got), _params(gamma=g), O.REC2020_WS, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+        ref.append(got)
+    ref_ctx.close()
+    s = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    ctx = capi.Context(0, s[0].cuda_stream)
+    src = [torch.from_numpy(p).to(dev) for p in img]
+    outs = []
+    torch.cuda.synchronize()
+    for k, g in enumerate((1.7, 2.2, 1.7)):
+        st = s[k % 2]
+        ctx.set_stream(st.cuda_stream)
+        with torch.cuda.stream(st):
+            work = [t.clone() for t in src]
+            ctx.rgb_denoise(capi.RGB(*[capi.device_plane(t) for t in work]), _params(gamma=g), O.REC2020_WS, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+        outs.append((st, work))
+    torch.cuda.synchronize()
+    ctx.close()
+    for (st, work), r in zip(outs, ref):
+        assert _same([t.cpu().numpy() for t in work], r) == [0, 0, 0]
+
+
 def test_fused_shrink_pass_under_uneven_load():
     """The strips of a band hand their column sums to each other through global memory while the workgroups that hold them come and go:
     three contexts on three host threads run RGB_denoise on frames of different sizes at the same time, ten rounds each, and every result
