@@ -318,6 +318,7 @@ int artgpu_improc_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise
  * and their order are those of the separate calls -- the image is simply not written and read again between them.
  *   demosaiced != NULL: `img` is an output only; its pixels are RawImageSource::getImage(demosaiced, sx1, sy1, skip 1, mul, do_clip) followed
  *                       by convertColorSpace(cam_to_work; NULL = none), evaluated where the denoise reads them (artgpu_get_image's arguments);
+ *                       `img` must not overlap the demosaiced planes (as for artgpu_get_image: the crop shifts the pixels);
  *   exposure_enabled:   ImProcFunctions::exposure(exp_scale, black) (artgpu_exposure's arguments) is applied to the tool's result.
  * A part that cannot be fused for the given parameters (nothing to denoise, the guided smoothing / NL-means stages between the wavelet
  * denoise and the exposure, host planes) runs as the separate call it stands for: same result either way.  fusion == NULL: artgpu_improc_denoise. */
