@@ -25,20 +25,24 @@ template <> struct LeeTw<32> { static constexpr float c[16] = {0.500602998f, 0.5
 
 template <> struct LeeTw<64> { static constexpr float c[32] = {0.500150636f, 0.501358452f, 0.503788726f, 0.507471172f, 0.512451479f, 0.518792713f, 0.526577315f, 0.535909817f, 0.546920438f, 0.559769813f, 0.574655184f, 0.591818536f, 0.611557348f, 0.634238937f, 0.660319808f, 0.690372128f, 0.725120522f, 0.765494165f, 0.812702091f, 0.868344715f, 0.934583597f, 1.01440826f, 1.11207162f, 1.23383274f, 1.38929396f, 1.59397228f, 1.87467598f, 2.28205007f, 2.92462843f, 4.08461108f, 6.79675071f, 20.3738782f}; };
 
-template <int N>
-__device__ __forceinline__ void lee_fwd(float (&x)[N])
+// The recursion over an element type T: float, or a pair of floats (two independent transforms in lockstep, every operation a packed
+// v_pk_add_f32 / v_pk_mul_f32 -- the same IEEE additions and multiplications on each half, so the same bits).
+typedef float lee_f2 __attribute__((ext_vector_type(2)));
+
+template <int N, typename T>
+__device__ __forceinline__ void lee_fwd_t(T (&x)[N])
 {
     if constexpr (N == 1) {
         return;
     } else {
-        float a[N / 2], b[N / 2];
+        T a[N / 2], b[N / 2];
 #pragma unroll
         for (int n = 0; n < N / 2; ++n) {
             a[n] = x[n] + x[N - 1 - n];
             b[n] = (x[n] - x[N - 1 - n]) * LeeTw<N>::c[n];
         }
-        lee_fwd<N / 2>(a);
-        lee_fwd<N / 2>(b);
+        lee_fwd_t<N / 2, T>(a);
+        lee_fwd_t<N / 2, T>(b);
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) {
             x[2 * k] = a[k];
@@ -47,27 +51,69 @@ __device__ __forceinline__ void lee_fwd(float (&x)[N])
     }
 }
 
-template <int N>
-__device__ __forceinline__ void lee_inv(float (&z)[N])
+template <int N, typename T>
+__device__ __forceinline__ void lee_inv_t(T (&z)[N])
 {
     if constexpr (N == 1) {
         return;
     } else {
-        float a[N / 2], b[N / 2];
+        T a[N / 2], b[N / 2];
 #pragma unroll
         for (int k = 0; k < N / 2; ++k) {
             a[k] = z[2 * k];
             b[k] = (k > 0) ? z[2 * k + 1] + z[2 * k - 1] : z[1];
         }
-        lee_inv<N / 2>(a);
-        lee_inv<N / 2>(b);
+        lee_inv_t<N / 2, T>(a);
+        lee_inv_t<N / 2, T>(b);
 #pragma unroll
         for (int n = 0; n < N / 2; ++n) {
-            const float t = b[n] * LeeTw<N>::c[n];
+            const T t = b[n] * LeeTw<N>::c[n];
             z[n] = a[n] + t;
             z[N - 1 - n] = a[n] - t;
         }
     }
 }
+
+// One line of N samples: the two half-size transforms of the first recursion step are independent and have the same shape, so they run
+// as ONE transform over pairs (even half, odd half) -- about half the vector instructions of the scalar recursion, the same operations.
+#ifndef LEE_SCALAR
+template <int N>
+__device__ __forceinline__ void lee_fwd(float (&x)[N])
+{
+    lee_f2 p[N / 2];
+#pragma unroll
+    for (int n = 0; n < N / 2; ++n) {
+        p[n].x = x[n] + x[N - 1 - n];
+        p[n].y = (x[n] - x[N - 1 - n]) * LeeTw<N>::c[n];
+    }
+    lee_fwd_t<N / 2, lee_f2>(p);
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) {
+        x[2 * k] = p[k].x;
+        x[2 * k + 1] = (k + 1 < N / 2) ? p[k].y + p[k + 1].y : p[k].y;
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void lee_inv(float (&z)[N])
+{
+    lee_f2 p[N / 2];
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) {
+        p[k].x = z[2 * k];
+        p[k].y = (k > 0) ? z[2 * k + 1] + z[2 * k - 1] : z[1];
+    }
+    lee_inv_t<N / 2, lee_f2>(p);
+#pragma unroll
+    for (int n = 0; n < N / 2; ++n) {
+        const float t = p[n].y * LeeTw<N>::c[n];
+        z[n] = p[n].x + t;
+        z[N - 1 - n] = p[n].x - t;
+    }
+}
+#else
+template <int N> __device__ __forceinline__ void lee_fwd(float (&x)[N]) { lee_fwd_t<N, float>(x); }
+template <int N> __device__ __forceinline__ void lee_inv(float (&z)[N]) { lee_inv_t<N, float>(z); }
+#endif
 
 } // namespace artgpu

@@ -6,8 +6,8 @@
 // FFTW_MEASURE, L1604,1614,1924-1931): a third-party library whose round-off is not reproducible,
 // so this stage is compared with a tolerance, everything else on the path is
 // bit-exact.  Here one WAVE owns one block: each lane keeps a 64-sample line in registers and
-// runs a straight-line fast DCT-II / DCT-III on it (dct64.h, Lee's recursion: ~770 VALU ops per
-// line instead of 4096), with one LDS transpose between the two dimensions of each transform.
+// runs a straight-line fast DCT-II / DCT-III on it (dct64.h, Lee's recursion: ~770 operations per
+// line instead of 4096, two per packed fp32 instruction), with one LDS transpose between the two dimensions of each transform.
 // ~73 k blocks per 45 MP frame; VALU-bound.
 // Block results go to a block buffer; a second kernel sums the up-to-9 overlapping blocks per
 // pixel in the reference's serial order (vblk, then hblk) -- deterministic, no float atomics.
