@@ -29,6 +29,7 @@ struct artgpu_ctx {
     const float *gam_tab = nullptr; float gam_key[6] = {};   // RGB_denoise's gamma / inverse-gamma tables in pool[P_GAM]: what they were built from
     int opt_lut_lds = 1;           // 0: never the LUT-in-LDS shapes of the pixel passes (tests compare the two)
     int opt_dn_streams = 1;        // 0: the whole chain on the context's stream, one kernel after the other, in the reference's order
+    int ccalc_nonneg = 0;          // set by artgpu_improc_denoise around RGB_denoise: the chroma noise map is the one chroma_map_kernel has just written (squares: no negative value)
     int opt_dn_fused = 1;          // ShrinkAllL / ShrinkAllAB -- 0: three kernels per channel (factors, row sums, column sums + update); 2: one kernel per
                                    // channel; 1: one kernel, and one launch for all three channels where nothing has to happen between them
     std::string err;
@@ -1311,7 +1312,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         else { fa.coef = cin; fa.coef_out = cout; fa.nL = nb; }
         fa.coefL = cL; fa.n = n2; fa.w = w2; fa.h = h2;
         fa.madL = mL; fa.madab = mab;
-        fa.noisevar = ccalc_dev; fa.noisevar_const = nv_const; fa.noisevar_scale = maxNoiseVarab; fa.noisevar_ab[0] = fa.noisevar_ab[1] = noisevar_ab;
+        fa.noisevar = ccalc_dev; fa.noisevar_nonneg = ctx->ccalc_nonneg; fa.noisevar_const = nv_const; fa.noisevar_scale = maxNoiseVarab; fa.noisevar_ab[0] = fa.noisevar_ab[1] = noisevar_ab;
         fa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
         for (int l = 0; l < 10; ++l) fa.rad[l] = bl0.rad[l];
         fa.level0 = lev0; fa.nsub = nb;
@@ -1514,7 +1515,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         FusedShrinkArgs fa = {};
         fa.coef = Ld.bands; fa.coef_out = Lbands2; fa.coefC = Cdd[0].bands; fa.coefL = Ld.bands; fa.n = n2; fa.w = w2; fa.h = h2;
         fa.madL = madL; fa.madab = merged_mad ? mad + nsub : mad + 32; fa.mad_ch_stride = nsub;
-        fa.noisevar = ccalc_dev; fa.noisevar_const = noisevarL; fa.noisevar_scale = maxNoiseVarab;
+        fa.noisevar = ccalc_dev; fa.noisevar_nonneg = ctx->ccalc_nonneg; fa.noisevar_const = noisevarL; fa.noisevar_scale = maxNoiseVarab;
         fa.noisevar_ab[0] = noisevar_abc[0]; fa.noisevar_ab[1] = noisevar_abc[1];
         fa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
         for (int l = 0; l < 10; ++l) fa.rad[l] = bl0.rad[l];
@@ -2577,7 +2578,9 @@ int artgpu_improc_denoise_fused(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_d
     ctx->fuse_post = fuse_post ? (float)std::pow(2.0, -ecomp) : 0.f;
     float iwsf[9];
     if (iws) for (int k = 0; k < 9; ++k) iwsf[k] = (float)iws[k];
+    ctx->ccalc_nonneg = ccalc_p ? 1 : 0;
     rc = artgpu_rgb_denoise(ctx, img, &p->dn, wsf, iws ? iwsf : nullptr, 0.0, scale, ccalc_p, flags, nullptr, nullptr);
+    ctx->ccalc_nonneg = 0;
     ctx->fuse_pre = ctx->fuse_post = 0.f;
     if (rc) return rc;
     // the exposure steps behind the tool's last stage -- its own expcomp(-ecomp) (L1181-1184) where yuv2rgb could not take it, and the STAGE_1

@@ -56,6 +56,24 @@ __device__ __forceinline__ float sl_exp_core(float d)
 __device__ __forceinline__ float xexpf_s(float d) { return d <= -104.0f ? 0.0f : sl_exp_core<false>(d); }
 __device__ __forceinline__ float xexpf_v(float d) { const float u = sl_exp_core<true>(d); return (-104.f > d) ? 0.f : u; }
 __device__ __forceinline__ float xexpf_v_nocheck(float d) { return sl_exp_core<true>(d); }
+// xexpf_v with sl_ldexpk's five multiplications by powers of two as ONE v_ldexp_f32.  Multiplying by a power of two is exact until the value
+// leaves the normal range, so the two agree wherever exp(d) is a normal number; where it is subnormal (d < -87.3) ldexpk rounds more than
+// once and the results can differ in the last bits of a number below 1.2e-38 (scripts/exp_ldexp_check.c walks every float and reports exactly
+// that set).  For callers that add the result to something at least 2^24 times larger -- see the call sites.
+__device__ __forceinline__ float xexpf_v_ldexp(float d)
+{
+    const int q = __float2int_rn(d * ART_R_LN2f);
+    float s = sl_mla((float)q, -ART_L2Uf, d);
+    s = sl_mla((float)q, -ART_L2Lf, s);
+    float u = 0.00136324646882712841033936f;
+    u = sl_mla(u, s, 0.00836596917361021041870117f);
+    u = sl_mla(u, s, 0.0416710823774337768554688f);
+    u = sl_mla(u, s, 0.166665524244308471679688f);
+    u = sl_mla(u, s, 0.499999850988388061523438f);
+    u = 1.0f + sl_mla(s * s, u, s);
+    u = __builtin_amdgcn_ldexpf(u, q);
+    return (-104.f > d) ? 0.f : u;
+}
 
 template <bool VEC>
 __device__ __forceinline__ float sl_log_core(float d)

@@ -413,6 +413,7 @@ struct FusedShrinkArgs {
     const float *madL;      // [bands per channel] SQR(MadRgb) of the L bands
     const float *madab;     // SQR(MadRgb) of the chroma bands: channel c's at madab + c * mad_ch_stride
     const float *noisevar;  // chroma: per-coefficient noise variance map (n floats) or nullptr
+    int noisevar_nonneg;    // the map is known to hold no negative value (the library computed it): see shrinkblur.hip, FASTEXP
     float noisevar_const;   // L: noisevarL
     float noisevar_scale;   // chroma: maxNoiseVarab
     float noisevar_ab[2];   // chroma, per channel (chroma curve off)

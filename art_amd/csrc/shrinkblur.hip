@@ -47,16 +47,26 @@ struct SfConst { float mad_L, levelFactor, madab, rmadLm9, nv_const, nv_scale; i
 
 // TAIL: the block holds coefficients of the band's last n % 4 (the reference's scalar loop tail, other operation order); everywhere else the
 // vector form is the only one, and the factors of a thread's rows are independent straight-line chains the scheduler can interleave
-template <bool AB, bool TAIL>
+// FASTEXP: the exponential's scaling by 2^q as one v_ldexp_f32 instead of sleef's five multiplications by powers of two (xexpf_v_ldexp,
+// devsleef.h: a third of its instructions).  scripts/exp_ldexp_check.c walks every float: the two forms return the same bits except (i) for
+// 35 497 arguments in [-99.36, -89.07], where the result is a subnormal below 2.1e-39 whose last bits depend on how often it was rounded on the way
+// down, and (ii) from +398.9 on, where ldexpk's factors leave the exponent field and the chain returns noise instead of +inf.  The band's
+// constants are tested once per ticket (`fastexp` in the kernel) so that the argument cannot be positive -- it is -(x / y) - z with x, z >= 0
+// by construction and y, z's scale >= 0 by that test --, and a result below 2.1e-39 never reaches the factor: for L it is multiplied by madv <=
+// mag / 801 (the argument is -mag / (9 madv) <= -89) and added to mag, 2^80 times larger; for chroma it is subtracted from 1.  So the factors are
+// the same bits whichever form runs (tests: the fused pass against the three-kernel form and the oracle, both of which scale with ldexpk; strong
+// edges over faint noise in test_fused_shrink_pass_strong_edges_faint_noise put thousands of arguments below -89).
+template <bool AB, bool TAIL, bool FASTEXP = false>
 __device__ __forceinline__ float shrink_factor(const SfConst &k, float c, float cl, float nvv, bool vecform)
 {
     const float eps = 0.01f;
+    auto expv = [](float d) { return FASTEXP ? xexpf_v_ldexp(d) : xexpf_v(d); };
     if constexpr (!AB) {
         const float nv = k.has_nv ? nvv : k.nv_const;
         const float mag = sqr(c);
         if (!TAIL || vecform) {
             const float madv = nv * k.levelFactor;
-            return mag / (mag + madv * xexpf_v(-mag / (9.0f * madv)) + eps);
+            return mag / (mag + madv * expv(-mag / (9.0f * madv)) + eps);
         }
         return mag / (mag + k.levelFactor * nv * xexpf_s(-mag / (9 * k.levelFactor * nv)) + eps);
     } else {
@@ -65,7 +75,7 @@ __device__ __forceinline__ float shrink_factor(const SfConst &k, float c, float 
         if (!TAIL || vecform) {
             const float mad_abv = nvc * k.madab;
             const float mag_L = sqr(cl) * k.rmadLm9;
-            return 1.f - xexpf_v(-(mag_ab / mad_abv) - mag_L);
+            return 1.f - expv(-(mag_ab / mad_abv) - mag_L);
         }
         const float mag_L = sqr(cl);
         return 1.f - xexpf_s(-(mag_ab / (nvc * k.madab)) - (mag_L / (9.f * k.mad_L)));
@@ -136,6 +146,9 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
         kc.madab = a.useNoiseCCurve ? m : m * a.noisevar_ab[ch];
         kc.rmadLm9 = 1.f / (kc.mad_L * 9.f);
     }
+    // (see shrink_factor: with these signs the exponential's argument is <= 0 or NaN; a NaN constant fails the test)
+    const bool fastexp = AB ? ((!kc.has_nv || (a.noisevar_nonneg && kc.nv_scale >= 0.f)) && kc.madab >= 0.f && kc.rmadLm9 >= 0.f)
+                            : kc.nv_const * kc.levelFactor >= 0.f;
     const int R0 = strip * FS_R, Rb = min(R0 + FS_R, H);
     const bool first = strip == 0, last = Rb == H;
     const bool inner = !first && !last;            // window rows [0, 64 + rad) are image rows, rows [0, 64) of them are written
@@ -259,11 +272,11 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
             if (T < NB) {
                 const int col = T * FS_C + lane;
                 const bool tailblk = last && T * FS_C + FS_C > W - 4;
-                auto factors = [&](auto abtag) {                     // (one instantiation per kind of band: no per-row branch on the kind)
-                    constexpr bool ABc = decltype(abtag)::value;
+                auto factors = [&](auto abtag, auto fasttag) {       // (one instantiation per kind of band: no per-row branch on the kind)
+                    constexpr bool ABc = decltype(abtag)::value, FASTc = decltype(fasttag)::value;
                     if (!tailblk) {
                         auto fac = [&](int q) {
-                            const float sf = shrink_factor<ABc, false>(kc, pc[q], pl[q], pn[q], true);
+                            const float sf = shrink_factor<ABc, false, FASTc>(kc, pc[q], pl[q], pn[q], true);
                             if (col < W) S[(rbase + rstride * q) * FS_SWS + (col & (FS_SWIN - 1))] = sf;
                         };
                         if (inner) {
@@ -286,7 +299,8 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
                         }
                     }
                 };
-                if (AB) factors(std::true_type{}); else factors(std::false_type{});
+                if (fastexp) { if (AB) factors(std::true_type{}, std::true_type{}); else factors(std::false_type{}, std::true_type{}); }
+                else { if (AB) factors(std::true_type{}, std::false_type{}); else factors(std::false_type{}, std::false_type{}); }
                 if (T + 1 < NB) fetch(T + 1);
             }
             FS_T1(3)

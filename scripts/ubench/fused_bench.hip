@@ -28,7 +28,7 @@ int main(int argc, char **argv)
     CK(hipMemcpy(nv, one.data(), n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(mad, m.data(), 128 * 4, hipMemcpyHostToDevice));
     FusedShrinkArgs a = {};
     a.coef = coef; a.coef_out = coef2; a.coefC = coefC; a.coefL = coef; a.n = n; a.w = W; a.h = H; a.madL = mad; a.madab = mad + 32; a.mad_ch_stride = 32;
-    a.noisevar = nv; a.noisevar_const = 1.f; a.noisevar_scale = 1.f; a.noisevar_ab[0] = a.noisevar_ab[1] = 1.f; a.useNoiseCCurve = 1;
+    a.noisevar = nv; a.noisevar_nonneg = 1; a.noisevar_const = 1.f; a.noisevar_scale = 1.f; a.noisevar_ab[0] = a.noisevar_ab[1] = 1.f; a.useNoiseCCurve = 1;
     for (int l = 0; l < 10; ++l) a.rad[l] = l + 2;
     a.level0 = 0; a.nsub = NSUB; a.nL = NL; a.nsub_ch = 15; a.prof = prof;
     CK(hipMalloc(&scratch, shrink_blur_scratch_floats(W, H, NSUB, 6) * 4));

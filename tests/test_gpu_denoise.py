@@ -318,6 +318,41 @@ def test_fused_shrink_pass_same_bits_as_three_kernels(gpu_ctx, w, h, kw):
         assert _same(outs[(1, 0)], ref) == [0, 0, 0]
 
 
+@pytest.mark.parametrize("lum,chrom", [(3.0, 2.0), (12.0, 6.0)])
+def test_fused_shrink_pass_strong_edges_faint_noise(gpu_ctx, lum, chrom):
+    """The fused pass scales its exponentials with one v_ldexp_f32 where the three-kernel form and the oracle multiply by powers of two five
+    times (shrinkblur.hip, FASTEXP): the two differ only in subnormal results, for arguments in [-99.4, -89.1] (scripts/exp_ldexp_check.c),
+    which the factor then swallows.  Here nearly every coefficient is far above the noise -- flat squares with hard edges under faint noise and weak
+    denoising: arguments of -10 to -1e9, thousands of them in that window -- and the three forms still have to agree bit for bit, with and
+    without the chroma noise map (the map's coefficients take the fast form only through artgpu_improc_denoise, which knows its sign)."""
+    w, h = 1100, 820
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = []
+    for k, (per, amp) in enumerate(((23, 50000.0), (31, 42000.0), (19, 30000.0))):
+        base = (((xx + 3 * k) // per + (yy + 5 * k) // per) % 2).astype(np.float32) * amp + 4000.0
+        img.append((base + rng.normal(0.0, 2.5, (h, w))).clip(0, 65535).astype(np.float32))
+    p = _params(luminance=lum, chrominance=chrom)
+    outs = {}
+    try:
+        for fused in (1, 0):
+            gpu_ctx.set_option("dn_fused", fused)
+            got = [q.copy() for q in img]
+            gpu_ctx.rgb_denoise(capi.host_rgb(got), p, O.REC2020_WS, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+            tool = [q.copy() for q in img]
+            curve, _ = capi.noise_curve_lut()
+            tp = capi.DenoiseToolParams(p, 0, 3, 0, 80)
+            gpu_ctx.improc_denoise(capi.host_rgb(tool), tp, O.REC2020_WS_D, ecomp=0.0, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+            outs[fused] = (got, tool)
+    finally:
+        gpu_ctx.set_option("dn_fused", 1)
+    assert _same(outs[1][0], outs[0][0]) == [0, 0, 0]
+    assert _same(outs[1][1], outs[0][1]) == [0, 0, 0]
+    ref = O.rgb_denoise(img, O.default_denoise_params(luminance=lum, chrominance=chrom))
+    assert _same(outs[1][0], ref) == [0, 0, 0]
+    assert _same(outs[1][0], img) != [0, 0, 0]
+
+
 def test_fused_shrink_pass_repeats_on_one_context(gpu_ctx):
     """the strips of a band wait for each other through counters in global memory: ten calls in a row, different sizes in between"""
     img = _rgb(1000, 760, 5)
