@@ -62,9 +62,10 @@ __device__ __forceinline__ float xexpf_v_nocheck(float d) { return sl_exp_core<t
 // that set).  For callers that add the result to something at least 2^24 times larger -- see the call sites.
 __device__ __forceinline__ float xexpf_v_ldexp(float d)
 {
-    const int q = __float2int_rn(d * ART_R_LN2f);
-    float s = sl_mla((float)q, -ART_L2Uf, d);
-    s = sl_mla((float)q, -ART_L2Lf, s);
+    const float qf = __builtin_rintf(d * ART_R_LN2f);      // (float)q without the way through the integer: the same number while q fits an int
+    const int q = (int)qf;
+    float s = sl_mla(qf, -ART_L2Uf, d);
+    s = sl_mla(qf, -ART_L2Lf, s);
     float u = 0.00136324646882712841033936f;
     u = sl_mla(u, s, 0.00836596917361021041870117f);
     u = sl_mla(u, s, 0.0416710823774337768554688f);
