@@ -130,6 +130,7 @@ def _load():
     lib.artgpu_get_timings.argtypes = [C.c_void_p, C.POINTER(Timings)]
     lib.artgpu_scratch_bytes.argtypes = [C.c_void_p]
     lib.artgpu_scratch_bytes.restype = C.c_size_t
+    lib.artgpu_trim_scratch.argtypes = [C.c_void_p]
     lib.artgpu_demosaic_bayer.argtypes = [C.c_void_p, C.c_int, C.POINTER(Plane), C.c_uint32, C.c_double, C.c_int, C.POINTER(RGB)]
     lib.artgpu_border_interpolate2.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_uint32, C.c_int, C.POINTER(RGB)]
     lib.artgpu_wavelet_decompose.argtypes = [C.c_void_p, C.POINTER(Plane), C.c_int, C.POINTER(C.c_void_p)]
@@ -191,7 +192,7 @@ def _load():
 LIB = _load()
 
 EXPORTS = ["artgpu_set_progress_callback", "artgpu_set_option", "artgpu_get_option", "artgpu_set_curve_tail", "artgpu_set_curve_tail_parametric", "artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
-           "artgpu_synchronize", "artgpu_enable_timing", "artgpu_get_timings", "artgpu_scratch_bytes",
+           "artgpu_synchronize", "artgpu_enable_timing", "artgpu_get_timings", "artgpu_scratch_bytes", "artgpu_trim_scratch",
            "artgpu_demosaic_bayer", "artgpu_border_interpolate2", "artgpu_get_image",
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_mad", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
@@ -262,6 +263,9 @@ class Context:
 
     def scratch_bytes(self) -> int:
         return LIB.artgpu_scratch_bytes(self._h)
+
+    def trim_scratch(self):
+        self._chk(LIB.artgpu_trim_scratch(self._h))
 
     def demosaic_bayer(self, method: int, raw: Plane, filters: int, initial_gain: float, border: int, out: RGB):
         self._chk(LIB.artgpu_demosaic_bayer(self._h, method, C.byref(raw), filters, initial_gain, border, C.byref(out)))

@@ -33,6 +33,7 @@ struct artgpu_ctx {
     int opt_dn_fused = 1;          // ShrinkAllL / ShrinkAllAB -- 0: three kernels per channel (factors, row sums, column sums + update); 2: one kernel per
                                    // channel; 1: one kernel, and one launch for all three channels where nothing has to happen between them
     std::string err;
+    int *fs_diag = nullptr;        // pinned host words the fused shrink pass writes before it traps (which strip waited for which): see fail()
     // per-workgroup work arenas (demosaic)
     float *arena = nullptr;
     size_t arena_bytes = 0;
@@ -103,7 +104,17 @@ int fail(artgpu_ctx *ctx, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
+    if (ctx) {
+        ctx->err = buf;
+        // a fault raised by the fused shrink pass's bounded wait (shrinkblur.hip) is attributed: the kernel left these words in pinned host
+        // memory before it trapped, the queue only reports a generic launch failure
+        if (code == ARTGPU_EHIP && ctx->fs_diag && (unsigned)ctx->fs_diag[0] == 0xF5D1A600u) {
+            char more[192];
+            snprintf(more, sizeof more, " [shrink_blur_kernel: band %d strip %d waited 5 s for the strip above to hand down block %d (its counter: %d)]",
+                     ctx->fs_diag[1], ctx->fs_diag[2], ctx->fs_diag[3], ctx->fs_diag[4]);
+            ctx->err += more;
+        }
+    }
     return code;
 }
 
@@ -336,6 +347,7 @@ int artgpu_destroy(artgpu_ctx *ctx)
         if (ctx->stage[k]) (void)hipFree(ctx->stage[k]);
     if (ctx->lut) (void)hipFree(ctx->lut);
     if (ctx->tab_ring) (void)hipHostFree(ctx->tab_ring);
+    if (ctx->fs_diag) (void)hipHostFree(ctx->fs_diag);
     if (ctx->tab_ev) (void)hipEventDestroy(ctx->tab_ev);
     if (ctx->bbox) (void)hipFree(ctx->bbox);
     if (ctx->amz_lists) (void)hipFree(ctx->amz_lists);
@@ -478,6 +490,28 @@ size_t artgpu_scratch_bytes(const artgpu_ctx *ctx)
     s += ctx->lut_bytes;
     for (int k = 0; k < artgpu_ctx::NPOOL; ++k) s += ctx->pool_bytes[k];
     return s;
+}
+
+int artgpu_trim_scratch(artgpu_ctx *ctx)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // nothing may still be running on what is about to be freed: the context's stream and the side streams it forks to
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->aux) HIPCHK(ctx, hipStreamSynchronize(ctx->aux));
+    if (ctx->dn_stream[0]) HIPCHK(ctx, hipStreamSynchronize(ctx->dn_stream[0]));
+    if (ctx->amz_side) HIPCHK(ctx, hipStreamSynchronize(ctx->amz_side));
+    auto drop = [](float **p, size_t *b) { if (*p) (void)hipFree(*p); *p = nullptr; *b = 0; };
+    drop(&ctx->arena, &ctx->arena_bytes);
+    for (int k = 0; k < artgpu_ctx::NSTAGE; ++k) drop(&ctx->stage[k], &ctx->stage_bytes[k]);
+    for (int k = 0; k < artgpu_ctx::NPOOL; ++k) drop(&ctx->pool[k], &ctx->pool_bytes[k]);
+    // host-side records of what pool slots held: the tables are gone with them
+    ctx->gam_tab = nullptr;
+    ctx->ncurve_host.clear();
+    for (int k = 0; k < 3; ++k) ctx->rgbcurve_host[k].clear();
+    int rc = ARTGPU_OK;
+    for (artgpu_ctx *l : ctx->lanes) { const int r = artgpu_trim_scratch(l); if (r && !rc) rc = r; }
+    return rc;
 }
 
 // Host-side milestones of an entry point: the reference's ProgressListener (rtengine.h:165; amaze_demosaic_RT.cc:1567-1580 reports
@@ -1215,12 +1249,26 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         (rc = pool_get(ctx, P_HISTO, (merged_mad ? 3 : 1) * histo_bytes, &histo_fc[0])) ||
         (rc = pool_get(ctx, P_MAD, 3 * 32 * 4, &mad)) || (rc = pool_get(ctx, P_GAM, 2 * 65536 * 4, &gamlut)))
         return rc;
+    // a context that changes between the two forms of the passes gives back what only the other form uses (everything else is shared)
+    auto pool_drop = [&](int slot) -> int {
+        if (!ctx->pool[slot]) return ARTGPU_OK;
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->dn_stream[0]) HIPCHK(ctx, hipStreamSynchronize(ctx->dn_stream[0]));
+        HIPCHK(ctx, hipFree(ctx->pool[slot]));
+        ctx->pool[slot] = nullptr; ctx->pool_bytes[slot] = 0;
+        return ARTGPU_OK;
+    };
     if (fused) {
+        if ((rc = pool_drop(P_SF_A)) || (rc = pool_drop(P_SF_B)) || (merged && (rc = pool_drop(P_CBANDS2)))) return rc;
+        if (!ctx->fs_diag) {      // (optional: without it a timed-out wait still traps, merely unattributed)
+            if (hipHostMalloc(reinterpret_cast<void **>(&ctx->fs_diag), 64, hipHostMallocDefault) == hipSuccess) std::memset(ctx->fs_diag, 0, 64);
+            else { ctx->fs_diag = nullptr; (void)hipGetLastError(); }
+        }
         if ((rc = pool_get(ctx, P_FUSED, shrink_blur_scratch_floats(w2, h2, merged ? 3 * nsub : nsub, maxrad) * 4, &fused_scratch))) return rc;
         // the chroma factors need the L coefficients as the decomposition left them: whenever they are evaluated beside or after the L pass
         // (one launch for all channels; the side stream's order) the L pass writes a second band set instead of updating the first
         if ((fork || merged) && (rc = pool_get(ctx, P_LBANDS2, band_bytes, &Lbands2))) return rc;
-    } else if ((rc = pool_get(ctx, P_SF, band_bytes, &sfc[0])) || (rc = pool_get(ctx, P_TMP, band_bytes, &tmp1))) return rc;
+    } else if ((rc = pool_drop(P_FUSED)) || (rc = pool_drop(P_LBANDS2)) || (rc = pool_get(ctx, P_SF, band_bytes, &sfc[0])) || (rc = pool_get(ctx, P_TMP, band_bytes, &tmp1))) return rc;
     tmpc[0] = tmpc[1] = tmpc[2] = tmp1;
     if (two_chroma) {
         if (merged_mad) Cdd[0].bands = Ld.bands + (size_t)nsub * n2;       // (one MadRgb launch set walks the bands of all three channels)
@@ -1315,7 +1363,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         fa.noisevar = ccalc_dev; fa.noisevar_nonneg = ctx->ccalc_nonneg; fa.noisevar_const = nv_const; fa.noisevar_scale = maxNoiseVarab; fa.noisevar_ab[0] = fa.noisevar_ab[1] = noisevar_ab;
         fa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
         for (int l = 0; l < 10; ++l) fa.rad[l] = bl0.rad[l];
-        fa.level0 = lev0; fa.nsub = nb;
+        fa.level0 = lev0; fa.nsub = nb; fa.diag = ctx->fs_diag;
         HIPCHK(ctx, launch_shrink_blur(fa, fused_scratch, sL));
         return ARTGPU_OK;
     };
@@ -1519,7 +1567,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         fa.noisevar_ab[0] = noisevar_abc[0]; fa.noisevar_ab[1] = noisevar_abc[1];
         fa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
         for (int l = 0; l < 10; ++l) fa.rad[l] = bl0.rad[l];
-        fa.level0 = 0; fa.nsub = 3 * nsub; fa.nL = nsub; fa.nsub_ch = nsub;
+        fa.level0 = 0; fa.nsub = 3 * nsub; fa.nL = nsub; fa.nsub_ch = nsub; fa.diag = ctx->fs_diag;
         HIPCHK(ctx, launch_shrink_blur(fa, fused_scratch, sL));
         return ARTGPU_OK;
     };

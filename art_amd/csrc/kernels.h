@@ -430,6 +430,7 @@ struct FusedShrinkArgs {
     int wpad;               // columns of a slot row (whole blocks)
     int *progress;          // [nsub][nstrips] blocks a strip has handed down
     int *ticket;
+    int *diag;              // pinned host words (or nullptr): {magic, band, strip, block, counter} written before the bounded wait traps
     long long *prof;        // -DFS_PROFILE: cycle counters (step time, busy time per role and per wave, time spent waiting for the strip above)
 };
 bool shrink_blur_supported(int w, int h, const int *rad, int level0, int nsub);

@@ -23,6 +23,15 @@
 #include "devmath.h"
 #include "devsleef.h"
 #include <type_traits>
+#include <mutex>
+
+// Hardware assumption of the strip-to-strip hand-over below (the hand-over wave's `s_waitcnt vmcnt(0)` between its data stores and its flag
+// store, relaxed agent-scope accesses on both sides): on the gfx9 family -- gfx942, gfx950 -- stores count in vmcnt, so the wait covers them,
+// and agent-scope (sc1) stores write through the XCD's L2 while agent-scope loads miss it; a target with a separate store counter (vscnt)
+// could publish the flag ahead of the data.  This translation unit is therefore only valid for those two targets.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "shrinkblur.hip: the strip hand-over relies on the gfx942 / gfx950 memory model (stores counted in vmcnt, write-through sc1 stores)"
+#endif
 
 namespace artgpu {
 
@@ -30,6 +39,14 @@ namespace {
 
 constexpr int FS_R = 64, FS_C = 64, FS_T = 1024, FS_NE = FS_T / 64 - 3;   // 16 waves: row sums, column sums, hand-over, 13 elementwise
 constexpr int FS_SWIN = 256, FS_SWS = FS_SWIN + 1;                          // factor window: 256 columns (circular), odd row stride
+// Hand-over slots per band.  Strip s reads slot s % FS_RING (written by strip s - 1) and writes slot (s + 1) % FS_RING.  Two are enough: strip
+// s + 1 stores block j of ITS hand-over -- into the slot strip s reads -- only behind its own wait for `progress[s] >= j + 1` (the hand-over wave
+// polls before it stores, and a strip's steps are separated by workgroup barriers), and strip s publishes j + 1 at its step j + 4, three steps
+// after its column sums consumed block j of that slot.  So a slot is rewritten only behind its reader, and nobody waits for anything the
+// per-strip slots of rounds 4 did not make them wait for: 45 bands x 2 x 266 KB = 24 MB instead of 0.5 GB for a 45 MP frame.
+constexpr int FS_RING = 2;
+constexpr unsigned FS_DIAG_MAGIC = 0xF5D1A600u;
+constexpr long long FS_WAIT_TICKS = 500000000LL;                           // 5 s of the 100 MHz s_memrealtime clock
 
 // Barrier for data that travels through LDS only: __syncthreads() would also wait for this wave's global loads -- the coefficients of the
 // next block, fetched a step ahead precisely so that nobody waits for them
@@ -157,8 +174,8 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
     const int nov = 2 * rad + 1;
     const int NB = (W + rad + FS_C - 1) / FS_C;
     const size_t slot = (size_t)(2 * MAXR + 2) * a.wpad;
-    float *const hand_hb = a.hand + (size_t)(sub * a.nstrips + strip) * slot;      // what the strip above left for this one, block-major:
-    float *const hand_nx = hand_hb + slot;                                         // [block][2 MAXR + 2 rows][64 columns]
+    float *const hand_hb = a.hand + (size_t)(sub * FS_RING + strip % FS_RING) * slot;        // what the strip above left for this one, block-major:
+    float *const hand_nx = a.hand + (size_t)(sub * FS_RING + (strip + 1) % FS_RING) * slot;  // [block][2 MAXR + 2 rows][64 columns]
     int *const prog = a.progress + sub * a.nstrips;
 
     // ---- elementwise waves: registers that travel a step ahead (clamped addresses: every load is unconditional)
@@ -193,11 +210,25 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
         if (seen < J + 1) {
             FS_T0
             int v, spins = 0;
+            long long t_wait = 0;
             while ((v = __hip_atomic_load(prog + strip - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < J + 1) {
                 __builtin_amdgcn_s_sleep(2);
                 // the strip above belongs to a ticket taken before this one, i.e. to a running workgroup: the wait is bounded by that strip's
-                // progress.  Should that ever not hold (seconds without the counter moving), fail loudly instead of hanging the device.
-                if (++spins > (1 << 23)) __builtin_trap();
+                // progress.  Should that ever not hold -- FIVE SECONDS of the constant 100 MHz clock without the counter getting there, not a
+                // number of polls: under a debugger, thread tracing, power capping or CU masking a healthy run is merely slow --, say where
+                // (pinned host words the library reads when the queue reports the fault: artgpu_last_error) and fail loudly instead of
+                // hanging the device.
+                if ((++spins & 1023) == 0) {
+                    const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+                    if (t_wait == 0) t_wait = now;
+                    else if (now - t_wait > FS_WAIT_TICKS) {
+                        if (a.diag && lane == 0) {
+                            a.diag[1] = sub; a.diag[2] = strip; a.diag[3] = J; a.diag[4] = v;
+                            __hip_atomic_store(a.diag, (int)FS_DIAG_MAGIC, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                        __builtin_trap();
+                    }
+                }
             }
             seen = v;
             FS_T1(6)
@@ -429,7 +460,7 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
                 HBj[HROWS * HS + lane] = tvpre;
             }
             if (!last && T >= 4) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (gfx942 / gfx950: this wave's data stores have left -- see the #error at the top)
                 if (lane == 0) __hip_atomic_store(prog + strip, T - 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (!first && T < NB) prefetch_hand(T);
@@ -464,10 +495,16 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
 }
 
 template <int MAXR>
-hipError_t launch_one(const FusedShrinkArgs &a, hipStream_t s)
+constexpr int fs_lds_bytes()
 {
     constexpr int SROWS = FS_R + MAXR, HROWS = FS_R + 2 * MAXR + 1, HS = FS_C + 1;
-    constexpr int lds = (SROWS * FS_SWS + 3 * (HROWS + 2) * HS) * (int)sizeof(float);
+    return (SROWS * FS_SWS + 3 * (HROWS + 2) * HS) * (int)sizeof(float);
+}
+
+template <int MAXR>
+hipError_t launch_one(const FusedShrinkArgs &a, hipStream_t s)
+{
+    constexpr int lds = fs_lds_bytes<MAXR>();
     static_assert(lds <= 160 * 1024 - 64, "LDS");
     hipError_t e = dyn_lds_once(reinterpret_cast<const void *>(shrink_blur_kernel<MAXR>), lds);
     if (e != hipSuccess) return e;
@@ -480,22 +517,44 @@ hipError_t launch_one(const FusedShrinkArgs &a, hipStream_t s)
 
 } // namespace
 
+// What a workgroup of the current device may have: the kernel needs 137 KB (radii up to 7) or 157 KB (up to 15) of dynamic LDS and 1024
+// threads; a device (or a build for another target) with less gets the three-kernel form of the passes instead of a failing launch.
+static bool fs_device_fits(int lds_bytes)
+{
+    static std::mutex m;
+    static int lds_of[64], thr_of[64];
+    static bool known[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lk(m);
+    if (!known[dev]) {
+        int l = 0, t = 0;
+        if (hipDeviceGetAttribute(&l, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) l = 0;
+        if (hipDeviceGetAttribute(&t, hipDeviceAttributeMaxThreadsPerBlock, dev) != hipSuccess) t = 0;
+        lds_of[dev] = l; thr_of[dev] = t; known[dev] = true;
+    }
+    return lds_of[dev] >= lds_bytes && thr_of[dev] >= FS_T;
+}
+
 bool shrink_blur_supported(int w, int h, const int *rad, int level0, int nsub)
 {
     if (w < 64 || h < 64 || nsub < 1 || (long long)w * h >= (1LL << 31)) return false;
+    int maxr = 0;
     for (int sub = 0; sub < nsub; ++sub) {
         const int r = rad[level0 + sub / 3];
         if (r < 1 || r > 15) return false;
+        maxr = r > maxr ? r : maxr;
     }
-    return true;
+    return fs_device_fits(maxr > 7 ? fs_lds_bytes<15>() : fs_lds_bytes<7>());
 }
 static int fs_strips(int h) { return (h + FS_R - 1) / FS_R; }
 static int fs_wpad(int w) { return ((w + 15 + FS_C - 1) / FS_C) * FS_C; }      // NB blocks of 64 columns (rad <= 15)
 size_t shrink_blur_scratch_floats(int w, int h, int nsub, int maxr)
 {
     const int rows = 2 * (maxr > 7 ? 15 : 7) + 2;
-    // (nsub * nstrips + 1) hand-over slots of `rows` x wpad floats, then the progress counters and the ticket (ints)
-    return (size_t)(nsub * fs_strips(h) + 1) * rows * fs_wpad(w) + (size_t)nsub * fs_strips(h) + 64;
+    // FS_RING hand-over slots of `rows` x wpad floats per band (live only while the two strips either side of them are in flight), then the
+    // progress counters and the ticket (ints)
+    return (size_t)nsub * FS_RING * rows * fs_wpad(w) + (size_t)nsub * fs_strips(h) + 64;
 }
 
 hipError_t launch_shrink_blur(FusedShrinkArgs a, float *scratch, hipStream_t s)
@@ -508,7 +567,7 @@ hipError_t launch_shrink_blur(FusedShrinkArgs a, float *scratch, hipStream_t s)
     a.nstrips = fs_strips(a.h);
     a.wpad = fs_wpad(a.w);
     a.hand = scratch;
-    a.progress = reinterpret_cast<int *>(scratch + (size_t)(a.nsub * a.nstrips + 1) * rows * a.wpad);
+    a.progress = reinterpret_cast<int *>(scratch + (size_t)a.nsub * FS_RING * rows * a.wpad);
     a.ticket = a.progress + a.nsub * a.nstrips;
     hipError_t e = hipMemsetAsync(a.progress, 0, ((size_t)a.nsub * a.nstrips + 1) * sizeof(int), s);
     if (e != hipSuccess) return e;

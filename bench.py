@@ -437,6 +437,7 @@ def main() -> None:
                          + ("(BASELINE configs[4])" if xtrans else "(per-frame pipe of BASELINE configs[3])" if smoothing else "(BASELINE configs[2])"))
                         if pipeline else f"{args.workload.upper()} demosaic only, {W}x{H} Bayer RGGB fp32 (BASELINE configs[1])",
             "stage_ms": stage_ms,
+            "stage_ms_schema": 2 if (pipeline and fused_tool) else 1,     # 1: one key per reference stage; 2: the fused tool's three stages as one key
             "stage_calls": ("fused tool: artgpu_improc_denoise_fused (getImage + matrix in front of ImProcFunctions::denoise, exposure behind it, inside its pixel passes)"
                             if pipeline and fused_tool else "one call per stage"),
             "frame": f"{W}x{H}", "frames_per_step": world * args.lanes, "lanes_per_gpu": args.lanes,
@@ -496,6 +497,42 @@ def main() -> None:
         barrier()
         n_ms = 1e3 * (time.perf_counter() - n0) / nn
         result["neutral_tone"] = {"ms_per_step": round(n_ms, 4), "value": round(mp / (n_ms / 1e3), 2), "unit": "MP/s", "steps": nn}
+
+    # Round-over-round comparability: up to round 3 `stage_ms` had one key per reference stage (demosaic / get_image+matrix / denoise /
+    # exposure / tone_curve); since round 4 the default step calls the fused tool and the three middle stages are one key.  The line carries
+    # BOTH: `config.stage_ms` describes the timed steps (schema 2 when the fused tool runs), `separate_stages` times a few steps with one
+    # call per stage and reports the round-1..3 keys -- the difference between the two ms_per_step figures is what the API-level fusion is
+    # worth, as opposed to kernel work.
+    if pipeline and fused_tool and world == 1 and args.tone == "std" and args.lanes == 1:
+        sep_names = ["demosaic", "get_image+matrix", "denoise", "exposure", "tone_curve"]
+        ns_ = max(1, min(args.steps, 5))
+        sev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(sep_names) + 1)] for _ in range(ns_)]
+
+        def step_separate(ev=None):
+            def mk(k):
+                if ev is not None:
+                    ev[k].record(stream)
+            mk(0)
+            ctx.demosaic_xtrans(3, True, p_raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, out) if xtrans else ctx.demosaic_bayer(method, p_raw, filt, 1.0, border, out)
+            mk(1)
+            ctx.get_image(out, border, border, mul, True, mat, img)
+            mk(2)
+            ctx.improc_denoise(img, dn, ws, ecomp=expcomp, calclum_mat=mat, noise_c_curve=ccurve)
+            mk(3)
+            ctx.exposure(img, exp_scale, 0.0)
+            mk(4)
+            ctx.tone_curve(img, lut, 1.0, True)
+            mk(5)
+        step_separate()
+        barrier()
+        q0 = time.perf_counter()
+        for k in range(ns_):
+            step_separate(sev[k])
+        barrier()
+        q_ms = 1e3 * (time.perf_counter() - q0) / ns_
+        result["separate_stages"] = {"ms_per_step": round(q_ms, 4), "value": round(mp / (q_ms / 1e3), 2), "unit": "MP/s", "steps": ns_,
+                                     "stage_ms": {nm: round(statistics.mean(ev[i].elapsed_time(ev[i + 1]) for ev in sev), 4) for i, nm in enumerate(sep_names)},
+                                     "stage_calls": "one call per stage (the round-1..3 key set; flag: --separate-stages)"}
 
     # what `--lanes 2` gives (a second frame in flight on its own context / stream / host thread), beside the one-frame-per-step line
     if pipeline and world == 1 and args.lanes == 1 and args.sustained_seconds > 0:

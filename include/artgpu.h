@@ -518,9 +518,16 @@ int artgpu_set_batch_lanes(artgpu_ctx *ctx, int lanes);
 int artgpu_batch_complete(artgpu_ctx *ctx, void *rccl_comm, int nranks, const int64_t record[ARTGPU_BATCH_RECORD_WORDS], int64_t *all_records);
 
 /* Bytes of device scratch the context currently holds (arena + staging + the denoise pool: for a 45 MP frame through
- * artgpu_improc_denoise about 5.5 GB -- two L band sets, the chroma band sets of both channels, the DCT block buffer, the hand-over slots of
- * the fused shrink pass -- per context and per batch lane; grown on demand, kept between frames). */
+ * artgpu_improc_denoise about 5.0 GB -- two L band sets, the chroma band sets of both channels, the DCT block buffer; the hand-over ring of the
+ * fused shrink pass is 24 MB -- per context and per batch lane; grown on demand, kept between frames, artgpu_trim_scratch gives it back). */
 size_t artgpu_scratch_bytes(const artgpu_ctx *ctx);
+
+/* Gives the context's device scratch back to the driver (work arenas, staging planes, the denoise pool, of the context and of its batch
+ * lanes): waits for the context's queued work first, keeps settings, curves and streams; the next call grows what it needs again and rebuilds
+ * the tables that lived in the pool.  The reference frees its scratch when each tool returns (FTblockDN.cc:2655-2689, amaze_demosaic_RT.cc:1583);
+ * the device path keeps it between frames because allocation is what a steady-state batch must not pay for -- this is the call for the moment
+ * a batch is over, a much smaller frame size follows, or several contexts / ranks have to share one GPU's memory. */
+int artgpu_trim_scratch(artgpu_ctx *ctx);
 
 #ifdef __cplusplus
 }

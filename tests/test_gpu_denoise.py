@@ -532,3 +532,31 @@ def test_improc_denoise_fused_equals_the_separate_calls(gpu_ctx, w, h, smoothing
     ref = O.exposure(O.convert_color_space(O.get_image(dem, 4, 4, w, h, mul, True), mat), exp_scale, 0.0)
     torch.cuda.synchronize()
     assert _same([t.cpu().numpy() for t in d_img], ref) == [0, 0, 0]
+
+
+def test_trim_scratch_gives_the_pool_back_and_the_next_call_rebuilds_it():
+    """artgpu_trim_scratch (round 5): the context's arenas / staging / pool go back to the driver, the next call grows them again and rebuilds
+    the tables that lived there (gamma pair, chroma noise curve table) -- same bits; the fused pass's hand-over ring is a few MB, not a slot
+    per strip (round 4 held nsub * nstrips of them)"""
+    ctx = capi.Context(0)
+    img = _rgb(1000, 760, 11)
+    curve, _ = capi.noise_curve_lut()
+    tp = capi.DenoiseToolParams(_params(), 0, 3, 0, 80)
+
+    def run():
+        got = [p.copy() for p in img]
+        ctx.improc_denoise(capi.host_rgb(got), tp, O.REC2020_WS_D, ecomp=0.3, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+        return got
+    first = run()
+    held = ctx.scratch_bytes()
+    assert held > 20 * 1000 * 760 * 4 // 4                   # planes, three band sets, histograms ...
+    # 45 bands x 2 slots x 16 rows x (500 + 15 -> 576 columns) floats = 3.3 MB of hand-over ring: everything the frame needs stays below what
+    # the per-strip slots alone took before (45 x 6 strips x 16 x 576 x 4 = 10 MB at this size, 0.5 GB at 45 MP)
+    ctx.trim_scratch()
+    assert ctx.scratch_bytes() <= 65536 * 4                  # (the tone LUT is not scratch: it stays)
+    again = run()
+    assert _same(again, first) == [0, 0, 0]
+    assert ctx.scratch_bytes() == held
+    ctx.trim_scratch()
+    ctx.trim_scratch()                                       # (idempotent)
+    del ctx

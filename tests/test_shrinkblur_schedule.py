@@ -257,3 +257,71 @@ def test_hand_over_lag():
     lag = max(publish_step(J) - need_at(J) for J in range(nb))
     assert lag == 4
     assert 15 * (nb // lag) < 256 <= 45 * (nb // lag)     # one channel cannot fill 256 CUs, three can
+
+
+# ---------------------------------------------------------------- 3. the hand-over ring (round 5)
+def simulate_hand_over_ring(nstrips, nb, ring, rng, greedy_below=False, wait=True):
+    """The strips of ONE band, each a sequence of steps T = 0 .. nb + 3 whose hand-over wave does, in program order (shrinkblur.hip, the
+    `else` role of the step loop): publish progress = T - 3 (T >= 4); wait for progress[s - 1] >= T + 1 and READ block T of slot s % ring
+    (T < nb); STORE block T - 2's rows and block T - 3's column sums into slot (s + 1) % ring.  Strips advance in an arbitrary interleaving
+    (any strip that is not blocked may take its next step: workgroups run at unrelated speeds); stores land the moment they are issued -- the
+    worst case for a slot that is rewritten behind its reader.  Every read has to find what strip s - 1 wrote."""
+    step = [0] * nstrips                      # next step of strip s
+    prog = [0] * nstrips
+    rows_tag = [[None] * nb for _ in range(ring)]      # which strip wrote block j's rows / column sums of ring slot k (per band)
+    tv_tag = [[None] * nb for _ in range(ring)]
+    started = 1                               # strips come into being in ticket order
+    reads = 0
+    while any(step[s] < nb + 4 for s in range(nstrips)):
+        runnable = []
+        for s in range(started):
+            T = step[s]
+            if T >= nb + 4:
+                continue
+            if wait and s > 0 and T < nb and prog[s - 1] < T + 1:
+                continue                      # (blocked in prefetch_hand: the strip's other roles wait at the barrier)
+            runnable.append(s)
+        if started < nstrips and (not runnable or rng.random() < 0.3):
+            started += 1
+            continue
+        assert runnable, "deadlock"
+        s = max(runnable) if greedy_below else runnable[int(rng.integers(len(runnable)))]
+        T = step[s]
+        last = s == nstrips - 1
+        if not last and T >= 4:
+            prog[s] = T - 3
+        if s > 0 and T < nb:
+            k = s % ring
+            assert rows_tag[k][T] == s - 1 and tv_tag[k][T] == s - 1, (s, T, rows_tag[k][T], tv_tag[k][T])
+            reads += 1
+        if not last:
+            k = (s + 1) % ring
+            if 0 <= T - 2 < nb:
+                rows_tag[k][T - 2] = s
+            if 0 <= T - 3 < nb:
+                tv_tag[k][T - 3] = s
+        step[s] = T + 1
+    return reads
+
+
+@pytest.mark.parametrize("greedy", [False, True])
+def test_two_hand_over_slots_per_band_are_enough(greedy):
+    """FS_RING = 2: strip s + 1 rewrites the slot strip s reads only behind its own wait for strip s's counter, and strip s counts a block
+    three steps after it consumed it.  Random interleavings, and the adversarial one (always the lowest strip that can move = the writer below
+    races ahead of its reader as far as the protocol lets it)."""
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        nstrips = int(rng.integers(2, 12)); nb = int(rng.integers(1, 20))
+        assert simulate_hand_over_ring(nstrips, nb, 2, rng, greedy) == (nstrips - 1) * nb
+
+
+def test_the_model_sees_a_strip_that_does_not_wait():
+    """the model does see what it is there to exclude: without the wait for the strip above a strip reads slots nobody has filled yet (or,
+    with few slots, ones the strip below has already rewritten).  (With the wait even ONE slot per band passes this model -- a strip stores
+    block j two steps after it read block j -- two keep a wave from reading and rewriting the same addresses.)"""
+    rng = np.random.default_rng(6)
+    with pytest.raises(AssertionError):
+        for trial in range(20):
+            simulate_hand_over_ring(6, 12, 2, rng, wait=False)
+    for trial in range(20):
+        simulate_hand_over_ring(6, 12, 1, rng)
