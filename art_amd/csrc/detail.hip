@@ -21,6 +21,7 @@ namespace artgpu {
 
 namespace {
 constexpr int TS = 64, OFF = 25, BLKRAD = 1;
+constexpr int NXCD = 8;                         // XCDs of an MI355X (workgroups are dispatched to them round robin)
 __device__ __forceinline__ int reflect(int v, int n)
 {
     // datarow / row padding of detail_recovery (L1545-1562)
@@ -38,8 +39,17 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
     constexpr int XR = 4;                       // spare rows, >= blur radius + 1
     __shared__ float B[TS + XR][TS + 1];
     const int lane = threadIdx.x;
-    const int blk = blockIdx.x;
-    const int vblk = blk / a.numblox_W, hblk = blk - vblk * a.numblox_W;
+    // Blocks overlap 64 / 25 = 2.56 x per axis, so a pixel of Lin / L is wanted by up to nine blocks: 2.4 GB of loads for 0.36 GB of
+    // planes on a 45 MP frame.  Workgroups are dealt to the eight XCDs round robin (workgroup b runs on XCD b % 8, each with an L2 of its
+    // own), so in raster order every XCD's L2 saw every image row in flight -- the ~7 block rows the chip holds at once = 240 image rows x
+    // the whole width = 16 MB against 4 MB of L2 -- and nearly every load missed (counters: 3.7 GB per launch).  Here XCD k owns the
+    // k-th eighth of the block COLUMNS and walks it in raster order: its L2 sees 240 rows x an eighth of the width = 2 MB, and the
+    // re-reads stay on the XCD.  (Which workgroup computes a block does not change the block: same bits.)
+    const int wk = (a.numblox_W + NXCD - 1) / NXCD;
+    const int xcd = blockIdx.x % NXCD, idx = blockIdx.x / NXCD;
+    const int vblk = idx / wk, hblk = xcd * wk + (idx - vblk * wk);
+    if (hblk >= a.numblox_W) return;            // (the ragged eighth; uniform over the workgroup)
+    const int blk = vblk * a.numblox_W + hblk;
     const int top = (vblk - BLKRAD) * OFF, left = (hblk - BLKRAD) * OFF;
     constexpr int rad = RAD;                    // = a.blur_rad, 1..3 (XR - 1)
     float x[TS];
@@ -190,7 +200,7 @@ __global__ void __launch_bounds__(1024) detail_gather_kernel(DetailArgs a)
 hipError_t launch_detail_blocks(const DetailArgs &a, hipStream_t s)
 {
     // blur_rad = max(1, int(3 / scale)), scale >= 1 (FTblockDN.cc:1499): 1, 2 or 3
-    const dim3 grid(a.numblox_W * a.numblox_H);
+    const dim3 grid(NXCD * ((a.numblox_W + NXCD - 1) / NXCD) * a.numblox_H);      // (an eighth of the block columns per XCD, padded)
     switch (a.blur_rad) {
     case 1: hipLaunchKernelGGL(detail_blocks_kernel<1>, grid, dim3(64), 0, s, a); break;
     case 2: hipLaunchKernelGGL(detail_blocks_kernel<2>, grid, dim3(64), 0, s, a); break;
