@@ -48,6 +48,7 @@ struct artgpu_ctx {
     // artgpu_batch_run lanes: sibling contexts (own stream, arena, pools) that take every lanes-th frame on their own host thread
     std::vector<artgpu_ctx *> lanes;
     int batch_lanes = 1;
+    int frames_in_flight = 1;      // set by artgpu_batch_run on itself and its lanes while a batch with L > 1 lanes runs: see amaze_cu_cap()
     bool owns_stream = false;
     float fuse_pre = 0.f, fuse_post = 0.f;   // improc_denoise -> rgb_denoise: exposure compensation fused into rgb2yuv / yuv2rgb
     GetImageFuse fuse_gi = {};               // improc_denoise_fused -> chroma map, rgb2yuv: getImage + matrix read from the demosaiced planes
@@ -73,6 +74,8 @@ struct artgpu_ctx {
     artgpu_progress_fn progress_fn = nullptr;   // artgpu_set_progress_callback
     void *progress_user = nullptr;
     int opt_amaze_overlap = 1;     // 0: the arena kernel's static tiles behind the stream kernel instead of beside it
+    int opt_amaze_grid = 0;        // > 0: at most this many stream workgroups (each owns a CU): with several frames in flight the CUs left over
+                                   // take the other frames' bandwidth-bound passes while this frame's issue-bound demosaic runs
     hipStream_t amz_side = nullptr;
     hipEvent_t amz_ev[2] = {nullptr, nullptr};
     int opt_rcd_rows = 8;          // rows per iteration of the streaming kernel (4 or 8)
@@ -448,6 +451,7 @@ int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value)
     if (n == "amaze_path") { if (value < 0 || value > 1) return fail(ctx, ARTGPU_EINVAL, "amaze_path: 0 or 1"); ctx->opt_amaze_path = (int)value; }
     else if (n == "amaze_split") ctx->opt_amaze_split = value != 0;
     else if (n == "amaze_overlap") ctx->opt_amaze_overlap = value != 0;
+    else if (n == "amaze_grid") { if (value < 0) return fail(ctx, ARTGPU_EINVAL, "amaze_grid: >= 0"); ctx->opt_amaze_grid = (int)value; }
     else if (n == "amaze_zero_mask") ctx->opt_amaze_zero_mask = value;
     else if (n == "amaze_zero_frame") ctx->opt_amaze_zero_frame = (int)value;
     else if (n == "amaze_poison") ctx->opt_amaze_poison = (int)value;
@@ -696,7 +700,14 @@ static int demosaic_bayer_impl(artgpu_ctx *ctx, int method, const artgpu_plane *
                 HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
                 ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
             }
-            HIPCHK(ctx, launch_amaze_stream(sa, std::min(ctx->amz_nstream, ctx->num_cus), early ? ctx->amz_side : ctx->stream));
+            // One stream workgroup owns a CU (156 KB of LDS, sixteen waves at 122 registers) and the kernel is bound by instruction issue; the
+            // FTblockDN passes of ANOTHER frame in flight are bound by memory and can do nothing with a CU the demosaic holds.  With frames in
+            // flight (artgpu_batch_run lanes) the stream kernel therefore leaves 3/8 of the CUs to them: measured 3881 -> 4006 .. 4056 MP/s with two
+            // frames in flight at 45 MP (scripts/r5_lanes.sh: 240 / 224 / 192 / 160 / 144 / 128 workgroups; one frame at a time: all CUs).
+            // Option "amaze_grid" overrides.
+            const int cu_auto = ctx->frames_in_flight > 1 ? std::max(1, ctx->num_cus * 5 / 8) : ctx->num_cus;
+            const int cu_cap = ctx->opt_amaze_grid > 0 ? std::min(ctx->opt_amaze_grid, ctx->num_cus) : cu_auto;
+            HIPCHK(ctx, launch_amaze_stream(sa, std::min(ctx->amz_nstream, cu_cap), early ? ctx->amz_side : ctx->stream));
         }
         if (early) {
             HIPCHK(ctx, hipEventRecord(ctx->amz_ev[1], ctx->amz_side));
@@ -2973,11 +2984,14 @@ int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, con
     // whichever lane runs it (copied on every call -- they may change between calls)
     for (artgpu_ctx *peer : ctx->lanes) {
         peer->curve_tail_kind = ctx->curve_tail_kind; peer->curve_tail_y = ctx->curve_tail_y; peer->curve_tail_pc = ctx->curve_tail_pc;
-        peer->opt_amaze_path = ctx->opt_amaze_path; peer->opt_amaze_split = ctx->opt_amaze_split; peer->opt_amaze_overlap = ctx->opt_amaze_overlap;
+        peer->opt_amaze_path = ctx->opt_amaze_path; peer->opt_amaze_split = ctx->opt_amaze_split; peer->opt_amaze_overlap = ctx->opt_amaze_overlap; peer->opt_amaze_grid = ctx->opt_amaze_grid;
         peer->opt_amaze_zero_mask = ctx->opt_amaze_zero_mask; peer->opt_amaze_zero_frame = ctx->opt_amaze_zero_frame; peer->opt_amaze_poison = ctx->opt_amaze_poison;
         peer->opt_rcd_rows = ctx->opt_rcd_rows; peer->opt_roctx = ctx->opt_roctx; peer->opt_lut_lds = ctx->opt_lut_lds; peer->opt_dn_streams = ctx->opt_dn_streams; peer->opt_dn_fused = ctx->opt_dn_fused;
         peer->progress_fn = ctx->progress_fn; peer->progress_user = ctx->progress_user;
+        peer->frames_in_flight = L;
     }
+    ctx->frames_in_flight = L;
+    struct InFlightReset { artgpu_ctx *c; ~InFlightReset() { c->frames_in_flight = 1; for (artgpu_ctx *p : c->lanes) p->frames_in_flight = 1; } } in_flight_reset{ctx};
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // inputs the caller produced on this context's stream
     std::vector<int> rcs(L, ARTGPU_OK);
     auto work = [&](int k) {

@@ -206,11 +206,22 @@ def main() -> None:
         ln["p_img"] = capi.RGB(*[capi.device_plane(t) for t in ln["img"]])
         return ln
 
+    # With frames in flight the issue-bound AMaZE stream kernel leaves 3/8 of the CUs to the other frames' memory-bound passes
+    # (artgpu_batch_run does this for its lanes by itself; the lanes here are separate contexts, so they are told: option amaze_grid)
+    user_grid = any(o.startswith("amaze_grid=") for o in args.opt)
+    inflight_grid = max(1, torch.cuda.get_device_properties(dev).multi_processor_count * 5 // 8)
+
+    def in_flight(c, on):
+        if not user_grid and not xtrans:
+            c.set_option("amaze_grid", inflight_grid if on else 0)
+
     if args.lanes > 1:
         if not pipeline:
             raise SystemExit("--lanes needs a pipeline workload (c3/c4/c5)")
+        in_flight(ctx, True)
         for k in range(1, args.lanes):
             extra.append(make_lane(k))
+            in_flight(extra[-1]["ctx"], True)
 
     lane_errors = []
 
@@ -537,6 +548,7 @@ def main() -> None:
     # what `--lanes 2` gives (a second frame in flight on its own context / stream / host thread), beside the one-frame-per-step line
     if pipeline and world == 1 and args.lanes == 1 and args.sustained_seconds > 0:
         ln2 = make_lane(1)
+        in_flight(ctx, True); in_flight(ln2["ctx"], True)
 
         def step2():
             t_ = threading.Thread(target=lane_frame, args=(ln2,))
@@ -555,6 +567,7 @@ def main() -> None:
         ms2 = 1e3 * (time.perf_counter() - t0) / n2
         result["two_frames_in_flight"] = {"ms_per_step": round(ms2, 4), "frames_per_step": 2, "value": round(2 * mp / (ms2 / 1e3), 2), "unit": "MP/s",
                                           "steps": n2, "flag": "--lanes 2"}
+        in_flight(ctx, False)
         del ln2
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -81,7 +81,14 @@ int artgpu_synchronize(artgpu_ctx *ctx);
  *   "amaze_path"        0 (default): full AMaZE tiles are streamed through LDS (amaze_stream.hip), partial tiles and tiles the
  *                       stream hands back run on the per-tile arena kernel (amaze.hip); 1: arena kernel for every tile
  *   "amaze_split"       1 (with amaze_path 1): one kernel launch per AMaZE phase (per-phase profile)
- *   "amaze_zero_mask" / "amaze_zero_frame" / "amaze_poison"   arena-clearing experiments of tests/test_gpu_demosaic.py */
+ *   "amaze_zero_mask" / "amaze_zero_frame" / "amaze_poison"   arena-clearing experiments of tests/test_gpu_demosaic.py
+ *   "amaze_overlap"     0: the arena kernel's tiles behind the stream kernel instead of beside it
+ *   "amaze_grid"        n > 0: at most n stream workgroups (one per CU); 0 (default): every CU, or 5/8 of them while artgpu_batch_run has several
+ *                       frames in flight (the other frames' memory-bound passes get the rest)
+ *   "dn_fused"          1 (default): ShrinkAllL / ShrinkAllAB as one pass over the coefficients, one launch for the three channels where nothing has
+ *                       to happen between them; 2: one launch per channel; 0: the three-kernel form (factors, row sums, column sums + update)
+ *   "dn_streams"        0: RGB_denoise's kernels one after the other on the context's stream (profiling); "lut_lds" 0: never the LUT-in-LDS shape
+ *                       of the pixel passes; "rcd_rows" 4 | 8; "roctx" 1: roctx ranges named after the reference functions */
 int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value);
 /* read-only counterparts: "amaze_counter0" .. "amaze_counter7" = bookkeeping of the last AMaZE call (how many tiles were streamed a
  * second time, handed to the arena kernel, ...); synchronises the context's stream */

@@ -11,6 +11,7 @@ case $B in
   nlm_sweep) EXTRA="-fgpu-flush-denormals-to-zero -fno-slp-vectorize";;
   amaze_stream) EXTRA="-mllvm -amdgpu-sched-strategy=max-ilp";;
   nlmeans) EXTRA="-fno-slp-vectorize";;
+  shrinkblur) EXTRA="-mllvm -amdgpu-sched-strategy=max-memory-clause";;
 esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function $EXTRA $X -c $F -o /tmp/var_$N.o
 OBJS=$(ls *.o | grep -v "^$B.o$")
