@@ -2357,7 +2357,7 @@ static int chroma_map_dev(artgpu_ctx *ctx, float *const planes[3], size_t stride
     a.stride = stride; a.wid = wid; a.hei = hei;
     a.has_mat = mat ? 1 : 0;
     for (int k = 0; k < 9; ++k) { a.mat[k] = mat ? mat[k] : 0.0; a.wpi[k] = (float)ws[k]; }
-    a.cachef = tab; a.curve = tab + 65536; a.out = map;
+    a.cachef = tab; a.curve = tab + 65536; a.out = map; a.no_lds_lut = !ctx->opt_lut_lds;
     HIPCHK(ctx, launch_chroma_map(a, ctx->stream));
     *out = map;
     return ARTGPU_OK;

@@ -356,6 +356,7 @@ struct ChromaMapArgs {
     const float *cachef;                  // 65536-entry Lab f() LUT (device)
     const float *curve;                   // 501-entry NoiseCurve LUT (device)
     float *out;                           // wid x hei
+    int no_lds_lut;                       // artgpu_set_option "lut_lds" 0
 };
 hipError_t launch_chroma_map(const ChromaMapArgs &a, hipStream_t s);
 bool flat_curve_sample(const double *pts, int npts, bool periodic, int ppn, double identity, int nout, double *out);

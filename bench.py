@@ -82,6 +82,8 @@ def main() -> None:
                          "denoise + exposure + tone curve (BASELINE configs[2], the configuration the metric is quoted on); "
                          "c4: c3 + guided chroma smoothing + NL-means (the per-frame pipe of BASELINE configs[3]); "
                          "c5: X-Trans 3-pass (Markesteijn, CIELab) + the c3 stages on a 100 MP 11648x8736 frame (BASELINE configs[4])")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="only the timed steps (no NEUTRAL / separate-stage / two-frames legs behind them): kernel traces and counter passes")
     ap.add_argument("--separate-stages", action="store_true",
                     help="one library call per stage of the reference's order (getImage, denoise, exposure) instead of the fused tool "
                          "artgpu_improc_denoise_fused; same result, the image written and read again between the stages")
@@ -382,8 +384,11 @@ def main() -> None:
     # profiles/ (KB units; uncorrected -- the kernel's accesses are 4 B per lane, see profiles/r1/README.md)
     traffic, traffic_src, traffic_raw, issue = None, None, None, None
     kname = "xtrans_tiles_kernel" if xtrans else "amaze_stream_kernel" if method == capi.BAYER_AMAZE else "rcd_stream_kernel"
-    pmc_rel = os.path.join("profiles", "r4", {"amaze_stream_kernel": "amaze_stream_pmc_summary.json", "rcd_stream_kernel": "rcd_stream_pmc_summary.json",
-                                              "xtrans_tiles_kernel": "xtrans_tiles_pmc_summary.json"}[kname])
+    pmc_file = {"amaze_stream_kernel": "amaze_stream_pmc_summary.json", "rcd_stream_kernel": "rcd_stream_pmc_summary.json",
+                "xtrans_tiles_kernel": "xtrans_tiles_pmc_summary.json"}[kname]
+    # the newest round's counter summary of the kernel (each carries the digest of the sources it was taken from: `traffic_stale` below)
+    pmc_rel = next((os.path.join("profiles", rn, pmc_file) for rn in ("r5", "r4") if os.path.exists(os.path.join(ROOT, "profiles", rn, pmc_file))),
+                   os.path.join("profiles", "r5", pmc_file))
     pmc_path = os.path.join(ROOT, pmc_rel)
     traffic_stale = None
     full_size = (W, H) == ((11648, 8736) if xtrans else (W45, H45))
@@ -488,7 +493,7 @@ def main() -> None:
                                "ratio_to_timed_steps": round(s_ms / (1e3 * elapsed / args.steps), 4)}
 
     # ART's default tone-curve mode is NEUTRAL (curves.cc:854-1038), the headline line uses STD: report the NEUTRAL step beside it
-    if pipeline and world == 1 and args.tone == "std" and args.lanes == 1:
+    if pipeline and world == 1 and args.tone == "std" and args.lanes == 1 and not args.no_extra_legs:
         def step_neutral():
             ctx.demosaic_xtrans(3, True, p_raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, out) if xtrans else ctx.demosaic_bayer(method, p_raw, filt, 1.0, border, out)
             if fused_tool:
@@ -514,7 +519,7 @@ def main() -> None:
     # BOTH: `config.stage_ms` describes the timed steps (schema 2 when the fused tool runs), `separate_stages` times a few steps with one
     # call per stage and reports the round-1..3 keys -- the difference between the two ms_per_step figures is what the API-level fusion is
     # worth, as opposed to kernel work.
-    if pipeline and fused_tool and world == 1 and args.tone == "std" and args.lanes == 1:
+    if pipeline and fused_tool and world == 1 and args.tone == "std" and args.lanes == 1 and not args.no_extra_legs:
         sep_names = ["demosaic", "get_image+matrix", "denoise", "exposure", "tone_curve"]
         ns_ = max(1, min(args.steps, 5))
         sev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(sep_names) + 1)] for _ in range(ns_)]

@@ -560,3 +560,35 @@ def test_trim_scratch_gives_the_pool_back_and_the_next_call_rebuilds_it():
     ctx.trim_scratch()
     ctx.trim_scratch()                                       # (idempotent)
     del ctx
+
+
+def test_large_chroma_noise_map_lds_table_same_bits_as_plain_kernel(gpu_ctx):
+    """maps of >= 1 Mpx run calclum + ccalc with the lower 40704 entries of the Lab f() table in LDS (chroma_map_lds_kernel, round 5): values on
+    both sides of the split, negative, above 65535 and NaN, with and without the colour matrix -- the bits of the plain kernel and of the oracle"""
+    w, h = 2310, 1826                       # map 1155 x 913 = 1.05 Mpx: odd width, a ragged last chunk, rows that do not fill the last batch
+    rng = np.random.default_rng(15)
+    base = rng.uniform(0, 1, (h, w)).astype(np.float32) ** 2 * 60000.0
+    img = [(base * rng.uniform(0.3, 1.4, (h, w))).astype(np.float32) for _ in range(3)]
+    img[0][:60] *= 3.0                      # strongly coloured band: cN > 100, X / D50x above the table
+    img[1][100:130] = -40.0
+    img[2][200:230] = 0.0
+    img[0][300, ::7] = np.nan
+    mat = np.array([[0.6325, 0.2312, 0.0921], [0.2198, 0.7712, 0.0090], [0.0166, 0.0713, 0.7514]])
+    curve, _ = capi.noise_curve_lut()
+    for m in (mat, None):
+        got = np.zeros(((h + 1) // 2, (w + 1) // 2), np.float32)
+        gpu_ctx.denoise_chroma_map(capi.host_rgb(img), m, O.REC2020_WS_D, curve, capi.host_plane(got))
+        gpu_ctx.set_option("lut_lds", 0)
+        try:
+            plain = np.zeros_like(got)
+            gpu_ctx.denoise_chroma_map(capi.host_rgb(img), m, O.REC2020_WS_D, curve, capi.host_plane(plain))
+        finally:
+            gpu_ctx.set_option("lut_lds", 1)
+        ref = O.chroma_noise_map(img, m, O.REC2020_WS_D, curve)
+
+        def same(x, y):        # bit for bit; a NaN has to be a NaN (its payload is the host's / the device's own)
+            nx, ny = np.isnan(x), np.isnan(y)
+            return np.array_equal(nx, ny) and np.array_equal(x.view(np.uint32)[~nx], y.view(np.uint32)[~ny])
+        assert np.array_equal(got.view(np.uint32), plain.view(np.uint32))
+        assert same(got, ref)
+        assert len(np.unique(ref[np.isfinite(ref)])) > 100
