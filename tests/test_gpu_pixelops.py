@@ -331,3 +331,43 @@ def test_tone_std_large_frame_lds_curve_bit_exact(gpu_ctx, monkeypatch, w, h, cl
     for g, p, r in zip(got, plain, ref):
         assert np.array_equal(g.view(np.uint32), r.view(np.uint32))
         assert np.array_equal(p.view(np.uint32), r.view(np.uint32))
+
+
+@pytest.mark.parametrize("w,h", [(343, 211), (2304, 1800)])          # plain kernel / the kernel with the curve in LDS
+def test_filmlike_clip_every_branch_of_the_reference_tree(gpu_ctx, w, h):
+    """Color::filmlike_clip (color.cc:6650-6688) branches seven ways on the order of the channels.  Every order, every tie (r == g, g == b,
+    r == b, all equal), values on both sides of the clip level, zeros, negatives, +-inf and NaN in each channel: the bits of the oracle.
+    (Round 5 also measured a one-body form -- the tree's comparisons select a permutation, clip_rgb_tone runs once: same bits on this test,
+    17 us faster on random data, 17 us SLOWER on the benchmark frame, whose waves mostly agree on the order: not kept)"""
+    from art_amd import capi
+    import oracle_lib as O
+    rng = np.random.default_rng(7)
+    vals = np.array([0.0, -3.0, 1.0, 500.0, 30000.0, 65535.0 * 0.9 - 1, 65535.0 * 0.9, 65535.0 * 0.9 + 1, 65535.0, 70000.0, 2.0e5, np.inf, -np.inf, np.nan], np.float32)
+    n = len(vals)
+    # the first rows: every (r, g, b) triple of the special values (ties and orders by construction); the rest: random neutral-ish data
+    tri = np.array(np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")).reshape(3, -1)
+    img = [rng.uniform(0.0, 75000.0, (h, w)).astype(np.float32) for _ in range(3)]
+    base = img[0].copy()
+    img[1] = (base + rng.normal(0, 900, (h, w))).astype(np.float32)          # close channels: the order changes from pixel to pixel
+    img[2] = (base + rng.normal(0, 900, (h, w))).astype(np.float32)
+    flat = [p.reshape(-1) for p in img]
+    for c in range(3):
+        flat[c][:tri.shape[1]] = vals[tri[c]]
+    x = np.arange(65536, dtype=np.float64) / 65535.0
+    lut = ((1.0 - np.cos(np.pi * x ** 0.7)) / 2.0 * 65535.0).astype(np.float32)
+
+    def same(a, b):            # bit for bit; a NaN has to be a NaN (its payload is the host's / the device's own)
+        bad = 0
+        for p, q in zip(a, b):
+            npn, nq = np.isnan(p), np.isnan(q)
+            bad += int((npn != nq).sum()) + int((p.view(np.uint32)[~npn & ~nq] != q.view(np.uint32)[~npn & ~nq]).sum())
+        return bad
+    for whitept in (0.9, 1.0):
+        ref = O.tone_std(img, lut, whitept, True)
+        got = [p.copy() for p in img]
+        gpu_ctx.tone_curve(capi.host_rgb(got), lut, whitept, True)
+        assert same(got, ref) == 0
+    # the seven cases really occur in the random part
+    r, g, b = [p.reshape(-1)[tri.shape[1]:] for p in img]
+    cases = np.where(r >= g, np.where(g > b, 0, np.where(b > r, 1, np.where(b > g, 2, 3))), np.where(r >= b, 4, np.where(b > g, 5, 6)))
+    assert set(np.unique(cases)) >= {0, 1, 2, 4, 5, 6}
