@@ -28,7 +28,9 @@ struct artgpu_ctx {
     hipEvent_t dn_ev[2] = {nullptr, nullptr};
     const float *gam_tab = nullptr; float gam_key[6] = {};   // RGB_denoise's gamma / inverse-gamma tables in pool[P_GAM]: what they were built from
     int opt_lut_lds = 1;           // 0: never the LUT-in-LDS shapes of the pixel passes (tests compare the two)
-    int opt_dn_streams = 1;        // 0: the whole chain on the context's stream, one kernel after the other, in the reference's order
+    int opt_dn_streams = 0;        // 1: the DCT detail recovery of L on a side stream beside the reconstructions of a and b.  The default until round 5, when the
+                                   // stage waited on LDS round trips and left the chip half idle; since detail_blocks_kernel lost a fifth of its time (detail.hip) the
+                                   // two chains only get in each other's way: one kernel after the other is 0.1 - 0.15 ms per 45 MP frame faster (scripts/r5_ab9.sh)
     int ccalc_nonneg = 0;          // set by artgpu_improc_denoise around RGB_denoise: the chroma noise map is the one chroma_map_kernel has just written (squares: no negative value)
     int opt_dn_fused = 1;          // ShrinkAllL / ShrinkAllAB -- 0: three kernels per channel (factors, row sums, column sums + update); 2: one kernel per
                                    // channel; 1: one kernel, and one launch for all three channels where nothing has to happen between them
@@ -1223,9 +1225,10 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     bool autoch = p->chrominance_method == 1;
 
     // ---- streams.  The reference runs a, then b, then L (L2328-2438).  The chains only meet in the untouched L coefficients and their MADs
-    // (read by the chroma shrink factors) and in yuv2rgb, so their order is free.  With "dn_streams" the DCT detail recovery of L -- bound by
+    // (read by the chroma shrink factors) and in yuv2rgb, so their order is free.  With option "dn_streams" 1 the DCT detail recovery of L -- bound by
     // instruction issue, it leaves HBM idle -- runs on a side stream beside the box blurs and reconstructions of a and b, which are bound by
     // HBM: L goes first for that, after the chroma shrink factors have read its coefficients.  Same kernels on the same data: the same bits.
+    // (Rounds 3 and 4: -0.3 ms per frame, the default.  Round 5: off by default -- see opt_dn_streams.)
     // (Running all three chains side by side was measured too: 9.7 ms against 9.2 -- three HBM-bound chains only get in each other's way.)
     const bool fork = ctx->opt_dn_streams != 0 && do_detail && denoiseLuminance;
 

@@ -106,39 +106,80 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
     __syncthreads();
     // ... then down the columns (lane = column m) and the shrink factor 1 - exp(-blur^2 / factor).  The factor of row `row`
     // is written where N[row - rad - 1] was (its last use is this step); the first rad + 1 rows use the spare rows.
+    // Round 5, two changes that only pay together (scripts/r5_ab8.sh: 0.91 ms per 45 MP frame before, the same with either one alone, 0.73 with both):
+    //  * the steady rows go in groups of eight inside a ROLLED loop -- the sixteen LDS reads of a group first (they do not depend on the running sum),
+    //    then the eight dependent additions, then the eight factors, whose writes land on rows the group has already read; one row per
+    //    iteration waited an LDS round trip per row with two waves per SIMD to hide it.  (All 64 rows as straight-line code ran as fast alone
+    //    but slowed the frame: 50 KB of code beside the chroma reconstructions' kernels on the side stream.)
+    //  * -blur^2 / factor as a multiplication by the factor's reciprocal, formed once per lane for the launch's two factors: the correctly
+    //    rounded division was 17 of a row's ~50 issue slots.  The quotient changes by at most one unit in the last place, the shrink factor by
+    //    1e-7 of itself -- like the exponential below, far inside what the stage's tolerance is there for (FFTW's own round-off).
     {
         float lenf = (float)(rad + 1);
         float tv = B[0][lane];
+#pragma unroll
         for (int i = 1; i <= rad; i++) tv = tv + B[i][lane];
         tv = tv / lenf;
-        float rlen = 0.f;
         const bool colin = (left + lane) >= 0 && (left + lane) < a.w;
-        for (int row = 0; row < TS; ++row) {
-            if (row == 0) {
-            } else if (row <= rad) {
-                const float lenp1 = lenf + 1.f;
-                tv = (tv * lenf + B[row + rad][lane]) / lenp1;
-                lenf = lenp1;
-            } else if (row < TS - rad) {
-                tv = tv + (B[row + rad][lane] - B[row - rad - 1][lane]) * rlen;
-            } else {
-                const float lenm1 = lenf - 1.f;
-                tv = (tv * lenf - B[row - rad - 1][lane]) / lenm1;
-                lenf = lenm1;
-            }
-            if (row == rad) rlen = 1.f / lenf;
-            // detail_factor is indexed by block position (FTblockDN.cc:1571-1596): hi inside the image
+        const float inv_hi = 1.f / a.detail_hi, inv_lo = 1.f / a.detail_lo;
+        // detail_factor is indexed by block position (FTblockDN.cc:1571-1596): hi inside the image
+        auto emit = [&](int row, float tvr) {
             const bool rowin = (top + row) >= 0 && (top + row) < a.h;
             float factor = (rowin && colin) ? a.detail_hi : a.detail_lo;
+            float rfac = (rowin && colin) ? inv_hi : inv_lo;
             if (a.mask && rowin && colin) {     // compute_detail(params_Ldetail * mask) (FTblockDN.cc:1481-1486,1583)
                 const float d = a.params_Ldetail * a.mask[(size_t)(top + row) * a.w + left + lane];
                 const float t = static_cast<float>((100. - d) * (100. - d) + 50. * (100. - d)) * TS * 0.5f;
                 factor = t * t;
+                rfac = 1.f / factor;
             }
+            (void)factor; (void)rfac;
             const int slot = row > rad ? row - rad - 1 : TS + row;
             // (hardware exp2: the 4096 exponentials of a block were a quarter of the kernel's instructions as sleef's xexpf; this stage
             // is tolerance-checked against an exact DCT anyway -- FFTW's round-off is not reproducible -- and the factor changes by 2^-22)
-            B[slot][lane] = 1.0f - __expf(-sqr(tv) / factor);
+#ifdef DETAIL_EXACT_DIV
+            B[slot][lane] = 1.0f - __expf(-sqr(tvr) / factor);
+#else
+            B[slot][lane] = 1.0f - __expf(-sqr(tvr) * rfac);
+#endif
+        };
+        emit(0, tv);
+#pragma unroll
+        for (int row = 1; row <= rad; ++row) {
+            const float lenp1 = lenf + 1.f;
+            tv = (tv * lenf + B[row + rad][lane]) / lenp1;
+            lenf = lenp1;
+            emit(row, tv);
+        }
+        const float rlen = 1.f / lenf;
+        constexpr int S0 = rad + 1, S1 = TS - rad, G = 8;          // steady rows [S0, S1)
+        constexpr int SG = S0 + (S1 - S0) / G * G;                 // ... of which [S0, SG) in whole groups
+#ifndef DETAIL_ROLLED_ROWS
+#pragma unroll 1
+        for (int r0 = S0; r0 < SG; r0 += G) {
+            float hi[G], lo[G], tvs[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) { hi[k] = B[r0 + k + rad][lane]; lo[k] = B[r0 + k - rad - 1][lane]; }
+#pragma unroll
+            for (int k = 0; k < G; ++k) { tv = tv + (hi[k] - lo[k]) * rlen; tvs[k] = tv; }
+#pragma unroll
+            for (int k = 0; k < G; ++k) emit(r0 + k, tvs[k]);
+        }
+#pragma unroll 1
+        for (int row = SG; row < S1; ++row) {
+#else
+#pragma unroll 1
+        for (int row = S0; row < S1; ++row) {
+#endif
+            tv = tv + (B[row + rad][lane] - B[row - rad - 1][lane]) * rlen;
+            emit(row, tv);
+        }
+#pragma unroll 1
+        for (int row = S1; row < TS; ++row) {
+            const float lenm1 = lenf - 1.f;
+            tv = (tv * lenf - B[row - rad - 1][lane]) / lenm1;
+            lenf = lenm1;
+            emit(row, tv);
         }
     }
     __syncthreads();

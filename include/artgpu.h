@@ -87,7 +87,8 @@ int artgpu_synchronize(artgpu_ctx *ctx);
  *                       frames in flight (the other frames' memory-bound passes get the rest)
  *   "dn_fused"          1 (default): ShrinkAllL / ShrinkAllAB as one pass over the coefficients, one launch for the three channels where nothing has
  *                       to happen between them; 2: one launch per channel; 0: the three-kernel form (factors, row sums, column sums + update)
- *   "dn_streams"        0: RGB_denoise's kernels one after the other on the context's stream (profiling); "lut_lds" 0: never the LUT-in-LDS shape
+ *   "dn_streams"        0 (default since round 5): RGB_denoise's kernels one after the other on the context's stream; 1: the DCT detail recovery of L on a
+ *                       side stream beside the reconstructions of a and b (the default of rounds 3 and 4); "lut_lds" 0: never the LUT-in-LDS shape
  *                       of the pixel passes; "rcd_rows" 4 | 8; "roctx" 1: roctx ranges named after the reference functions */
 int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value);
 /* read-only counterparts: "amaze_counter0" .. "amaze_counter7" = bookkeeping of the last AMaZE call (how many tiles were streamed a

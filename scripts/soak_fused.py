@@ -10,7 +10,7 @@ import torch
 from art_amd import capi, synth
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-FLAGS = 0 if (len(sys.argv) > 2 and sys.argv[2] == "detail") else capi.DN_SKIP_DETAIL_RECOVERY   # "detail": with the DCT stage on its side stream
+FLAGS = 0 if (len(sys.argv) > 2 and sys.argv[2] == "detail") else capi.DN_SKIP_DETAIL_RECOVERY   # "detail": with the DCT stage (on its side stream: option dn_streams 1 below)
 W, H = 8184, 5456
 WS = np.array([[0.6734241, 0.1656411, 0.1251286], [0.2790177, 0.6753402, 0.0456377], [-0.0019300, 0.0299784, 0.7973330]])
 MAT = np.array([[0.6325, 0.2312, 0.0921], [0.2198, 0.7712, 0.0090], [0.0166, 0.0713, 0.7514]])
@@ -34,6 +34,8 @@ tp = capi.DenoiseToolParams(capi.DenoiseParams(40.0, 50.0, 0, 15.0, 0.0, 0.0, 1.
 curve, _ = capi.noise_curve_lut()
 s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
 c1, c2 = capi.Context(0, s1.cuda_stream), capi.Context(0, s2.cuda_stream)
+if FLAGS == 0:
+    c1.set_option("dn_streams", 1)      # the side stream is what this mode soaks (off by default since round 5)
 src = frame(W, H, 1)
 with torch.cuda.stream(s1):
     first = [torch.empty_like(t) for t in src]

@@ -308,7 +308,7 @@ def test_fused_shrink_pass_same_bits_as_three_kernels(gpu_ctx, w, h, kw):
                 outs[(fused, streams)] = got
     finally:
         gpu_ctx.set_option("dn_fused", 1)
-        gpu_ctx.set_option("dn_streams", 1)
+        gpu_ctx.set_option("dn_streams", 0)        # (the default since round 5)
     for f in (1, 2):
         assert _same(outs[(f, 0)], outs[(0, 0)]) == [0, 0, 0]
         assert _same(outs[(f, 1)], outs[(0, 1)]) == [0, 0, 0]      # (with the DCT stage on: the same kernels on the same L plane)
