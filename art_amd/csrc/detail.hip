@@ -217,6 +217,49 @@ __global__ void __launch_bounds__(1024) detail_gather_kernel(DetailArgs a)
     __syncthreads();
     const float DCTnorm = 1.0f / (4 * TS * TS);
     const long long n = (long long)a.w * a.h;
+#ifndef DETAIL_GATHER_LOOPS
+    // Round 5: the nine candidate terms of a pixel as straight-line code.  Block row yc - 1 + s (s = 0, 1, 2; yc = y / 25) holds pixel row y at
+    // its row i = y % 25 + 50 - 25 s: s = 1 and 2 always exist and contain it, s = 0 does when yc > 0 and y % 25 < 14; the same along x.  All
+    // nine block values are loaded first -- a term that does not exist loads the (2, 2) term's address again, a line the lane has in flight
+    // anyway -- and then summed in the reference's order (vblk, then hblk), a missing term by a select that leaves both sums as they are.
+    // The nested loops this replaces skipped the missing terms with `continue`: each load sat in a divergent region of its own and the wave
+    // waited for it before it issued the next (85 % of the kernel's wave cycles were such waits).
+    for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+        const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
+        const int yc = y / OFF, xc = x / OFF, ry = y - yc * OFF, rx = x - xc * OFF;
+        bool vs[3], hs[3];
+        int iv[3], jh[3], vb[3], hb[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            vs[k] = k > 0 || (yc > 0 && ry < TS - 2 * OFF);
+            hs[k] = k > 0 || (xc > 0 && rx < TS - 2 * OFF);
+            iv[k] = vs[k] ? ry + 2 * OFF - OFF * k : ry;  vb[k] = vs[k] ? yc - 1 + k : yc + 1;
+            jh[k] = hs[k] ? rx + 2 * OFF - OFF * k : rx;  hb[k] = hs[k] ? xc - 1 + k : xc + 1;
+        }
+        float blk[9], tmo[9], tmi[9];
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+            for (int t_ = 0; t_ < 3; ++t_) {
+                const int m = iv[s_] * TS + jh[t_];
+                blk[3 * s_ + t_] = a.blocks[((size_t)vb[s_] * a.numblox_W + hb[t_]) * TS * TS + m];
+                tmo[3 * s_ + t_] = s_out[m];
+                tmi[3 * s_ + t_] = s_in[m];
+            }
+        const float Lold = a.L[t];
+        float Ldetail = 0.f, totwt = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 3; ++s_)
+#pragma unroll
+            for (int t_ = 0; t_ < 3; ++t_) {
+                const bool v = vs[s_] && hs[t_];
+                const float ld = Ldetail + tmo[3 * s_ + t_] * blk[3 * s_ + t_] * DCTnorm, tw = totwt + tmi[3 * s_ + t_] * tmo[3 * s_ + t_];
+                Ldetail = v ? ld : Ldetail;
+                totwt = v ? tw : totwt;
+            }
+        a.L[t] = Lold + Ldetail / totwt;
+    }
+#else
     for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
         const int y = (int)(t / a.w), x = (int)(t - (long long)y * a.w);
         // blocks with top <= y < top + 64, top = (vblk - 1) * 25: at most three per axis
@@ -236,6 +279,7 @@ __global__ void __launch_bounds__(1024) detail_gather_kernel(DetailArgs a)
         }
         a.L[t] += Ldetail / totwt;
     }
+#endif
 }
 
 hipError_t launch_detail_blocks(const DetailArgs &a, hipStream_t s)
