@@ -609,57 +609,54 @@ __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
     float tempval = 0.f;
     int len = rad + 1;
     float reclen = 0.f;
-    for (int c0 = 0; c0 < W; c0 += HB_COLS) {
-        // window columns [c0 - rad - 1, c0 + HB_COLS + rad): coalesced row segments -> LDS,
-        // 8 rows (16 independent loads) in flight per lane before the LDS stores.  After the first chunk the 2 * rad + 1 columns the
-        // next window shares with this one are moved inside LDS and only the HB_COLS new columns are read (the re-read was a third of
-        // this kernel's traffic).
-        const int wc0 = c0 - rad - 1, wn = HB_COLS + 2 * rad + 1;
-        if (c0 == 0) {
-            const int colA = wc0 + lane, colB = wc0 + lane + 64, colC = wc0 + lane + 128;
-            const bool okA = colA >= 0 && colA < W, okB = (lane + 64 < wn) && colB >= 0 && colB < W;
-            const bool okC = HB_MAXR > 31 && (lane + 128 < wn) && colC >= 0 && colC < W;
-            for (int k0 = 0; k0 < HB_ROWS; k0 += 8) {
-                float va[8], vb[8], vc[8];
+    // The workgroup is ONE wave: its LDS traffic is ordered by the hardware, so the three phases of a chunk -- window into LDS, running sums,
+    // rows out -- need no s_barrier, only the compiler kept from moving LDS accesses across them.  (__syncthreads() also waited for the wave's
+    // global stores and loads, vmcnt(0): the phases of a chunk ran strictly one after the other, a memory round trip each -- 5 us per chunk of
+    // which the sums are 2; with 3.5 such waves per CU nothing else filled the gaps.)  Round 5: the next chunk's new columns are requested
+    // BEFORE this chunk's sums and land while they run; the stores of a chunk are never waited for.
+    auto wave_lds_sync = []() {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // window of chunk 0: columns [-rad - 1, HB_COLS + rad): coalesced row segments -> LDS, 8 rows (16 independent loads) in flight per lane
+    {
+        const int wc0 = -rad - 1, wn = HB_COLS + 2 * rad + 1;
+        const int colA = wc0 + lane, colB = wc0 + lane + 64, colC = wc0 + lane + 128;
+        const bool okA = colA >= 0 && colA < W, okB = (lane + 64 < wn) && colB >= 0 && colB < W;
+        const bool okC = HB_MAXR > 31 && (lane + 128 < wn) && colC >= 0 && colC < W;
+        for (int k0 = 0; k0 < HB_ROWS; k0 += 8) {
+            float va[8], vb[8], vc[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int k = k0 + i;
-                    const size_t ro = (size_t)(r0 + k) * W;
-                    va[i] = (okA && k < nrows) ? src[ro + colA] : 0.f;
-                    vb[i] = (okB && k < nrows) ? src[ro + colB] : 0.f;
-                    if constexpr (HB_MAXR > 31) vc[i] = (okC && k < nrows) ? src[ro + colC] : 0.f;
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    sT[k0 + i][lane] = va[i];
-                    if (lane + 64 < wn) sT[k0 + i][lane + 64] = vb[i];
-                    if constexpr (HB_MAXR > 31) { if (lane + 128 < wn) sT[k0 + i][lane + 128] = vc[i]; }
-                }
-            }
-        } else {
-            // the new columns first (their loads fly while the overlap moves)
-            const int colN = c0 + rad + lane;                       // window index 2 * rad + 1 + lane
-            const bool okN = colN < W;
-            float vn[HB_ROWS];
-#pragma unroll
-            for (int k = 0; k < HB_ROWS; ++k) vn[k] = (okN && k < nrows) ? src[(size_t)(r0 + k) * W + colN] : 0.f;
-            const int nov = 2 * rad + 1;                            // <= 2 * HB_MAXR + 1 columns per row
-            constexpr int NMV = (HB_ROWS * (2 * HB_MAXR + 1) + 63) / 64;
-            float mv[NMV];
-#pragma unroll
-            for (int q = 0; q < NMV; ++q) {
-                const int e = lane + 64 * q, k = e / nov, x = e - k * nov;
-                mv[q] = k < HB_ROWS ? sT[k][x + HB_COLS] : 0.f;
+            for (int i = 0; i < 8; ++i) {
+                const int k = k0 + i;
+                const size_t ro = (size_t)(r0 + k) * W;
+                va[i] = (okA && k < nrows) ? src[ro + colA] : 0.f;
+                vb[i] = (okB && k < nrows) ? src[ro + colB] : 0.f;
+                if constexpr (HB_MAXR > 31) vc[i] = (okC && k < nrows) ? src[ro + colC] : 0.f;
             }
 #pragma unroll
-            for (int q = 0; q < NMV; ++q) {
-                const int e = lane + 64 * q, k = e / nov, x = e - k * nov;
-                if (k < HB_ROWS) sT[k][x] = mv[q];
+            for (int i = 0; i < 8; ++i) {
+                sT[k0 + i][lane] = va[i];
+                if (lane + 64 < wn) sT[k0 + i][lane + 64] = vb[i];
+                if constexpr (HB_MAXR > 31) { if (lane + 128 < wn) sT[k0 + i][lane + 128] = vc[i]; }
             }
-#pragma unroll
-            for (int k = 0; k < HB_ROWS; ++k) sT[k][nov + lane] = vn[k];
         }
-        __syncthreads();
+    }
+    wave_lds_sync();
+    for (int c0 = 0; c0 < W; c0 += HB_COLS) {
+        // the next chunk's HB_COLS new columns (window index 2 * rad + 1 + lane of ITS window): requested now, stored into LDS behind this chunk's sums
+        const bool more = c0 + HB_COLS < W;
+        const int colN = c0 + HB_COLS + rad + lane;
+        const bool okN = more && colN < W;
+        // (unconditional loads from clamped addresses, the zero by a select: a load under its own condition sits in a basic block of its own,
+        // and the wait-count pass then no longer knows at the loop's head which of them are still in flight -- it drained vmcnt there, i.e. waited
+        // for the previous chunk's STORES every chunk)
+        float vn[HB_ROWS];
+        const int colNc = colN < W ? colN : W - 1;
+#pragma unroll
+        for (int k = 0; k < HB_ROWS; ++k) vn[k] = src[(size_t)(r0 + (k < nrows ? k : nrows - 1)) * W + colNc];
+#pragma unroll
+        for (int k = 0; k < HB_ROWS; ++k) vn[k] = (okN && k < nrows) ? vn[k] : 0.f;
         const int cend = min(HB_COLS, W - c0);
         if (lane < HB_ROWS && myrow < H) {
             const float *s = &sT[lane][rad + 1]; // s[j] = src[row][c0 + j]
@@ -696,18 +693,44 @@ __global__ void __launch_bounds__(64) hblur_kernel(BlurArgs a)
                 }
             }
         }
-        __syncthreads();
-        if (lane < cend) {
-            for (int k0 = 0; k0 < nrows; k0 += 8) {
+        wave_lds_sync();
+        {
+            // (sixteen unconditional stores: a lane past the chunk's last column / a row past the workgroup's last row stores the neighbour's
+            // value to the neighbour's place once more.  Stores under conditions of their own cannot be counted by the wait-count pass, and the
+            // wait for the prefetched columns below then waits for them as well.)
+            const int lc = lane < cend ? lane : cend - 1;
+#pragma unroll
+            for (int k0 = 0; k0 < HB_ROWS; k0 += 8) {
                 float v[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v[i] = oT[(k0 + i) & (HB_ROWS - 1)][lane];
+                for (int i = 0; i < 8; ++i) v[i] = oT[k0 + i < nrows ? k0 + i : nrows - 1][lc];
 #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (k0 + i < nrows) dst[(size_t)(r0 + k0 + i) * W + c0 + lane] = v[i];
+                for (int i = 0; i < 8; ++i) dst[(size_t)(r0 + (k0 + i < nrows ? k0 + i : nrows - 1)) * W + c0 + lc] = v[i];
             }
         }
-        __syncthreads();
+        {
+            // the next window: the 2 * rad + 1 columns it shares with this one are moved inside LDS (their re-read was a third of the
+            // kernel's traffic), the new ones come from the registers filled above.  (Also behind the last chunk, where nobody reads it:
+            // were the registers only consumed under `if (more)`, the wait-count pass would again have to assume loads in flight at the
+            // loop's head.)
+            const int nov = 2 * rad + 1;                            // <= 2 * HB_MAXR + 1 columns per row
+            constexpr int NMV = (HB_ROWS * (2 * HB_MAXR + 1) + 63) / 64;
+            float mv[NMV];
+#pragma unroll
+            for (int q = 0; q < NMV; ++q) {
+                const int e = lane + 64 * q, k = e / nov, x = e - k * nov;
+                mv[q] = k < HB_ROWS ? sT[k][x + HB_COLS] : 0.f;
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int q = 0; q < NMV; ++q) {
+                const int e = lane + 64 * q, k = e / nov, x = e - k * nov;
+                if (k < HB_ROWS) sT[k][x] = mv[q];
+            }
+#pragma unroll
+            for (int k = 0; k < HB_ROWS; ++k) sT[k][nov + lane] = vn[k];
+        }
+        wave_lds_sync();
     }
 }
 
@@ -770,6 +793,9 @@ __global__ void __launch_bounds__(64) hblur_big_kernel(BlurArgs a)
 }
 
 // ---------------------------------------------------------------- vertical box blur + coefficient update (boxblur.h:602-742)
+// PLAIN (a.plain: the guided filter's box blurs -- the blurred value is stored, no factor / coefficient planes): the two loads per row leave
+// room for 24 rows per batch (48 loads in flight per lane; 8 rows left a lone wave one memory round trip per 8 rows: 124 ns per row)
+template <bool PLAIN>
 __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
 {
     const int sub = blockIdx.y, level = a.level0 + sub / 3;
@@ -782,8 +808,8 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
     if (col >= W) return;
     const size_t nv4 = (a.n / 4) * 4;
     const float eps = 0.01f;
-    const bool vec = a.plain ? true : col < (W / 4) * 4;
-    float *plain_dst = a.plain ? a.dst + (size_t)sub * a.n : nullptr;
+    const bool vec = PLAIN ? true : col < (W / 4) * 4;
+    float *plain_dst = PLAIN ? a.dst + (size_t)sub * a.n : nullptr;
     float tv = 0.f;
     float lenf = (float)(rad + 1);
     int leni = rad + 1;
@@ -815,7 +841,7 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
             leni++;
         }
         const size_t i = (size_t)row * W + col;
-        commit(row, tv, a.plain ? 0.f : sfave[i], a.plain ? 0.f : coef[i]);
+        commit(row, tv, PLAIN ? 0.f : sfave[i], PLAIN ? 0.f : coef[i]);
     }
     rlen = 1.f / lenf;
     // steady state, 8 rows of independent loads in flight
@@ -823,15 +849,15 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
     // One wave owns 64 columns for the whole height, and there are only W / 64 x bands of them (fewer than four per CU), so a batch's
     // memory latency is not hidden by other waves: the next batch is loaded while this one is computed, and its loads are issued BEFORE
     // this batch's stores (vmcnt retires in order: a wait for loads issued after stores waits for the stores as well).
-    constexpr int VB = 8;       // rows per batch: 4 x 8 loads in flight per lane, two batches deep (16 rows per batch measured no better)
+    constexpr int VB = PLAIN ? 24 : 8;       // rows per batch: 4 x 8 loads in flight per lane, two batches deep (16 rows per batch measured no better)
     float hi[VB], lo[VB], sf[VB], c[VB], nhi[VB], nlo[VB], nsf[VB], nc[VB];
     auto fetch = [&](int r, float *h_, float *l_, float *s_, float *c_) {
 #pragma unroll
         for (int k = 0; k < VB; ++k) {
             h_[k] = t[(size_t)(r + k + rad) * W + col];
             l_[k] = t[(size_t)(r + k - rad - 1) * W + col];
-            s_[k] = a.plain ? 0.f : sfave[(size_t)(r + k) * W + col];
-            c_[k] = a.plain ? 0.f : coef[(size_t)(r + k) * W + col];
+            s_[k] = PLAIN ? 0.f : sfave[(size_t)(r + k) * W + col];
+            c_[k] = PLAIN ? 0.f : coef[(size_t)(r + k) * W + col];
         }
     };
     if (row + VB <= steady_end) fetch(row, hi, lo, sf, c);
@@ -851,7 +877,7 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
         const float d = t[(size_t)(row + rad) * W + col] - t[(size_t)(row - rad - 1) * W + col];
         tv = vec ? tv + d * rlen : tv + d / leni;
         const size_t i = (size_t)row * W + col;
-        commit(row, tv, a.plain ? 0.f : sfave[i], a.plain ? 0.f : coef[i]);
+        commit(row, tv, PLAIN ? 0.f : sfave[i], PLAIN ? 0.f : coef[i]);
     }
     for (; row < H; ++row) {
         if (vec) {
@@ -863,7 +889,7 @@ __global__ void __launch_bounds__(64) vblur_combine_kernel(BlurArgs a)
             leni--;
         }
         const size_t i = (size_t)row * W + col;
-        commit(row, tv, a.plain ? 0.f : sfave[i], a.plain ? 0.f : coef[i]);
+        commit(row, tv, PLAIN ? 0.f : sfave[i], PLAIN ? 0.f : coef[i]);
     }
 }
 
@@ -962,7 +988,8 @@ hipError_t launch_hblur(const BlurArgs &a, int nsub, hipStream_t s)
 }
 hipError_t launch_vblur_combine(const BlurArgs &a, int nsub, hipStream_t s)
 {
-    hipLaunchKernelGGL(vblur_combine_kernel, dim3((a.w + 63) / 64, nsub), dim3(64), 0, s, a);
+    if (a.plain) hipLaunchKernelGGL(vblur_combine_kernel<true>, dim3((a.w + 63) / 64, nsub), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(vblur_combine_kernel<false>, dim3((a.w + 63) / 64, nsub), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 
