@@ -248,11 +248,16 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
     float tempval = 0.f, reclen = 0.f;
     int hlen = rad + 1;
 
+    // One loop per ROLE (round 5; the roles used to be the arms of an if-chain inside one step loop).  The wait-count pass works on the instruction
+    // stream, not on waves: behind the chain it had to assume that the loads and stores of EVERY arm may be in flight, so the first use of a
+    // prefetched coefficient in the next step waited for vmcnt(0) -- for the stores and the prefetches the wave had issued a moment ago as well.
+    // Every role still meets the others at one LDS-only barrier per step: the barrier counts arrivals, wherever in the code they happen.
+    if (ew >= 0) {
     for (int T = 0; T < NB + 4; ++T) {
 #ifdef FS_PROFILE
         const long long ts_ = __builtin_readcyclecounter();
 #endif
-        if (ew >= 0) {
+        {
             FS_T0
             // ---- coefficient update of block J = T - 3 (FTblockDN.cc:698-714, 803-836), rows [ro0, ro1)
             if (T >= 3) {
@@ -335,7 +340,18 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
                 if (T + 1 < NB) fetch(T + 1);
             }
             FS_T1(3)
-        } else if (wv == 0) {
+        }
+        lds_barrier();
+#ifdef FS_PROFILE
+        pt[0] += __builtin_readcyclecounter() - ts_;
+#endif
+    }
+    } else if (wv == 0) {
+    for (int T = 0; T < NB + 4; ++T) {
+#ifdef FS_PROFILE
+        const long long ts_ = __builtin_readcyclecounter();
+#endif
+        {
             // ---- row sums of block J = T - 1 over columns [X0 - rad, X0 + 64 - rad) (boxblur.h:565-600, hblur_kernel)
             if (T >= 1 && T <= NB && R0 + lane < Rb) {
                 FS_T0
@@ -376,7 +392,18 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
                 }
                 FS_T1(1)
             }
-        } else if (wv == 1) {
+        }
+        lds_barrier();
+#ifdef FS_PROFILE
+        pt[0] += __builtin_readcyclecounter() - ts_;
+#endif
+    }
+    } else if (wv == 1) {
+    for (int T = 0; T < NB + 4; ++T) {
+#ifdef FS_PROFILE
+        const long long ts_ = __builtin_readcyclecounter();
+#endif
+        {
             // ---- column sums of block J = T - 2 over rows [ro0, ro1) (boxblur.h:602-742, vblur_combine_kernel); the value of row r replaces
             //      the row-blurred value of row r - rad - 1, which that step was the last to need
             const int J = T - 2;
@@ -443,7 +470,18 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
                 HBj[(HROWS + 1) * HS + lane] = tv;                        // leaves the strip through the hand-over wave
                 FS_T1(2)
             }
-        } else {
+        }
+        lds_barrier();
+#ifdef FS_PROFILE
+        pt[0] += __builtin_readcyclecounter() - ts_;
+#endif
+    }
+    } else {
+    for (int T = 0; T < NB + 4; ++T) {
+#ifdef FS_PROFILE
+        const long long ts_ = __builtin_readcyclecounter();
+#endif
+        {
             // ---- the hand-over.  Everything that crosses to another workgroup goes through THIS wave: its write-through (sc1) stores are
             //      the only stores it has in flight, so waiting for them a step later costs nothing and neither holds up the coefficient
             //      traffic of the other waves nor needs a release fence (which would write back the XCD's whole dirty L2, full of this
@@ -481,6 +519,7 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
 #ifdef FS_PROFILE
         pt[0] += __builtin_readcyclecounter() - ts_;
 #endif
+    }
     }
   }
 #ifdef FS_PROFILE
