@@ -315,12 +315,21 @@ __global__ void __launch_bounds__(256) mad_sample_kernel(const float *bands, siz
     int *s = scr + (size_t)sub * MAD_WIN_STRIDE;
     for (int i = threadIdx.x; i <= MAD_SAMPLE_BINS; i += 256) h[i] = 0;
     __syncthreads();
-    // every 32nd chunk of 256 consecutive coefficients
-    for (size_t chunk = (size_t)blockIdx.x * 32; chunk * 256 < n; chunk += (size_t)gridDim.x * 32) {
-        const size_t i = chunk * 256 + threadIdx.x;
-        if (i < n) {
-            const int v = (int)fminf(fabsf(data[i]), 65535.f);
-            atomicAdd(&h[v < MAD_SAMPLE_BINS ? v : MAD_SAMPLE_BINS], 1);
+    // every 32nd chunk of 256 consecutive coefficients; eight chunks per iteration with their loads first (a load under `if (i < n)` is waited
+    // for before the next one is issued: one load in flight per wave, 46 us for 63 MB)
+    constexpr int U = 8;
+    const size_t cstride = (size_t)gridDim.x * 32;
+    for (size_t chunk0 = (size_t)blockIdx.x * 32; chunk0 * 256 < n; chunk0 += cstride * U) {
+        float x[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) { const size_t i = (chunk0 + k * cstride) * 256 + threadIdx.x; x[k] = data[i < n ? i : n - 1]; }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const size_t i = (chunk0 + k * cstride) * 256 + threadIdx.x;
+            if (i < n) {
+                const int v = (int)fminf(fabsf(x[k]), 65535.f);
+                atomicAdd(&h[v < MAD_SAMPLE_BINS ? v : MAD_SAMPLE_BINS], 1);
+            }
         }
     }
     __syncthreads();
