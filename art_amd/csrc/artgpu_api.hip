@@ -118,6 +118,7 @@ int fail(artgpu_ctx *ctx, int code, const char *fmt, ...)
             snprintf(more, sizeof more, " [shrink_blur_kernel: band %d strip %d waited 5 s for the strip above to hand down block %d (its counter: %d)]",
                      ctx->fs_diag[1], ctx->fs_diag[2], ctx->fs_diag[3], ctx->fs_diag[4]);
             ctx->err += more;
+            ctx->fs_diag[0] = 0;      // reported once: a later, unrelated failure is not attributed to it
         }
     }
     return code;
