@@ -1,0 +1,75 @@
+"""CPU: what the compiler made of the kernels the design depends on, read from the built library's gfx950 code objects (art_amd/codeobj.py).
+The persistent kernels run ONE 1024-thread workgroup per CU -- sixteen waves, four per SIMD, 128 registers per lane -- and are bound by
+instruction issue or by a tight step loop: a register spill or a scratch array there costs a memory round trip per use with nothing to hide it
+behind.  These are properties of (source, compiler) pairs, so they are pinned here rather than found in a bench line."""
+import os
+import re
+
+import pytest
+
+from art_amd import codeobj
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "art_amd", "libartgpu.so")
+
+
+@pytest.fixture(scope="module")
+def table():
+    return codeobj.kernel_table(LIB)
+
+
+def _find(table, pattern):
+    hits = {n: r for n, r in table.items() if re.search(pattern, n)}
+    assert hits, f"no kernel matches {pattern!r}"
+    return hits
+
+
+def test_every_translation_unit_has_a_gfx950_code_object(table):
+    # one bundle per .hip file of the library, every kernel family present
+    for fam in ("amaze_stream_kernel", "rcd_stream_kernel", "xtrans_tiles_kernel", "shrink_blur_kernel", "detail_blocks_kernel", "nlm_group_kernel",
+                "wavelet_analysis0_kernel", "tone_std_lds_kernel", "tone_neutral_lds_kernel", "gf_finish_kernel", "vng4_green_kernel"):
+        _find(table, fam)
+    assert len(table) >= 120
+
+
+# kernel (regex on the demangled name) -> most registers it may use.  1024 threads: 128; the figures below that are the ones DESIGN.md quotes
+NO_SPILL = {
+    r"amaze_stream_kernel": 128,                     # 122 in round 5
+    r"rcd_stream_kernel<[48]>": 128,
+    r"shrink_blur_kernel<7>": 128,                   # 99 since the per-role loops
+    r"shrink_blur_kernel<15>": 128,                  # 126, and no spills left
+    r"rgb2yuv_lds_kernel": 128, r"yuv2rgb_lds_kernel": 128, r"chroma_map_lds_kernel": 128,
+    r"tone_std_lds_kernel<false>": 128, r"tone_neutral_lds_kernel<(true|false)>": 128,
+    r"detail_gather_kernel": 128,
+    r"detail_blocks_kernel<[123]>": 256,             # one wave per workgroup, two per SIMD
+    r"nlm_group_kernel<[12]>": 168,                  # 704 threads: eleven waves, three on a SIMD
+    r"wavelet_(analysis0|synthesis0|haar_analysis|haar_synthesis)_kernel": 128,
+    r"mad_(sample|window|hist)_kernel": 128,
+    r"hblur_kernel<\d+, (true|false)>": 128, r"vblur_combine_kernel<(true|false)>": 128,
+    r"gauss_stream_kernel<false>": 256,
+}
+
+
+@pytest.mark.parametrize("pattern", sorted(NO_SPILL))
+def test_hot_kernels_neither_spill_nor_use_scratch(table, pattern):
+    for name, r in _find(table, pattern).items():
+        assert r["vgpr_spills"] == 0 and r["scratch_bytes"] == 0, (name, r)
+        assert r["vgprs"] <= NO_SPILL[pattern], (name, r)
+
+
+def test_workgroups_fit_their_cu(table):
+    """registers x waves per SIMD within the 512-entry file, static LDS within 160 KB (dynamic LDS is checked at launch: dyn_lds_once)"""
+    for name, r in table.items():
+        waves_per_simd = -(-r["max_workgroup"] // 256)
+        assert r["vgprs"] * waves_per_simd <= 512, (name, r)
+        assert r["static_lds_bytes"] <= 160 * 1024, (name, r)
+
+
+def test_known_exceptions_stay_small(table):
+    """X-Trans keeps one register in scratch at 128 (a second workgroup per CU is ruled out by its 156 KB of LDS anyway); the arena form of AMaZE
+    (amaze_kernel<0, ...>: the few tiles the stream kernel hands back, 9 us per frame) and the double-precision curve tail of the tone pass may spill"""
+    (xt,) = _find(table, r"xtrans_tiles_kernel").values()
+    assert xt["vgpr_spills"] <= 2 and xt["scratch_bytes"] <= 16, xt
+    allowed = r"xtrans_tiles_kernel|amaze_kernel<0, |tone_std_lds_kernel<true>|gauss_stream_kernel<true>"
+    others = {n: r for n, r in table.items() if (r["vgpr_spills"] or r["scratch_bytes"]) and not re.search(allowed, n)}
+    assert not others, others
