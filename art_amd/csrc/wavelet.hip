@@ -23,7 +23,13 @@ __constant__ float SYN_LO[6] = {-0.091506351f, 0.15849365f, 0.59150635f, 0.34150
 __constant__ float SYN_HI[6] = {0.f, 0.f, -0.34150635f, 0.59150635f, -0.15849365f, -0.091506351f};
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-constexpr int A0_TW = 64, A0_TH = 16;          // output tile of the level-0 analysis
+#ifndef A0_TW_
+#define A0_TW_ 64
+#endif
+#ifndef A0_TH_
+#define A0_TH_ 16
+#endif
+constexpr int A0_TW = A0_TW_, A0_TH = A0_TH_;   // output tile of the level-0 analysis
 constexpr int A0_LW = 2 * A0_TW + 6;           // tmp columns kept in LDS
 #ifndef S0_TW_
 #define S0_TW_ 128
