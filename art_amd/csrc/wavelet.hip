@@ -27,9 +27,13 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 #define A0_TW_ 64
 #endif
 #ifndef A0_TH_
+#ifdef A0_PLAIN
 #define A0_TH_ 16
+#else
+#define A0_TH_ 32
 #endif
-constexpr int A0_TW = A0_TW_, A0_TH = A0_TH_;   // output tile of the level-0 analysis
+#endif
+constexpr int A0_TW = A0_TW_, A0_TH = A0_TH_;   // output tile of the level-0 analysis (64 x 32; -DA0_PLAIN: the six-loads-per-value form of rounds 1 - 4 with its 64 x 16)
 constexpr int A0_LW = 2 * A0_TW + 6;           // tmp columns kept in LDS
 #ifndef S0_TW_
 #define S0_TW_ 128
@@ -42,6 +46,11 @@ constexpr int S0_LH = S0_TH / 2 + 4;           // horizontally synthesised rows 
 } // namespace
 
 // ---- level 0 analysis: src (w x h) -> lo, b1, b2, b3 (w2 x h2) ----
+// Column stage first (the reference's tmpLo / tmpHi, here a tile in LDS), then the row stage from LDS.  A tmp value is six input rows of one column,
+// and output rows one apart share four of their six: a thread walks A0_WR output rows down ONE tmp column with the 2 A0_WR + 4 input values in
+// registers -- all loads issued first, 2.25 loads per tmp value instead of 6 --, 128 columns x A0_TH / A0_WR row groups per workgroup; the six halo
+// columns of the tile take the plain six-load form.  Every sum keeps the reference's term order (zero taps included).
+#ifdef A0_PLAIN
 __global__ void __launch_bounds__(256) wavelet_analysis0_kernel(WaveArgs a)
 {
     __shared__ float tLo[A0_TH][A0_LW], tHi[A0_TH][A0_LW];
@@ -83,6 +92,77 @@ __global__ void __launch_bounds__(256) wavelet_analysis0_kernel(WaveArgs a)
         a.lo[o] = l0; a.b1[o] = h0; a.b2[o] = l1; a.b3[o] = h1;
     }
 }
+
+#else
+constexpr int A0_WR = 16;
+static_assert(A0_TW == 64 && A0_TH * 128 == 256 * A0_WR, "the walkers' mapping: 128 tmp columns x A0_TH / A0_WR row groups = 256 threads");
+__global__ void __launch_bounds__(256) wavelet_analysis0_kernel(WaveArgs a)
+{
+    __shared__ float tLo[A0_TH][A0_LW], tHi[A0_TH][A0_LW];
+    const int w = a.w, h = a.h, w2 = a.w2;
+    const int c0 = blockIdx.x * A0_TW, r0 = blockIdx.y * A0_TH; // output coords
+    const int icol0 = 2 * c0 - 3;                                // first tmp column held
+    {
+        // tmp columns 0 .. 127: thread = (row group, column)
+        const int g = threadIdx.x >> 7, cc = threadIdx.x & 127;
+        const int orow0 = r0 + g * A0_WR;
+        const int k = clampi(icol0 + cc, 0, w - 1);
+        const int b0 = 2 * orow0 - 3;                            // lowest input row of the walk: output row q reads rows b0 + 2 q + 5 - j, j = 0 .. 5
+        float v[2 * A0_WR + 4];
+#pragma unroll
+        for (int i = 0; i < 2 * A0_WR + 4; ++i) v[i] = a.src[(size_t)clampi(b0 + i, 0, h - 1) * a.src_stride + k];
+        // tmp columns 128 .. 133 (A0_TH x 6 values): one each
+        const int hr = threadIdx.x / 6, hc = 128 + (int)threadIdx.x - hr * 6;
+        const bool halo = hr < A0_TH;
+        const int hk = clampi(icol0 + hc, 0, w - 1), hrow = 2 * (r0 + (halo ? hr : 0));
+        float hv[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) hv[j] = a.src[(size_t)clampi(hrow + (2 - j), 0, h - 1) * a.src_stride + hk];
+#pragma unroll
+        for (int q = 0; q < A0_WR; ++q) {
+            float l = 0.f, hh = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float sv = v[2 * q + 5 - j];
+                l += DAUB_LO[j] * sv;
+                hh += DAUB_HI[j] * sv;
+            }
+            if (orow0 + q < a.h2) {
+                tLo[g * A0_WR + q][cc] = l;
+                tHi[g * A0_WR + q][cc] = hh;
+            }
+        }
+        if (halo && r0 + hr < a.h2) {
+            float l = 0.f, hh = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                l += DAUB_LO[j] * hv[j];
+                hh += DAUB_HI[j] * hv[j];
+            }
+            tLo[hr][hc] = l;
+            tHi[hr][hc] = hh;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < A0_TH * A0_TW; t += 256) {
+        const int rr = t / A0_TW, cc = t - rr * A0_TW;
+        const int orow = r0 + rr, ocol = c0 + cc;
+        if (orow >= a.h2 || ocol >= w2) continue;
+        const int i = 2 * ocol;
+        float l0 = 0.f, h0 = 0.f, l1 = 0.f, h1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            // clamped column i+2-j, expressed in LDS coordinates (LDS column x holds clamp(icol0+x))
+            const int x = clampi(i + (2 - j), 0, w - 1) - icol0;
+            const float sl = tLo[rr][x], sh = tHi[rr][x];
+            l0 += DAUB_LO[j] * sl; h0 += DAUB_HI[j] * sl;
+            l1 += DAUB_LO[j] * sh; h1 += DAUB_HI[j] * sh;
+        }
+        const size_t o = (size_t)orow * w2 + ocol;
+        a.lo[o] = l0; a.b1[o] = h0; a.b2[o] = l1; a.b3[o] = h1;
+    }
+}
+#endif
 
 // ---- levels >= 1 analysis: undecimated Haar (cplx_wavelet_level.h:206-238) ----
 __global__ void __launch_bounds__(256) wavelet_haar_analysis_kernel(WaveArgs a)
