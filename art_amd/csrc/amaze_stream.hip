@@ -63,7 +63,8 @@ __device__ __forceinline__ void wave_p13(amz_lf lds, const TileArgs &a, int r, i
 __device__ __forceinline__ void wave_list(amz_lf lds, const TileArgs &a, int T, int r, int lane)
 {
     const int buf = (T + 1) & 1;     // the list step T+1 consumes
-    amz_li red = (amz_li)(lds + RED_OFF), list = (amz_li)(lds + LIST_OFF + buf * LIST_INTS);
+    amz_li red = (amz_li)(lds + RED_OFF);
+    amz_ls list = (amz_ls)(lds + LIST_OFF + buf * LIST_INTS);
     int n = 0;
     if (r + 1 >= 8 && r < a.rr1 - 8) {
 #pragma unroll
@@ -73,7 +74,7 @@ __device__ __forceinline__ void wave_list(amz_lf lds, const TileArgs &a, int T, 
             const bool f = nyq_site(lds, a, r, c, &rr);
             const unsigned long long m = __ballot(f);
             const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-            if (f) list[pos] = (rr << 8) | c;
+            if (f) list[pos] = (unsigned short)((rr << 8) | c);
             n += __popcll(m);
         }
     }
@@ -82,11 +83,207 @@ __device__ __forceinline__ void wave_list(amz_lf lds, const TileArgs &a, int T, 
 
 } // namespace
 
+// ---- the tile sequence of a workgroup (every wave keeps its own copy in scalar registers; the leader -- thread 0 -- feeds it) ----
+// tile blockIdx.x first, then whatever the shared tile counter hands out (the workgroups do not start together when the arena kernel's
+// tiles occupy some CUs at first, and a fixed share per workgroup made the last starter the kernel's length), then the redo queue
+__device__ __forceinline__ TileRef seq_tile_ref(const AmazeStreamArgs &s, amz_lf lds, int k)
+{
+    amz_li dyn = (amz_li)(lds + DYN_OFF);          // the entry the leader pulled for sequence position dyn[0]
+    TileRef t;
+    int tile = -1;
+    if (k == 0) tile = s.tiles[blockIdx.x];
+    else if (dyn[0] == k && dyn[1] >= 0) tile = dyn[1];
+    if (tile >= 0) {
+        const int ty = tile / s.ntx, tx = tile - ty * s.ntx;
+        const int top = -16 + ty * (TS - 32);
+        tile_ref_set(t, k, tile, top, -16 + tx * (TS - 32), min(top + TS, s.H + 16) - top);
+        if (k > 0 && dyn[6]) { t.tile |= TILE_REDO; t.box = ny_pack(dyn[2], dyn[3], dyn[4], dyn[5]); }
+    } else {
+        tile_ref_none(t, k);
+    }
+    return t;
+}
+// leader: take the next fresh tile, or one entry of the redo queue, for sequence position k (none: dyn[1] = -1)
+__device__ __noinline__ void seq_pull(const AmazeStreamArgs &s, amz_lf lds, int k)
+{
+    amz_li dyn = (amz_li)(lds + DYN_OFF);
+    int *const cnt = reinterpret_cast<int *>(s.queue_words + s.ntiles);    // eight bookkeeping counters behind the queue (artgpu_get_option)
+    int tile = -1;
+    unsigned long long w = 0;
+    if (dyn[7]) {
+        // tiles gridDim.x .. ntiles - 1 of the list are handed out in order (queue_hdr[2], cleared per launch)
+        const int i = (int)gridDim.x + atomicAdd(&s.queue_hdr[2], 1);
+        if (i < s.ntiles) {
+            dyn[0] = k; dyn[1] = s.tiles[i]; dyn[6] = 0;
+            return;
+        }
+        dyn[7] = 0;
+    }
+    // every read of the queue is a read-modify-write (+0): the per-XCD L2s are not coherent with each other, and a plain or sc1
+    // load can return what an earlier launch left in this XCD's L2 -- a consumer that trusted a stale "reserved" count took a
+    // slot that was never published in this launch, and the real entry published there later was lost
+    const int taken = __hip_atomic_fetch_add(&s.queue_hdr[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int reserved = __hip_atomic_fetch_add(&s.queue_hdr[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (taken < reserved) {
+        int expect = taken;
+        if (__hip_atomic_compare_exchange_strong(&s.queue_hdr[1], &expect, taken + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            // the producer publishes the word right after reserving the slot; if it does not show up, abandon the slot (the
+            // producer's publishing compare-and-swap then fails and it hands the tile to the arena kernel instead)
+            for (int spin = 0; spin < 4096; ++spin) {
+                w = __hip_atomic_fetch_or(&s.queue_words[taken], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (w) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            if (!w) {
+                unsigned long long zero = 0;
+                if (!__hip_atomic_compare_exchange_strong(&s.queue_words[taken], &zero, ~0ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                    w = zero;      // published in the meantime
+            }
+            if (w && w != ~0ull) tile = (int)(w & 0xffffffu);
+        }
+    }
+    atomicAdd(&cnt[tile >= 0 ? 0 : 1], 1);
+    dyn[0] = k; dyn[1] = tile; dyn[6] = 1;
+    dyn[2] = (int)((w >> 24) & 0xff); dyn[3] = (int)((w >> 32) & 0xff); dyn[4] = (int)((w >> 40) & 0xff); dyn[5] = (int)((w >> 48) & 0xff);
+}
+// leader, every stage has left tile q.back: is it valid?  If not, stream it again with the true box: publish a queue entry; if the slot
+// was abandoned, the arena kernel takes the tile.
+// The per-XCD L2s are not coherent with each other: the second attempt runs on another CU, possibly another XCD, and BOTH L2s would hold
+// dirty copies of the tile's output lines -- whichever is written back last wins.  So before the tile is offered again its pixels leave
+// this XCD's L2: the storing waves drain their stores one step ahead (the output stage finished the tile eight steps ago), then the
+// leader writes the L2 back (release, agent scope) and publishes.
+__device__ __noinline__ void seq_tile_done(const AmazeStreamArgs &s, amz_lf lds, int par, int rr1, int tile, int redo)
+{
+    int *const cnt = reinterpret_cast<int *>(s.queue_words + s.ntiles);
+    int box[4];
+    if (!tile_valid(lds, par, rr1, box) && !redo) {
+        const unsigned long long w = (unsigned long long)tile | ((unsigned long long)box[0] << 24) | ((unsigned long long)box[1] << 32) |
+                                     ((unsigned long long)box[2] << 40) | ((unsigned long long)box[3] << 48) | (1ull << 63);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int slot = atomicAdd(&s.queue_hdr[0], 1);
+        unsigned long long zero = 0;
+        atomicAdd(&cnt[2], 1);
+        if (!__hip_atomic_compare_exchange_strong(&s.queue_words[slot], &zero, w, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            const int fs = atomicAdd(&s.fallback[0], 1);
+            s.fallback[1 + fs] = tile;
+            atomicAdd(&cnt[3], 1);
+        }
+    }
+    red_reset(lds, par);
+}
+
+#ifdef AMZ_PROFILE
+#define AMZ_T0 const long long t0_ = __builtin_amdgcn_s_memtime();
+#define AMZ_T1(acc) { const long long t1_ = __builtin_amdgcn_s_memtime(); acc += t1_ - t0_; }
+#else
+#define AMZ_T0
+#define AMZ_T1(acc)
+#endif
+
+// One step loop per pair of roles (round 6).  A wave plays role KA in sub-step a and KB in sub-step b for the whole kernel, and the
+// workgroup barrier only counts arrivals, so every pair of roles gets a loop of its own: it keeps what ITS two stages need in registers
+// (the one loop of rounds 2 - 5 carried every role's scalars through every role's code: 106 scalar registers, 43 of them spilled to
+// lanes), hoists its lane offsets out of the loop, and only the leader's loop carries the tile bookkeeping.
+template <int KA, int KB, bool LEADER>
+__device__ __forceinline__ void role_loop(const AmazeStreamArgs &s, amz_lf lds, const int wave, const int ca_, const int cb_, const int lane_)
+{
+    TileArgs frame;
+    frame.raw = (amz_gcf)s.raw; frame.rs = (long)s.raw_stride;
+    frame.red = (amz_gf)s.red; frame.green = (amz_gf)s.green; frame.blue = (amz_gf)s.blue; frame.os = (long)s.out_stride;
+    frame.W = s.W; frame.H = s.H; frame.filters = s.filters; frame.clip_pt = s.clip_pt; frame.clip_pt8 = s.clip_pt8; frame.g00 = s.g00; frame.ey = s.ey;
+    frame.top = 0; frame.left = 0; frame.rr1 = 0; frame.gbase = 0; frame.rbase = 0; frame.g0 = 0; frame.pos = 0; frame.ny_box = 0;
+
+    TileSeq q;
+    q.t2 = 0;
+    tile_ref_none(q.back, -1);
+    q.front = seq_tile_ref(s, lds, 0);
+    q.next = seq_tile_ref(s, lds, 1);
+    int nk = q.next.rr1 > 0 ? 2 : 1;
+
+    ThreadRegs rg;
+    bb_reset(rg.bb);
+    rg.pos_p = rg.pos_h = rg.pos_stride2 = rg.pos_off4 = 0;
+    P8Regs p8;
+    p8.cc = -1;
+    if (KA == LOADER_ROLE) st_load_first(lds, frame, q, ca_);
+    if (KA == A_LIGHT) pos_init(lds, ca_, rg);
+    lds_barrier();                                   // (the ring position table of step 0)
+#ifdef AMZ_PROFILE
+    long long ta = 0, tb = 0, tw = 0;
+#endif
+    int tt = 0;                                      // T % STEPS_PER_TILE
+    for (int T = 0; T < STEPS_PER_TILE * nk + TAIL_STEPS; ++T, ++tt) {
+        q.t2 = 2 * T;
+        if (tt == STEPS_PER_TILE) {                  // the load front enters the next tile
+            tt = 0;
+            q.back = q.front;
+            q.front = q.next;
+            const int kn = q.front.gbase / TS + 1;
+            q.next = seq_tile_ref(s, lds, kn);
+            if (q.next.rr1 > 0 && nk < kn + 1) nk = kn + 1;
+        }
+        int ca = ca_, cb = cb_, lane = lane_;
+#ifndef AMZ_HOIST_LANES
+        // the column / lane are made opaque per step: otherwise a role's column-derived addresses are hoisted out of the step loop and kept
+        // live across the other sub-step's role
+        asm volatile("" : "+v"(ca), "+v"(cb), "+v"(lane));
+#endif
+        if (KB == B_P16OUT) { if (tile_drain(q, T)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (LEADER && threadIdx.x == 0) {
+            if (tile_done(q, T)) seq_tile_done(s, lds, (q.back.gbase / TS) & 1, q.back.rr1, tile_index(q.back), tile_redo(q.back) ? 1 : 0);
+            // one step before the load front needs a sequence position beyond the first tile: ask the tile counter / the redo queue
+            if (tt + 1 == STEPS_PER_TILE) seq_pull(s, lds, q.front.gbase / TS + 2);
+        }
+        { AMZ_T0 if (KA != A_P8) substep_a(lds, frame, q, T, KA, ca, rg); else p8_step_a(lds, frame, q, T, lane, p8, rg.bb); AMZ_T1(ta) }
+        { AMZ_T0 lds_barrier(); AMZ_T1(tw) }
+        AMZ_T0
+        if (KB < B_P9) {
+            substep_b_threads(lds, frame, q, T, KB, cb);
+        } else if (KB == B_P9) {
+            const TileArgs a = stage_tile(frame, q, 2 * T - 26);
+            wave_p9(lds, a, a.rbase - 26, lane);
+        } else if (KB == B_P13_P14) {
+            {
+                const TileArgs a = stage_tile(frame, q, 2 * T - 26);
+                wave_p13(lds, a, a.rbase - 26, lane);
+            }
+            const TileArgs a = stage_tile(frame, q, 2 * T - 30);
+            p14_worker(lds, a, a.rbase - 30, lane);
+            wave_order();
+            if (lane == 0) hot_reset(lds, 1);
+        } else if (KB == B_P7_P10) {
+            {
+                const TileArgs a = stage_tile(frame, q, 2 * T - 14);
+                st_p7(lds, a, a.rbase - 14, lane);
+                st_p7(lds, a, a.rbase - 14, 64 + lane);
+                st_p7(lds, a, a.rbase - 14, 128 + lane);
+            }
+            {
+                const TileArgs a = stage_tile(frame, q, 2 * T - 20);
+                wave_list(lds, a, T, a.rbase - 20, lane);
+            }
+            const TileArgs a = stage_tile(frame, q, 2 * T - 30);
+            p10_worker(lds, a, a.rbase - 30, lane);
+            wave_order();
+            if (lane == 0) hot_reset(lds, 0);
+        } else {
+            p8_step_b(lds, frame, q, T, lane, p8, rg.bb);
+        }
+        AMZ_T1(tb)
+        { AMZ_T0 lds_barrier(); AMZ_T1(tw) }
+    }
+#ifdef AMZ_PROFILE
+    if (blockIdx.x == 100 && lane_ == 0) printf("wave %2d (a %d b %d): a %8lld  b %8lld  barrier-wait %8lld cycles (%d tiles)\n", wave, KA, KB, ta, tb, tw, nk);
+#endif
+}
+
 __global__ void __launch_bounds__(amz::NTHREADS)
 amaze_stream_kernel(AmazeStreamArgs s)
 {
     extern __shared__ float dyn_lds[];
     amz_lf lds = (amz_lf)dyn_lds;
+    if ((int)blockIdx.x >= s.ntiles) return;       // (more workgroups than tiles)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane_ = tid & 63;
@@ -97,194 +294,25 @@ amaze_stream_kernel(AmazeStreamArgs s)
     // issue arbitration on their SIMD, the column roles fill the gaps
     if (role.b >= B_P9 || role.a == A_P8) __builtin_amdgcn_s_setprio(2);
 
-    TileArgs frame;
-    frame.raw = (amz_gcf)s.raw; frame.rs = (long)s.raw_stride;
-    frame.red = (amz_gf)s.red; frame.green = (amz_gf)s.green; frame.blue = (amz_gf)s.blue; frame.os = (long)s.out_stride;
-    frame.W = s.W; frame.H = s.H; frame.filters = s.filters; frame.clip_pt = s.clip_pt; frame.clip_pt8 = s.clip_pt8; frame.g00 = s.g00; frame.ey = s.ey;
-    frame.top = 0; frame.left = 0; frame.rr1 = 0; frame.gbase = 0;
-
-    // this workgroup's tile sequence: tile blockIdx.x, then whatever the shared tile counter hands out (the workgroups do not start
-    // together when the arena kernel's tiles occupy some CUs at first, and a fixed share per workgroup made the last starter the
-    // kernel's length), then whatever the redo queue holds
-    int nk = ((int)blockIdx.x < s.ntiles) ? 1 : 0;
-    const int nk_static = nk;
-    amz_li dyn = (amz_li)(lds + DYN_OFF);          // the redo entry tid 0 pulled for sequence position dyn[0]
-    auto tile_ref = [&](int k) -> TileRef {
-        TileRef t;
-        if (k < nk_static) {
-            const int tile = s.tiles[blockIdx.x];
-            const int ty = tile / s.ntx, tx = tile - ty * s.ntx;
-            const int top = -16 + ty * (TS - 32);
-            tile_ref_set(t, k, tile, top, -16 + tx * (TS - 32), min(top + TS, s.H + 16) - top);
-        } else if (dyn[0] == k && dyn[1] >= 0) {
-            const int tile = dyn[1];
-            const int ty = tile / s.ntx, tx = tile - ty * s.ntx;
-            const int top = -16 + ty * (TS - 32);
-            tile_ref_set(t, k, tile, top, -16 + tx * (TS - 32), min(top + TS, s.H + 16) - top);
-            if (dyn[6]) { t.tile |= TILE_REDO; t.box = ny_pack(dyn[2], dyn[3], dyn[4], dyn[5]); }
-        } else {
-            tile_ref_none(t, k);
-        }
-        return t;
-    };
-    // tid 0: take one entry of the redo queue for sequence position k (none: dyn[1] = -1)
-    int *const cnt = reinterpret_cast<int *>(s.queue_words + s.ntiles);    // eight bookkeeping counters behind the queue (artgpu_get_option)
-    bool tiles_left = true;
-    auto pull = [&](int k) {
-        int tile = -1;
-        unsigned long long w = 0;
-        if (tiles_left) {
-            // tiles gridDim.x .. ntiles - 1 of the list are handed out in order (queue_hdr[2], cleared per launch)
-            const int i = (int)gridDim.x + atomicAdd(&s.queue_hdr[2], 1);
-            if (i < s.ntiles) {
-                dyn[0] = k; dyn[1] = s.tiles[i]; dyn[6] = 0;
-                return;
-            }
-            tiles_left = false;
-        }
-        // every read of the queue is a read-modify-write (+0): the per-XCD L2s are not coherent with each other, and a plain or sc1
-        // load can return what an earlier launch left in this XCD's L2 -- a consumer that trusted a stale "reserved" count took a
-        // slot that was never published in this launch, and the real entry published there later was lost
-        const int taken = __hip_atomic_fetch_add(&s.queue_hdr[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int reserved = __hip_atomic_fetch_add(&s.queue_hdr[0], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (taken < reserved) {
-            int expect = taken;
-            if (__hip_atomic_compare_exchange_strong(&s.queue_hdr[1], &expect, taken + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                // the producer publishes the word right after reserving the slot; if it does not show up, abandon the slot (the
-                // producer's publishing compare-and-swap then fails and it hands the tile to the arena kernel instead)
-                for (int spin = 0; spin < 4096; ++spin) {
-                    w = __hip_atomic_fetch_or(&s.queue_words[taken], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (w) break;
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                if (!w) {
-                    unsigned long long zero = 0;
-                    if (!__hip_atomic_compare_exchange_strong(&s.queue_words[taken], &zero, ~0ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                        w = zero;      // published in the meantime
-                }
-                if (w && w != ~0ull) tile = (int)(w & 0xffffffu);
-            }
-        }
-        atomicAdd(&cnt[tile >= 0 ? 0 : 1], 1);
-        dyn[0] = k; dyn[1] = tile; dyn[6] = 1;
-        dyn[2] = (int)((w >> 24) & 0xff); dyn[3] = (int)((w >> 32) & 0xff); dyn[4] = (int)((w >> 40) & 0xff); dyn[5] = (int)((w >> 48) & 0xff);
-    };
-    if (nk == 0) return;       // (more workgroups than tiles)
-    if (tid == 0) { dyn[0] = -1; dyn[1] = -1; if (nk_static == 1) pull(1); }
+    if (tid == 0) {
+        amz_li dyn = (amz_li)(lds + DYN_OFF);
+        dyn[0] = -1; dyn[1] = -1; dyn[7] = 1;      // dyn[7]: the tile counter still has tiles
+        seq_pull(s, lds, 1);
+    }
     seq_begin(lds, tid);
     lds_barrier();
-    TileSeq q;
-    tile_ref_none(q.back, -1);
-    q.front = tile_ref(0);
-    q.next = tile_ref(1);
-    if (q.next.rr1 > 0 && nk < 2) nk = 2;
-
-    ThreadRegs rg;
-    bb_reset(rg.bb);
-    P8Regs p8;
-    p8.cc = -1;
-    if (role.a == LOADER_ROLE) st_load_first(lds, frame, q, ca_);
-#ifdef AMZ_PROFILE
-    long long ta = 0, tb = 0, tw = 0;
-#define AMZ_T0 const long long t0_ = __builtin_amdgcn_s_memtime();
-#define AMZ_T1(acc) { const long long t1_ = __builtin_amdgcn_s_memtime(); acc += t1_ - t0_; }
-#else
-#define AMZ_T0
-#define AMZ_T1(acc)
-#endif
-#ifdef AMZ_DEBUG
-    int dbg[3][8]; int ndbg = 0;
-#endif
-    for (int T = 0; T < STEPS_PER_TILE * nk + TAIL_STEPS; ++T) {
-        if (T > 0 && T % STEPS_PER_TILE == 0) {      // the load front enters the next tile
-            q.back = q.front;
-            q.front = q.next;
-            const int kn = T / STEPS_PER_TILE + 1;
-            q.next = tile_ref(kn);
-            if (q.next.rr1 > 0 && nk < kn + 1) nk = kn + 1;
-        }
-        // the column / lane are made opaque per step: otherwise every role's column-derived addresses are hoisted out of the
-        // step loop and kept live across all the other roles (the kernel then spills into scratch inside the loop)
-        int ca = ca_, cb = cb_, lane = lane_;
-        asm volatile("" : "+v"(ca), "+v"(cb), "+v"(lane));
-        // The per-XCD L2s are not coherent with each other: if tile q.back has to be streamed again, the second attempt runs on another
-        // CU, possibly another XCD, and BOTH L2s would hold dirty copies of the tile's output lines -- whichever is written back last
-        // wins.  So before the tile is offered again its pixels leave this XCD's L2: every wave drains its stores one step ahead
-        // (the output stage finished the tile eight steps ago), then thread 0 writes the L2 back (release, agent scope) and publishes.
-        if (tile_drain(q, T)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (tid == 0) {
-            if (tile_done(q, T)) {                   // every stage has left tile q.back
-                const int par = (q.back.gbase / TS) & 1;
-                int box[4];
-#ifdef AMZ_DEBUG
-                { amz_li red = (amz_li)(lds + RED_OFF) + 8 * par; const bool v_ = tile_valid(lds, par, q.back.rr1, box);
-                  if ((!v_ || tile_redo(q.back)) && ndbg < 3) { dbg[ndbg][0] = tile_index(q.back); dbg[ndbg][1] = tile_redo(q.back); dbg[ndbg][2] = (int)v_; dbg[ndbg][3] = box[2]; dbg[ndbg][4] = box[3]; dbg[ndbg][5] = red[6]; dbg[ndbg][6] = red[7]; dbg[ndbg][7] = T; ++ndbg; } }
-#endif
-                if (!tile_valid(lds, par, q.back.rr1, box) && !tile_redo(q.back)) {
-                    // stream it again with the true box: publish a queue entry; if the slot was abandoned, the arena kernel takes the tile
-                    const unsigned long long w = (unsigned long long)tile_index(q.back) | ((unsigned long long)box[0] << 24) | ((unsigned long long)box[1] << 32) |
-                                                 ((unsigned long long)box[2] << 40) | ((unsigned long long)box[3] << 48) | (1ull << 63);
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const int slot = atomicAdd(&s.queue_hdr[0], 1);
-                    unsigned long long zero = 0;
-                    atomicAdd(&cnt[2], 1);
-                    if (!__hip_atomic_compare_exchange_strong(&s.queue_words[slot], &zero, w, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        const int fs = atomicAdd(&s.fallback[0], 1);
-                        s.fallback[1 + fs] = tile_index(q.back);
-                        atomicAdd(&cnt[3], 1);
-                    }
-                }
-                red_reset(lds, par);
-            }
-            // one step before the load front needs a sequence position beyond the static tiles: look into the redo queue
-            const int kn = (T + 1) / STEPS_PER_TILE + 1;
-            if ((T + 1) % STEPS_PER_TILE == 0 && kn >= nk_static) pull(kn);
-        }
-        { AMZ_T0 if (role.a != A_P8) substep_a(lds, frame, q, T, role.a, ca, rg); else p8_step_a(lds, frame, q, T, lane, p8, rg.bb); AMZ_T1(ta) }
-        { AMZ_T0 lds_barrier(); AMZ_T1(tw) }
-        AMZ_T0
-        if (role.b < B_P9) {
-            substep_b_threads(lds, frame, q, T, role.b, cb);
-        } else if (role.b == B_P9) {
-            const TileArgs a = stage_tile(frame, q, 2 * T - 26);
-            wave_p9(lds, a, 2 * T - 26 - a.gbase, lane);
-        } else if (role.b == B_P13_P14) {
-            {
-                const TileArgs a = stage_tile(frame, q, 2 * T - 26);
-                wave_p13(lds, a, 2 * T - 26 - a.gbase, lane);
-            }
-            const TileArgs a = stage_tile(frame, q, 2 * T - 30);
-            p14_worker(lds, a, 2 * T - 30 - a.gbase, lane);
-            wave_order();
-            if (lane == 0) hot_reset(lds, 1);
-        } else if (role.b == B_P7_P10) {
-            {
-                const TileArgs a = stage_tile(frame, q, 2 * T - 14);
-                st_p7(lds, a, 2 * T - 14 - a.gbase, lane);
-                st_p7(lds, a, 2 * T - 14 - a.gbase, 64 + lane);
-                st_p7(lds, a, 2 * T - 14 - a.gbase, 128 + lane);
-            }
-            {
-                const TileArgs a = stage_tile(frame, q, 2 * T - 20);
-                wave_list(lds, a, T, 2 * T - 20 - a.gbase, lane);
-            }
-            const TileArgs a = stage_tile(frame, q, 2 * T - 30);
-            p10_worker(lds, a, 2 * T - 30 - a.gbase, lane);
-            wave_order();
-            if (lane == 0) hot_reset(lds, 0);
-        } else {
-            p8_step_b(lds, frame, q, T, lane, p8, rg.bb);
-        }
-        AMZ_T1(tb)
-        { AMZ_T0 lds_barrier(); AMZ_T1(tw) }
+    switch (role.a) {
+    case A_P2: role_loop<A_P2, B_P16OUT, false>(s, lds, wave, ca_, cb_, lane_); break;
+    case A_P5L: role_loop<A_P5L, B_P3R0, false>(s, lds, wave, ca_, cb_, lane_); break;
+    case A_P12: role_loop<A_P12, B_P3R1, false>(s, lds, wave, ca_, cb_, lane_); break;
+    case A_LIGHT: role_loop<A_LIGHT, B_P1P11, true>(s, lds, wave, ca_, cb_, lane_); break;
+    case A_P8: role_loop<A_P8, B_P8, false>(s, lds, wave, ca_, cb_, lane_); break;
+    default:
+        if (role.b == B_P13_P14) role_loop<A_P4, B_P13_P14, false>(s, lds, wave, ca_, cb_, lane_);
+        else if (role.b == B_P7_P10) role_loop<A_P4, B_P7_P10, false>(s, lds, wave, ca_, cb_, lane_);
+        else role_loop<A_P4, B_P9, false>(s, lds, wave, ca_, cb_, lane_);
+        break;
     }
-#ifdef AMZ_DEBUG
-    if (tid == 0) for (int k = 0; k < ndbg; ++k) printf("wg %d: tile %d redo %d valid %d box cols %d %d sites cols %d %d at T %d (nk %d)\n", (int)blockIdx.x, dbg[k][0], dbg[k][1], dbg[k][2], dbg[k][3], dbg[k][4], dbg[k][5], dbg[k][6], dbg[k][7], nk);
-#endif
-#ifdef AMZ_PROFILE
-    if (blockIdx.x == 100 && lane_ == 0) printf("wave %2d: a %8lld  b %8lld  barrier-wait %8lld cycles (%d tiles)\n", wave, ta, tb, tw, nk);
-#endif
 }
 
 hipError_t launch_amaze_stream(const AmazeStreamArgs &s, int grid, hipStream_t stream)

@@ -38,6 +38,8 @@
 typedef float *amz_lf;
 typedef unsigned char *amz_lb;
 typedef int *amz_li;
+typedef unsigned short *amz_ls;
+typedef char *amz_lc;
 typedef const float *amz_gcf;
 typedef float *amz_gf;
 namespace amz {
@@ -60,6 +62,8 @@ static inline int imax(int a, int b) { return a > b ? a : b; }
 typedef __attribute__((address_space(3))) float *amz_lf;
 typedef __attribute__((address_space(3))) unsigned char *amz_lb;
 typedef __attribute__((address_space(3))) int *amz_li;
+typedef __attribute__((address_space(3))) unsigned short *amz_ls;
+typedef __attribute__((address_space(3))) char *amz_lc;
 typedef const __attribute__((address_space(1))) float *amz_gcf;
 typedef __attribute__((address_space(1))) float *amz_gf;
 namespace amz {
@@ -139,8 +143,8 @@ constexpr int SIDE_OFF = LAYOUT.off[R_COUNT];   // delhvsqsum(row 4..75, cols 76
 constexpr int SIDE_FLOATS = 72 * 8;
 constexpr int NQA_OFF = SIDE_OFF + SIDE_FLOATS;  // cddiffsq(row 19, cols 80..119): the bytes nyquist2 rows 156,157 alias (never memset, L879)
 constexpr int NQA_FLOATS = 40;
-constexpr int LIST_OFF = NQA_OFF + NQA_FLOATS;   // P8 site list of one step (row << 8 | col), at most 144 entries
-constexpr int LIST_INTS = 160;                   // two lists: the one step t consumes is rebuilt (for step t+2) only after step t
+constexpr int LIST_OFF = NQA_OFF + NQA_FLOATS;   // P8 site list of one step (row << 8 | col, 16 bits each), at most 144 entries
+constexpr int LIST_INTS = 80;                    // two lists: the one step t consumes is rebuilt (for step t+2) only after step t
 constexpr int RED_OFF = LIST_OFF + 2 * LIST_INTS;    // int words: [0..3] flag box (min row, max row, min col, max col), [4..7] extent of the
 constexpr int RED_INTS = 24;                     // nyquist2 sites P8 processed; [8..15]: the same for the other tile in flight; [16], [17] list counts
 constexpr int STG_OFF = RED_OFF + RED_INTS;      // CFA staging: the raw values of the next step's two rows, written by LDS-DMA (two buffers)
@@ -149,7 +153,31 @@ constexpr int HOT_OFF = STG_OFF + STG_FLOATS;      // P10 / P14 site lists of on
 constexpr int HOT_INTS = 2 + 2 * 160;
 constexpr int DYN_OFF = HOT_OFF + HOT_INTS;      // the redo-queue entry pulled for the next sequence position (position, tile, box)
 constexpr int DYN_INTS = 8;
-constexpr int LDS_FLOATS = DYN_OFF + DYN_INTS;
+// Ring positions (round 6).  Every ring depth is even and a step starts at an even global row G0 = 2 T, so the rows of a PAIR
+// (G0 - 2 j, G0 - 2 j + 1) are neighbours in every ring and never straddle its wrap-around.  Where pair j of ring n lives in this step --
+// the byte address of its first row -- is one entry of a table in LDS; the table of step T + 1 is written during step T by the lanes of
+// the lightest column role (each lane owns one entry and advances it by one pair slot with a compare and a select), two tables alternate.
+// A row pointer is then ONE table word plus a literal (second row of the pair: + one row stride) instead of eight scalar instructions
+// for (gbase + row) % depth * stride + offset -- those were ~90 % of the kernel's scalar instruction stream (1.05e9 per 45 MP frame).
+struct PosTable {
+    int first[R_COUNT + 1];        // first entry of ring n; entry first[n] + j = pair j of ring n, 0 <= j < depth / 2
+    short h[192], j[192];          // per entry: pairs in its ring, its pair distance
+    int stride2[192], off4[192];   // bytes per pair, byte offset of the ring
+    constexpr PosTable() : first(), h(), j(), stride2(), off4()
+    {
+        int e = 0, k = 0;
+#define X(n, d, s) first[k++] = e; for (int i = 0; i < d / 2; ++i) { h[e] = d / 2; j[e] = (short)i; stride2[e] = 2 * s * 4; off4[e] = n##_OFF * 4; ++e; }
+        AMZ_RINGS(X)
+#undef X
+        first[k] = e;
+        for (; e < 192; ++e) { h[e] = 1; j[e] = 0; stride2[e] = 0; off4[e] = 0; }
+    }
+};
+constexpr PosTable POSTAB{};
+constexpr int POS_PAIRS = POSTAB.first[R_COUNT];
+static_assert(POS_PAIRS <= 192, "one entry per lane of the producing column role");
+constexpr int POS_OFF = DYN_OFF + DYN_INTS;      // two tables of POS_PAIRS words (byte addresses)
+constexpr int LDS_FLOATS = POS_OFF + 2 * POS_PAIRS;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
 
 constexpr int NTHREADS = 1024;
@@ -179,15 +207,16 @@ static inline void tag_read(int ring, int depth, int row)
 #define AMZ_GB (a.gbase)
 // row pointers: W = this stage writes the row, R = it reads a row that must hold exactly that tile row,
 // X = it reads a row whose content cannot reach an output (no check)
-#define ROWW(n, row) (AMZ_TAGW(n, AMZ_GB + (row)), lds + (amz::n##_OFF + (int)((unsigned)(AMZ_GB + (row)) % amz::n##_D) * amz::n##_S))
-#define ROWR(n, row) (AMZ_TAGR(n, AMZ_GB + (row)), lds + (amz::n##_OFF + (int)((unsigned)(AMZ_GB + (row)) % amz::n##_D) * amz::n##_S))
-#define ROWX(n, row) (lds + (amz::n##_OFF + (int)((unsigned)(AMZ_GB + (row)) % amz::n##_D) * amz::n##_S))
-// the same for a row r + k + s where r is uniform over the wave and s (0 or 1) differs per lane: both candidates are scalar
-// computations (a per-lane modulo costs five VALU instructions per row pointer), the lane only selects
-#define AMZ_SLOT(n, row) (amz::n##_OFF + (int)((unsigned)(AMZ_GB + (row)) % amz::n##_D) * amz::n##_S)
-#define SROWW(n, r, k, s) (AMZ_TAGW(n, AMZ_GB + (r) + (k) + (s)), lds + ((s) ? AMZ_SLOT(n, (r) + (k) + 1) : AMZ_SLOT(n, (r) + (k))))
-#define SROWR(n, r, k, s) (AMZ_TAGR(n, AMZ_GB + (r) + (k) + (s)), lds + ((s) ? AMZ_SLOT(n, (r) + (k) + 1) : AMZ_SLOT(n, (r) + (k))))
-#define SROWX(n, r, k, s) (lds + ((s) ? AMZ_SLOT(n, (r) + (k) + 1) : AMZ_SLOT(n, (r) + (k))))
+#define AMZ_ROWP(n, row) amz::ring_ptr<amz::R_##n, amz::n##_D, amz::n##_S, amz::n##_OFF>(lds, a, (row))
+#define ROWW(n, row) (AMZ_TAGW(n, AMZ_GB + (row)), AMZ_ROWP(n, row))
+#define ROWR(n, row) (AMZ_TAGR(n, AMZ_GB + (row)), AMZ_ROWP(n, row))
+#define ROWX(n, row) (AMZ_ROWP(n, row))
+// the same for a row r + k + s where r is uniform over the wave and s (0 or 1) differs per lane: with r + k even the two candidates are the
+// rows of one pair (one table word, the lane adds s row strides), with r + k odd they are the last row of one pair and the first of the next
+#define AMZ_SROWP(n, r, k, s) amz::ring_ptr_s<amz::R_##n, amz::n##_D, amz::n##_S, amz::n##_OFF>(lds, a, (r) + (k), (s))
+#define SROWW(n, r, k, s) (AMZ_TAGW(n, AMZ_GB + (r) + (k) + (s)), AMZ_SROWP(n, r, k, s))
+#define SROWR(n, r, k, s) (AMZ_TAGR(n, AMZ_GB + (r) + (k) + (s)), AMZ_SROWP(n, r, k, s))
+#define SROWX(n, r, k, s) (AMZ_SROWP(n, r, k, s))
 
 struct TileArgs {
     amz_gcf raw;        // CFA plane
@@ -197,6 +226,10 @@ struct TileArgs {
     int top, left;      // tile origin in the frame (may be negative: mirrored border, L205-334)
     int rr1;            // rows of the tile (160, less at the bottom edge of the frame; 0: no tile)
     int gbase;          // 160 * (position of the tile in the workgroup's sequence): ring rows are gbase + tile row
+    int rbase;          // the tile row the step starts at: gbase + rbase = g0 (negative rows and rows beyond the tile are fine); a stage at
+                        // offset off gets r = rbase - off, so that (its rows) - rbase are literal constants
+    int g0;             // 2 T, the global row the step starts at (even)
+    int pos;            // byte offset of this step's ring position table
     int ny_box;         // the Nyquist box P7 / P8 / P10 work in (L827-876), [8, rr1-8) x [8, 152) on the first attempt, one byte per bound
                         // (r0 | r1 << 8 | c0 << 16 | c1 << 24: every value the kernel keeps per tile in flight is a scalar register it does not have)
     int W, H;
@@ -211,6 +244,32 @@ AMZ_DEV int ny_r0(const TileArgs &a) { return a.ny_box & 255; }
 AMZ_DEV int ny_r1(const TileArgs &a) { return (a.ny_box >> 8) & 255; }
 AMZ_DEV int ny_c0(const TileArgs &a) { return (a.ny_box >> 16) & 255; }
 AMZ_DEV int ny_c1(const TileArgs &a) { return (int)((unsigned)a.ny_box >> 24); }
+
+// pointer to tile row `row` of a ring (depth D rows of S floats at OFF) -- see "Ring positions" at the LDS layout
+template <int RING, int D, int S, int OFF>
+AMZ_DEV amz_lf ring_ptr(amz_lf lds, const TileArgs &a, int row)
+{
+    static_assert(D % 2 == 0, "ring depths are even: the two rows of a step are neighbours in every ring");
+    const int kc = row - a.rbase;                  // a literal once the stage is inlined (rows are r + const, r = rbase - off): <= 1
+    const int j = (-(kc >> 1)) % (D / 2);          // pair distance from the step's first row, modulo the ring's pairs
+    const int byte = *(amz_li)((amz_lc)lds + a.pos + 4 * (POSTAB.first[RING] + j)) + (kc & 1) * (S * 4);
+#ifdef AMZ_EMUL
+    if (kc > 1 || byte != OFF * 4 + (int)((unsigned)(a.gbase + row) % (unsigned)D) * S * 4) {
+        if (!g_tags.errors) { g_tags.first_ring = 100 + RING; g_tags.first_want = a.gbase + row; g_tags.first_have = byte; }
+        g_tags.errors++;
+        return lds + OFF + (int)((unsigned)(a.gbase + row) % (unsigned)D) * S;
+    }
+#endif
+    return (amz_lf)((amz_lc)lds + byte);
+}
+template <int RING, int D, int S, int OFF>
+AMZ_DEV amz_lf ring_ptr_s(amz_lf lds, const TileArgs &a, int rk, int s)
+{
+    const int kc = rk - a.rbase;
+    if ((kc & 1) == 0) return ring_ptr<RING, D, S, OFF>(lds, a, rk) + s * S;
+    amz_lf p0 = ring_ptr<RING, D, S, OFF>(lds, a, rk), p1 = ring_ptr<RING, D, S, OFF>(lds, a, rk + 1);
+    return s ? p1 : p0;
+}
 
 // parity helpers: site (r,c) is green iff ((r + c) & 1) ^ g00; the R/B sites of row r are the columns cc = par(r) mod 2
 AMZ_DEV int row_par(const TileArgs &a, int r) { return (r & 1) ^ a.g00; }
@@ -499,7 +558,7 @@ AMZ_DEV void st_p4(amz_lf lds, const TileArgs &a, int r, int c)
 // bounding box of the Nyquist flags it set / the nyquist2 sites it processed (min row, max row, min col, max col), merged into the
 // workgroup's boxes once per tile.  (An LDS atomic per flag would be turned into a scalar loop over the active lanes by the
 // compiler: four such loops per step cost more than the stage itself.)
-struct ThreadRegs { int bb[4]; };
+struct ThreadRegs { int bb[4]; int pos_p, pos_h, pos_stride2, pos_off4; };    // pos_*: the ring position table entry a lane of the producing role owns
 AMZ_DEV void bb_reset(int *bb) { bb[0] = 1 << 30; bb[1] = 0; bb[2] = 1 << 30; bb[3] = 0; }
 AMZ_DEV void bb_add(int *bb, int rr, int cc) { bb[0] = imin(bb[0], rr); bb[1] = imax(bb[1], rr); bb[2] = imin(bb[2], cc); bb[3] = imax(bb[3], cc); }
 AMZ_DEV void bb_flush(amz_lf lds, int base, const int *bb)
@@ -514,6 +573,22 @@ AMZ_DEV void bb_flush(amz_lf lds, int base, const int *bb)
     __hip_atomic_fetch_min(&red[2], bb[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_max(&red[3], bb[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
+}
+
+// the ring position table ("Ring positions" at the LDS layout): lane c of the producing column role owns entry c.  At step T the entry of
+// pair j of a ring is the ring's pair slot (T - j) mod h; a lane carries its slot and advances it by one per step.
+AMZ_DEV void pos_init(amz_lf lds, int c, ThreadRegs &rg)
+{
+    if (c >= POS_PAIRS) return;
+    rg.pos_h = POSTAB.h[c]; rg.pos_stride2 = POSTAB.stride2[c]; rg.pos_off4 = POSTAB.off4[c];
+    rg.pos_p = (rg.pos_h - POSTAB.j[c]) % rg.pos_h;
+    ((amz_li)(lds + POS_OFF))[c] = rg.pos_off4 + rg.pos_p * rg.pos_stride2;      // the table of step 0
+}
+AMZ_DEV void pos_produce(amz_lf lds, int T, int c, ThreadRegs &rg)
+{
+    if (c >= POS_PAIRS) return;
+    rg.pos_p = rg.pos_p + 1 == rg.pos_h ? 0 : rg.pos_p + 1;
+    ((amz_li)(lds + POS_OFF + ((T + 1) & 1) * POS_PAIRS))[c] = rg.pos_off4 + rg.pos_p * rg.pos_stride2;       // the table of step T + 1
 }
 
 // P5 + P6 (L746-825): nyquist test value and flag of the site of column c; helper lanes 160..171 clear the flag bytes without a site
@@ -645,7 +720,7 @@ struct P8Regs { P8Acc acc; int sl, cc; };
 AMZ_DEV void p8_wave_a(amz_lf lds, const TileArgs &a, int t, int r, int lane, P8Regs &pr)
 {
     amz_li red = (amz_li)(lds + RED_OFF);
-    amz_li list = (amz_li)(lds + LIST_OFF + (t & 1) * LIST_INTS);
+    amz_ls list = (amz_ls)(lds + LIST_OFF + (t & 1) * LIST_INTS);
     const int n = red[16 + (t & 1)];
     pr.cc = -1;
     if (lane < n) {
@@ -659,7 +734,7 @@ AMZ_DEV void p8_wave_a(amz_lf lds, const TileArgs &a, int t, int r, int lane, P8
 AMZ_DEV void p8_wave_b(amz_lf lds, const TileArgs &a, int t, int r, int lane, P8Regs &pr, int *bb)
 {
     amz_li red = (amz_li)(lds + RED_OFF);
-    amz_li list = (amz_li)(lds + LIST_OFF + (t & 1) * LIST_INTS);
+    amz_ls list = (amz_ls)(lds + LIST_OFF + (t & 1) * LIST_INTS);
     const int n = red[16 + (t & 1)];
     if (pr.cc >= 0) {
         p8_accumulate<2, 6>(lds, a, r, pr.sl, pr.cc, pr.acc);
@@ -1034,21 +1109,22 @@ struct TileRef { int top, left, rr1, gbase, tile, box; };   // tile: index in th
 constexpr int TILE_REDO = 1 << 30;
 AMZ_DEV int tile_index(const TileRef &t) { return t.tile < 0 ? t.tile : (t.tile & (TILE_REDO - 1)); }
 AMZ_DEV bool tile_redo(const TileRef &t) { return t.tile >= 0 && (t.tile & TILE_REDO) != 0; }
-struct TileSeq { TileRef back, front, next; };
-AMZ_DEV TileArgs with_tile(const TileArgs &frame, const TileRef &t)
+struct TileSeq { TileRef back, front, next; int t2; };      // t2 = 2 T, the global row the current step starts at (set by the driver per step)
+AMZ_DEV TileArgs with_tile(const TileArgs &frame, const TileRef &t, int t2)
 {
     TileArgs a = frame;
     a.top = t.top; a.left = t.left; a.rr1 = t.rr1; a.gbase = t.gbase;
+    a.rbase = t2 - t.gbase; a.g0 = t2; a.pos = POS_OFF * 4 + ((t2 & 2) ? POS_PAIRS * 4 : 0);
     a.ny_box = t.box;
     return a;
 }
 // the tile a stage at global row G works on
-AMZ_DEV TileArgs stage_tile(const TileArgs &frame, const TileSeq &q, int G) { return with_tile(frame, G >= q.front.gbase ? q.front : q.back); }
+AMZ_DEV TileArgs stage_tile(const TileArgs &frame, const TileSeq &q, int G) { return with_tile(frame, G >= q.front.gbase ? q.front : q.back, q.t2); }
 #define AMZ_STAGE(fn, off, ...)                                              \
     {                                                                        \
         const int G_ = 2 * T - (off);                                        \
         const TileArgs A_ = stage_tile(frame, q, G_);                        \
-        fn(lds, A_, G_ - A_.gbase, __VA_ARGS__);                             \
+        fn(lds, A_, A_.rbase - (off), __VA_ARGS__);                          \
     }
 
 // load: the CFA rows travel global memory -> LDS staging buffer (asynchronous LDS-DMA, issued one step ahead, no register in
@@ -1072,8 +1148,8 @@ AMZ_DEV void stage_fetch(amz_lf lds, const TileArgs &b, int buf, int n0, int n1,
 AMZ_DEV void st_load(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T, int c, ThreadRegs &rg)
 {
     if (c >= TS) return;
-    const TileArgs a = with_tile(frame, q.front);
-    const int r = 2 * T - a.gbase;
+    const TileArgs a = with_tile(frame, q.front, q.t2);
+    const int r = a.rbase;
 #ifndef AMZ_EMUL
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's own DMA of the previous step has landed
 #endif
@@ -1084,14 +1160,14 @@ AMZ_DEV void st_load(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T,
     }
     // unconditional (row index clamped)
     const bool nxt = r + 2 >= TS;
-    const TileArgs b = with_tile(frame, nxt ? q.next : q.front);
+    const TileArgs b = with_tile(frame, nxt ? q.next : q.front, q.t2);
     const int lim = b.rr1 > 0 ? b.rr1 - 1 : 0;
     stage_fetch(lds, b, (T + 1) & 1, imin(nxt ? 0 : r + 2, lim), imin(nxt ? 1 : r + 3, lim), c);
 }
 AMZ_DEV void st_load_first(amz_lf lds, const TileArgs &frame, const TileSeq &q, int c)
 {
     if (c >= TS) return;
-    stage_fetch(lds, with_tile(frame, q.front), 0, 0, 1, c);
+    stage_fetch(lds, with_tile(frame, q.front, 0), 0, 0, 1, c);
 }
 
 // a stage that keeps a per-thread box enters a new tile (its global row reaches the front tile's first row): merge the box into
@@ -1114,20 +1190,22 @@ enum RoleB { B_P3R0 = 0, B_P3R1, B_P16OUT, B_P1P11, B_P9, B_P13_P14, B_P7_P10, B
 struct WaveRole { int a, apart, b, bpart; };
 AMZ_DEV WaveRole wave_role(int wave)
 {
-    //                      SIMD class 0                 1                          2                          3
-    // a: 0,4,8,12 / 1,5,9,13 / 2,6,10,14 = P2, P5+L, P12, P4 (part 0 / 1 / 2);   3,7,11 = classification parts 0..2, 15 = P8
-    // b: class 0: w0 P16OUT.2, w4 P3r0.0, w8 P1P11.0, w12 P13+P14 | class 1: w1 P3r0.1, w5 P3r0.2, w9 P3r1.0, w13 P7+P10
-    //    class 2: w2 P16OUT.1, w6 P1P11.2, w10 P3r1.1, w14 P9     | class 3: w3 P16OUT.0, w7 P1P11.1, w11 P3r1.2, w15 P8
-    // (round 3: chosen with the per-wave timestamps of -DAMZ_PROFILE instead of static instruction counts -- the table of round 2 with
-    // P16OUT.0 / P1P11.0 and P16OUT.2 / P1P11.2 exchanged between the SIMD classes: 4.60 -> 4.35 ms per 45 MP frame.  Five other exchanges,
-    // and P7 moved from the P10 wave to the P9 wave, were slower.)
+    // Round 6: a wave keeps ONE pair of roles (a, b) for the whole kernel and every pair has a step loop of its own (amaze_stream.hip), so
+    // the pairs are fixed -- P2 + P16OUT, P5L + P3R0, P12 + P3R1, LIGHT (+ the ring position table) + P1P11, each on three waves (parts 0..2),
+    // P4 (three parts) + one of the single-wave jobs P13+P14 / P7+P10 / P9, and the P8 wave -- and only their placement on the SIMDs is free:
+    //   SIMD class 0 (waves 0, 4, 8, 12): LIGHT+P1P11 parts 0..2, P8      (wave 0 = the leader: tile counter, redo queue)
+    //   class c = 1..3 (waves c, c+4, c+8, c+12): P2+P16OUT, P5L+P3R0, P12+P3R1 part c-1, P4 part c-1 + P13P14 / P7P10 / P9
     const int cls = wave & 3, row = wave >> 2;
     WaveRole r;
-    if (cls == 3) { r.a = row == 3 ? A_P8 : A_LIGHT; r.apart = row; }
-    else { r.a = row == 0 ? A_P2 : (row == 1 ? A_P5L : (row == 2 ? A_P12 : A_P4)); r.apart = cls; }
-    const int btab[16] = {B_P16OUT, B_P3R0, B_P16OUT, B_P16OUT, B_P3R0, B_P3R0, B_P1P11, B_P1P11, B_P1P11, B_P3R1, B_P3R1, B_P3R1, B_P13_P14, B_P7_P10, B_P9, B_P8};
-    const int bpar[16] = {2, 1, 1, 0, 0, 2, 2, 1, 0, 0, 1, 2, 0, 0, 0, 0};
-    r.b = btab[wave]; r.bpart = bpar[wave];
+    if (cls == 0) {
+        r.a = row == 3 ? A_P8 : A_LIGHT; r.apart = row;
+        r.b = row == 3 ? B_P8 : B_P1P11; r.bpart = row;
+    } else {
+        const int atab[4] = {A_P2, A_P5L, A_P12, A_P4};
+        const int btab[4] = {B_P16OUT, B_P3R0, B_P3R1, cls == 1 ? B_P13_P14 : (cls == 2 ? B_P7_P10 : B_P9)};
+        r.a = atab[row]; r.apart = cls - 1;
+        r.b = btab[row]; r.bpart = row == 3 ? 0 : cls - 1;
+    }
     return r;
 }
 constexpr int LOADER_ROLE = A_P5L;
@@ -1150,6 +1228,7 @@ AMZ_DEV void substep_a(amz_lf lds, const TileArgs &frame, const TileSeq &q, int 
         break;
     case A_LIGHT:
         AMZ_STAGE(st_p1014_light, 30, c)
+        pos_produce(lds, T, c, rg);
         break;
     case A_P4:
         AMZ_STAGE(st_p4, 14, c)
@@ -1183,13 +1262,13 @@ AMZ_DEV void p8_step_a(amz_lf lds, const TileArgs &frame, const TileSeq &q, int 
     bb_tile_change(lds, q, T, 22, 4, bb);
     const int G = 2 * T - 22;
     const TileArgs a = stage_tile(frame, q, G);
-    p8_wave_a(lds, a, T, G - a.gbase, lane, pr);
+    p8_wave_a(lds, a, T, a.rbase - 22, lane, pr);
 }
 AMZ_DEV void p8_step_b(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T, int lane, P8Regs &pr, int *bb)
 {
     const int G = 2 * T - 22;
     const TileArgs a = stage_tile(frame, q, G);
-    p8_wave_b(lds, a, T, G - a.gbase, lane, pr, bb);
+    p8_wave_b(lds, a, T, a.rbase - 22, lane, pr, bb);
 }
 // the last stage (output, offset 38) has just left tile q.back: is the tile valid?  (called by one thread, between barriers)
 // (one step after the output stage wrote its last rows of q.back: at that earlier step every wave drains its global stores, see the

@@ -33,12 +33,13 @@ static void wave_p13(float *lds, const TileArgs &a, int r)
 static void wave_list(float *lds, const TileArgs &a, int T, int r)
 {
     const int buf = (T + 1) & 1;
-    int *red = (int *)(lds + RED_OFF), *list = (int *)(lds + LIST_OFF + buf * LIST_INTS);
+    int *red = (int *)(lds + RED_OFF);
+    unsigned short *list = (unsigned short *)(lds + LIST_OFF + buf * LIST_INTS);
     int n = 0;
     if (r + 1 >= 8 && r < a.rr1 - 8)
         for (int c = 0; c < TS; ++c) {
             int rr;
-            if (nyq_site(lds, a, r, c, &rr)) list[n++] = (rr << 8) | c;
+            if (nyq_site(lds, a, r, c, &rr)) list[n++] = (unsigned short)((rr << 8) | c);
         }
     red[16 + buf] = n;
 }
@@ -81,7 +82,7 @@ int amaze_stream_emul_seq(const float *raw, long rs, int W, int H, unsigned filt
 {
     TileArgs frame;
     frame.raw = raw; frame.rs = rs; frame.red = red; frame.green = green; frame.blue = blue; frame.os = os;
-    frame.top = 0; frame.left = 0; frame.rr1 = 0; frame.gbase = 0;
+    frame.top = 0; frame.left = 0; frame.rr1 = 0; frame.gbase = 0; frame.rbase = 0; frame.g0 = 0;
     frame.ny_box = 0;
     frame.W = W; frame.H = H; frame.filters = filters; frame.clip_pt = clip_pt; frame.clip_pt8 = clip_pt8;
     frame.g00 = (int)(fc(filters, 0, 0) & 1);
@@ -103,6 +104,8 @@ int amaze_stream_emul_seq(const float *raw, long rs, int W, int H, unsigned filt
     std::vector<P8Regs> p8(64);
     for (auto &x : p8) x.cc = -1;
     for (auto &x : regs) bb_reset(x.bb);
+    int p8w = 0;                                   // the wave that plays the P8 role
+    for (int w = 0; w < NTHREADS / 64; ++w) if (wave_role(w).a == A_P8) p8w = w;
     std::vector<int> ord(NTHREADS);
     for (int i = 0; i < NTHREADS; ++i) ord[i] = order == 1 ? NTHREADS - 1 - i : i;
     if (order >= 2) {
@@ -124,9 +127,10 @@ int amaze_stream_emul_seq(const float *raw, long rs, int W, int H, unsigned filt
     q.front = tile_ref(0);
     q.next = tile_ref(1);
     seq_begin(lds, 0);
-    for (int tid = 0; tid < NTHREADS; ++tid) { const WaveRole wr = wave_role(tid >> 6); if (wr.a == LOADER_ROLE) st_load_first(lds, frame, q, wr.apart * 64 + (tid & 63)); }
+    for (int tid = 0; tid < NTHREADS; ++tid) { const WaveRole wr = wave_role(tid >> 6); if (wr.a == LOADER_ROLE) st_load_first(lds, frame, q, wr.apart * 64 + (tid & 63)); if (wr.a == A_LIGHT) pos_init(lds, wr.apart * 64 + (tid & 63), regs[tid]); }
     const int nsteps = STEPS_PER_TILE * ntiles + TAIL_STEPS;
     for (int T = 0; T < nsteps; ++T) {
+        q.t2 = 2 * T;
         if (T > 0 && T % STEPS_PER_TILE == 0) { q.back = q.front; q.front = q.next; q.next = tile_ref(T / STEPS_PER_TILE + 1); }
         if (tile_done(q, T)) {
             const int kb = q.back.gbase / TS, par = kb & 1;
@@ -142,23 +146,23 @@ int amaze_stream_emul_seq(const float *raw, long rs, int W, int H, unsigned filt
         const TileArgs a9 = stage_tile(frame, q, 2 * T - 26), a7 = stage_tile(frame, q, 2 * T - 14), al = stage_tile(frame, q, 2 * T - 20);
         const TileArgs ah = stage_tile(frame, q, 2 * T - 30);
         auto workers = [&]() {
-            for (int l = 0; l < 64; ++l) p14_worker(lds, ah, 2 * T - 30 - ah.gbase, order & 1 ? 63 - l : l);
-            for (int l = 0; l < 64; ++l) p10_worker(lds, ah, 2 * T - 30 - ah.gbase, order & 1 ? 63 - l : l);
+            for (int l = 0; l < 64; ++l) p14_worker(lds, ah, ah.rbase - 30, order & 1 ? 63 - l : l);
+            for (int l = 0; l < 64; ++l) p10_worker(lds, ah, ah.rbase - 30, order & 1 ? 63 - l : l);
             hot_reset(lds, 0); hot_reset(lds, 1);
         };
         if (order & 1) {
             workers();
-            wave_list(lds, al, T, 2 * T - 20 - al.gbase);
-            for (int l = 63; l >= 0; --l) p8_step_b(lds, frame, q, T, l, p8[l], regs[960 + l].bb);
-            wave_p13(lds, a9, 2 * T - 26 - a9.gbase); wave_p9(lds, a9, 2 * T - 26 - a9.gbase);
-            for (int i = 0; i < 192; ++i) st_p7(lds, a7, 2 * T - 14 - a7.gbase, i);
+            wave_list(lds, al, T, al.rbase - 20);
+            for (int l = 63; l >= 0; --l) p8_step_b(lds, frame, q, T, l, p8[l], regs[64 * p8w + l].bb);
+            wave_p13(lds, a9, a9.rbase - 26); wave_p9(lds, a9, a9.rbase - 26);
+            for (int i = 0; i < 192; ++i) st_p7(lds, a7, a7.rbase - 14, i);
         }
         for (int i = 0; i < NTHREADS; ++i) { const WaveRole wr = wave_role(ord[i] >> 6); if (wr.b < B_P9) substep_b_threads(lds, frame, q, T, wr.b, wr.bpart * 64 + (ord[i] & 63)); }
         if (!(order & 1)) {
-            for (int i = 0; i < 192; ++i) st_p7(lds, a7, 2 * T - 14 - a7.gbase, i);
-            wave_p9(lds, a9, 2 * T - 26 - a9.gbase); wave_p13(lds, a9, 2 * T - 26 - a9.gbase);
-            for (int l = 0; l < 64; ++l) p8_step_b(lds, frame, q, T, l, p8[l], regs[960 + l].bb);
-            wave_list(lds, al, T, 2 * T - 20 - al.gbase);
+            for (int i = 0; i < 192; ++i) st_p7(lds, a7, a7.rbase - 14, i);
+            wave_p9(lds, a9, a9.rbase - 26); wave_p13(lds, a9, a9.rbase - 26);
+            for (int l = 0; l < 64; ++l) p8_step_b(lds, frame, q, T, l, p8[l], regs[64 * p8w + l].bb);
+            wave_list(lds, al, T, al.rbase - 20);
             workers();
         }
         // ---- barrier ----
