@@ -6,6 +6,8 @@
 //
 // Replaces RawImageSource::amaze_demosaic_RT (reference: rtengine/amaze_demosaic_RT.cc:41-1595, x86-64 / __SSE2__ branches).
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "kernels.h"
 #include "amaze_stream_core.h"
 
@@ -224,13 +226,14 @@ __device__ __forceinline__ void role_loop(const AmazeStreamArgs &s, amz_lf lds, 
             if (q.next.rr1 > 0 && nk < kn + 1) nk = kn + 1;
         }
         int ca = ca_, cb = cb_, lane = lane_;
-#ifndef AMZ_HOIST_LANES
-        // the column / lane are made opaque per step: otherwise a role's column-derived addresses are hoisted out of the step loop and kept
-        // live across the other sub-step's role
+#ifdef AMZ_OPAQUE_LANES
+        // (rounds 2 - 5, one loop for all roles: the column / lane were made opaque per step, otherwise every role's column-derived addresses
+        // were hoisted out of the step loop and kept live across all the other roles.  With a loop per pair of roles the hoisting is what is
+        // wanted: 3.84 -> 3.63 ms.)
         asm volatile("" : "+v"(ca), "+v"(cb), "+v"(lane));
 #endif
         if (KB == B_P16OUT) { if (tile_drain(q, T)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        if (LEADER && threadIdx.x == 0) {
+        if (LEADER && ca_ == 0) {          // (lane 0 of the role's part 0)
             if (tile_done(q, T)) seq_tile_done(s, lds, (q.back.gbase / TS) & 1, q.back.rr1, tile_index(q.back), tile_redo(q.back) ? 1 : 0);
             // one step before the load front needs a sequence position beyond the first tile: ask the tile counter / the redo queue
             if (tt + 1 == STEPS_PER_TILE) seq_pull(s, lds, q.front.gbase / TS + 2);
@@ -254,12 +257,6 @@ __device__ __forceinline__ void role_loop(const AmazeStreamArgs &s, amz_lf lds, 
             if (lane == 0) hot_reset(lds, 1);
         } else if (KB == B_P7_P10) {
             {
-                const TileArgs a = stage_tile(frame, q, 2 * T - 14);
-                st_p7(lds, a, a.rbase - 14, lane);
-                st_p7(lds, a, a.rbase - 14, 64 + lane);
-                st_p7(lds, a, a.rbase - 14, 128 + lane);
-            }
-            {
                 const TileArgs a = stage_tile(frame, q, 2 * T - 20);
                 wave_list(lds, a, T, a.rbase - 20, lane);
             }
@@ -278,6 +275,12 @@ __device__ __forceinline__ void role_loop(const AmazeStreamArgs &s, amz_lf lds, 
 #endif
 }
 
+#ifdef AMZ_ROLE_ENV
+// experiment only (scripts/amz_roles_search.py): the wave -> (loop, part) table from the environment, one byte per wave = loop << 2 | part;
+// loops: 0 P2+P16OUT, 1 P5L+P3R0, 2 P12+P3R1, 3 LIGHT+P1P11 (its part 0 leads), 4 P4+P13P14, 5 P4+LIST+P10, 6 P4+P9, 7 P8
+__device__ unsigned char amz_roles_dev[16];
+#endif
+
 __global__ void __launch_bounds__(amz::NTHREADS)
 amaze_stream_kernel(AmazeStreamArgs s)
 {
@@ -287,7 +290,16 @@ amaze_stream_kernel(AmazeStreamArgs s)
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane_ = tid & 63;
-    const WaveRole role = wave_role(wave);       // what this wave does in sub-step a / b, and which 64 columns of a column role
+    WaveRole role = wave_role(wave);             // what this wave does in sub-step a / b, and which 64 columns of a column role
+#ifdef AMZ_ROLE_ENV
+    {
+        const int e = __builtin_amdgcn_readfirstlane((int)amz_roles_dev[wave]);
+        const int lp = e >> 2, pt = e & 3;
+        const int ka[8] = {A_P2, A_P5L, A_P12, A_LIGHT, A_P4, A_P4, A_P4, A_P8};
+        const int kb[8] = {B_P16OUT, B_P3R0, B_P3R1, B_P1P11, B_P13_P14, B_P7_P10, B_P9, B_P8};
+        role.a = ka[lp]; role.b = kb[lp]; role.apart = lp >= 4 && lp < 7 ? lp - 4 : pt; role.bpart = lp >= 4 ? 0 : pt;
+    }
+#endif
     const int ca_ = role.apart * 64 + lane_, cb_ = role.bpart * 64 + lane_;
 
     // the single-wave roles (row recurrences, the Nyquist area sums) are the longest serial chains of a sub-step: they win the
@@ -319,6 +331,13 @@ hipError_t launch_amaze_stream(const AmazeStreamArgs &s, int grid, hipStream_t s
 {
     constexpr size_t dyn = (size_t)amz::LDS_FLOATS * sizeof(float);
     if (hipError_t e = dyn_lds_once(reinterpret_cast<const void *>(&amaze_stream_kernel), (int)dyn); e != hipSuccess) return e;
+#ifdef AMZ_ROLE_ENV
+    if (const char *e = getenv("AMZ_ROLES")) {
+        unsigned char t[16];
+        for (int i = 0; i < 16; ++i) { unsigned v = 0; sscanf(e + 2 * i, "%2x", &v); t[i] = (unsigned char)v; }
+        if (hipError_t er = hipMemcpyToSymbol(HIP_SYMBOL(amz_roles_dev), t, 16); er != hipSuccess) return er;
+    }
+#endif
     hipLaunchKernelGGL(amaze_stream_kernel, dim3(grid), dim3(amz::NTHREADS), dyn, stream, s);
     return hipGetLastError();
 }

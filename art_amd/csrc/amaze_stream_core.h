@@ -1191,21 +1191,19 @@ struct WaveRole { int a, apart, b, bpart; };
 AMZ_DEV WaveRole wave_role(int wave)
 {
     // Round 6: a wave keeps ONE pair of roles (a, b) for the whole kernel and every pair has a step loop of its own (amaze_stream.hip), so
-    // the pairs are fixed -- P2 + P16OUT, P5L + P3R0, P12 + P3R1, LIGHT (+ the ring position table) + P1P11, each on three waves (parts 0..2),
-    // P4 (three parts) + one of the single-wave jobs P13+P14 / P7+P10 / P9, and the P8 wave -- and only their placement on the SIMDs is free:
-    //   SIMD class 0 (waves 0, 4, 8, 12): LIGHT+P1P11 parts 0..2, P8      (wave 0 = the leader: tile counter, redo queue)
-    //   class c = 1..3 (waves c, c+4, c+8, c+12): P2+P16OUT, P5L+P3R0, P12+P3R1 part c-1, P4 part c-1 + P13P14 / P7P10 / P9
-    const int cls = wave & 3, row = wave >> 2;
+    // the pairs are fixed -- loop 0: P2 + P16OUT, 1: P5L + P3R0, 2: P12 + P3R1, 3: LIGHT (+ the ring position table) + P1P11 + P7, each on
+    // three waves (parts 0..2; part 0 of loop 3 leads: tile counter, redo queue), 4 / 5 / 6: P4 (part 0 / 1 / 2) + one of the single-wave jobs
+    // P13+P14 / site list + P10 / P9, 7: the P8 wave -- and only their placement on the SIMDs is free (waves w, w+4, w+8, w+12 share one).
+    // The table is the best of 300 random placements (a pair-swap descent from it found nothing better), timed on the 45 MP benchmark frame
+    // (scripts/amz_roles_search.py: -4.6 % against "LIGHT x 3 + P8 | one wave of each other loop per SIMD"):
+    //   SIMD class 0: P2.0 P12.0 P12.2 L.1 | class 1: P2.1 P5L.0 P12.1 P4.1+LIST+P10 | class 2: P5L.1 P5L.2 L.2 P8 | class 3: P2.2 L.0 P4.0+P13P14 P4.2+P9
+    const unsigned char tab[16] = {0, 1, 5, 2, 8, 4, 6, 12, 10, 9, 14, 16, 13, 20, 28, 24};       // by wave: loop << 2 | part
+    const int ka[8] = {A_P2, A_P5L, A_P12, A_LIGHT, A_P4, A_P4, A_P4, A_P8};
+    const int kb[8] = {B_P16OUT, B_P3R0, B_P3R1, B_P1P11, B_P13_P14, B_P7_P10, B_P9, B_P8};
+    const int lp = tab[wave] >> 2, pt = tab[wave] & 3;
     WaveRole r;
-    if (cls == 0) {
-        r.a = row == 3 ? A_P8 : A_LIGHT; r.apart = row;
-        r.b = row == 3 ? B_P8 : B_P1P11; r.bpart = row;
-    } else {
-        const int atab[4] = {A_P2, A_P5L, A_P12, A_P4};
-        const int btab[4] = {B_P16OUT, B_P3R0, B_P3R1, cls == 1 ? B_P13_P14 : (cls == 2 ? B_P7_P10 : B_P9)};
-        r.a = atab[row]; r.apart = cls - 1;
-        r.b = btab[row]; r.bpart = row == 3 ? 0 : cls - 1;
-    }
+    r.a = ka[lp]; r.b = kb[lp];
+    r.apart = lp >= 4 && lp < 7 ? lp - 4 : pt; r.bpart = lp >= 4 ? 0 : pt;
     return r;
 }
 constexpr int LOADER_ROLE = A_P5L;
@@ -1252,6 +1250,7 @@ AMZ_DEV void substep_b_threads(amz_lf lds, const TileArgs &frame, const TileSeq 
         AMZ_STAGE(st_p1, 2, c)
         AMZ_STAGE(st_p1, 1, c)
         AMZ_STAGE(st_p11, 20, c)
+        AMZ_STAGE(st_p7, 14, c)         // (192 items: one per lane of the role's three waves)
         break;
     default: break;
     }

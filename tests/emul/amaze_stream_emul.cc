@@ -143,7 +143,7 @@ int amaze_stream_emul_seq(const float *raw, long rs, int W, int H, unsigned filt
             else p8_step_a(lds, frame, q, T, ord[i] & 63, p8[ord[i] & 63], regs[ord[i]].bb);
         }
         // ---- barrier ----
-        const TileArgs a9 = stage_tile(frame, q, 2 * T - 26), a7 = stage_tile(frame, q, 2 * T - 14), al = stage_tile(frame, q, 2 * T - 20);
+        const TileArgs a9 = stage_tile(frame, q, 2 * T - 26), al = stage_tile(frame, q, 2 * T - 20);
         const TileArgs ah = stage_tile(frame, q, 2 * T - 30);
         auto workers = [&]() {
             for (int l = 0; l < 64; ++l) p14_worker(lds, ah, ah.rbase - 30, order & 1 ? 63 - l : l);
@@ -155,11 +155,9 @@ int amaze_stream_emul_seq(const float *raw, long rs, int W, int H, unsigned filt
             wave_list(lds, al, T, al.rbase - 20);
             for (int l = 63; l >= 0; --l) p8_step_b(lds, frame, q, T, l, p8[l], regs[64 * p8w + l].bb);
             wave_p13(lds, a9, a9.rbase - 26); wave_p9(lds, a9, a9.rbase - 26);
-            for (int i = 0; i < 192; ++i) st_p7(lds, a7, a7.rbase - 14, i);
         }
         for (int i = 0; i < NTHREADS; ++i) { const WaveRole wr = wave_role(ord[i] >> 6); if (wr.b < B_P9) substep_b_threads(lds, frame, q, T, wr.b, wr.bpart * 64 + (ord[i] & 63)); }
         if (!(order & 1)) {
-            for (int i = 0; i < 192; ++i) st_p7(lds, a7, a7.rbase - 14, i);
             wave_p9(lds, a9, a9.rbase - 26); wave_p13(lds, a9, a9.rbase - 26);
             for (int l = 0; l < 64; ++l) p8_step_b(lds, frame, q, T, l, p8[l], regs[64 * p8w + l].bb);
             wave_list(lds, al, T, al.rbase - 20);
