@@ -85,41 +85,52 @@ __device__ __forceinline__ void wave_list(amz_lf lds, const TileArgs &a, int T, 
 
 } // namespace
 
-// ---- the tile sequence of a workgroup (every wave keeps its own copy in scalar registers; the leader -- thread 0 -- feeds it) ----
+// ---- the tile sequence of a workgroup: the leader (lane 0 of part 0 of the LIGHT role) fills the slots, every wave reads them ----
 // tile blockIdx.x first, then whatever the shared tile counter hands out (the workgroups do not start together when the arena kernel's
 // tiles occupy some CUs at first, and a fixed share per workgroup made the last starter the kernel's length), then the redo queue
-__device__ __forceinline__ TileRef seq_tile_ref(const AmazeStreamArgs &s, amz_lf lds, int k)
+__device__ __forceinline__ TileRef seq_tile_ref(amz_lf lds, int k)
 {
-    amz_li dyn = (amz_li)(lds + DYN_OFF);          // the entry the leader pulled for sequence position dyn[0]
+    amz_li slot = (amz_li)(lds + DYN_OFF) + (k & 3) * DYN_SLOT;
     TileRef t;
-    int tile = -1;
-    if (k == 0) tile = s.tiles[blockIdx.x];
-    else if (dyn[0] == k && dyn[1] >= 0) tile = dyn[1];
-    if (tile >= 0) {
-        const int ty = tile / s.ntx, tx = tile - ty * s.ntx;
-        const int top = -16 + ty * (TS - 32);
-        tile_ref_set(t, k, tile, top, -16 + tx * (TS - 32), min(top + TS, s.H + 16) - top);
-        if (k > 0 && dyn[6]) { t.tile |= TILE_REDO; t.box = ny_pack(dyn[2], dyn[3], dyn[4], dyn[5]); }
+    const int sk = __builtin_amdgcn_readfirstlane(slot[0]), tile = __builtin_amdgcn_readfirstlane(slot[1]);
+    if (sk == k && tile >= 0) {
+        t.gbase = TS * k;
+        t.tile = tile | (__builtin_amdgcn_readfirstlane(slot[6]) ? TILE_REDO : 0);
+        t.top = __builtin_amdgcn_readfirstlane(slot[2]); t.left = __builtin_amdgcn_readfirstlane(slot[3]);
+        t.rr1 = __builtin_amdgcn_readfirstlane(slot[4]); t.box = __builtin_amdgcn_readfirstlane(slot[5]);
     } else {
         tile_ref_none(t, k);
     }
     return t;
 }
-// leader: take the next fresh tile, or one entry of the redo queue, for sequence position k (none: dyn[1] = -1)
-__device__ __noinline__ void seq_pull(const AmazeStreamArgs &s, amz_lf lds, int k)
+__device__ __forceinline__ void seq_slot_set(const AmazeStreamArgs &s, amz_lf lds, int k, int tile, int redo, int box)
+{
+    amz_li slot = (amz_li)(lds + DYN_OFF) + (k & 3) * DYN_SLOT;
+    TileRef t;
+    tile_ref_none(t, k);
+    if (tile >= 0) {
+        const int ty = tile / s.ntx, tx = tile - ty * s.ntx;
+        const int top = -16 + ty * (TS - 32);
+        tile_ref_set(t, k, tile, top, -16 + tx * (TS - 32), min(top + TS, s.H + 16) - top);
+        if (redo) t.box = box;
+    }
+    slot[0] = k; slot[1] = tile; slot[2] = t.top; slot[3] = t.left; slot[4] = t.rr1; slot[5] = t.box; slot[6] = redo;
+}
+// leader: take the next fresh tile, or one entry of the redo queue, for sequence position k (none: tile -1)
+__device__ __forceinline__ void seq_pull(const AmazeStreamArgs &s, amz_lf lds, int k)
 {
     amz_li dyn = (amz_li)(lds + DYN_OFF);
     int *const cnt = reinterpret_cast<int *>(s.queue_words + s.ntiles);    // eight bookkeeping counters behind the queue (artgpu_get_option)
     int tile = -1;
     unsigned long long w = 0;
-    if (dyn[7]) {
+    if (dyn[4 * DYN_SLOT]) {
         // tiles gridDim.x .. ntiles - 1 of the list are handed out in order (queue_hdr[2], cleared per launch)
         const int i = (int)gridDim.x + atomicAdd(&s.queue_hdr[2], 1);
         if (i < s.ntiles) {
-            dyn[0] = k; dyn[1] = s.tiles[i]; dyn[6] = 0;
+            seq_slot_set(s, lds, k, s.tiles[i], 0, 0);
             return;
         }
-        dyn[7] = 0;
+        dyn[4 * DYN_SLOT] = 0;
     }
     // every read of the queue is a read-modify-write (+0): the per-XCD L2s are not coherent with each other, and a plain or sc1
     // load can return what an earlier launch left in this XCD's L2 -- a consumer that trusted a stale "reserved" count took a
@@ -145,8 +156,7 @@ __device__ __noinline__ void seq_pull(const AmazeStreamArgs &s, amz_lf lds, int 
         }
     }
     atomicAdd(&cnt[tile >= 0 ? 0 : 1], 1);
-    dyn[0] = k; dyn[1] = tile; dyn[6] = 1;
-    dyn[2] = (int)((w >> 24) & 0xff); dyn[3] = (int)((w >> 32) & 0xff); dyn[4] = (int)((w >> 40) & 0xff); dyn[5] = (int)((w >> 48) & 0xff);
+    seq_slot_set(s, lds, k, tile, 1, ny_pack((int)((w >> 24) & 0xff), (int)((w >> 32) & 0xff), (int)((w >> 40) & 0xff), (int)((w >> 48) & 0xff)));
 }
 // leader, every stage has left tile q.back: is it valid?  If not, stream it again with the true box: publish a queue entry; if the slot
 // was abandoned, the arena kernel takes the tile.
@@ -154,7 +164,7 @@ __device__ __noinline__ void seq_pull(const AmazeStreamArgs &s, amz_lf lds, int 
 // dirty copies of the tile's output lines -- whichever is written back last wins.  So before the tile is offered again its pixels leave
 // this XCD's L2: the storing waves drain their stores one step ahead (the output stage finished the tile eight steps ago), then the
 // leader writes the L2 back (release, agent scope) and publishes.
-__device__ __noinline__ void seq_tile_done(const AmazeStreamArgs &s, amz_lf lds, int par, int rr1, int tile, int redo)
+__device__ __forceinline__ void seq_tile_done(const AmazeStreamArgs &s, amz_lf lds, int par, int rr1, int tile, int redo)
 {
     int *const cnt = reinterpret_cast<int *>(s.queue_words + s.ntiles);
     int box[4];
@@ -199,8 +209,8 @@ __device__ __forceinline__ void role_loop(const AmazeStreamArgs &s, amz_lf lds, 
     TileSeq q;
     q.t2 = 0;
     tile_ref_none(q.back, -1);
-    q.front = seq_tile_ref(s, lds, 0);
-    q.next = seq_tile_ref(s, lds, 1);
+    q.front = seq_tile_ref(lds, 0);
+    q.next = seq_tile_ref(lds, 1);
     int nk = q.next.rr1 > 0 ? 2 : 1;
 
     ThreadRegs rg;
@@ -214,17 +224,19 @@ __device__ __forceinline__ void role_loop(const AmazeStreamArgs &s, amz_lf lds, 
 #ifdef AMZ_PROFILE
     long long ta = 0, tb = 0, tw = 0;
 #endif
-    int tt = 0;                                      // T % STEPS_PER_TILE
+    int tt = 0, kf = 0;                              // T % STEPS_PER_TILE, the front tile's position in the sequence
     for (int T = 0; T < STEPS_PER_TILE * nk + TAIL_STEPS; ++T, ++tt) {
         q.t2 = 2 * T;
         if (tt == STEPS_PER_TILE) {                  // the load front enters the next tile
             tt = 0;
+            ++kf;
             q.back = q.front;
-            q.front = q.next;
-            const int kn = q.front.gbase / TS + 1;
-            q.next = seq_tile_ref(s, lds, kn);
-            if (q.next.rr1 > 0 && nk < kn + 1) nk = kn + 1;
+            q.front = seq_tile_ref(lds, kf);
+            if (seq_tile_ref(lds, kf + 1).rr1 > 0) nk = kf + 2;
         }
+        // (only the loader looks at the tile after the front one, and only in the front tile's last step: not carried through the loop)
+        q.next = q.front;
+        if (KA == LOADER_ROLE && tt == STEPS_PER_TILE - 1) q.next = seq_tile_ref(lds, kf + 1);
         int ca = ca_, cb = cb_, lane = lane_;
 #ifdef AMZ_OPAQUE_LANES
         // (rounds 2 - 5, one loop for all roles: the column / lane were made opaque per step, otherwise every role's column-derived addresses
@@ -234,9 +246,9 @@ __device__ __forceinline__ void role_loop(const AmazeStreamArgs &s, amz_lf lds, 
 #endif
         if (KB == B_P16OUT) { if (tile_drain(q, T)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         if (LEADER && ca_ == 0) {          // (lane 0 of the role's part 0)
-            if (tile_done(q, T)) seq_tile_done(s, lds, (q.back.gbase / TS) & 1, q.back.rr1, tile_index(q.back), tile_redo(q.back) ? 1 : 0);
+            if (tile_done(q, T)) seq_tile_done(s, lds, (kf - 1) & 1, q.back.rr1, tile_index(q.back), tile_redo(q.back) ? 1 : 0);
             // one step before the load front needs a sequence position beyond the first tile: ask the tile counter / the redo queue
-            if (tt + 1 == STEPS_PER_TILE) seq_pull(s, lds, q.front.gbase / TS + 2);
+            if (tt + 1 == STEPS_PER_TILE) seq_pull(s, lds, kf + 2);
         }
         { AMZ_T0 if (KA != A_P8) substep_a(lds, frame, q, T, KA, ca, rg); else p8_step_a(lds, frame, q, T, lane, p8, rg.bb); AMZ_T1(ta) }
         { AMZ_T0 lds_barrier(); AMZ_T1(tw) }
@@ -308,7 +320,9 @@ amaze_stream_kernel(AmazeStreamArgs s)
 
     if (tid == 0) {
         amz_li dyn = (amz_li)(lds + DYN_OFF);
-        dyn[0] = -1; dyn[1] = -1; dyn[7] = 1;      // dyn[7]: the tile counter still has tiles
+        for (int k = 0; k < 4; ++k) { dyn[k * DYN_SLOT] = -1; dyn[k * DYN_SLOT + 1] = -1; }
+        dyn[4 * DYN_SLOT] = 1;                     // the tile counter still has tiles
+        seq_slot_set(s, lds, 0, s.tiles[blockIdx.x], 0, 0);
         seq_pull(s, lds, 1);
     }
     seq_begin(lds, tid);

@@ -151,8 +151,9 @@ constexpr int STG_OFF = RED_OFF + RED_INTS;      // CFA staging: the raw values 
 constexpr int STG_ROW = 192, STG_FLOATS = 2 * 2 * STG_ROW;
 constexpr int HOT_OFF = STG_OFF + STG_FLOATS;      // P10 / P14 site lists of one step: [0] n10, [1] n14, [2..161] list10, [162..321] list14
 constexpr int HOT_INTS = 2 + 2 * 160;
-constexpr int DYN_OFF = HOT_OFF + HOT_INTS;      // the redo-queue entry pulled for the next sequence position (position, tile, box)
-constexpr int DYN_INTS = 8;
+constexpr int DYN_OFF = HOT_OFF + HOT_INTS;      // the tiles of the workgroup's sequence: four slots of eight words, position k in slot k & 3 (back, front,
+constexpr int DYN_SLOT = 8;                      // next and the one being pulled): [0] k, [1] tile (-1: none), [2] top, [3] left, [4] rows, [5] Nyquist box,
+constexpr int DYN_INTS = 4 * DYN_SLOT + 4;       // [6] second attempt; word 32: the tile counter still has tiles
 // Ring positions (round 6).  Every ring depth is even and a step starts at an even global row G0 = 2 T, so the rows of a PAIR
 // (G0 - 2 j, G0 - 2 j + 1) are neighbours in every ring and never straddle its wrap-around.  Where pair j of ring n lives in this step --
 // the byte address of its first row -- is one entry of a table in LDS; the table of step T + 1 is written during step T by the lanes of
@@ -1194,10 +1195,10 @@ AMZ_DEV WaveRole wave_role(int wave)
     // the pairs are fixed -- loop 0: P2 + P16OUT, 1: P5L + P3R0, 2: P12 + P3R1, 3: LIGHT (+ the ring position table) + P1P11 + P7, each on
     // three waves (parts 0..2; part 0 of loop 3 leads: tile counter, redo queue), 4 / 5 / 6: P4 (part 0 / 1 / 2) + one of the single-wave jobs
     // P13+P14 / site list + P10 / P9, 7: the P8 wave -- and only their placement on the SIMDs is free (waves w, w+4, w+8, w+12 share one).
-    // The table is the best of 300 random placements (a pair-swap descent from it found nothing better), timed on the 45 MP benchmark frame
-    // (scripts/amz_roles_search.py: -4.6 % against "LIGHT x 3 + P8 | one wave of each other loop per SIMD"):
-    //   SIMD class 0: P2.0 P12.0 P12.2 L.1 | class 1: P2.1 P5L.0 P12.1 P4.1+LIST+P10 | class 2: P5L.1 P5L.2 L.2 P8 | class 3: P2.2 L.0 P4.0+P13P14 P4.2+P9
-    const unsigned char tab[16] = {0, 1, 5, 2, 8, 4, 6, 12, 10, 9, 14, 16, 13, 20, 28, 24};       // by wave: loop << 2 | part
+    // The table is the best of 300 random placements followed by a pair-swap descent, timed on the 45 MP benchmark frame
+    // (scripts/amz_roles_search.py; -5 % against "LIGHT x 3 + P8 | one wave of each other loop per SIMD"):
+    //   SIMD class 0: P2.1 P5L.0 P5L.2 P4.2+P9 | class 1: P2.0 P4.1+LIST+P10 P12.0 P5L.1 | class 2: P2.2 P12.1 L.2 P4.0+P13P14 | class 3: L.1 P12.2 L.0 P8
+    const unsigned char tab[16] = {1, 0, 2, 13, 4, 20, 9, 10, 6, 8, 14, 12, 24, 5, 16, 28};       // by wave: loop << 2 | part
     const int ka[8] = {A_P2, A_P5L, A_P12, A_LIGHT, A_P4, A_P4, A_P4, A_P8};
     const int kb[8] = {B_P16OUT, B_P3R0, B_P3R1, B_P1P11, B_P13_P14, B_P7_P10, B_P9, B_P8};
     const int lp = tab[wave] >> 2, pt = tab[wave] & 3;
@@ -1206,7 +1207,7 @@ AMZ_DEV WaveRole wave_role(int wave)
     r.apart = lp >= 4 && lp < 7 ? lp - 4 : pt; r.bpart = lp >= 4 ? 0 : pt;
     return r;
 }
-constexpr int LOADER_ROLE = A_P5L;
+constexpr int LOADER_ROLE = A_P4;
 
 // sub-step a of a column role; c = 64 * part + lane
 AMZ_DEV void substep_a(amz_lf lds, const TileArgs &frame, const TileSeq &q, int T, int role, int c, ThreadRegs &rg)
@@ -1219,7 +1220,6 @@ AMZ_DEV void substep_a(amz_lf lds, const TileArgs &frame, const TileSeq &q, int 
     case A_P5L:
         bb_tile_change(lds, q, T, 12, 0, rg.bb);
         AMZ_STAGE(st_p5, 12, c, rg)
-        st_load(lds, frame, q, T, c, rg);
         break;
     case A_P12:
         AMZ_STAGE(st_p12, 24, c)
@@ -1230,6 +1230,7 @@ AMZ_DEV void substep_a(amz_lf lds, const TileArgs &frame, const TileSeq &q, int 
         break;
     case A_P4:
         AMZ_STAGE(st_p4, 14, c)
+        st_load(lds, frame, q, T, c, rg);       // (round 6: the loader rides on the lightest column role of sub-step a, it used to be P5's)
         break;
     default: break;     // A_P8: p8_step_a (it carries registers into sub-step b, so the driver calls it)
     }
