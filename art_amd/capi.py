@@ -155,6 +155,8 @@ def _load():
     lib.artgpu_denoise_compute_params.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_double),
                                                   C.POINTER(C.c_double), C.c_double, C.POINTER(DenoiseInfoStore), C.POINTER(DenoiseParams)]
     lib.artgpu_ordered_sum_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_float)]
+    lib.artgpu_eval_primitive.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+                                          C.POINTER(C.c_float), C.c_int]
     lib.artgpu_saturation_vibrance.argtypes = [C.c_void_p, C.POINTER(RGB), C.c_int, C.c_int, C.POINTER(C.c_double)]
     lib.artgpu_set_batch_lanes.argtypes = [C.c_void_p, C.c_int]
     lib.artgpu_set_progress_callback.argtypes = [C.c_void_p, PROGRESS_FN, C.c_void_p]
@@ -191,7 +193,32 @@ def _load():
 
 LIB = _load()
 
-EXPORTS = ["artgpu_set_progress_callback", "artgpu_set_option", "artgpu_get_option", "artgpu_set_curve_tail", "artgpu_set_curve_tail_parametric", "artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
+# artgpu_eval_primitive ids (include/artgpu.h: ARTGPU_PRIM_*)
+PRIM_XEXPF_S = 0
+PRIM_XEXPF_V = 1
+PRIM_XEXPF_VN = 2
+PRIM_XEXPF_V_LDEXP = 3
+PRIM_XLOGF_S = 4
+PRIM_XLOGF_V = 5
+PRIM_XLOGF_VN = 6
+PRIM_POW_F = 7
+PRIM_XLIN2LOG = 8
+PRIM_XLOG2LIN = 9
+PRIM_XCBRTF = 10
+PRIM_XATAN2F = 11
+PRIM_XSINCOSF = 12
+PRIM_LUTF_SCALAR = 13
+PRIM_LUTF_VECTOR = 14
+PRIM_MEDIAN3 = 15
+PRIM_VMINF = 16
+PRIM_VMAXF = 17
+PRIM_VINTPF = 18
+PRIM_XDIV2F = 19
+PRIM_XDIVF2 = 20
+PRIM_XLOG_D = 21
+PRIM_XEXP_D = 22
+
+EXPORTS = ["artgpu_eval_primitive", "artgpu_set_progress_callback", "artgpu_set_option", "artgpu_get_option", "artgpu_set_curve_tail", "artgpu_set_curve_tail_parametric", "artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
            "artgpu_synchronize", "artgpu_enable_timing", "artgpu_get_timings", "artgpu_scratch_bytes", "artgpu_trim_scratch",
            "artgpu_demosaic_bayer", "artgpu_border_interpolate2", "artgpu_get_image",
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
@@ -350,6 +377,20 @@ class Context:
             assert x.is_contiguous() and x.dtype.itemsize == 4
             self._chk(LIB.artgpu_ordered_sum_f32(self._h, x.data_ptr(), x.numel(), 1, C.byref(r)))
         return np.float32(r.value)
+
+    def eval_primitive(self, prim: int, a, b=None, c=None, param: float = 0.0, table=None):
+        """out0[i] = f(a[i] [, b[i] [, c[i]]]) with the device's own math primitive `prim` (PRIM_*); host numpy arrays in and out.
+        PRIM_XSINCOSF returns (sin, cos); PRIM_XLOG_D / PRIM_XEXP_D work on float64."""
+        dt = np.float64 if prim in (PRIM_XLOG_D, PRIM_XEXP_D) else np.float32
+        arrs = [None if x is None else np.ascontiguousarray(x, dtype=dt) for x in (a, b, c)]
+        n = arrs[0].size
+        out0, out1 = np.empty(n, dt), np.empty(n, dt)
+        tab = None if table is None else np.ascontiguousarray(table, dtype=np.float32)
+        ptr = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+        self._chk(LIB.artgpu_eval_primitive(self._h, int(prim), ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(out0), ptr(out1), C.c_int64(n),
+                                            C.c_float(param), None if tab is None else tab.ctypes.data_as(C.POINTER(C.c_float)),
+                                            0 if tab is None else tab.size))
+        return (out0, out1) if prim == PRIM_XSINCOSF else out0
 
     def saturation_vibrance(self, image: RGB, saturation: int, vibrance: int, ws):
         self._chk(LIB.artgpu_saturation_vibrance(self._h, C.byref(image), int(saturation), int(vibrance),

@@ -2511,6 +2511,39 @@ int artgpu_ordered_sum_f32(artgpu_ctx *ctx, const float *x, int64_t n, int on_de
     return ARTGPU_OK;
 }
 
+int artgpu_eval_primitive(artgpu_ctx *ctx, int prim, const void *a, const void *b, const void *c, void *out0, void *out1, int64_t n,
+                          float param, const float *table, int table_size)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (prim < 0 || prim >= PRIM_COUNT || n < 0 || (n > 0 && (!a || !out0))) return fail(ctx, ARTGPU_EINVAL, "eval_primitive: bad argument");
+    const bool dbl = prim == PRIM_XLOG_D || prim == PRIM_XEXP_D;
+    const bool need_b = prim == PRIM_POW_F || prim == PRIM_XATAN2F || prim == PRIM_MEDIAN3 || prim == PRIM_VMINF || prim == PRIM_VMAXF || prim == PRIM_VINTPF;
+    const bool need_c = prim == PRIM_MEDIAN3 || prim == PRIM_VINTPF;
+    const bool lut = prim == PRIM_LUTF_SCALAR || prim == PRIM_LUTF_VECTOR;
+    if ((need_b && !b) || (need_c && !c) || (prim == PRIM_XSINCOSF && !out1) || (lut && (!table || table_size < 2)))
+        return fail(ctx, ARTGPU_EINVAL, "eval_primitive: primitive %d lacks an operand", prim);
+    if (n == 0) return ARTGPU_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t esz = dbl ? 8 : 4, bytes = (size_t)n * esz, tbytes = lut ? (size_t)table_size * 4 : 0;
+    float *buf;
+    int rc = pool_get(ctx, P_TMP, 5 * bytes + tbytes + 64, &buf);
+    if (rc) return rc;
+    char *base = reinterpret_cast<char *>(buf);
+    PrimArgs p{};
+    p.prim = prim; p.n = n; p.param = param; p.table_size = table_size;
+    p.a = base; p.b = base + bytes; p.c = base + 2 * bytes; p.out0 = base + 3 * bytes; p.out1 = base + 4 * bytes;
+    p.table = reinterpret_cast<const float *>(base + 5 * bytes);
+    HIPCHK(ctx, hipMemcpyAsync(base, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (need_b) HIPCHK(ctx, hipMemcpyAsync(base + bytes, b, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (need_c) HIPCHK(ctx, hipMemcpyAsync(base + 2 * bytes, c, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (lut) HIPCHK(ctx, hipMemcpyAsync(base + 5 * bytes, table, tbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, launch_prim_eval(p, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(out0, p.out0, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (prim == PRIM_XSINCOSF) HIPCHK(ctx, hipMemcpyAsync(out1, p.out1, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ARTGPU_OK;
+}
+
 int artgpu_denoise_chroma_map(artgpu_ctx *ctx, const artgpu_rgb *img, const double *calclum_mat, const double ws[9],
                               const float noise_c_curve[501], artgpu_plane *ccalc)
 {

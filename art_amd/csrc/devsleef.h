@@ -188,6 +188,26 @@ __device__ __forceinline__ void xsincosf_v(float d, float &sn, float &cs)
     sn = x; cs = y;
 }
 
+// pow_F, xlin2log, xlog2lin (rtengine/sleef.h:1296-1313): scalar exp / log forms
+__device__ __forceinline__ float pow_F(float a, float b) { return xexpf_s(b * xlogf_s(a)); }
+__device__ __forceinline__ float xlin2log(float x, float base) { return xlogf_s(x * (base - 1.f) + 1.f) / xlogf_s(base); }
+__device__ __forceinline__ float xlog2lin(float x, float base) { return (pow_F(base, x) - 1.f) / (base - 1.f); }
+
+// vclampf (sleefsseavx.h:1396-1399): low for NaN -- vminf / vmaxf are the SSE forms (second operand when unordered)
+__device__ __forceinline__ float vclampf(float v, float lo, float hi)
+{
+    const float m = hi < v ? hi : v;      // vminf(hi, v)
+    return m > lo ? m : lo;               // vmaxf(m, lo)
+}
+// LUTf::operator[](vfloat) (rtengine/LUT.h:349-377), one lane
+__device__ __forceinline__ float lutf_vlookup(const float *__restrict__ data, int size, float index)
+{
+    const int idx = (int)vclampf(index, 0.f, (float)(size - 2));
+    const float lower = data[idx], upper = data[idx + 1];
+    const float diff = vclampf(index, 0.f, (float)(size - 1)) - (float)idx;
+    return diff * upper + (1.f - diff) * lower;
+}
+
 // LUTf::operator[](float) (rtengine/LUT.h:436-459): clip_above selects LUT_CLIP_ABOVE behaviour
 template <bool CLIP_ABOVE>
 __device__ __forceinline__ float lutf_lookup(const float *__restrict__ data, int size, float index)

@@ -20,14 +20,6 @@ namespace artgpu {
 namespace {
 
 constexpr float MAXVALF = 65535.f;
-__device__ __forceinline__ float vclampf(float v, float lo, float hi) { return sse_max(sse_min(hi, v), lo); }
-__device__ __forceinline__ float lutf_vlookup(const float *__restrict__ data, int size, float index)
-{
-    const int idx = (int)vclampf(index, 0.f, (float)(size - 2));
-    const float lower = data[idx], upper = data[idx + 1];
-    const float diff = vclampf(index, 0.f, (float)(size - 1)) - (float)idx;
-    return diff * upper + (1.f - diff) * lower;
-}
 __device__ __forceinline__ float xyz2laby_s(const float *__restrict__ cachefy, float f)
 {
     if (f != f) return f;

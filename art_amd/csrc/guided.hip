@@ -14,9 +14,6 @@
 namespace artgpu {
 
 namespace {
-__device__ __forceinline__ float pow_F(float a, float b) { return xexpf_s(b * xlogf_s(a)); }
-__device__ __forceinline__ float xlin2log(float x, float base) { return xlogf_s(x * (base - 1.f) + 1.f) / xlogf_s(base); }
-__device__ __forceinline__ float xlog2lin(float x, float base) { return (pow_F(base, x) - 1.f) / (base - 1.f); }
 
 __device__ __forceinline__ float bilinear(const float *__restrict__ src, int W, int H, float x, float y)
 {

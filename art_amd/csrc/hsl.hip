@@ -13,8 +13,6 @@
 namespace artgpu {
 
 namespace {
-__device__ __forceinline__ float pow_F(float a, float b) { return xexpf_s(b * xlogf_s(a)); }
-__device__ __forceinline__ float xlog2lin(float x, float base) { return (pow_F(base, x) - 1.f) / (base - 1.f); }
 __device__ __forceinline__ float sgnf(float v) { return (float)((0.f < v) - (v < 0.f)); }
 
 // FlatCurve::getVal, FCT_MinMaxCPoints (flatcurves.cc:344-365)

@@ -20,16 +20,6 @@ namespace {
 
 constexpr float D50x = 0.9642f, D50z = 0.8249f, MAXVALF = 65535.f;
 
-// vclampf (sleefsseavx.h:1396-1399): low for NaN
-__device__ __forceinline__ float vclampf(float v, float lo, float hi) { return sse_max(sse_min(hi, v), lo); }
-// LUTf::operator[](vfloat) (LUT.h:349-377)
-__device__ __forceinline__ float lutf_vlookup(const float *__restrict__ data, int size, float index)
-{
-    const int idx = (int)vclampf(index, 0.f, (float)(size - 2));
-    const float lower = data[idx], upper = data[idx + 1];
-    const float diff = vclampf(index, 0.f, (float)(size - 1)) - (float)idx;
-    return diff * upper + (1.f - diff) * lower;
-}
 // Color::computeXYZ2Lab / computeXYZ2LabY (color.cc:1247-1275)
 __device__ __forceinline__ float xyz2lab_s(const float *__restrict__ cachef, float f)
 {

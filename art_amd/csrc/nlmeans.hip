@@ -23,8 +23,6 @@ namespace artgpu {
 
 namespace {
 __device__ __forceinline__ float ftz(float x) { return fabsf(x) < FLT_MIN ? copysignf(0.f, x) : x; }
-__device__ __forceinline__ float pow_F(float a, float b) { return xexpf_s(b * xlogf_s(a)); }
-__device__ __forceinline__ float xlin2log(float x, float base) { return xlogf_s(x * (base - 1.f) + 1.f) / xlogf_s(base); }
 __device__ __forceinline__ float bilinear(const float *__restrict__ src, int W, int H, float x, float y)
 {
     const int xi = min((int)x, W - 1), yi = min((int)y, H - 1);

@@ -274,13 +274,12 @@ hipError_t launch_exposure(const PixArgs &a, hipStream_t s)
 }
 // ImProcFunctions::saturationVibrance (ipsaturation.cc:29-83): chroma = rgb - luminance (double working-space row), optional
 // vibrance as a power law on |chroma| above 2^-16, then l + saturation * chroma floored at 2^-16
-__device__ __forceinline__ float pow_F(float a, float b) { return xexpf_s(b * xlogf_s(a)); }     // sleef.h:1309-1313
 __device__ __forceinline__ float apply_vibrance_px(float x, float vib, float noise)
 {
     const float ax = fabsf(x / 65535.f);
     if (ax > noise) {
         const float sgn = (float)((0.f < x) - (x < 0.f));
-        return sgn * pow_F(ax, vib) * 65535.f;
+        return sgn * pow_F(ax, vib) * 65535.f;      // pow_F: sleef.h:1309-1313
     }
     return x;
 }

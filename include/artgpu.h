@@ -460,6 +460,23 @@ int artgpu_get_scanlines(artgpu_ctx *ctx, const artgpu_rgb *img, int bps, int is
  * artgpu_denoise_compute_params that is worth testing on its own. */
 int artgpu_ordered_sum_f32(artgpu_ctx *ctx, const float *x, int64_t n, int on_device, float *result);
 
+/* The device-side math primitives of the path (art_amd/csrc/devmath.h, devsleef.h, paramcurve.h -- every kernel is built from them),
+ * evaluated one value per lane on host arrays of n values: out0[i] = f(a[i] [, b[i] [, c[i]]]).  Diagnostic entry point: it lets a caller
+ * (tests/test_gpu_primitives.py) compare the GPU's results bit for bit with fixtures generated from the reference's own headers
+ * compiled in place -- rtengine/sleef.h:938-966,1198-1313 (xexpf, xlogf, pow_F, xlin2log, xlog2lin, xcbrtf, xatan2f, double xlog / xexp),
+ * sleefsseavx.h:978-1000,1232-1345 (the 4-lane forms, whose last bits differ), sleefsseavx.h:1435-1442 + helpersse2.h:168-179 (vminf / vmaxf
+ * operand order, vintpf), median.h (median3), LUT.h:349-377 / 436-459 (LUTf::operator[] for vfloat / float).  The product path never calls it.
+ * XSINCOSF writes sin to out0 and cos to out1; XLIN2LOG / XLOG2LIN take the base in `param`; the LUTF_* forms look a[i] up in
+ * table[table_size]; XLOG_D / XEXP_D read and write double arrays.  Returns ARTGPU_EINVAL for a missing operand. */
+enum {
+    ARTGPU_PRIM_XEXPF_S = 0, ARTGPU_PRIM_XEXPF_V, ARTGPU_PRIM_XEXPF_VN, ARTGPU_PRIM_XEXPF_V_LDEXP, ARTGPU_PRIM_XLOGF_S, ARTGPU_PRIM_XLOGF_V,
+    ARTGPU_PRIM_XLOGF_VN, ARTGPU_PRIM_POW_F, ARTGPU_PRIM_XLIN2LOG, ARTGPU_PRIM_XLOG2LIN, ARTGPU_PRIM_XCBRTF, ARTGPU_PRIM_XATAN2F,
+    ARTGPU_PRIM_XSINCOSF, ARTGPU_PRIM_LUTF_SCALAR, ARTGPU_PRIM_LUTF_VECTOR, ARTGPU_PRIM_MEDIAN3, ARTGPU_PRIM_VMINF, ARTGPU_PRIM_VMAXF,
+    ARTGPU_PRIM_VINTPF, ARTGPU_PRIM_XDIV2F, ARTGPU_PRIM_XDIVF2, ARTGPU_PRIM_XLOG_D, ARTGPU_PRIM_XEXP_D, ARTGPU_PRIM_COUNT
+};
+int artgpu_eval_primitive(artgpu_ctx *ctx, int prim, const void *a, const void *b, const void *c, void *out0, void *out1, int64_t n,
+                          float param, const float *table, int table_size);
+
 /* Two of the default-off pixelwise steps of ImProcFunctions::process, so that a frame with these
  * common edits stays on the device:
  * artgpu_channel_mixer : the pixel loop of ImProcFunctions::channelMixer (ipchmixer.cc:185-230); m = {RR,RG,RB, GR,GG,GB,
