@@ -77,6 +77,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=W45)
     ap.add_argument("--height", type=int, default=H45)
+    ap.add_argument("--xtrans-passes", type=int, default=3, choices=[1, 3],
+                    help="c5: the Markesteijn method BASELINE.md C5 names -- 3 = THREE_PASS (CIELab homogeneity, xtrans_demosaic.cc:477-651), "
+                         "1 = ONE_PASS (YPbPr, L688-741); the default line is 3-pass and carries the 1-pass step as `xtrans_one_pass`")
     ap.add_argument("--workload", default="c3", choices=["amaze", "rcd", "c3", "c4", "c5"],
                     help="amaze/rcd: demosaic only (BASELINE configs[1]); c3: AMaZE + getImage/matrix + FTblockDN wavelet "
                          "denoise + exposure + tone curve (BASELINE configs[2], the configuration the metric is quoted on); "
@@ -145,6 +148,7 @@ def main() -> None:
 
     W, H = args.width, args.height
     xtrans = args.workload == "c5"
+    xt_passes = args.xtrans_passes
     if xtrans and (W, H) == (W45, H45):
         W, H = 11648, 8736                                    # 100 MP X-Trans sensor
     filt = synth.FILTERS_RGGB
@@ -237,7 +241,7 @@ def main() -> None:
     def lane_frame_body(ln):
         c = ln["ctx"]
         if xtrans:
-            c.demosaic_xtrans(3, True, ln["p_raw"], synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, ln["p_out"])
+            c.demosaic_xtrans(xt_passes, xt_passes == 3, ln["p_raw"], synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, ln["p_out"])
         else:
             c.demosaic_bayer(method, ln["p_raw"], filt, 1.0, border, ln["p_out"])
         if fused_tool:
@@ -265,7 +269,7 @@ def main() -> None:
     def step0():
         mark(0)
         if xtrans:
-            ctx.demosaic_xtrans(3, True, p_raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, out)
+            ctx.demosaic_xtrans(xt_passes, xt_passes == 3, p_raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, out)
         else:
             ctx.demosaic_bayer(method, p_raw, filt, 1.0, border, out)
         mark(1)
@@ -446,7 +450,7 @@ def main() -> None:
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": (("X-Trans 3-pass Markesteijn (CIELab)" if xtrans else "AMaZE") + f" + getImage/matrix + ImProcFunctions::denoise (chroma noise-curve map, FTblockDN wavelet shrinkage luma 40 / "
+            "workload": ((("X-Trans 3-pass Markesteijn (CIELab)" if xt_passes == 3 else "X-Trans 1-pass Markesteijn (YPbPr)") if xtrans else "AMaZE") + f" + getImage/matrix + ImProcFunctions::denoise (chroma noise-curve map, FTblockDN wavelet shrinkage luma 40 / "
                          f"chroma 15 / gamma 1.7 + DCT detail recovery 50"
                          + (", guided chroma smoothing r=3, NL-means 50/80" if smoothing else "")
                          + f") + exposure 0.3 EV + tone curve {args.tone.upper()}, {W}x{H} " + ("X-Trans" if xtrans else "Bayer RGGB") + f" fp32, {args.lanes} frame{'s' if args.lanes > 1 else ''} per GPU per step "
@@ -492,10 +496,25 @@ def main() -> None:
                                "value": round(args.lanes * mp / (s_ms / 1e3), 2), "unit": "MP/s per GPU",
                                "ratio_to_timed_steps": round(s_ms / (1e3 * elapsed / args.steps), 4)}
 
+    # BASELINE.md C5 names both Markesteijn methods: the timed steps run THREE_PASS, the same step with ONE_PASS is reported beside it
+    if xtrans and pipeline and world == 1 and args.lanes == 1 and xt_passes == 3 and not args.no_extra_legs:
+        xt_passes = 1
+        step0()
+        barrier()
+        o0 = time.perf_counter()
+        no_ = max(1, min(args.steps, 5))
+        for _ in range(no_):
+            step0()
+        barrier()
+        o_ms = 1e3 * (time.perf_counter() - o0) / no_
+        xt_passes = 3
+        result["xtrans_one_pass"] = {"ms_per_step": round(o_ms, 4), "value": round(mp / (o_ms / 1e3), 2), "unit": "MP/s", "steps": no_,
+                                     "note": "the same step with the ONE_PASS method (xtrans_demosaic.cc:688-741; flag: --xtrans-passes 1)"}
+
     # ART's default tone-curve mode is NEUTRAL (curves.cc:854-1038), the headline line uses STD: report the NEUTRAL step beside it
     if pipeline and world == 1 and args.tone == "std" and args.lanes == 1 and not args.no_extra_legs:
         def step_neutral():
-            ctx.demosaic_xtrans(3, True, p_raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, out) if xtrans else ctx.demosaic_bayer(method, p_raw, filt, 1.0, border, out)
+            ctx.demosaic_xtrans(xt_passes, xt_passes == 3, p_raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, out) if xtrans else ctx.demosaic_bayer(method, p_raw, filt, 1.0, border, out)
             if fused_tool:
                 ctx.improc_denoise_fused(img, dn, ws, demosaiced=out, sx1=border, sy1=border, mul=mul, do_clip=True, cam_to_work=mat,
                                          exposure=(exp_scale, 0.0), ecomp=expcomp, calclum_mat=mat, noise_c_curve=ccurve)
@@ -529,7 +548,7 @@ def main() -> None:
                 if ev is not None:
                     ev[k].record(stream)
             mk(0)
-            ctx.demosaic_xtrans(3, True, p_raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, out) if xtrans else ctx.demosaic_bayer(method, p_raw, filt, 1.0, border, out)
+            ctx.demosaic_xtrans(xt_passes, xt_passes == 3, p_raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, out) if xtrans else ctx.demosaic_bayer(method, p_raw, filt, 1.0, border, out)
             mk(1)
             ctx.get_image(out, border, border, mul, True, mat, img)
             mk(2)

@@ -140,6 +140,20 @@ def test_config5_xtrans_and_ftblockdn_100mp_bit_exact(gpu_ctx):
         assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))
 
 
+def test_config5_xtrans_one_pass_100mp_bit_exact(gpu_ctx):
+    """BASELINE.md C5 names both Markesteijn methods: ONE_PASS (YPbPr homogeneity, xtrans_demosaic.cc:688-741) at the full 100 MP size
+    (the THREE_PASS leg is the test above; until round 6 the 1-pass path was only exercised up to 2400 x 2350)."""
+    W, H = 11648, 8736
+    raw = synth.xtrans_frame(W, H, seed=1)
+    d_raw = torch.from_numpy(raw).cuda()
+    d_out, out = _dev_planes(H, W)
+    gpu_ctx.demosaic_xtrans(1, False, capi.device_plane(d_raw), synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, out)
+    gpu_ctx.synchronize()
+    ref = O.xtrans_demosaic(raw, synth.XTRANS_FUJI, synth.XTRANS_RGB_CAM, 1, False)
+    for t, r in zip(d_out, ref):
+        assert np.array_equal(t.cpu().numpy().view(np.uint32), r.view(np.uint32))
+
+
 def test_nlmeans_12mp_bit_exact(gpu_ctx):
     """NL-means (v3 kernel: workgroup per 150x150 reference tile, 27x20 tiles incl. partial ones) on a 12 MP luminance plane."""
     W, H = 4000, 3000
