@@ -28,6 +28,43 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_PX = 16         # 4 B CFA in + 12 B RGB out
 
 
+class StepGuard:
+    """A step that fails on ONE rank must not strand the others: the reference's queue stops at the failing job (simpleprocess.cc:600-602,
+    one process, one queue); here the ranks are independent processes that meet at the barriers and at the completion gather, so a rank whose
+    step raised keeps quiet for the rest of the run (no further device work), still joins every barrier and the gather, and reports
+    status != 0 and the steps it completed in its 64-byte record.  Every rank then sees the failure in the gathered records, rank 0 prints a
+    line with `failed_ranks` (value = the frames of the ranks that succeeded), and all ranks exit with code 3."""
+
+    def __init__(self, rank):
+        self.rank, self.status, self.done = rank, 0, 0
+
+    def run(self, fn, *a):
+        if self.status:
+            return None
+        try:
+            r = fn(*a)
+            self.done += 1
+            return r
+        except Exception as e:      # noqa: BLE001
+            msg = str(e)
+            self.status = int(msg[1:msg.index("]")]) if msg.startswith("[") and "]" in msg and msg[1:msg.index("]")].lstrip("-").isdigit() else 1
+            self.status = self.status or 1
+            print(f"[bench rank {self.rank}] step failed, status {self.status}: {msg}", file=sys.stderr, flush=True)
+            return None
+
+    def done_timed(self, warmup):
+        return max(0, self.done - warmup)
+
+
+def failure_line(records, failed, elapsed, mp, args, world, dry=False):
+    good = sum(r["frames"] for r in records if r["status"] == 0)
+    return {"metric": "megapixels/sec end-to-end (AMaZE+FTblockDN+tone), 45 MP Bayer", "dry": dry, "failed_ranks": failed,
+            "value": round(args.lanes * good * mp / max(elapsed, 1e-9), 2), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "scaling": "weak", "data": "synthetic",
+            "config": {"workload": "INCOMPLETE: a rank's step failed; value counts the frames of the ranks that succeeded", "workload_flag": args.workload,
+                       "completion_records": len(records), "records": records}}
+
+
 def dry_main(args, rank, world, dist, torch, synth) -> None:
     """The rank-side control flow of a real run -- frame `rank` of the batch, warm-up, barrier, K timed steps, barrier, completion
     all-gather with MAX of the elapsed time, one JSON line from rank 0 -- with gloo and without a device (no kernel is called)."""
@@ -45,19 +82,30 @@ def dry_main(args, rank, world, dist, torch, synth) -> None:
         if world > 1:
             dist.barrier()
 
-    def step():
+    def step(k=-1):
+        if args.dry_fail_rank == rank and k == min(1, args.steps - 1):
+            raise RuntimeError("simulated device failure (--dry-fail-rank)")
         return int(raw[H // 2, W // 2])                          # stands in for the device work on this rank's frame
 
+    guard = StepGuard(rank)
     for _ in range(args.warmup):
-        step()
+        guard.run(step)
     barrier()
     t0 = time.perf_counter()
     probe = 0
-    for _ in range(args.steps):
-        probe = step()
+    for k in range(args.steps):
+        r_ = guard.run(step, k)
+        probe = probe if r_ is None else r_
     barrier()
     t1 = time.perf_counter()
-    records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, args.steps, 0, batch.checksum64([probe]), t1 - t0)
+    records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, guard.done_timed(args.warmup), guard.status, batch.checksum64([probe]), t1 - t0)
+    failed = [r["rank"] for r in records if r["status"] != 0]
+    if failed:
+        if rank == 0:
+            print(json.dumps(failure_line(records, failed, elapsed, W * H / 1e6, args, world, dry=True)), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(3)
     if rank == 0:
         print(json.dumps({"metric": "megapixels/sec end-to-end (AMaZE+FTblockDN+tone), 45 MP Bayer", "dry": True,
                           "value": round(world * args.lanes * args.steps * W * H / 1e6 / max(elapsed, 1e-9), 2), "unit": "MP/s",
@@ -77,6 +125,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=W45)
     ap.add_argument("--height", type=int, default=H45)
+    ap.add_argument("--dry-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # --dry only: this rank's second timed step raises
     ap.add_argument("--xtrans-passes", type=int, default=3, choices=[1, 3],
                     help="c5: the Markesteijn method BASELINE.md C5 names -- 3 = THREE_PASS (CIELab homogeneity, xtrans_demosaic.cc:477-651), "
                          "1 = ONE_PASS (YPbPr, L688-741); the default line is 3-pass and carries the 1-pass step as `xtrans_one_pass`")
@@ -321,8 +370,9 @@ def main() -> None:
             print(f"[bench rank {rank}] the RCCL communicator for artgpu_batch_complete did not come up: completing through torch.distributed", file=sys.stderr, flush=True)
             use_rccl_capi, rccl_stuck = False, True
 
+    guard = StepGuard(rank)
     for _ in range(args.warmup):
-        step()
+        guard.run(step)
     barrier()
     # per-launch duration of the dominant kernel, HIP events on the launch stream.  For AMaZE with border >= 4 the demosaic call launches
     # amaze_stream_kernel plus ~20 us of bookkeeping (a 2-KB memset / copy of the tile lists and the arena kernel over the tiles the
@@ -337,22 +387,25 @@ def main() -> None:
     barrier()
     t0 = time.perf_counter()
     evs[0].record(stream)
-    for k in range(args.steps):
+    def timed_step(k):
         cur["ev"] = stage_ev[k]
         step()
         if lib_timing:
             kernel_ms.append(ctx.timings().demosaic_ms)
+    for k in range(args.steps):
+        guard.run(timed_step, k)
     cur["ev"] = None
     evs[1].record(stream)
     barrier()
     t1 = time.perf_counter()
     if lib_timing:
         ctx.enable_timing(False)
-    else:
+    elif not guard.status:
         kernel_ms = [ev[0].elapsed_time(ev[1]) for ev in stage_ev]
     # completion step: all-gather of the 64-byte per-rank records (the batch's only collective),
     # elapsed = MAX over ranks
-    cs = batch.checksum64([int(d_out[1][H // 2, W // 2].item())])
+    cs = batch.checksum64([int(d_out[1][H // 2, W // 2].item())]) if not guard.status else 0
+    steps_done = guard.done_timed(args.warmup)
     hard_exit = False
     if use_rccl_capi:
         # under a launcher (any N): through the C ABI, over the RCCL communicator opened before the timed region (artgpu_batch_complete)
@@ -360,7 +413,7 @@ def main() -> None:
         # completed through torch.distributed instead of being lost)
         import threading
         box = {}
-        th = threading.Thread(target=lambda: box.update(r=batch.complete_batch_rccl(ctx, rccl_handle, dist, dev, rank, world, args.steps, 0, cs, t1 - t0)), daemon=True)
+        th = threading.Thread(target=lambda: box.update(r=batch.complete_batch_rccl(ctx, rccl_handle, dist, dev, rank, world, steps_done, guard.status, cs, t1 - t0)), daemon=True)
         th.start()
         th.join(timeout=float(os.environ.get("ARTGPU_BENCH_RCCL_TIMEOUT", "180")))
         if "r" in box:
@@ -369,16 +422,22 @@ def main() -> None:
                 rccl_handle.close()
         else:
             print(f"[bench rank {rank}] artgpu_batch_complete over RCCL did not finish: completing through torch.distributed", file=sys.stderr, flush=True)
-            records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, args.steps, 0, cs, t1 - t0)
+            records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, steps_done, guard.status, cs, t1 - t0)
             gather_via = "torch.distributed (rccl-capi timed out)"
             hard_exit = True
     else:
-        records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, args.steps, 0, cs, t1 - t0)
+        records, elapsed = batch.complete_batch(dist if world > 1 else None, dev, rank, steps_done, guard.status, cs, t1 - t0)
         gather_via = ("torch.distributed" if world > 1 else "single process") + (" (rccl-capi set-up timed out)" if rccl_stuck else "")
         hard_exit = rccl_stuck
 
-    stage_ms = {nm: round(statistics.mean(ev[i].elapsed_time(ev[i + 1]) for ev in stage_ev), 4) for i, nm in enumerate(stage_names)}
     mp = W * H / 1e6
+    failed = [r["rank"] for r in records if r["status"] != 0]
+    if failed:      # (StepGuard: the gather completed on every rank; nobody reports a throughput for an incomplete batch)
+        if rank == 0:
+            print(json.dumps(failure_line(records, failed, elapsed, mp, args, world)), flush=True)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(3)
+    stage_ms = {nm: round(statistics.mean(ev[i].elapsed_time(ev[i + 1]) for ev in stage_ev), 4) for i, nm in enumerate(stage_names)}
     value = world * args.lanes * args.steps * mp / elapsed
     kern_ms = statistics.mean(kernel_ms)
     achieved = (W * H * ALGO_BYTES_PER_PX / 1e9) / (kern_ms / 1e3)

@@ -143,3 +143,61 @@ def test_bench_py_rank_path_dry_world8_and_config4(gpus, workload):
     assert c["workload_flag"] == workload
     assert [x["rank"] for x in c["records"]] == list(range(gpus)) and all(x["frames"] == 2 and x["status"] == 0 for x in c["records"])
     assert len({x["checksum"] for x in c["records"]}) == gpus          # rank r works on frame r of the batch
+
+
+def _worker_failing(rank, world, port, q):
+    """rank 1's device work failed (status 7 after one frame): it still takes part in the completion gather, so that rank 0 does not hang"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    status, frames = (7, 1) if rank == 1 else (0, 3)
+    recs, tmax = batch.complete_batch(dist, torch.device("cpu"), rank, frames, status, 100 + rank, 0.001 * (rank + 1))
+    q.put((rank, recs, tmax))
+    dist.destroy_process_group()
+
+
+def test_failing_rank_still_completes_the_gather_on_all_ranks():
+    """The reference's queue is one process and stops at the job that failed (simpleprocess.cc:600-602).  Here every rank is a process of its
+    own: a rank whose frame failed reports status != 0 and the frames it finished, and EVERY rank gets all the records -- nobody is left
+    waiting in the collective."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_failing, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1]                      # both ranks hold the same two records
+    recs = res[0][1]
+    assert [r["status"] for r in recs] == [0, 7] and [r["frames"] for r in recs] == [3, 1]
+
+
+@pytest.mark.parametrize("gpus,bad", [(2, 1), (4, 0)])
+def test_bench_py_failing_rank_dry(gpus, bad):
+    """bench.py's own N > 1 path with one rank whose second timed step raises (--dry-fail-rank): the failing rank skips its remaining
+    steps but joins every barrier and the completion gather (StepGuard), rank 0 prints ONE line that names the failed rank and counts only
+    the other ranks' frames, and the job's exit code is 3 -- no rank hangs (the timeout would catch it)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--dry", "--steps", "3", "--warmup", "1",
+                        "--width", "256", "--height", "192", "--dry-fail-rank", str(bad)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["failed_ranks"] == [bad] and d["n_gpus"] == gpus
+    recs = d["config"]["records"]
+    assert d["config"]["completion_records"] == gpus and [x["rank"] for x in recs] == list(range(gpus))
+    for x in recs:
+        if x["rank"] == bad:
+            assert x["status"] != 0 and x["frames"] == 1      # the first timed step finished, the second raised
+        else:
+            assert x["status"] == 0 and x["frames"] == 3
+    assert f"[bench rank {bad}] step failed" in r.stderr
