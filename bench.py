@@ -26,6 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 W45, H45 = 8192, 5464
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 ALGO_BYTES_PER_PX = 16         # 4 B CFA in + 12 B RGB out
+BARRIER_AWARE_B_PER_PX = {"amaze": 16, "rcd": 16, "c3": 16 + 760, "c4": 16 + 760 + 12 + 40, "c5": 16 + 760}     # SURVEY.md section 8d, last row
 
 
 class StepGuard:
@@ -126,6 +127,7 @@ def main() -> None:
     ap.add_argument("--width", type=int, default=W45)
     ap.add_argument("--height", type=int, default=H45)
     ap.add_argument("--dry-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # --dry only: this rank's second timed step raises
+    ap.add_argument("--cpu-sample-only", action="store_true", help="cpu_baseline: only the bounded region sample, not the whole frame once")
     ap.add_argument("--xtrans-passes", type=int, default=3, choices=[1, 3],
                     help="c5: the Markesteijn method BASELINE.md C5 names -- 3 = THREE_PASS (CIELab homogeneity, xtrans_demosaic.cc:477-651), "
                          "1 = ONE_PASS (YPbPr, L688-741); the default line is 3-pass and carries the 1-pass step as `xtrans_one_pass`")
@@ -529,6 +531,12 @@ def main() -> None:
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src, "traffic_stale": traffic_stale, "traffic_raw_counters": traffic_raw,
             # the whole step against the same contract (MP/s x 16 B / 8 TB/s), next to the dominant kernel's fraction
             "end_to_end_frac": round(value * 1e6 * ALGO_BYTES_PER_PX / 1e9 / HBM_PEAK_GBS / max(world, 1), 5),
+            # the survey's diagnostic ceiling: traffic no fusion can remove because of global dependencies -- MAD medians need whole
+            # subbands before shrinking, separable recurrences a transpose point: FTblockDN ~760 B/px on top of the 16 B/px contract (config 4: + NL-means
+            # 12 B/px + guided filter ~40 B/px) => ~10 300 MP/s per GPU for config 3.  Not the contract figure; it says how far the chain is from what
+            # its barriers allow.
+            "barrier_aware": {"bytes_per_px": BARRIER_AWARE_B_PER_PX[args.workload], "ceiling_mps": round(HBM_PEAK_GBS * 1e9 / BARRIER_AWARE_B_PER_PX[args.workload] / 1e6, 1),
+                              "end_to_end_frac": round(value / max(world, 1) / (HBM_PEAK_GBS * 1e9 / BARRIER_AWARE_B_PER_PX[args.workload] / 1e6), 4)},
             "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": W * H * ALGO_BYTES_PER_PX,
             "device_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
             "traffic_rate_frac_of_copy": None if (copy_gbs is None or traffic is None) else round(traffic / 1e9 / (kern_ms / 1e3) / copy_gbs, 4),
@@ -697,14 +705,28 @@ def main() -> None:
         t_fast = timed(1, args.cpu_repeats)
         t_chk = timed(0, 1)
         sample = f"{cw}x{ch} region of the frame through the same stages of the CPU oracle (oracle/*.c, OpenMP), median of {args.cpu_repeats}"
-        result["cpu_baseline"] = {
-            "value": round(cw * ch / 1e6 / t_fast, 2), "unit": "MP/s", "cores": ncores, "kind": "port", "variant": "port-fast (timing only)",
-            "sample": sample,
-            "checker": {"value": round(cw * ch / 1e6 / t_chk, 2), "unit": "MP/s", "cores": ncores, "kind": "port", "variant": "the tests' checker", "sample": sample.replace(f"median of {args.cpu_repeats}", "one run")},
-            "note": "a CPU restatement of the reference's algorithm, not the reference (it cannot be built here: glibmm, lcms2, fftw3 are absent); "
-                    "SURVEY probe for scale: the reference's AMaZE alone runs 38.9 MP/s on 8 vCPU.  The GPU/CPU ratio is not a quality measure; "
-                    "roofline.frac and roofline.end_to_end_frac are.",
-        }
+        quarter = {"value": round(cw * ch / 1e6 / t_fast, 2), "unit": "MP/s", "cores": ncores, "kind": "port", "variant": "port-fast (timing only)", "sample": sample,
+                   "checker": {"value": round(cw * ch / 1e6 / t_chk, 2), "unit": "MP/s", "cores": ncores, "kind": "port", "variant": "the tests' checker",
+                               "sample": sample.replace(f"median of {args.cpu_repeats}", "one run")}}
+        if pipeline and not args.cpu_sample_only:
+            # ... and the WHOLE frame once, same inputs and stage boundaries as the timed GPU steps: the sample above is a
+            # quarter (1/16 for X-Trans) of the frame and its figure moves with the host's mood (5.96 -> 4.95 MP/s between rounds 4 and 5 with no
+            # change to the port); ~9 s of host time for 45 MP, ~25 s for 100 MP
+            cw, ch, craw = W, H, raw
+            ciw, cih = W - 2 * border, H - 2 * border
+            fast_flag.value = 1
+            try:
+                c0 = time.perf_counter(); fn(); t_full = time.perf_counter() - c0
+            finally:
+                fast_flag.value = 0
+            result["cpu_baseline"] = {"value": round(W * H / 1e6 / t_full, 2), "unit": "MP/s", "cores": ncores, "kind": "port", "variant": "port-fast (timing only)",
+                                      "sample": f"the whole {W}x{H} frame through the same stages of the CPU oracle (oracle/*.c, OpenMP), one run of {round(t_full, 1)} s",
+                                      "region_sample": quarter}
+        else:
+            result["cpu_baseline"] = quarter
+        result["cpu_baseline"]["note"] = ("a CPU restatement of the reference's algorithm, not the reference (it cannot be built here: glibmm, lcms2, fftw3 are absent); "
+                                          "SURVEY probe for scale: the reference's AMaZE alone runs 38.9 MP/s on 8 vCPU.  The GPU/CPU ratio is not a quality measure; "
+                                          "roofline.frac and roofline.end_to_end_frac are.")
     if rank == 0:
         print(json.dumps(result), flush=True)
     if hard_exit:               # a thread is still blocked inside RCCL: do not wait for it
