@@ -36,6 +36,9 @@ struct artgpu_ctx {
                                    // channel; 1: one kernel, and one launch for all three channels where nothing has to happen between them
     std::string err;
     int *fs_diag = nullptr;        // pinned host words the fused shrink pass writes before it traps (which strip waited for which): see fail()
+    int opt_dn_debug_stall = -1;   // test hook: band << 16 | strip of the fused shrink pass that never publishes its progress (-1: none)
+    long opt_dn_wait_ms = 0;       // how long a strip of the fused shrink pass waits for the strip above before it gives up (0: five seconds)
+    int dn_form = -1, dn_form_streak = 0;   // RGB_denoise: the shrink passes' form of the last call (1 fused / 0 three kernels) and how many calls in a row used it
     // per-workgroup work arenas (demosaic)
     float *arena = nullptr;
     size_t arena_bytes = 0;
@@ -50,7 +53,7 @@ struct artgpu_ctx {
     // artgpu_batch_run lanes: sibling contexts (own stream, arena, pools) that take every lanes-th frame on their own host thread
     std::vector<artgpu_ctx *> lanes;
     int batch_lanes = 1;
-    int frames_in_flight = 1;      // set by artgpu_batch_run on itself and its lanes while a batch with L > 1 lanes runs: see amaze_cu_cap()
+    int frames_in_flight = 1;      // set by artgpu_batch_run on itself and its lanes while a batch with L > 1 lanes runs: the demosaic then takes 5/8 of the CUs (option amaze_grid)
     bool owns_stream = false;
     float fuse_pre = 0.f, fuse_post = 0.f;   // improc_denoise -> rgb_denoise: exposure compensation fused into rgb2yuv / yuv2rgb
     GetImageFuse fuse_gi = {};               // improc_denoise_fused -> chroma map, rgb2yuv: getImage + matrix read from the demosaiced planes
@@ -112,10 +115,10 @@ int fail(artgpu_ctx *ctx, int code, const char *fmt, ...)
     if (ctx) {
         ctx->err = buf;
         // a fault raised by the fused shrink pass's bounded wait (shrinkblur.hip) is attributed: the kernel left these words in pinned host
-        // memory before it trapped, the queue only reports a generic launch failure
+        // memory when it gave up (check_async_faults finds them at the next synchronisation point)
         if (code == ARTGPU_EHIP && ctx->fs_diag && (unsigned)ctx->fs_diag[0] == 0xF5D1A600u) {
             char more[192];
-            snprintf(more, sizeof more, " [shrink_blur_kernel: band %d strip %d waited 5 s for the strip above to hand down block %d (its counter: %d)]",
+            snprintf(more, sizeof more, " [shrink_blur_kernel: band %d strip %d gave up waiting for the strip above to hand down block %d (its counter: %d)]",
                      ctx->fs_diag[1], ctx->fs_diag[2], ctx->fs_diag[3], ctx->fs_diag[4]);
             ctx->err += more;
             ctx->fs_diag[0] = 0;      // reported once: a later, unrelated failure is not attributed to it
@@ -399,12 +402,22 @@ int artgpu_set_stream(artgpu_ctx *ctx, void *hip_stream)
     return ARTGPU_OK;
 }
 
+// A kernel that gave up a bounded wait (the fused shrink pass: a strip whose predecessor did not hand down a block within five seconds) says so in
+// pinned host words and runs to its end with wrong coefficients instead of trapping -- a trap aborts the host process inside the runtime.  The
+// library reads the words wherever it has just waited for the stream and turns them into ARTGPU_EHIP with the band / strip / block in
+// artgpu_last_error (fail() appends them); the frame in flight is invalid, the context stays usable.
+static int check_async_faults(artgpu_ctx *ctx)
+{
+    if (ctx->fs_diag && (unsigned)ctx->fs_diag[0] == 0xF5D1A600u) return fail(ctx, ARTGPU_EHIP, "a kernel gave up a bounded wait: the results of the calls since the last synchronisation are invalid");
+    return ARTGPU_OK;
+}
+
 int artgpu_synchronize(artgpu_ctx *ctx)
 {
     if (!ctx) return ARTGPU_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return ARTGPU_OK;
+    return check_async_faults(ctx);
 }
 
 int artgpu_set_curve_tail(artgpu_ctx *ctx, int kind, double y_last)
@@ -461,6 +474,8 @@ int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value)
     else if (n == "roctx") ctx->opt_roctx = value != 0;
     else if (n == "dn_streams") ctx->opt_dn_streams = value != 0;
     else if (n == "dn_fused") ctx->opt_dn_fused = (int)value;
+    else if (n == "dn_debug_stall") ctx->opt_dn_debug_stall = (int)value;
+    else if (n == "dn_wait_ms") ctx->opt_dn_wait_ms = value < 0 ? 0 : value;
     else if (n == "lut_lds") ctx->opt_lut_lds = value != 0;
     else if (n == "rcd_rows") { if (value != 4 && value != 8) return fail(ctx, ARTGPU_EINVAL, "rcd_rows: 4 or 8"); ctx->opt_rcd_rows = (int)value; }
     else return fail(ctx, ARTGPU_EINVAL, "set_option: unknown option '%s'", name);
@@ -1273,8 +1288,14 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         ctx->pool[slot] = nullptr; ctx->pool_bytes[slot] = 0;
         return ARTGPU_OK;
     };
+    // What only the OTHER form of the shrink passes uses (band-sized slots) is given back, but not on every switch: `fused` depends on the
+    // frame (w2, h2 >= 64, radii <= 15), so a context or a batch that alternates small and large frames would pay a stream drain and a band-sized
+    // hipFree / hipMalloc per frame -- the allocation the pool exists to avoid.  The slots go after FOUR calls in a row in the same form
+    // (artgpu_trim_scratch returns everything at once).
+    if (ctx->dn_form == (fused ? 1 : 0)) ++ctx->dn_form_streak; else { ctx->dn_form = fused ? 1 : 0; ctx->dn_form_streak = 1; }
+    const bool settle = ctx->dn_form_streak >= 4;
     if (fused) {
-        if ((rc = pool_drop(P_SF_A)) || (rc = pool_drop(P_SF_B)) || (merged && (rc = pool_drop(P_CBANDS2)))) return rc;
+        if (settle && ((rc = pool_drop(P_SF_A)) || (rc = pool_drop(P_SF_B)) || (merged && (rc = pool_drop(P_CBANDS2))))) return rc;
         if (!ctx->fs_diag) {      // (optional: without it a timed-out wait still traps, merely unattributed)
             if (hipHostMalloc(reinterpret_cast<void **>(&ctx->fs_diag), 64, hipHostMallocDefault) == hipSuccess) std::memset(ctx->fs_diag, 0, 64);
             else { ctx->fs_diag = nullptr; (void)hipGetLastError(); }
@@ -1283,7 +1304,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         // the chroma factors need the L coefficients as the decomposition left them: whenever they are evaluated beside or after the L pass
         // (one launch for all channels; the side stream's order) the L pass writes a second band set instead of updating the first
         if ((fork || merged) && (rc = pool_get(ctx, P_LBANDS2, band_bytes, &Lbands2))) return rc;
-    } else if ((rc = pool_drop(P_FUSED)) || (rc = pool_drop(P_LBANDS2)) || (rc = pool_get(ctx, P_SF, band_bytes, &sfc[0])) || (rc = pool_get(ctx, P_TMP, band_bytes, &tmp1))) return rc;
+    } else if ((settle && ((rc = pool_drop(P_FUSED)) || (rc = pool_drop(P_LBANDS2)))) || (rc = pool_get(ctx, P_SF, band_bytes, &sfc[0])) || (rc = pool_get(ctx, P_TMP, band_bytes, &tmp1))) return rc;
     tmpc[0] = tmpc[1] = tmpc[2] = tmp1;
     if (two_chroma) {
         if (merged_mad) Cdd[0].bands = Ld.bands + (size_t)nsub * n2;       // (one MadRgb launch set walks the bands of all three channels)
@@ -1378,7 +1399,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         fa.noisevar = ccalc_dev; fa.noisevar_nonneg = ctx->ccalc_nonneg; fa.noisevar_const = nv_const; fa.noisevar_scale = maxNoiseVarab; fa.noisevar_ab[0] = fa.noisevar_ab[1] = noisevar_ab;
         fa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
         for (int l = 0; l < 10; ++l) fa.rad[l] = bl0.rad[l];
-        fa.level0 = lev0; fa.nsub = nb; fa.diag = ctx->fs_diag;
+        fa.level0 = lev0; fa.nsub = nb; fa.diag = ctx->fs_diag; fa.wait_ticks = (long long)ctx->opt_dn_wait_ms * 100000LL; fa.stall_band = ctx->opt_dn_debug_stall < 0 ? -1 : ctx->opt_dn_debug_stall >> 16; fa.stall_strip = ctx->opt_dn_debug_stall < 0 ? -1 : ctx->opt_dn_debug_stall & 0xffff;
         HIPCHK(ctx, launch_shrink_blur(fa, fused_scratch, sL));
         return ARTGPU_OK;
     };
@@ -1582,7 +1603,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
         fa.noisevar_ab[0] = noisevar_abc[0]; fa.noisevar_ab[1] = noisevar_abc[1];
         fa.useNoiseCCurve = useNoiseCCurve ? 1 : 0;
         for (int l = 0; l < 10; ++l) fa.rad[l] = bl0.rad[l];
-        fa.level0 = 0; fa.nsub = 3 * nsub; fa.nL = nsub; fa.nsub_ch = nsub; fa.diag = ctx->fs_diag;
+        fa.level0 = 0; fa.nsub = 3 * nsub; fa.nL = nsub; fa.nsub_ch = nsub; fa.diag = ctx->fs_diag; fa.wait_ticks = (long long)ctx->opt_dn_wait_ms * 100000LL; fa.stall_band = ctx->opt_dn_debug_stall < 0 ? -1 : ctx->opt_dn_debug_stall >> 16; fa.stall_strip = ctx->opt_dn_debug_stall < 0 ? -1 : ctx->opt_dn_debug_stall & 0xffff;
         HIPCHK(ctx, launch_shrink_blur(fa, fused_scratch, sL));
         return ARTGPU_OK;
     };

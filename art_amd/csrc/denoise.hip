@@ -913,7 +913,7 @@ hipError_t launch_gamma_lut(float *lut, float gamma, float start, float slope, f
 // the LDS-table shape: large frames with the gamma LUTs in use (their pool memory is 16-byte aligned)
 static bool dn_lds_shape(const DnPixArgs &a, const float *lut, int *cus)
 {
-    if (a.lab_mode || !(a.gam > 1.f) || (long long)a.w * a.h < (1 << 22) || (reinterpret_cast<uintptr_t>(lut) & 15) || a.no_lds_lut) return false;
+    if (a.lab_mode || !(a.gam > 1.f) || (long long)a.w * a.h < (1 << 22) || (reinterpret_cast<uintptr_t>(lut) & 15) || a.no_lds_lut || !device_block_fits(LUT_LDS_N * (int)sizeof(float), 1024)) return false;
     int dev = 0;
     *cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1100,7 +1100,7 @@ __global__ void __launch_bounds__(1024) chroma_map_lds_kernel(ChromaMapArgs a)
 }
 hipError_t launch_chroma_map(const ChromaMapArgs &a, hipStream_t s)
 {
-    if ((long long)a.wid * a.hei >= (1 << 20) && (reinterpret_cast<uintptr_t>(a.cachef) & 15) == 0 && !a.no_lds_lut) {
+    if ((long long)a.wid * a.hei >= (1 << 20) && (reinterpret_cast<uintptr_t>(a.cachef) & 15) == 0 && !a.no_lds_lut && device_block_fits(LUT_LDS_N * (int)sizeof(float), 1024)) {
         const size_t lds = (size_t)LUT_LDS_N * sizeof(float);
         hipError_t e = dyn_lds_once(reinterpret_cast<const void *>(chroma_map_lds_kernel), (int)lds);
         if (e != hipSuccess) return e;

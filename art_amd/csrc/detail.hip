@@ -112,8 +112,10 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
     //    iteration waited an LDS round trip per row with two waves per SIMD to hide it.  (All 64 rows as straight-line code ran as fast alone
     //    but slowed the frame: 50 KB of code beside the chroma reconstructions' kernels on the side stream.)
     //  * -blur^2 / factor as a multiplication by the factor's reciprocal, formed once per lane for the launch's two factors: the correctly
-    //    rounded division was 17 of a row's ~50 issue slots.  The quotient changes by at most one unit in the last place, the shrink factor by
-    //    1e-7 of itself -- like the exponential below, far inside what the stage's tolerance is there for (FFTW's own round-off).
+    //    rounded division was 17 of a row's ~50 issue slots.  Two roundings instead of one (the reciprocal, then the product): the quotient can
+    //    differ from the correctly rounded one by up to ~1.5 units in the last place, the shrink factor by ~2e-7 of itself -- like the exponential
+    //    below, far inside what the stage's tolerance is there for (FFTW's own round-off).  With a detail MASK the factor differs per
+    //    pixel: a per-pixel reciprocal is a division itself, so that branch keeps the reference's `/ factor` (no speed to gain, no bits to lose).
     {
         float lenf = (float)(rad + 1);
         float tv = B[0][lane];
@@ -126,12 +128,12 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
         auto emit = [&](int row, float tvr) {
             const bool rowin = (top + row) >= 0 && (top + row) < a.h;
             float factor = (rowin && colin) ? a.detail_hi : a.detail_lo;
-            float rfac = (rowin && colin) ? inv_hi : inv_lo;
-            if (a.mask && rowin && colin) {     // compute_detail(params_Ldetail * mask) (FTblockDN.cc:1481-1486,1583)
+            const float rfac = (rowin && colin) ? inv_hi : inv_lo;
+            const bool masked = a.mask && rowin && colin;
+            if (masked) {     // compute_detail(params_Ldetail * mask) (FTblockDN.cc:1481-1486,1583)
                 const float d = a.params_Ldetail * a.mask[(size_t)(top + row) * a.w + left + lane];
                 const float t = static_cast<float>((100. - d) * (100. - d) + 50. * (100. - d)) * TS * 0.5f;
                 factor = t * t;
-                rfac = 1.f / factor;
             }
             (void)factor; (void)rfac;
             const int slot = row > rad ? row - rad - 1 : TS + row;
@@ -140,7 +142,8 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
 #ifdef DETAIL_EXACT_DIV
             B[slot][lane] = 1.0f - __expf(-sqr(tvr) / factor);
 #else
-            B[slot][lane] = 1.0f - __expf(-sqr(tvr) * rfac);
+            if (a.mask) B[slot][lane] = 1.0f - __expf(masked ? -sqr(tvr) / factor : -sqr(tvr) * rfac);      // (uniform: only launches with a mask carry the division)
+            else B[slot][lane] = 1.0f - __expf(-sqr(tvr) * rfac);
 #endif
         };
         emit(0, tv);
@@ -154,7 +157,7 @@ __global__ void __launch_bounds__(64) detail_blocks_kernel(DetailArgs a)
         const float rlen = 1.f / lenf;
         constexpr int S0 = rad + 1, S1 = TS - rad, G = 8;          // steady rows [S0, S1)
         constexpr int SG = S0 + (S1 - S0) / G * G;                 // ... of which [S0, SG) in whole groups
-#ifndef DETAIL_ROLLED_ROWS
+#ifndef DETAIL_ROW_AT_A_TIME      // (defined: the steady rows one per iteration, the form before round 5 -- timing comparisons only)
 #pragma unroll 1
         for (int r0 = S0; r0 < SG; r0 += G) {
             float hi[G], lo[G], tvs[G];

@@ -26,6 +26,26 @@ inline hipError_t dyn_lds_once(const void *fn, int bytes)
     return e;
 }
 
+// What a workgroup of the current device may have (asked once per device).  The kernels that keep a look-up table or a tile's state in LDS want
+// 137 - 160 KB of dynamic LDS and 1024 threads; a device (or a build for another target) with less takes the plain form of the pass instead
+// of failing at launch.
+inline bool device_block_fits(int lds_bytes, int threads)
+{
+    static std::mutex m;
+    static int lds_of[64], thr_of[64];
+    static bool known[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    std::lock_guard<std::mutex> lk(m);
+    if (!known[dev]) {
+        int l = 0, t = 0;
+        if (hipDeviceGetAttribute(&l, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) l = 0;
+        if (hipDeviceGetAttribute(&t, hipDeviceAttributeMaxThreadsPerBlock, dev) != hipSuccess) t = 0;
+        lds_of[dev] = l; thr_of[dev] = t; known[dev] = true;
+    }
+    return lds_of[dev] >= lds_bytes && thr_of[dev] >= threads;
+}
+
 namespace artgpu {
 
 // ---- AMaZE (amaze.hip) ----
@@ -446,7 +466,9 @@ struct FusedShrinkArgs {
     int wpad;               // columns of a slot row (whole blocks)
     int *progress;          // [nsub][nstrips] blocks a strip has handed down
     int *ticket;
-    int *diag;              // pinned host words (or nullptr): {magic, band, strip, block, counter} written before the bounded wait traps
+    int *diag;              // pinned host words (or nullptr): {magic, band, strip, block, counter} written when a bounded wait gives up
+    long long wait_ticks;   // how long a strip waits for the strip above before it gives up (100 MHz ticks; 0: five seconds)
+    int stall_band, stall_strip;   // test hook (option dn_debug_stall): this strip never publishes its progress (-1: none)
     long long *prof;        // -DFS_PROFILE: cycle counters (step time, busy time per role and per wave, time spent waiting for the strip above)
 };
 bool shrink_blur_supported(int w, int h, const int *rad, int level0, int nsub);

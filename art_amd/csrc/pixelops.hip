@@ -410,7 +410,7 @@ hipError_t launch_yuv_mode(const PixArgs &a, hipStream_t s)
 hipError_t launch_tone_std(const PixArgs &a, hipStream_t s)
 {
     // large frames with a curve: the LDS-resident variant (the curve pointer is 16-byte aligned: pool or hipMalloc memory)
-    if (a.lut && (long long)a.w * a.h >= (1 << 22) && (reinterpret_cast<uintptr_t>(a.lut) & 15) == 0 && !a.no_lds_lut) {
+    if (a.lut && (long long)a.w * a.h >= (1 << 22) && (reinterpret_cast<uintptr_t>(a.lut) & 15) == 0 && !a.no_lds_lut && device_block_fits(LUT_LDS_N * (int)sizeof(float), 1024)) {
         const size_t lds = (size_t)LUT_LDS_N * sizeof(float);
         const bool pc = a.tail_kind == 4;
         hipError_t e = hipFuncSetAttribute(pc ? reinterpret_cast<const void *>(tone_std_lds_kernel<true>) : reinterpret_cast<const void *>(tone_std_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

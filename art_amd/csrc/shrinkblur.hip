@@ -44,6 +44,14 @@ constexpr int FS_SWIN = 256, FS_SWS = FS_SWIN + 1;                          // f
 // polls before it stores, and a strip's steps are separated by workgroup barriers), and strip s publishes j + 1 at its step j + 4, three steps
 // after its column sums consumed block j of that slot.  So a slot is rewritten only behind its reader, and nobody waits for anything the
 // per-strip slots of rounds 4 did not make them wait for: 45 bands x 2 x 266 KB = 24 MB instead of 0.5 GB for a 45 MP frame.
+// RELIANCE ON THE MEMORY MODEL (recorded here on purpose): with two slots the same global addresses are written and read several times within
+// one launch -- strip s + 2 reads where strip s read.  The write-after-read order is the protocol above; the FRESHNESS of a read rests on the
+// hand-over's `sc1` (agent-scope, relaxed) loads never being served from a stale line: on gfx942 / gfx950 an `sc1` load bypasses the CU's L1
+// and an `sc1` store is written through the XCD's L2 to the fabric, so a line strip s left in some XCD's L2 cannot satisfy strip s + 2's read
+// on another -- or the same -- XCD (MI355X_MICROARCH.md, "inter-workgroup visibility"; the translation unit refuses any other target at compile time).  The
+// per-strip slots of round 4 wrote and read each address once per launch and did not depend on it.  Guard:
+// tests/test_gpu_denoise.py::test_fused_hand_over_ring_under_many_short_strips (47 strips of two blocks, fresh data per repetition, every
+// repetition against the three-kernel form) and scripts/soak_fused.py.
 constexpr int FS_RING = 2;
 constexpr unsigned FS_DIAG_MAGIC = 0xF5D1A600u;
 constexpr long long FS_WAIT_TICKS = 500000000LL;                           // 5 s of the 100 MHz s_memrealtime clock
@@ -216,17 +224,21 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
                 // the strip above belongs to a ticket taken before this one, i.e. to a running workgroup: the wait is bounded by that strip's
                 // progress.  Should that ever not hold -- FIVE SECONDS of the constant 100 MHz clock without the counter getting there, not a
                 // number of polls: under a debugger, thread tracing, power capping or CU masking a healthy run is merely slow --, say where
-                // (pinned host words the library reads when the queue reports the fault: artgpu_last_error) and fail loudly instead of
-                // hanging the device.
+                // (pinned host words) and GO ON with whatever the slot holds: the launch then ends in finite time with wrong coefficients in
+                // this band, and the library reports the fault at its next synchronisation point (artgpu_synchronize / any call that waits
+                // for the stream: check_async_faults in artgpu_api.hip; artgpu_last_error names band, strip and block).  Round 5 trapped here;
+                // a wave trap surfaces as a queue exception that aborts the host PROCESS inside the runtime before any HIP call returns, so
+                // the attribution was never read and a host application lost more than one frame (round-5 advisor).
                 if ((++spins & 1023) == 0) {
                     const long long now = (long long)__builtin_amdgcn_s_memrealtime();
                     if (t_wait == 0) t_wait = now;
-                    else if (now - t_wait > FS_WAIT_TICKS) {
+                    else if (now - t_wait > (a.wait_ticks > 0 ? a.wait_ticks : FS_WAIT_TICKS)) {
                         if (a.diag && lane == 0) {
                             a.diag[1] = sub; a.diag[2] = strip; a.diag[3] = J; a.diag[4] = v;
                             __hip_atomic_store(a.diag, (int)FS_DIAG_MAGIC, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                         }
-                        __builtin_trap();
+                        v = 1 << 30;          // (no further waits in this strip)
+                        break;
                     }
                 }
             }
@@ -499,7 +511,7 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
             }
             if (!last && T >= 4) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (gfx942 / gfx950: this wave's data stores have left -- see the #error at the top)
-                if (lane == 0) __hip_atomic_store(prog + strip, T - 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0 && !(sub == a.stall_band && strip == a.stall_strip)) __hip_atomic_store(prog + strip, T - 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (!first && T < NB) prefetch_hand(T);
             if (!last) {
@@ -558,22 +570,7 @@ hipError_t launch_one(const FusedShrinkArgs &a, hipStream_t s)
 
 // What a workgroup of the current device may have: the kernel needs 137 KB (radii up to 7) or 157 KB (up to 15) of dynamic LDS and 1024
 // threads; a device (or a build for another target) with less gets the three-kernel form of the passes instead of a failing launch.
-static bool fs_device_fits(int lds_bytes)
-{
-    static std::mutex m;
-    static int lds_of[64], thr_of[64];
-    static bool known[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    std::lock_guard<std::mutex> lk(m);
-    if (!known[dev]) {
-        int l = 0, t = 0;
-        if (hipDeviceGetAttribute(&l, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) l = 0;
-        if (hipDeviceGetAttribute(&t, hipDeviceAttributeMaxThreadsPerBlock, dev) != hipSuccess) t = 0;
-        lds_of[dev] = l; thr_of[dev] = t; known[dev] = true;
-    }
-    return lds_of[dev] >= lds_bytes && thr_of[dev] >= FS_T;
-}
+static bool fs_device_fits(int lds_bytes) { return device_block_fits(lds_bytes, FS_T); }
 
 bool shrink_blur_supported(int w, int h, const int *rad, int level0, int nsub)
 {

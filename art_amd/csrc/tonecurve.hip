@@ -253,7 +253,7 @@ hipError_t launch_neutral_hues(const NeutralArgs &a, hipStream_t s)
 }
 hipError_t launch_tone_neutral(const NeutralArgs &a, hipStream_t s)
 {
-    if ((long long)a.w * a.h >= (1 << 22) && (reinterpret_cast<uintptr_t>(a.pq) & 15) == 0 && !a.no_lds_lut) {
+    if ((long long)a.w * a.h >= (1 << 22) && (reinterpret_cast<uintptr_t>(a.pq) & 15) == 0 && !a.no_lds_lut && device_block_fits(LUT_LDS_N * (int)sizeof(float), 1024)) {
         const size_t lds = (size_t)LUT_LDS_N * sizeof(float);
         const bool pc = a.tail_kind == 4;
         hipError_t e = hipFuncSetAttribute(pc ? reinterpret_cast<const void *>(tone_neutral_lds_kernel<true>) : reinterpret_cast<const void *>(tone_neutral_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: detail_blocks_kernel with -blur^2 / factor as a multiplication by the factor's reciprocal (default build) against the correctly rounded
-# division and one row per iteration (variants/libdet_old.so = scripts/mkvariant.sh det_old detail.hip "-DDETAIL_EXACT_DIV -DDETAIL_ROLLED_ROWS") and against the
+# division and one row per iteration (variants/libdet_old.so = scripts/mkvariant.sh det_old detail.hip "-DDETAIL_EXACT_DIV -DDETAIL_ROW_AT_A_TIME") and against the
 # groups of eight with the division kept (libdet_g8div.so: -DDETAIL_EXACT_DIV, the bits of det_old); other bits in the tolerance stage: checksums differ
 mkdir -p gpurun_out/r5ab8
 {

@@ -562,6 +562,82 @@ def test_trim_scratch_gives_the_pool_back_and_the_next_call_rebuilds_it():
     del ctx
 
 
+def test_slots_of_the_other_shrink_form_survive_an_alternation_and_go_after_four_calls():
+    """round-5 advisor: a context that alternates between the fused and the three-kernel form of the shrink passes (`fused` depends on the frame
+    size) must not free and re-allocate band-sized slots per frame.  The other form's slots stay across a switch and are released once four
+    calls in a row used the same form; the results are the same bits throughout."""
+    ctx = capi.Context(0)
+    img = _rgb(1000, 760, 12)
+    curve, _ = capi.noise_curve_lut()
+    tp = capi.DenoiseToolParams(_params(), 0, 3, 0, 80)
+
+    def run(form):
+        ctx.set_option("dn_fused", form)
+        got = [p.copy() for p in img]
+        ctx.improc_denoise(capi.host_rgb(got), tp, O.REC2020_WS_D, ecomp=0.3, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+        return got
+    ref = run(1)
+    fused_only = ctx.scratch_bytes()
+    sizes = []
+    for form in (0, 1, 0, 1):                               # alternating: both forms' slots are held, nothing is dropped
+        assert _same(run(form), ref) == [0, 0, 0]
+        sizes.append(ctx.scratch_bytes())
+    assert sizes[0] > fused_only and sizes[1:] == [sizes[0]] * 3
+    for _ in range(4):
+        assert _same(run(0), ref) == [0, 0, 0]
+    assert ctx.scratch_bytes() < sizes[0]                   # four three-kernel calls in a row: the fused form's second band set and ring went back
+    assert _same(run(1), ref) == [0, 0, 0]                   # ... and come back when asked for
+    assert ctx.scratch_bytes() == sizes[0]
+    del ctx
+
+
+def test_fused_shrink_pass_reports_a_strip_that_never_hands_down_instead_of_hanging_or_trapping():
+    """round-5 advisor: the bounded wait of the strip wavefront (shrinkblur.hip).  A strip that never publishes its progress (test hook, option
+    dn_debug_stall) makes the strip below give up after the bound (option dn_wait_ms: 30 ms here instead of five seconds): the launch ends, the
+    process lives, artgpu_synchronize returns an error that names band, strip and block, and the context goes on to produce the right bits."""
+    ctx = capi.Context(0)
+    img = _rgb(1000, 760, 13)
+    curve, _ = capi.noise_curve_lut()
+    tp = capi.DenoiseToolParams(_params(), 0, 3, 0, 80)
+
+    def run():
+        got = [p.copy() for p in img]
+        ctx.improc_denoise(capi.host_rgb(got), tp, O.REC2020_WS_D, ecomp=0.3, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+        ctx.synchronize()
+        return got
+    ref = run()
+    ctx.set_option("dn_wait_ms", 30)
+    ctx.set_option("dn_debug_stall", (4 << 16) | 1)          # band 4, strip 1 of 6 keeps its progress to itself
+    with pytest.raises(capi.ArtGpuError) as ei:
+        run()
+    msg = str(ei.value)
+    assert "shrink_blur_kernel: band 4 strip 2 gave up waiting" in msg, msg
+    ctx.set_option("dn_debug_stall", -1)
+    ctx.set_option("dn_wait_ms", 0)
+    assert _same(run(), ref) == [0, 0, 0]                   # reported once, and the context is as good as new
+    del ctx
+
+
+def test_fused_hand_over_ring_under_many_short_strips():
+    """round-5 advisor: the two-slot hand-over ring (FS_RING, shrinkblur.hip) reuses its global addresses within a launch -- strip s + 2 reads
+    where strip s read -- and relies on `sc1` loads never seeing a stale line.  A tall, narrow frame makes the case as sharp as it gets: 47 strips
+    per band that are two blocks long, so a slot is rewritten microseconds after it was read; fresh data in every repetition, and every
+    repetition against the three-kernel form (dn_fused 0), bit for bit."""
+    ctx = capi.Context(0)
+    curve, _ = capi.noise_curve_lut()
+    tp = capi.DenoiseToolParams(_params(), 0, 3, 0, 80)
+    for rep in range(6):
+        img = _rgb(200, 6000, 100 + rep)
+        out = []
+        for form in (1, 0):
+            ctx.set_option("dn_fused", form)
+            got = [p.copy() for p in img]
+            ctx.improc_denoise(capi.host_rgb(got), tp, O.REC2020_WS_D, ecomp=0.3, noise_c_curve=curve, flags=capi.DN_SKIP_DETAIL_RECOVERY)
+            out.append(got)
+        assert _same(out[0], out[1]) == [0, 0, 0], rep
+    del ctx
+
+
 def test_large_chroma_noise_map_lds_table_same_bits_as_plain_kernel(gpu_ctx):
     """maps of >= 1 Mpx run calclum + ccalc with the lower 40704 entries of the Lab f() table in LDS (chroma_map_lds_kernel, round 5): values on
     both sides of the split, negative, above 65535 and NaN, with and without the colour matrix -- the bits of the plain kernel and of the oracle"""

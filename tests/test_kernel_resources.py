@@ -15,7 +15,21 @@ LIB = os.path.join(ROOT, "art_amd", "libartgpu.so")
 
 @pytest.fixture(scope="module")
 def table():
-    return codeobj.kernel_table(LIB)
+    # properties of a BUILT library for gfx950: without the build (the .so is git-ignored), without a gfx950 bundle in it, or without the
+    # tools that read it (msgpack for the metadata notes, c++filt for the names) there is nothing to check -- skip, do not fail
+    import shutil
+    if not os.path.exists(LIB):
+        pytest.skip("art_amd/libartgpu.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+    pytest.importorskip("msgpack")
+    if shutil.which("c++filt") is None and shutil.which("llvm-cxxfilt") is None and not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-cxxfilt"):
+        pytest.skip("no c++filt to demangle kernel names")
+    try:
+        t = codeobj.kernel_table(LIB)
+    except ValueError as e:          # no .hip_fatbin section
+        pytest.skip(str(e))
+    if not t:
+        pytest.skip("libartgpu.so holds no gfx950 code object (built for another architecture)")
+    return t
 
 
 def _find(table, pattern):
@@ -34,7 +48,7 @@ def test_every_translation_unit_has_a_gfx950_code_object(table):
 
 # kernel (regex on the demangled name) -> most registers it may use.  1024 threads: 128; the figures below that are the ones DESIGN.md quotes
 NO_SPILL = {
-    r"amaze_stream_kernel": 128,                     # 122 in round 5
+    r"amaze_stream_kernel": 128,                     # 122 in round 5, 122 with a loop per pair of roles (round 6)
     r"rcd_stream_kernel<[48]>": 128,
     r"shrink_blur_kernel<7>": 128,                   # 99 since the per-role loops
     r"shrink_blur_kernel<15>": 128,                  # 126, and no spills left
