@@ -452,8 +452,9 @@ def main() -> None:
     pmc_file = {"amaze_stream_kernel": "amaze_stream_pmc_summary.json", "rcd_stream_kernel": "rcd_stream_pmc_summary.json",
                 "xtrans_tiles_kernel": "xtrans_tiles_pmc_summary.json"}[kname]
     # the newest round's counter summary of the kernel (each carries the digest of the sources it was taken from: `traffic_stale` below)
-    pmc_rel = next((os.path.join("profiles", rn, pmc_file) for rn in ("r5", "r4") if os.path.exists(os.path.join(ROOT, "profiles", rn, pmc_file))),
-                   os.path.join("profiles", "r5", pmc_file))
+    rounds = sorted((d for d in os.listdir(os.path.join(ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit()), key=lambda d: -int(d[1:])) if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    pmc_rel = next((os.path.join("profiles", rn, pmc_file) for rn in rounds if os.path.exists(os.path.join(ROOT, "profiles", rn, pmc_file))),
+                   os.path.join("profiles", "r6", pmc_file))
     pmc_path = os.path.join(ROOT, pmc_rel)
     traffic_stale = None
     full_size = (W, H) == ((11648, 8736) if xtrans else (W45, H45))
