@@ -233,7 +233,9 @@ __global__ void __launch_bounds__(FS_T) shrink_blur_kernel(FusedShrinkArgs a)
                     const long long now = (long long)__builtin_amdgcn_s_memrealtime();
                     if (t_wait == 0) t_wait = now;
                     else if (now - t_wait > (a.wait_ticks > 0 ? a.wait_ticks : FS_WAIT_TICKS)) {
-                        if (a.diag && lane == 0) {
+                        // (the strips below a waiting strip wait as well and give up moments later: the FIRST one to give up -- elected through
+                        // a device word behind the ticket, cleared with it per launch -- is the one next to the cause and the one that is reported)
+                        if (a.diag && lane == 0 && atomicCAS(a.ticket + 1, 0, 1) == 0) {
                             a.diag[1] = sub; a.diag[2] = strip; a.diag[3] = J; a.diag[4] = v;
                             __hip_atomic_store(a.diag, (int)FS_DIAG_MAGIC, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                         }
@@ -605,7 +607,7 @@ hipError_t launch_shrink_blur(FusedShrinkArgs a, float *scratch, hipStream_t s)
     a.hand = scratch;
     a.progress = reinterpret_cast<int *>(scratch + (size_t)a.nsub * FS_RING * rows * a.wpad);
     a.ticket = a.progress + a.nsub * a.nstrips;
-    hipError_t e = hipMemsetAsync(a.progress, 0, ((size_t)a.nsub * a.nstrips + 1) * sizeof(int), s);
+    hipError_t e = hipMemsetAsync(a.progress, 0, ((size_t)a.nsub * a.nstrips + 2) * sizeof(int), s);     // + the ticket and the word that elects the first strip to report a fault
     if (e != hipSuccess) return e;
     return maxr > 7 ? launch_one<15>(a, s) : launch_one<7>(a, s);
 }

@@ -611,10 +611,17 @@ def test_fused_shrink_pass_reports_a_strip_that_never_hands_down_instead_of_hang
     with pytest.raises(capi.ArtGpuError) as ei:
         run()
     msg = str(ei.value)
-    assert "shrink_blur_kernel: band 4 strip 2 gave up waiting" in msg, msg
+    # (the strips below the waiting one wait too and give up within moments of each other; the first to give up is reported -- normally
+    # strip 2, the stalled strip's successor, but the order in which they started to wait is not guaranteed)
+    import re
+    m = re.search(r"shrink_blur_kernel: band 4 strip (\d+) gave up waiting", msg)
+    assert m and 2 <= int(m.group(1)) <= 5, msg
+    with pytest.raises(capi.ArtGpuError) as ei2:            # a second faulty frame on the same context is reported again
+        run()
+    assert "gave up waiting" in str(ei2.value)
     ctx.set_option("dn_debug_stall", -1)
     ctx.set_option("dn_wait_ms", 0)
-    assert _same(run(), ref) == [0, 0, 0]                   # reported once, and the context is as good as new
+    assert _same(run(), ref) == [0, 0, 0]                   # reported once per fault, and the context is as good as new
     del ctx
 
 
