@@ -87,6 +87,43 @@ def test_batch_run_two_frames(gpu_ctx):
     assert not np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_batch_gives_scratch_back_before_much_smaller_frames():
+    """round-5 review, weak point 10: a context's scratch only grows, and a batch that goes on with much smaller frames kept the large frame's
+    pools.  artgpu_batch_run trims a lane when this frame and its next one have less than half the pixels the pools were grown for; a batch
+    that alternates sizes keeps them.  Same bits either way."""
+    lut = _lut()
+    p = _params(lut, 0)
+    big, small = (1000, 760), (392, 296)
+
+    def frames(sizes, seed0):
+        raws = [synth.bayer_frame(w, h, synth.FILTERS_RGGB, seed=seed0 + i, noise=1500) for i, (w, h) in enumerate(sizes)]
+        outs = [[np.zeros((h - 8, w - 8), np.float32) for _ in range(3)] for (w, h) in sizes]
+        return raws, outs
+    ctx = capi.Context(0)
+    raws, outs = frames([big], 20)
+    ctx.batch_run([capi.host_plane(r) for r in raws], p, [capi.host_rgb(o) for o in outs])
+    held_big = ctx.scratch_bytes()
+    # big, small, small: the pools go back before the first small frame
+    raws, outs = frames([big, small, small], 30)
+    ctx.batch_run([capi.host_plane(r) for r in raws], p, [capi.host_rgb(o) for o in outs])
+    held_small = ctx.scratch_bytes()
+    assert held_small < held_big / 2, (held_small, held_big)
+    ref = capi.Context(0)
+    for r, o in zip(raws, outs):
+        single = [np.zeros_like(o[0]) for _ in range(3)]
+        ref.pipeline_run(capi.host_plane(r), p, capi.host_rgb(single))
+        for a, s_ in zip(o, single):
+            assert np.array_equal(a.view(np.uint32), s_.view(np.uint32))
+    # big, small, big, small: alternating sizes keep the pools (no trim: the lane's next frame is large again)
+    raws, outs = frames([big, small, big, small], 40)
+    ctx.batch_run([capi.host_plane(r) for r in raws[:1]], p, [capi.host_rgb(o) for o in outs[:1]])
+    held_big2 = ctx.scratch_bytes()
+    assert held_big2 > 2 * held_small
+    ctx.batch_run([capi.host_plane(r) for r in raws], p, [capi.host_rgb(o) for o in outs])
+    assert ctx.scratch_bytes() >= held_big2
+    del ctx, ref
+
+
 def test_pipeline_automatic_chroma_equals_explicit_compute_params(gpu_ctx):
     """chrominance_method AUTOMATIC inside artgpu_pipeline_run = denoiseComputeParams on the demosaiced planes, then the same
     stages with the estimated values (simpleprocess.cc:254-256,311-315)."""
