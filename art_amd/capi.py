@@ -79,6 +79,21 @@ PipelineParams._fields_ = [
     ("tone_mode", C.c_int32), ("tone_lut", C.POINTER(C.c_float)), ("white_point", C.c_float), ("to_out", C.c_float * 9),
     ("to_work", C.c_float * 9), ("scale", C.c_double), ("chrominance_auto_factor", C.c_double)]
 
+
+
+class SensorFrame(C.Structure):
+    """artgpu_sensor_frame: a frame as the decoder hands it over (uint16 / float sensor data + scaleColors' constants)"""
+    _fields_ = [("data", C.c_void_p), ("w", C.c_int32), ("h", C.c_int32), ("row_stride_bytes", C.c_int64), ("is_u16", C.c_int32),
+                ("on_device", C.c_int32), ("cblacksom", C.c_float * 4), ("scale_mul", C.c_float * 4)]
+
+
+class ScanlineFrame(C.Structure):
+    """artgpu_scanline_frame: a frame as the writers take it (rgb2out matrix path + getScanline)"""
+    _fields_ = [("scanlines", C.c_void_p), ("row_stride_bytes", C.c_int64), ("bps", C.c_int32), ("is_float", C.c_int32),
+                ("on_device", C.c_int32), ("rgb2out_enabled", C.c_int32), ("out_matrix", C.c_float * 9), ("trc_linear", C.c_int32),
+                ("trc_lut", C.POINTER(C.c_float)), ("trc_lutsz", C.c_int32), ("chmax", C.c_float * 4), ("status", C.c_int32)]
+
+
 DN_SKIP_DETAIL_RECOVERY = 1
 # the chroma noise curve ImProcFunctions::denoise always installs (ipdenoise.cc:1139-1149)
 DEFAULT_NOISE_C_CURVE_POINTS = (1.0, 0.05, 0.50, 0.35, 0.35, 0.35, 0.05, 0.35, 0.35)
@@ -176,6 +191,7 @@ def _load():
     lib.artgpu_rgb_curves.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.artgpu_pipeline_run.argtypes = [C.c_void_p, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
     lib.artgpu_batch_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(Plane), C.POINTER(PipelineParams), C.POINTER(RGB)]
+    lib.artgpu_batch_run_io.argtypes = [C.c_void_p, C.c_int, C.POINTER(SensorFrame), C.POINTER(PipelineParams), C.POINTER(ScanlineFrame)]
     lib.artgpu_demosaic_xtrans.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Plane), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(RGB)]
     lib.artgpu_tone_curve_neutral.argtypes = [C.c_void_p, C.POINTER(RGB), C.POINTER(C.c_float), C.c_float, C.POINTER(NeutralState)]
     lib.artgpu_noise_curve_lut.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -224,12 +240,36 @@ EXPORTS = ["artgpu_eval_primitive", "artgpu_set_progress_callback", "artgpu_set_
            "artgpu_convert_color_space", "artgpu_exposure", "artgpu_tone_curve",
            "artgpu_wavelet_decompose", "artgpu_wavelet_mad", "artgpu_wavelet_info", "artgpu_wavelet_get_band", "artgpu_wavelet_set_band",
            "artgpu_wavelet_reconstruct", "artgpu_wavelet_free", "artgpu_rgb_denoise", "artgpu_denoise_guided_smoothing",
-           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_improc_denoise_fused", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_batch_complete", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter", "artgpu_hsl_equalizer", "artgpu_log_encoding", "artgpu_rgb_to_lab", "artgpu_lab_to_rgb", "artgpu_lab_histogram", "artgpu_lab_adjustments", "artgpu_dual_demosaic_bayer"]
+           "artgpu_gaussian_blur", "artgpu_detail_mask", "artgpu_nlmeans", "artgpu_improc_denoise", "artgpu_improc_denoise_fused", "artgpu_noise_curve_lut", "artgpu_denoise_chroma_map", "artgpu_tone_curve_neutral", "artgpu_demosaic_xtrans", "artgpu_pipeline_run", "artgpu_batch_run", "artgpu_batch_run_io", "artgpu_scale_colors", "artgpu_channel_mixer", "artgpu_rgb_curves", "artgpu_denoise_compute_params", "artgpu_ordered_sum_f32", "artgpu_get_image_skip", "artgpu_saturation_vibrance", "artgpu_set_batch_lanes", "artgpu_batch_complete", "artgpu_rgb2out_matrix", "artgpu_get_scanlines", "artgpu_guided_filter", "artgpu_hsl_equalizer", "artgpu_log_encoding", "artgpu_rgb_to_lab", "artgpu_lab_to_rgb", "artgpu_lab_histogram", "artgpu_lab_adjustments", "artgpu_dual_demosaic_bayer"]
 
 
 def host_plane(a: np.ndarray) -> Plane:
     assert a.dtype == np.float32 and a.ndim == 2 and a.strides[1] == 4
     return Plane(a.ctypes.data, a.shape[1], a.shape[0], a.strides[0], 0)
+
+
+def sensor_frame(a: np.ndarray, cblacksom=(0.0, 0.0, 0.0, 0.0), scale_mul=(1.0, 1.0, 1.0, 1.0)) -> SensorFrame:
+    assert a.dtype in (np.uint16, np.float32) and a.ndim == 2 and a.strides[1] == a.itemsize
+    return SensorFrame(a.ctypes.data, a.shape[1], a.shape[0], a.strides[0], 1 if a.dtype == np.uint16 else 0, 0,
+                       (C.c_float * 4)(*[float(v) for v in cblacksom]), (C.c_float * 4)(*[float(v) for v in scale_mul]))
+
+
+def scanline_frame(a: np.ndarray, matrix=None, trc_lut=None, is_float: bool = False) -> ScanlineFrame:
+    """`a`: (h, w, 3) uint8 / uint16 / float32 host array the scanlines land in (uint16 + is_float: half floats).  matrix: rgb2out's
+    3 x 3 (None: no rgb2out); trc_lut: float32 array the caller keeps alive until the batch call has returned (None: linear TRC)."""
+    assert a.ndim == 3 and a.shape[2] == 3 and a.strides[2] == a.itemsize and a.strides[1] == 3 * a.itemsize
+    f = ScanlineFrame()
+    f.scanlines = a.ctypes.data; f.row_stride_bytes = a.strides[0]; f.bps = 8 * a.itemsize
+    f.is_float = 1 if (is_float or a.dtype == np.float32) else 0
+    f.on_device = 0
+    f.rgb2out_enabled = 0 if matrix is None else 1
+    if matrix is not None:
+        f.out_matrix[:] = [float(v) for v in np.asarray(matrix, np.float32).reshape(9)]
+    f.trc_linear = 1 if trc_lut is None else 0
+    if trc_lut is not None:
+        assert trc_lut.dtype == np.float32 and trc_lut.flags.c_contiguous
+        f.trc_lut = trc_lut.ctypes.data_as(C.POINTER(C.c_float)); f.trc_lutsz = trc_lut.size
+    return f
 
 
 def host_rgb(planes) -> RGB:
@@ -481,6 +521,18 @@ class Context:
     def batch_run(self, raws, params: PipelineParams, outs):
         n = len(raws)
         self._chk(LIB.artgpu_batch_run(self._h, n, (Plane * n)(*raws), C.byref(params), (RGB * n)(*outs)))
+
+    def batch_run_io(self, sensor_frames, params: PipelineParams, scanline_frames):
+        """artgpu_batch_run_io: sensor data in, writers' scanlines out, copies beside the kernels.  `sensor_frames`: numpy arrays (uint16 /
+        float32, host) or ready SensorFrame structures; `scanline_frames`: ScanlineFrame structures (scanline_frame() builds one around a
+        numpy array).  Returns the array of ScanlineFrame (chmax / status filled in)."""
+        n = len(sensor_frames)
+        ins = (SensorFrame * n)()
+        for k, f in enumerate(sensor_frames):
+            ins[k] = f if isinstance(f, SensorFrame) else sensor_frame(f)
+        outs = (ScanlineFrame * n)(*scanline_frames)
+        self._chk(LIB.artgpu_batch_run_io(self._h, n, ins, C.byref(params), outs))
+        return outs
 
     def demosaic_xtrans(self, passes: int, use_cielab: bool, raw: Plane, xtrans, rgb_cam, out: RGB):
         xt = np.ascontiguousarray(xtrans, dtype=np.int32).reshape(36)

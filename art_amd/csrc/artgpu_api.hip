@@ -48,7 +48,7 @@ struct artgpu_ctx {
     float *stage[NSTAGE] = {};
     size_t stage_bytes[NSTAGE] = {};
     // grow-only scratch pool for the denoise path (planes, decompositions, shrink buffers)
-    static constexpr int NPOOL = 48;
+    static constexpr int NPOOL = 64;
     float *pool[NPOOL] = {};
     size_t pool_bytes[NPOOL] = {};
     // artgpu_batch_run lanes: sibling contexts (own stream, arena, pools) that take every lanes-th frame on their own host thread
@@ -56,6 +56,15 @@ struct artgpu_ctx {
     int batch_lanes = 1;
     int frames_in_flight = 1;      // set by artgpu_batch_run on itself and its lanes while a batch with L > 1 lanes runs: the demosaic then takes 5/8 of the CUs (option amaze_grid)
     bool owns_stream = false;
+    // artgpu_batch_run_io: a frame's upload and download run on streams of their own beside the kernels on `stream`.  Events, by staging slot
+    // (the parity of the frame's turn on this lane): [0,1] uploaded, [2,3] the upload slot has been read, [4,5] scanlines written, [6,7] downloaded
+    hipStream_t io_up = nullptr, io_down = nullptr;
+    hipEvent_t io_ev[8] = {};
+    int *io_host = nullptr;        // pinned, 8 words per frame of the lane: channel maxima (bit patterns) x 3, -, rgb2out's count of unsupported values
+    int io_host_cap = 0;
+    int cu_reserve = 0;            // set around a batch whose downloads run as a kernel of a few workgroups: the persistent one-workgroup-per-CU pixel passes leave those CUs alone
+    int opt_io_direct = -1;        // artgpu_batch_run_io, scanlines into pinned host memory: n > 0: written there by n persistent workgroups (no staging, no copy); 0: staged +
+                                   // hipMemcpy; -1 (default): 8 workgroups with several lanes, the runtime's copy with one (io_frame has the measurements)
     float fuse_pre = 0.f, fuse_post = 0.f;   // improc_denoise -> rgb_denoise: exposure compensation fused into rgb2yuv / yuv2rgb
     GetImageFuse fuse_gi = {};               // improc_denoise_fused -> chroma map, rgb2yuv: getImage + matrix read from the demosaiced planes
     float fuse_exp_scale = 0.f, fuse_exp_black = 0.f;   // improc_denoise_fused -> yuv2rgb: ImProcFunctions::exposure behind the last pass
@@ -368,6 +377,11 @@ int artgpu_destroy(artgpu_ctx *ctx)
         if (ctx->ev[k]) (void)hipEventDestroy(ctx->ev[k]);
     for (artgpu_ctx *l : ctx->lanes) (void)artgpu_destroy(l);
     ctx->lanes.clear();
+    if (ctx->io_up) { (void)hipStreamSynchronize(ctx->io_up); (void)hipStreamDestroy(ctx->io_up); }
+    if (ctx->io_down) { (void)hipStreamSynchronize(ctx->io_down); (void)hipStreamDestroy(ctx->io_down); }
+    for (int k = 0; k < 8; ++k)
+        if (ctx->io_ev[k]) (void)hipEventDestroy(ctx->io_ev[k]);
+    if (ctx->io_host) (void)hipHostFree(ctx->io_host);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (int k = 0; k < 2; ++k)
         if (ctx->aux_ev[k]) (void)hipEventDestroy(ctx->aux_ev[k]);
@@ -478,6 +492,7 @@ int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value)
     else if (n == "dn_debug_stall") ctx->opt_dn_debug_stall = (int)value;
     else if (n == "dn_wait_ms") ctx->opt_dn_wait_ms = value < 0 ? 0 : value;
     else if (n == "lut_lds") ctx->opt_lut_lds = value != 0;
+    else if (n == "io_direct") { if (value < -1 || value > 4096) return fail(ctx, ARTGPU_EINVAL, "io_direct: -1 (automatic), 0 .. 4096 workgroups"); ctx->opt_io_direct = (int)value; }
     else if (n == "rcd_rows") { if (value != 4 && value != 8) return fail(ctx, ARTGPU_EINVAL, "rcd_rows: 4 or 8"); ctx->opt_rcd_rows = (int)value; }
     else return fail(ctx, ARTGPU_EINVAL, "set_option: unknown option '%s'", name);
     return ARTGPU_OK;
@@ -524,6 +539,8 @@ int artgpu_trim_scratch(artgpu_ctx *ctx)
     if (ctx->aux) HIPCHK(ctx, hipStreamSynchronize(ctx->aux));
     if (ctx->dn_stream[0]) HIPCHK(ctx, hipStreamSynchronize(ctx->dn_stream[0]));
     if (ctx->amz_side) HIPCHK(ctx, hipStreamSynchronize(ctx->amz_side));
+    if (ctx->io_up) HIPCHK(ctx, hipStreamSynchronize(ctx->io_up));
+    if (ctx->io_down) HIPCHK(ctx, hipStreamSynchronize(ctx->io_down));
     auto drop = [](float **p, size_t *b) { if (*p) (void)hipFree(*p); *p = nullptr; *b = 0; };
     drop(&ctx->arena, &ctx->arena_bytes);
     for (int k = 0; k < artgpu_ctx::NSTAGE; ++k) drop(&ctx->stage[k], &ctx->stage_bytes[k]);
@@ -935,7 +952,7 @@ int artgpu_tone_curve(artgpu_ctx *ctx, artgpu_rgb *image, int mode, const float 
         if ((rc = upload_curve(ctx, lut65536))) return rc;
         a.lut = ctx->lut;
     }
-    a.no_lds_lut = !ctx->opt_lut_lds;
+    a.no_lds_lut = !ctx->opt_lut_lds; a.cu_reserve = ctx->cu_reserve;
     HIPCHK(ctx, launch_tone_std(a, ctx->stream));
     return unbind_rgb(ctx, image, &d);
 }
@@ -1101,7 +1118,9 @@ int artgpu_wavelet_free(artgpu_ctx *ctx, artgpu_wavelet *wv)
 
 namespace {
 
-enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_BATCH, P_DCTTAB, P_CBANDS2, P_CLOW0_2, P_CLOW1_2, P_SF_A, P_SF_B, P_HISTO_A, P_HISTO_B, P_RGBCURVES, P_FUSED, P_LBANDS2, P_NSLOTS };
+enum { P_L = 0, P_A, P_B, P_LBANDS, P_LLOW0, P_LLOW1, P_CBANDS, P_CLOW0, P_CLOW1, P_SF, P_TMP, P_HISTO, P_MAD, P_GAM, P_CCALC, P_LIN, P_BLOCKS, P_DTAB, P_CCMAP, P_CACHEF, P_PQ, P_XCBRT, P_GAUSS64, P_DMASK, P_LABTABS, P_PIPE_R, P_PIPE_G, P_PIPE_B, P_DNINFO, P_BATCH, P_DCTTAB, P_CBANDS2, P_CLOW0_2, P_CLOW1_2, P_SF_A, P_SF_B, P_HISTO_A, P_HISTO_B, P_RGBCURVES, P_FUSED, P_LBANDS2,
+       P_IO_IN0, P_IO_IN1, P_IO_CFA, P_IO_IMG0, P_IO_IMG1, P_IO_IMG2, P_IO_IMG3, P_IO_IMG4, P_IO_IMG5, P_IO_OUT0, P_IO_OUT1, P_IO_FLAGS,      // artgpu_batch_run_io: staging slots, the CFA plane, the working image, the frames' flag words
+       P_NSLOTS };
 static_assert(P_NSLOTS <= artgpu_ctx::NPOOL, "grow artgpu_ctx::pool");
 
 struct DevDecomp {
@@ -1358,7 +1377,7 @@ int artgpu_rgb_denoise(artgpu_ctx *ctx, artgpu_rgb *img, const artgpu_denoise_pa
     px.gain = gain; px.newGain = 1.f / gain;
     px.gam = gam; px.gamthresh = gamthresh; px.gamslope = gamslope; px.igam = igam; px.igamthresh = igamthresh; px.igamslope = igamslope;
     px.gamcurve = gamlut; px.igamcurve = gamlut + 65536;
-    px.pre_scale = ctx->fuse_pre; px.post_scale = ctx->fuse_post; px.no_lds_lut = !ctx->opt_lut_lds;
+    px.pre_scale = ctx->fuse_pre; px.post_scale = ctx->fuse_post; px.no_lds_lut = !ctx->opt_lut_lds; px.cu_reserve = ctx->cu_reserve;
     px.gi = ctx->fuse_gi; px.exp_on = ctx->fuse_exp_on; px.exp_scale = ctx->fuse_exp_scale; px.exp_black = ctx->fuse_exp_black;
     // the inverse-gamma pass looks up gamma-encoded values: the mid-tones sit in the middle of the table, so the 40704 entries kept in LDS
     // start at 8000 (gamma 1.7: linear 0.03 .. 0.60 of white); the forward pass and the tone curve index with linear data and keep [0, 40704)
@@ -2331,7 +2350,7 @@ int artgpu_tone_curve_neutral(artgpu_ctx *ctx, artgpu_rgb *image, const float *l
     a.whitecoeff = whitecoeff;
     a.tail_kind = ctx->curve_tail_kind == ARTGPU_CURVE_TAIL_HOST ? 0 : ctx->curve_tail_kind; a.tail_y = ctx->curve_tail_y; a.tail_pc = ctx->curve_tail_pc;
     if (fresh) HIPCHK(ctx, launch_neutral_hues(a, ctx->stream));
-    a.no_lds_lut = !ctx->opt_lut_lds;
+    a.no_lds_lut = !ctx->opt_lut_lds; a.cu_reserve = ctx->cu_reserve;
     HIPCHK(ctx, launch_tone_neutral(a, ctx->stream));
     return unbind_rgb(ctx, image, &d);
 }
@@ -2384,7 +2403,7 @@ static int chroma_map_dev(artgpu_ctx *ctx, float *const planes[3], size_t stride
     a.stride = stride; a.wid = wid; a.hei = hei;
     a.has_mat = mat ? 1 : 0;
     for (int k = 0; k < 9; ++k) { a.mat[k] = mat ? mat[k] : 0.0; a.wpi[k] = (float)ws[k]; }
-    a.cachef = tab; a.curve = tab + 65536; a.out = map; a.no_lds_lut = !ctx->opt_lut_lds;
+    a.cachef = tab; a.curve = tab + 65536; a.out = map; a.no_lds_lut = !ctx->opt_lut_lds; a.cu_reserve = ctx->cu_reserve;
     HIPCHK(ctx, launch_chroma_map(a, ctx->stream));
     *out = map;
     return ARTGPU_OK;
@@ -3016,41 +3035,32 @@ int artgpu_set_batch_lanes(artgpu_ctx *ctx, int lanes)
     return ARTGPU_OK;
 }
 
-int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, const artgpu_pipeline_params *params, artgpu_rgb *outs)
+namespace {
+// The scratch of a context only grows (about 5 GB for a 45 MP frame through the whole tool).  A batch that goes on with much smaller frames
+// would keep the large frame's pools for nothing: when this frame AND the lane's next one have less than half the pixels the pools were
+// grown for, the lane gives them back first (artgpu_trim_scratch: a stream drain and a few hipFree, paid once per such transition; a
+// batch that alternates sizes keeps its pools).  Round-5 review, weak point 10.  `nxt` < 0: the lane's last frame has no successor to go
+// by -- it keeps the pools, a caller that is done calls artgpu_trim_scratch.
+int batch_settle_scratch(artgpu_ctx *c, long long px, long long nxt)
 {
-    if (!ctx) return ARTGPU_EINVAL;
-    if (nframes < 0 || (nframes && (!raws || !params || !outs))) return fail(ctx, ARTGPU_EINVAL, "batch_run: null argument");
-    const int L = std::min(ctx->batch_lanes, nframes);
-    // The scratch of a context only grows (about 5 GB for a 45 MP frame through the whole tool).  A batch that goes on with much smaller frames
-    // would keep the large frame's pools for nothing: when this frame AND the lane's next one have less than half the pixels the pools were
-    // grown for, the lane gives them back first (artgpu_trim_scratch: a stream drain and a few hipFree, paid once per such transition; a
-    // batch that alternates sizes keeps its pools).  Round-5 review, weak point 10.
-    auto px_of = [&](int f) { return (long long)raws[f].w * raws[f].h; };
-    auto settle_scratch = [&](artgpu_ctx *c, int f, int step) -> int {
-        // (the batch's last frame of a lane has no successor to go by: it keeps the pools, a caller that is done calls artgpu_trim_scratch)
-        const long long px = px_of(f), nxt = f + step < nframes ? px_of(f + step) : c->batch_px;
-        if (c->batch_px && 2 * px < c->batch_px && 2 * nxt < c->batch_px) {
-            std::vector<artgpu_ctx *> keep;
-            keep.swap(c->lanes);                       // (only this context's own pools: its lanes decide for themselves)
-            const int rc = artgpu_trim_scratch(c);
-            keep.swap(c->lanes);
-            if (rc) return rc;
-            c->batch_px = 0;
-        }
-        if (px > c->batch_px) c->batch_px = px;
-        return ARTGPU_OK;
-    };
-    if (L <= 1) {
-        for (int f = 0; f < nframes; ++f) {
-            int rc = settle_scratch(ctx, f, 1);
-            if (!rc) rc = artgpu_pipeline_run(ctx, &raws[f], params, &outs[f]);
-            if (rc) return rc;
-        }
-        return ARTGPU_OK;
+    if (nxt < 0) nxt = c->batch_px;
+    if (c->batch_px && 2 * px < c->batch_px && 2 * nxt < c->batch_px) {
+        std::vector<artgpu_ctx *> keep;
+        keep.swap(c->lanes);                       // (only this context's own pools: its lanes decide for themselves)
+        const int rc = artgpu_trim_scratch(c);
+        keep.swap(c->lanes);
+        if (rc) return rc;
+        c->batch_px = 0;
     }
-    // Frames are independent: lane k (its own context, stream and host thread) takes frames k, k+L, ...  The kernels of one frame
-    // are a mix of latency-bound (AMaZE) and bandwidth-bound (wavelet passes) work, so frames in flight on different streams fill
-    // each other's gaps (+11 % throughput with three lanes at 45 MP, scripts/overlap_time.py).
+    if (px > c->batch_px) c->batch_px = px;
+    return ARTGPU_OK;
+}
+
+// Frames are independent: lane k (its own context, stream and host thread) takes frames k, k+L, ...  The kernels of one frame
+// are a mix of latency-bound (AMaZE) and bandwidth-bound (wavelet passes) work, so frames in flight on different streams fill
+// each other's gaps (+11 % throughput with three lanes at 45 MP, scripts/overlap_time.py).
+int batch_prepare_lanes(artgpu_ctx *ctx, int L)
+{
     HIPCHK(ctx, hipSetDevice(ctx->device));
     while ((int)ctx->lanes.size() < L - 1) {
         artgpu_ctx *peer = nullptr;
@@ -3067,30 +3077,256 @@ int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, con
         peer->opt_amaze_path = ctx->opt_amaze_path; peer->opt_amaze_split = ctx->opt_amaze_split; peer->opt_amaze_overlap = ctx->opt_amaze_overlap; peer->opt_amaze_grid = ctx->opt_amaze_grid;
         peer->opt_amaze_zero_mask = ctx->opt_amaze_zero_mask; peer->opt_amaze_zero_frame = ctx->opt_amaze_zero_frame; peer->opt_amaze_poison = ctx->opt_amaze_poison;
         peer->opt_rcd_rows = ctx->opt_rcd_rows; peer->opt_roctx = ctx->opt_roctx; peer->opt_lut_lds = ctx->opt_lut_lds; peer->opt_dn_streams = ctx->opt_dn_streams; peer->opt_dn_fused = ctx->opt_dn_fused;
-        peer->opt_dn_wait_ms = ctx->opt_dn_wait_ms; peer->opt_dn_debug_stall = ctx->opt_dn_debug_stall;
+        peer->opt_dn_wait_ms = ctx->opt_dn_wait_ms; peer->opt_dn_debug_stall = ctx->opt_dn_debug_stall; peer->opt_io_direct = ctx->opt_io_direct;
         peer->progress_fn = ctx->progress_fn; peer->progress_user = ctx->progress_user;
         peer->frames_in_flight = L;
     }
     ctx->frames_in_flight = L;
-    struct InFlightReset { artgpu_ctx *c; ~InFlightReset() { c->frames_in_flight = 1; for (artgpu_ctx *p : c->lanes) p->frames_in_flight = 1; } } in_flight_reset{ctx};
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // inputs the caller produced on this context's stream
+    return ARTGPU_OK;
+}
+struct InFlightReset { artgpu_ctx *c; ~InFlightReset() { c->frames_in_flight = 1; for (artgpu_ctx *p : c->lanes) p->frames_in_flight = 1; } };
+
+// run `work(lane context, lane index)` on L lanes (lane 0 on the calling thread) and gather the status codes
+extern "C++" {
+template <typename F>
+int batch_on_lanes(artgpu_ctx *ctx, int L, F work)
+{
     std::vector<int> rcs(L, ARTGPU_OK);
-    auto work = [&](int k) {
-        artgpu_ctx *c = k == 0 ? ctx : ctx->lanes[k - 1];
-        for (int f = k; f < nframes; f += L) {
-            int rc = settle_scratch(c, f, L);
-            if (!rc) rc = artgpu_pipeline_run(c, &raws[f], params, &outs[f]);
-            if (rc) { rcs[k] = rc; return; }
-        }
-        if (k > 0 && hipStreamSynchronize(c->stream) != hipSuccess) rcs[k] = ARTGPU_EHIP;
-    };
+    // (the lanes' contexts are looked up HERE: lane 0 may take ctx->lanes aside for a moment while it trims its own pools -- batch_settle_scratch --,
+    // and a thread that starts late must not index the vector then)
+    std::vector<artgpu_ctx *> cs(L, ctx);
+    for (int k = 1; k < L; ++k) cs[k] = ctx->lanes[k - 1];
     std::vector<std::thread> threads;
-    for (int k = 1; k < L; ++k) threads.emplace_back(work, k);
-    work(0);
+    for (int k = 1; k < L; ++k) threads.emplace_back([&rcs, &work, &cs, k]() { rcs[k] = work(cs[k], k); });
+    rcs[0] = work(ctx, 0);
     for (std::thread &t : threads) t.join();
     for (int k = 0; k < L; ++k)
-        if (rcs[k]) return fail(ctx, rcs[k], "batch_run: lane %d: %s", k, k == 0 ? ctx->err.c_str() : ctx->lanes[k - 1]->err.c_str());
+        if (rcs[k]) return fail(ctx, rcs[k], "batch_run: lane %d: %s", k, k == 0 ? ctx->err.c_str() : cs[k]->err.c_str());
     return ARTGPU_OK;
+}
+} // extern "C++"
+} // namespace
+
+int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, const artgpu_pipeline_params *params, artgpu_rgb *outs)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (nframes < 0 || (nframes && (!raws || !params || !outs))) return fail(ctx, ARTGPU_EINVAL, "batch_run: null argument");
+    const int L = std::min(ctx->batch_lanes, nframes);
+    auto px_of = [&](int f) { return (long long)raws[f].w * raws[f].h; };
+    if (L <= 1) {
+        for (int f = 0; f < nframes; ++f) {
+            int rc = batch_settle_scratch(ctx, px_of(f), f + 1 < nframes ? px_of(f + 1) : -1);
+            if (!rc) rc = artgpu_pipeline_run(ctx, &raws[f], params, &outs[f]);
+            if (rc) return rc;
+        }
+        return ARTGPU_OK;
+    }
+    int rc = batch_prepare_lanes(ctx, L);
+    if (rc) return rc;
+    InFlightReset in_flight_reset{ctx};
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // inputs the caller produced on this context's stream
+    return batch_on_lanes(ctx, L, [&](artgpu_ctx *c, int k) -> int {
+        for (int f = k; f < nframes; f += L) {
+            int rc2 = batch_settle_scratch(c, px_of(f), f + L < nframes ? px_of(f + L) : -1);
+            if (!rc2) rc2 = artgpu_pipeline_run(c, &raws[f], params, &outs[f]);
+            if (rc2) return rc2;
+        }
+        if (k > 0 && hipStreamSynchronize(c->stream) != hipSuccess) return fail(c, ARTGPU_EHIP, "batch_run: lane %d: stream", k);
+        return ARTGPU_OK;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// the batch between the decoder's and the writers' formats, copies beside the kernels
+// ---------------------------------------------------------------------------------------------
+namespace {
+int io_setup(artgpu_ctx *c, int nfr)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    // The copy streams get the LOWEST priority: where the runtime moves a buffer with a kernel (it does for device -> pinned host: 268 MB in
+    // 4.9 ms, every wave of it waiting on PCIe), that kernel's workgroups would otherwise sit in the CUs' wave slots in front of the next
+    // frame's kernels, which then wait for the copy instead of running beside it (measured: scale_colors_kernel 5.8 ms instead of 0.1).
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (!c->io_up) HIPCHK(c, hipStreamCreateWithPriority(&c->io_up, hipStreamNonBlocking, prio_least));
+    if (!c->io_down) HIPCHK(c, hipStreamCreateWithPriority(&c->io_down, hipStreamNonBlocking, prio_least));
+    for (int k = 0; k < 8; ++k)
+        if (!c->io_ev[k]) HIPCHK(c, hipEventCreateWithFlags(&c->io_ev[k], hipEventDisableTiming));
+    if (c->io_host_cap < nfr) {
+        if (c->io_host) { HIPCHK(c, hipHostFree(c->io_host)); c->io_host = nullptr; c->io_host_cap = 0; }
+        const int cap = nfr < 16 ? 16 : nfr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&c->io_host), (size_t)cap * 8 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+            c->io_host = nullptr;
+            return fail(c, ARTGPU_ENOMEM, "batch_run_io: pinned flag words for %d frames", cap);
+        }
+        c->io_host_cap = cap;
+    }
+    std::memset(c->io_host, 0, (size_t)c->io_host_cap * 8 * sizeof(int));
+    return ARTGPU_OK;
+}
+
+// frame `i` of this lane: everything is queued, nothing is waited for (the staging slots of turn i - 2 are released through events)
+int io_frame(artgpu_ctx *c, int i, const artgpu_sensor_frame *in, const artgpu_pipeline_params *p, artgpu_scanline_frame *out)
+{
+    const int s = i & 1, W = in->w, H = in->h, b = p->border;
+    const int esz = in->is_u16 ? 2 : 4;
+    if (!in->data || W <= 0 || H <= 0 || in->row_stride_bytes < (int64_t)W * esz || in->row_stride_bytes % esz)
+        return fail(c, ARTGPU_EINVAL, "batch_run_io: sensor frame: bad pointer/size/stride");
+    if (b < 0 || W - 2 * b < 8 || H - 2 * b < 8) return fail(c, ARTGPU_EINVAL, "batch_run_io: border %d leaves no image", b);
+    const int iw = W - 2 * b, ih = H - 2 * b;
+    const bool okfmt = out->is_float ? (out->bps == 16 || out->bps == 32) : (out->bps == 8 || out->bps == 16);
+    if (!okfmt) return fail(c, ARTGPU_EINVAL, "batch_run_io: bps %d / is_float %d", out->bps, out->is_float);
+    const size_t rowb = (size_t)iw * 3 * (out->bps / 8);
+    if (!out->scanlines || out->row_stride_bytes < (int64_t)rowb) return fail(c, ARTGPU_EINVAL, "batch_run_io: scanlines: bad pointer / row stride < %zu", rowb);
+    if (out->rgb2out_enabled) {
+        if (!out->trc_linear && (!out->trc_lut || out->trc_lutsz < 2)) return fail(c, ARTGPU_EINVAL, "batch_run_io: a non-linear TRC needs its LUT");
+        if (out->trc_lut && (out->trc_lutsz < 2 || out->trc_lutsz > 65536)) return fail(c, ARTGPU_EINVAL, "batch_run_io: trc_lutsz %d", out->trc_lutsz);
+    }
+    int rc;
+    float *cfa, *img[3], *flags_f;
+    if ((rc = pool_get(c, P_IO_CFA, (size_t)W * H * 4, &cfa)) || (rc = pool_get(c, P_IO_FLAGS, 2 * 8 * sizeof(int), &flags_f))) return rc;
+    for (int k = 0; k < 3; ++k)
+        if ((rc = pool_get(c, P_IO_IMG0 + 3 * s + k, (size_t)iw * ih * 4, &img[k]))) return rc;      // (two sets: the download of turn i reads its set while turn i + 1 is computed)
+    int *flags = reinterpret_cast<int *>(flags_f) + 8 * s;
+    // Where do the scanlines go?  Pinned host memory is mapped into the device's address space: a few workgroups on the download stream write
+    // them there directly.  Anything else (pageable memory, rows that are not 16-byte aligned, option io_direct = 0) is staged and copied.
+    // Measured on 8192 x 5464 frames, 16-bit scanlines, pinned memory (scripts/pcie_batch.py): the runtime's device -> host copy is a kernel whose
+    // waves fill every CU while they wait on PCIe -- one lane: 11.6 ms per frame, three lanes: 14.4 (the other lanes' kernels queue up behind
+    // it); 8 workgroups of the direct kernel: 12.6 ms with one lane (they take eight CUs from the persistent one-workgroup-per-CU kernels of the
+    // next frame for 5 ms), 11.8 with two or three.  So: direct with frames in flight on other lanes, the runtime's copy otherwise.
+    const int direct_wgs = c->opt_io_direct >= 0 ? c->opt_io_direct : (c->frames_in_flight > 1 ? 8 : 0);
+    unsigned char *host_dev = nullptr;
+    if (!out->on_device && direct_wgs > 0 && (reinterpret_cast<uintptr_t>(out->scanlines) & 15) == 0 && (out->row_stride_bytes & 15) == 0) {
+        hipPointerAttribute_t at = {};
+        if (hipPointerGetAttributes(&at, out->scanlines) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) host_dev = static_cast<unsigned char *>(at.devicePointer);
+        else (void)hipGetLastError();        // (pageable memory is "invalid value" to the query: not an error of this call)
+    }
+    c->cu_reserve = host_dev ? direct_wgs * (c->frames_in_flight > 1 ? 2 : 1) : 0;      // (this lane's download and a neighbour's; reset when the lane is done)
+    // the working image of this slot is free again once the download of turn i - 2 has read it
+    if (i >= 2 && !out->on_device) HIPCHK(c, hipStreamWaitEvent(c->stream, c->io_ev[6 + s], 0));
+
+    // ---- upload (io_up) -> copyOriginalPixels + scaleColors (stream)
+    ScaleArgs a = {};
+    a.w = W; a.h = H; a.src_u16 = in->is_u16 ? 1 : 0;
+    if (in->on_device) { a.src = in->data; a.src_stride = (size_t)(in->row_stride_bytes / esz); }
+    else {
+        float *st;
+        if ((rc = pool_get(c, P_IO_IN0 + s, (size_t)W * H * esz, &st))) return rc;
+        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->io_up, c->io_ev[2 + s], 0));       // the kernel that read this slot two turns ago
+        // (a contiguous frame travels as ONE linear copy: the copy engines take it, where a pitched copy is a kernel that queues up with the frames' own)
+        if (in->row_stride_bytes == (int64_t)W * esz) HIPCHK(c, hipMemcpyAsync(st, in->data, (size_t)W * esz * H, hipMemcpyHostToDevice, c->io_up));
+        else HIPCHK(c, hipMemcpy2DAsync(st, (size_t)W * esz, in->data, (size_t)in->row_stride_bytes, (size_t)W * esz, H, hipMemcpyHostToDevice, c->io_up));
+        HIPCHK(c, hipEventRecord(c->io_ev[s], c->io_up));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->io_ev[s], 0));
+        a.src = st; a.src_stride = W;
+    }
+    a.dst = cfa; a.dst_stride = W;
+    a.bayer = p->sensor == 0 ? 1 : 0;
+    for (int r = 0; r < 6; ++r)
+        for (int col = 0; col < 6; ++col) {
+            int v;
+            if (p->sensor != 0) v = p->xtrans[r * 6 + col];
+            else v = (p->filters >> ((((r << 1) & 14) + (col & 1)) << 1)) & 3;
+            if (v < 0 || v > 2) return fail(c, ARTGPU_EUNSUPPORTED, "batch_run_io: three-colour CFAs only");
+            a.cfa[r * 6 + col] = v;
+        }
+    for (int k = 0; k < 4; ++k) { a.cblacksom[k] = in->cblacksom[k]; a.scale_mul[k] = in->scale_mul[k]; }
+    a.chmax_bits = flags;
+    HIPCHK(c, hipMemsetAsync(flags, 0, 8 * sizeof(int), c->stream));
+    HIPCHK(c, launch_scale_colors(a, c->stream));
+    if (!in->on_device) HIPCHK(c, hipEventRecord(c->io_ev[2 + s], c->stream));
+
+    // ---- the path
+    artgpu_plane raw = {cfa, W, H, (int64_t)W * 4, 1};
+    artgpu_rgb image;
+    artgpu_plane *ip[3] = {&image.r, &image.g, &image.b};
+    for (int k = 0; k < 3; ++k) { ip[k]->p = img[k]; ip[k]->w = iw; ip[k]->h = ih; ip[k]->row_stride_bytes = (int64_t)iw * 4; ip[k]->on_device = 1; }
+    if ((rc = artgpu_pipeline_run(c, &raw, p, &image))) return rc;
+
+    // ---- rgb2out (matrix + TRC, in place) and the writers' scanlines
+    OutArgs o = {};
+    for (int k = 0; k < 3; ++k) { o.src[k] = img[k]; o.dst[k] = img[k]; }
+    o.src_stride = iw; o.dst_stride = iw; o.w = iw; o.h = ih;
+    if (out->rgb2out_enabled) {
+        for (int k = 0; k < 9; ++k) o.m[k] = out->out_matrix[k];
+        o.linear = out->trc_linear ? 1 : 0;
+        o.unsupported = flags + 4;
+        if (out->trc_lut) {
+            float *tab;
+            if ((rc = pool_get(c, P_PIPE_R, (size_t)65536 * 4, &tab)) || (rc = h2d_table(c, tab, out->trc_lut, (size_t)out->trc_lutsz * 4))) return rc;   // (the demosaiced plane in this slot is done with)
+            o.lut = tab; o.lutsz = out->trc_lutsz;
+        }
+        HIPCHK(c, launch_rgb2out_matrix(o, c->stream));
+    }
+    o.bps = out->bps; o.is_float = out->is_float ? 1 : 0;
+    if (host_dev) {
+        // flags, then the scanlines on the download stream, straight into the caller's buffer
+        HIPCHK(c, hipMemcpyAsync(c->io_host + 8 * i, flags, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipEventRecord(c->io_ev[4 + s], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->io_down, c->io_ev[4 + s], 0));
+        o.out = host_dev; o.out_stride_bytes = (size_t)out->row_stride_bytes;
+        HIPCHK(c, launch_scanlines_host(o, direct_wgs, c->io_down));
+        HIPCHK(c, hipEventRecord(c->io_ev[6 + s], c->io_down));
+        return ARTGPU_OK;
+    }
+    if (out->on_device) { o.out = static_cast<unsigned char *>(out->scanlines); o.out_stride_bytes = (size_t)out->row_stride_bytes; }
+    else {
+        float *st;
+        if ((rc = pool_get(c, P_IO_OUT0 + s, rowb * ih + 16, &st))) return rc;
+        o.out = reinterpret_cast<unsigned char *>(st); o.out_stride_bytes = rowb;         // (free again: the wait for turn i - 2's download above)
+    }
+    HIPCHK(c, launch_scanlines(o, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->io_host + 8 * i, flags, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (!out->on_device) {
+        HIPCHK(c, hipEventRecord(c->io_ev[4 + s], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->io_down, c->io_ev[4 + s], 0));
+        if (out->row_stride_bytes == (int64_t)rowb) HIPCHK(c, hipMemcpyAsync(out->scanlines, o.out, rowb * ih, hipMemcpyDeviceToHost, c->io_down));
+        else HIPCHK(c, hipMemcpy2DAsync(out->scanlines, (size_t)out->row_stride_bytes, o.out, rowb, rowb, ih, hipMemcpyDeviceToHost, c->io_down));
+        HIPCHK(c, hipEventRecord(c->io_ev[6 + s], c->io_down));
+    }
+    return ARTGPU_OK;
+}
+} // namespace
+
+int artgpu_batch_run_io(artgpu_ctx *ctx, int nframes, const artgpu_sensor_frame *in, const artgpu_pipeline_params *params, artgpu_scanline_frame *out)
+{
+    if (!ctx) return ARTGPU_EINVAL;
+    if (nframes < 0 || (nframes && (!in || !params || !out))) return fail(ctx, ARTGPU_EINVAL, "batch_run_io: null argument");
+    if (nframes == 0) return ARTGPU_OK;
+    const int L = std::min(ctx->batch_lanes, nframes);
+    int rc = batch_prepare_lanes(ctx, L);          // (L == 1: no lanes, frames_in_flight = 1)
+    if (rc) return rc;
+    InFlightReset in_flight_reset{ctx};
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // inputs the caller produced on this context's stream
+    auto px_of = [&](int f) { return (long long)in[f].w * in[f].h; };
+    for (int f = 0; f < nframes; ++f) { out[f].status = ARTGPU_OK; out[f].chmax[0] = out[f].chmax[1] = out[f].chmax[2] = out[f].chmax[3] = 0.f; }
+    rc = batch_on_lanes(ctx, L, [&](artgpu_ctx *c, int k) -> int {
+        const int mine = (nframes - k + L - 1) / L;
+        int rc2 = io_setup(c, mine);
+        for (int f = k, i = 0; !rc2 && f < nframes; f += L, ++i) {
+            rc2 = batch_settle_scratch(c, px_of(f), f + L < nframes ? px_of(f + L) : -1);
+            if (!rc2) rc2 = io_frame(c, i, &in[f], params, &out[f]);
+        }
+        // the lane's copies and kernels, then what the frames left in the pinned words
+        c->cu_reserve = 0;
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (c->io_down) { const hipError_t e2 = hipStreamSynchronize(c->io_down); if (e == hipSuccess) e = e2; }
+        if (c->io_up) { const hipError_t e2 = hipStreamSynchronize(c->io_up); if (e == hipSuccess) e = e2; }
+        if (rc2) return rc2;
+        if (e != hipSuccess) return fail(c, ARTGPU_EHIP, "batch_run_io: lane %d: %s", k, hipGetErrorString(e));
+        if ((rc2 = check_async_faults(c))) return rc2;
+        for (int f = k, i = 0; f < nframes; f += L, ++i) {
+            const int *w = c->io_host + 8 * i;
+            for (int ch = 0; ch < 3; ++ch) std::memcpy(&out[f].chmax[ch], &w[ch], sizeof(float));
+            out[f].chmax[3] = out[f].chmax[1];
+            if (out[f].rgb2out_enabled && w[4]) {
+                out[f].status = ARTGPU_EUNSUPPORTED;
+                if (!rc2) rc2 = fail(c, ARTGPU_EUNSUPPORTED, "batch_run_io: frame %d: %d channel values above 1 need ARTOutputProfile::eval (lcms2/libm) on the host", f, w[4]);
+            }
+        }
+        return rc2;
+    });
+    return rc;
 }
 
 // The one collective of a multi-GPU batch: an all-gather of the ranks' completion records over the caller's RCCL communicator.

@@ -917,6 +917,7 @@ static bool dn_lds_shape(const DnPixArgs &a, const float *lut, int *cus)
     int dev = 0;
     *cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (a.cu_reserve > 0) *cus = *cus - a.cu_reserve > 1 ? *cus - a.cu_reserve : 1;
     return true;
 }
 hipError_t launch_rgb2yuv(const DnPixArgs &a, hipStream_t s)
@@ -1106,6 +1107,7 @@ hipError_t launch_chroma_map(const ChromaMapArgs &a, hipStream_t s)
         if (e != hipSuccess) return e;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (a.cu_reserve > 0) cus = cus - a.cu_reserve > 1 ? cus - a.cu_reserve : 1;
         hipLaunchKernelGGL(chroma_map_lds_kernel, dim3(cus < a.hei ? cus : a.hei), dim3(1024), lds, s, a);
         return hipGetLastError();
     }

@@ -189,6 +189,8 @@ struct PixArgs {
     double tail_y;
     ParamCurve tail_pc;    // kind 4 (artgpu_set_curve_tail_parametric)
     int no_lds_lut;        // artgpu_set_option "lut_lds" 0: the plain one-lane-per-pixel kernels (table lookups served by L2) on every frame size
+    int cu_reserve;        // CUs a kernel running BESIDE this frame's holds (artgpu_batch_run_io's download): the persistent one-workgroup-per-CU shape, which shares
+                           // no CU with anything, launches that many workgroups fewer -- a workgroup without a CU would start when that kernel ends, 5 ms later
 };
 hipError_t launch_get_image_convert(const PixArgs &a, hipStream_t s);
 hipError_t launch_exposure(const PixArgs &a, hipStream_t s);
@@ -309,6 +311,9 @@ struct OutArgs {
 };
 hipError_t launch_rgb2out_matrix(const OutArgs &a, hipStream_t s);
 hipError_t launch_scanlines(const OutArgs &a, hipStream_t s);
+// the scanlines written by a few persistent workgroups straight into mapped (pinned) host memory: `a.out` = its device address
+bool scanlines_host_ok(const OutArgs &a);
+hipError_t launch_scanlines_host(const OutArgs &a, int workgroups, hipStream_t s);
 // saturationVibrance (ipsaturation.cc:43-83)
 struct SatArgs { float *dst[3]; size_t stride; int w, h; float saturation, vibrance; int vib; double ws1[3]; };
 hipError_t launch_saturation_vibrance(const SatArgs &a, hipStream_t s);
@@ -324,6 +329,7 @@ struct NeutralArgs {
     double tail_y;
     ParamCurve tail_pc;
     int no_lds_lut;              // as in PixArgs
+    int cu_reserve;              // as in PixArgs
 };
 hipError_t launch_neutral_hues(const NeutralArgs &a, hipStream_t s);
 hipError_t launch_tone_neutral(const NeutralArgs &a, hipStream_t s);
@@ -380,6 +386,7 @@ struct DnPixArgs {
     float wpi[9], iws[9];          // LAB: working space <-> XYZ, float casts
     const float *cachef, *cachefy, *dn_gamma, *dn_igamma;   // LAB: 65536-entry LUTs
     int no_lds_lut;                // artgpu_set_option "lut_lds" 0
+    int cu_reserve;                // as in PixArgs
 };
 // chroma noise-curve map (ipdenoise.cc:1113-1131 + FTblockDN.cc:1716-1777)
 struct ChromaMapArgs {
@@ -392,6 +399,7 @@ struct ChromaMapArgs {
     const float *curve;                   // 501-entry NoiseCurve LUT (device)
     float *out;                           // wid x hei
     int no_lds_lut;                       // artgpu_set_option "lut_lds" 0
+    int cu_reserve;                       // as in PixArgs
 };
 hipError_t launch_chroma_map(const ChromaMapArgs &a, hipStream_t s);
 bool flat_curve_sample(const double *pts, int npts, bool periodic, int ppn, double identity, int nout, double *out);

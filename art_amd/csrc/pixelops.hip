@@ -353,6 +353,12 @@ __device__ __forceinline__ unsigned short float_to_half_dng(float f)
     return (unsigned short)(sign | (exponent << 10) | (mantissa >> 13));
 }
 // Imagefloat::getScanline for every row (imagefloat.cc:125-170): interleaved RGB, 8/16-bit integer, half or float
+__device__ __forceinline__ unsigned scan_elem(float v, int bps, int is_float)
+{
+    if (is_float) return bps == 32 ? __float_as_uint(v / 65535.f) : (unsigned)float_to_half_dng(v / 65535.f);
+    const unsigned short q = (unsigned short)clipf(v);                       // CLIP, then the implicit float -> uint16 conversion
+    return bps == 16 ? (unsigned)q : (unsigned)(unsigned char)((((int)q + 128) - (((int)q + 128) >> 8)) >> 8);     // uint16ToUint8Rounded
+}
 __global__ void __launch_bounds__(256) scanlines_kernel(OutArgs a)
 {
     FOR_IMAGE_XY(y, x, a.w, a.h) {
@@ -360,16 +366,72 @@ __global__ void __launch_bounds__(256) scanlines_kernel(OutArgs a)
         unsigned char *row = a.out + (size_t)y * a.out_stride_bytes;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float v = a.src[c][si];
-            if (a.is_float) {
-                if (a.bps == 32) reinterpret_cast<float *>(row)[3 * x + c] = v / 65535.f;
-                else reinterpret_cast<unsigned short *>(row)[3 * x + c] = float_to_half_dng(v / 65535.f);
-            } else {
-                const unsigned short q = (unsigned short)clipf(v);                       // CLIP, then the implicit float -> uint16 conversion
-                if (a.bps == 16) reinterpret_cast<unsigned short *>(row)[3 * x + c] = q;
-                else row[3 * x + c] = (unsigned char)((((int)q + 128) - (((int)q + 128) >> 8)) >> 8);     // uint16ToUint8Rounded
+            const unsigned e = scan_elem(a.src[c][si], a.bps, a.is_float);
+            if (a.bps == 32) reinterpret_cast<unsigned *>(row)[3 * x + c] = e;
+            else if (a.bps == 16) reinterpret_cast<unsigned short *>(row)[3 * x + c] = (unsigned short)e;
+            else row[3 * x + c] = (unsigned char)e;
+        }
+    }
+}
+// The same scanlines written straight into the caller's pinned host buffer (artgpu_batch_run_io): a FEW persistent workgroups, each turning
+// 2048 pixels of a row into the writers' bytes in LDS and sending them off as 16-byte pieces, 1 KB contiguous per wave and store -- the
+// stores are posted, so a workgroup goes on with its next chunk while they cross PCIe.  With a grid of a few workgroups the download
+// takes the time PCIe takes (268 MB of 16-bit scanlines in ~5 ms) on a few CUs, beside the next frame's kernels; the runtime's own
+// device -> host copy is a kernel too, but one that fills every CU's wave slots with waves waiting on PCIe.
+// Rows and the buffer are 16-byte aligned (the launcher checks); the last piece of a row is written byte by byte.
+constexpr int SCAN_T = 1024, SCAN_CHUNK = 2 * SCAN_T;
+typedef unsigned scan_u4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(SCAN_T) scanlines_host_kernel(OutArgs a)
+{
+    // two chunk buffers: the barrier between converting a chunk and sending it off orders LDS traffic only (a __syncthreads() would also wait
+    // for the previous chunk's stores to come back across PCIe), and the planes' values of the NEXT chunk are fetched before this one is
+    // sent off, so that a workgroup's time per chunk is not a memory round trip plus a PCIe round trip
+    __shared__ __attribute__((aligned(16))) unsigned char bufs[2][SCAN_CHUNK * 3 * 4];
+    const int esz = a.bps / 8, cpr = (a.w + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    const long long nchunks = (long long)cpr * a.h;
+    const int tid = threadIdx.x;
+    float v[2][3];
+    auto fetch = [&](long long ch) {
+        const int y = (int)(ch / cpr), x0 = (int)(ch - (long long)y * cpr) * SCAN_CHUNK;
+        const int npx = min(SCAN_CHUNK, a.w - x0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int xl = min(tid + SCAN_T * q, npx - 1);
+            const size_t si = (size_t)y * a.src_stride + x0 + xl;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[q][c] = a.src[c][si];
+        }
+    };
+    if ((long long)blockIdx.x < nchunks) fetch(blockIdx.x);
+    int par = 0;
+    for (long long ch = blockIdx.x; ch < nchunks; ch += gridDim.x, par ^= 1) {
+        unsigned char *buf = bufs[par];
+        const int y = (int)(ch / cpr), x0 = (int)(ch - (long long)y * cpr) * SCAN_CHUNK;
+        const int npx = min(SCAN_CHUNK, a.w - x0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int xl = tid + SCAN_T * q;
+            if (xl >= npx) break;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned e = scan_elem(v[q][c], a.bps, a.is_float);
+                if (a.bps == 32) reinterpret_cast<unsigned *>(buf)[3 * xl + c] = e;
+                else if (a.bps == 16) reinterpret_cast<unsigned short *>(buf)[3 * xl + c] = (unsigned short)e;
+                else buf[3 * xl + c] = (unsigned char)e;
             }
         }
+        if (ch + gridDim.x < nchunks) fetch(ch + gridDim.x);
+        // (one barrier per chunk is enough with two buffers: a thread that is a chunk ahead writes the OTHER buffer, and it cannot be two
+        // chunks ahead without having passed the barrier of the chunk in between, which every reader of this buffer's previous contents
+        // reaches only after its reads)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        unsigned char *dst = a.out + (size_t)y * a.out_stride_bytes + (size_t)x0 * 3 * esz;
+        const int nbytes = npx * 3 * esz, whole = nbytes & ~15;
+        for (int o = tid * 16; o < whole; o += SCAN_T * 16)
+            *reinterpret_cast<scan_u4 *>(dst + o) = *reinterpret_cast<const scan_u4 *>(buf + o);
+        if (tid < nbytes - whole) dst[whole + tid] = buf[whole + tid];
     }
 }
 hipError_t launch_rgb2out_matrix(const OutArgs &a, hipStream_t s)
@@ -380,6 +442,14 @@ hipError_t launch_rgb2out_matrix(const OutArgs &a, hipStream_t s)
 hipError_t launch_scanlines(const OutArgs &a, hipStream_t s)
 {
     hipLaunchKernelGGL(scanlines_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+bool scanlines_host_ok(const OutArgs &a) { return (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && (a.out_stride_bytes & 15) == 0; }
+hipError_t launch_scanlines_host(const OutArgs &a, int workgroups, hipStream_t s)
+{
+    const long long nchunks = (long long)((a.w + SCAN_CHUNK - 1) / SCAN_CHUNK) * a.h;
+    const int g = (int)(nchunks < workgroups ? (nchunks ? nchunks : 1) : (workgroups < 1 ? 1 : workgroups));
+    hipLaunchKernelGGL(scanlines_host_kernel, dim3(g), dim3(SCAN_T), 0, s, a);
     return hipGetLastError();
 }
 
@@ -396,10 +466,11 @@ hipError_t launch_rgb_curves(const MixArgs &a, hipStream_t s)
 }
 hipError_t launch_scale_colors(const ScaleArgs &a, hipStream_t s)
 {
-    const long long n = (long long)a.w * a.h;
-    long long g = (n + 255) / 256;
-    (void)g;
-    hipLaunchKernelGGL(scale_colors_kernel, image_grid(a.w, a.h), dim3(256), 0, s, a);
+    // a bounded grid: every workgroup ends with three atomic maxima on the same three words, and one workgroup per row segment of a 45 MP frame
+    // (350 000 of them) spent 2.2 ms queueing up for those words; 256 rows of workgroups walk the frame instead (~0.1 ms)
+    dim3 g = image_grid(a.w, a.h);
+    if (g.y > 256) g.y = 256;
+    hipLaunchKernelGGL(scale_colors_kernel, g, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_yuv_mode(const PixArgs &a, hipStream_t s)
@@ -417,6 +488,7 @@ hipError_t launch_tone_std(const PixArgs &a, hipStream_t s)
         if (e != hipSuccess) return e;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (a.cu_reserve > 0) cus = cus - a.cu_reserve > 1 ? cus - a.cu_reserve : 1;
         if (pc) hipLaunchKernelGGL(tone_std_lds_kernel<true>, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
         else hipLaunchKernelGGL(tone_std_lds_kernel<false>, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
         return hipGetLastError();

@@ -260,6 +260,7 @@ hipError_t launch_tone_neutral(const NeutralArgs &a, hipStream_t s)
         if (e != hipSuccess) return e;
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (a.cu_reserve > 0) cus = cus - a.cu_reserve > 1 ? cus - a.cu_reserve : 1;
         if (pc) hipLaunchKernelGGL(tone_neutral_lds_kernel<true>, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
         else hipLaunchKernelGGL(tone_neutral_lds_kernel<false>, dim3(cus < a.h ? cus : a.h), dim3(1024), lds, s, a);
         return hipGetLastError();

@@ -662,6 +662,47 @@ def main() -> None:
         in_flight(ctx, False)
         del ln2
 
+    # The boundary can also take HOST buffers.  The PCIe-inclusive rate of the same frame -- never `value` -- through artgpu_batch_run_io:
+    # uint16 sensor data up (scaleColors on the device), 16-bit scanlines down (rgb2out's matrix path + getScanline), pinned memory, a frame's
+    # copies on streams of their own beside its neighbours' kernels (scripts/pcie_batch.py has the other forms)
+    if pipeline and not xtrans and world == 1 and args.lanes == 1 and args.tone == "std" and args.sustained_seconds > 0 and not smoothing:
+        try:
+            import ctypes as C_
+            pp = capi.PipelineParams()
+            pp.sensor = 0; pp.bayer_method = method; pp.filters = filt; pp.initial_gain = 1.0; pp.xtrans_passes = 3; pp.border = border
+            pp.mul[:] = mul; pp.do_clip = 1; pp.has_cam_to_work = 1
+            pp.cam_to_work[:] = [float(v) for v in mat.reshape(9)]
+            pp.ws[:] = [float(v) for v in ws.reshape(9)]; pp.iws[:] = [float(v) for v in iws_n.reshape(9)]
+            pp.denoise_enabled = 1; pp.denoise = dn
+            pp.exposure_enabled = 1; pp.expcomp = expcomp; pp.black = 0.0
+            pp.tone_enabled = 1; pp.tone_mode = 0
+            pp.tone_lut = lut.ctypes.data_as(C_.POINTER(C_.c_float)); pp.white_point = 1.0
+            pp.to_out[:] = [1, 0, 0, 0, 1, 0, 0, 0, 1]; pp.to_work[:] = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+            pp.scale = 1.0
+            nio = 8
+            raw16 = torch.from_numpy(np.clip(raw, 0, 65535).astype(np.uint16).view(np.int16)).pin_memory()
+            scans = [torch.empty((ih, iw, 3), dtype=torch.int16).pin_memory() for _ in range(nio)]
+            ins = [capi.sensor_frame(raw16.numpy().view(np.uint16)) for _ in range(nio)]
+            outs = [capi.scanline_frame(t_.numpy().view(np.uint16), np.eye(3, dtype=np.float32)) for t_ in scans]
+            legs = {}
+            for nl in (1, 2):
+                ctx.set_batch_lanes(nl)
+                ctx.batch_run_io(ins[:2 * nl], pp, outs[:2 * nl])
+                h0 = time.perf_counter()
+                ctx.batch_run_io(ins, pp, outs)
+                h_ms = 1e3 * (time.perf_counter() - h0) / nio
+                legs[f"lanes{nl}"] = {"ms_per_frame": round(h_ms, 3), "value": round(mp / (h_ms / 1e3), 1)}
+            ctx.set_batch_lanes(1)
+            result["host_buffers"] = {"unit": "MP/s", "frames": nio, "bytes_per_px": {"up": 2, "down": 6}, "host_memory": "pinned", **legs,
+                                      "note": "PCIe-inclusive, artgpu_batch_run_io (uint16 sensor data in, 16-bit scanlines out); not the reported value"}
+            del raw16, scans, ins, outs
+        except Exception as e:      # noqa: BLE001  (a leg beside the line, never a reason to lose the line)
+            result["host_buffers"] = {"error": repr(e)[:200]}
+            try:
+                ctx.set_batch_lanes(1)
+            except Exception:      # noqa: BLE001
+                pass
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_lib
         ncores = os.cpu_count() or 1

@@ -89,7 +89,10 @@ int artgpu_synchronize(artgpu_ctx *ctx);
  *                       to happen between them; 2: one launch per channel; 0: the three-kernel form (factors, row sums, column sums + update)
  *   "dn_streams"        0 (default since round 5): RGB_denoise's kernels one after the other on the context's stream; 1: the DCT detail recovery of L on a
  *                       side stream beside the reconstructions of a and b (the default of rounds 3 and 4); "lut_lds" 0: never the LUT-in-LDS shape
- *                       of the pixel passes; "rcd_rows" 4 | 8; "roctx" 1: roctx ranges named after the reference functions */
+ *                       of the pixel passes; "rcd_rows" 4 | 8; "roctx" 1: roctx ranges named after the reference functions
+ *   "io_direct"         artgpu_batch_run_io, scanlines that go to PINNED host memory: n > 0: n persistent workgroups on the download stream write
+ *                       them there directly (no staging plane, no copy); 0: staged on the device and copied by the runtime; -1 (default): 8 with
+ *                       several lanes, 0 with one */
 int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value);
 /* read-only counterparts: "amaze_counter0" .. "amaze_counter7" = bookkeeping of the last AMaZE call (how many tiles were streamed a
  * second time, handed to the arena kernel, ...); synchronises the context's stream */
@@ -532,6 +535,45 @@ int artgpu_batch_run(artgpu_ctx *ctx, int nframes, const artgpu_plane *raws, con
  * context keeps lanes-1 sibling contexts (own stream, work arenas and host thread); frame f runs on lane f % lanes, the results are
  * the same bits.  On return the secondary lanes have completed; lane 0 stays ordered on the context's stream as before. */
 int artgpu_set_batch_lanes(artgpu_ctx *ctx, int lanes);
+
+/* A batch whose frames arrive as the decoder delivers them and leave as the writers take them -- the data formats either side of the
+ * path, so that 2 + 6 (or 2 + 3) bytes per pixel cross PCIe instead of 4 + 12:
+ *   in : uint16 (or float) sensor data + the black levels / multipliers of RawImageSource::scaleColors (rawimagesource.cc:2677-2859,
+ *        artgpu_scale_colors); the frame's channel maxima come back in `chmax`;
+ *   out: ARTOutputProfile's matrix + TRC fast path of ImProcFunctions::rgb2out (iprgb2out.cc:94-172,452-461, artgpu_rgb2out_matrix;
+ *        rgb2out_enabled = 0: the working-space image as it is) followed by Imagefloat::getScanline for every row
+ *        (imagefloat.cc:125-170, artgpu_get_scanlines: (bps, is_float) = (8,0), (16,0), (16,1), (32,1)).
+ * Between the two: artgpu_pipeline_run's stages with `params` (params->border trims the scanlines like getImage does).
+ * The call is built for host buffers: every lane (artgpu_set_batch_lanes) keeps a frame's upload, its kernels and its download on three
+ * streams with two staging slots each, so the upload of frame f + 1 and the download of frame f - 1 run beside the kernels of frame f and
+ * the host thread never waits for a copy before the batch ends.  Pinned host memory (hipHostMalloc / hipHostRegister) is what makes the
+ * copies asynchronous; pageable memory works and is staged by the runtime, one blocking copy at a time.  Device pointers (on_device != 0)
+ * skip the corresponding copy.  `status` of a frame: ARTGPU_OK, or ARTGPU_EUNSUPPORTED when rgb2out met values above 1 with a
+ * non-linear TRC (artgpu_rgb2out_matrix's rule; the scanlines are complete for every other pixel); the call returns the first
+ * non-zero status.  Same bits as artgpu_scale_colors -> artgpu_pipeline_run -> artgpu_rgb2out_matrix -> artgpu_get_scanlines. */
+typedef struct {
+    const void *data;               /* sensor values, row-major */
+    int32_t w, h;
+    int64_t row_stride_bytes;
+    int32_t is_u16;                 /* 1: uint16_t, 0: float */
+    int32_t on_device;
+    float cblacksom[4], scale_mul[4];
+} artgpu_sensor_frame;
+typedef struct {
+    void *scanlines;                /* (h - 2 border) rows of (w - 2 border) interleaved RGB pixels */
+    int64_t row_stride_bytes;
+    int32_t bps, is_float;
+    int32_t on_device;
+    int32_t rgb2out_enabled;
+    float out_matrix[9];
+    int32_t trc_linear;
+    const float *trc_lut;           /* host, trc_lutsz entries (NULL with trc_linear) */
+    int32_t trc_lutsz;
+    float chmax[4];                 /* out: scaleColors' channel maxima (chmax[3] = chmax[1]) */
+    int32_t status;                 /* out */
+} artgpu_scanline_frame;
+int artgpu_batch_run_io(artgpu_ctx *ctx, int nframes, const artgpu_sensor_frame *in, const artgpu_pipeline_params *params,
+                        artgpu_scanline_frame *out);
 
 /* The completion step of a multi-GPU batch -- the only collective of the path (frames are independent; the reference's loop
  * simply finishes, simpleprocess.cc:591-611): every rank contributes one 64-byte record (by convention of art_amd/batch.py: rank,
