@@ -64,7 +64,7 @@ struct artgpu_ctx {
     int io_host_cap = 0;
     int cu_reserve = 0;            // set around a batch whose downloads run as a kernel of a few workgroups: the persistent one-workgroup-per-CU pixel passes leave those CUs alone
     int opt_io_direct = -1;        // artgpu_batch_run_io, scanlines into pinned host memory: n > 0: written there by n persistent workgroups (no staging, no copy); 0: staged +
-                                   // hipMemcpy; -1 (default): 8 workgroups with several lanes, the runtime's copy with one (io_frame has the measurements)
+                                   // hipMemcpy; -1 (default) = 0 (io_frame has the measurements)
     float fuse_pre = 0.f, fuse_post = 0.f;   // improc_denoise -> rgb_denoise: exposure compensation fused into rgb2yuv / yuv2rgb
     GetImageFuse fuse_gi = {};               // improc_denoise_fused -> chroma map, rgb2yuv: getImage + matrix read from the demosaiced planes
     float fuse_exp_scale = 0.f, fuse_exp_black = 0.f;   // improc_denoise_fused -> yuv2rgb: ImProcFunctions::exposure behind the last pass
@@ -3143,13 +3143,8 @@ namespace {
 int io_setup(artgpu_ctx *c, int nfr)
 {
     HIPCHK(c, hipSetDevice(c->device));
-    // The copy streams get the LOWEST priority: where the runtime moves a buffer with a kernel (it does for device -> pinned host: 268 MB in
-    // 4.9 ms, every wave of it waiting on PCIe), that kernel's workgroups would otherwise sit in the CUs' wave slots in front of the next
-    // frame's kernels, which then wait for the copy instead of running beside it (measured: scale_colors_kernel 5.8 ms instead of 0.1).
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (!c->io_up) HIPCHK(c, hipStreamCreateWithPriority(&c->io_up, hipStreamNonBlocking, prio_least));
-    if (!c->io_down) HIPCHK(c, hipStreamCreateWithPriority(&c->io_down, hipStreamNonBlocking, prio_least));
+    if (!c->io_up) HIPCHK(c, hipStreamCreateWithFlags(&c->io_up, hipStreamNonBlocking));
+    if (!c->io_down) HIPCHK(c, hipStreamCreateWithFlags(&c->io_down, hipStreamNonBlocking));
     for (int k = 0; k < 8; ++k)
         if (!c->io_ev[k]) HIPCHK(c, hipEventCreateWithFlags(&c->io_ev[k], hipEventDisableTiming));
     if (c->io_host_cap < nfr) {
@@ -3163,6 +3158,15 @@ int io_setup(artgpu_ctx *c, int nfr)
     }
     std::memset(c->io_host, 0, (size_t)c->io_host_cap * 8 * sizeof(int));
     return ARTGPU_OK;
+}
+
+// pinned (hipHostMalloc / hipHostRegister) host memory?  Its device address if so.  Pageable memory is "invalid value" to the query: not an error here.
+void *pinned_device_address(const void *p)
+{
+    hipPointerAttribute_t at = {};
+    if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) return at.devicePointer;
+    (void)hipGetLastError();
+    return nullptr;
 }
 
 // frame `i` of this lane: everything is queued, nothing is waited for (the staging slots of turn i - 2 are released through events)
@@ -3190,17 +3194,18 @@ int io_frame(artgpu_ctx *c, int i, const artgpu_sensor_frame *in, const artgpu_p
     int *flags = reinterpret_cast<int *>(flags_f) + 8 * s;
     // Where do the scanlines go?  Pinned host memory is mapped into the device's address space: a few workgroups on the download stream write
     // them there directly.  Anything else (pageable memory, rows that are not 16-byte aligned, option io_direct = 0) is staged and copied.
-    // Measured on 8192 x 5464 frames, 16-bit scanlines, pinned memory (scripts/pcie_batch.py): the runtime's device -> host copy is a kernel whose
-    // waves fill every CU while they wait on PCIe -- one lane: 11.6 ms per frame, three lanes: 14.4 (the other lanes' kernels queue up behind
-    // it); 8 workgroups of the direct kernel: 12.6 ms with one lane (they take eight CUs from the persistent one-workgroup-per-CU kernels of the
-    // next frame for 5 ms), 11.8 with two or three.  So: direct with frames in flight on other lanes, the runtime's copy otherwise.
-    const int direct_wgs = c->opt_io_direct >= 0 ? c->opt_io_direct : (c->frames_in_flight > 1 ? 8 : 0);
+    // Scanlines for PINNED memory can be written there by a kernel of the download stream (option io_direct = n workgroups) instead of being staged and
+    // copied.  Measured on 8192 x 5464 frames, 16-bit scanlines (scripts/pcie_batch.py, 24 frames): the runtime's copy -- itself a kernel, 268 MB in
+    // 4.9 ms -- 11.0 / 10.6 / 11.3 ms per frame with one / two / three lanes; eight workgroups writing directly 11.0 - 12.6 / 11.4 / 12.6 (they hold eight
+    // CUs for 5 ms, and the one-workgroup-per-CU kernels of the next frame wait for a CU or run on fewer: cu_reserve).  So the copy is the default.
+    const int direct_wgs = c->opt_io_direct > 0 ? c->opt_io_direct : 0;
+    // A copy from / to PAGEABLE memory blocks the calling thread until it is done (the runtime stages it in pieces): nothing is gained by giving it a
+    // stream of its own, so it stays on the context's stream like the copies of the four separate entry points; lanes still overlap each other.
+    unsigned char *const out_pinned = out->on_device ? nullptr : static_cast<unsigned char *>(pinned_device_address(out->scanlines));
+    const hipStream_t s_up = (in->on_device || pinned_device_address(in->data)) ? c->io_up : c->stream;
+    const hipStream_t s_down = out_pinned ? c->io_down : c->stream;
     unsigned char *host_dev = nullptr;
-    if (!out->on_device && direct_wgs > 0 && (reinterpret_cast<uintptr_t>(out->scanlines) & 15) == 0 && (out->row_stride_bytes & 15) == 0) {
-        hipPointerAttribute_t at = {};
-        if (hipPointerGetAttributes(&at, out->scanlines) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) host_dev = static_cast<unsigned char *>(at.devicePointer);
-        else (void)hipGetLastError();        // (pageable memory is "invalid value" to the query: not an error of this call)
-    }
+    if (out_pinned && direct_wgs > 0 && (reinterpret_cast<uintptr_t>(out->scanlines) & 15) == 0 && (out->row_stride_bytes & 15) == 0) host_dev = out_pinned;
     c->cu_reserve = host_dev ? direct_wgs * (c->frames_in_flight > 1 ? 2 : 1) : 0;      // (this lane's download and a neighbour's; reset when the lane is done)
     // the working image of this slot is free again once the download of turn i - 2 has read it
     if (i >= 2 && !out->on_device) HIPCHK(c, hipStreamWaitEvent(c->stream, c->io_ev[6 + s], 0));
@@ -3212,11 +3217,10 @@ int io_frame(artgpu_ctx *c, int i, const artgpu_sensor_frame *in, const artgpu_p
     else {
         float *st;
         if ((rc = pool_get(c, P_IO_IN0 + s, (size_t)W * H * esz, &st))) return rc;
-        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(c->io_up, c->io_ev[2 + s], 0));       // the kernel that read this slot two turns ago
-        // (a contiguous frame travels as ONE linear copy: the copy engines take it, where a pitched copy is a kernel that queues up with the frames' own)
-        if (in->row_stride_bytes == (int64_t)W * esz) HIPCHK(c, hipMemcpyAsync(st, in->data, (size_t)W * esz * H, hipMemcpyHostToDevice, c->io_up));
-        else HIPCHK(c, hipMemcpy2DAsync(st, (size_t)W * esz, in->data, (size_t)in->row_stride_bytes, (size_t)W * esz, H, hipMemcpyHostToDevice, c->io_up));
-        HIPCHK(c, hipEventRecord(c->io_ev[s], c->io_up));
+        if (i >= 2) HIPCHK(c, hipStreamWaitEvent(s_up, c->io_ev[2 + s], 0));       // the kernel that read this slot two turns ago
+        // (always the pitched form: a LINEAR copy from or to pageable memory makes the runtime pin the caller's pages for the occasion, 25 ms for a frame's scanlines)
+        HIPCHK(c, hipMemcpy2DAsync(st, (size_t)W * esz, in->data, (size_t)in->row_stride_bytes, (size_t)W * esz, H, hipMemcpyHostToDevice, s_up));
+        HIPCHK(c, hipEventRecord(c->io_ev[s], s_up));
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->io_ev[s], 0));
         a.src = st; a.src_stride = W;
     }
@@ -3279,10 +3283,9 @@ int io_frame(artgpu_ctx *c, int i, const artgpu_sensor_frame *in, const artgpu_p
     HIPCHK(c, hipMemcpyAsync(c->io_host + 8 * i, flags, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (!out->on_device) {
         HIPCHK(c, hipEventRecord(c->io_ev[4 + s], c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->io_down, c->io_ev[4 + s], 0));
-        if (out->row_stride_bytes == (int64_t)rowb) HIPCHK(c, hipMemcpyAsync(out->scanlines, o.out, rowb * ih, hipMemcpyDeviceToHost, c->io_down));
-        else HIPCHK(c, hipMemcpy2DAsync(out->scanlines, (size_t)out->row_stride_bytes, o.out, rowb, rowb, ih, hipMemcpyDeviceToHost, c->io_down));
-        HIPCHK(c, hipEventRecord(c->io_ev[6 + s], c->io_down));
+        HIPCHK(c, hipStreamWaitEvent(s_down, c->io_ev[4 + s], 0));
+        HIPCHK(c, hipMemcpy2DAsync(out->scanlines, (size_t)out->row_stride_bytes, o.out, rowb, rowb, ih, hipMemcpyDeviceToHost, s_down));
+        HIPCHK(c, hipEventRecord(c->io_ev[6 + s], s_down));
     }
     return ARTGPU_OK;
 }
