@@ -233,6 +233,7 @@ PRIM_XDIV2F = 19
 PRIM_XDIVF2 = 20
 PRIM_XLOG_D = 21
 PRIM_XEXP_D = 22
+PRIM_FLOAT_TO_HALF = 23     # out: float32-sized words, the half in the low 16 bits (eval_primitive returns them as uint32)
 
 EXPORTS = ["artgpu_eval_primitive", "artgpu_set_progress_callback", "artgpu_set_option", "artgpu_get_option", "artgpu_set_curve_tail", "artgpu_set_curve_tail_parametric", "artgpu_create", "artgpu_destroy", "artgpu_last_error", "artgpu_version", "artgpu_set_stream",
            "artgpu_synchronize", "artgpu_enable_timing", "artgpu_get_timings", "artgpu_scratch_bytes", "artgpu_trim_scratch",
@@ -430,6 +431,8 @@ class Context:
         self._chk(LIB.artgpu_eval_primitive(self._h, int(prim), ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(out0), ptr(out1), C.c_int64(n),
                                             C.c_float(param), None if tab is None else tab.ctypes.data_as(C.POINTER(C.c_float)),
                                             0 if tab is None else tab.size))
+        if prim == PRIM_FLOAT_TO_HALF:
+            return out0.view(np.uint32)
         return (out0, out1) if prim == PRIM_XSINCOSF else out0
 
     def saturation_vibrance(self, image: RGB, saturation: int, vibrance: int, ws):

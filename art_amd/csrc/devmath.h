@@ -61,6 +61,29 @@ __device__ __forceinline__ int ngroups(int start, int bound, int step)
     return bound > start ? (bound - start + step - 1) / step : 0;
 }
 
+// DNG_FloatToHalf (halffloat.h:9-46)
+__device__ __forceinline__ unsigned short float_to_half_dng(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    const int sign = (u >> 16) & 0x8000;
+    int exponent = (int)((u >> 23) & 0xff) - (127 - 15);
+    int mantissa = u & 0x007fffff;
+    if (exponent <= 0) {
+        if (exponent < -10) return (unsigned short)sign;
+        mantissa = (mantissa | 0x00800000) >> (1 - exponent);
+        if (mantissa & 0x00001000) mantissa += 0x00002000;
+        return (unsigned short)(sign | (mantissa >> 13));
+    } else if (exponent == 0xff - (127 - 15)) {
+        return (unsigned short)(mantissa == 0 ? (sign | 0x7c00) : (sign | 0x7c00 | (mantissa >> 13)));
+    }
+    if (mantissa & 0x00001000) {
+        mantissa += 0x00002000;
+        if (mantissa & 0x00800000) { mantissa = 0; exponent += 1; }
+    }
+    if (exponent > 30) return (unsigned short)(sign | 0x7c00);
+    return (unsigned short)(sign | (exponent << 10) | (mantissa >> 13));
+}
+
 } // namespace artgpu
 
 // pixels per thread and batch of the persistent 1024-thread LUT-in-LDS pixel kernels (rgb2yuv_lds, yuv2rgb_lds, tone_std_lds): with one

@@ -104,7 +104,7 @@ hipError_t launch_amaze_stream(const AmazeStreamArgs &s, int grid, hipStream_t s
 // ---- device math primitives on caller arrays (selftest.hip; the ids are the ARTGPU_PRIM_* values of include/artgpu.h) ----
 enum { PRIM_XEXPF_S = 0, PRIM_XEXPF_V, PRIM_XEXPF_VN, PRIM_XEXPF_V_LDEXP, PRIM_XLOGF_S, PRIM_XLOGF_V, PRIM_XLOGF_VN, PRIM_POW_F, PRIM_XLIN2LOG,
        PRIM_XLOG2LIN, PRIM_XCBRTF, PRIM_XATAN2F, PRIM_XSINCOSF, PRIM_LUTF_SCALAR, PRIM_LUTF_VECTOR, PRIM_MEDIAN3, PRIM_VMINF, PRIM_VMAXF,
-       PRIM_VINTPF, PRIM_XDIV2F, PRIM_XDIVF2, PRIM_XLOG_D, PRIM_XEXP_D, PRIM_COUNT };
+       PRIM_VINTPF, PRIM_XDIV2F, PRIM_XDIVF2, PRIM_XLOG_D, PRIM_XEXP_D, PRIM_FLOAT_TO_HALF, PRIM_COUNT };
 struct PrimArgs {
     int prim;
     long long n;

@@ -2,7 +2,7 @@
 // arrays.  Every kernel of the library is built from these inline functions (devmath.h, devsleef.h, paramcurve.h); this entry point exists
 // so that they can be checked ON THE GPU, bit for bit, against fixtures generated from the reference's own headers compiled in place
 // (tests/golden/*.npz <- oracle/_ref: rtengine/sleef.h:1198-1313, sleefsseavx.h:1232-1345,1435-1442, LUT.h:349-459,
-// helpersse2.h:168-179, median.h) -- tests/test_gpu_primitives.py.  It computes nothing the product path needs.
+// helpersse2.h:168-179, median.h, halffloat.h:9-46) -- tests/test_gpu_primitives.py.  It computes nothing the product path needs.
 #include <hip/hip_runtime.h>
 #include "devmath.h"
 #include "devsleef.h"
@@ -42,6 +42,7 @@ __global__ void __launch_bounds__(256) prim_eval_kernel(PrimArgs p)
     case PRIM_XDIVF2: o0[i] = xdivf(a[i], 2); break;
     case PRIM_XLOG_D: ((double *)p.out0)[i] = pc_xlog(((const double *)p.a)[i]); break;
     case PRIM_XEXP_D: ((double *)p.out0)[i] = pc_xexp(((const double *)p.a)[i]); break;
+    case PRIM_FLOAT_TO_HALF: ((unsigned *)p.out0)[i] = float_to_half_dng(a[i]); break;     // (32-bit words: the half in the low 16 bits)
     default: break;
     }
 }

@@ -470,12 +470,14 @@ int artgpu_ordered_sum_f32(artgpu_ctx *ctx, const float *x, int64_t n, int on_de
  * sleefsseavx.h:978-1000,1232-1345 (the 4-lane forms, whose last bits differ), sleefsseavx.h:1435-1442 + helpersse2.h:168-179 (vminf / vmaxf
  * operand order, vintpf), median.h (median3), LUT.h:349-377 / 436-459 (LUTf::operator[] for vfloat / float).  The product path never calls it.
  * XSINCOSF writes sin to out0 and cos to out1; XLIN2LOG / XLOG2LIN take the base in `param`; the LUTF_* forms look a[i] up in
- * table[table_size]; XLOG_D / XEXP_D read and write double arrays.  Returns ARTGPU_EINVAL for a missing operand. */
+ * table[table_size]; XLOG_D / XEXP_D read and write double arrays; FLOAT_TO_HALF (DNG_FloatToHalf, halffloat.h:9-46: the half-float scanlines)
+ * writes 32-bit words with the half in the low 16 bits.  Returns ARTGPU_EINVAL for a missing operand. */
 enum {
     ARTGPU_PRIM_XEXPF_S = 0, ARTGPU_PRIM_XEXPF_V, ARTGPU_PRIM_XEXPF_VN, ARTGPU_PRIM_XEXPF_V_LDEXP, ARTGPU_PRIM_XLOGF_S, ARTGPU_PRIM_XLOGF_V,
     ARTGPU_PRIM_XLOGF_VN, ARTGPU_PRIM_POW_F, ARTGPU_PRIM_XLIN2LOG, ARTGPU_PRIM_XLOG2LIN, ARTGPU_PRIM_XCBRTF, ARTGPU_PRIM_XATAN2F,
     ARTGPU_PRIM_XSINCOSF, ARTGPU_PRIM_LUTF_SCALAR, ARTGPU_PRIM_LUTF_VECTOR, ARTGPU_PRIM_MEDIAN3, ARTGPU_PRIM_VMINF, ARTGPU_PRIM_VMAXF,
-    ARTGPU_PRIM_VINTPF, ARTGPU_PRIM_XDIV2F, ARTGPU_PRIM_XDIVF2, ARTGPU_PRIM_XLOG_D, ARTGPU_PRIM_XEXP_D, ARTGPU_PRIM_COUNT
+    ARTGPU_PRIM_VINTPF, ARTGPU_PRIM_XDIV2F, ARTGPU_PRIM_XDIVF2, ARTGPU_PRIM_XLOG_D, ARTGPU_PRIM_XEXP_D, ARTGPU_PRIM_FLOAT_TO_HALF,
+    ARTGPU_PRIM_COUNT
 };
 int artgpu_eval_primitive(artgpu_ctx *ctx, int prim, const void *a, const void *b, const void *c, void *out0, void *out1, int64_t n,
                           float param, const float *table, int table_size);

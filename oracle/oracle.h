@@ -76,6 +76,7 @@ void oracle_scale_colors(const void *src, int src_u16, int w, int h, const int c
                          const float scale_mul[4], float *dst, float chmax[4]);
 void oracle_channel_mixer(float *const img[3], size_t s, int w, int h, const float m[9]);
 int oracle_rgb2out_matrix(const float *const src[3], float *const dst[3], size_t s, int w, int h, const float m[9], int linear, const float *lut, int lutsz);
+void oracle_float_to_half(const float *x, unsigned short *y, size_t n);   /* DNG_FloatToHalf, halffloat.h:9-46 */
 void oracle_get_scanlines(const float *const img[3], size_t s, int w, int h, int bps, int is_float, void *out);
 void oracle_hsl_equalizer(float *const img[3], int W, int H, const double *hcurve, int nh, const double *scurve, int ns, const double *lcurve, int nl,
                           int smoothing, const double ws[9], double scale, int to_rgb);

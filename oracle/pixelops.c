@@ -374,6 +374,7 @@ static unsigned short float_to_half_dng(float f)
     if (exponent > 30) return (unsigned short)(sign | 0x7c00);
     return (unsigned short)(sign | (exponent << 10) | (mantissa >> 13));
 }
+void oracle_float_to_half(const float *x, unsigned short *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = float_to_half_dng(x[i]); }
 /* Imagefloat::getScanline for every row (imagefloat.cc:125-170); out: h rows of w*3 samples */
 void oracle_get_scanlines(const float *const img[3], size_t s, int w, int h, int bps, int is_float, void *out)
 {

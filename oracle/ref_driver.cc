@@ -15,6 +15,7 @@
 #include "rescale.h"
 #include "iccmatrices.h"
 #include "linalgebra.h"
+#include "halffloat.h"
 
 extern "C" {
 
@@ -114,4 +115,6 @@ void ref_lutf(const float *table, size_t tsize, const float *x, float *y_scalar,
 }
 #endif
 
+// halffloat.h:9-46 (the half-float scanlines of Imagefloat::getScanline)
+void ref_float_to_half(const float *x, unsigned short *y, size_t n) { for (size_t i = 0; i < n; ++i) y[i] = rtengine::DNG_FloatToHalf(x[i]); }
 } // extern "C"

@@ -217,7 +217,28 @@ def sleef_double():
     np.savez_compressed(os.path.join(HERE, "sleef_d.npz"), xl=xl, log=yl, xe=xe, exp=ye)
 
 
+def halffloat():
+    """DNG_FloatToHalf (halffloat.h:9-46): every half value as a float, its float neighbours, the midpoints between adjacent halfs (ties and
+    both sides of them), exponents from the subnormal floats to +-inf / NaN, and random bit patterns"""
+    rng = np.random.default_rng(7)
+    h = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    hb = h.view(np.uint32)
+    fin = np.isfinite(h)
+    cand = [hb, hb[fin] + 1, hb[fin] - 1]
+    for off in (0x0FFF, 0x1000, 0x1001, 0x1FFF, 0x2000):          # around the rounding bit of a normal half's 13 dropped bits
+        cand.append(hb[fin] + np.uint32(off))
+    cand.append(rng.integers(0, 1 << 32, 120000, dtype=np.uint64).astype(np.uint32))
+    for e in range(0, 256):                                       # every float exponent with a few mantissas
+        cand.append((np.uint32(e) << np.uint32(23)) | np.array([0, 1, 0x1000, 0x7FFFFF, 0x400000, 0x3FF000, 0x3FF001], np.uint32))
+        cand.append(np.uint32(0x80000000) | (np.uint32(e) << np.uint32(23)) | np.array([0, 0x1FFF, 0x2000, 0x7FE000], np.uint32))
+    x = np.unique(np.concatenate([c.astype(np.uint32) for c in cand])).view(np.float32)
+    y = np.empty(x.size, np.uint16)
+    R.ref_float_to_half(P(x), y.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_size_t(x.size))
+    np.savez_compressed(os.path.join(HERE, "halffloat.npz"), x_bits=x.view(np.uint32), half=y)
+
+
 if __name__ == "__main__":
+    halffloat()
     sleef_double()
     linalgebra()
     rescale_and_matrices()

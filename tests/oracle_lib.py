@@ -457,6 +457,14 @@ def rgb2out_matrix(img, m, linear, lut=None):
     return out, bad
 
 
+def float_to_half(x):
+    """DNG_FloatToHalf (halffloat.h:9-46) on a float32 array -> uint16"""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.empty(x.size, np.uint16)
+    lib().oracle_float_to_half(_ptr(x), y.ctypes.data_as(C.c_void_p), C.c_size_t(x.size))
+    return y.reshape(x.shape)
+
+
 def get_scanlines(img, bps, is_float=False):
     img = [np.ascontiguousarray(p, dtype=np.float32) for p in img]
     h, w = img[0].shape

@@ -151,6 +151,20 @@ def test_double_xlog_xexp_match_reference_sleef_h():
         assert bool(np.all((y.view(np.uint64) == want.view(np.uint64)) | nan))
 
 
+def test_float_to_half_matches_reference_halffloat_h():
+    """oracle/pixelops.c float_to_half_dng against DNG_FloatToHalf itself (halffloat.h:9-46 compiled in place): ~600 000 floats -- every half
+    value, its neighbours, the rounding ties, every exponent, random patterns"""
+    g = np.load(os.path.join(G, "halffloat.npz"))
+    x = g["x_bits"].view(np.float32)
+    assert x.size > 500000
+    assert np.array_equal(O.float_to_half(x), g["half"])
+    # and the scanline form that uses it: value / 65535 first (imagefloat.cc:150-158)
+    v = (x[::16][:30000] * np.float32(65535.0)).reshape(100, 100, 3)
+    planes = [np.ascontiguousarray(v[:, :, c]) for c in range(3)]
+    want = O.float_to_half((v / np.float32(65535.0)).astype(np.float32))
+    assert np.array_equal(O.get_scanlines(planes, 16, True), want)
+
+
 def test_parametric_curve_is_continuous_with_its_lut_and_monotonic_above_one():
     """oracle_parametric_getval (diagonalcurves.cc:448-470, unpinned: curves.h needs glibmm): a float64 model of the same formulas
     with libm's log / exp agrees to rounding level, getVal(1) is 1, and the tail keeps rising above 1"""

@@ -101,3 +101,22 @@ def test_missing_operand_is_an_error(ctx):
     from art_amd import capi
     with pytest.raises(Exception):
         ctx.eval_primitive(capi.PRIM_POW_F, np.ones(4, np.float32))
+
+
+def test_device_float_to_half_matches_reference_halffloat_h(ctx):
+    """DNG_FloatToHalf (halffloat.h:9-46 compiled in place -> tests/golden/halffloat.npz): every half value, its float neighbours, the rounding
+    ties, every float exponent, random patterns -- through the primitive and through the half-float scanlines that use it"""
+    from art_amd import capi
+    g = np.load(os.path.join(G, "halffloat.npz"))
+    x = g["x_bits"].view(np.float32)
+    got = ctx.eval_primitive(capi.PRIM_FLOAT_TO_HALF, x)
+    assert np.array_equal(got.astype(np.uint16), g["half"]) and int(got.max()) <= 0xFFFF
+    import torch
+    v = (x[::16][:30000] * np.float32(65535.0)).reshape(100, 100, 3)
+    planes = [torch.from_numpy(np.ascontiguousarray(v[:, :, c])).cuda() for c in range(3)]
+    scan = ctx.get_scanlines(capi.RGB(*[capi.device_plane(t) for t in planes]), 16, True)
+    lut = dict(zip(g["x_bits"].tolist(), g["half"].tolist()))
+    back = (v / np.float32(65535.0)).astype(np.float32)          # the scanline's own division
+    known = np.array([lut.get(int(b), -1) for b in back.view(np.uint32).ravel()]).reshape(back.shape)
+    sel = known >= 0
+    assert sel.mean() > 0.5 and np.array_equal(scan[sel], known[sel].astype(np.uint16))
