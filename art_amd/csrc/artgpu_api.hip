@@ -492,6 +492,7 @@ int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value)
     else if (n == "dn_debug_stall") ctx->opt_dn_debug_stall = (int)value;
     else if (n == "dn_wait_ms") ctx->opt_dn_wait_ms = value < 0 ? 0 : value;
     else if (n == "lut_lds") ctx->opt_lut_lds = value != 0;
+    else if (n == "cu_reserve") { if (value < 0 || value > 4096) return fail(ctx, ARTGPU_EINVAL, "cu_reserve: 0 .. 4096"); ctx->cu_reserve = (int)value; }
     else if (n == "io_direct") { if (value < -1 || value > 4096) return fail(ctx, ARTGPU_EINVAL, "io_direct: -1 (automatic), 0 .. 4096 workgroups"); ctx->opt_io_direct = (int)value; }
     else if (n == "rcd_rows") { if (value != 4 && value != 8) return fail(ctx, ARTGPU_EINVAL, "rcd_rows: 4 or 8"); ctx->opt_rcd_rows = (int)value; }
     else return fail(ctx, ARTGPU_EINVAL, "set_option: unknown option '%s'", name);
