@@ -4,7 +4,7 @@ cd $GRAFT_REPO_ROOT
 SEEDS=${@:-11 12}
 rc=0
 for s in $SEEDS; do
-  for f in fuzz_demosaic fuzz_xtrans fuzz_sizes fuzz_tools fuzz_nlm fuzz_pixel fuzz_dninfo; do
+  for f in fuzz_demosaic fuzz_xtrans fuzz_sizes fuzz_tools fuzz_nlm fuzz_pixel fuzz_dninfo fuzz_batch_io; do
     out=$(SEED=$s timeout 600 python scripts/$f.py 2>&1 | tail -1); r=$?
     echo "[$f seed $s] $out"
   done
