@@ -7,6 +7,9 @@
 //   artgpu-cli --in frame.f32 --width 4000 --height 3000 [--u16] [--filters 0x94949494]
 //              [--method amaze|rcd] [--border 4] [--denoise L,C] [--chroma-auto] [--expcomp 0.3] [--out out.ppm]
 //              [--dual bilinear|vng4] [--dual-contrast C] [--logenc REG] [--saturation S,V] [--labchroma C]   (SURVEY 8f N4 tools)
+//   artgpu-cli --batch a.u16,b.u16,... --width W --height H [--lanes N] [--black B] [--method ..] [--denoise L,C] [--expcomp E] [--out prefix]
+//              the batch queue's loop (simpleprocess.cc:586-612): uint16 sensor frames through scaleColors + the same stages, 16-bit
+//              scanlines as the writers take them (getScanline: clip and truncate), written as prefix.K.ppm; artgpu_batch_run_io
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -32,7 +35,9 @@ static std::vector<float> default_tone_lut()
 
 int main(int argc, char **argv)
 {
-    std::string in, out;
+    std::string in, out, batch;
+    int lanes = 1;
+    float black = 0.f;
     int W = 0, H = 0, border = 4, method = ARTGPU_BAYER_AMAZE;
     bool u16 = false;
     uint32_t filters = 0x94949494u;
@@ -48,6 +53,9 @@ int main(int argc, char **argv)
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
         if (a == "--in") in = next();
+        else if (a == "--batch") batch = next();
+        else if (a == "--lanes") lanes = std::atoi(next());
+        else if (a == "--black") black = (float)std::atof(next());
         else if (a == "--out") out = next();
         else if (a == "--width") W = std::atoi(next());
         else if (a == "--height") H = std::atoi(next());
@@ -68,7 +76,56 @@ int main(int argc, char **argv)
         else if (a == "--labchroma") { labchroma = std::atoi(next()); labcurve = true; }
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
-    if (in.empty() || W <= 0 || H <= 0) { std::fprintf(stderr, "usage: artgpu-cli --in frame.f32 --width W --height H [options]\n"); return 2; }
+    if ((in.empty() && batch.empty()) || W <= 0 || H <= 0) { std::fprintf(stderr, "usage: artgpu-cli --in frame.f32 | --batch a.u16,b.u16,... --width W --height H [options]\n"); return 2; }
+    if (!batch.empty()) {
+        try {
+            Context ctx(0);
+            ProcParams params;
+            params.bayersensor.method = method; params.bayersensor.border = border;
+            params.denoise.enabled = dn; params.denoise.luminance = lum; params.denoise.chrominance = chroma; params.denoise.luminanceDetail = 50;
+            params.exposure.expcomp = expcomp;
+            params.toneCurve.lut = default_tone_lut(); params.toneCurve.curveMode = tone_mode;
+            BatchQueue q(ctx, 16);
+            std::vector<std::string> names;
+            for (size_t pos = 0; pos <= batch.size();) {
+                const size_t e = batch.find(',', pos);
+                names.push_back(batch.substr(pos, e == std::string::npos ? std::string::npos : e - pos));
+                if (e == std::string::npos) break;
+                pos = e + 1;
+            }
+            for (const std::string &n : names) {
+                BatchQueue::Job &j = q.addJob(W, H, border);
+                std::ifstream f(n, std::ios::binary);
+                if (!f) throw std::runtime_error("cannot open " + n);
+                f.read(reinterpret_cast<char *>(j.sensor), (std::streamsize)W * H * 2);
+                if (!f) throw std::runtime_error("short read on " + n);
+            }
+            const float mul[3] = {2.1374f, 1.0f, 1.5918f};
+            const double mat[9] = {0.6325, 0.2312, 0.0921, 0.2198, 0.7712, 0.0090, 0.0166, 0.0713, 0.7514};
+            const float cblack[4] = {black, black, black, black}, smul[4] = {1.f, 1.f, 1.f, 1.f};
+            auto t0 = std::chrono::steady_clock::now();
+            q.process(params, filters, mul, mat, lanes, cblack, smul);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            const int fw = W - 2 * border, fh = H - 2 * border;
+            for (size_t k = 0; k < q.jobs.size(); ++k) {
+                if (out.empty()) break;
+                std::ofstream o(out + "." + std::to_string(k) + ".ppm", std::ios::binary);
+                o << "P6\n" << fw << " " << fh << "\n65535\n";
+                const uint16_t *sc = reinterpret_cast<const uint16_t *>(q.jobs[k].scanlines);
+                std::vector<unsigned char> row((size_t)fw * 6);
+                for (int y = 0; y < fh; ++y) {
+                    for (size_t e = 0; e < (size_t)fw * 3; ++e) { const uint16_t v = sc[(size_t)y * fw * 3 + e]; row[2 * e] = (unsigned char)(v >> 8); row[2 * e + 1] = (unsigned char)(v & 255); }
+                    o.write(reinterpret_cast<char *>(row.data()), (std::streamsize)row.size());
+                }
+            }
+            std::printf("{\"frames\": %zu, \"lanes\": %d, \"width\": %d, \"height\": %d, \"out_width\": %d, \"out_height\": %d, \"batch_ms\": %.3f, \"chmax0\": [%.1f, %.1f, %.1f]}\n",
+                        q.jobs.size(), lanes, W, H, fw, fh, ms, q.jobs[0].chmax[0], q.jobs[0].chmax[1], q.jobs[0].chmax[2]);
+        } catch (const std::exception &e) {
+            std::fprintf(stderr, "artgpu-cli: %s\n", e.what());
+            return 1;
+        }
+        return 0;
+    }
     try {
         std::vector<float> cfa((size_t)W * H);
         std::ifstream f(in, std::ios::binary);

@@ -317,4 +317,68 @@ public:
     double scale;
 };
 
+// The batch queue's loop (rtengine/simpleprocess.cc:586-612 batchProcessingThread: one ImageProcessor per job, jobs share nothing) between
+// the decoder's and the writers' formats: uint16 sensor data in, the scanlines Imagefloat::getScanline hands the TIFF / PNG writers out
+// (artgpu_batch_run_io).  Buffers are pinned (hipHostMalloc) so that a job's upload and download run beside its neighbours' kernels.
+class BatchQueue {
+public:
+    struct Job {
+        uint16_t *sensor = nullptr;      // W x H, pinned
+        unsigned char *scanlines = nullptr;   // (H - 2 border) x (W - 2 border) x 3 x bps / 8, pinned
+        int W = 0, H = 0;
+        float chmax[4] = {0, 0, 0, 0};
+        int status = 0;
+    };
+    BatchQueue(Context &c, int bps = 16) : ctx(c), bps(bps) {}
+    ~BatchQueue() { for (Job &j : jobs) { if (j.sensor) (void)hipHostFree(j.sensor); if (j.scanlines) (void)hipHostFree(j.scanlines); } }
+    BatchQueue(const BatchQueue &) = delete;
+    BatchQueue &operator=(const BatchQueue &) = delete;
+    // a job's buffers; the caller fills `sensor` (the decoder's output)
+    Job &addJob(int W, int H, int border)
+    {
+        Job j; j.W = W; j.H = H;
+        hipcheck(hipHostMalloc(reinterpret_cast<void **>(&j.sensor), (size_t)W * H * 2, hipHostMallocDefault), "hipHostMalloc(sensor)");
+        hipcheck(hipHostMalloc(reinterpret_cast<void **>(&j.scanlines), rowBytes(W, border) * (size_t)(H - 2 * border), hipHostMallocDefault), "hipHostMalloc(scanlines)");
+        jobs.push_back(j);
+        return jobs.back();
+    }
+    size_t rowBytes(int W, int border) const { return (size_t)(W - 2 * border) * 3 * (bps / 8); }
+    // ImageProcessor::operator() for every job: stage_init (scaleColors + demosaic), stage_denoise, stage_finish up to the tone curve, then the
+    // output profile's matrix (identity here: the working space is the output space) and getScanline
+    void process(const ProcParams &p, uint32_t filters, const float mul[3], const double cam2work[9], int lanes,
+                 const float cblacksom[4], const float scale_mul[4])
+    {
+        artgpu_pipeline_params pp = {};
+        pp.sensor = 0; pp.bayer_method = p.bayersensor.method; pp.filters = filters; pp.initial_gain = 1.0; pp.xtrans_passes = 3; pp.border = p.bayersensor.border;
+        for (int k = 0; k < 3; ++k) pp.mul[k] = mul[k];
+        pp.do_clip = 1; pp.has_cam_to_work = 1;
+        for (int k = 0; k < 9; ++k) { pp.cam_to_work[k] = cam2work[k]; pp.ws[k] = p.workingSpace[k]; pp.iws[k] = p.workingSpaceInverse[k]; pp.to_out[k] = p.toOut[k]; pp.to_work[k] = p.toWork[k]; }
+        const auto &d = p.denoise;
+        pp.denoise_enabled = d.enabled ? 1 : 0;
+        pp.denoise = artgpu_denoise_tool_params{{d.luminance, d.luminanceDetail, d.luminanceDetailThreshold, d.chrominance, d.chrominanceRedGreen, d.chrominanceBlueYellow,
+                                                 d.gamma, d.aggressive ? 1 : 0, d.colorSpace, d.chrominanceMethod},
+                                                d.smoothingEnabled ? 1 : 0, d.guidedChromaRadius, d.nlStrength, d.nlDetail};
+        pp.exposure_enabled = p.exposure.enabled ? 1 : 0; pp.expcomp = p.exposure.expcomp; pp.black = p.exposure.black;
+        pp.tone_enabled = p.toneCurve.enabled ? 1 : 0; pp.tone_mode = p.toneCurve.curveMode; pp.tone_lut = p.toneCurve.lut.data(); pp.white_point = p.toneCurve.whitePoint;
+        pp.scale = 1.0; pp.chrominance_auto_factor = d.chrominanceAutoFactor;
+        std::vector<artgpu_sensor_frame> in(jobs.size());
+        std::vector<artgpu_scanline_frame> out(jobs.size());
+        for (size_t k = 0; k < jobs.size(); ++k) {
+            const Job &j = jobs[k];
+            in[k] = artgpu_sensor_frame{j.sensor, j.W, j.H, (int64_t)j.W * 2, 1, 0, {cblacksom[0], cblacksom[1], cblacksom[2], cblacksom[3]},
+                                        {scale_mul[0], scale_mul[1], scale_mul[2], scale_mul[3]}};
+            out[k] = artgpu_scanline_frame{};
+            out[k].scanlines = j.scanlines; out[k].row_stride_bytes = (int64_t)rowBytes(j.W, pp.border); out[k].bps = bps; out[k].is_float = 0;
+            out[k].rgb2out_enabled = 0; out[k].trc_linear = 1;
+        }
+        ctx.check(artgpu_set_batch_lanes(ctx.get(), lanes));
+        const int rc = artgpu_batch_run_io(ctx.get(), (int)jobs.size(), in.data(), &pp, out.data());
+        for (size_t k = 0; k < jobs.size(); ++k) { jobs[k].status = out[k].status; for (int c = 0; c < 4; ++c) jobs[k].chmax[c] = out[k].chmax[c]; }
+        ctx.check(rc);
+    }
+    std::vector<Job> jobs;
+    Context &ctx;
+    int bps;
+};
+
 } // namespace artgpu_host

@@ -179,3 +179,30 @@ def test_n4_tools_through_the_cpp_mirror(tmp_path):
     ref = np.stack([np.rint(np.clip(p, 0, 65535)).astype(np.uint16) for p in img], axis=-1)
     assert got.shape == ref.shape
     assert np.array_equal(got, ref)
+
+
+def test_batch_queue_through_cli(tmp_path):
+    """artgpu-cli --batch: the batch queue's loop over BatchQueue (rtengine_gpu.h) -> artgpu_batch_run_io -- uint16 sensor frames in, the
+    writers' 16-bit scanlines out -- against the oracle's scaleColors + pipeline + getScanline, two lanes"""
+    w, h, filt, b, black = 520, 392, synth.FILTERS_RGGB, 4, 64.0
+    frames = [np.clip(synth.bayer_frame(w, h, filt, seed=40 + k, noise=1500), 0, 65535).astype(np.uint16) for k in range(3)]
+    names = []
+    for k, f in enumerate(frames):
+        n = tmp_path / f"f{k}.u16"
+        f.astype("<u2").tofile(n)
+        names.append(str(n))
+    res = subprocess.run([CLI, "--batch", ",".join(names), "--width", str(w), "--height", str(h), "--lanes", "2", "--black", str(black),
+                          "--denoise", "30,12", "--expcomp", "0.3", "--out", str(tmp_path / "o")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    info = json.loads(res.stdout.strip().splitlines()[-1])
+    assert info["frames"] == 3 and (info["out_width"], info["out_height"]) == (w - 2 * b, h - 2 * b)
+    for k, f in enumerate(frames):
+        raw = np.maximum(f.astype(np.float32) - np.float32(black), np.float32(0.0))          # scaleColors with scale_mul 1
+        ref = oracle_pipeline(raw, filt, "amaze", b, denoise=(30, 12), expcomp=0.3, dct=True)
+        want = O.get_scanlines(ref, 16, False)
+        got = read_ppm16(tmp_path / f"o.{k}.ppm")
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        # the DCT detail-recovery stage is the path's one tolerance (DESIGN.md section 3): a count of 65535 at most
+        assert d.max() <= 1 and (d > 0).mean() < 0.02, (k, int(d.max()), float((d > 0).mean()))
+    r0 = np.maximum(frames[0].astype(np.float32) - np.float32(black), np.float32(0.0))
+    assert info["chmax0"] == [float(r0[0::2, 0::2].max()), float(max(r0[0::2, 1::2].max(), r0[1::2, 0::2].max())), float(r0[1::2, 1::2].max())]     # RGGB
