@@ -64,7 +64,7 @@ struct artgpu_ctx {
     int io_host_cap = 0;
     int cu_reserve = 0;            // set around a batch whose downloads run as a kernel of a few workgroups: the persistent one-workgroup-per-CU pixel passes leave those CUs alone
     int opt_io_direct = -1;        // artgpu_batch_run_io, scanlines into pinned host memory: n > 0: written there by n persistent workgroups (no staging, no copy); 0: staged +
-                                   // hipMemcpy; -1 (default) = 0 (io_frame has the measurements)
+                                   // hipMemcpy; -1 (default): 8 with two lanes, 0 otherwise (io_frame has the measurements)
     float fuse_pre = 0.f, fuse_post = 0.f;   // improc_denoise -> rgb_denoise: exposure compensation fused into rgb2yuv / yuv2rgb
     GetImageFuse fuse_gi = {};               // improc_denoise_fused -> chroma map, rgb2yuv: getImage + matrix read from the demosaiced planes
     float fuse_exp_scale = 0.f, fuse_exp_black = 0.f;   // improc_denoise_fused -> yuv2rgb: ImProcFunctions::exposure behind the last pass
@@ -3200,10 +3200,11 @@ int io_frame(artgpu_ctx *c, int i, const artgpu_sensor_frame *in, const artgpu_p
     // Where do the scanlines go?  Pinned host memory is mapped into the device's address space: a few workgroups on the download stream write
     // them there directly.  Anything else (pageable memory, rows that are not 16-byte aligned, option io_direct = 0) is staged and copied.
     // Scanlines for PINNED memory can be written there by a kernel of the download stream (option io_direct = n workgroups) instead of being staged and
-    // copied.  Measured on 8192 x 5464 frames, 16-bit scanlines (scripts/pcie_batch.py, 24 frames): the runtime's copy -- itself a kernel, 268 MB in
-    // 4.9 ms -- 11.0 / 10.6 / 11.3 ms per frame with one / two / three lanes; eight workgroups writing directly 11.0 - 12.6 / 11.4 / 12.6 (they hold eight
-    // CUs for 5 ms, and the one-workgroup-per-CU kernels of the next frame wait for a CU or run on fewer: cu_reserve).  So the copy is the default.
-    const int direct_wgs = c->opt_io_direct > 0 ? c->opt_io_direct : 0;
+    // copied.  Measured on 8192 x 5464 frames, 16-bit scanlines (scripts/pcie_batch.py, batches of 24 - 36 frames, seven runs): the runtime's copy -- itself a
+    // kernel, 268 MB in 4.9 ms -- 11.0 ms per frame with one lane, 10.6 - 13.8 with two (two modes: the lanes lock into step with the copy kernel in
+    // about half the runs), 10.7 - 11.3 with three; eight workgroups writing directly 11.7 - 12.6 / 11.2 - 11.8 / 11.7 - 12.9 (they hold eight CUs for
+    // 5 ms, and the one-workgroup-per-CU kernels of the next frame wait for a CU or run on fewer: cu_reserve).  So: the copy, except with two lanes.
+    const int direct_wgs = c->opt_io_direct >= 0 ? c->opt_io_direct : (c->frames_in_flight == 2 ? 8 : 0);
     // A copy from / to PAGEABLE memory blocks the calling thread until it is done (the runtime stages it in pieces): nothing is gained by giving it a
     // stream of its own, so it stays on the context's stream like the copies of the four separate entry points; lanes still overlap each other.
     unsigned char *const out_pinned = out->on_device ? nullptr : static_cast<unsigned char *>(pinned_device_address(out->scanlines));

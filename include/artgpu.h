@@ -91,8 +91,8 @@ int artgpu_synchronize(artgpu_ctx *ctx);
  *                       side stream beside the reconstructions of a and b (the default of rounds 3 and 4); "lut_lds" 0: never the LUT-in-LDS shape
  *                       of the pixel passes; "rcd_rows" 4 | 8; "roctx" 1: roctx ranges named after the reference functions
  *   "io_direct"         artgpu_batch_run_io, scanlines that go to PINNED host memory: n > 0: n persistent workgroups on the download stream write
- *                       them there directly (no staging plane, no copy); 0 or -1 (default): staged on the device and copied by the runtime
- *                       (measured equal or faster: DESIGN.md section 17); "cu_reserve" n: the persistent one-workgroup-per-CU pixel passes launch
+ *                       them there directly (no staging plane, no copy); 0: staged on the device and copied by the runtime; -1 (default): 8 with
+ *                       two lanes, 0 otherwise (measured: DESIGN.md section 17); "cu_reserve" n: the persistent one-workgroup-per-CU pixel passes launch
  *                       n workgroups fewer (experiments with kernels running beside a frame; artgpu_batch_run_io sets it for its direct downloads) */
 int artgpu_set_option(artgpu_ctx *ctx, const char *name, long value);
 /* read-only counterparts: "amaze_counter0" .. "amaze_counter7" = bookkeeping of the last AMaZE call (how many tiles were streamed a
